@@ -1,0 +1,161 @@
+/*
+ * unigen_hip.h — C ABI of libunigen_hip.so (gfx950 / MI355X).
+ *
+ * This is the drop-in boundary for ONE hot path of gavin-gqzhang/UniGen: the
+ * condition-weaving + expert-modulation diffusion forward pass
+ * (reference: src/UniGenTransformer.py:712-1450 UniGenFlux / MultiCondtionUniGenFlux,
+ *  src/UniGenUtils.py:17-228,340-622, denoise loop src/UniGenPipeline.py:721-789).
+ *
+ * The reference has no FFI of its own (it is pure PyTorch eager); every entry point
+ * below names the reference torch call site it replaces. Conventions:
+ *   - extern "C", plain pointers and sizes, no torch types.
+ *   - every pointer is a DEVICE pointer unless the name ends in _host.
+ *   - asynchronous, stream-ordered on `stream` (a hipStream_t passed as void*);
+ *     no allocation, no ownership transfer, no host synchronisation.
+ *   - bf16 storage (uint16 bit patterns), fp32 accumulate / statistics / gate / RoPE tables.
+ *   - return 0 on success, a negative UG_ERR_* otherwise; ug_last_error() gives the
+ *     thread-local message of the most recent failure.
+ *   - "row map": a logical row m of an operand lives at physical row
+ *         (m / rows_per_batch) * batch_stride + (m % rows_per_batch)
+ *     of its buffer (rows_per_batch == 0 means identity). It lets a GEMM read or write
+ *     a token slice of a concatenated (text|image|condition) buffer without a copy.
+ */
+#ifndef UNIGEN_HIP_H
+#define UNIGEN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* ug_stream_t; /* hipStream_t */
+
+enum {
+    UG_OK = 0,
+    UG_ERR_BAD_SHAPE = -1,
+    UG_ERR_BAD_ALIGN = -2,
+    UG_ERR_UNSUPPORTED = -3,
+    UG_ERR_HIP = -4
+};
+
+/* GEMM epilogues (ug_gemm_desc.epilogue). v = bf16(acc + bias) is rounded first, as the
+ * reference's separate nn.Linear does, then: */
+enum {
+    UG_EPI_BIAS = 0,       /* C = v                                            nn.Linear */
+    UG_EPI_BIAS_GELU = 1,  /* C = gelu_tanh(v)                                 FeedForward net.0 (diffusers GELU approximate="tanh") */
+    UG_EPI_RES_GATE = 2,   /* C = R + gate[sample(m)][n] * v                   x + gate.unsqueeze(1) * attn/ff  (FluxTransformerBlock) */
+    UG_EPI_RES_SCALE = 3,  /* C = R + alpha * v                                x + cn_block(z) * conditioning_scale (UniGenTransformer.py:1104,1141) */
+    UG_EPI_F32 = 4         /* C(fp32) = acc + bias (no rounding; verification / gate logits) */
+};
+
+typedef struct ug_gemm_desc {
+    /* C[m][n] = epilogue( sum_k A[m][k] * W[n][k] + bias[n] ), all bf16, W in nn.Linear layout [N][K] */
+    const void* A; int64_t lda; int64_t a_rpb; int64_t a_bstride;
+    const void* W; int64_t ldw;
+    const void* bias;                 /* [N] bf16 or NULL */
+    void* C; int64_t ldc; int64_t c_rpb; int64_t c_bstride;
+    const void* R; int64_t ldr; int64_t r_rpb; int64_t r_bstride; /* residual (may alias C) */
+    const void* gate; int64_t gate_ld; int64_t rows_per_sample;   /* gate[(m / rows_per_sample) * gate_ld + n] bf16 */
+    float alpha;
+    int32_t epilogue;
+    int64_t M, N, K;
+    /* grouped / batched over `groups` experts (blockIdx.z); strides in ELEMENTS */
+    int32_t groups; int32_t _pad0;
+    int64_t a_gstride, w_gstride, bias_gstride, c_gstride;
+    /* optional LoRA epilogue (peft 0.15 Linear; src/lora_switching_module.py:11-38):
+     *   acc += lora_scale-premultiplied T[m][0..r) . B[n][0..r)   with T = scale * (x A^T) computed by a prior ug_gemm_bf16 */
+    const void* lora_T; int64_t ldt;
+    const void* lora_B; int64_t ldb;
+    int32_t lora_r; int32_t _pad1;
+} ug_gemm_desc;
+
+/* replaces every nn.Linear on the path (torch F.linear -> BLAS) incl. fused epilogues. */
+int ug_gemm_bf16(const ug_gemm_desc* d, ug_stream_t stream);
+
+/* out[m][n] = R[m][n] + bf16( sum_k act(x[m][k]) * W[n][k] + b[n] ),  M <= 16 rows (per-sample vectors).
+ * act: 0 none, 1 SiLU. Replaces AdaLayerNormZero.linear(silu(emb)), TimestepEmbedding, PixArtAlphaTextProjection
+ * (diffusers 0.32.2 normalization.py / embeddings.py; called from UniGenTransformer.py:1222,1048-1049). */
+int ug_small_linear_bf16(const void* x, int64_t ldx, const void* W, int64_t ldw, const void* bias,
+                         const void* R, int64_t ldr, void* out, int64_t ldo,
+                         int64_t M, int64_t N, int64_t K, int32_t act_in, ug_stream_t stream);
+
+/* out = LayerNorm(x; eps, no affine) * (1 + scale[sample]) + shift[sample]   (AdaLayerNormZero / norm2+modulate /
+ * AdaLayerNormContinuous; diffusers normalization.py; src/UniGenUtils.py:354-373). shift/scale are bf16 rows of the
+ * adaLN linear output with leading dimension mod_ld. */
+int ug_adaln_modulate(const void* x, int64_t ldx, int64_t x_rpb, int64_t x_bstride,
+                      const void* shift, const void* scale, int64_t mod_ld, int64_t rows_per_sample,
+                      void* out, int64_t ldo, int64_t rows, int64_t D, float eps, ug_stream_t stream);
+
+/* In-place RMSNorm(q), RMSNorm(k) (per head, weight) then RoPE on a fused [.. q | k | v ..] projection buffer.
+ * Row r in [0, rows_per_batch) of batch b is at buf + (b*batch_stride_rows + r)*ld and has sequence position
+ * pos = pos_offset + r. Positions < split use (wq_a, wk_a) (text: norm_added_q/k), positions >= split use (wq_b, wk_b)
+ * (image: norm_q/k). cos/sin: fp32 [>= pos_offset + rows_per_batch][dh] indexed by pos, or NULL (no RoPE);
+ * weights may be NULL (no qk-norm). q_off < 0 skips q (k/v-only context streams).
+ * Replaces Attention.norm_q/norm_k + apply_rotary_emb (FluxAttnProcessor2_0; src/UniGenUtils.py:561-599). */
+int ug_qk_rmsnorm_rope(void* buf, int64_t ld, int64_t batches, int64_t rows_per_batch, int64_t batch_stride_rows,
+                       int64_t pos_offset, int64_t q_off, int64_t k_off, int32_t heads, int32_t dh,
+                       const void* wq_a, const void* wk_a, const void* wq_b, const void* wk_b, int64_t split,
+                       const float* cos_tab, const float* sin_tab, float eps, ug_stream_t stream);
+
+/* O = softmax(Q K^T / sqrt(dh)) V, non-causal, no mask; Q rows [Lq], K/V rows [Lkv]; head h occupies
+ * columns [h*dh, (h+1)*dh) of each row. Strides in elements. Replaces F.scaled_dot_product_attention
+ * (src/UniGenUtils.py:601 and diffusers FluxAttnProcessor2_0). dh in {64, 128}. */
+int ug_flash_attn_fwd(const void* q, int64_t q_row_stride, int64_t q_batch_stride,
+                      const void* k, int64_t k_row_stride, int64_t k_batch_stride,
+                      const void* v, int64_t v_row_stride, int64_t v_batch_stride,
+                      void* o, int64_t o_row_stride, int64_t o_batch_stride,
+                      int64_t batches, int32_t heads, int64_t Lq, int64_t Lkv, int32_t dh,
+                      float softmax_scale, ug_stream_t stream);
+
+/* Sinusoidal Timesteps(256, flip_sin_to_cos=True, downscale_freq_shift=0): out[b] = [cos(t f) | sin(t f)] as bf16.
+ * (diffusers embeddings.get_timestep_embedding; called inside time_text_embed, UniGenTransformer.py:1222). */
+int ug_timestep_embed(const float* t, void* out, int64_t ldo, int64_t B, int32_t dim, ug_stream_t stream);
+
+/* x = bf16( float(x) + dt * float(v) )  FlowMatchEulerDiscreteScheduler.step (src/UniGenPipeline.py:768). */
+int ug_euler_step(void* x, const void* v, float dt, int64_t n, ug_stream_t stream);
+
+/* out = bf16(a + b) elementwise (bf16), rows x D with leading dims. */
+int ug_add_bf16(const void* a, int64_t lda, const void* b, int64_t ldb, void* out, int64_t ldo,
+                int64_t rows, int64_t D, ug_stream_t stream);
+
+/* ---- CoMoE (src/UniGenUtils.py:74-191 MOELayer + deepspeed 0.16.5 top1gating; UniGenTransformer.py:925-1026) ---- */
+
+/* Gate: xc = bf16(x + c); logits = xc.float() @ wg.float()^T (fp32); gates = softmax; idx = argmax.
+ * Writes gates fp32 [S][E], idx int32 [S]. */
+int ug_moe_gate_top1(const void* x, const void* c, int64_t ld, const void* wg, int64_t S, int64_t D, int32_t E,
+                     float* gates, int32_t* idx, ug_stream_t stream);
+
+/* Capacity selection with Random Token Selection (use_rts=True, drop_tokens=True): per expert keep the `capacity`
+ * tokens with the largest uniform[s][idx[s]]; slot = rank of the token among kept tokens of its expert (token order).
+ * Writes slot int32 [S] (-1 = dropped), token_of_slot int32 [E][capacity] (-1 = empty), exp_counts int64 [E]
+ * (pre-drop counts, as deepspeed returns), l_aux fp32 scalar = E * sum_e mean_s(gates[s][e]) * mean_s(idx[s]==e). */
+int ug_moe_capacity_rts(const float* gates, const int32_t* idx, const float* uniform, int64_t S, int32_t E,
+                        int64_t capacity, int32_t* slot, int32_t* token_of_slot, int64_t* exp_counts, float* l_aux,
+                        ug_stream_t stream);
+
+/* Dispatch + expert modulation prologue (replaces einsum("sec,sm->ecm") src/UniGenUtils.py:140 and the s-scaling of
+ * modulated_flatten src/UniGenUtils.py:204-228):
+ *   out[e][slot][:] = bf16( mod[e][sample(tok)][:] * bf16( x[tok][:] + (add ? add[e][slot][:] : 0) ) ), zeros for empty slots.
+ * mod: bf16 [E][B][D] = Linear(768->D)(pooled) per expert. tokens_per_sample = N. */
+int ug_moe_dispatch_modulate(const void* x, int64_t ldx, const void* add, const void* mod, int64_t B,
+                             const int32_t* token_of_slot, int32_t E, int64_t capacity, int64_t tokens_per_sample,
+                             int64_t D, void* out, ug_stream_t stream);
+
+/* Combine (replaces einsum("sec,ecm->sm") src/UniGenUtils.py:183) fused with the CoMoE residual sums
+ * (UniGenTransformer.py:1024,1089):
+ *   eh = bf16(bf16(p) * yh[e][slot]) (0 if dropped), ec likewise from yc;
+ *   out = bf16( bf16(xs + eh) + bf16(cs + ec) )    when xs/cs given (shared experts),
+ *   out = bf16( eh + ec )                          otherwise.
+ * If `accumulate` != 0, out = bf16(out_prev + that)  (MultiCondtionUniGenFlux sum over conditions, :1316). */
+int ug_moe_combine(const void* yh, const void* yc, const float* gates, const int32_t* idx, const int32_t* slot,
+                   int32_t E, int64_t capacity, const void* xs, const void* cs, int64_t ld_s,
+                   void* out, int64_t ldo, int64_t S, int64_t D, int32_t accumulate, ug_stream_t stream);
+
+int ug_version(void);
+const char* ug_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UNIGEN_HIP_H */

@@ -1,0 +1,617 @@
+"""CPU oracle: a plain-PyTorch restatement of UniGen's condition-weaving + expert-modulation forward pass.
+
+TEST INFRASTRUCTURE ONLY. Nothing in the product path (unigen_amd/, src/) imports this module; only tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg do, as the checker / the timed CPU baseline.
+
+PARITY UNPINNED: the reference (gavin-gqzhang/UniGen @ /root/reference) ships no tests, golden vectors or fixtures, it
+cannot be imported here (deepspeed / diffusers / peft / ipdb are absent: ordinary ModuleNotFoundError) and `UniGenFlux`
+uses classes that are defined nowhere (FluxJointRoPETransformerBlock, FluxSingleRoPETransformerBlock). This file restates
+  * src/UniGenTransformer.py:712-1450   (UniGenFlux, MultiCondtionUniGenFlux)
+  * src/UniGenUtils.py:17-228,340-622   (MoE glue, modulated_flatten, JointAttnRopeProcessor)
+  * src/UniGenPipeline.py:662-677,721-789 (timesteps, denoise loop)
+and the published algorithms of its un-vendored dependencies, pinned in /root/reference/environment.yaml:
+  diffusers==0.32.2 (FluxTransformerBlock, FluxSingleTransformerBlock, FluxAttnProcessor2_0, AdaLayerNormZero*,
+  FluxPosEmbed, apply_rotary_emb, CombinedTimestepTextProjEmbeddings, FlowMatchEulerDiscreteScheduler),
+  deepspeed==0.16.5 (sharded_moe.top1gating / TopKGate), peft==0.15.0 (LoRA Linear).
+
+Everything runs on a flat `state` dict {reference state-dict key: tensor}. `dtype` chooses the arithmetic:
+  torch.bfloat16 -> the reference's own eager rounding points (every torch op rounds to bf16),
+  torch.float32  -> the same graph on bf16-rounded weights without intermediate rounding ("fp32 truth").
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+
+State = Dict[str, torch.Tensor]
+
+
+@dataclass
+class FluxConfig:
+    """diffusers FluxTransformer2DModel config + UniGen control params (config/unigen.yaml)."""
+    in_channels: int = 64
+    num_layers: int = 19
+    num_single_layers: int = 38
+    attention_head_dim: int = 128
+    num_attention_heads: int = 24
+    joint_attention_dim: int = 4096
+    pooled_projection_dim: int = 768
+    guidance_embeds: bool = False
+    axes_dims_rope: Tuple[int, int, int] = (16, 56, 56)
+    # control params (src/UniGenTransformer.py:720-783, 807-893)
+    condition_nums: int = 1
+    use_rope: bool = True
+    use_pooled_prompt_embeds: bool = True
+    use_shared_expert: bool = True
+    use_single_trans_blocks: bool = True
+    single_control_dev: int = 2
+    single_block_control_method: str = "overall_add"
+    expert_num_each_condition: int = 3
+    expert_num: Optional[int] = None
+    top_num: int = 1
+
+    @property
+    def inner_dim(self) -> int:
+        return self.num_attention_heads * self.attention_head_dim
+
+    @property
+    def expert_nums(self) -> int:  # src/UniGenTransformer.py:807
+        return self.expert_num if self.expert_num is not None else (self.condition_nums + 1) * self.expert_num_each_condition
+
+    @property
+    def cn_joint_layers(self) -> int:  # :744
+        return self.num_layers // self.single_control_dev
+
+    @property
+    def cn_single_layers(self) -> int:
+        return self.num_single_layers // self.single_control_dev
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# primitives (diffusers 0.32.2 semantics)
+# ---------------------------------------------------------------------------------------------------------------------
+
+def linear(state: State, prefix: str, x: torch.Tensor) -> torch.Tensor:
+    w = state[prefix + ".weight"].to(x.dtype)
+    b = state.get(prefix + ".bias")
+    return F.linear(x, w, None if b is None else b.to(x.dtype))
+
+
+def timestep_sinusoid(t: torch.Tensor, dim: int = 256) -> torch.Tensor:
+    """get_timestep_embedding(flip_sin_to_cos=True, downscale_freq_shift=0, scale=1, max_period=10000) -> fp32 [B, dim]."""
+    half = dim // 2
+    exponent = -math.log(10000) * torch.arange(0, half, dtype=torch.float32) / half
+    emb = t[:, None].float() * torch.exp(exponent)[None, :]
+    emb = torch.cat([torch.sin(emb), torch.cos(emb)], dim=-1)
+    return torch.cat([emb[:, half:], emb[:, :half]], dim=-1)  # flip -> [cos | sin]
+
+
+def time_text_embed(state: State, prefix: str, timestep: torch.Tensor, pooled: torch.Tensor,
+                    guidance: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """CombinedTimestep(Guidance)TextProjEmbeddings: timestep_embedder(time_proj(t)) [+ guidance_embedder] + text_embedder(pooled)."""
+    dt = pooled.dtype
+    tp = timestep_sinusoid(timestep).to(dt)
+    temb = linear(state, prefix + ".timestep_embedder.linear_2", F.silu(linear(state, prefix + ".timestep_embedder.linear_1", tp)))
+    if guidance is not None:
+        gp = timestep_sinusoid(guidance).to(dt)
+        temb = temb + linear(state, prefix + ".guidance_embedder.linear_2", F.silu(linear(state, prefix + ".guidance_embedder.linear_1", gp)))
+    pe = linear(state, prefix + ".text_embedder.linear_2", F.silu(linear(state, prefix + ".text_embedder.linear_1", pooled)))
+    return temb + pe
+
+
+def flux_pos_embed(ids: torch.Tensor, axes_dim: Sequence[int], theta: float = 10000.0) -> Tuple[torch.Tensor, torch.Tensor]:
+    """FluxPosEmbed.forward: per axis get_1d_rotary_pos_embed(repeat_interleave_real=True, use_real=True, float64 freqs) -> fp32 cos, sin [S, sum(axes)]."""
+    cos_out, sin_out = [], []
+    pos = ids.float()
+    for i, d in enumerate(axes_dim):
+        freqs = 1.0 / (theta ** (torch.arange(0, d, 2, dtype=torch.float64) / d))
+        ang = torch.outer(pos[:, i].to(torch.float64), freqs)
+        cos_out.append(ang.cos().repeat_interleave(2, dim=1).float())
+        sin_out.append(ang.sin().repeat_interleave(2, dim=1).float())
+    return torch.cat(cos_out, dim=-1), torch.cat(sin_out, dim=-1)
+
+
+def apply_rotary_emb(x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor) -> torch.Tensor:
+    """diffusers apply_rotary_emb(use_real=True, use_real_unbind_dim=-1) on [B, H, S, dh]."""
+    cos, sin = cos[None, None], sin[None, None]
+    xr, xi = x.reshape(*x.shape[:-1], -1, 2).unbind(-1)
+    x_rot = torch.stack([-xi, xr], dim=-1).flatten(3)
+    return (x.float() * cos + x_rot.float() * sin).to(x.dtype)
+
+
+def rms_norm(x: torch.Tensor, weight: Optional[torch.Tensor], eps: float = 1e-6) -> torch.Tensor:
+    """diffusers RMSNorm.forward: fp32 statistics, x * rsqrt(var + eps) in fp32, cast to the weight dtype, * weight."""
+    dt = x.dtype
+    var = x.to(torch.float32).pow(2).mean(-1, keepdim=True)
+    x = x * torch.rsqrt(var + eps)
+    if weight is not None:
+        w = weight.to(dt)
+        if w.dtype in (torch.float16, torch.bfloat16):
+            x = x.to(w.dtype)
+        x = x * w
+    else:
+        x = x.to(dt)
+    return x
+
+
+def layer_norm(x: torch.Tensor, eps: float = 1e-6) -> torch.Tensor:
+    return F.layer_norm(x, (x.shape[-1],), None, None, eps)
+
+
+def adaln_zero(state: State, prefix: str, x: torch.Tensor, emb: torch.Tensor):
+    """AdaLayerNormZero.forward -> (x_mod, gate_msa, shift_mlp, scale_mlp, gate_mlp)."""
+    e = linear(state, prefix + ".linear", F.silu(emb))
+    shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp = e.chunk(6, dim=1)
+    x = layer_norm(x) * (1 + scale_msa[:, None]) + shift_msa[:, None]
+    return x, gate_msa, shift_mlp, scale_mlp, gate_mlp
+
+
+def adaln_zero_single(state: State, prefix: str, x: torch.Tensor, emb: torch.Tensor):
+    e = linear(state, prefix + ".linear", F.silu(emb))
+    shift_msa, scale_msa, gate_msa = e.chunk(3, dim=1)
+    x = layer_norm(x) * (1 + scale_msa[:, None]) + shift_msa[:, None]
+    return x, gate_msa
+
+
+def adaln_continuous(state: State, prefix: str, x: torch.Tensor, emb: torch.Tensor) -> torch.Tensor:
+    e = linear(state, prefix + ".linear", F.silu(emb).to(x.dtype))
+    scale, shift = torch.chunk(e, 2, dim=1)
+    return layer_norm(x) * (1 + scale)[:, None, :] + shift[:, None, :]
+
+
+def feed_forward(state: State, prefix: str, x: torch.Tensor) -> torch.Tensor:
+    """FeedForward(activation_fn='gelu-approximate'): net.0.proj -> gelu(tanh) -> net.2."""
+    return linear(state, prefix + ".net.2", F.gelu(linear(state, prefix + ".net.0.proj", x), approximate="tanh"))
+
+
+def _heads(x: torch.Tensor, H: int) -> torch.Tensor:
+    B, L, D = x.shape
+    return x.view(B, L, H, D // H).transpose(1, 2)
+
+
+def _sdpa(q, k, v):
+    return F.scaled_dot_product_attention(q, k, v, dropout_p=0.0, is_causal=False)
+
+
+def joint_attention(state: State, prefix: str, cfg: FluxConfig, x: torch.Tensor, enc: Optional[torch.Tensor],
+                    rope: Optional[Tuple[torch.Tensor, torch.Tensor]], text_first: bool):
+    """Attention module of a Flux block.
+    text_first=True : FluxAttnProcessor2_0 (cat([context, sample]); rope rows follow that order).
+    text_first=False: JointAttnRopeProcessor src/UniGenUtils.py:532-622 (cat([sample, context])).
+    Returns (sample_out, context_out) after to_out[0] / to_add_out; for enc=None returns the raw attention (single block)."""
+    H = cfg.num_attention_heads
+    q = rms_norm(_heads(linear(state, prefix + ".to_q", x), H), state[prefix + ".norm_q.weight"])
+    k = rms_norm(_heads(linear(state, prefix + ".to_k", x), H), state[prefix + ".norm_k.weight"])
+    v = _heads(linear(state, prefix + ".to_v", x), H)
+    if enc is not None:
+        eq = rms_norm(_heads(linear(state, prefix + ".add_q_proj", enc), H), state[prefix + ".norm_added_q.weight"])
+        ek = rms_norm(_heads(linear(state, prefix + ".add_k_proj", enc), H), state[prefix + ".norm_added_k.weight"])
+        ev = _heads(linear(state, prefix + ".add_v_proj", enc), H)
+        if text_first:
+            q, k, v = torch.cat([eq, q], 2), torch.cat([ek, k], 2), torch.cat([ev, v], 2)
+        else:
+            q, k, v = torch.cat([q, eq], 2), torch.cat([k, ek], 2), torch.cat([v, ev], 2)
+    if rope is not None:
+        q, k = apply_rotary_emb(q, *rope), apply_rotary_emb(k, *rope)
+    o = _sdpa(q, k, v)
+    B = x.shape[0]
+    o = o.transpose(1, 2).reshape(B, -1, cfg.inner_dim).to(q.dtype)
+    if enc is None:
+        return o, None
+    T, N = enc.shape[1], x.shape[1]
+    if text_first:
+        eo, xo = o[:, :T], o[:, T:]
+    else:
+        xo, eo = o[:, :N], o[:, N:]
+    return linear(state, prefix + ".to_out.0", xo), linear(state, prefix + ".to_add_out", eo)
+
+
+def flux_double_block(state: State, prefix: str, cfg: FluxConfig, x, enc, temb, rope, text_first: bool = True):
+    """diffusers FluxTransformerBlock.forward. Returns (enc, x)."""
+    n, g, sh, sc, gm = adaln_zero(state, prefix + ".norm1", x, temb)
+    nc, cg, csh, csc, cgm = adaln_zero(state, prefix + ".norm1_context", enc, temb)
+    a, ca = joint_attention(state, prefix + ".attn", cfg, n, nc, rope, text_first)
+    x = x + g.unsqueeze(1) * a
+    n2 = layer_norm(x) * (1 + sc[:, None]) + sh[:, None]
+    x = x + gm.unsqueeze(1) * feed_forward(state, prefix + ".ff", n2)
+    enc = enc + cg.unsqueeze(1) * ca
+    nc2 = layer_norm(enc) * (1 + csc[:, None]) + csh[:, None]
+    enc = enc + cgm.unsqueeze(1) * feed_forward(state, prefix + ".ff_context", nc2)
+    return enc, x
+
+
+def flux_single_block(state: State, prefix: str, cfg: FluxConfig, h, temb, rope):
+    """diffusers FluxSingleTransformerBlock.forward."""
+    n, gate = adaln_zero_single(state, prefix + ".norm", h, temb)
+    mlp = F.gelu(linear(state, prefix + ".proj_mlp", n), approximate="tanh")
+    a, _ = joint_attention(state, prefix + ".attn", cfg, n, None, rope, True)
+    out = linear(state, prefix + ".proj_out", torch.cat([a, mlp], dim=2))
+    return h + gate.unsqueeze(1) * out
+
+
+def control_rope(cfg: FluxConfig, ids: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """rope_embed(ids) cast to the ids dtype as JointAttnRopeProcessor does (src/UniGenUtils.py:597); the pipeline builds
+    ids in the latent dtype (src/UniGenPipeline.py:640) so the control-path tables are rounded to that dtype."""
+    cos, sin = flux_pos_embed(ids, cfg.axes_dims_rope)
+    return cos.to(ids.dtype), sin.to(ids.dtype)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# CoMoE: deepspeed 0.16.5 top1gating + src/UniGenUtils.py:74-191 + src/UniGenTransformer.py:925-1026
+# ---------------------------------------------------------------------------------------------------------------------
+
+def moe_capacity(S: int, E: int, capacity_factor: float = 1.0, min_capacity: int = 4) -> int:
+    return max(int(math.ceil((S / E) * capacity_factor)), min_capacity)
+
+
+def top1gating(logits: torch.Tensor, uniform: torch.Tensor, capacity: int):
+    """deepspeed.moe.sharded_moe.top1gating(use_rts=True, drop_tokens=True), with the Uniform(0,1) sample passed in.
+    Returns l_aux, combine_weights [S,E,C] fp32, dispatch_mask [S,E,C] bool, exp_counts [E] int64."""
+    S, E = logits.shape
+    gates = F.softmax(logits, dim=1)
+    idx = torch.argmax(gates, dim=1)
+    mask1 = F.one_hot(idx, num_classes=E)
+    exp_counts = torch.sum(mask1, dim=0).detach()
+    me = torch.mean(gates, dim=0)
+    ce = torch.mean(mask1.float(), dim=0)
+    l_aux = torch.sum(me * ce) * E
+    mask1_rand = mask1 * uniform
+    top_idx = torch.topk(mask1_rand, k=capacity, dim=0)[1]
+    mask1 = mask1 * torch.zeros_like(mask1).scatter_(0, top_idx, 1)
+    locations1 = torch.cumsum(mask1, dim=0) - 1
+    locations1_s = torch.sum(locations1 * mask1, dim=1)
+    mask1_float = mask1.float()
+    gates = gates * mask1_float
+    locations1_sc = F.one_hot(locations1_s, num_classes=capacity).float()
+    combine_weights = torch.einsum("se,sc->sec", gates, locations1_sc)
+    dispatch_mask = combine_weights.bool()
+    return l_aux, combine_weights, dispatch_mask, exp_counts
+
+
+def routing_from_gates(gates: torch.Tensor, uniform: torch.Tensor, capacity: int):
+    """Index form of top1gating: per token (expert idx, slot or -1). Used to check the dense form and the HIP kernels."""
+    S, E = gates.shape
+    idx = torch.argmax(gates, dim=1)
+    slot = torch.full((S,), -1, dtype=torch.int64)
+    token_of_slot = torch.full((E, capacity), -1, dtype=torch.int64)
+    for e in range(E):
+        toks = torch.nonzero(idx == e).flatten()
+        if toks.numel() > capacity:
+            keys = uniform[toks, e]
+            keep = torch.topk(keys, k=capacity)[1]
+            toks = toks[torch.sort(keep)[0]]
+        slot[toks] = torch.arange(toks.numel())
+        token_of_slot[e, : toks.numel()] = toks
+    return idx, slot, token_of_slot
+
+
+def modulated_flatten_literal(x: torch.Tensor, w: torch.Tensor, s: torch.Tensor) -> torch.Tensor:
+    """src/UniGenUtils.py:204-228, 3-D `s` branch, verbatim semantics (materialises b x n x o x i): tiny sizes only."""
+    w = w.unsqueeze(0).unsqueeze(1) * s.unsqueeze(2)
+    return torch.einsum("bnoi,bni->bno", w, x)
+
+
+def modulated_linear(x: torch.Tensor, w: torch.Tensor, s: torch.Tensor) -> torch.Tensor:
+    """Algebraically identical restatement used at scale: Linear_W(s * x)."""
+    return F.linear(s * x, w)
+
+
+def comoe_experts(state: State, cfg: FluxConfig, x, c, pooled, cond_pooled, gates_in: Optional[torch.Tensor],
+                  uniform: torch.Tensor, literal: bool = False):
+    """MOELayer.forward + UniGenFlux.expert_forward with modulated experts. x, c: [B, N, D]. Returns
+    (expert_h [B,N,D], expert_c [B,N,D], l_aux, exp_counts, routing dict)."""
+    B, N, D = x.shape
+    E = cfg.expert_nums
+    S = B * N
+    dt = x.dtype
+    choice = (x + c).reshape(S, D)
+    wg = state["moe.moe_layer.gate.wg.weight"]
+    logits = F.linear(choice.float(), wg.float())           # TopKGate.forward: fp32 input and weight
+    C = moe_capacity(S, E)
+    l_aux, combine_weights, dispatch_mask, exp_counts = top1gating(logits, uniform, C)
+    gates = F.softmax(logits, dim=1)
+    idx, slot, token_of_slot = routing_from_gates(gates, uniform, C)
+
+    def dispatch(t2d):  # einsum("sec,sm->ecm") with a one-hot mask == row gather, zeros for empty slots
+        out = torch.zeros(E, C, t2d.shape[-1], dtype=t2d.dtype)
+        valid = token_of_slot >= 0
+        out[valid] = t2d[token_of_slot[valid]]
+        return out
+
+    if literal:
+        dm = dispatch_mask.to(dt)
+        xd = torch.einsum("sec,sm->ecm", dm, x.reshape(S, D))
+        cd = torch.einsum("sec,sm->ecm", dm, c.reshape(S, D))
+        pd = torch.einsum("sec,sm->ecm", dm, pooled.unsqueeze(1).expand(-1, N, -1).reshape(S, -1))
+        cpd = torch.einsum("sec,sm->ecm", dm, cond_pooled.unsqueeze(1).expand(-1, N, -1).reshape(S, -1))
+    else:
+        xd, cd = dispatch(x.reshape(S, D)), dispatch(c.reshape(S, D))
+        pd = dispatch(pooled.unsqueeze(1).expand(-1, N, -1).reshape(S, -1))
+        cpd = dispatch(cond_pooled.unsqueeze(1).expand(-1, N, -1).reshape(S, -1))
+    mf = modulated_flatten_literal if literal else modulated_linear
+    yh, yc = [], []
+    for e in range(E):
+        p = f"moe.moe_layer.experts.deepspeed_experts.{e}"
+        wc, bc = state[p + ".0.0.weight"].to(dt), state[p + ".0.0.bias"].to(dt)
+        wh, bh = state[p + ".1.0.weight"].to(dt), state[p + ".1.0.bias"].to(dt)
+        s_c = linear(state, p + ".0.1", cpd[e][None])
+        s_h = linear(state, p + ".1.1", pd[e][None])
+        c_e = mf(cd[e][None], wc, s_c) + bc.unsqueeze(0)
+        h_e = mf(xd[e][None] + c_e, wh, s_h) + bh.unsqueeze(0)
+        yh.append(h_e[0]); yc.append(c_e[0])
+    yh, yc = torch.stack(yh), torch.stack(yc)               # [E, C, D]
+    cw = combine_weights.to(dt)
+    eh = torch.einsum("sec,ecm->sm", cw, yh).reshape(B, N, D)
+    ec = torch.einsum("sec,ecm->sm", cw, yc).reshape(B, N, D)
+    routing = dict(gates=gates, idx=idx, slot=slot, token_of_slot=token_of_slot, capacity=C, logits=logits)
+    return eh, ec, l_aux, exp_counts, routing
+
+
+def comoe(state: State, cfg: FluxConfig, x, cond_tokens, ctrl_enc, control_temb, condition_temb, pooled, cond_pooled,
+          ids: Dict[str, torch.Tensor], uniform: torch.Tensor):
+    """One condition's CoMoE: control_x_embedder + MoE experts + shared experts (src/UniGenTransformer.py:969-1026,1040).
+    Returns (expert_hidden_states, expert_condition_hidden_states, l_aux, exp_counts, routing)."""
+    c = linear(state, "control_x_embedder", cond_tokens)
+    eh, ec, l_aux, exp_counts, routing = comoe_experts(state, cfg, x, c, pooled, cond_pooled, None, uniform)
+    if not cfg.use_shared_expert:
+        return eh, ec, l_aux, exp_counts, routing
+    # shared_expert[0](hidden=x, encoder=c, temb=condition_temb): sample-first [img | cond]   (:1013-1015)
+    rope0 = control_rope(cfg, torch.cat([ids["img_ids"], ids["condition_ids"]], 0)) if cfg.use_rope else None
+    cond_s, x_s = flux_double_block(state, "shared_expert.0", cfg, x, c, condition_temb, rope0, text_first=False)
+    # shared_expert[1](hidden=[x_s | cond_s], encoder=ctrl_enc, temb=control_temb)                 (:1017-1022)
+    rope1 = control_rope(cfg, torch.cat([ids["img_ids"], ids["condition_ids"], ids["prompt_ids"]], 0)) if cfg.use_rope else None
+    _, hc = flux_double_block(state, "shared_expert.1", cfg, torch.cat([x_s, cond_s], 1), ctrl_enc, control_temb, rope1, text_first=False)
+    N = x.shape[1]
+    x_s, cond_s = hc[:, :N], hc[:, N:]
+    return x_s + eh, cond_s + ec, l_aux, exp_counts, routing
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# UniGenFlux.forward / MultiCondtionUniGenFlux.forward
+# ---------------------------------------------------------------------------------------------------------------------
+
+def unigen_flux_forward(state: State, cfg: FluxConfig, *, hidden_states, condition_hidden_states, encoder_hidden_states,
+                        pooled_projections, condition_pooled_projections, timestep, img_ids, txt_ids, condition_ids,
+                        guidance=None, conditioning_scale: float = 1.0, gate_uniform=None, dtype=torch.bfloat16,
+                        io_dtype=torch.bfloat16, trace: Optional[dict] = None):
+    """src/UniGenTransformer.py:1182-1271 (single condition) and :1360-1450 (lists => MultiCondtionUniGenFlux).
+    gate_uniform: [S, E] fp32 uniforms (one tensor, or a list per condition) standing in for the RTS draw."""
+    multi = isinstance(condition_hidden_states, (list, tuple))
+    dt = dtype
+    cast = lambda t: t.to(dt)
+    x = linear(state, "x_embedder", cast(hidden_states))
+    # `timestep.to(hidden_states.dtype) * 1000` (:1217-1220): evaluated in the model's I/O dtype (bf16) in both modes, so the
+    # fp32 mode sees the same effective timestep (e.g. 752, not 750) as the reference's bf16 run.
+    if guidance is not None:
+        guidance = (guidance.to(io_dtype) * 1000).to(dt)
+    timestep = (timestep.to(io_dtype) * 1000).to(dt)
+    pooled = cast(pooled_projections)
+    temb = time_text_embed(state, "time_text_embed", timestep, pooled, guidance)
+    enc = linear(state, "context_embedder", cast(encoder_hidden_states))
+    rope = flux_pos_embed(torch.cat((txt_ids, img_ids), dim=0), cfg.axes_dims_rope)   # base path: fp32 tables
+    ids = dict(img_ids=img_ids, prompt_ids=txt_ids)
+    T = enc.shape[1]
+
+    moe_out = None
+    n_d, n_cj = cfg.num_layers, cfg.cn_joint_layers
+    for i in range(n_d):
+        enc, x = flux_double_block(state, f"transformer_blocks.{i}", cfg, x, enc, temb, rope, text_first=True)
+        m = int(i / (n_d / n_cj))
+        if moe_out is None:  # preprocess_moe_forward, once per step, with the text stream AFTER base block 0 (:1137 -> :1051)
+            control_pooled = pooled if cfg.use_pooled_prompt_embeds else torch.zeros_like(pooled)
+            control_temb = time_text_embed(state, "control_time_text_embed", timestep, control_pooled, guidance)
+            ctrl_enc = linear(state, "control_context_embedder", enc)
+            conds = list(zip(condition_hidden_states, condition_pooled_projections, condition_ids)) if multi else \
+                [(condition_hidden_states, condition_pooled_projections, condition_ids)]
+            unis = gate_uniform if isinstance(gate_uniform, (list, tuple)) else [gate_uniform] * len(conds)
+            merged, merged_temb = None, None
+            for (ct, cp, cid), uni in zip(conds, unis):
+                cp = cast(cp)
+                condition_temb = time_text_embed(state, "control_condition_embed", timestep, cp, guidance)
+                eh, ec, l_aux, exp_counts, routing = comoe(state, cfg, x, cast(ct), ctrl_enc, control_temb, condition_temb, pooled, cp,
+                                                           dict(ids, condition_ids=cid), uni)
+                z = eh + ec
+                merged = z if merged is None else merged + z              # sum(list) (:1316)
+                merged_temb = condition_temb if merged_temb is None else merged_temb + condition_temb
+                if trace is not None:
+                    trace.setdefault("routing", []).append(routing)
+            moe_out = dict(ctrl_enc=ctrl_enc, condition_temb=merged_temb, l_aux=l_aux, exp_counts=exp_counts)
+            z_in = merged
+            if trace is not None:
+                trace["z0"] = merged
+        else:
+            z_in = x
+        crope = control_rope(cfg, torch.cat([img_ids, txt_ids], 0)) if cfg.use_rope else None
+        _, z = flux_double_block(state, f"control_joint_trans_blocks.{m}", cfg, z_in, moe_out["ctrl_enc"], moe_out["condition_temb"],
+                                 crope, text_first=False)
+        x = x + linear(state, f"controlnet_add_joint_blocks.{m}", z) * conditioning_scale
+        if trace is not None:
+            trace.setdefault("x_after_double", []).append(x)
+
+    h = torch.cat([enc, x], dim=1)
+    n_s, n_cs = cfg.num_single_layers, cfg.cn_single_layers
+    for j in range(n_s):
+        h = flux_single_block(state, f"single_transformer_blocks.{j}", cfg, h, temb, rope)
+        if cfg.use_single_trans_blocks:
+            m = int(j / (n_s / n_cs))
+            crope = control_rope(cfg, torch.cat([txt_ids, img_ids], 0)) if cfg.use_rope else None
+            z = flux_single_block(state, f"control_single_trans_blocks.{m}", cfg, h, moe_out["condition_temb"], crope)
+            y = linear(state, f"controlnet_add_single_blocks.{m}", z) * conditioning_scale
+            if cfg.single_block_control_method == "overall_add":
+                h = h + y
+            else:
+                h = torch.cat([h[:, :T], h[:, T:] + y[:, T:]], dim=1)
+    x = h[:, T:]
+    x = adaln_continuous(state, "norm_out", x, temb)
+    out = linear(state, "proj_out", x)
+    return out, dict(moe_loss=moe_out["l_aux"] * 0.1), dict(expert_counts=moe_out["exp_counts"])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# denoise loop (src/UniGenPipeline.py:662-677, 721-789) and FlowMatchEulerDiscreteScheduler
+# ---------------------------------------------------------------------------------------------------------------------
+
+def schnell_sigmas(num_steps: int, shift: float = 1.0) -> torch.Tensor:
+    sig = torch.linspace(1.0, 1.0 / num_steps, num_steps, dtype=torch.float32)
+    sig = shift * sig / (1 + (shift - 1) * sig)
+    return torch.cat([sig, torch.zeros(1)])
+
+
+def euler_step(latents: torch.Tensor, model_output: torch.Tensor, sigma: float, sigma_next: float) -> torch.Tensor:
+    prev = latents.to(torch.float32) + (sigma_next - sigma) * model_output.to(torch.float32)
+    return prev.to(model_output.dtype)
+
+
+def denoise(state: State, cfg: FluxConfig, *, latents, num_steps: int, dtype=torch.bfloat16, gate_uniforms=None, **fwd_kwargs):
+    """UniGenFLUXPipeline.__call__ loop: timestep = t.expand(B).to(latents.dtype); forward(timestep / 1000); Euler step."""
+    sig = schnell_sigmas(num_steps)
+    latents = latents.to(dtype)
+    B = latents.shape[0]
+    for i in range(num_steps):
+        t = (sig[i] * 1000).expand(B).to(latents.dtype)
+        uni = None if gate_uniforms is None else gate_uniforms[i]
+        pred = unigen_flux_forward(state, cfg, hidden_states=latents, timestep=t / 1000, gate_uniform=uni, dtype=dtype, **fwd_kwargs)[0]
+        latents = euler_step(latents, pred, float(sig[i]), float(sig[i + 1]))
+    return latents
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# LoRA (peft 0.15 Linear; src/lora_switching_module.py:4-38 — never invoked by the reference)
+# ---------------------------------------------------------------------------------------------------------------------
+
+def lora_linear(x, w, b, adapters: List[Tuple[torch.Tensor, torch.Tensor, float]]):
+    """y = base(x) + sum_a B_a(A_a(x)) * scaling_a, scaling = lora_alpha / r (adapters: (A [r,K], B [N,r], scaling))."""
+    y = F.linear(x, w, b)
+    for A, Bm, sc in adapters:
+        y = y + F.linear(F.linear(x, A), Bm) * sc
+    return y
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# synthetic weights / inputs: N(0, 0.02^2) weights, zero biases, unit RMSNorm weights, zero-res
+# projections re-initialised so the control path contributes.
+# ---------------------------------------------------------------------------------------------------------------------
+
+def _double_block_shapes(p: str, D: int, dh: int) -> Dict[str, Tuple[int, ...]]:
+    s = {}
+    for n in ("norm1", "norm1_context"):
+        s[f"{p}.{n}.linear.weight"] = (6 * D, D); s[f"{p}.{n}.linear.bias"] = (6 * D,)
+    for n in ("to_q", "to_k", "to_v", "add_q_proj", "add_k_proj", "add_v_proj", "to_out.0", "to_add_out"):
+        s[f"{p}.attn.{n}.weight"] = (D, D); s[f"{p}.attn.{n}.bias"] = (D,)
+    for n in ("norm_q", "norm_k", "norm_added_q", "norm_added_k"):
+        s[f"{p}.attn.{n}.weight"] = (dh,)
+    for n in ("ff", "ff_context"):
+        s[f"{p}.{n}.net.0.proj.weight"] = (4 * D, D); s[f"{p}.{n}.net.0.proj.bias"] = (4 * D,)
+        s[f"{p}.{n}.net.2.weight"] = (D, 4 * D); s[f"{p}.{n}.net.2.bias"] = (D,)
+    return s
+
+
+def _single_block_shapes(p: str, D: int, dh: int) -> Dict[str, Tuple[int, ...]]:
+    s = {f"{p}.norm.linear.weight": (3 * D, D), f"{p}.norm.linear.bias": (3 * D,),
+         f"{p}.proj_mlp.weight": (4 * D, D), f"{p}.proj_mlp.bias": (4 * D,),
+         f"{p}.proj_out.weight": (D, 5 * D), f"{p}.proj_out.bias": (D,)}
+    for n in ("to_q", "to_k", "to_v"):
+        s[f"{p}.attn.{n}.weight"] = (D, D); s[f"{p}.attn.{n}.bias"] = (D,)
+    for n in ("norm_q", "norm_k"):
+        s[f"{p}.attn.{n}.weight"] = (dh,)
+    return s
+
+
+def _tte_shapes(p: str, D: int, pooled: int, guidance: bool) -> Dict[str, Tuple[int, ...]]:
+    s = {f"{p}.timestep_embedder.linear_1.weight": (D, 256), f"{p}.timestep_embedder.linear_1.bias": (D,),
+         f"{p}.timestep_embedder.linear_2.weight": (D, D), f"{p}.timestep_embedder.linear_2.bias": (D,),
+         f"{p}.text_embedder.linear_1.weight": (D, pooled), f"{p}.text_embedder.linear_1.bias": (D,),
+         f"{p}.text_embedder.linear_2.weight": (D, D), f"{p}.text_embedder.linear_2.bias": (D,)}
+    if guidance:
+        s.update({f"{p}.guidance_embedder.linear_1.weight": (D, 256), f"{p}.guidance_embedder.linear_1.bias": (D,),
+                  f"{p}.guidance_embedder.linear_2.weight": (D, D), f"{p}.guidance_embedder.linear_2.bias": (D,)})
+    return s
+
+
+def state_shapes(cfg: FluxConfig) -> Dict[str, Tuple[int, ...]]:
+    """Every parameter of UniGenFlux after init_condition_block, under the reference's state-dict key names."""
+    D, dh = cfg.inner_dim, cfg.attention_head_dim
+    s: Dict[str, Tuple[int, ...]] = {}
+    s["x_embedder.weight"] = (D, cfg.in_channels); s["x_embedder.bias"] = (D,)
+    s["context_embedder.weight"] = (D, cfg.joint_attention_dim); s["context_embedder.bias"] = (D,)
+    s.update(_tte_shapes("time_text_embed", D, cfg.pooled_projection_dim, cfg.guidance_embeds))
+    for i in range(cfg.num_layers):
+        s.update(_double_block_shapes(f"transformer_blocks.{i}", D, dh))
+    for j in range(cfg.num_single_layers):
+        s.update(_single_block_shapes(f"single_transformer_blocks.{j}", D, dh))
+    s["norm_out.linear.weight"] = (2 * D, D); s["norm_out.linear.bias"] = (2 * D,)
+    s["proj_out.weight"] = (cfg.in_channels, D); s["proj_out.bias"] = (cfg.in_channels,)
+    # control modules (src/UniGenTransformer.py:727-773)
+    s.update(_tte_shapes("control_time_text_embed", D, cfg.pooled_projection_dim, cfg.guidance_embeds))
+    s.update(_tte_shapes("control_condition_embed", D, cfg.pooled_projection_dim, cfg.guidance_embeds))
+    s["control_context_embedder.weight"] = (D, D); s["control_context_embedder.bias"] = (D,)
+    s["control_x_embedder.weight"] = (D, cfg.in_channels); s["control_x_embedder.bias"] = (D,)
+    for m in range(cfg.cn_joint_layers):
+        s.update(_double_block_shapes(f"control_joint_trans_blocks.{m}", D, dh))
+        s[f"controlnet_add_joint_blocks.{m}.weight"] = (D, D); s[f"controlnet_add_joint_blocks.{m}.bias"] = (D,)
+    if cfg.use_single_trans_blocks:
+        for m in range(cfg.cn_single_layers):
+            s.update(_single_block_shapes(f"control_single_trans_blocks.{m}", D, dh))
+            s[f"controlnet_add_single_blocks.{m}.weight"] = (D, D); s[f"controlnet_add_single_blocks.{m}.bias"] = (D,)
+    # CoMoE (:833-842, 857)
+    s["moe.moe_layer.gate.wg.weight"] = (cfg.expert_nums, D)
+    for e in range(cfg.expert_nums):
+        p = f"moe.moe_layer.experts.deepspeed_experts.{e}"
+        for k in (0, 1):
+            s[f"{p}.{k}.0.weight"] = (D, D); s[f"{p}.{k}.0.bias"] = (D,)
+            s[f"{p}.{k}.1.weight"] = (D, cfg.pooled_projection_dim); s[f"{p}.{k}.1.bias"] = (D,)
+    if cfg.use_shared_expert:
+        for k in (0, 1):
+            s.update(_double_block_shapes(f"shared_expert.{k}", D, dh))
+    return s
+
+
+def make_state(cfg: FluxConfig, seed: int = 0, std: float = 0.02, bias_std: float = 0.0, dtype=torch.bfloat16,
+               device: str = "cpu") -> State:
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    st: State = {}
+    for name, shape in state_shapes(cfg).items():
+        if ".norm_q." in name or ".norm_k." in name or ".norm_added_q." in name or ".norm_added_k." in name:
+            t = 1.0 + 0.1 * torch.randn(shape, generator=g) if bias_std > 0 else torch.ones(shape)
+        elif name.endswith(".bias"):
+            t = bias_std * torch.randn(shape, generator=g) if bias_std > 0 else torch.zeros(shape)
+        else:
+            t = std * torch.randn(shape, generator=g)
+        st[name] = t.to(dtype).to(device)
+    return st
+
+
+def make_ids(h: int, w: int, dtype=torch.bfloat16) -> torch.Tensor:
+    """_prepare_latent_image_ids: [h*w, 3] with [:,1]=row, [:,2]=col (diffusers FluxPipeline)."""
+    ids = torch.zeros(h, w, 3)
+    ids[..., 1] = ids[..., 1] + torch.arange(h)[:, None]
+    ids[..., 2] = ids[..., 2] + torch.arange(w)[None, :]
+    return ids.reshape(h * w, 3).to(dtype)
+
+
+def make_inputs(cfg: FluxConfig, B: int, grid: int, T: int, seed: int = 12443, n_cond: int = 1, dtype=torch.bfloat16):
+    """Synthetic inputs of SURVEY 8(d): latents, condition tokens ~ N(0,1); prompt embeds ~ 0.1 N(0,1); pooled ~ N(0,1)."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    N = grid * grid
+    E = cfg.expert_nums
+    inp = dict(
+        hidden_states=torch.randn(B, N, cfg.in_channels, generator=g).to(dtype),
+        encoder_hidden_states=(0.1 * torch.randn(B, T, cfg.joint_attention_dim, generator=g)).to(dtype),
+        pooled_projections=torch.randn(B, cfg.pooled_projection_dim, generator=g).to(dtype),
+        img_ids=make_ids(grid, grid, dtype), txt_ids=torch.zeros(T, 3, dtype=dtype),
+    )
+    conds = [torch.randn(B, N, cfg.in_channels, generator=g).to(dtype) for _ in range(n_cond)]
+    cpools = [torch.randn(B, cfg.pooled_projection_dim, generator=g).to(dtype) for _ in range(n_cond)]
+    unis = [torch.rand(B * N, E, generator=g) for _ in range(n_cond)]
+    if n_cond == 1:
+        inp.update(condition_hidden_states=conds[0], condition_pooled_projections=cpools[0], condition_ids=make_ids(grid, grid, dtype))
+        inp["gate_uniform"] = unis[0]
+    else:
+        inp.update(condition_hidden_states=conds, condition_pooled_projections=cpools,
+                   condition_ids=[make_ids(grid, grid, dtype) for _ in range(n_cond)])
+        inp["gate_uniform"] = unis
+    return inp

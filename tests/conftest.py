@@ -1,0 +1,24 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def gpu():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU visible")
+    from unigen_amd import lib
+
+    lib.load()  # fail loudly if the HIP library is missing: there is no fallback
+    return torch.device("cuda:0")

@@ -1,0 +1,306 @@
+"""GPU parity tests, kernel level: every C-ABI entry point of libunigen_hip.so against the CPU oracle (oracle/unigen_ref.py
+primitives, i.e. the reference's torch semantics) on identical seeded bf16 inputs.
+
+Stated tolerance (north star: <= 1e-3 vs reference): relative L2 error <= 1e-3 against the oracle evaluated with the
+reference's own rounding points; attention is allowed 4e-3 because P is quantised to bf16 for the P.V MFMA exactly as
+the reference's SDPA flash kernels do, with a different (but equally valid) tile order. Integer routing outputs are exact.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import unigen_ref as R
+from tests.util import bf, report
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+BF = torch.bfloat16
+
+
+def _rand(g, *shape, scale=1.0):
+    return (torch.randn(*shape, generator=g) * scale).to(BF)
+
+
+def _epi_ref(acc, bias, epi, res=None, gate=None, rows_per_sample=1, alpha=1.0):
+    """acc fp32 [M,N] (fp32 accumulate of bf16 products) -> reference rounding points of Linear + following torch ops."""
+    v = (acc + (bias.float() if bias is not None else 0)).to(BF)
+    if epi == "bias":
+        return v
+    if epi == "gelu":
+        return F.gelu(v, approximate="tanh")
+    if epi == "res_gate":
+        g = gate.repeat_interleave(rows_per_sample, dim=0)[: res.shape[0]]
+        return res + g * v
+    if epi == "res_scale":
+        return res + v * alpha
+    raise ValueError(epi)
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 260, 64), (128, 64, 192), (1, 8, 64), (513, 384, 1024)])
+@pytest.mark.parametrize("epi", ["bias", "gelu", "res_gate", "res_scale", "f32"])
+def test_gemm_epilogues(gpu, M, N, K, epi):
+    from unigen_amd import lib as L, ops
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    a, w, b = _rand(g, M, K), _rand(g, N, K, scale=K ** -0.5), _rand(g, N, scale=0.1)
+    res = _rand(g, M, N)
+    rps = 50 if M >= 100 else 1
+    nsamp = (M + rps - 1) // rps
+    gate = _rand(g, nsamp, N)
+    acc = a.float() @ w.float().t()
+    ad, wd, bd, resd, gated = (t.to(gpu) for t in (a, w, b, res, gate))
+    if epi == "f32":
+        out = torch.empty(M, N, device=gpu, dtype=torch.float32)
+        ops.gemm(ad, wd, bd, out, M=M, epilogue=L.EPI_F32)
+        ref = acc + b.float()
+        m = report(f"gemm_f32_{M}x{N}x{K}", out, ref)
+        assert m["rel_l2"] <= 1e-5
+        return
+    out = torch.empty(M, N, device=gpu, dtype=BF)
+    code = dict(bias=L.EPI_BIAS, gelu=L.EPI_BIAS_GELU, res_gate=L.EPI_RES_GATE, res_scale=L.EPI_RES_SCALE)[epi]
+    ops.gemm(ad, wd, bd, out, M=M, epilogue=code, residual=resd if epi.startswith("res") else None,
+             gate=gated if epi == "res_gate" else None, gate_ld=N, rows_per_sample=rps, alpha=0.75)
+    ref = _epi_ref(acc, b, epi, res, gate, rps, 0.75)[:M]
+    m = report(f"gemm_{epi}_{M}x{N}x{K}", out, ref)
+    assert m["rel_l2"] <= TOL, m
+
+
+def test_gemm_rowmaps_inplace_grouped_lora(gpu):
+    from unigen_amd import lib as L, ops
+    g = torch.Generator().manual_seed(5)
+    # A is the image slice of a [B, T+N, K] buffer, C the image slice of a [B, T+N, N] buffer, residual in place
+    B, T, Nn, K, No = 3, 24, 40, 128, 192
+    Lt = T + Nn
+    abuf, cbuf = _rand(g, B, Lt, K), _rand(g, B, Lt, No)
+    w, b = _rand(g, No, K, scale=K ** -0.5), _rand(g, No, scale=0.1)
+    ad, cd = abuf.to(gpu), cbuf.to(gpu)
+    ops.gemm(ad[0, T:], w.to(gpu), b.to(gpu), cd[0, T:], M=B * Nn, epilogue=L.EPI_RES_SCALE, lda=K, ldc=No,
+             a_map=ops.RowMap(Nn, Lt), c_map=ops.RowMap(Nn, Lt), residual=cd[0, T:], ldr=No, r_map=ops.RowMap(Nn, Lt), alpha=0.5)
+    ref = cbuf.clone()
+    acc = abuf[:, T:].float() @ w.float().t()
+    ref[:, T:] = cbuf[:, T:] + (acc + b.float()).to(BF) * 0.5
+    m = report("gemm_rowmap_inplace", cd, ref)
+    assert m["rel_l2"] <= TOL and torch.equal(cd[:, :T].cpu(), cbuf[:, :T]), m
+    # grouped (experts): E groups of C rows each
+    E, Cc, D = 5, 70, 128
+    xa, we, be = _rand(g, E, Cc, D), _rand(g, E, D, D, scale=D ** -0.5), _rand(g, E, D, scale=0.1)
+    out = torch.empty(E, Cc, D, device=gpu, dtype=BF)
+    ops.gemm(xa.to(gpu), we.to(gpu), be.to(gpu), out, M=Cc, groups=E, a_gstride=Cc * D, w_gstride=D * D, bias_gstride=D, c_gstride=Cc * D)
+    ref = (torch.einsum("ecd,eod->eco", xa.float(), we.float()) + be.float()[:, None]).to(BF)
+    m = report("gemm_grouped", out, ref)
+    assert m["rel_l2"] <= TOL, m
+    # LoRA epilogue: y = x W^T + b + scale * (x A^T) B^T, rank padded to 64
+    M, K, N, r = 200, 128, 256, 16
+    x, w, b = _rand(g, M, K), _rand(g, N, K, scale=K ** -0.5), _rand(g, N, scale=0.1)
+    A, Bm, sc = _rand(g, r, K, scale=K ** -0.5), _rand(g, N, r, scale=0.3), 2.0
+    Ap = torch.zeros(64, K, dtype=BF); Ap[:r] = A
+    Bp = torch.zeros(N, 64, dtype=BF); Bp[:, :r] = (Bm.float() * sc).to(BF)
+    t = torch.empty(M, 64, device=gpu, dtype=BF)
+    ops.gemm(x.to(gpu), Ap.to(gpu), None, t, M=M)
+    out = torch.empty(M, N, device=gpu, dtype=BF)
+    ops.gemm(x.to(gpu), w.to(gpu), b.to(gpu), out, M=M, lora_t=t, lora_b=Bp.to(gpu))
+    ref = R.lora_linear(x.float(), w.float(), b.float(), [(A.float(), Bm.float(), sc)])
+    m = report("gemm_lora", out, ref)
+    assert m["rel_l2"] <= 3e-3, m   # T = x A^T is rounded to bf16 between the two products (peft does the same in bf16)
+
+
+def test_gemm_rejects_bad_args(gpu):
+    from unigen_amd import lib as L, ops
+    a = torch.zeros(8, 72, device=gpu, dtype=BF)
+    w = torch.zeros(8, 72, device=gpu, dtype=BF)
+    with pytest.raises(L.UniGenHipError, match="multiple of 64"):
+        ops.gemm(a, w, None, torch.empty(8, 8, device=gpu, dtype=BF), M=8)
+    with pytest.raises(L.UniGenHipError):
+        ops.gemm(a.cpu(), w, None, torch.empty(8, 8, device=gpu, dtype=BF), M=8)
+
+
+@pytest.mark.parametrize("M,N,K,silu,resid", [(4, 768, 256, False, False), (2, 1536, 256, True, True), (8, 100, 64, True, False), (16, 264, 3072, True, True)])
+def test_small_linear(gpu, M, N, K, silu, resid):
+    from unigen_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    x, w, b, r = _rand(g, M, K), _rand(g, N, K, scale=K ** -0.5), _rand(g, N, scale=0.1), _rand(g, M, N)
+    out = torch.empty(M, N, device=gpu, dtype=BF)
+    ops.small_linear(x.to(gpu), w.to(gpu), b.to(gpu), out, silu_in=silu, residual=r.to(gpu) if resid else None)
+    xin = F.silu(x) if silu else x
+    ref = F.linear(xin.float(), w.float(), b.float()).to(BF)
+    if resid:
+        ref = r + ref
+    m = report(f"small_linear_{M}x{N}x{K}", out, ref)
+    assert m["rel_l2"] <= TOL, m
+
+
+@pytest.mark.parametrize("B,rows,D", [(2, 37, 256), (3, 64, 3072), (1, 5, 1536)])
+def test_adaln_modulate(gpu, B, rows, D):
+    from unigen_amd import ops
+    g = torch.Generator().manual_seed(D + rows)
+    x = _rand(g, B, rows, D, scale=2.0) + 0.5
+    emb = _rand(g, B, 6 * D, scale=0.5)
+    out = torch.empty(B * rows, D, device=gpu, dtype=BF)
+    embd = emb.to(gpu)
+    ops.adaln_modulate(x.to(gpu).view(B * rows, D), embd[:, 3 * D:], embd[:, 4 * D:], out, rows=B * rows, D=D, rows_per_sample=rows, mod_ld=6 * D)
+    shift, scale = emb[:, 3 * D:4 * D], emb[:, 4 * D:5 * D]
+    ref = R.layer_norm(x) * (1 + scale[:, None]) + shift[:, None]
+    m = report(f"adaln_{B}x{rows}x{D}", out.view(B, rows, D), ref)
+    assert m["rel_l2"] <= TOL, m
+
+
+@pytest.mark.parametrize("dh,H", [(128, 2), (64, 3)])
+def test_qk_rmsnorm_rope(gpu, dh, H):
+    from unigen_amd import ops
+    g = torch.Generator().manual_seed(dh)
+    B, T, N = 2, 5, 12
+    Lt, D = T + N, H * dh
+    buf = _rand(g, B, Lt, 3 * D)
+    wq_a, wk_a, wq_b, wk_b = (1 + _rand(g, dh, scale=0.1) for _ in range(4))
+    ids = torch.cat([torch.zeros(T, 3), R.make_ids(3, 4, torch.float32)], 0).to(BF)
+    axes = (16, 56, 56) if dh == 128 else (8, 28, 28)
+    cos, sin = R.flux_pos_embed(ids, axes)
+    d = buf.to(gpu)
+    ops.qk_rmsnorm_rope(d, batches=B, rows_per_batch=Lt, ld=3 * D, q_off=0, k_off=D, heads=H, dh=dh, wq_a=wq_a.to(gpu), wk_a=wk_a.to(gpu),
+                        wq_b=wq_b.to(gpu), wk_b=wk_b.to(gpu), split=T, cos=cos.to(gpu), sin=sin.to(gpu))
+    ref = buf.clone()
+    for off, wa, wb in ((0, wq_a, wq_b), (D, wk_a, wk_b)):
+        t = buf[:, :, off:off + D].view(B, Lt, H, dh).transpose(1, 2)
+        t = torch.cat([R.rms_norm(t[:, :, :T], wa), R.rms_norm(t[:, :, T:], wb)], 2)
+        t = R.apply_rotary_emb(t, cos, sin)
+        ref[:, :, off:off + D] = t.transpose(1, 2).reshape(B, Lt, D)
+    m = report(f"qk_rmsnorm_rope_dh{dh}", d, ref)
+    assert m["rel_l2"] <= TOL and torch.equal(d[:, :, 2 * D:].cpu(), buf[:, :, 2 * D:]), m
+    # k-only on a row sub-range (control blocks: text K/V cached, image rows re-done), no q
+    d2 = buf.to(gpu)
+    ops.qk_rmsnorm_rope(d2[0, T:], batches=B, rows_per_batch=N, batch_stride_rows=Lt, pos_offset=T, ld=3 * D, q_off=-1, k_off=D, heads=H, dh=dh,
+                        wk_a=wk_a.to(gpu), wk_b=wk_b.to(gpu), split=T, cos=cos.to(gpu), sin=sin.to(gpu))
+    ref2 = buf.clone()
+    ref2[:, T:, D:2 * D] = ref[:, T:, D:2 * D]
+    m = report(f"qk_rmsnorm_rope_sub_dh{dh}", d2, ref2)
+    assert m["rel_l2"] <= TOL, m
+
+
+@pytest.mark.parametrize("B,H,Lq,Lkv,qoff", [(1, 2, 256, 256, 0), (2, 3, 300, 333, 0), (1, 2, 64, 200, 136), (1, 1, 512, 1024, 0)])
+def test_flash_attn(gpu, B, H, Lq, Lkv, qoff):
+    """qoff > 0: queries are rows [qoff, qoff+Lq) of the joint sequence (image-only queries of a control joint block)."""
+    from unigen_amd import ops
+    dh = 128
+    D = H * dh
+    g = torch.Generator().manual_seed(Lq + Lkv)
+    qkv = _rand(g, B, Lkv, 3 * D)
+    d = qkv.to(gpu)
+    out = torch.zeros(B, Lq, D, device=gpu, dtype=BF)
+    ops.flash_attn(d[0, qoff:], d[0, 0, D:], d[0, 0, 2 * D:], out, batches=B, heads=H, dh=dh, Lq=Lq, Lkv=Lkv,
+                   q_strides=(3 * D, Lkv * 3 * D), k_strides=(3 * D, Lkv * 3 * D), v_strides=(3 * D, Lkv * 3 * D), o_strides=(D, Lq * D))
+    q = qkv[:, qoff:qoff + Lq, :D].view(B, Lq, H, dh).transpose(1, 2).float()
+    k = qkv[:, :, D:2 * D].view(B, Lkv, H, dh).transpose(1, 2).float()
+    v = qkv[:, :, 2 * D:].view(B, Lkv, H, dh).transpose(1, 2).float()
+    ref = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B, Lq, D)
+    m = report(f"flash_attn_B{B}H{H}_{Lq}x{Lkv}", out, ref)
+    assert m["rel_l2"] <= 4e-3, m
+
+
+def test_flash_attn_rescale_branch(gpu):
+    """Force the online-softmax rescale: one key row far larger than the rest in a LATE tile (cdna guide rule 26)."""
+    from unigen_amd import ops
+    B, H, Lq, Lkv, dh = 1, 1, 256, 320, 128
+    g = torch.Generator().manual_seed(3)
+    q, k, v = _rand(g, B, Lq, dh), _rand(g, B, Lkv, dh, scale=0.3), _rand(g, B, Lkv, dh)
+    k[0, 200] = q[0, 17] * 4.0     # spikes the score of query 17 (and correlates with others) in tile 3
+    k[0, 300] = q[0, 99] * 6.0     # and again in the last tile
+    out = torch.zeros(B, Lq, dh, device=gpu, dtype=BF)
+    ops.flash_attn(q.to(gpu), k.to(gpu), v.to(gpu), out, batches=B, heads=H, dh=dh, Lq=Lq, Lkv=Lkv, q_strides=(dh, Lq * dh),
+                   k_strides=(dh, Lkv * dh), v_strides=(dh, Lkv * dh), o_strides=(dh, Lq * dh))
+    ref = F.scaled_dot_product_attention(q.float()[:, None], k.float()[:, None], v.float()[:, None])[:, 0]
+    m = report("flash_attn_rescale", out, ref)
+    assert m["rel_l2"] <= 4e-3, m
+
+
+def test_timestep_euler_add(gpu):
+    from unigen_amd import ops
+    t = torch.tensor([1000.0, 752.0, 500.0, 250.0, 0.0])
+    out = torch.empty(5, 256, device=gpu, dtype=BF)
+    ops.timestep_embed(t.to(gpu), out)
+    ref = R.timestep_sinusoid(t).to(BF)
+    m = report("timestep_embed", out, ref)
+    assert m["max_rel"] <= 8e-3, m          # bf16 ulp of values in [0.5, 1]; sin/cos of ~1e3 rad differ in the last fp32 bits
+    g = torch.Generator().manual_seed(0)
+    x, v = _rand(g, 4, 64, 64), _rand(g, 4, 64, 64)
+    xd = x.to(gpu).clone()
+    ops.euler_step(xd, v.to(gpu), -0.25)
+    ref = R.euler_step(x, v, 1.0, 0.75)
+    m = report("euler_step", xd, ref)
+    assert m["mismatch_frac"] == 0.0, m
+    o = torch.empty(4, 64, 64, device=gpu, dtype=BF)
+    ops.add(x.to(gpu), v.to(gpu), o)
+    assert torch.equal(o.cpu(), x + v)
+
+
+@pytest.mark.parametrize("S,E,D", [(128, 6, 256), (1000, 12, 128), (4099, 6, 64)])
+def test_moe_routing_dispatch_combine(gpu, S, E, D):
+    from unigen_amd import ops
+    g = torch.Generator().manual_seed(S + E)
+    B = 1 if S % 2 else 2
+    N = S // B
+    x, c = _rand(g, S, D), _rand(g, S, D)
+    wg = _rand(g, E, D, scale=0.2)
+    uni = torch.rand(S, E, generator=g)
+    C = R.moe_capacity(S, E)
+    gates = torch.empty(S, E, device=gpu, dtype=torch.float32)
+    idx = torch.empty(S, device=gpu, dtype=torch.int32)
+    ops.moe_gate_top1(x.to(gpu), c.to(gpu), wg.to(gpu), gates, idx)
+    logits = F.linear((x + c).float(), wg.float())
+    ref_gates = F.softmax(logits, dim=1)
+    m = report(f"moe_gates_S{S}", gates, ref_gates)
+    assert m["rel_l2"] <= 1e-5, m
+    # argmax must agree wherever the top-2 gap is not a floating-point tie
+    top2 = torch.topk(ref_gates, 2, dim=1)[0]
+    clear = (top2[:, 0] - top2[:, 1]) > 1e-5
+    assert torch.equal(idx.cpu().long()[clear], ref_gates.argmax(1)[clear])
+    # routing from the DEVICE gates (so that later comparisons are exact index comparisons)
+    gates_h = gates.cpu()
+    ridx, rslot, rtos = R.routing_from_gates(gates_h, uni, C)
+    l_aux_ref, cw, dm, cnt_ref = R.top1gating(torch.log(gates_h), uni, C)
+    slot = torch.empty(S, device=gpu, dtype=torch.int32)
+    tos = torch.empty(E, C, device=gpu, dtype=torch.int32)
+    cnt = torch.empty(E, device=gpu, dtype=torch.int64)
+    l_aux = torch.empty(1, device=gpu, dtype=torch.float32)
+    ops.moe_capacity_rts(gates, idx, uni.to(gpu), C, slot, tos, cnt, l_aux)
+    assert torch.equal(idx.cpu().long(), ridx)
+    assert torch.equal(slot.cpu().long(), rslot), "slot assignment differs from deepspeed top1gating"
+    assert torch.equal(tos.cpu().long(), rtos)
+    assert torch.equal(cnt.cpu(), cnt_ref)
+    assert abs(float(l_aux) - float(l_aux_ref)) <= 1e-5 * abs(float(l_aux_ref))
+    # the dense combine_weights of top1gating say the same thing as (idx, slot)
+    s_ar = torch.arange(S)
+    kept = rslot >= 0
+    assert torch.equal(dm.sum((1, 2)).bool(), kept)
+    assert torch.allclose(cw[s_ar[kept], ridx[kept], rslot[kept]], gates_h[s_ar[kept], ridx[kept]])
+    # dispatch + modulate, with and without the added expert output
+    mod = _rand(g, E, B, D)
+    add_ = _rand(g, E, C, D)
+    for use_add in (False, True):
+        out = torch.empty(E, C, D, device=gpu, dtype=BF)
+        ops.moe_dispatch_modulate(x.to(gpu), add_.to(gpu) if use_add else None, mod.to(gpu), tos, out, B=B, E=E, capacity=C, tokens_per_sample=N)
+        ref = torch.zeros(E, C, D, dtype=BF)
+        for e in range(E):
+            for s_ in range(C):
+                t = int(rtos[e, s_])
+                if t >= 0:
+                    xin = x[t] + add_[e, s_] if use_add else x[t]
+                    ref[e, s_] = (mod[e, t // N].float() * xin.float()).to(BF)
+        m = report(f"moe_dispatch_S{S}_add{int(use_add)}", out, ref)
+        assert m["mismatch_frac"] == 0.0, m
+    # combine
+    yh, yc, xs, cs = _rand(g, E, C, D), _rand(g, E, C, D), _rand(g, S, D), _rand(g, S, D)
+    cw2 = torch.zeros(S, E, C)
+    cw2[s_ar[kept], ridx[kept], rslot[kept]] = gates_h[s_ar[kept], ridx[kept]]   # combine_weights built from the device gates
+    cwb = cw2.to(BF)
+    eh = torch.einsum("sec,ecm->sm", cwb.float(), yh.float()).to(BF)
+    ec = torch.einsum("sec,ecm->sm", cwb.float(), yc.float()).to(BF)
+    out = torch.empty(S, D, device=gpu, dtype=BF)
+    ops.moe_combine(yh.to(gpu), yc.to(gpu), gates, idx, slot, out, E=E, capacity=C, xs=xs.to(gpu), cs=cs.to(gpu))
+    ref = (xs + eh) + (cs + ec)
+    m = report(f"moe_combine_S{S}", out, ref)
+    assert m["mismatch_frac"] == 0.0, m
+    ops.moe_combine(yh.to(gpu), yc.to(gpu), gates, idx, slot, out, E=E, capacity=C, accumulate=True)
+    ref2 = ref + (eh + ec)
+    m = report(f"moe_combine_acc_S{S}", out, ref2)
+    assert m["mismatch_frac"] == 0.0, m

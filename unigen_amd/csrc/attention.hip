@@ -1,0 +1,237 @@
+// Flash-style fused attention forward for the joint text|image|condition sequences of the UniGen MM-DiT blocks.
+//   O = softmax(Q K^T * scale) V, non-causal, no mask, bf16 in/out, fp32 scores / statistics / accumulators.
+// Replaces F.scaled_dot_product_attention at src/UniGenUtils.py:601 (JointAttnRopeProcessor) and inside diffusers
+// FluxAttnProcessor2_0 (base blocks, src/UniGenTransformer.py:1129,1151). L = 4608 / 8192 / 8704 at 1024^2.
+//
+// Structure (gfx950, wave64): one workgroup = 8 waves = 256 query rows of one (batch, head); each wave owns 32 query
+// rows, Q fragments live in registers. K/V tiles of 64 keys are staged HBM -> registers -> LDS (issue early, write late),
+// double buffered, in an XOR-swizzled 256-byte-row image that is conflict-free for both the row reads (K, ds_read_b128)
+// and the transposed reads (V, ds_read_b64_tr_b16).
+//   S^T = K Q^T   with v_mfma_f32_32x32x16_bf16: the query index lands on the LANE, so the softmax row statistics are
+//                 lane-local (one exchange with lane^32 per tile for the max).
+//   O^T = V^T P^T : the S^T accumulator registers 8s..8s+7, packed to bf16, ARE the B operand of k-step s (permuted k
+//                 order, matched by the key order of the transposed V reads) - P never touches LDS or other lanes.
+#include "ug_common.h"
+
+namespace {
+
+constexpr int QROWS = 256;   // query rows per workgroup
+constexpr int KVB = 64;      // keys per tile
+
+typedef __attribute__((address_space(3))) bf16x4* lds_b64_ptr;
+
+// byte offset of 16-byte chunk ch of row `row` in a [rows][128 x bf16] tile image (256-byte rows)
+__device__ __forceinline__ int img_off(int row, int ch) {
+    return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+}
+
+__device__ __forceinline__ bf16x8 tr_read_pair(const unsigned char* lo, const unsigned char* hi) {
+    const bf16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b64_ptr)lo);
+    const bf16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b64_ptr)hi);
+    return (bf16x8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+}
+
+__global__ __launch_bounds__(512, 2) void flash_attn128_kernel(
+    const bf16_t* __restrict__ q, int64_t q_rs, int64_t q_bs, const bf16_t* __restrict__ k, int64_t k_rs, int64_t k_bs,
+    const bf16_t* __restrict__ v, int64_t v_rs, int64_t v_bs, bf16_t* __restrict__ o, int64_t o_rs, int64_t o_bs,
+    int heads, int Lq, int Lkv, int nQ, float c /* softmax_scale * log2(e) */) {
+    constexpr int DH = 128;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [2][K 16 KiB | V 16 KiB]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+
+    // XCD-aware block order: all query tiles of one (batch, head) run on one XCD so its K/V stay in that L2.
+    const int nwg = gridDim.x;
+    const int qd = nwg >> 3, rm = nwg & 7;
+    const int xcd = blockIdx.x & 7, kk = blockIdx.x >> 3;
+    const int logical = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + kk;
+    const int qt = logical % nQ;
+    const int bh = logical / nQ;
+    const int head = bh % heads, b = bh / heads;
+
+    const bf16_t* Qb = q + (int64_t)b * q_bs + head * DH;
+    const bf16_t* Kb = k + (int64_t)b * k_bs + head * DH;
+    const bf16_t* Vb = v + (int64_t)b * v_bs + head * DH;
+
+    // ---- Q fragments (B operand of S^T = K Q^T): lane (r, h) holds Q[q = r][d = 16 s + 8 h + j] ----
+    const int q_row = qt * QROWS + wave * 32 + r;
+    const int q_ld = q_row < Lq ? q_row : Lq - 1;
+    bf16x8 qf[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) qf[s] = *(const bf16x8*)(Qb + (int64_t)q_ld * q_rs + 16 * s + 8 * h);
+
+    // ---- staging assignment: thread -> 2 chunks of K and 2 of V per tile ----
+    int st_row[2], st_ch[2], st_off[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int cid = tid + 512 * u;
+        st_row[u] = cid >> 4; st_ch[u] = cid & 15;
+        st_off[u] = img_off(st_row[u], st_ch[u]);
+    }
+    u32x4 kreg[2], vreg[2];
+    auto stage_load = [&](int kv0) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            int key = kv0 + st_row[u]; if (key > Lkv - 1) key = Lkv - 1;
+            kreg[u] = *(const u32x4*)(Kb + (int64_t)key * k_rs + st_ch[u] * 8);
+            vreg[u] = *(const u32x4*)(Vb + (int64_t)key * v_rs + st_ch[u] * 8);
+        }
+    };
+    auto stage_write = [&](int buf) {
+        unsigned char* Kbuf = smem + buf * 32768;
+        unsigned char* Vbuf = Kbuf + 16384;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            *(u32x4*)(Kbuf + st_off[u]) = kreg[u];
+            *(u32x4*)(Vbuf + st_off[u]) = vreg[u];
+        }
+    };
+
+    // ---- per-lane LDS read offsets ----
+    // K row read: row = kb*32 + r, chunk = 2s + h  ->  256*row + 16*((2s) ^ kx),  kx = h ^ swizzle(r)
+    const int k_rowoff = 256 * r;
+    const int kx = h ^ (((r & 3) << 2) | ((r >> 2) & 3));
+    // V transposed read: group g = lane>>4 (16 lanes), i = lane&15. Block rows = keys 16ks + 4h + (i>>2) (+8 for the
+    // second half of the k-step), columns d = 32db + 16(g&1) + 4(i&3)..+3. Lane receives column d = 32db + (lane&31).
+    const int i16 = lane & 15, g16 = lane >> 4;
+    const int v_key = 4 * h + (i16 >> 2);
+    const int v_lowch = 2 * (g16 & 1) + ((i16 & 3) >> 1);
+    const int v_b8 = 8 * (i16 & 1);
+    int voff_lo[4], voff_hi[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+        const int ch = 4 * db + v_lowch;
+        voff_lo[db] = 256 * v_key + 16 * (ch ^ (((i16 >> 2) << 2) | h)) + v_b8;            // key & 3 = i>>2, (key>>2)&3 = h
+        voff_hi[db] = 256 * (v_key + 8) + 16 * (ch ^ (((i16 >> 2) << 2) | (h + 2))) + v_b8;  // key + 8: (key>>2)&3 = h + 2
+    }
+
+    f32x16 oacc[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) oacc[db][i] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int ntiles = (Lkv + KVB - 1) / KVB;
+    stage_load(0);
+    stage_write(0);
+    __syncthreads();
+
+    for (int t = 0; t < ntiles; ++t) {
+        const int cur = t & 1;
+        const int kv0 = t * KVB;
+        const unsigned char* Kbuf = smem + cur * 32768;
+        const unsigned char* Vbuf = Kbuf + 16384;
+        if (t + 1 < ntiles) stage_load(kv0 + KVB);
+
+        // ---- S^T[key][q] ----
+        f32x16 sacc[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sacc[kb][i] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const bf16x8 kf = *(const bf16x8*)(Kbuf + kb * 8192 + k_rowoff + 16 * ((2 * s) ^ kx));
+                sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc[kb], 0, 0, 0);
+            }
+        }
+        if (kv0 + KVB > Lkv) {   // ragged last tile: keys >= Lkv do not exist
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int key = kv0 + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    if (key >= Lkv) sacc[kb][i] = -INFINITY;
+                }
+        }
+        // ---- online softmax, all lane-local (this lane: query r, 32 of the tile's 64 keys; lane^32 has the rest) ----
+        float tmax = sacc[0][0];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) tmax = fmaxf(tmax, sacc[kb][i]);
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m_run, tmax);
+        if (!__all(m_new == m_run)) {
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+            l_run *= alpha;
+#pragma unroll
+            for (int db = 0; db < 4; ++db)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) oacc[db][i] *= alpha;
+            m_run = m_new;
+        }
+        const float mc = m_run * c;
+        bf16x8 pf[2][2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            float p[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                p[i] = __builtin_amdgcn_exp2f(fmaf(sacc[kb][i], c, -mc));
+                l_run += p[i];
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                u32x4 w;
+                w.x = pack2bf(p[8 * s2 + 0], p[8 * s2 + 1]); w.y = pack2bf(p[8 * s2 + 2], p[8 * s2 + 3]);
+                w.z = pack2bf(p[8 * s2 + 4], p[8 * s2 + 5]); w.w = pack2bf(p[8 * s2 + 6], p[8 * s2 + 7]);
+                pf[kb][s2] = __builtin_bit_cast(bf16x8, w);
+            }
+        }
+        // ---- O^T[d][q] += V^T[d][key] P^T[key][q] ----
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 vf = tr_read_pair(Vbuf + ks * 4096 + voff_lo[db], Vbuf + ks * 4096 + voff_hi[db]);
+                oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[ks >> 1][ks & 1], oacc[db], 0, 0, 0);
+            }
+        }
+        if (t + 1 < ntiles) stage_write(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: O[q][d] = O^T / l ----
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    if (q_row < Lq) {
+        bf16_t* Orow = o + (int64_t)b * o_bs + (int64_t)q_row * o_rs + head * DH;
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                u32x2 w;
+                w.x = pack2bf(oacc[db][4 * g4 + 0] * inv, oacc[db][4 * g4 + 1] * inv);
+                w.y = pack2bf(oacc[db][4 * g4 + 2] * inv, oacc[db][4 * g4 + 3] * inv);
+                *(u32x2*)(Orow + 32 * db + 8 * g4 + 4 * h) = w;
+            }
+    }
+}
+
+}  // namespace
+
+extern "C" int ug_flash_attn_fwd(const void* q, int64_t q_row_stride, int64_t q_batch_stride, const void* k,
+                                 int64_t k_row_stride, int64_t k_batch_stride, const void* v, int64_t v_row_stride,
+                                 int64_t v_batch_stride, void* o, int64_t o_row_stride, int64_t o_batch_stride,
+                                 int64_t batches, int32_t heads, int64_t Lq, int64_t Lkv, int32_t dh, float softmax_scale,
+                                 ug_stream_t stream) {
+    if (batches == 0 || Lq == 0) return UG_OK;
+    UG_REQUIRE(q && k && v && o && batches > 0 && heads > 0 && Lq > 0 && Lkv > 0, UG_ERR_BAD_SHAPE, "ug_flash_attn_fwd: bad arguments");
+    UG_REQUIRE(dh == 128, UG_ERR_UNSUPPORTED, "ug_flash_attn_fwd: head dim %d not supported yet (128 only)", dh);
+    UG_REQUIRE(Lq < (1 << 30) && Lkv < (1 << 30), UG_ERR_UNSUPPORTED, "ug_flash_attn_fwd: sequence too long");
+    UG_REQUIRE(q_row_stride % 8 == 0 && k_row_stride % 8 == 0 && v_row_stride % 8 == 0 && o_row_stride % 4 == 0 &&
+               q_batch_stride % 8 == 0 && k_batch_stride % 8 == 0 && v_batch_stride % 8 == 0 && o_batch_stride % 4 == 0 &&
+               ug_aligned(q, 16) && ug_aligned(k, 16) && ug_aligned(v, 16) && ug_aligned(o, 8),
+               UG_ERR_BAD_ALIGN, "ug_flash_attn_fwd: strides must be multiples of 8 elements and bases 16-byte aligned");
+    const int nQ = (int)((Lq + QROWS - 1) / QROWS);
+    const int64_t nwg = (int64_t)nQ * heads * batches;
+    UG_REQUIRE(nwg < (1ll << 31), UG_ERR_UNSUPPORTED, "ug_flash_attn_fwd: grid too large");
+    const float c = softmax_scale * 1.4426950408889634f;
+    hipLaunchKernelGGL(flash_attn128_kernel, dim3((unsigned)nwg), dim3(512), 65536, (hipStream_t)stream, (const bf16_t*)q,
+                       q_row_stride, q_batch_stride, (const bf16_t*)k, k_row_stride, k_batch_stride, (const bf16_t*)v,
+                       v_row_stride, v_batch_stride, (bf16_t*)o, o_row_stride, o_batch_stride, (int)heads, (int)Lq, (int)Lkv, nQ, c);
+    UG_CHECK_LAUNCH("ug_flash_attn_fwd");
+    return UG_OK;
+}

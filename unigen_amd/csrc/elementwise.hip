@@ -1,0 +1,352 @@
+// HBM-bound row kernels of the UniGen forward: AdaLayerNorm-Zero modulate, q/k RMSNorm + RoPE, per-sample
+// (small-M) linears, sinusoidal timestep features, Euler step, add. All bf16 in/out, fp32 math, 16-byte accesses.
+// Rounding points mirror the reference's separate bf16 torch ops so results are comparable element-for-element.
+#include "ug_common.h"
+#include <algorithm>
+
+namespace {
+
+__device__ __forceinline__ void unpack8(const u32x4 v, float* f) {
+    f[0] = bflo(v.x); f[1] = bfhi(v.x); f[2] = bflo(v.y); f[3] = bfhi(v.y);
+    f[4] = bflo(v.z); f[5] = bfhi(v.z); f[6] = bflo(v.w); f[7] = bfhi(v.w);
+}
+__device__ __forceinline__ u32x4 pack8(const float* f) {
+    u32x4 v;
+    v.x = pack2bf(f[0], f[1]); v.y = pack2bf(f[2], f[3]); v.z = pack2bf(f[4], f[5]); v.w = pack2bf(f[6], f[7]);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// AdaLayerNorm modulate: out = LN(x) * (1 + scale[b]) + shift[b].  One wave per row, row kept in registers.
+// reference: diffusers AdaLayerNormZero.forward / FluxTransformerBlock norm2 + modulate; src/UniGenUtils.py:354-373
+// ---------------------------------------------------------------------------------------------------------
+constexpr int LN_MAXCH = 8;  // chunks (of 8 elements) per lane -> D <= 4096
+
+__global__ __launch_bounds__(256) void adaln_modulate_kernel(
+    const bf16_t* __restrict__ x, int64_t ldx, int64_t x_rpb, int64_t x_bstride,
+    const bf16_t* __restrict__ shift, const bf16_t* __restrict__ scale, int64_t mod_ld, int64_t rows_per_sample,
+    bf16_t* __restrict__ out, int64_t ldo, int64_t rows, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nchunk = D >> 3;
+    const bf16_t* xr = x + ug_rowmap(row, x_rpb, x_bstride) * ldx;
+    float v[LN_MAXCH][8];
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < LN_MAXCH; ++t) {
+        const int c = lane + t * 64;
+        if (c < nchunk) {
+            unpack8(*(const u32x4*)(xr + c * 8), v[t]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += v[t][e];
+        }
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int t = 0; t < LN_MAXCH; ++t) {
+        const int c = lane + t * 64;
+        if (c < nchunk) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = v[t][e] - mean; q += d * d; }
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+    const int64_t b = row / rows_per_sample;
+    const bf16_t* sh = shift + b * mod_ld;
+    const bf16_t* sc = scale + b * mod_ld;
+    bf16_t* orow = out + row * ldo;
+#pragma unroll
+    for (int t = 0; t < LN_MAXCH; ++t) {
+        const int c = lane + t * 64;
+        if (c < nchunk) {
+            float fs[8], fc[8], o[8];
+            unpack8(*(const u32x4*)(sh + c * 8), fs);
+            unpack8(*(const u32x4*)(sc + c * 8), fc);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float n = rbf((v[t][e] - mean) * rstd);   // LayerNorm output (bf16 tensor in the reference)
+                const float s1 = rbf(1.0f + fc[e]);             // (1 + scale)
+                o[e] = rbf(n * s1) + fs[e];                     // * then +, each a bf16 op in the reference
+            }
+            *(u32x4*)(orow + c * 8) = pack8(o);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// q/k RMSNorm + RoPE, in place on the fused projection buffer. DH/8 lanes per head vector.
+// reference: diffusers RMSNorm (Attention.norm_q/k, norm_added_q/k) + apply_rotary_emb; src/UniGenUtils.py:561-599
+// ---------------------------------------------------------------------------------------------------------
+template <int DH>
+__global__ __launch_bounds__(256) void qk_rmsnorm_rope_kernel(
+    bf16_t* __restrict__ buf, int64_t ld, int64_t total_rows, int64_t rows_per_batch, int64_t batch_stride_rows,
+    int64_t pos_offset, int64_t q_off, int64_t k_off, int heads, const bf16_t* __restrict__ wq_a, const bf16_t* __restrict__ wk_a, const bf16_t* __restrict__ wq_b,
+    const bf16_t* __restrict__ wk_b, int64_t split, const float* __restrict__ cos_tab,
+    const float* __restrict__ sin_tab, float eps) {
+    constexpr int LPV = DH / 8;                 // lanes per head vector
+    constexpr int VPW = 64 / LPV;               // vectors per wave
+    const int lane = threadIdx.x & 63;
+    const int sub = lane % LPV, vin = lane / LPV;
+    const int nwhich = q_off >= 0 ? 2 : 1;
+    const int64_t nvec = total_rows * nwhich * heads;
+    const int64_t wave_id = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t vec = wave_id * VPW + vin;
+    const bool active = vec < nvec;
+    const int64_t vv = active ? vec : 0;
+    const int h = (int)(vv % heads);
+    const int64_t t1 = vv / heads;
+    const int which = q_off >= 0 ? (int)(t1 % 2) : 1;   // 0 = q, 1 = k
+    const int64_t row = q_off >= 0 ? t1 / 2 : t1;
+    const int64_t bidx = row / rows_per_batch;
+    const int64_t rr = row - bidx * rows_per_batch;
+    const int64_t pos = pos_offset + rr;
+    bf16_t* p = buf + (bidx * batch_stride_rows + rr) * ld + (which == 0 ? q_off : k_off) + (int64_t)h * DH + sub * 8;
+    float x[8];
+    unpack8(*(const u32x4*)p, x);
+    const bf16_t* w = (pos < split) ? (which == 0 ? wq_a : wk_a) : (which == 0 ? wq_b : wk_b);
+    if (w) {
+        float ss = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ss += x[e] * x[e];
+#pragma unroll
+        for (int o = LPV / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+        const float rs = rsqrtf(ss / (float)DH + eps);
+        float wf[8];
+        unpack8(*(const u32x4*)(w + sub * 8), wf);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = rbf(rbf(x[e] * rs) * wf[e]);
+    }
+    if (cos_tab) {
+        const float* cp = cos_tab + pos * DH + sub * 8;
+        const float* sp = sin_tab + pos * DH + sub * 8;
+        const f32x4 c0 = *(const f32x4*)cp, c1 = *(const f32x4*)(cp + 4);
+        const f32x4 s0 = *(const f32x4*)sp, s1 = *(const f32x4*)(sp + 4);
+        const float c[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+        const float s[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+            o[e] = x[e] * c[e] + (-x[e + 1]) * s[e];
+            o[e + 1] = x[e + 1] * c[e + 1] + x[e] * s[e + 1];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = o[e];
+    }
+    if (active) *(u32x4*)p = pack8(x);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Per-sample linears (M <= 16): out = R + bf16(act(x) W^T + b). x is staged once per block in LDS (with SiLU
+// applied), each wave streams whole weight rows from HBM with 16-byte loads. HBM-bound on W.
+// reference: AdaLayerNormZero.linear(silu(emb)), TimestepEmbedding, PixArtAlphaTextProjection (diffusers 0.32.2)
+// ---------------------------------------------------------------------------------------------------------
+constexpr int SL_COLS_PER_WAVE = 8;
+
+template <int MT>
+__global__ __launch_bounds__(256) void small_linear_kernel(
+    const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ W, int64_t ldw,
+    const bf16_t* __restrict__ bias, const bf16_t* __restrict__ R, int64_t ldr, bf16_t* __restrict__ out,
+    int64_t ldo, int M, int64_t N, int K, int act_in) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16_t* xs = (bf16_t*)smem;  // [MT][K]
+    const int nchunk = K >> 3;
+    for (int i = threadIdx.x; i < MT * nchunk; i += 256) {
+        const int m = i / nchunk, c = i - m * nchunk;
+        float f[8];
+        if (m < M) {
+            unpack8(*(const u32x4*)(x + (int64_t)m * ldx + c * 8), f);
+            if (act_in == 1) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = f[e] / (1.0f + __expf(-f[e]));   // SiLU, rounded to bf16 below
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = 0.f;
+        }
+        *(u32x4*)(xs + (int64_t)m * K + c * 8) = pack8(f);
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t nbase = ((int64_t)blockIdx.x * 4 + wave) * SL_COLS_PER_WAVE;
+    for (int cc = 0; cc < SL_COLS_PER_WAVE; ++cc) {
+        const int64_t n = nbase + cc;
+        if (n >= N) break;
+        float acc[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m] = 0.f;
+        const bf16_t* wr = W + n * ldw;
+        for (int c = lane; c < nchunk; c += 64) {
+            float wf[8];
+            unpack8(*(const u32x4*)(wr + c * 8), wf);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                float xf[8];
+                unpack8(*(const u32x4*)(xs + (int64_t)m * K + c * 8), xf);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[m] += xf[e] * wf[e];
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m] = wave_sum(acc[m]);
+        if (lane < M) {
+            float v = 0.f;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) if (m == lane) v = acc[m];
+            if (bias) v += bf2f(bias[n]);
+            v = rbf(v);
+            if (R) v += bf2f(R[(int64_t)lane * ldr + n]);
+            out[(int64_t)lane * ldo + n] = f2bf(v);
+        }
+    }
+}
+
+__global__ void timestep_embed_kernel(const float* __restrict__ t, bf16_t* __restrict__ out, int64_t ldo, int B, int dim) {
+    const int half = dim >> 1;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * half) return;
+    const int b = i / half, k = i - b * half;
+    const float f = expf(-9.210340371976184f * (float)k / (float)half);  // exp(-ln(10000) k / half)
+    const float a = t[b] * f;
+    out[(int64_t)b * ldo + k] = f2bf(cosf(a));          // flip_sin_to_cos=True -> [cos | sin]
+    out[(int64_t)b * ldo + half + k] = f2bf(sinf(a));
+}
+
+__global__ void euler_step_kernel(bf16_t* __restrict__ x, const bf16_t* __restrict__ v, float dt, int64_t nchunk) {
+    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < nchunk; c += (int64_t)gridDim.x * blockDim.x) {
+        float a[8], b[8];
+        unpack8(*(const u32x4*)(x + c * 8), a);
+        unpack8(*(const u32x4*)(v + c * 8), b);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] = a[e] + dt * b[e];
+        *(u32x4*)(x + c * 8) = pack8(a);
+    }
+}
+
+__global__ void add_kernel(const bf16_t* __restrict__ a, int64_t lda, const bf16_t* __restrict__ b, int64_t ldb,
+                           bf16_t* __restrict__ out, int64_t ldo, int64_t rows, int chunks_per_row) {
+    const int64_t total = rows * chunks_per_row;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / chunks_per_row; const int c = (int)(i - r * chunks_per_row);
+        float fa[8], fb[8];
+        unpack8(*(const u32x4*)(a + r * lda + c * 8), fa);
+        unpack8(*(const u32x4*)(b + r * ldb + c * 8), fb);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) fa[e] += fb[e];
+        *(u32x4*)(out + r * ldo + c * 8) = pack8(fa);
+    }
+}
+
+}  // namespace
+
+extern "C" int ug_adaln_modulate(const void* x, int64_t ldx, int64_t x_rpb, int64_t x_bstride, const void* shift,
+                                 const void* scale, int64_t mod_ld, int64_t rows_per_sample, void* out, int64_t ldo,
+                                 int64_t rows, int64_t D, float eps, ug_stream_t stream) {
+    if (rows == 0) return UG_OK;
+    UG_REQUIRE(x && shift && scale && out && rows > 0 && rows_per_sample > 0, UG_ERR_BAD_SHAPE, "ug_adaln_modulate: bad arguments");
+    UG_REQUIRE(D % 8 == 0 && D > 0 && D <= LN_MAXCH * 64 * 8, UG_ERR_UNSUPPORTED, "ug_adaln_modulate: D=%lld must be a multiple of 8 and <= 4096", (long long)D);
+    UG_REQUIRE(ldx % 8 == 0 && ldo % 8 == 0 && mod_ld % 8 == 0 && ug_aligned(x, 16) && ug_aligned(out, 16) &&
+               ug_aligned(shift, 16) && ug_aligned(scale, 16), UG_ERR_BAD_ALIGN, "ug_adaln_modulate: 16-byte alignment required");
+    const unsigned grid = (unsigned)((rows + 3) / 4);
+    hipLaunchKernelGGL(adaln_modulate_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, x_rpb,
+                       x_bstride, (const bf16_t*)shift, (const bf16_t*)scale, mod_ld, rows_per_sample, (bf16_t*)out, ldo,
+                       rows, (int)D, eps);
+    UG_CHECK_LAUNCH("ug_adaln_modulate");
+    return UG_OK;
+}
+
+extern "C" int ug_qk_rmsnorm_rope(void* buf, int64_t ld, int64_t batches, int64_t rows_per_batch, int64_t batch_stride_rows,
+                                  int64_t pos_offset, int64_t q_off, int64_t k_off, int32_t heads, int32_t dh, const void* wq_a, const void* wk_a,
+                                  const void* wq_b, const void* wk_b, int64_t split, const float* cos_tab,
+                                  const float* sin_tab, float eps, ug_stream_t stream) {
+    const int64_t total_rows = batches * rows_per_batch;
+    if (total_rows == 0) return UG_OK;
+    UG_REQUIRE(buf && heads > 0 && k_off >= 0 && batch_stride_rows >= rows_per_batch && pos_offset >= 0, UG_ERR_BAD_SHAPE,
+               "ug_qk_rmsnorm_rope: bad arguments");
+    UG_REQUIRE(dh == 64 || dh == 128, UG_ERR_UNSUPPORTED, "ug_qk_rmsnorm_rope: head dim %d not in {64,128}", dh);
+    UG_REQUIRE(ld % 8 == 0 && k_off % 8 == 0 && (q_off < 0 || q_off % 8 == 0) && ug_aligned(buf, 16), UG_ERR_BAD_ALIGN,
+               "ug_qk_rmsnorm_rope: 16-byte alignment required");
+    UG_REQUIRE((cos_tab == nullptr) == (sin_tab == nullptr), UG_ERR_BAD_SHAPE, "ug_qk_rmsnorm_rope: cos/sin must both be given");
+    UG_REQUIRE(!cos_tab || (ug_aligned(cos_tab, 16) && ug_aligned(sin_tab, 16)), UG_ERR_BAD_ALIGN, "ug_qk_rmsnorm_rope: tables misaligned");
+    const bool haveq = q_off >= 0;
+    if (haveq) UG_REQUIRE((wq_a == nullptr) == (wk_a == nullptr) && (wq_b == nullptr) == (wk_b == nullptr), UG_ERR_BAD_SHAPE,
+                          "ug_qk_rmsnorm_rope: q/k norm weights must come in pairs");
+    const int64_t nvec = total_rows * (haveq ? 2 : 1) * heads;
+    const int vpw = 64 / (dh / 8);
+    const int64_t waves = (nvec + vpw - 1) / vpw;
+    const unsigned grid = (unsigned)((waves + 3) / 4);
+    hipStream_t s = (hipStream_t)stream;
+    if (dh == 128)
+        hipLaunchKernelGGL(qk_rmsnorm_rope_kernel<128>, dim3(grid), dim3(256), 0, s, (bf16_t*)buf, ld, total_rows, rows_per_batch,
+                           batch_stride_rows, pos_offset, q_off, k_off, heads, (const bf16_t*)wq_a, (const bf16_t*)wk_a, (const bf16_t*)wq_b,
+                           (const bf16_t*)wk_b, split, cos_tab, sin_tab, eps);
+    else
+        hipLaunchKernelGGL(qk_rmsnorm_rope_kernel<64>, dim3(grid), dim3(256), 0, s, (bf16_t*)buf, ld, total_rows, rows_per_batch,
+                           batch_stride_rows, pos_offset, q_off, k_off, heads, (const bf16_t*)wq_a, (const bf16_t*)wk_a, (const bf16_t*)wq_b,
+                           (const bf16_t*)wk_b, split, cos_tab, sin_tab, eps);
+    UG_CHECK_LAUNCH("ug_qk_rmsnorm_rope");
+    return UG_OK;
+}
+
+extern "C" int ug_small_linear_bf16(const void* x, int64_t ldx, const void* W, int64_t ldw, const void* bias,
+                                    const void* R, int64_t ldr, void* out, int64_t ldo, int64_t M, int64_t N, int64_t K,
+                                    int32_t act_in, ug_stream_t stream) {
+    if (M == 0 || N == 0) return UG_OK;
+    UG_REQUIRE(x && W && out && M > 0 && N > 0 && K > 0, UG_ERR_BAD_SHAPE, "ug_small_linear_bf16: bad arguments");
+    UG_REQUIRE(M <= 16, UG_ERR_UNSUPPORTED, "ug_small_linear_bf16: M=%lld > 16 (use ug_gemm_bf16)", (long long)M);
+    UG_REQUIRE(K % 8 == 0 && ldx % 8 == 0 && ldw % 8 == 0 && ug_aligned(x, 16) && ug_aligned(W, 16), UG_ERR_BAD_ALIGN,
+               "ug_small_linear_bf16: K, ldx, ldw must be multiples of 8 and bases 16-byte aligned");
+    UG_REQUIRE(act_in == 0 || act_in == 1, UG_ERR_UNSUPPORTED, "ug_small_linear_bf16: act_in %d", act_in);
+    const int MT = M <= 4 ? 4 : (M <= 8 ? 8 : 16);
+    const size_t lds = (size_t)MT * K * 2;
+    UG_REQUIRE(lds <= 128 * 1024, UG_ERR_UNSUPPORTED, "ug_small_linear_bf16: M*K too large for LDS staging");
+    const int64_t cols_per_block = 4 * SL_COLS_PER_WAVE;
+    const unsigned grid = (unsigned)((N + cols_per_block - 1) / cols_per_block);
+    hipStream_t s = (hipStream_t)stream;
+#define UG_SL_LAUNCH(MTV)                                                                                             \
+    do {                                                                                                              \
+        static bool set_ = false;                                                                                     \
+        if (!set_) { (void)hipFuncSetAttribute((const void*)small_linear_kernel<MTV>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); set_ = true; } \
+        hipLaunchKernelGGL(small_linear_kernel<MTV>, dim3(grid), dim3(256), lds, s, (const bf16_t*)x, ldx, (const bf16_t*)W, ldw,  \
+                           (const bf16_t*)bias, (const bf16_t*)R, ldr, (bf16_t*)out, ldo, (int)M, N, (int)K, act_in); \
+    } while (0)
+    if (MT == 4) UG_SL_LAUNCH(4); else if (MT == 8) UG_SL_LAUNCH(8); else UG_SL_LAUNCH(16);
+#undef UG_SL_LAUNCH
+    UG_CHECK_LAUNCH("ug_small_linear_bf16");
+    return UG_OK;
+}
+
+extern "C" int ug_timestep_embed(const float* t, void* out, int64_t ldo, int64_t B, int32_t dim, ug_stream_t stream) {
+    if (B == 0) return UG_OK;
+    UG_REQUIRE(t && out && B > 0 && dim > 0 && dim % 2 == 0 && ldo >= dim, UG_ERR_BAD_SHAPE, "ug_timestep_embed: bad arguments");
+    const int total = (int)B * (dim / 2);
+    hipLaunchKernelGGL(timestep_embed_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, t, (bf16_t*)out, ldo, (int)B, dim);
+    UG_CHECK_LAUNCH("ug_timestep_embed");
+    return UG_OK;
+}
+
+extern "C" int ug_euler_step(void* x, const void* v, float dt, int64_t n, ug_stream_t stream) {
+    if (n == 0) return UG_OK;
+    UG_REQUIRE(x && v && n > 0 && n % 8 == 0 && ug_aligned(x, 16) && ug_aligned(v, 16), UG_ERR_BAD_ALIGN,
+               "ug_euler_step: n must be a multiple of 8 and pointers 16-byte aligned");
+    const int64_t nchunk = n / 8;
+    const unsigned grid = (unsigned)std::min<int64_t>((nchunk + 255) / 256, 2048);
+    hipLaunchKernelGGL(euler_step_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (bf16_t*)x, (const bf16_t*)v, dt, nchunk);
+    UG_CHECK_LAUNCH("ug_euler_step");
+    return UG_OK;
+}
+
+extern "C" int ug_add_bf16(const void* a, int64_t lda, const void* b, int64_t ldb, void* out, int64_t ldo, int64_t rows,
+                           int64_t D, ug_stream_t stream) {
+    if (rows == 0 || D == 0) return UG_OK;
+    UG_REQUIRE(a && b && out && rows > 0 && D > 0, UG_ERR_BAD_SHAPE, "ug_add_bf16: bad arguments");
+    UG_REQUIRE(D % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldo % 8 == 0 && ug_aligned(a, 16) && ug_aligned(b, 16) && ug_aligned(out, 16),
+               UG_ERR_BAD_ALIGN, "ug_add_bf16: 16-byte alignment required");
+    const int64_t total = rows * (D / 8);
+    const unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, 2048);
+    hipLaunchKernelGGL(add_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a, lda, (const bf16_t*)b, ldb,
+                       (bf16_t*)out, ldo, rows, (int)(D / 8));
+    UG_CHECK_LAUNCH("ug_add_bf16");
+    return UG_OK;
+}

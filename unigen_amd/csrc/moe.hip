@@ -1,0 +1,327 @@
+// CoMoE routing kernels: top-1 gate, capacity selection with Random Token Selection, index-based dispatch fused with
+// the expert-modulation prologue, and the probability-weighted combine fused with the CoMoE residual sums.
+//
+// The reference (src/UniGenUtils.py:74-191 on top of deepspeed 0.16.5 sharded_moe.top1gating) materialises S x E x C
+// one-hot tensors and dispatches/combines with dense einsums (:140, :183). Here routing is a per-token (expert, slot)
+// pair and a per-slot token index: dispatch is a row gather, combine a row scatter, zero FLOPs.
+#include "ug_common.h"
+
+namespace {
+
+__device__ __forceinline__ void unpack8(const u32x4 v, float* f) {
+    f[0] = bflo(v.x); f[1] = bfhi(v.x); f[2] = bflo(v.y); f[3] = bfhi(v.y);
+    f[4] = bflo(v.z); f[5] = bfhi(v.z); f[6] = bflo(v.w); f[7] = bfhi(v.w);
+}
+__device__ __forceinline__ u32x4 pack8(const float* f) {
+    u32x4 v;
+    v.x = pack2bf(f[0], f[1]); v.y = pack2bf(f[2], f[3]); v.z = pack2bf(f[4], f[5]); v.w = pack2bf(f[6], f[7]);
+    return v;
+}
+
+constexpr int GATE_MAXE = 16;
+
+// one wave per token: logits[e] = sum_d bf16(x+c)[d] * wg[e][d] in fp32 (TopKGate: F.linear(input.float(), wg.float()))
+__global__ __launch_bounds__(256) void moe_gate_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ c, int64_t ld,
+                                                       const bf16_t* __restrict__ wg, int64_t S, int D, int E,
+                                                       float* __restrict__ gates, int32_t* __restrict__ idx) {
+    const int lane = threadIdx.x & 63;
+    const int64_t s = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (s >= S) return;
+    float acc[GATE_MAXE];
+#pragma unroll
+    for (int e = 0; e < GATE_MAXE; ++e) acc[e] = 0.f;
+    const int nchunk = D >> 3;
+    for (int ch = lane; ch < nchunk; ch += 64) {
+        float a[8], b[8];
+        unpack8(*(const u32x4*)(x + s * ld + ch * 8), a);
+        unpack8(*(const u32x4*)(c + s * ld + ch * 8), b);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a[i] = rbf(a[i] + b[i]);     // choice_expert_input = hidden + condition (bf16 add)
+#pragma unroll
+        for (int e = 0; e < GATE_MAXE; ++e) {
+            if (e < E) {
+                float w[8];
+                unpack8(*(const u32x4*)(wg + (int64_t)e * D + ch * 8), w);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[e] += a[i] * w[i];
+            }
+        }
+    }
+    float mx = -INFINITY;
+    int best = 0;
+#pragma unroll
+    for (int e = 0; e < GATE_MAXE; ++e) {
+        if (e < E) {
+            acc[e] = wave_sum(acc[e]);
+            if (acc[e] > mx) { mx = acc[e]; best = e; }     // first maximum wins, as torch.argmax
+        }
+    }
+    float den = 0.f;
+#pragma unroll
+    for (int e = 0; e < GATE_MAXE; ++e)
+        if (e < E) { acc[e] = expf(acc[e] - mx); den += acc[e]; }
+    if (lane == 0) {
+        for (int e = 0; e < E; ++e) gates[s * E + e] = acc[e] / den;
+        idx[s] = best;
+    }
+}
+
+// block-wide exclusive scan of one flag per thread (1024 threads); returns exclusive prefix, *total = block total
+__device__ __forceinline__ int block_excl_scan(int flag, int* wsum /*[17]*/, int* total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long bal = __ballot(flag);
+    const int within = __popcll(bal & ((1ull << lane) - 1ull));
+    __syncthreads();                       // protect wsum reuse
+    if (lane == 0) wsum[wave] = __popcll(bal);
+    __syncthreads();
+    int base = 0, tot = 0;
+    for (int w = 0; w < 16; ++w) { const int v = wsum[w]; if (w < wave) base += v; tot += v; }
+    *total = tot;
+    return base + within;
+}
+
+// one block (1024 threads) per expert
+__global__ __launch_bounds__(1024) void moe_capacity_kernel(const int32_t* __restrict__ idx, const float* __restrict__ uniform,
+                                                            int S, int E, int capacity, int32_t* __restrict__ slot,
+                                                            int32_t* __restrict__ token_of_slot, int64_t* __restrict__ exp_counts) {
+    __shared__ int hist[256];
+    __shared__ int wsum[17];
+    __shared__ unsigned sh_prefix;
+    __shared__ int sh_k;
+    const int e = blockIdx.x;
+    const int tid = threadIdx.x;
+    // 1. count tokens routed to e
+    int cnt = 0;
+    for (int s = tid; s < S; s += 1024) cnt += (idx[s] == e);
+    {
+        const int lane = tid & 63, wave = tid >> 6;
+        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+        if (lane == 0) wsum[wave] = cnt;
+        __syncthreads();
+        cnt = 0;
+        for (int w = 0; w < 16; ++w) cnt += wsum[w];
+        __syncthreads();
+    }
+    const int n_e = cnt;
+    if (tid == 0) exp_counts[e] = (int64_t)n_e;
+    // 2. threshold = capacity-th largest uniform among this expert's tokens (radix select, MSB first)
+    unsigned T = 0; int k_eq = 0;
+    const bool drop = n_e > capacity;
+    if (drop) {
+        unsigned prefix = 0, mask = 0; int k = capacity;
+        for (int shift = 24; shift >= 0; shift -= 8) {
+            for (int i = tid; i < 256; i += 1024) hist[i] = 0;
+            __syncthreads();
+            for (int s = tid; s < S; s += 1024) {
+                if (idx[s] == e) {
+                    const unsigned key = __float_as_uint(uniform[(int64_t)s * E + e]);
+                    if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255], 1);
+                }
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int kk = k, d = 255;
+                for (; d > 0; --d) { if (hist[d] >= kk) break; kk -= hist[d]; }
+                sh_prefix = prefix | ((unsigned)d << shift);
+                sh_k = kk;
+            }
+            __syncthreads();
+            prefix = sh_prefix; k = sh_k; mask |= (255u << shift);
+            __syncthreads();
+        }
+        T = prefix; k_eq = k;   // keep every key > T and the first k_eq tokens with key == T
+    }
+    // 3. slots = rank among kept tokens in token order (cumsum(mask1) - 1 in top1gating)
+    int base_eq = 0, base_kept = 0;
+    for (int s0 = 0; s0 < S; s0 += 1024) {
+        const int s = s0 + tid;
+        const bool mine = s < S && idx[s] == e;
+        bool kept = mine;
+        if (drop) {
+            unsigned key = 0;
+            if (mine) key = __float_as_uint(uniform[(int64_t)s * E + e]);
+            const int feq = mine && key == T;
+            int tot_eq;
+            const int r_eq = block_excl_scan(feq, wsum, &tot_eq);
+            kept = mine && (key > T || (feq && base_eq + r_eq < k_eq));
+            base_eq += tot_eq;
+        }
+        int tot_k;
+        const int rk = block_excl_scan(kept ? 1 : 0, wsum, &tot_k);
+        if (mine) {
+            const int sl = kept ? base_kept + rk : -1;
+            slot[s] = sl;
+            if (kept) token_of_slot[(int64_t)e * capacity + sl] = s;
+        }
+        base_kept += tot_k;
+    }
+    for (int c = base_kept + tid; c < capacity; c += 1024) token_of_slot[(int64_t)e * capacity + c] = -1;
+}
+
+// l_aux = E * sum_e mean_s(gates[s][e]) * (exp_counts[e] / S); single block, fixed summation order
+__global__ __launch_bounds__(1024) void moe_laux_kernel(const float* __restrict__ gates, const int64_t* __restrict__ exp_counts,
+                                                        int S, int E, float* __restrict__ l_aux) {
+    __shared__ float part[16];
+    __shared__ float terms[GATE_MAXE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int e = 0; e < E; ++e) {
+        float a = 0.f;
+        for (int s = tid; s < S; s += 1024) a += gates[(int64_t)s * E + e];
+        a = wave_sum(a);
+        if (lane == 0) part[wave] = a;
+        __syncthreads();
+        if (tid == 0) {
+            float t = 0.f;
+            for (int w = 0; w < 16; ++w) t += part[w];
+            terms[e] = (t / (float)S) * ((float)exp_counts[e] / (float)S);
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        float t = 0.f;
+        for (int e = 0; e < E; ++e) t += terms[e];
+        *l_aux = t * (float)E;
+    }
+}
+
+// one wave per (expert, slot) row
+__global__ __launch_bounds__(256) void moe_dispatch_kernel(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ add,
+                                                           const bf16_t* __restrict__ mod, int B, const int32_t* __restrict__ token_of_slot,
+                                                           int64_t nslots, int capacity, int tokens_per_sample, int D,
+                                                           bf16_t* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t sl = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (sl >= nslots) return;
+    const int tok = token_of_slot[sl];
+    bf16_t* orow = out + sl * D;
+    const int nchunk = D >> 3;
+    if (tok < 0) {
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        for (int ch = lane; ch < nchunk; ch += 64) *(u32x4*)(orow + ch * 8) = z;
+        return;
+    }
+    const int e = (int)(sl / capacity);
+    const int b = tok / tokens_per_sample;
+    const bf16_t* xr = x + (int64_t)tok * ldx;
+    const bf16_t* mr = mod + ((int64_t)e * B + b) * D;
+    const bf16_t* ar = add ? add + sl * D : nullptr;
+    for (int ch = lane; ch < nchunk; ch += 64) {
+        float a[8], m[8];
+        unpack8(*(const u32x4*)(xr + ch * 8), a);
+        unpack8(*(const u32x4*)(mr + ch * 8), m);
+        if (ar) {
+            float t[8];
+            unpack8(*(const u32x4*)(ar + ch * 8), t);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a[i] = rbf(a[i] + t[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a[i] *= m[i];
+        *(u32x4*)(orow + ch * 8) = pack8(a);
+    }
+}
+
+// one wave per token
+__global__ __launch_bounds__(256) void moe_combine_kernel(const bf16_t* __restrict__ yh, const bf16_t* __restrict__ yc,
+                                                          const float* __restrict__ gates, const int32_t* __restrict__ idx,
+                                                          const int32_t* __restrict__ slot, int E, int capacity,
+                                                          const bf16_t* __restrict__ xs, const bf16_t* __restrict__ cs, int64_t ld_s,
+                                                          bf16_t* __restrict__ out, int64_t ldo, int64_t S, int D, int accumulate) {
+    const int lane = threadIdx.x & 63;
+    const int64_t s = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (s >= S) return;
+    const int e = idx[s];
+    const int sl = slot[s];
+    const float p = rbf(gates[s * E + e]);                 // combine_weights.type_as(input)
+    const int64_t yrow = ((int64_t)e * capacity + (sl < 0 ? 0 : sl)) * D;
+    const int nchunk = D >> 3;
+    for (int ch = lane; ch < nchunk; ch += 64) {
+        float h[8], c[8], o[8];
+        if (sl >= 0) {
+            unpack8(*(const u32x4*)(yh + yrow + ch * 8), h);
+            unpack8(*(const u32x4*)(yc + yrow + ch * 8), c);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { h[i] = rbf(p * h[i]); c[i] = rbf(p * c[i]); }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { h[i] = 0.f; c[i] = 0.f; }
+        }
+        if (xs) {
+            float a[8], b[8];
+            unpack8(*(const u32x4*)(xs + s * ld_s + ch * 8), a);
+            unpack8(*(const u32x4*)(cs + s * ld_s + ch * 8), b);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = rbf(a[i] + h[i]) + rbf(b[i] + c[i]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = h[i] + c[i];
+        }
+        if (accumulate) {
+            float prev[8];
+            unpack8(*(const u32x4*)(out + s * ldo + ch * 8), prev);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = prev[i] + rbf(o[i]);
+        }
+        *(u32x4*)(out + s * ldo + ch * 8) = pack8(o);
+    }
+}
+
+}  // namespace
+
+extern "C" int ug_moe_gate_top1(const void* x, const void* c, int64_t ld, const void* wg, int64_t S, int64_t D, int32_t E,
+                                float* gates, int32_t* idx, ug_stream_t stream) {
+    if (S == 0) return UG_OK;
+    UG_REQUIRE(x && c && wg && gates && idx && S > 0 && D > 0, UG_ERR_BAD_SHAPE, "ug_moe_gate_top1: bad arguments");
+    UG_REQUIRE(E >= 1 && E <= GATE_MAXE, UG_ERR_UNSUPPORTED, "ug_moe_gate_top1: E=%d not in [1,%d]", E, GATE_MAXE);
+    UG_REQUIRE(D % 8 == 0 && ld % 8 == 0 && ug_aligned(x, 16) && ug_aligned(c, 16) && ug_aligned(wg, 16), UG_ERR_BAD_ALIGN,
+               "ug_moe_gate_top1: 16-byte alignment required");
+    hipLaunchKernelGGL(moe_gate_kernel, dim3((unsigned)((S + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+                       (const bf16_t*)c, ld, (const bf16_t*)wg, S, (int)D, (int)E, gates, idx);
+    UG_CHECK_LAUNCH("ug_moe_gate_top1");
+    return UG_OK;
+}
+
+extern "C" int ug_moe_capacity_rts(const float* gates, const int32_t* idx, const float* uniform, int64_t S, int32_t E,
+                                   int64_t capacity, int32_t* slot, int32_t* token_of_slot, int64_t* exp_counts, float* l_aux,
+                                   ug_stream_t stream) {
+    UG_REQUIRE(gates && idx && uniform && slot && token_of_slot && exp_counts && l_aux, UG_ERR_BAD_SHAPE, "ug_moe_capacity_rts: null argument");
+    UG_REQUIRE(S > 0 && S < (1ll << 30) && E >= 1 && E <= GATE_MAXE && capacity > 0 && capacity < (1ll << 30), UG_ERR_BAD_SHAPE,
+               "ug_moe_capacity_rts: bad S/E/capacity");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(moe_capacity_kernel, dim3((unsigned)E), dim3(1024), 0, s, idx, uniform, (int)S, (int)E, (int)capacity, slot,
+                       token_of_slot, exp_counts);
+    UG_CHECK_LAUNCH("ug_moe_capacity_rts");
+    hipLaunchKernelGGL(moe_laux_kernel, dim3(1), dim3(1024), 0, s, gates, (const int64_t*)exp_counts, (int)S, (int)E, l_aux);
+    UG_CHECK_LAUNCH("ug_moe_capacity_rts(l_aux)");
+    return UG_OK;
+}
+
+extern "C" int ug_moe_dispatch_modulate(const void* x, int64_t ldx, const void* add, const void* mod, int64_t B,
+                                        const int32_t* token_of_slot, int32_t E, int64_t capacity, int64_t tokens_per_sample,
+                                        int64_t D, void* out, ug_stream_t stream) {
+    UG_REQUIRE(x && mod && token_of_slot && out && E > 0 && capacity > 0 && tokens_per_sample > 0 && B > 0, UG_ERR_BAD_SHAPE,
+               "ug_moe_dispatch_modulate: bad arguments");
+    UG_REQUIRE(D % 8 == 0 && ldx % 8 == 0 && ug_aligned(x, 16) && ug_aligned(mod, 16) && ug_aligned(out, 16) && (!add || ug_aligned(add, 16)),
+               UG_ERR_BAD_ALIGN, "ug_moe_dispatch_modulate: 16-byte alignment required");
+    const int64_t nslots = (int64_t)E * capacity;
+    hipLaunchKernelGGL(moe_dispatch_kernel, dim3((unsigned)((nslots + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx,
+                       (const bf16_t*)add, (const bf16_t*)mod, (int)B, token_of_slot, nslots, (int)capacity, (int)tokens_per_sample,
+                       (int)D, (bf16_t*)out);
+    UG_CHECK_LAUNCH("ug_moe_dispatch_modulate");
+    return UG_OK;
+}
+
+extern "C" int ug_moe_combine(const void* yh, const void* yc, const float* gates, const int32_t* idx, const int32_t* slot, int32_t E,
+                              int64_t capacity, const void* xs, const void* cs, int64_t ld_s, void* out, int64_t ldo, int64_t S,
+                              int64_t D, int32_t accumulate, ug_stream_t stream) {
+    if (S == 0) return UG_OK;
+    UG_REQUIRE(yh && yc && gates && idx && slot && out && E > 0 && capacity > 0, UG_ERR_BAD_SHAPE, "ug_moe_combine: bad arguments");
+    UG_REQUIRE((xs == nullptr) == (cs == nullptr), UG_ERR_BAD_SHAPE, "ug_moe_combine: xs and cs must both be given or both NULL");
+    UG_REQUIRE(D % 8 == 0 && ldo % 8 == 0 && (!xs || ld_s % 8 == 0) && ug_aligned(yh, 16) && ug_aligned(yc, 16) && ug_aligned(out, 16) &&
+               (!xs || (ug_aligned(xs, 16) && ug_aligned(cs, 16))), UG_ERR_BAD_ALIGN, "ug_moe_combine: 16-byte alignment required");
+    hipLaunchKernelGGL(moe_combine_kernel, dim3((unsigned)((S + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)yh,
+                       (const bf16_t*)yc, gates, idx, slot, (int)E, (int)capacity, (const bf16_t*)xs, (const bf16_t*)cs, ld_s,
+                       (bf16_t*)out, ldo, S, (int)D, (int)accumulate);
+    UG_CHECK_LAUNCH("ug_moe_combine");
+    return UG_OK;
+}

@@ -1,0 +1,87 @@
+"""ctypes binding of libunigen_hip.so — the C ABI declared in include/unigen_hip.h.
+
+The product path has no fallback: if the shared library is missing or does not load, importing the ops raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libunigen_hip.so")
+
+UG_OK, UG_ERR_BAD_SHAPE, UG_ERR_BAD_ALIGN, UG_ERR_UNSUPPORTED, UG_ERR_HIP = 0, -1, -2, -3, -4
+EPI_BIAS, EPI_BIAS_GELU, EPI_RES_GATE, EPI_RES_SCALE, EPI_F32 = 0, 1, 2, 3, 4
+
+i64, i32, f32, vp = C.c_int64, C.c_int32, C.c_float, C.c_void_p
+
+
+class GemmDesc(C.Structure):
+    """Mirror of struct ug_gemm_desc (include/unigen_hip.h)."""
+
+    _fields_ = [
+        ("A", vp), ("lda", i64), ("a_rpb", i64), ("a_bstride", i64),
+        ("W", vp), ("ldw", i64),
+        ("bias", vp),
+        ("C", vp), ("ldc", i64), ("c_rpb", i64), ("c_bstride", i64),
+        ("R", vp), ("ldr", i64), ("r_rpb", i64), ("r_bstride", i64),
+        ("gate", vp), ("gate_ld", i64), ("rows_per_sample", i64),
+        ("alpha", f32),
+        ("epilogue", i32),
+        ("M", i64), ("N", i64), ("K", i64),
+        ("groups", i32), ("_pad0", i32),
+        ("a_gstride", i64), ("w_gstride", i64), ("bias_gstride", i64), ("c_gstride", i64),
+        ("lora_T", vp), ("ldt", i64),
+        ("lora_B", vp), ("ldb", i64),
+        ("lora_r", i32), ("_pad1", i32),
+    ]
+
+
+# name -> (restype, argtypes); must list every symbol declared in include/unigen_hip.h
+SIGNATURES = {
+    "ug_version": (i32, []),
+    "ug_last_error": (C.c_char_p, []),
+    "ug_gemm_bf16": (i32, [C.POINTER(GemmDesc), vp]),
+    "ug_small_linear_bf16": (i32, [vp, i64, vp, i64, vp, vp, i64, vp, i64, i64, i64, i64, i32, vp]),
+    "ug_adaln_modulate": (i32, [vp, i64, i64, i64, vp, vp, i64, i64, vp, i64, i64, i64, f32, vp]),
+    "ug_qk_rmsnorm_rope": (i32, [vp, i64, i64, i64, i64, i64, i64, i64, i32, i32, vp, vp, vp, vp, i64, vp, vp, f32, vp]),
+    "ug_flash_attn_fwd": (i32, [vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, i64, i64, i64, i32, i64, i64, i32, f32, vp]),
+    "ug_timestep_embed": (i32, [vp, vp, i64, i64, i32, vp]),
+    "ug_euler_step": (i32, [vp, vp, f32, i64, vp]),
+    "ug_add_bf16": (i32, [vp, i64, vp, i64, vp, i64, i64, i64, vp]),
+    "ug_moe_gate_top1": (i32, [vp, vp, i64, vp, i64, i64, i32, vp, vp, vp]),
+    "ug_moe_capacity_rts": (i32, [vp, vp, vp, i64, i32, i64, vp, vp, vp, vp, vp]),
+    "ug_moe_dispatch_modulate": (i32, [vp, i64, vp, vp, i64, vp, i32, i64, i64, i64, vp, vp]),
+    "ug_moe_combine": (i32, [vp, vp, vp, vp, vp, i32, i64, vp, vp, i64, vp, i64, i64, i64, i32, vp]),
+}
+
+_lib = None
+
+
+class UniGenHipError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load the HIP library (once). Raises if it has not been built: there is no CPU fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise UniGenHipError(
+            f"{LIB_PATH} not found: build it with `python -m unigen_amd.build` (hipcc --offload-arch=gfx950). "
+            "unigen_amd has no CPU fallback for the hot path."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != UG_OK:
+        msg = load().ug_last_error()
+        raise UniGenHipError(f"{what} failed (code {rc}): {msg.decode() if msg else '?'}")

@@ -1,0 +1,188 @@
+"""Thin torch-tensor front end over the C ABI (unigen_amd/lib.py).
+
+torch is used only for device memory and the current HIP stream; every computation below runs in libunigen_hip.so.
+All tensors must be bf16 CUDA(HIP) tensors with a contiguous last dimension unless stated otherwise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import lib as L
+
+bf16 = torch.bfloat16
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _chk(t: torch.Tensor, name: str, dtype=bf16) -> None:
+    if not t.is_cuda:
+        raise L.UniGenHipError(f"{name}: expected a GPU tensor (unigen_amd has no CPU path)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if t.dim() > 0 and t.stride(-1) != 1:
+        raise ValueError(f"{name}: last dimension must be contiguous")
+
+
+class RowMap:
+    """Logical row m -> physical row (m // rows_per_batch) * batch_stride + m % rows_per_batch (0 = identity)."""
+
+    __slots__ = ("rpb", "bstride")
+
+    def __init__(self, rows_per_batch: int = 0, batch_stride: int = 0):
+        self.rpb, self.bstride = rows_per_batch, batch_stride
+
+
+IDENT = RowMap()
+
+
+def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, *, M: int,
+         epilogue: int = L.EPI_BIAS, lda: Optional[int] = None, ldc: Optional[int] = None, a_map: RowMap = IDENT,
+         c_map: RowMap = IDENT, residual: Optional[torch.Tensor] = None, ldr: Optional[int] = None,
+         r_map: RowMap = IDENT, gate: Optional[torch.Tensor] = None, gate_ld: int = 0, rows_per_sample: int = 0,
+         alpha: float = 1.0, groups: int = 1, a_gstride: int = 0, w_gstride: int = 0, bias_gstride: int = 0,
+         c_gstride: int = 0, lora_t: Optional[torch.Tensor] = None, lora_b: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[m, :N] = epilogue(a[m, :K] @ w[:N, :K]^T + bias). `a`/`out`/`residual` are base tensors whose data_ptr is row 0
+    (slices of a bigger buffer are fine); leading dims default to the tensors' row strides."""
+    _chk(a, "a"); _chk(w, "w")
+    _chk(out, "out", torch.float32 if epilogue == L.EPI_F32 else bf16)
+    N, K = (w.shape[-2], w.shape[-1])
+    d = L.GemmDesc()
+    d.A, d.lda, d.a_rpb, d.a_bstride = a.data_ptr(), (lda if lda is not None else a.stride(-2)), a_map.rpb, a_map.bstride
+    d.W, d.ldw = w.data_ptr(), w.stride(-2)
+    d.bias = _p(bias)
+    d.C, d.ldc, d.c_rpb, d.c_bstride = out.data_ptr(), (ldc if ldc is not None else out.stride(-2)), c_map.rpb, c_map.bstride
+    if residual is not None:
+        _chk(residual, "residual")
+        d.R, d.ldr, d.r_rpb, d.r_bstride = residual.data_ptr(), (ldr if ldr is not None else residual.stride(-2)), r_map.rpb, r_map.bstride
+    if gate is not None:
+        _chk(gate, "gate")
+        d.gate, d.gate_ld, d.rows_per_sample = gate.data_ptr(), gate_ld, rows_per_sample
+    d.alpha, d.epilogue = alpha, epilogue
+    d.M, d.N, d.K = M, N, K
+    d.groups, d.a_gstride, d.w_gstride, d.bias_gstride, d.c_gstride = groups, a_gstride, w_gstride, bias_gstride, c_gstride
+    if lora_t is not None:
+        _chk(lora_t, "lora_t"); _chk(lora_b, "lora_b")
+        d.lora_T, d.ldt, d.lora_B, d.ldb, d.lora_r = lora_t.data_ptr(), lora_t.stride(-2), lora_b.data_ptr(), lora_b.stride(-2), lora_b.shape[-1]
+    L.check(L.load().ug_gemm_bf16(C.byref(d), _stream()), "ug_gemm_bf16")
+    return out
+
+
+def small_linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, *, silu_in: bool = False,
+                 residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[m] = residual[m] + bf16(act(x[m]) @ w^T + bias), M = x.shape[0] <= 16."""
+    _chk(x, "x"); _chk(w, "w"); _chk(out, "out")
+    M, K = x.shape
+    N = w.shape[0]
+    L.check(L.load().ug_small_linear_bf16(x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), _p(bias), _p(residual),
+                                          residual.stride(0) if residual is not None else 0, out.data_ptr(), out.stride(0),
+                                          M, N, K, 1 if silu_in else 0, _stream()), "ug_small_linear_bf16")
+    return out
+
+
+def adaln_modulate(x: torch.Tensor, shift: torch.Tensor, scale: torch.Tensor, out: torch.Tensor, *, rows: int, D: int,
+                   rows_per_sample: int, mod_ld: int, ldx: Optional[int] = None, x_map: RowMap = IDENT, eps: float = 1e-6) -> torch.Tensor:
+    _chk(x, "x"); _chk(shift, "shift"); _chk(scale, "scale"); _chk(out, "out")
+    L.check(L.load().ug_adaln_modulate(x.data_ptr(), ldx if ldx is not None else x.stride(-2), x_map.rpb, x_map.bstride,
+                                       shift.data_ptr(), scale.data_ptr(), mod_ld, rows_per_sample, out.data_ptr(),
+                                       out.stride(-2), rows, D, eps, _stream()), "ug_adaln_modulate")
+    return out
+
+
+def qk_rmsnorm_rope(buf: torch.Tensor, *, batches: int, rows_per_batch: int, ld: int, q_off: int, k_off: int, heads: int, dh: int,
+                    batch_stride_rows: Optional[int] = None, pos_offset: int = 0, wq_a=None, wk_a=None, wq_b=None, wk_b=None,
+                    split: int = 0, cos: Optional[torch.Tensor] = None, sin: Optional[torch.Tensor] = None, eps: float = 1e-6) -> torch.Tensor:
+    """buf.data_ptr() is row 0 of batch 0 of the processed row range."""
+    _chk(buf, "buf")
+    if batch_stride_rows is None:
+        batch_stride_rows = rows_per_batch
+    if cos is not None:
+        _chk(cos, "cos", torch.float32); _chk(sin, "sin", torch.float32)
+        assert cos.shape[0] >= pos_offset + rows_per_batch and cos.shape[1] == dh and cos.is_contiguous() and sin.is_contiguous(), \
+            (cos.shape, pos_offset, rows_per_batch, dh)
+    L.check(L.load().ug_qk_rmsnorm_rope(buf.data_ptr(), ld, batches, rows_per_batch, batch_stride_rows, pos_offset, q_off, k_off, heads, dh,
+                                        _p(wq_a), _p(wk_a), _p(wq_b), _p(wk_b), split, _p(cos), _p(sin), eps, _stream()), "ug_qk_rmsnorm_rope")
+    return buf
+
+
+def flash_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, *, batches: int, heads: int, dh: int,
+               Lq: int, Lkv: int, q_strides, k_strides, v_strides, o_strides, scale: Optional[float] = None) -> torch.Tensor:
+    """q/k/v/out are base tensors (data_ptr = element [batch 0, row 0, head 0, 0]); *_strides = (row_stride, batch_stride)."""
+    _chk(q, "q"); _chk(k, "k"); _chk(v, "v"); _chk(out, "out")
+    if scale is None:
+        scale = dh ** -0.5
+    L.check(L.load().ug_flash_attn_fwd(q.data_ptr(), q_strides[0], q_strides[1], k.data_ptr(), k_strides[0], k_strides[1],
+                                       v.data_ptr(), v_strides[0], v_strides[1], out.data_ptr(), o_strides[0], o_strides[1],
+                                       batches, heads, Lq, Lkv, dh, scale, _stream()), "ug_flash_attn_fwd")
+    return out
+
+
+def timestep_embed(t: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    _chk(t, "t", torch.float32); _chk(out, "out")
+    L.check(L.load().ug_timestep_embed(t.data_ptr(), out.data_ptr(), out.stride(0), t.shape[0], out.shape[1], _stream()), "ug_timestep_embed")
+    return out
+
+
+def euler_step(x: torch.Tensor, v: torch.Tensor, dt: float) -> torch.Tensor:
+    _chk(x, "x"); _chk(v, "v")
+    assert x.is_contiguous() and v.is_contiguous() and x.numel() == v.numel()
+    L.check(L.load().ug_euler_step(x.data_ptr(), v.data_ptr(), dt, x.numel(), _stream()), "ug_euler_step")
+    return x
+
+
+def add(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    _chk(a, "a"); _chk(b, "b"); _chk(out, "out")
+    D = a.shape[-1]
+    rows = a.numel() // D
+    a2, b2, o2 = a.reshape(rows, D), b.reshape(rows, D), out.view(rows, D)
+    L.check(L.load().ug_add_bf16(a2.data_ptr(), a2.stride(0), b2.data_ptr(), b2.stride(0), o2.data_ptr(), o2.stride(0), rows, D, _stream()), "ug_add_bf16")
+    return out
+
+
+def moe_gate_top1(x: torch.Tensor, c: torch.Tensor, wg: torch.Tensor, gates: torch.Tensor, idx: torch.Tensor) -> None:
+    _chk(x, "x"); _chk(c, "c"); _chk(wg, "wg"); _chk(gates, "gates", torch.float32); _chk(idx, "idx", torch.int32)
+    S, D = x.shape
+    E = wg.shape[0]
+    assert x.stride(0) == c.stride(0) and wg.is_contiguous() and gates.is_contiguous()
+    L.check(L.load().ug_moe_gate_top1(x.data_ptr(), c.data_ptr(), x.stride(0), wg.data_ptr(), S, D, E, gates.data_ptr(), idx.data_ptr(), _stream()),
+            "ug_moe_gate_top1")
+
+
+def moe_capacity_rts(gates, idx, uniform, capacity: int, slot, token_of_slot, exp_counts, l_aux) -> None:
+    _chk(gates, "gates", torch.float32); _chk(idx, "idx", torch.int32); _chk(uniform, "uniform", torch.float32)
+    _chk(slot, "slot", torch.int32); _chk(token_of_slot, "token_of_slot", torch.int32)
+    _chk(exp_counts, "exp_counts", torch.int64); _chk(l_aux, "l_aux", torch.float32)
+    S, E = gates.shape
+    assert uniform.shape == (S, E) and uniform.is_contiguous() and token_of_slot.numel() == E * capacity
+    L.check(L.load().ug_moe_capacity_rts(gates.data_ptr(), idx.data_ptr(), uniform.data_ptr(), S, E, capacity, slot.data_ptr(),
+                                         token_of_slot.data_ptr(), exp_counts.data_ptr(), l_aux.data_ptr(), _stream()), "ug_moe_capacity_rts")
+
+
+def moe_dispatch_modulate(x, add_, mod, token_of_slot, out, *, B: int, E: int, capacity: int, tokens_per_sample: int) -> torch.Tensor:
+    _chk(x, "x"); _chk(mod, "mod"); _chk(out, "out"); _chk(token_of_slot, "token_of_slot", torch.int32)
+    D = x.shape[-1]
+    assert mod.is_contiguous() and out.is_contiguous() and mod.numel() == E * B * D and out.numel() == E * capacity * D
+    if add_ is not None:
+        _chk(add_, "add"); assert add_.is_contiguous()
+    L.check(L.load().ug_moe_dispatch_modulate(x.data_ptr(), x.stride(-2), _p(add_), mod.data_ptr(), B, token_of_slot.data_ptr(), E, capacity,
+                                              tokens_per_sample, D, out.data_ptr(), _stream()), "ug_moe_dispatch_modulate")
+    return out
+
+
+def moe_combine(yh, yc, gates, idx, slot, out, *, E: int, capacity: int, xs=None, cs=None, accumulate: bool = False) -> torch.Tensor:
+    _chk(yh, "yh"); _chk(yc, "yc"); _chk(out, "out")
+    S, D = out.shape[-2], out.shape[-1]
+    if xs is not None:
+        _chk(xs, "xs"); _chk(cs, "cs"); assert xs.stride(-2) == cs.stride(-2)
+    L.check(L.load().ug_moe_combine(yh.data_ptr(), yc.data_ptr(), gates.data_ptr(), idx.data_ptr(), slot.data_ptr(), E, capacity, _p(xs), _p(cs),
+                                    xs.stride(-2) if xs is not None else 0, out.data_ptr(), out.stride(-2), S, D, 1 if accumulate else 0, _stream()),
+            "ug_moe_combine")
+    return out
