@@ -1,0 +1,687 @@
+"""Host side of the UniGenFlux / MultiCondtionUniGenFlux forward on MI355X.
+
+Mirrors the reference's call surface (src/UniGenTransformer.py:712-1450 of gavin-gqzhang/UniGen): same class names, constructor
+flow (`from_pretrained` / `from_config` -> `.to()` -> `init_condition_block(condition_nums, condition_types, control_params)`),
+forward kwargs, 3-tuple return and state-dict key names. The arithmetic is NOT torch: every projection, norm, attention and
+routing step is a call through the C ABI of libunigen_hip.so (unigen_amd/ops.py). torch supplies device memory, the
+parameter containers (so `state_dict` / `load_state_dict` / `.to` behave as callers expect) and the stream.
+
+What the reference leaves undefined (FluxJointRoPETransformerBlock / FluxSingleRoPETransformerBlock) is defined here
+as: parameters and math of the diffusers Flux double / single block, RoPE tables from FluxPosEmbed rounded to the ids dtype as
+JointAttnRopeProcessor does (src/UniGenUtils.py:597). Work whose result every caller discards (text-stream output of control
+joint blocks and of shared_expert[1]) is skipped, and a control block's text K/V are computed once per step, not once per use.
+"""
+from __future__ import annotations
+
+import json
+import math
+import os
+from types import SimpleNamespace
+from typing import Any, Dict, List, Optional, Sequence, Tuple
+
+import torch
+from torch import nn
+
+from . import lib as L
+from . import ops
+from .ops import RowMap
+
+BF = torch.bfloat16
+
+FLUX_SCHNELL_CONFIG = dict(patch_size=1, in_channels=64, num_layers=19, num_single_layers=38, attention_head_dim=128,
+                           num_attention_heads=24, joint_attention_dim=4096, pooled_projection_dim=768, guidance_embeds=False,
+                           axes_dims_rope=(16, 56, 56))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# parameter shapes under the reference's state-dict key names
+# ----------------------------------------------------------------------------------------------------------------------
+
+def _lin(s: dict, name: str, out_f: int, in_f: int) -> None:
+    s[name + ".weight"] = (out_f, in_f)
+    s[name + ".bias"] = (out_f,)
+
+
+def _double_block_shapes(s: dict, p: str, D: int, dh: int) -> None:
+    for n in ("norm1", "norm1_context"):
+        _lin(s, f"{p}.{n}.linear", 6 * D, D)
+    for n in ("to_q", "to_k", "to_v", "add_q_proj", "add_k_proj", "add_v_proj", "to_out.0", "to_add_out"):
+        _lin(s, f"{p}.attn.{n}", D, D)
+    for n in ("norm_q", "norm_k", "norm_added_q", "norm_added_k"):
+        s[f"{p}.attn.{n}.weight"] = (dh,)
+    for n in ("ff", "ff_context"):
+        _lin(s, f"{p}.{n}.net.0.proj", 4 * D, D)
+        _lin(s, f"{p}.{n}.net.2", D, 4 * D)
+
+
+def _single_block_shapes(s: dict, p: str, D: int, dh: int) -> None:
+    _lin(s, f"{p}.norm.linear", 3 * D, D)
+    _lin(s, f"{p}.proj_mlp", 4 * D, D)
+    _lin(s, f"{p}.proj_out", D, 5 * D)
+    for n in ("to_q", "to_k", "to_v"):
+        _lin(s, f"{p}.attn.{n}", D, D)
+    for n in ("norm_q", "norm_k"):
+        s[f"{p}.attn.{n}.weight"] = (dh,)
+
+
+def _time_text_embed_shapes(s: dict, p: str, D: int, pooled: int, guidance: bool) -> None:
+    _lin(s, f"{p}.timestep_embedder.linear_1", D, 256)
+    _lin(s, f"{p}.timestep_embedder.linear_2", D, D)
+    if guidance:
+        _lin(s, f"{p}.guidance_embedder.linear_1", D, 256)
+        _lin(s, f"{p}.guidance_embedder.linear_2", D, D)
+    _lin(s, f"{p}.text_embedder.linear_1", D, pooled)
+    _lin(s, f"{p}.text_embedder.linear_2", D, D)
+
+
+def base_param_shapes(cfg) -> Dict[str, Tuple[int, ...]]:
+    """diffusers FluxTransformer2DModel parameters."""
+    D, dh = cfg.num_attention_heads * cfg.attention_head_dim, cfg.attention_head_dim
+    s: Dict[str, Tuple[int, ...]] = {}
+    _lin(s, "x_embedder", D, cfg.in_channels)
+    _lin(s, "context_embedder", D, cfg.joint_attention_dim)
+    _time_text_embed_shapes(s, "time_text_embed", D, cfg.pooled_projection_dim, cfg.guidance_embeds)
+    for i in range(cfg.num_layers):
+        _double_block_shapes(s, f"transformer_blocks.{i}", D, dh)
+    for j in range(cfg.num_single_layers):
+        _single_block_shapes(s, f"single_transformer_blocks.{j}", D, dh)
+    _lin(s, "norm_out.linear", 2 * D, D)
+    _lin(s, "proj_out", cfg.in_channels, D)
+    return s
+
+
+def control_param_shapes(cfg, ctl) -> Dict[str, Tuple[int, ...]]:
+    """Modules created by init_control_block / init_moe_block (src/UniGenTransformer.py:717-923)."""
+    D, dh = cfg.num_attention_heads * cfg.attention_head_dim, cfg.attention_head_dim
+    s: Dict[str, Tuple[int, ...]] = {}
+    _time_text_embed_shapes(s, "control_time_text_embed", D, cfg.pooled_projection_dim, cfg.guidance_embeds)
+    _time_text_embed_shapes(s, "control_condition_embed", D, cfg.pooled_projection_dim, cfg.guidance_embeds)
+    _lin(s, "control_context_embedder", D, D)
+    _lin(s, "control_x_embedder", D, cfg.in_channels)
+    for m in range(ctl.cn_joint_layers):
+        _double_block_shapes(s, f"control_joint_trans_blocks.{m}", D, dh)
+        _lin(s, f"controlnet_add_joint_blocks.{m}", D, D)
+    if ctl.use_single_trans_blocks:
+        for m in range(ctl.cn_single_layers):
+            _single_block_shapes(s, f"control_single_trans_blocks.{m}", D, dh)
+            _lin(s, f"controlnet_add_single_blocks.{m}", D, D)
+    s["moe.moe_layer.gate.wg.weight"] = (ctl.expert_nums, D)
+    for e in range(ctl.expert_nums):
+        p = f"moe.moe_layer.experts.deepspeed_experts.{e}"
+        for k in (0, 1):        # [0] = condition-modulate, [1] = hidden-modulate (:833-842, 956)
+            _lin(s, f"{p}.{k}.0", D, D)
+            _lin(s, f"{p}.{k}.1", D, cfg.pooled_projection_dim)
+    if ctl.use_shared_expert:
+        for k in (0, 1):
+            _double_block_shapes(s, f"shared_expert.{k}", D, dh)
+    return s
+
+
+class _Holder(nn.Module):
+    """Parameter container; the arithmetic lives in libunigen_hip.so, so calling it is an error."""
+
+    def forward(self, *a, **k):  # pragma: no cover
+        raise L.UniGenHipError("parameter holder: unigen_amd modules are executed by the HIP engine, not called directly")
+
+
+def _register(root: nn.Module, name: str, shape: Tuple[int, ...], device, dtype) -> nn.Parameter:
+    parts = name.split(".")
+    mod = root
+    for part in parts[:-1]:
+        child = mod._modules.get(part)
+        if child is None:
+            child = _Holder()
+            mod.add_module(part, child)
+        mod = child
+    p = nn.Parameter(torch.empty(shape, device=device, dtype=dtype), requires_grad=False)
+    mod.register_parameter(parts[-1], p)
+    return p
+
+
+class _Workspace:
+    def __init__(self):
+        self._bufs: Dict[Tuple, torch.Tensor] = {}
+
+    def get(self, name: str, shape: Sequence[int], dtype, device) -> torch.Tensor:
+        key = (name, tuple(shape), dtype, str(device))
+        t = self._bufs.get(key)
+        if t is None:
+            t = torch.empty(tuple(shape), dtype=dtype, device=device)
+            self._bufs[key] = t
+        return t
+
+    def clear(self):
+        self._bufs.clear()
+
+
+class _Stream:
+    """A token stream [B, Ls, D] living in some buffer: `base` is a 2-D view whose row 0 is token (0, 0); logical row
+    m = b * Ls + r sits at physical row b * bstride + r (RowMap), leading dimension `ld`."""
+    __slots__ = ("base", "ld", "map", "Ls")
+
+    def __init__(self, base: torch.Tensor, Ls: int, bstride: Optional[int] = None):
+        self.base, self.ld, self.Ls = base, base.stride(0), Ls
+        self.map = RowMap() if (bstride is None or bstride == Ls) else RowMap(Ls, bstride)
+
+
+class UniGenFlux(nn.Module):
+    """Drop-in for the reference `UniGenFlux(FluxTransformer2DModel)`."""
+
+    multi_condition = False
+
+    # ------------------------------------------------------------------ construction ---------------------------------
+    def __init__(self, config: Optional[dict] = None, device=None, dtype=BF, **kwargs):
+        super().__init__()
+        c = dict(FLUX_SCHNELL_CONFIG)
+        c.update(config or {})
+        c.update(kwargs)
+        c["axes_dims_rope"] = tuple(c["axes_dims_rope"])
+        self.config = SimpleNamespace(**c)
+        self.inner_dim = self.config.num_attention_heads * self.config.attention_head_dim
+        self.out_channels = self.config.in_channels
+        if sum(self.config.axes_dims_rope) != self.config.attention_head_dim:
+            raise ValueError("axes_dims_rope must sum to attention_head_dim")
+        self._ws = _Workspace()
+        self._packed: Dict[str, torch.Tensor] = {}
+        self._ctl = None
+        self._rope_cache: Dict[Tuple, Tuple[torch.Tensor, torch.Tensor]] = {}
+        self.trainable_control_modules: Dict[str, nn.Module] = {}
+        for name, shape in base_param_shapes(self.config).items():
+            _register(self, name, shape, device, dtype)
+
+    @classmethod
+    def from_config(cls, config: dict, **kw) -> "UniGenFlux":
+        return cls(config, **kw)
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, subfolder: Optional[str] = None, revision=None, variant=None,
+                        torch_dtype=BF, device=None, **kw) -> "UniGenFlux":
+        """Local directory only (no hub access): config.json + diffusion_pytorch_model*.safetensors (infer.py:115-119)."""
+        path = os.fspath(pretrained_model_name_or_path)
+        if subfolder:
+            path = os.path.join(path, subfolder)
+        if not os.path.isdir(path):
+            raise OSError(f"{path} is not a local directory (unigen_amd loads checkpoints from disk only)")
+        with open(os.path.join(path, "config.json")) as f:
+            raw = json.load(f)
+        cfg = {k: raw[k] for k in FLUX_SCHNELL_CONFIG if k in raw}
+        model = cls(cfg, device=device, dtype=torch_dtype)
+        from safetensors.torch import load_file
+        files = sorted(f for f in os.listdir(path) if f.endswith(".safetensors"))
+        if not files:
+            raise OSError(f"no *.safetensors weights under {path}")
+        sd = {}
+        for fn in files:
+            sd.update(load_file(os.path.join(path, fn)))
+        res = model.load_state_dict(sd, strict=False)
+        if res.missing_keys:
+            raise RuntimeError(f"checkpoint misses base parameters: {res.missing_keys[:8]} ...")
+        return model
+
+    @property
+    def dtype(self):
+        return self.x_embedder.weight.dtype
+
+    @property
+    def device(self):
+        return self.x_embedder.weight.device
+
+    def init_condition_block(self, condition_nums: int = 1, condition_types: Optional[List[str]] = None, **kwargs):
+        """src/UniGenTransformer.py:713-715 -> init_control_block(control_params) -> init_moe_block."""
+        self.condition_nums = condition_nums
+        self.condition_types = condition_types
+        control_params = kwargs.get("control_params", None)
+        assert control_params is not None, ValueError("Please provice control net model parameter")
+        get = control_params.get
+        use_rope, use_modulate = bool(get("use_rope", False)), bool(get("use_modulate", False))
+        if not (use_rope or use_modulate):
+            # the shipped yaml yields stock single blocks fed per-token temb, which cannot run.
+            raise ValueError("UniGenFlux needs control_params.use_rope or control_params.use_modulate (modulated experts); "
+                             "the transformer-block expert variant of config/unigen.yaml is not executable in the reference either")
+        if get("use_consis_module", False):
+            raise ValueError("use_consis_module is not supported (off in every shipped configuration)")
+        if get("cn2base_method", "add") != "add":
+            raise ValueError("only cn2base_method='add' is supported (the CrossAttn variant is dead code in the reference)")
+        dev = int(get("single_control_dev", 2))
+        expert_num = get("expert_num", None)
+        ctl = SimpleNamespace(
+            use_rope=use_rope, use_modulate=use_modulate,
+            use_pooled_prompt_embeds=bool(get("use_pooled_prompt_embeds", True)),
+            use_encoder_hidden_states=bool(get("use_encoder_hidden_states", True)),
+            use_shared_expert=bool(get("use_shared_expert", False)),
+            use_single_trans_blocks=bool(get("use_single_trans_blocks", True)),
+            single_block_control_method=get("single_block_control_method", "overall_add"),
+            cn_joint_layers=self.config.num_layers // dev, cn_single_layers=self.config.num_single_layers // dev,
+            expert_nums=int(expert_num) if expert_num is not None else (condition_nums + 1) * int(get("expert_num_each_condition", 3)),
+            top_k=int(get("top_num", 1)),
+        )
+        if ctl.top_k != 1:
+            raise ValueError("only top-1 gating is implemented (top_num=1 in every shipped configuration)")
+        if ctl.expert_nums > 16:
+            raise ValueError("at most 16 experts are supported")
+        self._ctl = ctl
+        dev_, dt_ = self.device, self.dtype
+        for name, shape in control_param_shapes(self.config, ctl).items():
+            p = _register(self, name, shape, dev_, dt_)
+            with torch.no_grad():
+                p.zero_()
+        names = ["control_time_text_embed", "control_condition_embed", "control_context_embedder", "control_x_embedder",
+                 "control_joint_trans_blocks", "controlnet_add_joint_blocks", "moe"]
+        if ctl.use_single_trans_blocks:
+            names += ["control_single_trans_blocks", "controlnet_add_single_blocks"]
+        if ctl.use_shared_expert:
+            names.append("shared_expert")
+        self.trainable_control_modules = {n: getattr(self, n) for n in names}
+        if get("use_transformer_params", False):
+            self.init_control_param()
+        self._packed.clear()
+
+    def init_control_param(self):
+        """src/UniGenTransformer.py:789-804: start the control blocks from the base weights."""
+        sd = self.state_dict()
+        with torch.no_grad():
+            for k, v in sd.items():
+                for src, dst in (("time_text_embed.", "control_time_text_embed."), ("time_text_embed.", "control_condition_embed.")):
+                    if k.startswith(src):
+                        sd[dst + k[len(src):]].copy_(v)
+                if k.startswith("transformer_blocks."):
+                    i = int(k.split(".")[1])
+                    if i < self._ctl.cn_joint_layers:
+                        sd["control_joint_trans_blocks." + k[len("transformer_blocks."):]].copy_(v)
+                if k.startswith("single_transformer_blocks.") and self._ctl.use_single_trans_blocks:
+                    j = int(k.split(".")[1])
+                    if j < self._ctl.cn_single_layers:
+                        sd["control_single_trans_blocks." + k[len("single_transformer_blocks."):]].copy_(v)
+
+    def init_trainable_param(self):
+        for module in self.trainable_control_modules.values():
+            module.requires_grad_(True)
+
+    def enable_gradient_checkpointing(self):
+        pass  # forward-only engine
+
+    def init_synthetic_(self, seed: int = 0, std: float = 0.02, bias_std: float = 0.0) -> "UniGenFlux":
+        """Seeded N(0, std^2) weights, zero (or N(0, bias_std^2)) biases, unit RMSNorm weights; the zero-res projections are
+        randomised too so the control path contributes. Generated on the parameters' device."""
+        g = torch.Generator(device=self.device).manual_seed(seed)
+        with torch.no_grad():
+            for name, p in self.named_parameters():
+                if ".norm_q." in name or ".norm_k." in name or ".norm_added_q." in name or ".norm_added_k." in name:
+                    p.fill_(1.0)
+                elif name.endswith(".bias"):
+                    if bias_std > 0:
+                        p.copy_(torch.randn(p.shape, generator=g, device=p.device, dtype=torch.float32) * bias_std)
+                    else:
+                        p.zero_()
+                else:
+                    # chunked to bound the fp32 temporary for the 12288 x 3072 matrices
+                    p.copy_(torch.randn(p.shape, generator=g, device=p.device, dtype=torch.float32) * std)
+        return self
+
+    # ------------------------------------------------------------------ weight packing --------------------------------
+    def _P(self, name: str) -> torch.Tensor:
+        return self.get_parameter(name).data
+
+    def _pack(self, key: str, names: Sequence[str]) -> torch.Tensor:
+        """Concatenate parameters along dim 0 into one buffer and re-point them at views of it (no duplicate storage)."""
+        params = [self.get_parameter(n) for n in names]
+        t = self._packed.get(key)
+        if t is not None and params[0].data.data_ptr() == t.data_ptr() and params[0].device == t.device:
+            return t
+        t = torch.cat([p.data for p in params], dim=0).contiguous()
+        off = 0
+        for p in params:
+            n = p.data.shape[0]
+            p.data = t[off:off + n]
+            off += n
+        self._packed[key] = t
+        return t
+
+    def _pack_stack(self, key: str, names: Sequence[str]) -> torch.Tensor:
+        params = [self.get_parameter(n) for n in names]
+        t = self._packed.get(key)
+        if t is not None and params[0].data.data_ptr() == t.data_ptr() and params[0].device == t.device:
+            return t
+        t = torch.stack([p.data for p in params], dim=0).contiguous()
+        for i, p in enumerate(params):
+            p.data = t[i]
+        self._packed[key] = t
+        return t
+
+    def _attn_qkv(self, p: str) -> Tuple[torch.Tensor, torch.Tensor]:
+        return (self._pack(p + ".qkv.w", [f"{p}.to_q.weight", f"{p}.to_k.weight", f"{p}.to_v.weight"]),
+                self._pack(p + ".qkv.b", [f"{p}.to_q.bias", f"{p}.to_k.bias", f"{p}.to_v.bias"]))
+
+    def _attn_add_qkv(self, p: str) -> Tuple[torch.Tensor, torch.Tensor]:
+        return (self._pack(p + ".aqkv.w", [f"{p}.add_q_proj.weight", f"{p}.add_k_proj.weight", f"{p}.add_v_proj.weight"]),
+                self._pack(p + ".aqkv.b", [f"{p}.add_q_proj.bias", f"{p}.add_k_proj.bias", f"{p}.add_v_proj.bias"]))
+
+    # ------------------------------------------------------------------ small pieces ----------------------------------
+    def _w(self, name, shape, dtype=BF):
+        return self._ws.get(name, shape, dtype, self.device)
+
+    def _rope(self, ids_list: Sequence[torch.Tensor], round_to: Optional[torch.dtype]) -> Tuple[torch.Tensor, torch.Tensor]:
+        """FluxPosEmbed(theta=10000, axes_dims_rope) on cat(ids): fp32 cos/sin [S, dh]; `round_to` applies the control path's
+        cast to the ids dtype (src/UniGenUtils.py:597). Tables are tiny and cached per ids identity."""
+        key = tuple((t.data_ptr(), tuple(t.shape), t.dtype) for t in ids_list) + (round_to,)
+        hit = self._rope_cache.get(key)
+        if hit is not None:
+            return hit
+        ids = torch.cat([t.to(self.device) for t in ids_list], dim=0).float()
+        cos_out, sin_out = [], []
+        for i, d in enumerate(self.config.axes_dims_rope):
+            freqs = 1.0 / (10000.0 ** (torch.arange(0, d, 2, dtype=torch.float64, device=self.device) / d))
+            ang = torch.outer(ids[:, i].to(torch.float64), freqs)
+            cos_out.append(ang.cos().repeat_interleave(2, dim=1).float())
+            sin_out.append(ang.sin().repeat_interleave(2, dim=1).float())
+        cos, sin = torch.cat(cos_out, -1), torch.cat(sin_out, -1)
+        if round_to is not None and round_to != torch.float32:
+            cos, sin = cos.to(round_to).float(), sin.to(round_to).float()
+        out = (cos.contiguous(), sin.contiguous())
+        if len(self._rope_cache) > 64:
+            self._rope_cache.clear()
+        self._rope_cache[key] = out
+        return out
+
+    def _time_text_embed(self, prefix: str, t_f32: torch.Tensor, pooled: torch.Tensor, g_f32: Optional[torch.Tensor], tag: str) -> torch.Tensor:
+        """CombinedTimestep(Guidance)TextProjEmbeddings (diffusers embeddings.py)."""
+        B, D = pooled.shape[0], self.inner_dim
+        tp = ops.timestep_embed(t_f32, self._w("tp", (B, 256)))
+        h1 = ops.small_linear(tp, self._P(prefix + ".timestep_embedder.linear_1.weight"), self._P(prefix + ".timestep_embedder.linear_1.bias"), self._w("tte_h", (B, D)))
+        emb = ops.small_linear(h1, self._P(prefix + ".timestep_embedder.linear_2.weight"), self._P(prefix + ".timestep_embedder.linear_2.bias"),
+                               self._w("tte_t" + tag, (B, D)), silu_in=True)
+        if g_f32 is not None:
+            gp = ops.timestep_embed(g_f32, self._w("gp", (B, 256)))
+            h1 = ops.small_linear(gp, self._P(prefix + ".guidance_embedder.linear_1.weight"), self._P(prefix + ".guidance_embedder.linear_1.bias"), self._w("tte_h", (B, D)))
+            emb = ops.small_linear(h1, self._P(prefix + ".guidance_embedder.linear_2.weight"), self._P(prefix + ".guidance_embedder.linear_2.bias"),
+                                   self._w("tte_g" + tag, (B, D)), silu_in=True, residual=emb)
+        h2 = ops.small_linear(pooled, self._P(prefix + ".text_embedder.linear_1.weight"), self._P(prefix + ".text_embedder.linear_1.bias"), self._w("tte_h2", (B, D)))
+        return ops.small_linear(h2, self._P(prefix + ".text_embedder.linear_2.weight"), self._P(prefix + ".text_embedder.linear_2.bias"),
+                                self._w("temb_" + tag, (B, D)), silu_in=True, residual=emb)
+
+    def _adaln_emb(self, prefix: str, temb: torch.Tensor, nchunks: int, tag: str) -> torch.Tensor:
+        """AdaLayerNormZero*.linear(silu(emb)) -> [B, nchunks * D]."""
+        B, D = temb.shape[0], self.inner_dim
+        return ops.small_linear(temb, self._P(prefix + ".linear.weight"), self._P(prefix + ".linear.bias"), self._w("emb_" + tag, (B, nchunks * D)), silu_in=True)
+
+    def _modulate(self, s: _Stream, emb: torch.Tensor, shift_chunk: int, scale_chunk: int, B: int, tag: str) -> torch.Tensor:
+        D = self.inner_dim
+        out = self._w("norm_" + tag, (B * s.Ls, D))
+        ops.adaln_modulate(s.base, emb[:, shift_chunk * D:], emb[:, scale_chunk * D:], out, rows=B * s.Ls, D=D, rows_per_sample=s.Ls,
+                           mod_ld=emb.stride(0), ldx=s.ld, x_map=s.map)
+        return out
+
+    # ------------------------------------------------------------------ blocks ----------------------------------------
+    def _double_block(self, p: str, B: int, s_in: _Stream, s_out: _Stream, c_in: _Stream, c_out: Optional[_Stream], temb: torch.Tensor,
+                      rope: Optional[Tuple[torch.Tensor, torch.Tensor]], tag: str, ctx_cached: bool = False) -> None:
+        """One Flux double-stream block (diffusers FluxTransformerBlock; control twin A6). Joint layout [context | sample].
+        c_out None: the context stream only contributes K/V (its own output is discarded by every caller);
+        ctx_cached: the context K/V already sit in this tag's qkv workspace (same block, same step)."""
+        D, H, dh = self.inner_dim, self.config.num_attention_heads, self.config.attention_head_dim
+        Ls, Lc = s_in.Ls, c_in.Ls
+        Lj = Lc + Ls
+        a = p + ".attn"
+        qkv = self._w("qkv_" + tag, (B, Lj, 3 * D))
+        qkv2 = qkv.view(B * Lj, 3 * D)
+        cos, sin = rope if rope is not None else (None, None)
+        wq, wk = self._P(a + ".norm_q.weight"), self._P(a + ".norm_k.weight")
+        waq, wak = self._P(a + ".norm_added_q.weight"), self._P(a + ".norm_added_k.weight")
+        # sample stream: AdaLN-Zero -> fused QKV
+        emb_s = self._adaln_emb(p + ".norm1", temb, 6, tag + "s")
+        ns = self._modulate(s_in, emb_s, 0, 1, B, "s")
+        w_qkv, b_qkv = self._attn_qkv(a)
+        ops.gemm(ns, w_qkv, b_qkv, qkv2[Lc:], M=B * Ls, ldc=3 * D, c_map=RowMap(Ls, Lj))
+        # context stream
+        emb_c = None
+        if c_out is not None or not ctx_cached:
+            emb_c = self._adaln_emb(p + ".norm1_context", temb, 6, tag + "c")
+            nc = self._modulate(c_in, emb_c, 0, 1, B, "c")
+            w_a, b_a = self._attn_add_qkv(a)
+            if c_out is not None:
+                ops.gemm(nc, w_a, b_a, qkv2, M=B * Lc, ldc=3 * D, c_map=RowMap(Lc, Lj))
+            else:
+                ops.gemm(nc, w_a[D:], b_a[D:], qkv2[0, D:], M=B * Lc, ldc=3 * D, c_map=RowMap(Lc, Lj))
+        if c_out is not None:
+            ops.qk_rmsnorm_rope(qkv2, batches=B, rows_per_batch=Lj, ld=3 * D, q_off=0, k_off=D, heads=H, dh=dh, wq_a=waq, wk_a=wak,
+                                wq_b=wq, wk_b=wk, split=Lc, cos=cos, sin=sin)
+        else:
+            ops.qk_rmsnorm_rope(qkv2[Lc:], batches=B, rows_per_batch=Ls, batch_stride_rows=Lj, pos_offset=Lc, ld=3 * D, q_off=0, k_off=D,
+                                heads=H, dh=dh, wq_b=wq, wk_b=wk, split=0, cos=cos, sin=sin)
+            if not ctx_cached:
+                ops.qk_rmsnorm_rope(qkv2, batches=B, rows_per_batch=Lc, batch_stride_rows=Lj, pos_offset=0, ld=3 * D, q_off=-1, k_off=D,
+                                    heads=H, dh=dh, wk_a=wak, split=Lc, cos=cos, sin=sin)
+        # attention over the joint sequence; queries = every row, or the sample rows only
+        st = (3 * D, Lj * 3 * D)
+        if c_out is not None:
+            att = self._w("att_" + tag, (B * Lj, D))
+            ops.flash_attn(qkv2, qkv2[0, D:], qkv2[0, 2 * D:], att, batches=B, heads=H, dh=dh, Lq=Lj, Lkv=Lj, q_strides=st, k_strides=st,
+                           v_strides=st, o_strides=(D, Lj * D))
+            att_s, att_map = att[Lc:], RowMap(Ls, Lj)
+        else:
+            att = self._w("att_" + tag, (B * Ls, D))
+            ops.flash_attn(qkv2[Lc:], qkv2[0, D:], qkv2[0, 2 * D:], att, batches=B, heads=H, dh=dh, Lq=Ls, Lkv=Lj, q_strides=st, k_strides=st,
+                           v_strides=st, o_strides=(D, Ls * D))
+            att_s, att_map = att, RowMap()
+        # sample: x = x + gate_msa * to_out(attn); x = x + gate_mlp * ff(norm2(x) * (1 + scale_mlp) + shift_mlp)
+        ops.gemm(att_s, self._P(a + ".to_out.0.weight"), self._P(a + ".to_out.0.bias"), s_out.base, M=B * Ls, epilogue=L.EPI_RES_GATE, lda=D,
+                 a_map=att_map, ldc=s_out.ld, c_map=s_out.map, residual=s_in.base, ldr=s_in.ld, r_map=s_in.map, gate=emb_s[:, 2 * D:],
+                 gate_ld=emb_s.stride(0), rows_per_sample=Ls)
+        self._ff(p + ".ff", B, s_out, emb_s, "s")
+        if c_out is not None:
+            ops.gemm(att, self._P(a + ".to_add_out.weight"), self._P(a + ".to_add_out.bias"), c_out.base, M=B * Lc, epilogue=L.EPI_RES_GATE, lda=D,
+                     a_map=RowMap(Lc, Lj), ldc=c_out.ld, c_map=c_out.map, residual=c_in.base, ldr=c_in.ld, r_map=c_in.map, gate=emb_c[:, 2 * D:],
+                     gate_ld=emb_c.stride(0), rows_per_sample=Lc)
+            self._ff(p + ".ff_context", B, c_out, emb_c, "c")
+
+    def _ff(self, p: str, B: int, s: _Stream, emb: torch.Tensor, tag: str) -> None:
+        D = self.inner_dim
+        n2 = self._modulate(s, emb, 3, 4, B, tag)
+        hid = self._w("ffh_" + tag, (B * s.Ls, 4 * D))
+        ops.gemm(n2, self._P(p + ".net.0.proj.weight"), self._P(p + ".net.0.proj.bias"), hid, M=B * s.Ls, epilogue=L.EPI_BIAS_GELU)
+        ops.gemm(hid, self._P(p + ".net.2.weight"), self._P(p + ".net.2.bias"), s.base, M=B * s.Ls, epilogue=L.EPI_RES_GATE, ldc=s.ld, c_map=s.map,
+                 residual=s.base, ldr=s.ld, r_map=s.map, gate=emb[:, 5 * D:], gate_ld=emb.stride(0), rows_per_sample=s.Ls)
+
+    def _single_block(self, p: str, B: int, h_in: _Stream, h_out: _Stream, temb: torch.Tensor,
+                      rope: Optional[Tuple[torch.Tensor, torch.Tensor]]) -> None:
+        """diffusers FluxSingleTransformerBlock (control twin A7): h = h + gate * proj_out(cat[attn(n), gelu(proj_mlp(n))])."""
+        D, H, dh = self.inner_dim, self.config.num_attention_heads, self.config.attention_head_dim
+        Lj = h_in.Ls
+        a = p + ".attn"
+        cos, sin = rope if rope is not None else (None, None)
+        emb = self._adaln_emb(p + ".norm", temb, 3, "1")
+        n = self._modulate(h_in, emb, 0, 1, B, "j")
+        sb = self._w("single", (B * Lj, 8 * D))       # [q | k | v | attn | mlp(4D)]
+        w_qkv, b_qkv = self._attn_qkv(a)
+        ops.gemm(n, w_qkv, b_qkv, sb, M=B * Lj, ldc=8 * D)
+        ops.gemm(n, self._P(p + ".proj_mlp.weight"), self._P(p + ".proj_mlp.bias"), sb[0, 4 * D:], M=B * Lj, epilogue=L.EPI_BIAS_GELU, ldc=8 * D)
+        ops.qk_rmsnorm_rope(sb, batches=B, rows_per_batch=Lj, ld=8 * D, q_off=0, k_off=D, heads=H, dh=dh, wq_b=self._P(a + ".norm_q.weight"),
+                            wk_b=self._P(a + ".norm_k.weight"), split=0, cos=cos, sin=sin)
+        st = (8 * D, Lj * 8 * D)
+        ops.flash_attn(sb, sb[0, D:], sb[0, 2 * D:], sb[0, 3 * D:], batches=B, heads=H, dh=dh, Lq=Lj, Lkv=Lj, q_strides=st, k_strides=st,
+                       v_strides=st, o_strides=st)
+        ops.gemm(sb[0, 3 * D:], self._P(p + ".proj_out.weight"), self._P(p + ".proj_out.bias"), h_out.base, M=B * Lj, epilogue=L.EPI_RES_GATE,
+                 lda=8 * D, ldc=h_out.ld, c_map=h_out.map, residual=h_in.base, ldr=h_in.ld, r_map=h_in.map, gate=emb[:, 2 * D:],
+                 gate_ld=emb.stride(0), rows_per_sample=Lj)
+
+    # ------------------------------------------------------------------ CoMoE -----------------------------------------
+    def _comoe(self, B: int, N: int, T: int, x: torch.Tensor, cond_tokens: torch.Tensor, ctrl_enc: torch.Tensor, control_temb: torch.Tensor,
+               condition_temb: torch.Tensor, pooled: torch.Tensor, cond_pooled: torch.Tensor, img_ids, txt_ids, cond_ids,
+               uniform: Optional[torch.Tensor], z0: torch.Tensor, accumulate: bool):
+        """preprocess_moe_forward + moe_forward for one condition (src/UniGenTransformer.py:969-1068): returns (l_aux, exp_counts)
+        and writes / accumulates expert_hidden + expert_condition into z0 [B*N, D]."""
+        ctl, D, dev = self._ctl, self.inner_dim, self.device
+        E, S = ctl.expert_nums, B * N
+        C = max(int(math.ceil(S / E)), 4)          # deepspeed _capacity(capacity_factor=1, min_capacity=4)
+        # condition tokens -> D   (control_x_embedder, :1040)
+        c = self._w("moe_c", (S, D))
+        ops.gemm(cond_tokens.reshape(S, -1), self._P("control_x_embedder.weight"), self._P("control_x_embedder.bias"), c, M=S)
+        # gate on (x + c)
+        gates, idx = self._w("moe_gates", (S, E), torch.float32), self._w("moe_idx", (S,), torch.int32)
+        ops.moe_gate_top1(x, c, self._P("moe.moe_layer.gate.wg.weight"), gates, idx)
+        if uniform is None:
+            uniform = torch.rand(S, E, device=dev, dtype=torch.float32)   # RTS draw; the reference consumes the global device RNG too
+        slot, tos = self._w("moe_slot", (S,), torch.int32), self._w("moe_tos", (E, C), torch.int32)
+        exp_counts = torch.empty(E, device=dev, dtype=torch.int64)
+        l_aux = torch.empty(1, device=dev, dtype=torch.float32)
+        ops.moe_capacity_rts(gates, idx, uniform.contiguous(), C, slot, tos, exp_counts, l_aux)
+        # expert modulation: s = Linear(768 -> D)(pooled) per (expert, sample)
+        pe = "moe.moe_layer.experts.deepspeed_experts."
+        mod_c, mod_h = self._w("moe_modc", (E, B, D)), self._w("moe_modh", (E, B, D))
+        for e in range(E):
+            ops.small_linear(cond_pooled, self._P(f"{pe}{e}.0.1.weight"), self._P(f"{pe}{e}.0.1.bias"), mod_c[e])
+            ops.small_linear(pooled, self._P(f"{pe}{e}.1.1.weight"), self._P(f"{pe}{e}.1.1.bias"), mod_h[e])
+        w_c = self._pack_stack("moe.wc", [f"{pe}{e}.0.0.weight" for e in range(E)])
+        b_c = self._pack_stack("moe.bc", [f"{pe}{e}.0.0.bias" for e in range(E)])
+        w_h = self._pack_stack("moe.wh", [f"{pe}{e}.1.0.weight" for e in range(E)])
+        b_h = self._pack_stack("moe.bh", [f"{pe}{e}.1.0.bias" for e in range(E)])
+        xd, yc, yh = self._w("moe_xd", (E, C, D)), self._w("moe_yc", (E, C, D)), self._w("moe_yh", (E, C, D))
+        # c' = W_c (s_c * c) + b_c ;  h' = W_h (s_h * (h + c')) + b_h      (expert_forward :957-959)
+        ops.moe_dispatch_modulate(c, None, mod_c, tos, xd, B=B, E=E, capacity=C, tokens_per_sample=N)
+        ops.gemm(xd, w_c, b_c, yc, M=C, groups=E, a_gstride=C * D, w_gstride=D * D, bias_gstride=D, c_gstride=C * D)
+        ops.moe_dispatch_modulate(x, yc, mod_h, tos, xd, B=B, E=E, capacity=C, tokens_per_sample=N)
+        ops.gemm(xd, w_h, b_h, yh, M=C, groups=E, a_gstride=C * D, w_gstride=D * D, bias_gstride=D, c_gstride=C * D)
+        xs = cs = None
+        if ctl.use_shared_expert:
+            xc = self._w("moe_xc", (B, 2 * N, D))
+            xc2 = xc.view(B * 2 * N, D)
+            round_to = img_ids.dtype if ctl.use_rope else None
+            # shared_expert[0]: sample = image tokens, context = condition tokens, temb = condition_temb   (:1013-1015)
+            rope0 = self._rope([cond_ids, img_ids], round_to) if ctl.use_rope else None
+            self._double_block("shared_expert.0", B, _Stream(x, N), _Stream(xc2, N, 2 * N), _Stream(c, N), _Stream(xc2[N:], N, 2 * N),
+                               condition_temb, rope0, "se0")
+            # shared_expert[1]: sample = [image | condition], context = control text (K/V only), temb = control_temb   (:1017-1022)
+            rope1 = self._rope([txt_ids, img_ids, cond_ids], round_to) if ctl.use_rope else None
+            xcs = _Stream(xc2, 2 * N)
+            self._double_block("shared_expert.1", B, xcs, xcs, _Stream(ctrl_enc, T), None, control_temb, rope1, "se1")
+        for b in range(B):
+            sl = slice(b * N, (b + 1) * N)
+            if ctl.use_shared_expert:
+                xs, cs = xc[b, :N], xc[b, N:]
+            ops.moe_combine(yh, yc, gates[sl], idx[sl], slot[sl], z0[sl], E=E, capacity=C, xs=xs, cs=cs, accumulate=accumulate)
+        return l_aux, exp_counts
+
+    # ------------------------------------------------------------------ forward ---------------------------------------
+    @torch.no_grad()
+    def forward(self, hidden_states: torch.Tensor, condition_hidden_states=None, conditioning_scale: float = 1.0,
+                encoder_hidden_states: torch.Tensor = None, pooled_projections: torch.Tensor = None, condition_pooled_projections=None,
+                timestep: torch.Tensor = None, img_ids: torch.Tensor = None, txt_ids: torch.Tensor = None, guidance: torch.Tensor = None,
+                condition_ids=None, joint_attention_kwargs: Optional[Dict[str, Any]] = None, skip_layers=None, gate_uniform=None, **kwargs):
+        """src/UniGenTransformer.py:1182-1271 (lists of conditions: :1360-1450). Returns (pred [B, N, C_in], {'moe_loss'}, {'expert_counts'}).
+        `gate_uniform` (extra): the Uniform(0,1) [S, E] draw of deepspeed's Random Token Selection, for reproducible parity runs."""
+        if self._ctl is None:
+            raise RuntimeError("call init_condition_block(...) before forward")
+        if joint_attention_kwargs and any(k != "scale" for k in joint_attention_kwargs):
+            raise ValueError("joint_attention_kwargs other than 'scale' (e.g. IP-adapter embeds) are not supported")
+        ctl, cfg, D, dev = self._ctl, self.config, self.inner_dim, self.device
+        multi = isinstance(condition_hidden_states, (list, tuple))
+        if multi != self.multi_condition:
+            raise ValueError(f"{type(self).__name__} expects {'lists of' if self.multi_condition else 'single'} condition tensors")
+        if hidden_states.dtype != BF or self.dtype != BF:
+            raise TypeError("the HIP engine computes in bf16: cast the model and inputs to torch.bfloat16")
+        if txt_ids.ndim == 3:
+            txt_ids = txt_ids[0]
+        if img_ids.ndim == 3:
+            img_ids = img_ids[0]
+        B, N, _ = hidden_states.shape
+        T = encoder_hidden_states.shape[1]
+        Lj = T + N
+        # `timestep.to(hidden_states.dtype) * 1000` (:1217-1220) - bf16 scalar path, then fp32 for the sinusoid
+        t_f32 = (timestep.to(BF) * 1000).float().contiguous()
+        g_f32 = (guidance.to(BF) * 1000).float().contiguous() if guidance is not None else None
+        if cfg.guidance_embeds and g_f32 is None:
+            raise ValueError("guidance is required when config.guidance_embeds is True")
+        if not cfg.guidance_embeds:
+            g_f32 = None
+        pooled = pooled_projections.to(BF).contiguous()
+
+        x = self._w("x", (B * N, D))
+        ops.gemm(hidden_states.reshape(B * N, -1), self._P("x_embedder.weight"), self._P("x_embedder.bias"), x, M=B * N)
+        temb = self._time_text_embed("time_text_embed", t_f32, pooled, g_f32, "base")
+        enc = self._w("enc", (B * T, D))
+        ops.gemm(encoder_hidden_states.reshape(B * T, -1), self._P("context_embedder.weight"), self._P("context_embedder.bias"), enc, M=B * T)
+        rope_base = self._rope([txt_ids, img_ids], None)                         # base path: fp32 tables (:1238-1239)
+        rope_ctl = self._rope([txt_ids, img_ids], img_ids.dtype) if ctl.use_rope else None
+
+        xs, es = _Stream(x, N), _Stream(enc, T)
+        z = self._w("z", (B * N, D))
+        zs = _Stream(z, N)
+        moe = None
+        last_m = -1
+        n_d, n_cj = cfg.num_layers, ctl.cn_joint_layers
+        for i in range(n_d):
+            self._double_block(f"transformer_blocks.{i}", B, xs, xs, es, es, temb, rope_base, "base")
+            m = int(i / (n_d / n_cj))                                             # (:1126-1127)
+            if moe is None:
+                # preprocess_moe_forward, once per step, on the text stream AFTER base block 0 (:1137 -> :1051)
+                control_pooled = pooled if ctl.use_pooled_prompt_embeds else torch.zeros_like(pooled)
+                control_temb = self._time_text_embed("control_time_text_embed", t_f32, control_pooled, g_f32, "ctl")
+                ctrl_enc = self._w("ctrl_enc", (B * T, D))
+                ops.gemm(enc, self._P("control_context_embedder.weight"), self._P("control_context_embedder.bias"), ctrl_enc, M=B * T)
+                if multi:
+                    conds = list(zip(condition_hidden_states, condition_pooled_projections, condition_ids))
+                else:
+                    conds = [(condition_hidden_states, condition_pooled_projections, condition_ids)]
+                unis = gate_uniform if isinstance(gate_uniform, (list, tuple)) else [gate_uniform] * len(conds)
+                z0 = self._w("z0", (B * N, D))
+                cond_temb_sum = None
+                for k, ((ct, cp, cid), uni) in enumerate(zip(conds, unis)):
+                    if cp.ndim == 1:
+                        cp = cp.unsqueeze(0)
+                    if ct.ndim == 2:
+                        ct = ct.unsqueeze(0)
+                    cp = cp.to(BF).contiguous()
+                    cid = cid[0] if cid.ndim == 3 else cid
+                    cond_temb = self._time_text_embed("control_condition_embed", t_f32, cp, g_f32, f"cond{k}")
+                    l_aux, exp_counts = self._comoe(B, N, T, x, ct.to(BF), ctrl_enc, control_temb, cond_temb, pooled, cp, img_ids, txt_ids, cid,
+                                                    uni, z0, accumulate=k > 0)
+                    if cond_temb_sum is None:
+                        cond_temb_sum = cond_temb
+                    else:                                                         # sum(merge_condition_temb) (:1319)
+                        cond_temb_sum = ops.add(cond_temb_sum, cond_temb, self._w("cond_temb_sum", cond_temb.shape))
+                moe = dict(ctrl_enc=_Stream(ctrl_enc, T), condition_temb=cond_temb_sum, l_aux=l_aux, exp_counts=exp_counts)
+                z_in = _Stream(z0, N)
+            else:
+                z_in = xs                                                         # control blocks read the BASE stream (:1085-1097)
+            self._double_block(f"control_joint_trans_blocks.{m}", B, z_in, zs, moe["ctrl_enc"], None, moe["condition_temb"], rope_ctl, "ctl",
+                               ctx_cached=(m == last_m))
+            last_m = m
+            # x = x + controlnet_add_joint_blocks[m](z) * conditioning_scale   (:1104,1141)
+            ops.gemm(z, self._P(f"controlnet_add_joint_blocks.{m}.weight"), self._P(f"controlnet_add_joint_blocks.{m}.bias"), x, M=B * N,
+                     epilogue=L.EPI_RES_SCALE, residual=x, alpha=float(conditioning_scale))
+
+        # hidden_states = cat([encoder_hidden_states, hidden_states], dim=1)   (:1146)
+        h = self._w("h", (B, Lj, D))
+        h[:, :T].copy_(enc.view(B, T, D))
+        h[:, T:].copy_(x.view(B, N, D))
+        h2 = h.view(B * Lj, D)
+        hs = _Stream(h2, Lj)
+        zj = self._w("zj", (B * Lj, D))
+        zjs = _Stream(zj, Lj)
+        n_s, n_cs = cfg.num_single_layers, ctl.cn_single_layers
+        for j in range(n_s):
+            self._single_block(f"single_transformer_blocks.{j}", B, hs, hs, temb, rope_base)
+            if ctl.use_single_trans_blocks:
+                m = int(j / (n_s / n_cs))                                         # (:1159-1160)
+                self._single_block(f"control_single_trans_blocks.{m}", B, hs, zjs, moe["condition_temb"], rope_ctl)
+                wz, bz = self._P(f"controlnet_add_single_blocks.{m}.weight"), self._P(f"controlnet_add_single_blocks.{m}.bias")
+                if ctl.single_block_control_method == "overall_add":              # (:1166-1167)
+                    ops.gemm(zj, wz, bz, h2, M=B * Lj, epilogue=L.EPI_RES_SCALE, residual=h2, alpha=float(conditioning_scale))
+                else:                                                             # image tokens only (:1168-1172)
+                    mp = RowMap(N, Lj)
+                    ops.gemm(zj[T:], wz, bz, h2[T:], M=B * N, epilogue=L.EPI_RES_SCALE, lda=D, a_map=mp, ldc=D, c_map=mp, residual=h2[T:],
+                             ldr=D, r_map=mp, alpha=float(conditioning_scale))
+        # norm_out (AdaLayerNormContinuous: scale first) + proj_out on the image tokens   (:1174, 1264-1265)
+        emb_o = self._adaln_emb("norm_out", temb, 2, "o")
+        img = _Stream(h2[T:], N, Lj)
+        no = self._w("norm_s", (B * N, D))
+        ops.adaln_modulate(img.base, emb_o[:, D:], emb_o, no, rows=B * N, D=D, rows_per_sample=N, mod_ld=emb_o.stride(0), ldx=D, x_map=img.map)
+        out = torch.empty(B, N, self.out_channels, device=dev, dtype=BF)
+        ops.gemm(no, self._P("proj_out.weight"), self._P("proj_out.bias"), out.view(B * N, -1), M=B * N)
+        return out, dict(moe_loss=moe["l_aux"][0] * 0.1), dict(expert_counts=moe["exp_counts"])
+
+
+class MultiCondtionUniGenFlux(UniGenFlux):
+    """Drop-in for the reference `MultiCondtionUniGenFlux` (sic): lists of per-condition tensors; per-condition CoMoE outputs and
+    condition tembs are summed (src/UniGenTransformer.py:1275-1357)."""
+
+    multi_condition = True
