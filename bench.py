@@ -1,0 +1,190 @@
+#!/usr/bin/env python
+"""Headline benchmark: images/sec at 1024^2, FLUX-schnell geometry + canny condition, 4 denoise steps (BASELINE.json).
+
+  python bench.py --gpus N --steps K --warmup W
+  N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one pass of the hot path over one batch: the full 4-step denoise loop (4 UniGenFlux forwards + 4 Euler steps) of a
+batch of B = 4 synthetic 1024x1024 samples (cfg2: N = 4096 image tokens, T = 512 text tokens, 19 double + 38 single base blocks,
+9 + 19 control blocks, CoMoE with 6 experts). Inputs and weights are resident in HBM before the timed region. VAE / CLIP / T5 are
+excluded. Multi-GPU is batch-parallel: every rank holds a weight replica and its own samples; the only collectives
+are the barriers around the timed region and one MAX all-reduce of the elapsed time (weak scaling).
+
+The JSON line carries `roofline` (dominant kernel = the bf16 MFMA GEMM: algorithmic FLOPs per launch / HIP-event duration of
+the launches inside the timed region) and `cpu_baseline` (the oracle = CPU restatement of the reference, timed on this box's host
+cores on a bounded, reduced-depth slice of the same workload and scaled by algorithmic FLOPs).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA peak of MI355X (MI355X_MICROARCH.md, chip-level parameters)
+CONTROL_PARAMS = dict(use_rope=True, use_shared_expert=True, use_consis_module=False, use_single_trans_blocks=True, single_control_dev=2,
+                      single_block_control_method="overall_add", top_num=1, expert_num_each_condition=3)
+
+
+def canonical_flops_per_forward(D, N, T, n_double, n_single, n_cj, n_cs, n_cond, in_ch=64, txt_dim=4096):
+    """Necessary-work FLOPs of one sample-forward: 2MNK per contraction, 4 Lq Lkv D per attention."""
+    J = lambda a, b: 24 * D * D * (a + b) + 4 * (a + b) ** 2 * D
+    Sg = lambda l: 24 * D * D * l + 4 * l * l * D
+    Jk = lambda a, b, r: 24 * D * D * a + 4 * D * D * b * r + 4 * a * (a + b) * D
+    base = n_double * J(N, T) + n_single * Sg(N + T)
+    ctrl = n_double * Jk(N, T, n_cj / max(n_double, 1)) + n_single * Sg(N + T)
+    zero = n_double * 2 * D * D * N + n_single * 2 * D * D * (N + T)
+    comoe = n_cond * (4 * D * D * N + J(N, N) + Jk(2 * N, T, 1.0))
+    embeds = 2 * D * in_ch * N * (2 + n_cond) + 2 * D * txt_dim * T + 2 * D * D * T
+    return base + ctrl + zero + comoe + embeds
+
+
+def cpu_baseline(device_count_note: str, budget_hint_s: float = 25.0):
+    """Time the CPU oracle (port of the reference) on a reduced-depth slice of the same 1024^2 workload."""
+    from oracle import unigen_ref as R
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        pass
+    torch.set_num_threads(cores)
+    cfg = R.FluxConfig(num_layers=2, num_single_layers=2)          # FLUX width (D=3072, H=24, dh=128), 1 control joint + 1 control single block
+    B, grid, T = 1, 64, 512
+    st = R.make_state(cfg, seed=0)
+    inp = R.make_inputs(cfg, B=B, grid=grid, T=T)
+    t = torch.full((B,), 1.0, dtype=torch.bfloat16)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        R.unigen_flux_forward(st, cfg, timestep=t, dtype=torch.bfloat16, **inp)
+    dt = time.perf_counter() - t0
+    sample_flops = canonical_flops_per_forward(cfg.inner_dim, grid * grid, T, 2, 2, 1, 1, 1)
+    full_flops_per_image = 4 * canonical_flops_per_forward(3072, 4096, 512, 19, 38, 9, 19, 1)
+    img_per_s = (sample_flops / dt) / full_flops_per_image
+    return dict(value=img_per_s, unit="images/s", cores=cores, kind="port",
+                sample=(f"oracle (bf16 torch CPU restatement of the reference) on ONE forward at 1024^2, B=1, FLUX width, depth cut to 2 double + 2 single "
+                        f"base blocks (+1+1 control blocks, full CoMoE): {sample_flops / 1e12:.1f} TFLOP in {dt:.1f} s = {sample_flops / dt / 1e12:.2f} TFLOP/s; "
+                        f"scaled by algorithmic FLOPs to the full 4-step image ({full_flops_per_image / 1e12:.1f} TFLOP)"),
+                sample_seconds=dt, sample_tflops=sample_flops / 1e12)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=4, help="samples per GPU per step (cfg2: 4)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--small", action="store_true", help="debug: reduced depth (NOT the headline configuration)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: unigen_amd has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from unigen_amd import ops
+    from unigen_amd.flux import UniGenFlux
+    from unigen_amd.pipeline import denoise_loop, prepare_latent_image_ids
+
+    cfg = dict(num_layers=2, num_single_layers=4) if args.small else {}
+    model = UniGenFlux.from_config(cfg, device=dev, dtype=torch.bfloat16)
+    model.init_condition_block(condition_nums=1, condition_types=["canny"], control_params=dict(CONTROL_PARAMS))
+    model.init_synthetic_(seed=0, std=0.02)
+
+    B, grid, T, steps_per_image = args.batch, 64, 512, 4
+    N = grid * grid
+    g = torch.Generator(device=dev).manual_seed(12443 + rank)          # reference default seed (infer.py:61) + rank
+    rn = lambda *s: torch.randn(*s, generator=g, device=dev, dtype=torch.float32)
+    latents0 = rn(B, N, 64).to(torch.bfloat16)
+    control = rn(B, N, 64).to(torch.bfloat16)
+    prompt = (0.1 * rn(B, T, 4096)).to(torch.bfloat16)
+    pooled, cond_pooled = rn(B, 768).to(torch.bfloat16), rn(B, 768).to(torch.bfloat16)
+    ids = prepare_latent_image_ids(grid, grid, dev, torch.bfloat16)
+    txt_ids = torch.zeros(T, 3, device=dev, dtype=torch.bfloat16)
+    uniforms = [torch.rand(B * N, model._ctl.expert_nums, generator=g, device=dev) for _ in range(steps_per_image)]
+
+    def one_step():
+        lat = latents0.clone()
+        return denoise_loop(model, latents=lat, control_tokens=control, prompt_embeds=prompt, pooled_prompt_embeds=pooled,
+                            condition_pooled_prompt_embeds=cond_pooled, text_ids=txt_ids, latent_image_ids=ids, condition_ids=ids,
+                            num_inference_steps=steps_per_image, gate_uniforms=uniforms)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = one_step()
+    timer = None if args.no_kernel_timer else ops.KernelTimer()
+    barrier()
+    ops.set_timer(timer)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = one_step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ops.set_timer(None)
+    if not torch.isfinite(out.float()).all():
+        raise SystemExit("non-finite latents after denoising")
+    if world > 1:
+        te = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+
+    if rank == 0:
+        images = B * args.steps * world
+        value = images / elapsed
+        n_d, n_s = model.config.num_layers, model.config.num_single_layers
+        fl_img = steps_per_image * canonical_flops_per_forward(model.inner_dim, N, T, n_d, n_s, model._ctl.cn_joint_layers, model._ctl.cn_single_layers, 1)
+        line = dict(metric="images/sec at 1024^2, FLUX-schnell+canny, 4-step", value=value, unit="images/s", n_gpus=world, steps=args.steps,
+                    warmup=args.warmup, ms_per_step=1000.0 * elapsed / args.steps, higher_is_better=True, scaling="weak", vs_baseline=None,
+                    dtype="bf16", data="synthetic",
+                    config=dict(workload=("cfg2: UniGenFlux canny single-condition, 1024x1024 (N=4096, T=512), FLUX-schnell geometry "
+                                          "19 double + 38 single blocks D=3072 H=24, 9+19 control blocks, CoMoE E=6, 4 denoise steps, bf16, "
+                                          "random-init weights" + (" [--small DEBUG depth]" if args.small else "")),
+                                per_gpu_batch=B, global_batch=B * world, parallelism=f"dp{world} (independent samples, RCCL barrier only)",
+                                step="one 4-step denoise loop of the per-GPU batch"),
+                    flops_per_image_canonical=fl_img, e2e_mfma_frac=value / world * fl_img / (MFMA_BF16_PEAK_TFLOPS * 1e12))
+        if timer is not None:
+            s = timer.summary()
+            gm, at = s.get("gemm"), s.get("attn")
+            ach = gm["flops"] / (gm["ms"] * 1e-3) / 1e12
+            line["roofline"] = dict(bound="mfma", kernel="gemm128_kernel (ug_gemm_bf16)", achieved=ach, peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s",
+                                    frac=ach / MFMA_BF16_PEAK_TFLOPS, traffic=None, launches=gm["launches"],
+                                    avg_launch_us=1000.0 * gm["ms"] / gm["launches"], avg_launch_gflop=gm["flops"] / gm["launches"] / 1e9,
+                                    share_of_step_time=gm["ms"] * 1e-3 / elapsed)
+            if at:
+                a2 = at["flops"] / (at["ms"] * 1e-3) / 1e12
+                line["roofline_attention"] = dict(bound="mfma", kernel="flash_attn128_kernel (ug_flash_attn_fwd)", achieved=a2, peak=MFMA_BF16_PEAK_TFLOPS,
+                                                  unit="TFLOP/s", frac=a2 / MFMA_BF16_PEAK_TFLOPS, launches=at["launches"],
+                                                  avg_launch_us=1000.0 * at["ms"] / at["launches"], share_of_step_time=at["ms"] * 1e-3 / elapsed)
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline("")
+            line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -15,6 +15,47 @@ from . import lib as L
 bf16 = torch.bfloat16
 
 
+class KernelTimer:
+    """Optional per-launch timing for bench.py: HIP events recorded on the launch stream around each call of the named
+    kernel classes, with the algorithmic FLOPs of the launch. Off unless installed with `set_timer`."""
+
+    def __init__(self, kinds=("gemm", "attn")):
+        self.kinds = set(kinds)
+        self.records = []   # (kind, flops, start_event, end_event)
+
+    def begin(self, kind):
+        if kind not in self.kinds:
+            return None
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(torch.cuda.current_stream())
+        return ev
+
+    def end(self, kind, flops, ev0):
+        if ev0 is None:
+            return
+        ev1 = torch.cuda.Event(enable_timing=True)
+        ev1.record(torch.cuda.current_stream())
+        self.records.append((kind, flops, ev0, ev1))
+
+    def summary(self):
+        """-> {kind: dict(launches, flops, ms)} (call after a device synchronize)."""
+        out = {}
+        for kind, flops, e0, e1 in self.records:
+            d = out.setdefault(kind, dict(launches=0, flops=0.0, ms=0.0))
+            d["launches"] += 1
+            d["flops"] += flops
+            d["ms"] += e0.elapsed_time(e1)
+        return out
+
+
+_timer: Optional[KernelTimer] = None
+
+
+def set_timer(t: Optional[KernelTimer]) -> None:
+    global _timer
+    _timer = t
+
+
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
@@ -72,7 +113,10 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: to
     if lora_t is not None:
         _chk(lora_t, "lora_t"); _chk(lora_b, "lora_b")
         d.lora_T, d.ldt, d.lora_B, d.ldb, d.lora_r = lora_t.data_ptr(), lora_t.stride(-2), lora_b.data_ptr(), lora_b.stride(-2), lora_b.shape[-1]
+    ev = _timer.begin("gemm") if _timer is not None else None
     L.check(L.load().ug_gemm_bf16(C.byref(d), _stream()), "ug_gemm_bf16")
+    if ev is not None:
+        _timer.end("gemm", 2.0 * M * N * (K + (d.lora_r or 0)) * max(groups, 1), ev)
     return out
 
 
@@ -119,9 +163,12 @@ def flash_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Ten
     _chk(q, "q"); _chk(k, "k"); _chk(v, "v"); _chk(out, "out")
     if scale is None:
         scale = dh ** -0.5
+    ev = _timer.begin("attn") if _timer is not None else None
     L.check(L.load().ug_flash_attn_fwd(q.data_ptr(), q_strides[0], q_strides[1], k.data_ptr(), k_strides[0], k_strides[1],
                                        v.data_ptr(), v_strides[0], v_strides[1], out.data_ptr(), o_strides[0], o_strides[1],
                                        batches, heads, Lq, Lkv, dh, scale, _stream()), "ug_flash_attn_fwd")
+    if ev is not None:
+        _timer.end("attn", 4.0 * batches * heads * Lq * Lkv * dh, ev)
     return out
 
 

@@ -1,0 +1,171 @@
+"""Denoise loop of UniGenFLUXPipeline on MI355X (reference: src/UniGenPipeline.py:452-1133, loop :721-789 / :1048-1116).
+
+Scope: the timestep schedule, the transformer call with the reference's kwargs and the Euler step.
+Text encoders (CLIP/T5) and the VAE are the rows either side of the hot path and are NOT part of this package: the pipeline
+accepts what they produce - prompt embeds, pooled embeds, packed condition latents - exactly as the reference's `__call__`
+does through its `prompt_embeds=`, `pooled_prompt_embeds=`, `condition_pooled_prompt_embeds=`, `latents=` arguments, and returns
+latents (`output_type="latent"`). The reference defines `__call__` twice (single- and multi-condition; the second shadows the
+first); here one `__call__` serves both: nested lists select the multi-condition path.
+"""
+from __future__ import annotations
+
+import math
+from types import SimpleNamespace
+from typing import List, Optional, Sequence, Union
+
+import torch
+
+from . import ops
+
+BF = torch.bfloat16
+
+
+def calculate_shift(image_seq_len, base_seq_len=256, max_seq_len=4096, base_shift=0.5, max_shift=1.15) -> float:
+    """diffusers pipeline_flux.calculate_shift (src/UniGenPipeline.py:664-670)."""
+    m = (max_shift - base_shift) / (max_seq_len - base_seq_len)
+    return image_seq_len * m + (base_shift - m * base_seq_len)
+
+
+def flow_match_sigmas(num_inference_steps: int, *, sigmas: Optional[Sequence[float]] = None, shift: float = 1.0,
+                      use_dynamic_shifting: bool = False, mu: Optional[float] = None) -> List[float]:
+    """FlowMatchEulerDiscreteScheduler.set_timesteps: sigma' = shift*s/(1+(shift-1)s), or exp(mu)/(exp(mu)+(1/s-1))
+    with dynamic shifting (FLUX-dev); a final 0 is appended. FLUX-schnell: shift = 1, no dynamic shifting."""
+    if sigmas is None:
+        sigmas = [1.0 - i * (1.0 - 1.0 / num_inference_steps) / max(num_inference_steps - 1, 1) for i in range(num_inference_steps)]
+    out = []
+    for s in sigmas:
+        s = float(s)
+        if use_dynamic_shifting:
+            s = math.exp(mu) / (math.exp(mu) + (1.0 / s - 1.0))
+        else:
+            s = shift * s / (1.0 + (shift - 1.0) * s)
+        out.append(s)
+    return out + [0.0]
+
+
+def prepare_latent_image_ids(height: int, width: int, device, dtype) -> torch.Tensor:
+    """FluxPipeline._prepare_latent_image_ids: [h*w, 3], [:,1] = row, [:,2] = col."""
+    ids = torch.zeros(height, width, 3)
+    ids[..., 1] = ids[..., 1] + torch.arange(height)[:, None]
+    ids[..., 2] = ids[..., 2] + torch.arange(width)[None, :]
+    return ids.reshape(height * width, 3).to(device=device, dtype=dtype)
+
+
+def pack_latents(latents: torch.Tensor) -> torch.Tensor:
+    """FluxPipeline._pack_latents: [B, C, H, W] -> [B, H/2*W/2, 4C] (layout change outside the hot loop)."""
+    B, C, H, W = latents.shape
+    return latents.view(B, C, H // 2, 2, W // 2, 2).permute(0, 2, 4, 1, 3, 5).reshape(B, (H // 2) * (W // 2), C * 4)
+
+
+def unpack_latents(latents: torch.Tensor, height: int, width: int, vae_scale_factor: int = 8) -> torch.Tensor:
+    """FluxPipeline._unpack_latents (height/width in pixels)."""
+    B, _, ch = latents.shape
+    h = 2 * (int(height) // (vae_scale_factor * 2))
+    w = 2 * (int(width) // (vae_scale_factor * 2))
+    return latents.view(B, h // 2, w // 2, ch // 4, 2, 2).permute(0, 3, 1, 4, 2, 5).reshape(B, ch // 4, h, w)
+
+
+@torch.no_grad()
+def denoise_loop(transformer, *, latents: torch.Tensor, control_tokens, prompt_embeds: torch.Tensor, pooled_prompt_embeds: torch.Tensor,
+                 condition_pooled_prompt_embeds, text_ids: torch.Tensor, latent_image_ids: torch.Tensor, condition_ids,
+                 num_inference_steps: int = 4, sigmas: Optional[Sequence[float]] = None, guidance_scale: float = 3.5,
+                 conditioning_scale: float = 1.0, shift: float = 1.0, use_dynamic_shifting: bool = False, gate_uniforms=None) -> torch.Tensor:
+    """The hot loop (src/UniGenPipeline.py:721-789): per step `timestep = t.expand(B).to(latents.dtype)`, transformer(timestep / 1000)[0],
+    latents = latents + (sigma_next - sigma) * noise_pred evaluated in fp32 and cast back. Updates and returns `latents` in place."""
+    mu = calculate_shift(latents.shape[1]) if use_dynamic_shifting else None
+    sig = flow_match_sigmas(num_inference_steps, sigmas=sigmas, shift=shift, use_dynamic_shifting=use_dynamic_shifting, mu=mu)
+    B = latents.shape[0]
+    guidance = None
+    if transformer.config.guidance_embeds:
+        guidance = torch.full([B], guidance_scale, device=latents.device, dtype=torch.float32)
+    latents = latents.contiguous()
+    for i in range(num_inference_steps):
+        t = torch.tensor(sig[i] * 1000.0, dtype=torch.float32)
+        timestep = t.expand(B).to(latents.dtype).to(latents.device)
+        uni = None if gate_uniforms is None else gate_uniforms[i]
+        noise_pred = transformer(hidden_states=latents, condition_hidden_states=control_tokens, conditioning_scale=conditioning_scale,
+                                 encoder_hidden_states=prompt_embeds, pooled_projections=pooled_prompt_embeds,
+                                 condition_pooled_projections=condition_pooled_prompt_embeds, timestep=timestep / 1000, txt_ids=text_ids,
+                                 img_ids=latent_image_ids, guidance=guidance, condition_ids=condition_ids, gate_uniform=uni)[0]
+        ops.euler_step(latents, noise_pred, sig[i + 1] - sig[i])
+    return latents
+
+
+class UniGenFLUXPipeline:
+    """Call-surface twin of the reference `UniGenFLUXPipeline(FluxPipeline)` for the transformer-side of the pipeline."""
+
+    def __init__(self, transformer=None, scheduler_config: Optional[dict] = None, vae_scale_factor: int = 8):
+        self.transformer = transformer
+        self.vae_scale_factor = vae_scale_factor
+        self.default_sample_size = 128
+        sc = dict(shift=1.0, use_dynamic_shifting=False)
+        sc.update(scheduler_config or {})
+        self.scheduler = SimpleNamespace(config=sc)
+        self._device, self._dtype = None, BF
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path=None, transformer=None, **kwargs) -> "UniGenFLUXPipeline":
+        """infer.py:146-149 builds the pipeline with `transformer=None` and assigns `.transformer` afterwards. Only the scheduler
+        config is read from disk (model_index-style layout); encoders and VAE are out of scope and are not loaded."""
+        import json, os
+        sc = {}
+        if pretrained_model_name_or_path is not None:
+            p = os.path.join(os.fspath(pretrained_model_name_or_path), "scheduler", "scheduler_config.json")
+            if os.path.exists(p):
+                with open(p) as f:
+                    raw = json.load(f)
+                sc = {k: raw[k] for k in ("shift", "use_dynamic_shifting") if k in raw}
+        return cls(transformer=transformer, scheduler_config=sc)
+
+    def to(self, device=None, dtype=None):
+        if device is not None:
+            self._device = torch.device(device)
+        if dtype is not None:
+            self._dtype = dtype
+        if self.transformer is not None:
+            self.transformer.to(device=device, dtype=dtype)
+        return self
+
+    @torch.no_grad()
+    def __call__(self, prompt=None, prompt_2=None, condition_prompt=None, control_image=None, conditioning_scale: float = 1.0,
+                 height: Optional[int] = None, width: Optional[int] = None, num_inference_steps: int = 28, sigmas=None,
+                 guidance_scale: float = 3.5, generator=None, latents: Optional[torch.Tensor] = None,
+                 prompt_embeds: Optional[torch.Tensor] = None, pooled_prompt_embeds: Optional[torch.Tensor] = None,
+                 condition_pooled_prompt_embeds=None, condition_ids=None, output_type: str = "latent", return_dict: bool = True,
+                 max_sequence_length: int = 512, dtype: torch.dtype = BF, gate_uniforms=None, **kwargs):
+        if prompt is not None or condition_prompt is not None:
+            raise NotImplementedError("text encoders are outside this package's scope: pass prompt_embeds, pooled_prompt_embeds and "
+                                      "condition_pooled_prompt_embeds (as the reference's __call__ also accepts)")
+        if output_type != "latent":
+            raise NotImplementedError("the VAE is outside this package's scope: use output_type='latent'")
+        if prompt_embeds is None or pooled_prompt_embeds is None or condition_pooled_prompt_embeds is None or control_image is None:
+            raise ValueError("prompt_embeds, pooled_prompt_embeds, condition_pooled_prompt_embeds and control_image (packed latents) are required")
+        tr = self.transformer
+        dev = tr.device
+        multi = isinstance(control_image, (list, tuple))
+        height = height or self.default_sample_size * self.vae_scale_factor
+        width = width or self.default_sample_size * self.vae_scale_factor
+        hl, wl = height // (self.vae_scale_factor * 2), width // (self.vae_scale_factor * 2)
+        B = prompt_embeds.shape[0]
+        first = control_image[0] if multi else control_image
+        if first.ndim != 3:
+            raise ValueError("control_image must be packed condition latents [B, N, 4*C] (VAE encode + _pack_latents happen upstream)")
+        if latents is None:
+            latents = torch.randn(B, hl * wl, tr.config.in_channels, generator=generator, device=dev if generator is None or generator.device.type != "cpu" else "cpu",
+                                  dtype=torch.float32).to(dev)
+        latents = latents.to(device=dev, dtype=dtype).clone()
+        ids = prepare_latent_image_ids(hl, wl, dev, dtype)
+        if condition_ids is None:
+            condition_ids = [ids for _ in control_image] if multi else ids
+        text_ids = torch.zeros(prompt_embeds.shape[1], 3, device=dev, dtype=dtype)
+        cast = lambda t: t.to(device=dev, dtype=dtype)
+        out = denoise_loop(tr, latents=latents, control_tokens=[cast(c) for c in control_image] if multi else cast(control_image),
+                           prompt_embeds=cast(prompt_embeds), pooled_prompt_embeds=cast(pooled_prompt_embeds),
+                           condition_pooled_prompt_embeds=[cast(c) for c in condition_pooled_prompt_embeds] if multi else cast(condition_pooled_prompt_embeds),
+                           text_ids=text_ids, latent_image_ids=ids, condition_ids=condition_ids, num_inference_steps=num_inference_steps,
+                           sigmas=sigmas, guidance_scale=guidance_scale, conditioning_scale=conditioning_scale,
+                           shift=self.scheduler.config["shift"], use_dynamic_shifting=self.scheduler.config["use_dynamic_shifting"],
+                           gate_uniforms=gate_uniforms)
+        if not return_dict:
+            return (out,)
+        return SimpleNamespace(images=out)
