@@ -46,17 +46,19 @@ def canonical_flops_per_forward(D, N, T, n_double, n_single, n_cj, n_cs, n_cond,
     return base + ctrl + zero + comoe + embeds
 
 
-def cpu_baseline(device_count_note: str, budget_hint_s: float = 25.0):
-    """Time the CPU oracle (port of the reference) on a reduced-depth slice of the same 1024^2 workload."""
+def cpu_baseline(max_threads: int = 16):
+    """Time the CPU oracle (port of the reference) on a bounded, reduced slice of the same workload (rank 0, N=1 only).
+    The GPU box grants one GPU's share of the host (16 cores), so at most 16 threads are used whatever the affinity mask says."""
     from oracle import unigen_ref as R
-    cores = os.cpu_count() or 1
     try:
-        cores = len(os.sched_getaffinity(0))
+        avail = len(os.sched_getaffinity(0))
     except AttributeError:
-        pass
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, max_threads))
     torch.set_num_threads(cores)
-    cfg = R.FluxConfig(num_layers=2, num_single_layers=2)          # FLUX width (D=3072, H=24, dh=128), 1 control joint + 1 control single block
-    B, grid, T = 1, 64, 512
+    n_d, n_s = 6, 8                                                # depth cut: 6 of 19 double + 8 of 38 single base blocks, 3 + 4 control blocks
+    cfg = R.FluxConfig(num_layers=n_d, num_single_layers=n_s)      # FLUX width (D=3072, H=24, dh=128), full CoMoE
+    B, grid, T = 1, 64, 512                                        # one 1024x1024 sample: ~10-20 s of CPU work on 16 Zen5 cores
     st = R.make_state(cfg, seed=0)
     inp = R.make_inputs(cfg, B=B, grid=grid, T=T)
     t = torch.full((B,), 1.0, dtype=torch.bfloat16)
@@ -64,13 +66,23 @@ def cpu_baseline(device_count_note: str, budget_hint_s: float = 25.0):
     with torch.no_grad():
         R.unigen_flux_forward(st, cfg, timestep=t, dtype=torch.bfloat16, **inp)
     dt = time.perf_counter() - t0
-    sample_flops = canonical_flops_per_forward(cfg.inner_dim, grid * grid, T, 2, 2, 1, 1, 1)
+    sample_flops = canonical_flops_per_forward(cfg.inner_dim, grid * grid, T, n_d, n_s, cfg.cn_joint_layers, cfg.cn_single_layers, 1)
     full_flops_per_image = 4 * canonical_flops_per_forward(3072, 4096, 512, 19, 38, 9, 19, 1)
     img_per_s = (sample_flops / dt) / full_flops_per_image
-    return dict(value=img_per_s, unit="images/s", cores=cores, kind="port",
-                sample=(f"oracle (bf16 torch CPU restatement of the reference) on ONE forward at 1024^2, B=1, FLUX width, depth cut to 2 double + 2 single "
-                        f"base blocks (+1+1 control blocks, full CoMoE): {sample_flops / 1e12:.1f} TFLOP in {dt:.1f} s = {sample_flops / dt / 1e12:.2f} TFLOP/s; "
-                        f"scaled by algorithmic FLOPs to the full 4-step image ({full_flops_per_image / 1e12:.1f} TFLOP)"),
+    cpu_model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    cpu_model = ln.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return dict(value=img_per_s, unit="images/s", cores=cores, kind="port", cpu=cpu_model,
+                sample=(f"oracle (bf16 torch CPU restatement of the reference) on ONE forward, B=1, 1024^2 (N=4096, T=512), FLUX width, depth cut to "
+                        f"{n_d} double + {n_s} single base blocks (+{cfg.cn_joint_layers}+{cfg.cn_single_layers} control blocks, full CoMoE): {sample_flops / 1e12:.2f} TFLOP in {dt:.1f} s = "
+                        f"{sample_flops / dt / 1e12:.3f} TFLOP/s on {cores} threads; scaled by algorithmic FLOPs to the full 1024^2 4-step image "
+                        f"({full_flops_per_image / 1e12:.1f} TFLOP)"),
                 sample_seconds=dt, sample_tflops=sample_flops / 1e12)
 
 
@@ -95,10 +107,10 @@ def main():
         raise SystemExit("bench.py needs an MI355X: unigen_amd has no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    from unigen_amd import dist_utils as DU
+    rank, world = DU.init_distributed(dev)
     if world > 1:
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
 
     from unigen_amd import ops
     from unigen_amd.flux import UniGenFlux
@@ -111,7 +123,7 @@ def main():
 
     B, grid, T, steps_per_image = args.batch, 64, 512, 4
     N = grid * grid
-    g = torch.Generator(device=dev).manual_seed(12443 + rank)          # reference default seed (infer.py:61) + rank
+    g = torch.Generator(device=dev).manual_seed(DU.rank_seed(12443, rank))   # reference default seed (infer.py:61) + rank
     rn = lambda *s: torch.randn(*s, generator=g, device=dev, dtype=torch.float32)
     latents0 = rn(B, N, 64).to(torch.bfloat16)
     control = rn(B, N, 64).to(torch.bfloat16)
@@ -128,9 +140,7 @@ def main():
                             num_inference_steps=steps_per_image, gate_uniforms=uniforms)
 
     def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+        DU.barrier(dev, world)
 
     for _ in range(args.warmup):
         out = one_step()
@@ -145,10 +155,7 @@ def main():
     ops.set_timer(None)
     if not torch.isfinite(out.float()).all():
         raise SystemExit("non-finite latents after denoising")
-    if world > 1:
-        te = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = float(te.item())
+    elapsed = DU.max_over_ranks(elapsed, dev, world)
 
     if rank == 0:
         images = B * args.steps * world
@@ -178,7 +185,7 @@ def main():
                                                   unit="TFLOP/s", frac=a2 / MFMA_BF16_PEAK_TFLOPS, launches=at["launches"],
                                                   avg_launch_us=1000.0 * at["ms"] / at["launches"], share_of_step_time=at["ms"] * 1e-3 / elapsed)
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline("")
+            line["cpu_baseline"] = cpu_baseline()
             line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -1,0 +1,168 @@
+"""CPU tests of the oracle (oracle/unigen_ref.py): internal consistency of the restated algorithms, pins against the committed
+golden fixtures, and the size-independent properties the parity tests rely on. The reference ships no tests or vectors
+(SURVEY section 4), so these pin the oracle against drift, not against reference-generated data ("parity unpinned")."""
+import json
+import math
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+from safetensors import safe_open
+
+from oracle import unigen_ref as R
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TINY = dict(num_layers=2, num_single_layers=4, attention_head_dim=128, num_attention_heads=2, joint_attention_dim=64, pooled_projection_dim=64)
+
+
+def load_golden(name):
+    tensors = {}
+    with safe_open(os.path.join(GOLD, name + ".safetensors"), "pt") as f:
+        meta = f.metadata()
+        for k in f.keys():
+            tensors[k] = f.get_tensor(k)
+    case = json.loads(meta["case"])
+    cfg = json.loads(meta["config"])
+    inp = {}
+    for k, v in tensors.items():
+        if k.startswith("in."):
+            parts = k.split(".")
+            if len(parts) == 3:
+                inp.setdefault(parts[1], {})[int(parts[2])] = v
+            else:
+                inp[parts[1]] = v
+    inp = {k: ([v[i] for i in sorted(v)] if isinstance(v, dict) else v) for k, v in inp.items()}
+    return cfg, case, inp, tensors
+
+
+@pytest.mark.parametrize("name", ["flux_tiny_single", "flux_tiny_multi3"])
+def test_oracle_reproduces_golden(name):
+    cfg_d, case, inp, g = load_golden(name)
+    cfg = R.FluxConfig(condition_nums=case["n_cond"], **cfg_d)
+    st = R.make_state(cfg, seed=case["state_seed"], std=0.05, bias_std=0.02)
+    out16, loss, cnt = R.unigen_flux_forward(st, cfg, timestep=g["timestep"], dtype=torch.bfloat16, **inp)
+    assert torch.equal(cnt["expert_counts"], g["out.expert_counts"])
+    # same container, same torch build -> bitwise; keep a small tolerance for other CPUs' matmul kernels
+    assert float((out16.float() - g["out.bf16"].float()).norm() / g["out.bf16"].float().norm()) <= 2e-2
+    out32 = R.unigen_flux_forward(st, cfg, timestep=g["timestep"], dtype=torch.float32, **inp)[0]
+    assert float((out32 - g["out.fp32"]).norm() / g["out.fp32"].norm()) <= 1e-4
+    assert abs(float(loss["moe_loss"]) - float(g["out.moe_loss"])) <= 1e-4
+
+
+def test_top1gating_dense_equals_index_form():
+    """deepspeed's S x E x C one-hot tensors say exactly what (idx, slot) say; dropped tokens have all-zero rows."""
+    g = torch.Generator().manual_seed(0)
+    S, E = 200, 6
+    logits = torch.randn(S, E, generator=g)
+    logits[:, 2] += 1.5                       # overload expert 2 so that RTS must drop tokens
+    uni = torch.rand(S, E, generator=g)
+    C = R.moe_capacity(S, E)
+    l_aux, cw, dm, cnt = R.top1gating(logits, uni, C)
+    gates = F.softmax(logits, dim=1)
+    idx, slot, tos = R.routing_from_gates(gates, uni, C)
+    assert int(cnt[2]) > C and int((slot < 0).sum()) == int(cnt[2]) - C + sum(max(int(cnt[e]) - C, 0) for e in range(E) if e != 2)
+    for s in range(S):
+        nz = torch.nonzero(cw[s])
+        if slot[s] < 0:
+            assert nz.numel() == 0
+        else:
+            assert nz.tolist() == [[int(idx[s]), int(slot[s])]]
+            assert cw[s, idx[s], slot[s]] == gates[s, idx[s]]
+            assert int(tos[idx[s], slot[s]]) == s
+    # kept tokens of an overloaded expert are the `capacity` largest uniforms, slots in token order
+    toks = torch.nonzero(idx == 2).flatten()
+    kept = toks[slot[toks] >= 0]
+    assert kept.numel() == C
+    assert uni[kept, 2].min() > uni[toks[slot[toks] < 0], 2].max()
+    assert torch.equal(slot[kept], torch.arange(C))
+    # l_aux = E * sum_e mean(gates_e) * mean(mask_e)
+    me, ce = gates.mean(0), F.one_hot(idx, E).float().mean(0)
+    assert abs(float(l_aux) - float((me * ce).sum() * E)) < 1e-6
+    assert R.moe_capacity(10, 6) == 4 and R.moe_capacity(16384, 6) == 2731
+
+
+def test_modulated_flatten_literal_equals_linear_of_scaled_input():
+    """src/UniGenUtils.py:204-228 (b x n x o x i temp) == Linear_W(s * x): the restatement used at scale."""
+    g = torch.Generator().manual_seed(1)
+    x, w, s = torch.randn(1, 9, 32, generator=g), torch.randn(48, 32, generator=g), torch.randn(1, 9, 32, generator=g)
+    a, b = R.modulated_flatten_literal(x, w, s), R.modulated_linear(x, w, s)
+    assert torch.allclose(a, b, rtol=1e-5, atol=1e-5)
+
+
+def test_comoe_literal_dense_path_equals_index_path():
+    cfg = R.FluxConfig(**TINY)
+    st = {k: v.float() for k, v in R.make_state(cfg, seed=3, std=0.05, bias_std=0.02).items()}
+    g = torch.Generator().manual_seed(2)
+    B, N, D = 2, 16, cfg.inner_dim
+    x, c = torch.randn(B, N, D, generator=g), torch.randn(B, N, D, generator=g)
+    pooled, cpooled = torch.randn(B, 64, generator=g), torch.randn(B, 64, generator=g)
+    uni = torch.rand(B * N, cfg.expert_nums, generator=g)
+    a = R.comoe_experts(st, cfg, x, c, pooled, cpooled, None, uni, literal=True)
+    b = R.comoe_experts(st, cfg, x, c, pooled, cpooled, None, uni, literal=False)
+    assert torch.allclose(a[0], b[0], rtol=1e-4, atol=1e-5) and torch.allclose(a[1], b[1], rtol=1e-4, atol=1e-5)
+    assert torch.equal(a[3], b[3])
+    # dropped tokens get exactly zero expert output
+    dropped = (b[4]["slot"] < 0).reshape(B, N)
+    assert torch.all(b[0][dropped] == 0) and torch.all(b[1][dropped] == 0)
+
+
+def test_embeddings_rope_norms_known_answers():
+    t = torch.tensor([0.0, 1.0, 1000.0])
+    e = R.timestep_sinusoid(t)
+    assert e.shape == (3, 256)
+    assert torch.allclose(e[0, :128], torch.ones(128)) and torch.allclose(e[0, 128:], torch.zeros(128))       # [cos | sin]
+    assert abs(float(e[1, 0]) - math.cos(1.0)) < 1e-6 and abs(float(e[1, 128]) - math.sin(1.0)) < 1e-6
+    assert abs(float(e[2, 127]) - math.cos(1000.0 * math.exp(-math.log(10000) * 127 / 128))) < 1e-4
+    ids = R.make_ids(4, 5, torch.float32)
+    assert ids.shape == (20, 3) and ids[7].tolist() == [0.0, 1.0, 2.0]
+    cos, sin = R.flux_pos_embed(ids, (16, 56, 56))
+    assert cos.shape == (20, 128) and torch.all(cos[0] == 1) and torch.all(sin[0] == 0)
+    assert torch.equal(cos[:, 0::2], cos[:, 1::2])                                                            # repeat_interleave(2)
+    # rotation preserves pair norms; position 0 is the identity
+    x = torch.randn(1, 2, 20, 128)
+    y = R.apply_rotary_emb(x, cos, sin)
+    assert torch.allclose(y[:, :, 0], x[:, :, 0]) and torch.allclose(y.pow(2).sum(-1), x.pow(2).sum(-1), rtol=1e-4)
+    # RMSNorm / AdaLayerNormContinuous (scale first)
+    v = torch.randn(3, 128)
+    assert torch.allclose(R.rms_norm(v, torch.ones(128)).pow(2).mean(-1), torch.ones(3), atol=1e-4)
+    st = {"n.linear.weight": torch.zeros(8, 4), "n.linear.bias": torch.tensor([1., 1, 1, 1, 5, 5, 5, 5])}
+    out = R.adaln_continuous(st, "n", torch.randn(2, 3, 4), torch.randn(2, 4))
+    assert torch.allclose(out.mean(-1), torch.full((2, 3), 5.0), atol=1e-4)                                    # LN*(1+1)+5
+
+
+def test_schedule_and_euler():
+    s = R.schnell_sigmas(4)
+    assert torch.allclose(s, torch.tensor([1.0, 0.75, 0.5, 0.25, 0.0]))
+    x, v = torch.randn(2, 4, 8).bfloat16(), torch.randn(2, 4, 8).bfloat16()
+    y = R.euler_step(x, v, 1.0, 0.75)
+    assert y.dtype == torch.bfloat16 and torch.equal(y, (x.float() - 0.25 * v.float()).bfloat16())
+    # bf16 timestep quirk of the reference: 0.75 -> 752 (not 750) after `.to(bf16) * 1000`
+    assert float((torch.tensor(0.75).bfloat16() * 1000)) == 752.0
+
+
+def test_control_blocks_read_base_stream_and_zero_res_gates_the_control_path():
+    """With the zero-res projections at zero (the reference's init) the control path is invisible: output == base FLUX output
+    whatever the condition is; with conditioning_scale the contribution scales."""
+    cfg = R.FluxConfig(**TINY)
+    st = R.make_state(cfg, seed=5, std=0.05, bias_std=0.02)
+    for k in st:
+        if k.startswith("controlnet_add_"):
+            st[k] = torch.zeros_like(st[k])
+    inp = R.make_inputs(cfg, B=1, grid=4, T=8)
+    t = torch.full((1,), 0.5, dtype=torch.bfloat16)
+    a = R.unigen_flux_forward(st, cfg, timestep=t, dtype=torch.float32, **inp)[0]
+    inp2 = dict(inp); inp2["condition_hidden_states"] = torch.randn_like(inp["condition_hidden_states"].float()).bfloat16()
+    b = R.unigen_flux_forward(st, cfg, timestep=t, dtype=torch.float32, **inp2)[0]
+    assert torch.equal(a, b)
+    # block map of src/UniGenTransformer.py:1126-1127 at FLUX depth
+    assert [int(i / (19 / 9)) for i in range(19)] == [0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8]
+    assert [int(j / (38 / 19)) for j in range(38)] == [j // 2 for j in range(38)]
+
+
+def test_lora_formula():
+    g = torch.Generator().manual_seed(0)
+    x, w, b = torch.randn(5, 16, generator=g), torch.randn(8, 16, generator=g), torch.randn(8, generator=g)
+    A, Bm = torch.randn(4, 16, generator=g), torch.randn(8, 4, generator=g)
+    y = R.lora_linear(x, w, b, [(A, Bm, 0.5)])
+    assert torch.allclose(y, x @ (w + 0.5 * Bm @ A).t() + b, atol=1e-5)
