@@ -59,7 +59,7 @@ def cpu_baseline(max_threads: int = 16):
     n_d, n_s = 6, 8                                                # depth cut: 6 of 19 double + 8 of 38 single base blocks, 3 + 4 control blocks
     cfg = R.FluxConfig(num_layers=n_d, num_single_layers=n_s)      # FLUX width (D=3072, H=24, dh=128), full CoMoE
     B, grid, T = 1, 64, 512                                        # one 1024x1024 sample: ~10-20 s of CPU work on 16 Zen5 cores
-    st = R.make_state(cfg, seed=0)
+    st = R.make_state(cfg, seed=0, fast=True)
     inp = R.make_inputs(cfg, B=B, grid=grid, T=T)
     t = torch.full((B,), 1.0, dtype=torch.bfloat16)
     t0 = time.perf_counter()
