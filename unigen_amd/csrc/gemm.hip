@@ -13,6 +13,7 @@
 // up with 4 consecutive n for one m -> 8-byte row-major stores. Tails in M/N are handled by clamping load rows and
 // predicating stores; K must be a multiple of 64.
 #include "ug_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -56,6 +57,52 @@ __device__ __forceinline__ float gelu_tanh(float x) {
     const float e = __expf(2.0f * u);
     const float t = 1.0f - 2.0f / (1.0f + e);
     return 0.5f * x * (1.0f + t);
+}
+
+__device__ __forceinline__ void load_bias4(const bf16_t* bias, int64_t n, float* bv) {
+    bv[0] = bv[1] = bv[2] = bv[3] = 0.f;
+    if (bias) {
+        const u32x2 b2 = *(const u32x2*)(bias + n);
+        bv[0] = bflo(b2.x); bv[1] = bfhi(b2.x); bv[2] = bflo(b2.y); bv[3] = bfhi(b2.y);
+    }
+}
+
+// one lane's 4 consecutive n of row m: v = bf16(acc + bias) then the fused elementwise tail, 8-byte store
+template <int EPI>
+__device__ __forceinline__ void epi_store(const ug_gemm_desc& p, int g, int64_t m, int64_t n, const f32x4 a, const float* bv) {
+    float v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = a[r] + bv[r];
+    const int64_t cg = (int64_t)g * p.c_gstride;
+    const int64_t crow = ug_rowmap(m, p.c_rpb, p.c_bstride);
+    if constexpr (EPI == UG_EPI_F32) {
+        float* C = (float*)p.C + cg + crow * p.ldc + n;
+        *(f32x4*)C = (f32x4){v[0], v[1], v[2], v[3]};
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = rbf(v[r]);
+        if constexpr (EPI == UG_EPI_BIAS_GELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = gelu_tanh(v[r]);
+        } else if constexpr (EPI == UG_EPI_RES_GATE || EPI == UG_EPI_RES_SCALE) {
+            const bf16_t* R = (const bf16_t*)p.R + ug_rowmap(m, p.r_rpb, p.r_bstride) * p.ldr + n;
+            const u32x2 r2 = *(const u32x2*)R;
+            const float rv[4] = {bflo(r2.x), bfhi(r2.x), bflo(r2.y), bfhi(r2.y)};
+            if constexpr (EPI == UG_EPI_RES_GATE) {
+                const bf16_t* G = (const bf16_t*)p.gate + (m / p.rows_per_sample) * p.gate_ld + n;
+                const u32x2 g2 = *(const u32x2*)G;
+                const float gv[4] = {bflo(g2.x), bfhi(g2.x), bflo(g2.y), bfhi(g2.y)};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = rv[r] + rbf(gv[r] * v[r]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = rv[r] + rbf(p.alpha * v[r]);
+            }
+        }
+        bf16_t* C = (bf16_t*)p.C + cg + crow * p.ldc + n;
+        u32x2 o; o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]);
+        *(u32x2*)C = o;
+    }
 }
 
 template <int EPI>
@@ -148,66 +195,208 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(const ug_gemm_desc p) {
 
     // ---- epilogue: lane holds D[row = n (4 consecutive)][col = m] ------------------------------------------
     const bf16_t* bias = p.bias ? (const bf16_t*)p.bias + (int64_t)g * p.bias_gstride : nullptr;
-    const int64_t cg = (int64_t)g * p.c_gstride;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int64_t n = n0 + wc * 64 + j * 16 + (lane >> 4) * 4;
         if (n >= N) continue;
-        float bv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (bias) {
-            const u32x2 b2 = *(const u32x2*)(bias + n);
-            bv[0] = bflo(b2.x); bv[1] = bfhi(b2.x); bv[2] = bflo(b2.y); bv[3] = bfhi(b2.y);
-        }
+        float bv[4];
+        load_bias4(bias, n, bv);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int64_t m = m0 + wr * 64 + i * 16 + (lane & 15);
             if (m >= M) continue;
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + bv[r];
-            const int64_t crow = ug_rowmap(m, p.c_rpb, p.c_bstride);
-            if constexpr (EPI == UG_EPI_F32) {
-                float* C = (float*)p.C + cg + crow * p.ldc + n;
-                *(f32x4*)C = (f32x4){v[0], v[1], v[2], v[3]};
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = rbf(v[r]);
-                if constexpr (EPI == UG_EPI_BIAS_GELU) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = gelu_tanh(v[r]);
-                } else if constexpr (EPI == UG_EPI_RES_GATE || EPI == UG_EPI_RES_SCALE) {
-                    const bf16_t* R = (const bf16_t*)p.R + ug_rowmap(m, p.r_rpb, p.r_bstride) * p.ldr + n;
-                    const u32x2 r2 = *(const u32x2*)R;
-                    const float rv[4] = {bflo(r2.x), bfhi(r2.x), bflo(r2.y), bfhi(r2.y)};
-                    if constexpr (EPI == UG_EPI_RES_GATE) {
-                        const bf16_t* G = (const bf16_t*)p.gate + (m / p.rows_per_sample) * p.gate_ld + n;
-                        const u32x2 g2 = *(const u32x2*)G;
-                        const float gv[4] = {bflo(g2.x), bfhi(g2.x), bflo(g2.y), bfhi(g2.y)};
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = rv[r] + rbf(gv[r] * v[r]);
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = rv[r] + rbf(p.alpha * v[r]);
-                    }
-                }
-                bf16_t* C = (bf16_t*)p.C + cg + crow * p.ldc + n;
-                u32x2 o; o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]);
-                *(u32x2*)C = o;
-            }
+            epi_store<EPI>(p, g, m, n, acc[i][j], bv);
         }
     }
 }
 
+// =====================================================================================================================
+// 256x256x64 tile, 512 threads = 8 waves, one workgroup per CU (128 KiB LDS), for the large projections.
+//
+// Each K-tile is four 128x64 half-tiles (slots A0, B0, B1, A1; 16 KiB each, same swizzled image as above), two K-tile
+// buffers. Wave (wr, wc) owns rows {i*128 + wr*64 .. +64 : i = 0,1} and columns {j*128 + wc*32 .. +32 : j = 0,1}, i.e. four
+// 64x32 quadrants (i, j); a phase computes one quadrant (16 MFMAs) and needs only ONE new operand sub-tile:
+//   phase 0: (0,0) reads A0,B0 | phase 1: (0,1) reads B1 | phase 2: (1,1) reads A1 | phase 3: (1,0) re-reads B0.
+// Every phase is  L: {ds_read sub-tile, issue the LDS-DMA of one half-tile of the NEXT K-tile, counted vmcnt}  s_barrier
+// M: {16 MFMAs}  s_barrier.  Waves 4-7 (wr = 1) run one barrier behind waves 0-3: a SIMD hosts wave w and w+4, so one of
+// its two waves is always in an M segment while the other is in an L segment (cdna guide, "two waves per SIMD" item 9).
+// Loads stay in flight across barriers: vmcnt(4) keeps the two youngest half-tiles outstanding; raw s_barrier, never
+// __syncthreads. Hazards: a half-tile is waited for (by every wave, for its own DMA) at the end of the L segment BEFORE the
+// M segment that precedes its first read, so the wait of the late group still precedes the early group's read by a
+// barrier; a slot is re-staged >= 3 segments after its last ds_read.
+// =====================================================================================================================
+constexpr int HT_BYTES = 128 * 64 * 2;
+constexpr int KT_BYTES = 4 * HT_BYTES;
+constexpr int LDS256_BYTES = 2 * KT_BYTES;
+constexpr int SLOT_A0 = 0, SLOT_B0 = HT_BYTES, SLOT_B1 = 2 * HT_BYTES, SLOT_A1 = 3 * HT_BYTES;
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int64_t M = p.M, N = p.N;
+    const int nM = (int)((M + 255) / 256), nN = (int)((N + 255) / 256);
+    const TileCoord tc = tile_of_block(blockIdx.x, nM, nN);
+    const int64_t m0 = (int64_t)tc.tm * 256, n0 = (int64_t)tc.tn * 256;
+    const int g = blockIdx.z;
+    const bf16_t* Ab = (const bf16_t*)p.A + (int64_t)g * p.a_gstride;
+    const bf16_t* Wb = (const bf16_t*)p.W + (int64_t)g * p.w_gstride;
+
+    f32x4 acc[2][2][4][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[i][j][a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // staging: each wave moves rows [wave*16, wave*16+16) of every half-tile with two 1-KiB LDS-DMA instructions
+    const bf16_t* srcA[2][2]; const bf16_t* srcB[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = wave * 16 + i * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ (row & 7);
+            int64_t am = m0 + h * 128 + row; if (am > M - 1) am = M - 1;
+            int64_t wn = n0 + h * 128 + row; if (wn > N - 1) wn = N - 1;
+            srcA[h][i] = Ab + ug_rowmap(am, p.a_rpb, p.a_bstride) * p.lda + c * 8;
+            srcB[h][i] = Wb + wn * p.ldw + c * 8;
+        }
+    const int st_off = wave * 16 * 128;
+    auto stage = [&](unsigned char* slot, const bf16_t* const (&src)[2], int64_t ko) {
+        glds16(src[0] + ko, slot + st_off);
+        glds16(src[1] + ko, slot + st_off + 8 * 128);
+    };
+    // fragment reads
+    const int frow = lane & 15, fch = lane >> 4, fsw = lane & 7;
+    const int a_off = (wr * 64 + frow) * 128, b_off = (wc * 32 + frow) * 128;
+    const int ch0 = ((fch ^ fsw) << 4), ch1 = (((4 + fch) ^ fsw) << 4);
+    bf16x8 areg[4][2], breg[2][2];
+    auto read_A = [&](const unsigned char* slot) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            areg[mt][0] = *(const bf16x8*)(slot + a_off + mt * 2048 + ch0);
+            areg[mt][1] = *(const bf16x8*)(slot + a_off + mt * 2048 + ch1);
+        }
+    };
+    auto read_B = [&](const unsigned char* slot) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            breg[nt][0] = *(const bf16x8*)(slot + b_off + nt * 2048 + ch0);
+            breg[nt][1] = *(const bf16x8*)(slot + b_off + nt * 2048 + ch1);
+        }
+    };
+#define UG_MMA_QUADRANT(I, J)                                                                                          \
+    do {                                                                                                               \
+        __builtin_amdgcn_s_setprio(1);                                                                                 \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                               \
+            _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                           \
+                _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                       \
+                    acc[I][J][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(breg[nt][ks], areg[mt][ks], acc[I][J][mt][nt], 0, 0, 0); \
+        __builtin_amdgcn_s_setprio(0);                                                                                 \
+    } while (0)
+#define UG_BARRIER() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
+
+    const int nk = (int)(p.K / BK);
+    // prologue: the whole first K-tile
+    stage(smem + SLOT_A0, srcA[0], 0); stage(smem + SLOT_B0, srcB[0], 0);
+    stage(smem + SLOT_B1, srcB[1], 0); stage(smem + SLOT_A1, srcA[1], 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    UG_BARRIER();
+    if (wr == 1) UG_BARRIER();          // waves 4-7 run one barrier behind
+    for (int kt = 0; kt < nk; ++kt) {
+        unsigned char* cb = smem + (kt & 1) * KT_BYTES;
+        unsigned char* nb = smem + ((kt & 1) ^ 1) * KT_BYTES;
+        const bool has_next = kt + 1 < nk;
+        const int64_t kn = (int64_t)(kt + 1) * BK;
+        // phase 0: quadrant (0,0)
+        read_A(cb + SLOT_A0); read_B(cb + SLOT_B0);
+        if (has_next) { stage(nb + SLOT_A0, srcA[0], kn); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }   // B1(kt) landed
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        UG_BARRIER();
+        UG_MMA_QUADRANT(0, 0);
+        UG_BARRIER();
+        // phase 1: quadrant (0,1)
+        read_B(cb + SLOT_B1);
+        if (has_next) { stage(nb + SLOT_B0, srcB[0], kn); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }   // A1(kt) landed
+        UG_BARRIER();
+        UG_MMA_QUADRANT(0, 1);
+        UG_BARRIER();
+        // phase 2: quadrant (1,1)
+        read_A(cb + SLOT_A1);
+        if (has_next) stage(nb + SLOT_B1, srcB[1], kn);
+        UG_BARRIER();
+        UG_MMA_QUADRANT(1, 1);
+        UG_BARRIER();
+        // phase 3: quadrant (1,0)
+        read_B(cb + SLOT_B0);
+        if (has_next) { stage(nb + SLOT_A1, srcA[1], kn); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }   // A0,B0(kt+1) landed
+        UG_BARRIER();
+        UG_MMA_QUADRANT(1, 0);
+        UG_BARRIER();
+    }
+    if (wr == 0) UG_BARRIER();
+#undef UG_MMA_QUADRANT
+#undef UG_BARRIER
+
+    const bf16_t* bias = p.bias ? (const bf16_t*)p.bias + (int64_t)g * p.bias_gstride : nullptr;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int64_t n = n0 + j * 128 + wc * 32 + nt * 16 + (lane >> 4) * 4;
+            if (n >= N) continue;
+            float bv[4];
+            load_bias4(bias, n, bv);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    const int64_t m = m0 + i * 128 + wr * 64 + mt * 16 + (lane & 15);
+                    if (m >= M) continue;
+                    epi_store<EPI>(p, g, m, n, acc[i][j][mt][nt], bv);
+                }
+        }
+}
+
+// UG_GEMM_FORCE_TILE=128|256 pins the kernel choice (tests / A-B timing); default: 256^2 tiles when they fill the chip.
+int forced_tile() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("UG_GEMM_FORCE_TILE");
+        v = e ? atoi(e) : 0;
+    }
+    return v;
+}
+
 template <int EPI>
 int launch(const ug_gemm_desc& d, hipStream_t s) {
-    const int nM = (int)((d.M + BM - 1) / BM), nN = (int)((d.N + BN - 1) / BN);
-    dim3 grid((unsigned)(nM * nN), 1, (unsigned)(d.groups > 0 ? d.groups : 1));
+    const int groups = d.groups > 0 ? d.groups : 1;
+    const int64_t t256 = ((d.M + 255) / 256) * ((d.N + 255) / 256) * groups;
+    bool big = d.lora_r <= 0 && d.M >= 256 && d.N >= 256 && t256 >= 384;     // >= 1.5 tiles per CU
+    const int f = forced_tile();
+    if (f == 128) big = false;
+    if (f == 256 && d.lora_r <= 0) big = true;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)gemm128_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm256_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256_BYTES);
         attr_set = true;
     }
-    hipLaunchKernelGGL(gemm128_kernel<EPI>, grid, dim3(256), LDS_BYTES, s, d);
+    if (big) {
+        dim3 grid((unsigned)(t256 / groups), 1, (unsigned)groups);
+        hipLaunchKernelGGL(gemm256_kernel<EPI>, grid, dim3(512), LDS256_BYTES, s, d);
+    } else {
+        const int nM = (int)((d.M + BM - 1) / BM), nN = (int)((d.N + BN - 1) / BN);
+        dim3 grid((unsigned)(nM * nN), 1, (unsigned)groups);
+        hipLaunchKernelGGL(gemm128_kernel<EPI>, grid, dim3(256), LDS_BYTES, s, d);
+    }
     UG_CHECK_LAUNCH("ug_gemm_bf16");
     return UG_OK;
 }
