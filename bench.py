@@ -175,7 +175,7 @@ def main():
             s = timer.summary()
             gm, at = s.get("gemm"), s.get("attn")
             ach = gm["flops"] / (gm["ms"] * 1e-3) / 1e12
-            line["roofline"] = dict(bound="mfma", kernel="gemm128_kernel (ug_gemm_bf16)", achieved=ach, peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s",
+            line["roofline"] = dict(bound="mfma", kernel="gemm256_kernel / gemm128_kernel (ug_gemm_bf16)", achieved=ach, peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s",
                                     frac=ach / MFMA_BF16_PEAK_TFLOPS, traffic=None, launches=gm["launches"],
                                     avg_launch_us=1000.0 * gm["ms"] / gm["launches"], avg_launch_gflop=gm["flops"] / gm["launches"] / 1e9,
                                     share_of_step_time=gm["ms"] * 1e-3 / elapsed)

@@ -12,10 +12,10 @@
 //   O^T = V^T P^T : the S^T accumulator registers 8s..8s+7, packed to bf16, ARE the B operand of k-step s (permuted k
 //                 order, matched by the key order of the transposed V reads) - P never touches LDS or other lanes.
 #include "ug_common.h"
+#include <stdlib.h>
 
 namespace {
 
-constexpr int QROWS = 256;   // query rows per workgroup
 constexpr int KVB = 64;      // keys per tile
 
 typedef __attribute__((address_space(3))) bf16x4* lds_b64_ptr;
@@ -31,11 +31,13 @@ __device__ __forceinline__ bf16x8 tr_read_pair(const unsigned char* lo, const un
     return (bf16x8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
 }
 
-__global__ __launch_bounds__(512, 2) void flash_attn128_kernel(
+template <int NW>   // waves per workgroup: 8 (256 query rows, 1 workgroup / CU) or 4 (128 rows, 2 independent workgroups / CU)
+__global__ __launch_bounds__(64 * NW, 2) void flash_attn128_kernel(
     const bf16_t* __restrict__ q, int64_t q_rs, int64_t q_bs, const bf16_t* __restrict__ k, int64_t k_rs, int64_t k_bs,
     const bf16_t* __restrict__ v, int64_t v_rs, int64_t v_bs, bf16_t* __restrict__ o, int64_t o_rs, int64_t o_bs,
     int heads, int Lq, int Lkv, int nQ, float c /* softmax_scale * log2(e) */) {
     constexpr int DH = 128;
+    constexpr int QROWS = 32 * NW, NT = 64 * NW, NST = 1024 / NT;          // staging chunks of K (and of V) per thread and tile
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [2][K 16 KiB | V 16 KiB]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -59,19 +61,23 @@ __global__ __launch_bounds__(512, 2) void flash_attn128_kernel(
     bf16x8 qf[8];
 #pragma unroll
     for (int s = 0; s < 8; ++s) qf[s] = *(const bf16x8*)(Qb + (int64_t)q_ld * q_rs + 16 * s + 8 * h);
+    // Retire the Q loads HERE: the empty asm takes every fragment as a read-write operand, so hipcc must have the loaded
+    // values in hand before it (it waits vmcnt there) and treats them as fresh afterwards. Without it the loads are sunk to
+    // the loop header and every iteration re-waits for them with vmcnt(7..0), draining the K/V prefetch issued at its top.
+    asm volatile("" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3]), "+v"(qf[4]), "+v"(qf[5]), "+v"(qf[6]), "+v"(qf[7]));
 
     // ---- staging assignment: thread -> 2 chunks of K and 2 of V per tile ----
-    int st_row[2], st_ch[2], st_off[2];
+    int st_row[NST], st_ch[NST], st_off[NST];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int cid = tid + 512 * u;
+    for (int u = 0; u < NST; ++u) {
+        const int cid = tid + NT * u;
         st_row[u] = cid >> 4; st_ch[u] = cid & 15;
         st_off[u] = img_off(st_row[u], st_ch[u]);
     }
-    u32x4 kreg[2], vreg[2];
+    u32x4 kreg[NST], vreg[NST];
     auto stage_load = [&](int kv0) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < NST; ++u) {
             int key = kv0 + st_row[u]; if (key > Lkv - 1) key = Lkv - 1;
             kreg[u] = *(const u32x4*)(Kb + (int64_t)key * k_rs + st_ch[u] * 8);
             vreg[u] = *(const u32x4*)(Vb + (int64_t)key * v_rs + st_ch[u] * 8);
@@ -81,7 +87,7 @@ __global__ __launch_bounds__(512, 2) void flash_attn128_kernel(
         unsigned char* Kbuf = smem + buf * 32768;
         unsigned char* Vbuf = Kbuf + 16384;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < NST; ++u) {
             *(u32x4*)(Kbuf + st_off[u]) = kreg[u];
             *(u32x4*)(Vbuf + st_off[u]) = vreg[u];
         }
@@ -124,17 +130,29 @@ __global__ __launch_bounds__(512, 2) void flash_attn128_kernel(
         const unsigned char* Vbuf = Kbuf + 16384;
         if (t + 1 < ntiles) stage_load(kv0 + KVB);
 
-        // ---- S^T[key][q] ----
+        // ---- S^T[key][q]: all 8 K fragments of key block 0 first, then block-0 MFMAs with the block-1 reads between them ----
         f32x16 sacc[2];
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+        for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int i = 0; i < 16; ++i) sacc[kb][i] = 0.f;
+        {
+            bf16x8 kf0[8], kf1[8];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) kf0[s] = *(const bf16x8*)(Kbuf + k_rowoff + 16 * ((2 * s) ^ kx));
+#pragma unroll
+            for (int s = 0; s < 8; ++s) kf1[s] = *(const bf16x8*)(Kbuf + 8192 + k_rowoff + 16 * ((2 * s) ^ kx));
+#pragma unroll
+            for (int s = 0; s < 8; ++s) sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0[s], qf[s], sacc[0], 0, 0, 0);
+#pragma unroll
+            for (int s = 0; s < 8; ++s) sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1[s], qf[s], sacc[1], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);            // 8 ds_read (block 0)
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
-                const bf16x8 kf = *(const bf16x8*)(Kbuf + kb * 8192 + k_rowoff + 16 * ((2 * s) ^ kx));
-                sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc[kb], 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);        // 1 MFMA (block 0)
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);        // 1 ds_read (block 1)
             }
+            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);            // 8 MFMA (block 1)
         }
         if (kv0 + KVB > Lkv) {   // ragged last tile: keys >= Lkv do not exist
 #pragma unroll
@@ -180,14 +198,26 @@ __global__ __launch_bounds__(512, 2) void flash_attn128_kernel(
                 pf[kb][s2] = __builtin_bit_cast(bf16x8, w);
             }
         }
-        // ---- O^T[d][q] += V^T[d][key] P^T[key][q] ----
+        // ---- O^T[d][q] += V^T[d][key] P^T[key][q]: the V fragments of d-block db+1 are read between the MFMAs of block db ----
+        {
+            bf16x8 vf[4][4];
 #pragma unroll
-        for (int db = 0; db < 4; ++db) {
+            for (int db = 0; db < 4; ++db)
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const bf16x8 vf = tr_read_pair(Vbuf + ks * 4096 + voff_lo[db], Vbuf + ks * 4096 + voff_hi[db]);
-                oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[ks >> 1][ks & 1], oacc[db], 0, 0, 0);
+                for (int ks = 0; ks < 4; ++ks)
+                    vf[db][ks] = tr_read_pair(Vbuf + ks * 4096 + voff_lo[db], Vbuf + ks * 4096 + voff_hi[db]);
+#pragma unroll
+            for (int db = 0; db < 4; ++db)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+                    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[db][ks], pf[ks >> 1][ks & 1], oacc[db], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 8, 1);            // 8 tr reads (d-block 0)
+#pragma unroll
+            for (int i = 0; i < 12; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);        // 1 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 1);        // 2 tr reads of the next d-block
             }
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 1);            // last d-block
         }
         if (t + 1 < ntiles) stage_write(cur ^ 1);
         __syncthreads();
@@ -225,13 +255,21 @@ extern "C" int ug_flash_attn_fwd(const void* q, int64_t q_row_stride, int64_t q_
                q_batch_stride % 8 == 0 && k_batch_stride % 8 == 0 && v_batch_stride % 8 == 0 && o_batch_stride % 4 == 0 &&
                ug_aligned(q, 16) && ug_aligned(k, 16) && ug_aligned(v, 16) && ug_aligned(o, 8),
                UG_ERR_BAD_ALIGN, "ug_flash_attn_fwd: strides must be multiples of 8 elements and bases 16-byte aligned");
-    const int nQ = (int)((Lq + QROWS - 1) / QROWS);
+    static int nw = -1;
+    if (nw < 0) { const char* e = getenv("UG_ATTN_WAVES"); nw = (e && atoi(e) == 4) ? 4 : 8; }   // 8 measured faster (841 vs 800 TFLOP/s at L = 4608)
+    const int qrows = 32 * nw;
+    const int nQ = (int)((Lq + qrows - 1) / qrows);
     const int64_t nwg = (int64_t)nQ * heads * batches;
     UG_REQUIRE(nwg < (1ll << 31), UG_ERR_UNSUPPORTED, "ug_flash_attn_fwd: grid too large");
     const float c = softmax_scale * 1.4426950408889634f;
-    hipLaunchKernelGGL(flash_attn128_kernel, dim3((unsigned)nwg), dim3(512), 65536, (hipStream_t)stream, (const bf16_t*)q,
-                       q_row_stride, q_batch_stride, (const bf16_t*)k, k_row_stride, k_batch_stride, (const bf16_t*)v,
-                       v_row_stride, v_batch_stride, (bf16_t*)o, o_row_stride, o_batch_stride, (int)heads, (int)Lq, (int)Lkv, nQ, c);
+    if (nw == 8)
+        hipLaunchKernelGGL(flash_attn128_kernel<8>, dim3((unsigned)nwg), dim3(512), 65536, (hipStream_t)stream, (const bf16_t*)q,
+                           q_row_stride, q_batch_stride, (const bf16_t*)k, k_row_stride, k_batch_stride, (const bf16_t*)v,
+                           v_row_stride, v_batch_stride, (bf16_t*)o, o_row_stride, o_batch_stride, (int)heads, (int)Lq, (int)Lkv, nQ, c);
+    else
+        hipLaunchKernelGGL(flash_attn128_kernel<4>, dim3((unsigned)nwg), dim3(256), 65536, (hipStream_t)stream, (const bf16_t*)q,
+                           q_row_stride, q_batch_stride, (const bf16_t*)k, k_row_stride, k_batch_stride, (const bf16_t*)v,
+                           v_row_stride, v_batch_stride, (bf16_t*)o, o_row_stride, o_batch_stride, (int)heads, (int)Lq, (int)Lkv, nQ, c);
     UG_CHECK_LAUNCH("ug_flash_attn_fwd");
     return UG_OK;
 }
