@@ -68,6 +68,8 @@ typedef struct ug_gemm_desc {
     const void* lora_T; int64_t ldt;
     const void* lora_B; int64_t ldb;
     int32_t lora_r; int32_t _pad1;
+    /* group strides (ELEMENTS) of the residual and gate operands for grouped residual epilogues (per-expert transformer blocks) */
+    int64_t r_gstride, gate_gstride;
 } ug_gemm_desc;
 
 /* replaces every nn.Linear on the path (torch F.linear -> BLAS) incl. fused epilogues. */
@@ -119,6 +121,16 @@ int ug_euler_step(void* x, const void* v, float dt, int64_t n, ug_stream_t strea
 int ug_add_bf16(const void* a, int64_t lda, const void* b, int64_t ldb, void* out, int64_t ldo,
                 int64_t rows, int64_t D, ug_stream_t stream);
 
+/* x[r][:] = bf16( float(x[r][:]) + table[r % rows_per_batch][:] ), table fp32: PatchEmbed's `(latent + pos_embed).to(latent.dtype)`
+ * with the centre-cropped sincos table (diffusers embeddings.PatchEmbed.forward; UniGenSD3, src/UniGenTransformer.py:663,510). */
+int ug_add_rowbcast_f32(void* x, int64_t ldx, const float* table, int64_t ldt, int64_t rows, int64_t rows_per_batch, int64_t D,
+                        ug_stream_t stream);
+
+/* out[i][:W] = src[idx[i]][:W] (zeros when idx[i] < 0): per-slot rows of per-sample tables (per-token AdaLN embeddings of the
+ * SD3 transformer-block experts: the reference broadcasts temb per token and dispatches it, src/UniGenUtils.py:107-109). */
+int ug_gather_rows(const void* src, int64_t ld_src, const int32_t* idx, void* out, int64_t ld_out, int64_t n, int64_t W,
+                   ug_stream_t stream);
+
 /* ---- CoMoE (src/UniGenUtils.py:74-191 MOELayer + deepspeed 0.16.5 top1gating; UniGenTransformer.py:925-1026) ---- */
 
 /* Gate: xc = bf16(x + c); logits = xc.float() @ wg.float()^T (fp32); gates = softmax; idx = argmax.
@@ -137,7 +149,8 @@ int ug_moe_capacity_rts(const float* gates, const int32_t* idx, const float* uni
 /* Dispatch + expert modulation prologue (replaces einsum("sec,sm->ecm") src/UniGenUtils.py:140 and the s-scaling of
  * modulated_flatten src/UniGenUtils.py:204-228):
  *   out[e][slot][:] = bf16( mod[e][sample(tok)][:] * bf16( x[tok][:] + (add ? add[e][slot][:] : 0) ) ), zeros for empty slots.
- * mod: bf16 [E][B][D] = Linear(768->D)(pooled) per expert. tokens_per_sample = N. */
+ * mod: bf16 [E][B][D] = Linear(768->D)(pooled) per expert, or NULL for a plain dispatch (transformer-block experts).
+ * tokens_per_sample = N. */
 int ug_moe_dispatch_modulate(const void* x, int64_t ldx, const void* add, const void* mod, int64_t B,
                              const int32_t* token_of_slot, int32_t E, int64_t capacity, int64_t tokens_per_sample,
                              int64_t D, void* out, ug_stream_t stream);

@@ -621,3 +621,337 @@ def make_inputs(cfg: FluxConfig, B: int, grid: int, T: int, seed: int = 12443, n
                    condition_ids=[make_ids(grid, grid, dtype) for _ in range(n_cond)])
         inp["gate_uniform"] = unis
     return inp
+
+
+# =====================================================================================================================
+# UniGenSD3 (SD3.5-medium backbone): src/UniGenTransformer.py:21-710 (UniGenBase / UniGenSD3), src/UniGenUtils.py:340-530,
+# diffusers 0.32.2 SD3Transformer2DModel / JointTransformerBlock / SD3SingleTransformerBlock / PatchEmbed.
+# =====================================================================================================================
+
+@dataclass
+class SD3Config:
+    """diffusers SD3Transformer2DModel config (SD3.5-medium defaults) + UniGen control params."""
+    sample_size: int = 128
+    patch_size: int = 2
+    in_channels: int = 16
+    out_channels: int = 16
+    num_layers: int = 24
+    attention_head_dim: int = 64
+    num_attention_heads: int = 24
+    joint_attention_dim: int = 4096
+    caption_projection_dim: int = 1536
+    pooled_projection_dim: int = 2048
+    pos_embed_max_size: int = 384
+    dual_attention_layers: Tuple[int, ...] = tuple(range(13))
+    qk_norm: Optional[str] = "rms_norm"
+    # control params (config/unigen.yaml defaults: transformer-block experts, shared experts, no rope)
+    condition_nums: int = 1
+    use_modulate: bool = False
+    use_pooled_prompt_embeds: bool = True
+    use_shared_expert: bool = True
+    expert_num_each_condition: int = 3
+    expert_num: Optional[int] = None
+
+    @property
+    def inner_dim(self) -> int:
+        return self.num_attention_heads * self.attention_head_dim
+
+    @property
+    def expert_nums(self) -> int:
+        return self.expert_num if self.expert_num is not None else (self.condition_nums + 1) * self.expert_num_each_condition
+
+
+def sincos_pos_embed_2d(embed_dim: int, grid_size: int, base_size: int, interpolation_scale: float = 1.0) -> torch.Tensor:
+    """diffusers get_2d_sincos_pos_embed(output_type='pt') -> [grid_size^2, embed_dim] fp32 (the PatchEmbed `pos_embed` buffer)."""
+    grid_h = torch.arange(grid_size, dtype=torch.float32) / (grid_size / base_size) / interpolation_scale
+    grid_w = torch.arange(grid_size, dtype=torch.float32) / (grid_size / base_size) / interpolation_scale
+    gw, gh = torch.meshgrid(grid_w, grid_h, indexing="xy")
+    grid = torch.stack([gw, gh], dim=0).reshape(2, 1, grid_size, grid_size)
+
+    def one_d(dim, pos):
+        omega = torch.arange(dim // 2, dtype=torch.float64) / (dim / 2.0)
+        omega = 1.0 / 10000 ** omega
+        out = torch.outer(pos.reshape(-1).double(), omega)
+        return torch.cat([torch.sin(out), torch.cos(out)], dim=1)
+
+    emb = torch.cat([one_d(embed_dim // 2, grid[0]), one_d(embed_dim // 2, grid[1])], dim=1)
+    return emb.float()
+
+
+def patch_embed(state: State, prefix: str, cfg: SD3Config, latent: torch.Tensor) -> torch.Tensor:
+    """diffusers PatchEmbed.forward with pos_embed_max_size: Conv2d(k = s = patch) -> flatten -> + centre-cropped sincos table."""
+    p = cfg.patch_size
+    h, w = latent.shape[-2] // p, latent.shape[-1] // p
+    x = F.conv2d(latent, state[prefix + ".proj.weight"].to(latent.dtype), state[prefix + ".proj.bias"].to(latent.dtype), stride=p)
+    x = x.flatten(2).transpose(1, 2)
+    mx = cfg.pos_embed_max_size
+    pe = state[prefix + ".pos_embed"].reshape(1, mx, mx, -1)
+    top, left = (mx - h) // 2, (mx - w) // 2
+    pe = pe[:, top:top + h, left:left + w, :].reshape(1, h * w, -1)
+    return (x + pe).to(x.dtype)
+
+
+def adaln_zero_x(state: State, prefix: str, x: torch.Tensor, emb: torch.Tensor):
+    """SD35AdaLayerNormZeroX (reference restatement src/UniGenUtils.py:340-352); emb [B, D] or per-token [B, L, D]."""
+    e = linear(state, prefix + ".linear", F.silu(emb))
+    sh, sc, g, shm, scm, gm, sh2, sc2, g2 = e.chunk(9, dim=-1)
+    n = layer_norm(x)
+    if e.dim() == x.dim():
+        return n * (1 + sc) + sh, g, shm, scm, gm, n * (1 + sc2) + sh2, g2
+    return n * (1 + sc[:, None]) + sh[:, None], g, shm, scm, gm, n * (1 + sc2[:, None]) + sh2[:, None], g2
+
+
+def adaln_zero_any(state: State, prefix: str, x: torch.Tensor, emb: torch.Tensor):
+    """AdaLayerNormZero with the reference's per-token extension (src/UniGenUtils.py:354-363)."""
+    e = linear(state, prefix + ".linear", F.silu(emb))
+    sh, sc, g, shm, scm, gm = e.chunk(6, dim=-1)
+    if e.dim() == x.dim():
+        return layer_norm(x) * (1 + sc) + sh, g, shm, scm, gm
+    return layer_norm(x) * (1 + sc[:, None]) + sh[:, None], g, shm, scm, gm
+
+
+def _gate(g: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    return g * y if g.dim() == y.dim() else g.unsqueeze(1) * y
+
+
+def _mod(n: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor) -> torch.Tensor:
+    if scale.dim() == n.dim():
+        return n * (1 + scale) + shift
+    return n * (1 + scale[:, None]) + shift[:, None]
+
+
+def sd3_attention(state: State, prefix: str, H: int, x: torch.Tensor, enc: Optional[torch.Tensor], context_pre_only: bool = False):
+    """Attention + JointAttnProcessor2_0 (sample-first concat, no RoPE); qk RMSNorm when the weights exist."""
+    def nrm(t, name):
+        w = state.get(f"{prefix}.{name}.weight")
+        return rms_norm(t, w) if w is not None else t
+    q = nrm(_heads(linear(state, prefix + ".to_q", x), H), "norm_q")
+    k = nrm(_heads(linear(state, prefix + ".to_k", x), H), "norm_k")
+    v = _heads(linear(state, prefix + ".to_v", x), H)
+    N = x.shape[1]
+    if enc is not None:
+        eq = nrm(_heads(linear(state, prefix + ".add_q_proj", enc), H), "norm_added_q")
+        ek = nrm(_heads(linear(state, prefix + ".add_k_proj", enc), H), "norm_added_k")
+        ev = _heads(linear(state, prefix + ".add_v_proj", enc), H)
+        q, k, v = torch.cat([q, eq], 2), torch.cat([k, ek], 2), torch.cat([v, ev], 2)
+    o = _sdpa(q, k, v).transpose(1, 2).reshape(x.shape[0], -1, x.shape[2]).to(q.dtype)
+    if enc is None:
+        return linear(state, prefix + ".to_out.0", o), None
+    xo, eo = o[:, :N], o[:, N:]
+    xo = linear(state, prefix + ".to_out.0", xo)
+    eo = None if context_pre_only else linear(state, prefix + ".to_add_out", eo)
+    return xo, eo
+
+
+def sd3_joint_block(state: State, prefix: str, H: int, x, enc, temb, context_pre_only: bool = False, dual: bool = False):
+    """JointTransformerBlock.forward as restated by the reference (src/UniGenUtils.py:440-522). Returns (enc or None, x)."""
+    if dual:
+        n, g, shm, scm, gm, n2, g2 = adaln_zero_x(state, prefix + ".norm1", x, temb)
+    else:
+        n, g, shm, scm, gm = adaln_zero_any(state, prefix + ".norm1", x, temb)
+    if context_pre_only:
+        nc = adaln_continuous(state, prefix + ".norm1_context", enc, temb)
+    else:
+        nc, cg, cshm, cscm, cgm = adaln_zero_any(state, prefix + ".norm1_context", enc, temb)
+    a, ca = sd3_attention(state, prefix + ".attn", H, n, nc, context_pre_only)
+    x = x + _gate(g, a)
+    if dual:
+        a2, _ = sd3_attention(state, prefix + ".attn2", H, n2, None)
+        x = x + _gate(g2, a2)
+    x = x + _gate(gm, feed_forward(state, prefix + ".ff", _mod(layer_norm(x), scm, shm)))
+    if context_pre_only:
+        return None, x
+    enc = enc + _gate(cg, ca)
+    enc = enc + _gate(cgm, feed_forward(state, prefix + ".ff_context", _mod(layer_norm(enc), cscm, cshm)))
+    return enc, x
+
+
+def sd3_single_block(state: State, prefix: str, H: int, x, temb):
+    """SD3SingleTransformerBlock.forward (src/UniGenUtils.py:386-414); temb per sample [B, D] or per token [B, L, D]."""
+    n, g, shm, scm, gm = adaln_zero_any(state, prefix + ".norm1", x, temb)
+    a, _ = sd3_attention(state, prefix + ".attn", H, n, None)
+    x = x + _gate(g, a)
+    return x + _gate(gm, feed_forward(state, prefix + ".ff", _mod(layer_norm(x), scm, shm)))
+
+
+def sd3_comoe(state: State, cfg: SD3Config, x, c, ctrl_enc, control_temb, condition_temb, pooled, cond_pooled, uniform):
+    """UniGenBase.moe_forward + expert_forward (src/UniGenTransformer.py:225-296): MoE experts (modulated linears or two
+    SD3SingleTransformerBlocks fed per-token tembs, attending over the expert's capacity slots) + the two shared joint blocks."""
+    B, N, D = x.shape
+    E, S, H, dt = cfg.expert_nums, B * N, cfg.num_attention_heads, x.dtype
+    if cfg.use_modulate:
+        fcfg = FluxConfig(attention_head_dim=cfg.attention_head_dim, num_attention_heads=H, condition_nums=cfg.condition_nums,
+                          expert_num_each_condition=cfg.expert_num_each_condition, expert_num=cfg.expert_num)
+        eh, ec, l_aux, exp_counts, routing = comoe_experts(state, fcfg, x, c, pooled, cond_pooled, None, uniform)
+    else:
+        logits = F.linear((x + c).reshape(S, D).float(), state["moe.moe_layer.gate.wg.weight"].float())
+        C = moe_capacity(S, E)
+        l_aux, combine_weights, _, exp_counts = top1gating(logits, uniform, C)
+        gates = F.softmax(logits, dim=1)
+        idx, slot, tos = routing_from_gates(gates, uniform, C)
+
+        def dispatch(t2d):
+            out = torch.zeros(E, C, t2d.shape[-1], dtype=t2d.dtype)
+            valid = tos >= 0
+            out[valid] = t2d[tos[valid]]
+            return out
+
+        xd, cd = dispatch(x.reshape(S, D)), dispatch(c.reshape(S, D))
+        td = dispatch(control_temb.unsqueeze(1).expand(-1, N, -1).reshape(S, D))
+        ctd = dispatch(condition_temb.unsqueeze(1).expand(-1, N, -1).reshape(S, D))
+        yh, yc = [], []
+        for e in range(E):
+            p = f"moe.moe_layer.experts.deepspeed_experts.{e}"
+            yh.append(sd3_single_block(state, p + ".0", H, xd[e][None], td[e][None])[0])        # expert[0](hidden, temb)        (:261)
+            yc.append(sd3_single_block(state, p + ".1", H, cd[e][None], ctd[e][None])[0])       # expert[1](condition, cond_temb) (:262)
+        cw = combine_weights.to(dt)
+        eh = torch.einsum("sec,ecm->sm", cw, torch.stack(yh)).reshape(B, N, D)
+        ec = torch.einsum("sec,ecm->sm", cw, torch.stack(yc)).reshape(B, N, D)
+        routing = dict(gates=gates, idx=idx, slot=slot, token_of_slot=tos, capacity=C)
+    if not cfg.use_shared_expert:
+        return eh, ec, l_aux, exp_counts, routing
+    cond_s, x_s = sd3_joint_block(state, "shared_expert.0", H, x, c, condition_temb, context_pre_only=False, dual=False)
+    _, hc = sd3_joint_block(state, "shared_expert.1", H, torch.cat([x_s, cond_s], 1), ctrl_enc, control_temb, context_pre_only=True, dual=True)
+    x_s, cond_s = hc[:, :N], hc[:, N:]
+    return x_s + eh, cond_s + ec, l_aux, exp_counts, routing
+
+
+def unigen_sd3_forward(state: State, cfg: SD3Config, *, hidden_states, condition_hidden_states, encoder_hidden_states, pooled_projections,
+                       condition_pooled_projections, timestep, conditioning_scale: float = 1.0, gate_uniform=None, dtype=torch.bfloat16,
+                       io_dtype=torch.bfloat16, trace: Optional[dict] = None):
+    """UniGenSD3.forward (src/UniGenTransformer.py:625-710): latents NCHW in, NCHW out. The timestep is used as given (no x1000)."""
+    dt, H, L = dtype, cfg.num_attention_heads, cfg.num_layers
+    cast = lambda t: t.to(dt)
+    height, width = hidden_states.shape[-2:]
+    x = patch_embed(state, "pos_embed", cfg, cast(hidden_states))
+    pooled = cast(pooled_projections)
+    cpooled = cast(condition_pooled_projections)
+    tstep = timestep.float()      # SD3 passes the scheduler timestep unscaled; time_proj works on timesteps.float()
+    temb = time_text_embed(state, "time_text_embed", tstep, pooled)
+    enc = linear(state, "context_embedder", cast(encoder_hidden_states))
+    moe_out = None
+    for i in range(L):
+        last = i == L - 1
+        enc_new, x = sd3_joint_block(state, f"transformer_blocks.{i}", H, x, enc, temb, context_pre_only=last, dual=i in cfg.dual_attention_layers)
+        if moe_out is None:      # preprocess_moe_forward at base_block_idx == 0 (:559-563), text stream AFTER base block 0
+            c = patch_embed(state, "control_pos_embed_input", cfg, cast(condition_hidden_states))
+            control_pooled = pooled if cfg.use_pooled_prompt_embeds else torch.zeros_like(pooled)
+            control_temb = time_text_embed(state, "control_time_text_embed", tstep, control_pooled)
+            condition_temb = time_text_embed(state, "control_condition_embed", tstep, cpooled)
+            ctrl_enc = linear(state, "control_context_embedder", enc_new)
+            eh, ec, l_aux, exp_counts, routing = sd3_comoe(state, cfg, x, c, ctrl_enc, control_temb, condition_temb, pooled, cpooled, gate_uniform)
+            moe_out = dict(ctrl_enc=ctrl_enc, condition_temb=condition_temb, l_aux=l_aux, exp_counts=exp_counts)
+            z_in = eh + ec
+            if trace is not None:
+                trace["routing"], trace["z0"] = routing, z_in
+        else:
+            z_in = x
+        enc = enc_new
+        _, z = sd3_joint_block(state, f"control_transformer_blocks.{i}", H, z_in, moe_out["ctrl_enc"], moe_out["condition_temb"],
+                               context_pre_only=False, dual=i in cfg.dual_attention_layers)
+        x = x + linear(state, f"controlnet_add_blocks.{i}", z) * conditioning_scale
+    x = adaln_continuous(state, "norm_out", x, temb)
+    x = linear(state, "proj_out", x)
+    p = cfg.patch_size
+    h, w = height // p, width // p
+    x = x.reshape(x.shape[0], h, w, p, p, cfg.out_channels)
+    x = torch.einsum("nhwpqc->nchpwq", x)
+    out = x.reshape(x.shape[0], cfg.out_channels, h * p, w * p)
+    return out, dict(moe_loss=moe_out["l_aux"] * 0.1), dict(expert_counts=moe_out["exp_counts"])
+
+
+def _sd3_attn_shapes(s, p, D, dh, qk_norm, ctx: bool, context_pre_only: bool = False):
+    for n in ("to_q", "to_k", "to_v", "to_out.0"):
+        s[f"{p}.{n}.weight"] = (D, D); s[f"{p}.{n}.bias"] = (D,)
+    if qk_norm:
+        s[f"{p}.norm_q.weight"] = (dh,); s[f"{p}.norm_k.weight"] = (dh,)
+    if ctx:
+        for n in ("add_q_proj", "add_k_proj", "add_v_proj"):
+            s[f"{p}.{n}.weight"] = (D, D); s[f"{p}.{n}.bias"] = (D,)
+        if not context_pre_only:
+            s[f"{p}.to_add_out.weight"] = (D, D); s[f"{p}.to_add_out.bias"] = (D,)
+        if qk_norm:
+            s[f"{p}.norm_added_q.weight"] = (dh,); s[f"{p}.norm_added_k.weight"] = (dh,)
+
+
+def _sd3_ff_shapes(s, p, D):
+    s[f"{p}.net.0.proj.weight"] = (4 * D, D); s[f"{p}.net.0.proj.bias"] = (4 * D,)
+    s[f"{p}.net.2.weight"] = (D, 4 * D); s[f"{p}.net.2.bias"] = (D,)
+
+
+def _sd3_joint_shapes(s, p, D, dh, qk_norm, context_pre_only, dual):
+    s[f"{p}.norm1.linear.weight"] = ((9 if dual else 6) * D, D); s[f"{p}.norm1.linear.bias"] = ((9 if dual else 6) * D,)
+    nctx = 2 if context_pre_only else 6
+    s[f"{p}.norm1_context.linear.weight"] = (nctx * D, D); s[f"{p}.norm1_context.linear.bias"] = (nctx * D,)
+    _sd3_attn_shapes(s, p + ".attn", D, dh, qk_norm, True, context_pre_only)
+    if dual:
+        _sd3_attn_shapes(s, p + ".attn2", D, dh, qk_norm, False)
+    _sd3_ff_shapes(s, p + ".ff", D)
+    if not context_pre_only:
+        _sd3_ff_shapes(s, p + ".ff_context", D)
+
+
+def sd3_state_shapes(cfg: SD3Config) -> Dict[str, Tuple[int, ...]]:
+    D, dh, p = cfg.inner_dim, cfg.attention_head_dim, cfg.patch_size
+    s: Dict[str, Tuple[int, ...]] = {}
+    for pe in ("pos_embed", "control_pos_embed_input"):
+        s[pe + ".proj.weight"] = (D, cfg.in_channels, p, p); s[pe + ".proj.bias"] = (D,)
+        s[pe + ".pos_embed"] = (1, cfg.pos_embed_max_size ** 2, D)
+    for t in ("time_text_embed", "control_time_text_embed", "control_condition_embed"):
+        s.update(_tte_shapes(t, D, cfg.pooled_projection_dim, False))
+    s["context_embedder.weight"] = (cfg.caption_projection_dim, cfg.joint_attention_dim); s["context_embedder.bias"] = (cfg.caption_projection_dim,)
+    s["control_context_embedder.weight"] = (D, D); s["control_context_embedder.bias"] = (D,)
+    for i in range(cfg.num_layers):
+        dual = i in cfg.dual_attention_layers
+        _sd3_joint_shapes(s, f"transformer_blocks.{i}", D, dh, cfg.qk_norm, i == cfg.num_layers - 1, dual)
+        _sd3_joint_shapes(s, f"control_transformer_blocks.{i}", D, dh, cfg.qk_norm, False, dual)
+        s[f"controlnet_add_blocks.{i}.weight"] = (D, D); s[f"controlnet_add_blocks.{i}.bias"] = (D,)
+    s["norm_out.linear.weight"] = (2 * D, D); s["norm_out.linear.bias"] = (2 * D,)
+    s["proj_out.weight"] = (p * p * cfg.out_channels, D); s["proj_out.bias"] = (p * p * cfg.out_channels,)
+    s["moe.moe_layer.gate.wg.weight"] = (cfg.expert_nums, D)
+    for e in range(cfg.expert_nums):
+        pe = f"moe.moe_layer.experts.deepspeed_experts.{e}"
+        for k in (0, 1):
+            if cfg.use_modulate:
+                s[f"{pe}.{k}.0.weight"] = (D, D); s[f"{pe}.{k}.0.bias"] = (D,)
+                s[f"{pe}.{k}.1.weight"] = (D, cfg.pooled_projection_dim); s[f"{pe}.{k}.1.bias"] = (D,)
+            else:
+                s[f"{pe}.{k}.norm1.linear.weight"] = (6 * D, D); s[f"{pe}.{k}.norm1.linear.bias"] = (6 * D,)
+                _sd3_attn_shapes(s, f"{pe}.{k}.attn", D, dh, None, False)
+                _sd3_ff_shapes(s, f"{pe}.{k}.ff", D)
+    if cfg.use_shared_expert:
+        _sd3_joint_shapes(s, "shared_expert.0", D, dh, cfg.qk_norm, False, False)
+        _sd3_joint_shapes(s, "shared_expert.1", D, dh, cfg.qk_norm, True, True)
+    return s
+
+
+def make_sd3_state(cfg: SD3Config, seed: int = 0, std: float = 0.02, bias_std: float = 0.0, dtype=torch.bfloat16) -> State:
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    st: State = {}
+    base = cfg.sample_size // cfg.patch_size
+    for name, shape in sd3_state_shapes(cfg).items():
+        if name.endswith(".pos_embed"):
+            st[name] = sincos_pos_embed_2d(cfg.inner_dim, cfg.pos_embed_max_size, base).unsqueeze(0)      # fp32 buffer
+            continue
+        if ".norm_q." in name or ".norm_k." in name or ".norm_added_q." in name or ".norm_added_k." in name:
+            t = 1.0 + 0.1 * torch.randn(shape, generator=g) if bias_std > 0 else torch.ones(shape)
+        elif name.endswith(".bias"):
+            t = bias_std * torch.randn(shape, generator=g) if bias_std > 0 else torch.zeros(shape)
+        else:
+            t = std * torch.randn(shape, generator=g)
+        st[name] = t.to(dtype)
+    return st
+
+
+def make_sd3_inputs(cfg: SD3Config, B: int, hw: int, T: int, seed: int = 12443, dtype=torch.bfloat16):
+    """hw = latent height = width (pixels / 8); N = (hw / patch)^2 tokens."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    N = (hw // cfg.patch_size) ** 2
+    return dict(
+        hidden_states=torch.randn(B, cfg.in_channels, hw, hw, generator=g).to(dtype),
+        condition_hidden_states=torch.randn(B, cfg.in_channels, hw, hw, generator=g).to(dtype),
+        encoder_hidden_states=(0.1 * torch.randn(B, T, cfg.joint_attention_dim, generator=g)).to(dtype),
+        pooled_projections=torch.randn(B, cfg.pooled_projection_dim, generator=g).to(dtype),
+        condition_pooled_projections=torch.randn(B, cfg.pooled_projection_dim, generator=g).to(dtype),
+        gate_uniform=torch.rand(B * N, cfg.expert_nums, generator=g),
+    )

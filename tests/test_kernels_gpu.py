@@ -304,3 +304,61 @@ def test_moe_routing_dispatch_combine(gpu, S, E, D):
     ref2 = ref + (eh + ec)
     m = report(f"moe_combine_acc_S{S}", out, ref2)
     assert m["mismatch_frac"] == 0.0, m
+
+
+@pytest.mark.parametrize("B,H,Lq,Lkv", [(1, 2, 256, 256), (2, 3, 300, 333), (6, 2, 86, 86), (1, 24, 1024, 1357)])
+def test_flash_attn_head_dim_64(gpu, B, H, Lq, Lkv):
+    """SD3.5 heads (dh = 64); (6, 2, 86, 86) is the shape of the expert self-attention over capacity slots."""
+    from unigen_amd import ops
+    dh = 64
+    D = H * dh
+    g = torch.Generator().manual_seed(Lq * 3 + Lkv)
+    qkv = _rand(g, B, Lkv, 3 * D)
+    d = qkv.to(gpu)
+    out = torch.zeros(B, Lq, D, device=gpu, dtype=BF)
+    st = (3 * D, Lkv * 3 * D)
+    ops.flash_attn(d[0, Lkv - Lq:], d[0, 0, D:], d[0, 0, 2 * D:], out, batches=B, heads=H, dh=dh, Lq=Lq, Lkv=Lkv, q_strides=st, k_strides=st,
+                   v_strides=st, o_strides=(D, Lq * D))
+    q = qkv[:, Lkv - Lq:, :D].view(B, Lq, H, dh).transpose(1, 2).float()
+    k = qkv[:, :, D:2 * D].view(B, Lkv, H, dh).transpose(1, 2).float()
+    v = qkv[:, :, 2 * D:].view(B, Lkv, H, dh).transpose(1, 2).float()
+    ref = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B, Lq, D)
+    m = report(f"flash_attn64_B{B}H{H}_{Lq}x{Lkv}", out, ref)
+    assert m["rel_l2"] <= 4e-3, m
+
+
+def test_grouped_residual_gate_gather_rowbcast_plain_dispatch(gpu):
+    from unigen_amd import lib as L, ops
+    g = torch.Generator().manual_seed(9)
+    # grouped GEMM with a per-ROW gate and residual per group (per-token AdaLN gates of the SD3 expert blocks)
+    E, C, D = 4, 70, 128
+    x, w, b = _rand(g, E, C, D), _rand(g, E, D, D, scale=D ** -0.5), _rand(g, E, D, scale=0.1)
+    res, emb = _rand(g, E, C, D), _rand(g, E * C, 6 * D, scale=0.5)
+    out = res.to(gpu).clone()
+    embd = emb.to(gpu)
+    ops.gemm(x.to(gpu), w.to(gpu), b.to(gpu), out, M=C, epilogue=L.EPI_RES_GATE, groups=E, a_gstride=C * D, w_gstride=D * D, bias_gstride=D,
+             c_gstride=C * D, residual=out, r_gstride=C * D, gate=embd[:, 2 * D:], gate_ld=6 * D, rows_per_sample=1, gate_gstride=C * 6 * D)
+    v = (torch.einsum("ecd,eod->eco", x.float(), w.float()) + b.float()[:, None]).to(BF)
+    ref = res + emb[:, 2 * D:3 * D].view(E, C, D) * v
+    m = report("gemm_grouped_res_gate_per_row", out, ref)
+    assert m["rel_l2"] <= TOL, m
+    # row gather with empty rows
+    src = _rand(g, 11, 64)
+    idx = torch.tensor([3, -1, 10, 0, 3, -1, 7], dtype=torch.int32)
+    o = torch.empty(7, 64, device=gpu, dtype=BF)
+    ops.gather_rows(src.to(gpu), idx.to(gpu), o)
+    ref = torch.where((idx >= 0)[:, None], src[idx.clamp_min(0).long()], torch.zeros(1, 64, dtype=BF))
+    assert torch.equal(o.cpu(), ref)
+    # fp32 row-broadcast add (PatchEmbed pos table)
+    xx, tab = _rand(g, 3 * 10, 64), torch.randn(10, 64, generator=g)
+    xd = xx.to(gpu).clone()
+    ops.add_rowbcast_f32(xd, tab.to(gpu), 10)
+    ref = (xx.float().view(3, 10, 64) + tab[None]).to(BF).view(30, 64)
+    assert torch.equal(xd.cpu(), ref)
+    # plain dispatch (mod = None)
+    tos = torch.tensor([[2, 5, -1], [0, -1, -1]], dtype=torch.int32)
+    xs = _rand(g, 6, 64)
+    o = torch.empty(2, 3, 64, device=gpu, dtype=BF)
+    ops.moe_dispatch_modulate(xs.to(gpu), None, None, tos.to(gpu), o, B=1, E=2, capacity=3, tokens_per_sample=6)
+    ref = torch.zeros(2, 3, 64, dtype=BF); ref[0, 0], ref[0, 1], ref[1, 0] = xs[2], xs[5], xs[0]
+    assert torch.equal(o.cpu(), ref)

@@ -1,0 +1,39 @@
+"""GPU parity, UniGenSD3 (SD3.5 backbone) forward against the CPU oracle at reduced size: both expert variants (the shipped yaml's
+transformer-block experts with per-token AdaLN and self-attention over capacity slots, and the modulated linears), dual attention
+layers, context_pre_only last block, PatchEmbed with the cropped sincos table, NCHW in/out. Tolerance as in tests/test_flux_gpu.py."""
+import importlib
+
+import pytest
+import torch
+
+from oracle import unigen_ref as R
+from tests.util import report, rel_l2
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+TINY = dict(sample_size=16, num_layers=3, attention_head_dim=64, num_attention_heads=2, joint_attention_dim=64, caption_projection_dim=128,
+            pooled_projection_dim=64, pos_embed_max_size=12, dual_attention_layers=(0, 1))
+
+
+@pytest.mark.parametrize("modulated,B,hw,T", [(False, 2, 16, 24), (True, 2, 16, 24), (False, 1, 12, 33)])
+def test_sd3_forward_matches_oracle(gpu, modulated, B, hw, T):
+    cls = importlib.import_module("src.UniGenTransformer").UniGenSD3
+    model = cls.from_config(dict(TINY), device=gpu, dtype=BF)
+    model.init_condition_block(condition_nums=1, condition_types=["depth"], control_params=dict(use_shared_expert=True, use_modulate=modulated))
+    model.init_synthetic_(seed=5, std=0.05, bias_std=0.02)
+    state = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    rcfg = R.SD3Config(use_modulate=modulated, **TINY)
+    assert set(state) == set(R.sd3_state_shapes(rcfg))
+    inp = R.make_sd3_inputs(rcfg, B=B, hw=hw, T=T)
+    t = torch.full((B,), 600.0)
+    truth, _, _ = R.unigen_sd3_forward(state, rcfg, timestep=t, dtype=torch.float32, **inp)
+    ref16, loss16, cnt16 = R.unigen_sd3_forward(state, rcfg, timestep=t, dtype=BF, **inp)
+    out, losses, outs = model(timestep=t.to(gpu), **{k: v.to(gpu) for k, v in inp.items()})
+    torch.cuda.synchronize()
+    assert out.shape == truth.shape == (B, 16, hw, hw) and out.dtype == BF and torch.isfinite(out.float()).all()
+    err_hip, err_ref = rel_l2(out, truth), rel_l2(ref16, truth)
+    m = report(f"sd3_forward_mod{int(modulated)}_B{B}_hw{hw}", out, ref16, err_hip_vs_fp32=err_hip, err_oraclebf16_vs_fp32=err_ref)
+    assert torch.equal(outs["expert_counts"].cpu(), cnt16["expert_counts"]), (outs["expert_counts"], cnt16["expert_counts"])
+    assert err_hip <= 1.25 * err_ref + 1e-3, m
+    assert m["rel_l2"] <= 2.5e-2, m
+    assert abs(float(losses["moe_loss"]) - float(loss16["moe_loss"])) <= 1e-3 * abs(float(loss16["moe_loss"]))

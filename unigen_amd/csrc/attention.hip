@@ -20,9 +20,24 @@ constexpr int KVB = 64;      // keys per tile
 
 typedef __attribute__((address_space(3))) bf16x4* lds_b64_ptr;
 
-// byte offset of 16-byte chunk ch of row `row` in a [rows][128 x bf16] tile image (256-byte rows)
+// Row swizzle of the K/V tile images. f(row) is XORed into the 16-byte chunk index.
+//   DH = 128 (256-byte rows): f = ((row & 3) << 2) | ((row >> 2) & 3)          (cdna guide T10, image (b))
+//   DH =  64 (128-byte rows, two rows per 256-byte bank row): f = swap_bits_0_2((row >> 1) & 7): the 8 same-parity rows of a
+//            ds_read_b128 lane group get 8 distinct chunks, and rows r, r+2 of a transposed-read block land in different
+//            64-byte quarters -> both read kinds are conflict-free.
+template <int DH>
+__device__ __forceinline__ int row_swz(int row) {
+    if constexpr (DH == 128) {
+        return ((row & 3) << 2) | ((row >> 2) & 3);
+    } else {
+        const int v = (row >> 1) & 7;
+        return ((v & 1) << 2) | (v & 2) | ((v >> 2) & 1);
+    }
+}
+// byte offset of 16-byte chunk ch of row `row` in a [rows][DH x bf16] tile image
+template <int DH>
 __device__ __forceinline__ int img_off(int row, int ch) {
-    return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+    return 2 * DH * row + 16 * (ch ^ row_swz<DH>(row));
 }
 
 __device__ __forceinline__ bf16x8 tr_read_pair(const unsigned char* lo, const unsigned char* hi) {
@@ -31,14 +46,19 @@ __device__ __forceinline__ bf16x8 tr_read_pair(const unsigned char* lo, const un
     return (bf16x8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
 }
 
-template <int NW>   // waves per workgroup: 8 (256 query rows, 1 workgroup / CU) or 4 (128 rows, 2 independent workgroups / CU)
-__global__ __launch_bounds__(64 * NW, 2) void flash_attn128_kernel(
+template <int DH, int NW>   // head dim 128 | 64; waves per workgroup: 8 (256 query rows, 1 workgroup / CU) or 4 (128 rows, 2 / CU)
+__global__ __launch_bounds__(64 * NW, 2) void flash_attn_kernel(
     const bf16_t* __restrict__ q, int64_t q_rs, int64_t q_bs, const bf16_t* __restrict__ k, int64_t k_rs, int64_t k_bs,
     const bf16_t* __restrict__ v, int64_t v_rs, int64_t v_bs, bf16_t* __restrict__ o, int64_t o_rs, int64_t o_bs,
     int heads, int Lq, int Lkv, int nQ, float c /* softmax_scale * log2(e) */) {
-    constexpr int DH = 128;
-    constexpr int QROWS = 32 * NW, NT = 64 * NW, NST = 1024 / NT;          // staging chunks of K (and of V) per thread and tile
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [2][K 16 KiB | V 16 KiB]
+    constexpr int RB = 2 * DH;                       // row bytes
+    constexpr int NCH = DH / 8;                      // 16-byte chunks per row
+    constexpr int TILE = KVB * RB;                   // bytes of one K (or V) tile image
+    constexpr int QS = DH / 16;                      // k-steps of S^T = K Q^T
+    constexpr int NDB = DH / 32;                     // 32-wide d blocks of O^T
+    constexpr int QROWS = 32 * NW, NT = 64 * NW, NST = (KVB * NCH) / NT;   // staging chunks of K (and of V) per thread and tile
+    static_assert(NST >= 1, "tile smaller than the workgroup");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [2][K tile | V tile]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
 
@@ -58,21 +78,24 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn128_kernel(
     // ---- Q fragments (B operand of S^T = K Q^T): lane (r, h) holds Q[q = r][d = 16 s + 8 h + j] ----
     const int q_row = qt * QROWS + wave * 32 + r;
     const int q_ld = q_row < Lq ? q_row : Lq - 1;
-    bf16x8 qf[8];
+    bf16x8 qf[QS];
 #pragma unroll
-    for (int s = 0; s < 8; ++s) qf[s] = *(const bf16x8*)(Qb + (int64_t)q_ld * q_rs + 16 * s + 8 * h);
+    for (int s = 0; s < QS; ++s) qf[s] = *(const bf16x8*)(Qb + (int64_t)q_ld * q_rs + 16 * s + 8 * h);
     // Retire the Q loads HERE: the empty asm takes every fragment as a read-write operand, so hipcc must have the loaded
     // values in hand before it (it waits vmcnt there) and treats them as fresh afterwards. Without it the loads are sunk to
     // the loop header and every iteration re-waits for them with vmcnt(7..0), draining the K/V prefetch issued at its top.
-    asm volatile("" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3]), "+v"(qf[4]), "+v"(qf[5]), "+v"(qf[6]), "+v"(qf[7]));
+    if constexpr (QS == 8)
+        asm volatile("" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3]), "+v"(qf[4]), "+v"(qf[5]), "+v"(qf[6]), "+v"(qf[7]));
+    else
+        asm volatile("" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3]));
 
     // ---- staging assignment: thread -> 2 chunks of K and 2 of V per tile ----
     int st_row[NST], st_ch[NST], st_off[NST];
 #pragma unroll
     for (int u = 0; u < NST; ++u) {
         const int cid = tid + NT * u;
-        st_row[u] = cid >> 4; st_ch[u] = cid & 15;
-        st_off[u] = img_off(st_row[u], st_ch[u]);
+        st_row[u] = cid / NCH; st_ch[u] = cid % NCH;
+        st_off[u] = img_off<DH>(st_row[u], st_ch[u]);
     }
     u32x4 kreg[NST], vreg[NST];
     auto stage_load = [&](int kv0) {
@@ -84,8 +107,8 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn128_kernel(
         }
     };
     auto stage_write = [&](int buf) {
-        unsigned char* Kbuf = smem + buf * 32768;
-        unsigned char* Vbuf = Kbuf + 16384;
+        unsigned char* Kbuf = smem + buf * 2 * TILE;
+        unsigned char* Vbuf = Kbuf + TILE;
 #pragma unroll
         for (int u = 0; u < NST; ++u) {
             *(u32x4*)(Kbuf + st_off[u]) = kreg[u];
@@ -94,26 +117,26 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn128_kernel(
     };
 
     // ---- per-lane LDS read offsets ----
-    // K row read: row = kb*32 + r, chunk = 2s + h  ->  256*row + 16*((2s) ^ kx),  kx = h ^ swizzle(r)
-    const int k_rowoff = 256 * r;
-    const int kx = h ^ (((r & 3) << 2) | ((r >> 2) & 3));
+    // K row read: row = kb*32 + r, chunk = 2s + h  ->  RB*row + 16*((2s) ^ kx),  kx = h ^ f(r)   (f ignores the kb*32 part)
+    const int k_rowoff = RB * r;
+    const int kx = h ^ row_swz<DH>(r);
     // V transposed read: group g = lane>>4 (16 lanes), i = lane&15. Block rows = keys 16ks + 4h + (i>>2) (+8 for the
     // second half of the k-step), columns d = 32db + 16(g&1) + 4(i&3)..+3. Lane receives column d = 32db + (lane&31).
     const int i16 = lane & 15, g16 = lane >> 4;
     const int v_key = 4 * h + (i16 >> 2);
     const int v_lowch = 2 * (g16 & 1) + ((i16 & 3) >> 1);
     const int v_b8 = 8 * (i16 & 1);
-    int voff_lo[4], voff_hi[4];
+    int voff_lo[NDB], voff_hi[NDB];
 #pragma unroll
-    for (int db = 0; db < 4; ++db) {
+    for (int db = 0; db < NDB; ++db) {
         const int ch = 4 * db + v_lowch;
-        voff_lo[db] = 256 * v_key + 16 * (ch ^ (((i16 >> 2) << 2) | h)) + v_b8;            // key & 3 = i>>2, (key>>2)&3 = h
-        voff_hi[db] = 256 * (v_key + 8) + 16 * (ch ^ (((i16 >> 2) << 2) | (h + 2))) + v_b8;  // key + 8: (key>>2)&3 = h + 2
+        voff_lo[db] = RB * v_key + 16 * (ch ^ row_swz<DH>(v_key)) + v_b8;              // f(16 ks + key) == f(key)
+        voff_hi[db] = RB * (v_key + 8) + 16 * (ch ^ row_swz<DH>(v_key + 8)) + v_b8;
     }
 
-    f32x16 oacc[4];
+    f32x16 oacc[NDB];
 #pragma unroll
-    for (int db = 0; db < 4; ++db)
+    for (int db = 0; db < NDB; ++db)
 #pragma unroll
         for (int i = 0; i < 16; ++i) oacc[db][i] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
@@ -126,8 +149,8 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn128_kernel(
     for (int t = 0; t < ntiles; ++t) {
         const int cur = t & 1;
         const int kv0 = t * KVB;
-        const unsigned char* Kbuf = smem + cur * 32768;
-        const unsigned char* Vbuf = Kbuf + 16384;
+        const unsigned char* Kbuf = smem + cur * 2 * TILE;
+        const unsigned char* Vbuf = Kbuf + TILE;
         if (t + 1 < ntiles) stage_load(kv0 + KVB);
 
         // ---- S^T[key][q]: all 8 K fragments of key block 0 first, then block-0 MFMAs with the block-1 reads between them ----
@@ -137,22 +160,22 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn128_kernel(
 #pragma unroll
             for (int i = 0; i < 16; ++i) sacc[kb][i] = 0.f;
         {
-            bf16x8 kf0[8], kf1[8];
+            bf16x8 kf0[QS], kf1[QS];
 #pragma unroll
-            for (int s = 0; s < 8; ++s) kf0[s] = *(const bf16x8*)(Kbuf + k_rowoff + 16 * ((2 * s) ^ kx));
+            for (int s = 0; s < QS; ++s) kf0[s] = *(const bf16x8*)(Kbuf + k_rowoff + 16 * ((2 * s) ^ kx));
 #pragma unroll
-            for (int s = 0; s < 8; ++s) kf1[s] = *(const bf16x8*)(Kbuf + 8192 + k_rowoff + 16 * ((2 * s) ^ kx));
+            for (int s = 0; s < QS; ++s) kf1[s] = *(const bf16x8*)(Kbuf + 32 * RB + k_rowoff + 16 * ((2 * s) ^ kx));
 #pragma unroll
-            for (int s = 0; s < 8; ++s) sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0[s], qf[s], sacc[0], 0, 0, 0);
+            for (int s = 0; s < QS; ++s) sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0[s], qf[s], sacc[0], 0, 0, 0);
 #pragma unroll
-            for (int s = 0; s < 8; ++s) sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1[s], qf[s], sacc[1], 0, 0, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);            // 8 ds_read (block 0)
+            for (int s = 0; s < QS; ++s) sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1[s], qf[s], sacc[1], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, QS, 0);           // ds_reads of key block 0
 #pragma unroll
-            for (int s = 0; s < 8; ++s) {
+            for (int s = 0; s < QS; ++s) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);        // 1 MFMA (block 0)
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);        // 1 ds_read (block 1)
             }
-            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);            // 8 MFMA (block 1)
+            __builtin_amdgcn_sched_group_barrier(0x008, QS, 0);           // MFMAs of block 1
         }
         if (kv0 + KVB > Lkv) {   // ragged last tile: keys >= Lkv do not exist
 #pragma unroll
@@ -175,7 +198,7 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn128_kernel(
             const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
             l_run *= alpha;
 #pragma unroll
-            for (int db = 0; db < 4; ++db)
+            for (int db = 0; db < NDB; ++db)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) oacc[db][i] *= alpha;
             m_run = m_new;
@@ -200,20 +223,20 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn128_kernel(
         }
         // ---- O^T[d][q] += V^T[d][key] P^T[key][q]: the V fragments of d-block db+1 are read between the MFMAs of block db ----
         {
-            bf16x8 vf[4][4];
+            bf16x8 vf[NDB][4];
 #pragma unroll
-            for (int db = 0; db < 4; ++db)
+            for (int db = 0; db < NDB; ++db)
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks)
-                    vf[db][ks] = tr_read_pair(Vbuf + ks * 4096 + voff_lo[db], Vbuf + ks * 4096 + voff_hi[db]);
+                    vf[db][ks] = tr_read_pair(Vbuf + ks * 16 * RB + voff_lo[db], Vbuf + ks * 16 * RB + voff_hi[db]);
 #pragma unroll
-            for (int db = 0; db < 4; ++db)
+            for (int db = 0; db < NDB; ++db)
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks)
                     oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[db][ks], pf[ks >> 1][ks & 1], oacc[db], 0, 0, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 8, 1);            // 8 tr reads (d-block 0)
 #pragma unroll
-            for (int i = 0; i < 12; ++i) {
+            for (int i = 0; i < 4 * (NDB - 1); ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);        // 1 MFMA
                 __builtin_amdgcn_sched_group_barrier(0x100, 2, 1);        // 2 tr reads of the next d-block
             }
@@ -229,7 +252,7 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn128_kernel(
     if (q_row < Lq) {
         bf16_t* Orow = o + (int64_t)b * o_bs + (int64_t)q_row * o_rs + head * DH;
 #pragma unroll
-        for (int db = 0; db < 4; ++db)
+        for (int db = 0; db < NDB; ++db)
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 u32x2 w;
@@ -249,7 +272,7 @@ extern "C" int ug_flash_attn_fwd(const void* q, int64_t q_row_stride, int64_t q_
                                  ug_stream_t stream) {
     if (batches == 0 || Lq == 0) return UG_OK;
     UG_REQUIRE(q && k && v && o && batches > 0 && heads > 0 && Lq > 0 && Lkv > 0, UG_ERR_BAD_SHAPE, "ug_flash_attn_fwd: bad arguments");
-    UG_REQUIRE(dh == 128, UG_ERR_UNSUPPORTED, "ug_flash_attn_fwd: head dim %d not supported yet (128 only)", dh);
+    UG_REQUIRE(dh == 128 || dh == 64, UG_ERR_UNSUPPORTED, "ug_flash_attn_fwd: head dim %d not in {64, 128}", dh);
     UG_REQUIRE(Lq < (1 << 30) && Lkv < (1 << 30), UG_ERR_UNSUPPORTED, "ug_flash_attn_fwd: sequence too long");
     UG_REQUIRE(q_row_stride % 8 == 0 && k_row_stride % 8 == 0 && v_row_stride % 8 == 0 && o_row_stride % 4 == 0 &&
                q_batch_stride % 8 == 0 && k_batch_stride % 8 == 0 && v_batch_stride % 8 == 0 && o_batch_stride % 4 == 0 &&
@@ -262,14 +285,13 @@ extern "C" int ug_flash_attn_fwd(const void* q, int64_t q_row_stride, int64_t q_
     const int64_t nwg = (int64_t)nQ * heads * batches;
     UG_REQUIRE(nwg < (1ll << 31), UG_ERR_UNSUPPORTED, "ug_flash_attn_fwd: grid too large");
     const float c = softmax_scale * 1.4426950408889634f;
-    if (nw == 8)
-        hipLaunchKernelGGL(flash_attn128_kernel<8>, dim3((unsigned)nwg), dim3(512), 65536, (hipStream_t)stream, (const bf16_t*)q,
-                           q_row_stride, q_batch_stride, (const bf16_t*)k, k_row_stride, k_batch_stride, (const bf16_t*)v,
-                           v_row_stride, v_batch_stride, (bf16_t*)o, o_row_stride, o_batch_stride, (int)heads, (int)Lq, (int)Lkv, nQ, c);
-    else
-        hipLaunchKernelGGL(flash_attn128_kernel<4>, dim3((unsigned)nwg), dim3(256), 65536, (hipStream_t)stream, (const bf16_t*)q,
-                           q_row_stride, q_batch_stride, (const bf16_t*)k, k_row_stride, k_batch_stride, (const bf16_t*)v,
-                           v_row_stride, v_batch_stride, (bf16_t*)o, o_row_stride, o_batch_stride, (int)heads, (int)Lq, (int)Lkv, nQ, c);
+#define UG_ATTN_LAUNCH(DHV, NWV)                                                                                                     \
+    hipLaunchKernelGGL((flash_attn_kernel<DHV, NWV>), dim3((unsigned)nwg), dim3(64 * NWV), 2 * 2 * KVB * 2 * DHV, (hipStream_t)stream, \
+                       (const bf16_t*)q, q_row_stride, q_batch_stride, (const bf16_t*)k, k_row_stride, k_batch_stride, (const bf16_t*)v, \
+                       v_row_stride, v_batch_stride, (bf16_t*)o, o_row_stride, o_batch_stride, (int)heads, (int)Lq, (int)Lkv, nQ, c)
+    if (dh == 128) { if (nw == 8) UG_ATTN_LAUNCH(128, 8); else UG_ATTN_LAUNCH(128, 4); }
+    else           { if (nw == 8) UG_ATTN_LAUNCH(64, 8); else UG_ATTN_LAUNCH(64, 4); }
+#undef UG_ATTN_LAUNCH
     UG_CHECK_LAUNCH("ug_flash_attn_fwd");
     return UG_OK;
 }

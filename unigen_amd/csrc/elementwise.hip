@@ -238,7 +238,59 @@ __global__ void add_kernel(const bf16_t* __restrict__ a, int64_t lda, const bf16
     }
 }
 
+__global__ void add_rowbcast_f32_kernel(bf16_t* __restrict__ x, int64_t ldx, const float* __restrict__ t, int64_t ldt, int64_t rows,
+                                        int64_t rpb, int chunks_per_row) {
+    const int64_t total = rows * chunks_per_row;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / chunks_per_row; const int c = (int)(i - r * chunks_per_row);
+        float f[8];
+        unpack8(*(const u32x4*)(x + r * ldx + c * 8), f);
+        const float* tp = t + (r % rpb) * ldt + c * 8;
+        const f32x4 a = *(const f32x4*)tp, b = *(const f32x4*)(tp + 4);
+        f[0] += a[0]; f[1] += a[1]; f[2] += a[2]; f[3] += a[3]; f[4] += b[0]; f[5] += b[1]; f[6] += b[2]; f[7] += b[3];
+        *(u32x4*)(x + r * ldx + c * 8) = pack8(f);
+    }
+}
+
+__global__ void gather_rows_kernel(const bf16_t* __restrict__ src, int64_t ld_src, const int32_t* __restrict__ idx, bf16_t* __restrict__ out,
+                                   int64_t ld_out, int64_t n, int chunks_per_row) {
+    const int64_t total = n * chunks_per_row;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / chunks_per_row; const int c = (int)(i - r * chunks_per_row);
+        const int s = idx[r];
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (s >= 0) v = *(const u32x4*)(src + (int64_t)s * ld_src + c * 8);
+        *(u32x4*)(out + r * ld_out + c * 8) = v;
+    }
+}
+
 }  // namespace
+
+extern "C" int ug_add_rowbcast_f32(void* x, int64_t ldx, const float* table, int64_t ldt, int64_t rows, int64_t rows_per_batch, int64_t D,
+                                   ug_stream_t stream) {
+    if (rows == 0 || D == 0) return UG_OK;
+    UG_REQUIRE(x && table && rows > 0 && rows_per_batch > 0 && D > 0, UG_ERR_BAD_SHAPE, "ug_add_rowbcast_f32: bad arguments");
+    UG_REQUIRE(D % 8 == 0 && ldx % 8 == 0 && ldt % 4 == 0 && ug_aligned(x, 16) && ug_aligned(table, 16), UG_ERR_BAD_ALIGN,
+               "ug_add_rowbcast_f32: 16-byte alignment required");
+    const int64_t total = rows * (D / 8);
+    const unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, 2048);
+    hipLaunchKernelGGL(add_rowbcast_f32_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (bf16_t*)x, ldx, table, ldt, rows, rows_per_batch, (int)(D / 8));
+    UG_CHECK_LAUNCH("ug_add_rowbcast_f32");
+    return UG_OK;
+}
+
+extern "C" int ug_gather_rows(const void* src, int64_t ld_src, const int32_t* idx, void* out, int64_t ld_out, int64_t n, int64_t W,
+                              ug_stream_t stream) {
+    if (n == 0 || W == 0) return UG_OK;
+    UG_REQUIRE(src && idx && out && n > 0 && W > 0, UG_ERR_BAD_SHAPE, "ug_gather_rows: bad arguments");
+    UG_REQUIRE(W % 8 == 0 && ld_src % 8 == 0 && ld_out % 8 == 0 && ug_aligned(src, 16) && ug_aligned(out, 16), UG_ERR_BAD_ALIGN,
+               "ug_gather_rows: 16-byte alignment required");
+    const int64_t total = n * (W / 8);
+    const unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, ld_src, idx, (bf16_t*)out, ld_out, n, (int)(W / 8));
+    UG_CHECK_LAUNCH("ug_gather_rows");
+    return UG_OK;
+}
 
 extern "C" int ug_adaln_modulate(const void* x, int64_t ldx, int64_t x_rpb, int64_t x_bstride, const void* shift,
                                  const void* scale, int64_t mod_ld, int64_t rows_per_sample, void* out, int64_t ldo,

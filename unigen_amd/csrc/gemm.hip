@@ -85,11 +85,11 @@ __device__ __forceinline__ void epi_store(const ug_gemm_desc& p, int g, int64_t 
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = gelu_tanh(v[r]);
         } else if constexpr (EPI == UG_EPI_RES_GATE || EPI == UG_EPI_RES_SCALE) {
-            const bf16_t* R = (const bf16_t*)p.R + ug_rowmap(m, p.r_rpb, p.r_bstride) * p.ldr + n;
+            const bf16_t* R = (const bf16_t*)p.R + (int64_t)g * p.r_gstride + ug_rowmap(m, p.r_rpb, p.r_bstride) * p.ldr + n;
             const u32x2 r2 = *(const u32x2*)R;
             const float rv[4] = {bflo(r2.x), bfhi(r2.x), bflo(r2.y), bfhi(r2.y)};
             if constexpr (EPI == UG_EPI_RES_GATE) {
-                const bf16_t* G = (const bf16_t*)p.gate + (m / p.rows_per_sample) * p.gate_ld + n;
+                const bf16_t* G = (const bf16_t*)p.gate + (int64_t)g * p.gate_gstride + (m / p.rows_per_sample) * p.gate_ld + n;
                 const u32x2 g2 = *(const u32x2*)G;
                 const float gv[4] = {bflo(g2.x), bfhi(g2.x), bflo(g2.y), bfhi(g2.y)};
 #pragma unroll
@@ -422,11 +422,10 @@ extern "C" int ug_gemm_bf16(const ug_gemm_desc* dp, ug_stream_t stream) {
                "ug_gemm_bf16: C needs ldc %% 4 == 0 and an aligned base");
     UG_REQUIRE(!d.bias || (ug_aligned(d.bias, 8) && d.bias_gstride % 4 == 0), UG_ERR_BAD_ALIGN, "ug_gemm_bf16: bias alignment");
     if (d.epilogue == UG_EPI_RES_GATE || d.epilogue == UG_EPI_RES_SCALE) {
-        UG_REQUIRE(d.R && d.ldr % 4 == 0 && ug_aligned(d.R, 8), UG_ERR_BAD_ALIGN, "ug_gemm_bf16: residual missing/misaligned");
-        UG_REQUIRE(d.groups == 1, UG_ERR_UNSUPPORTED, "ug_gemm_bf16: residual epilogues are not grouped");
+        UG_REQUIRE(d.R && d.ldr % 4 == 0 && ug_aligned(d.R, 8) && d.r_gstride % 4 == 0, UG_ERR_BAD_ALIGN, "ug_gemm_bf16: residual missing/misaligned");
     }
     if (d.epilogue == UG_EPI_RES_GATE)
-        UG_REQUIRE(d.gate && d.rows_per_sample > 0 && d.gate_ld % 4 == 0 && ug_aligned(d.gate, 8), UG_ERR_BAD_SHAPE,
+        UG_REQUIRE(d.gate && d.rows_per_sample > 0 && d.gate_ld % 4 == 0 && ug_aligned(d.gate, 8) && d.gate_gstride % 4 == 0, UG_ERR_BAD_SHAPE,
                    "ug_gemm_bf16: gate missing/misaligned");
     if (d.lora_r > 0) {
         UG_REQUIRE(d.lora_r % BK == 0, UG_ERR_UNSUPPORTED, "ug_gemm_bf16: lora_r=%d must be padded to a multiple of %d", d.lora_r, BK);

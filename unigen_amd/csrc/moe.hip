@@ -203,20 +203,22 @@ __global__ __launch_bounds__(256) void moe_dispatch_kernel(const bf16_t* __restr
     const int e = (int)(sl / capacity);
     const int b = tok / tokens_per_sample;
     const bf16_t* xr = x + (int64_t)tok * ldx;
-    const bf16_t* mr = mod + ((int64_t)e * B + b) * D;
+    const bf16_t* mr = mod ? mod + ((int64_t)e * B + b) * D : nullptr;
     const bf16_t* ar = add ? add + sl * D : nullptr;
     for (int ch = lane; ch < nchunk; ch += 64) {
         float a[8], m[8];
         unpack8(*(const u32x4*)(xr + ch * 8), a);
-        unpack8(*(const u32x4*)(mr + ch * 8), m);
+        if (mr) unpack8(*(const u32x4*)(mr + ch * 8), m);
         if (ar) {
             float t[8];
             unpack8(*(const u32x4*)(ar + ch * 8), t);
 #pragma unroll
             for (int i = 0; i < 8; ++i) a[i] = rbf(a[i] + t[i]);
         }
+        if (mr) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) a[i] *= m[i];
+            for (int i = 0; i < 8; ++i) a[i] *= m[i];
+        }
         *(u32x4*)(orow + ch * 8) = pack8(a);
     }
 }
@@ -299,9 +301,9 @@ extern "C" int ug_moe_capacity_rts(const float* gates, const int32_t* idx, const
 extern "C" int ug_moe_dispatch_modulate(const void* x, int64_t ldx, const void* add, const void* mod, int64_t B,
                                         const int32_t* token_of_slot, int32_t E, int64_t capacity, int64_t tokens_per_sample,
                                         int64_t D, void* out, ug_stream_t stream) {
-    UG_REQUIRE(x && mod && token_of_slot && out && E > 0 && capacity > 0 && tokens_per_sample > 0 && B > 0, UG_ERR_BAD_SHAPE,
+    UG_REQUIRE(x && token_of_slot && out && E > 0 && capacity > 0 && tokens_per_sample > 0 && B > 0, UG_ERR_BAD_SHAPE,
                "ug_moe_dispatch_modulate: bad arguments");
-    UG_REQUIRE(D % 8 == 0 && ldx % 8 == 0 && ug_aligned(x, 16) && ug_aligned(mod, 16) && ug_aligned(out, 16) && (!add || ug_aligned(add, 16)),
+    UG_REQUIRE(D % 8 == 0 && ldx % 8 == 0 && ug_aligned(x, 16) && (!mod || ug_aligned(mod, 16)) && ug_aligned(out, 16) && (!add || ug_aligned(add, 16)),
                UG_ERR_BAD_ALIGN, "ug_moe_dispatch_modulate: 16-byte alignment required");
     const int64_t nslots = (int64_t)E * capacity;
     hipLaunchKernelGGL(moe_dispatch_kernel, dim3((unsigned)((nslots + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx,

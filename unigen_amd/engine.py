@@ -1,0 +1,291 @@
+"""Shared host-side machinery of the HIP engines (UniGenFlux, UniGenSD3): parameter containers under the reference's state-dict
+names, weight packing into fused buffers (parameters become views), a workspace cache, token-stream descriptors and the
+block routines that orchestrate calls through the C ABI (unigen_amd/ops.py). No arithmetic happens in torch here."""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Sequence, Tuple
+
+import torch
+from torch import nn
+
+from . import lib as L
+from . import ops
+from .ops import RowMap
+
+BF = torch.bfloat16
+
+
+class _Holder(nn.Module):
+    """Parameter container; the arithmetic lives in libunigen_hip.so, so calling it is an error."""
+
+    def forward(self, *a, **k):  # pragma: no cover
+        raise L.UniGenHipError("parameter holder: unigen_amd modules are executed by the HIP engine, not called directly")
+
+
+def _register(root: nn.Module, name: str, shape: Tuple[int, ...], device, dtype) -> nn.Parameter:
+    parts = name.split(".")
+    mod = root
+    for part in parts[:-1]:
+        child = mod._modules.get(part)
+        if child is None:
+            child = _Holder()
+            mod.add_module(part, child)
+        mod = child
+    p = nn.Parameter(torch.empty(shape, device=device, dtype=dtype), requires_grad=False)
+    mod.register_parameter(parts[-1], p)
+    return p
+
+
+class _Workspace:
+    def __init__(self):
+        self._bufs: Dict[Tuple, torch.Tensor] = {}
+
+    def get(self, name: str, shape: Sequence[int], dtype, device) -> torch.Tensor:
+        key = (name, tuple(shape), dtype, str(device))
+        t = self._bufs.get(key)
+        if t is None:
+            t = torch.empty(tuple(shape), dtype=dtype, device=device)
+            self._bufs[key] = t
+        return t
+
+    def clear(self):
+        self._bufs.clear()
+
+
+class _Stream:
+    """A token stream [B, Ls, D] living in some buffer: `base` is a 2-D view whose row 0 is token (0, 0); logical row
+    m = b * Ls + r sits at physical row b * bstride + r (RowMap), leading dimension `ld`."""
+    __slots__ = ("base", "ld", "map", "Ls")
+
+    def __init__(self, base: torch.Tensor, Ls: int, bstride: Optional[int] = None):
+        self.base, self.ld, self.Ls = base, base.stride(0), Ls
+        self.map = RowMap() if (bstride is None or bstride == Ls) else RowMap(Ls, bstride)
+
+
+class HipModule(nn.Module):
+    """Base of the drop-in transformer classes: holds parameters, never computes in torch."""
+
+    inner_dim: int
+    _heads: int
+    _head_dim: int
+
+    def __init__(self):
+        super().__init__()
+        self._ws = _Workspace()
+        self._packed: Dict[str, torch.Tensor] = {}
+        self.trainable_control_modules: Dict[str, nn.Module] = {}
+
+    def _probe(self) -> torch.Tensor:
+        return next(self.parameters())
+
+    @property
+    def dtype(self):
+        return self._probe().dtype
+
+    @property
+    def device(self):
+        return self._probe().device
+
+    def init_trainable_param(self):
+        for module in self.trainable_control_modules.values():
+            module.requires_grad_(True)
+
+    def enable_gradient_checkpointing(self):
+        pass  # forward-only engine
+
+    def init_synthetic_(self, seed: int = 0, std: float = 0.02, bias_std: float = 0.0) -> "HipModule":
+        """Seeded N(0, std^2) weights, zero (or N(0, bias_std^2)) biases, unit RMSNorm weights; the zero-res projections are
+        randomised too so the control path contributes. Generated on the parameters' device."""
+        g = torch.Generator(device=self.device).manual_seed(seed)
+        with torch.no_grad():
+            for name, p in self.named_parameters():
+                if ".norm_q." in name or ".norm_k." in name or ".norm_added_q." in name or ".norm_added_k." in name:
+                    p.fill_(1.0)
+                elif name.endswith(".bias"):
+                    if bias_std > 0:
+                        p.copy_(torch.randn(p.shape, generator=g, device=p.device, dtype=torch.float32) * bias_std)
+                    else:
+                        p.zero_()
+                else:
+                    # chunked to bound the fp32 temporary for the 12288 x 3072 matrices
+                    p.copy_(torch.randn(p.shape, generator=g, device=p.device, dtype=torch.float32) * std)
+        return self
+
+    # ------------------------------------------------------------------ weight packing --------------------------------
+    def _P(self, name: str) -> torch.Tensor:
+        return self.get_parameter(name).data
+
+    def _pack(self, key: str, names: Sequence[str]) -> torch.Tensor:
+        """Concatenate parameters along dim 0 into one buffer and re-point them at views of it (no duplicate storage)."""
+        params = [self.get_parameter(n) for n in names]
+        t = self._packed.get(key)
+        if t is not None and params[0].data.data_ptr() == t.data_ptr() and params[0].device == t.device:
+            return t
+        t = torch.cat([p.data for p in params], dim=0).contiguous()
+        off = 0
+        for p in params:
+            n = p.data.shape[0]
+            p.data = t[off:off + n]
+            off += n
+        self._packed[key] = t
+        return t
+
+    def _pack_stack(self, key: str, names: Sequence[str]) -> torch.Tensor:
+        params = [self.get_parameter(n) for n in names]
+        t = self._packed.get(key)
+        if t is not None and params[0].data.data_ptr() == t.data_ptr() and params[0].device == t.device:
+            return t
+        t = torch.stack([p.data for p in params], dim=0).contiguous()
+        for i, p in enumerate(params):
+            p.data = t[i]
+        self._packed[key] = t
+        return t
+
+    def _attn_qkv(self, p: str) -> Tuple[torch.Tensor, torch.Tensor]:
+        return (self._pack(p + ".qkv.w", [f"{p}.to_q.weight", f"{p}.to_k.weight", f"{p}.to_v.weight"]),
+                self._pack(p + ".qkv.b", [f"{p}.to_q.bias", f"{p}.to_k.bias", f"{p}.to_v.bias"]))
+
+    def _attn_add_qkv(self, p: str) -> Tuple[torch.Tensor, torch.Tensor]:
+        return (self._pack(p + ".aqkv.w", [f"{p}.add_q_proj.weight", f"{p}.add_k_proj.weight", f"{p}.add_v_proj.weight"]),
+                self._pack(p + ".aqkv.b", [f"{p}.add_q_proj.bias", f"{p}.add_k_proj.bias", f"{p}.add_v_proj.bias"]))
+
+    # ------------------------------------------------------------------ small pieces ----------------------------------
+    def _w(self, name, shape, dtype=BF):
+        return self._ws.get(name, shape, dtype, self.device)
+
+    def _time_text_embed(self, prefix: str, t_f32: torch.Tensor, pooled: torch.Tensor, g_f32: Optional[torch.Tensor], tag: str) -> torch.Tensor:
+        """CombinedTimestep(Guidance)TextProjEmbeddings (diffusers embeddings.py)."""
+        B, D = pooled.shape[0], self.inner_dim
+        tp = ops.timestep_embed(t_f32, self._w("tp", (B, 256)))
+        h1 = ops.small_linear(tp, self._P(prefix + ".timestep_embedder.linear_1.weight"), self._P(prefix + ".timestep_embedder.linear_1.bias"), self._w("tte_h", (B, D)))
+        emb = ops.small_linear(h1, self._P(prefix + ".timestep_embedder.linear_2.weight"), self._P(prefix + ".timestep_embedder.linear_2.bias"),
+                               self._w("tte_t" + tag, (B, D)), silu_in=True)
+        if g_f32 is not None:
+            gp = ops.timestep_embed(g_f32, self._w("gp", (B, 256)))
+            h1 = ops.small_linear(gp, self._P(prefix + ".guidance_embedder.linear_1.weight"), self._P(prefix + ".guidance_embedder.linear_1.bias"), self._w("tte_h", (B, D)))
+            emb = ops.small_linear(h1, self._P(prefix + ".guidance_embedder.linear_2.weight"), self._P(prefix + ".guidance_embedder.linear_2.bias"),
+                                   self._w("tte_g" + tag, (B, D)), silu_in=True, residual=emb)
+        h2 = ops.small_linear(pooled, self._P(prefix + ".text_embedder.linear_1.weight"), self._P(prefix + ".text_embedder.linear_1.bias"), self._w("tte_h2", (B, D)))
+        return ops.small_linear(h2, self._P(prefix + ".text_embedder.linear_2.weight"), self._P(prefix + ".text_embedder.linear_2.bias"),
+                                self._w("temb_" + tag, (B, D)), silu_in=True, residual=emb)
+
+    def _adaln_emb(self, prefix: str, temb: torch.Tensor, nchunks: int, tag: str) -> torch.Tensor:
+        """AdaLayerNormZero*.linear(silu(emb)) -> [B, nchunks * D]."""
+        B, D = temb.shape[0], self.inner_dim
+        return ops.small_linear(temb, self._P(prefix + ".linear.weight"), self._P(prefix + ".linear.bias"), self._w("emb_" + tag, (B, nchunks * D)), silu_in=True)
+
+    def _modulate(self, s: _Stream, emb: torch.Tensor, shift_chunk: int, scale_chunk: int, B: int, tag: str) -> torch.Tensor:
+        D = self.inner_dim
+        out = self._w("norm_" + tag, (B * s.Ls, D))
+        ops.adaln_modulate(s.base, emb[:, shift_chunk * D:], emb[:, scale_chunk * D:], out, rows=B * s.Ls, D=D, rows_per_sample=s.Ls,
+                           mod_ld=emb.stride(0), ldx=s.ld, x_map=s.map)
+        return out
+
+    # ------------------------------------------------------------------ blocks ----------------------------------------
+    def _double_block(self, p: str, B: int, s_in: _Stream, s_out: _Stream, c_in: _Stream, c_out: Optional[_Stream], temb: torch.Tensor,
+                      rope: Optional[Tuple[torch.Tensor, torch.Tensor]], tag: str, ctx_cached: bool = False, dual: bool = False,
+                      ctx_continuous: bool = False) -> None:
+        """One MM-DiT joint block: diffusers FluxTransformerBlock (and its undefined control twin) or SD3's
+        JointTransformerBlock as restated at src/UniGenUtils.py:440-522. Joint layout [context | sample] (attention is
+        order-free; RoPE tables, when given, follow this order).
+        c_out None : the context stream only contributes K/V (its own output is discarded by every caller, or the block is
+                     `context_pre_only`); ctx_continuous selects AdaLayerNormContinuous (scale first) for that stream.
+        ctx_cached : the context K/V already sit in this tag's qkv workspace (same block, same step).
+        dual       : SD3.5 dual attention (SD35AdaLayerNormZeroX: 9 chunks; attn2 = self-attention over the sample stream)."""
+        D, H, dh = self.inner_dim, self._heads, self._head_dim
+        Ls, Lc = s_in.Ls, c_in.Ls
+        Lj = Lc + Ls
+        a = p + ".attn"
+        qkv = self._w("qkv_" + tag, (B, Lj, 3 * D))
+        qkv2 = qkv.view(B * Lj, 3 * D)
+        cos, sin = rope if rope is not None else (None, None)
+        opt = lambda n: self._P(n) if n in self._pnames() else None
+        wq, wk = opt(a + ".norm_q.weight"), opt(a + ".norm_k.weight")
+        waq, wak = opt(a + ".norm_added_q.weight"), opt(a + ".norm_added_k.weight")
+        touch = cos is not None or wq is not None           # q/k need a pass at all (qk-norm and/or RoPE)
+        # sample stream: AdaLN-Zero -> fused QKV
+        emb_s = self._adaln_emb(p + ".norm1", temb, 9 if dual else 6, tag + "s")
+        ns = self._modulate(s_in, emb_s, 0, 1, B, "s")
+        w_qkv, b_qkv = self._attn_qkv(a)
+        ops.gemm(ns, w_qkv, b_qkv, qkv2[Lc:], M=B * Ls, ldc=3 * D, c_map=RowMap(Ls, Lj))
+        # context stream
+        emb_c = None
+        if c_out is not None or not ctx_cached:
+            if ctx_continuous:                                # AdaLayerNormContinuous: chunks (scale, shift)
+                emb_c = self._adaln_emb(p + ".norm1_context", temb, 2, tag + "c")
+                nc = self._modulate(c_in, emb_c, 1, 0, B, "c")
+            else:
+                emb_c = self._adaln_emb(p + ".norm1_context", temb, 6, tag + "c")
+                nc = self._modulate(c_in, emb_c, 0, 1, B, "c")
+            w_a, b_a = self._attn_add_qkv(a)
+            if c_out is not None:
+                ops.gemm(nc, w_a, b_a, qkv2, M=B * Lc, ldc=3 * D, c_map=RowMap(Lc, Lj))
+            else:
+                ops.gemm(nc, w_a[D:], b_a[D:], qkv2[0, D:], M=B * Lc, ldc=3 * D, c_map=RowMap(Lc, Lj))
+        if touch:
+            if c_out is not None:
+                ops.qk_rmsnorm_rope(qkv2, batches=B, rows_per_batch=Lj, ld=3 * D, q_off=0, k_off=D, heads=H, dh=dh, wq_a=waq, wk_a=wak,
+                                    wq_b=wq, wk_b=wk, split=Lc, cos=cos, sin=sin)
+            else:
+                ops.qk_rmsnorm_rope(qkv2[Lc:], batches=B, rows_per_batch=Ls, batch_stride_rows=Lj, pos_offset=Lc, ld=3 * D, q_off=0, k_off=D,
+                                    heads=H, dh=dh, wq_b=wq, wk_b=wk, split=0, cos=cos, sin=sin)
+                if not ctx_cached:
+                    ops.qk_rmsnorm_rope(qkv2, batches=B, rows_per_batch=Lc, batch_stride_rows=Lj, pos_offset=0, ld=3 * D, q_off=-1, k_off=D,
+                                        heads=H, dh=dh, wk_a=wak, split=Lc, cos=cos, sin=sin)
+        # attention over the joint sequence; queries = every row, or the sample rows only
+        st = (3 * D, Lj * 3 * D)
+        if c_out is not None:
+            att = self._w("att_" + tag, (B * Lj, D))
+            ops.flash_attn(qkv2, qkv2[0, D:], qkv2[0, 2 * D:], att, batches=B, heads=H, dh=dh, Lq=Lj, Lkv=Lj, q_strides=st, k_strides=st,
+                           v_strides=st, o_strides=(D, Lj * D))
+            att_s, att_map = att[Lc:], RowMap(Ls, Lj)
+        else:
+            att = self._w("att_" + tag, (B * Ls, D))
+            ops.flash_attn(qkv2[Lc:], qkv2[0, D:], qkv2[0, 2 * D:], att, batches=B, heads=H, dh=dh, Lq=Ls, Lkv=Lj, q_strides=st, k_strides=st,
+                           v_strides=st, o_strides=(D, Ls * D))
+            att_s, att_map = att, RowMap()
+        # sample: x = x + gate_msa * to_out(attn)
+        ops.gemm(att_s, self._P(a + ".to_out.0.weight"), self._P(a + ".to_out.0.bias"), s_out.base, M=B * Ls, epilogue=L.EPI_RES_GATE, lda=D,
+                 a_map=att_map, ldc=s_out.ld, c_map=s_out.map, residual=s_in.base, ldr=s_in.ld, r_map=s_in.map, gate=emb_s[:, 2 * D:],
+                 gate_ld=emb_s.stride(0), rows_per_sample=Ls)
+        if dual:
+            # x = x + gate_msa2 * attn2(LN(x_in) * (1 + scale_msa2) + shift_msa2): self-attention over the sample tokens only
+            a2 = p + ".attn2"
+            n2 = self._modulate(s_in, emb_s, 6, 7, B, "s")
+            q2 = self._w("qkv2_" + tag, (B * Ls, 3 * D))
+            w2, b2 = self._attn_qkv(a2)
+            ops.gemm(n2, w2, b2, q2, M=B * Ls)
+            w2q, w2k = opt(a2 + ".norm_q.weight"), opt(a2 + ".norm_k.weight")
+            if w2q is not None:
+                ops.qk_rmsnorm_rope(q2, batches=B, rows_per_batch=Ls, ld=3 * D, q_off=0, k_off=D, heads=H, dh=dh, wq_b=w2q, wk_b=w2k, split=0)
+            att2 = self._w("att2_" + tag, (B * Ls, D))
+            st2 = (3 * D, Ls * 3 * D)
+            ops.flash_attn(q2, q2[0, D:], q2[0, 2 * D:], att2, batches=B, heads=H, dh=dh, Lq=Ls, Lkv=Ls, q_strides=st2, k_strides=st2,
+                           v_strides=st2, o_strides=(D, Ls * D))
+            ops.gemm(att2, self._P(a2 + ".to_out.0.weight"), self._P(a2 + ".to_out.0.bias"), s_out.base, M=B * Ls, epilogue=L.EPI_RES_GATE,
+                     ldc=s_out.ld, c_map=s_out.map, residual=s_out.base, ldr=s_out.ld, r_map=s_out.map, gate=emb_s[:, 8 * D:],
+                     gate_ld=emb_s.stride(0), rows_per_sample=Ls)
+        # x = x + gate_mlp * ff(norm2(x) * (1 + scale_mlp) + shift_mlp)
+        self._ff(p + ".ff", B, s_out, emb_s, "s")
+        if c_out is not None:
+            ops.gemm(att, self._P(a + ".to_add_out.weight"), self._P(a + ".to_add_out.bias"), c_out.base, M=B * Lc, epilogue=L.EPI_RES_GATE, lda=D,
+                     a_map=RowMap(Lc, Lj), ldc=c_out.ld, c_map=c_out.map, residual=c_in.base, ldr=c_in.ld, r_map=c_in.map, gate=emb_c[:, 2 * D:],
+                     gate_ld=emb_c.stride(0), rows_per_sample=Lc)
+            self._ff(p + ".ff_context", B, c_out, emb_c, "c")
+
+    def _pnames(self):
+        names = getattr(self, "_pname_cache", None)
+        if names is None:        # subclasses reset the cache when they register parameters (init_condition_block)
+            names = {n for n, _ in self.named_parameters()}
+            self._pname_cache = names
+        return names
+
+    def _ff(self, p: str, B: int, s: _Stream, emb: torch.Tensor, tag: str) -> None:
+        D = self.inner_dim
+        n2 = self._modulate(s, emb, 3, 4, B, tag)
+        hid = self._w("ffh_" + tag, (B * s.Ls, 4 * D))
+        ops.gemm(n2, self._P(p + ".net.0.proj.weight"), self._P(p + ".net.0.proj.bias"), hid, M=B * s.Ls, epilogue=L.EPI_BIAS_GELU)
+        ops.gemm(hid, self._P(p + ".net.2.weight"), self._P(p + ".net.2.bias"), s.base, M=B * s.Ls, epilogue=L.EPI_RES_GATE, ldc=s.ld, c_map=s.map,
+                 residual=s.base, ldr=s.ld, r_map=s.map, gate=emb[:, 5 * D:], gate_ld=emb.stride(0), rows_per_sample=s.Ls)
+

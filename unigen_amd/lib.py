@@ -34,6 +34,7 @@ class GemmDesc(C.Structure):
         ("lora_T", vp), ("ldt", i64),
         ("lora_B", vp), ("ldb", i64),
         ("lora_r", i32), ("_pad1", i32),
+        ("r_gstride", i64), ("gate_gstride", i64),
     ]
 
 
@@ -49,6 +50,8 @@ SIGNATURES = {
     "ug_timestep_embed": (i32, [vp, vp, i64, i64, i32, vp]),
     "ug_euler_step": (i32, [vp, vp, f32, i64, vp]),
     "ug_add_bf16": (i32, [vp, i64, vp, i64, vp, i64, i64, i64, vp]),
+    "ug_add_rowbcast_f32": (i32, [vp, i64, vp, i64, i64, i64, i64, vp]),
+    "ug_gather_rows": (i32, [vp, i64, vp, vp, i64, i64, i64, vp]),
     "ug_moe_gate_top1": (i32, [vp, vp, i64, vp, i64, i64, i32, vp, vp, vp]),
     "ug_moe_capacity_rts": (i32, [vp, vp, vp, i64, i32, i64, vp, vp, vp, vp, vp]),
     "ug_moe_dispatch_modulate": (i32, [vp, i64, vp, vp, i64, vp, i32, i64, i64, i64, vp, vp]),

@@ -90,7 +90,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: to
          c_map: RowMap = IDENT, residual: Optional[torch.Tensor] = None, ldr: Optional[int] = None,
          r_map: RowMap = IDENT, gate: Optional[torch.Tensor] = None, gate_ld: int = 0, rows_per_sample: int = 0,
          alpha: float = 1.0, groups: int = 1, a_gstride: int = 0, w_gstride: int = 0, bias_gstride: int = 0,
-         c_gstride: int = 0, lora_t: Optional[torch.Tensor] = None, lora_b: Optional[torch.Tensor] = None) -> torch.Tensor:
+         c_gstride: int = 0, r_gstride: int = 0, gate_gstride: int = 0, lora_t: Optional[torch.Tensor] = None,
+         lora_b: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[m, :N] = epilogue(a[m, :K] @ w[:N, :K]^T + bias). `a`/`out`/`residual` are base tensors whose data_ptr is row 0
     (slices of a bigger buffer are fine); leading dims default to the tensors' row strides."""
     _chk(a, "a"); _chk(w, "w")
@@ -110,6 +111,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: to
     d.alpha, d.epilogue = alpha, epilogue
     d.M, d.N, d.K = M, N, K
     d.groups, d.a_gstride, d.w_gstride, d.bias_gstride, d.c_gstride = groups, a_gstride, w_gstride, bias_gstride, c_gstride
+    d.r_gstride, d.gate_gstride = r_gstride, gate_gstride
     if lora_t is not None:
         _chk(lora_t, "lora_t"); _chk(lora_b, "lora_b")
         d.lora_T, d.ldt, d.lora_B, d.ldb, d.lora_r = lora_t.data_ptr(), lora_t.stride(-2), lora_b.data_ptr(), lora_b.stride(-2), lora_b.shape[-1]
@@ -194,6 +196,24 @@ def add(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def add_rowbcast_f32(x: torch.Tensor, table: torch.Tensor, rows_per_batch: int) -> torch.Tensor:
+    """x[r] = bf16(x[r] + table[r % rows_per_batch]) in place; x [rows, D] bf16, table [rows_per_batch, D] fp32."""
+    _chk(x, "x"); _chk(table, "table", torch.float32)
+    rows, D = x.shape
+    assert table.shape == (rows_per_batch, D)
+    L.check(L.load().ug_add_rowbcast_f32(x.data_ptr(), x.stride(0), table.data_ptr(), table.stride(0), rows, rows_per_batch, D, _stream()), "ug_add_rowbcast_f32")
+    return x
+
+
+def gather_rows(src: torch.Tensor, idx: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """out[i] = src[idx[i]] (zeros where idx[i] < 0); src [R, W], idx int32 [n], out [n, W]."""
+    _chk(src, "src"); _chk(idx, "idx", torch.int32); _chk(out, "out")
+    n, W = out.shape
+    assert idx.numel() == n and src.shape[1] == W and idx.is_contiguous()
+    L.check(L.load().ug_gather_rows(src.data_ptr(), src.stride(0), idx.data_ptr(), out.data_ptr(), out.stride(0), n, W, _stream()), "ug_gather_rows")
+    return out
+
+
 def moe_gate_top1(x: torch.Tensor, c: torch.Tensor, wg: torch.Tensor, gates: torch.Tensor, idx: torch.Tensor) -> None:
     _chk(x, "x"); _chk(c, "c"); _chk(wg, "wg"); _chk(gates, "gates", torch.float32); _chk(idx, "idx", torch.int32)
     S, D = x.shape
@@ -214,12 +234,14 @@ def moe_capacity_rts(gates, idx, uniform, capacity: int, slot, token_of_slot, ex
 
 
 def moe_dispatch_modulate(x, add_, mod, token_of_slot, out, *, B: int, E: int, capacity: int, tokens_per_sample: int) -> torch.Tensor:
-    _chk(x, "x"); _chk(mod, "mod"); _chk(out, "out"); _chk(token_of_slot, "token_of_slot", torch.int32)
+    _chk(x, "x"); _chk(out, "out"); _chk(token_of_slot, "token_of_slot", torch.int32)
     D = x.shape[-1]
-    assert mod.is_contiguous() and out.is_contiguous() and mod.numel() == E * B * D and out.numel() == E * capacity * D
+    assert out.is_contiguous() and out.numel() == E * capacity * D
+    if mod is not None:
+        _chk(mod, "mod"); assert mod.is_contiguous() and mod.numel() == E * B * D
     if add_ is not None:
         _chk(add_, "add"); assert add_.is_contiguous()
-    L.check(L.load().ug_moe_dispatch_modulate(x.data_ptr(), x.stride(-2), _p(add_), mod.data_ptr(), B, token_of_slot.data_ptr(), E, capacity,
+    L.check(L.load().ug_moe_dispatch_modulate(x.data_ptr(), x.stride(-2), _p(add_), _p(mod), B, token_of_slot.data_ptr(), E, capacity,
                                               tokens_per_sample, D, out.data_ptr(), _stream()), "ug_moe_dispatch_modulate")
     return out
 
