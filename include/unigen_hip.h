@@ -117,6 +117,10 @@ int ug_timestep_embed(const float* t, void* out, int64_t ldo, int64_t B, int32_t
 /* x = bf16( float(x) + dt * float(v) )  FlowMatchEulerDiscreteScheduler.step (src/UniGenPipeline.py:768). */
 int ug_euler_step(void* x, const void* v, float dt, int64_t n, ug_stream_t stream);
 
+/* out = uncond + gs * (text - uncond), each step rounded to bf16 as the reference's tensor ops do: classifier-free guidance of
+ * UniGenSD3Pipeline (src/UniGenPipeline.py:404-407). n elements, contiguous. */
+int ug_cfg_combine(const void* uncond, const void* text, float guidance_scale, void* out, int64_t n, ug_stream_t stream);
+
 /* out = bf16(a + b) elementwise (bf16), rows x D with leading dims. */
 int ug_add_bf16(const void* a, int64_t lda, const void* b, int64_t ldb, void* out, int64_t ldo,
                 int64_t rows, int64_t D, ug_stream_t stream);

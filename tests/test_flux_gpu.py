@@ -11,7 +11,7 @@ import pytest
 import torch
 
 from oracle import unigen_ref as R
-from tests.util import report, rel_l2
+from tests.util import check_routing, report, rel_l2
 
 pytestmark = pytest.mark.gpu
 BF = torch.bfloat16
@@ -92,3 +92,39 @@ def test_single_add_and_no_shared_expert_variants(gpu):
         out = model(timestep=t.to(gpu), **{k: _to_dev(v, gpu) for k, v in inp.items()})[0]
         m = report(f"forward_variant_{list(ctl_over)[0]}", out, ref16)
         assert m["rel_l2"] <= 2e-2, m
+
+
+def test_denoise_loop_matches_oracle_and_golden(gpu):
+    """2-step denoise (schedule + forward + Euler) through UniGenFLUXPipeline vs the oracle's loop, on the committed fixture inputs."""
+    import importlib
+    from tests.test_oracle_cpu import load_golden
+    cfg_d, case, inp, g = load_golden("flux_tiny_single")
+    rcfg = R.FluxConfig(condition_nums=1, **cfg_d)
+    state = R.make_state(rcfg, seed=case["state_seed"], std=0.05, bias_std=0.02)
+    cls = importlib.import_module("src.UniGenTransformer").UniGenFlux
+    model = cls.from_config(cfg_d, device=gpu, dtype=BF)
+    model.init_condition_block(condition_nums=1, condition_types=["canny"], control_params=dict(CONTROL))
+    res = model.load_state_dict({k: v.to(gpu) for k, v in state.items()}, strict=False)
+    assert not res.missing_keys and not res.unexpected_keys
+    # single forward against the fixture
+    dev_inp = {k: _to_dev(v, gpu) for k, v in inp.items()}
+    out, _, outs = model(timestep=g["timestep"].to(gpu), **dev_inp)
+    m = report("golden_flux_tiny_single_forward", out, g["out.bf16"], err_hip_vs_fp32=rel_l2(out, g["out.fp32"]),
+               err_oraclebf16_vs_fp32=rel_l2(g["out.bf16"], g["out.fp32"]))
+    assert m["err_hip_vs_fp32"] <= 1.25 * m["err_oraclebf16_vs_fp32"] + 1e-3, m
+    # routing: this fixture contains an exact near-tie token, so compare per-token indices with the oracle's gate probabilities in hand
+    trace = {}
+    R.unigen_flux_forward(state, rcfg, timestep=g["timestep"], dtype=BF, trace=trace, **inp)
+    S = inp["hidden_states"].shape[0] * inp["hidden_states"].shape[1]
+    flips = check_routing(model._w("moe_idx", (S,), torch.int32), trace["routing"][0])
+    assert int((outs["expert_counts"].cpu() - g["out.expert_counts"]).abs().sum()) <= 2 * flips
+    pipe = importlib.import_module("src.UniGenPipeline").UniGenFLUXPipeline.from_pretrained(None, transformer=None)
+    pipe.transformer = model
+    B, N = inp["hidden_states"].shape[:2]
+    grid = int(N ** 0.5)
+    res = pipe(prompt_embeds=inp["encoder_hidden_states"], pooled_prompt_embeds=inp["pooled_projections"],
+               condition_pooled_prompt_embeds=inp["condition_pooled_projections"], control_image=inp["condition_hidden_states"],
+               latents=inp["hidden_states"], height=grid * 16, width=grid * 16, num_inference_steps=2, output_type="latent", dtype=BF,
+               gate_uniforms=[inp["gate_uniform"].to(gpu)] * 2)
+    m = report("golden_flux_tiny_single_denoise2", res.images, g["out.denoise2.bf16"])
+    assert m["rel_l2"] <= 2e-2, m

@@ -37,3 +37,37 @@ def test_sd3_forward_matches_oracle(gpu, modulated, B, hw, T):
     assert err_hip <= 1.25 * err_ref + 1e-3, m
     assert m["rel_l2"] <= 2.5e-2, m
     assert abs(float(losses["moe_loss"]) - float(loss16["moe_loss"])) <= 1e-3 * abs(float(loss16["moe_loss"]))
+
+
+def test_sd3_pipeline_cfg_loop(gpu):
+    """UniGenSD3Pipeline surface: CFG batch doubling + guidance combine + Euler step; compared with the same loop on the oracle."""
+    cls = importlib.import_module("src.UniGenTransformer").UniGenSD3
+    model = cls.from_config(dict(TINY), device=gpu, dtype=BF)
+    model.init_condition_block(condition_nums=1, condition_types=["depth"], control_params=dict(use_shared_expert=True, use_modulate=True))
+    model.init_synthetic_(seed=6, std=0.05, bias_std=0.02)
+    state = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    rcfg = R.SD3Config(use_modulate=True, **TINY)
+    inp = R.make_sd3_inputs(rcfg, B=1, hw=16, T=24)
+    neg = R.make_sd3_inputs(rcfg, B=1, hw=16, T=24, seed=7)
+    uni2 = torch.rand(2 * 64, rcfg.expert_nums, generator=torch.Generator().manual_seed(1))
+    pipe = importlib.import_module("src.UniGenPipeline").UniGenSD3Pipeline.from_pretrained(None, transformer=model)
+    steps, gs = 2, 5.0
+    res = pipe(control_image=inp["condition_hidden_states"], latents=inp["hidden_states"], prompt_embeds=inp["encoder_hidden_states"],
+               negative_prompt_embeds=neg["encoder_hidden_states"], pooled_prompt_embeds=inp["pooled_projections"],
+               negative_pooled_prompt_embeds=neg["pooled_projections"], condition_pooled_prompt_embeds=inp["condition_pooled_projections"],
+               num_inference_steps=steps, guidance_scale=gs, gate_uniforms=[uni2.to(gpu)] * steps).images
+    # the same loop on the oracle
+    from unigen_amd.pipeline import flow_match_sigmas
+    sig = flow_match_sigmas(steps, sigmas=[1.0 - i * (1.0 - 1e-3) / (steps - 1) for i in range(steps)], shift=3.0)
+    lat = inp["hidden_states"].clone()
+    for i in range(steps):
+        t = torch.full((2,), sig[i] * 1000.0)
+        o = R.unigen_sd3_forward(state, rcfg, hidden_states=torch.cat([lat] * 2), condition_hidden_states=torch.cat([inp["condition_hidden_states"]] * 2),
+                                 encoder_hidden_states=torch.cat([neg["encoder_hidden_states"], inp["encoder_hidden_states"]]),
+                                 pooled_projections=torch.cat([neg["pooled_projections"], inp["pooled_projections"]]),
+                                 condition_pooled_projections=torch.cat([inp["condition_pooled_projections"]] * 2), timestep=t, gate_uniform=uni2, dtype=BF)[0]
+        u, tx = o.chunk(2)
+        pred = u + gs * (tx - u)
+        lat = R.euler_step(lat, pred, sig[i], sig[i + 1])
+    m = report("sd3_pipeline_cfg_2steps", res, lat)
+    assert m["rel_l2"] <= 3e-2, m

@@ -34,3 +34,18 @@ def report(name: str, got: torch.Tensor, ref: torch.Tensor, **extra) -> dict:
 def bf(t: torch.Tensor) -> torch.Tensor:
     """round to bf16 and back to fp32 (the oracle works on bf16-representable values)"""
     return t.to(torch.bfloat16).float()
+
+
+def check_routing(dev_idx: torch.Tensor, routing: dict, max_flip_frac: float = 0.02, tie_gap: float = 5e-2) -> int:
+    """Top-1 expert indices from the device against the oracle's: they must agree except on tokens whose two largest gate
+    probabilities are within `tie_gap` of each other in the oracle (a discrete argmax over logits computed from activations that
+    differ in the last bf16 bits cannot be expected to agree on exact near-ties). Returns the number of flipped tokens."""
+    di = dev_idx.cpu().long()
+    oi = routing["idx"].long()
+    flips = torch.nonzero(di != oi).flatten()
+    if flips.numel():
+        top2 = torch.topk(routing["gates"].float(), 2, dim=1)[0]
+        gap = (top2[:, 0] - top2[:, 1])[flips]
+        assert float(gap.max()) <= tie_gap, f"expert assignment differs on a clear-cut token (gap {float(gap.max()):.3f})"
+        assert flips.numel() <= max(1, int(max_flip_frac * di.numel())), f"{flips.numel()} routing flips"
+    return int(flips.numel())

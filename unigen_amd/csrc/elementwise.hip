@@ -238,6 +238,17 @@ __global__ void add_kernel(const bf16_t* __restrict__ a, int64_t lda, const bf16
     }
 }
 
+__global__ void cfg_combine_kernel(const bf16_t* __restrict__ u, const bf16_t* __restrict__ t, float gs, bf16_t* __restrict__ out, int64_t nchunk) {
+    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < nchunk; c += (int64_t)gridDim.x * blockDim.x) {
+        float a[8], b[8];
+        unpack8(*(const u32x4*)(u + c * 8), a);
+        unpack8(*(const u32x4*)(t + c * 8), b);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] = a[e] + rbf(gs * rbf(b[e] - a[e]));
+        *(u32x4*)(out + c * 8) = pack8(a);
+    }
+}
+
 __global__ void add_rowbcast_f32_kernel(bf16_t* __restrict__ x, int64_t ldx, const float* __restrict__ t, int64_t ldt, int64_t rows,
                                         int64_t rpb, int chunks_per_row) {
     const int64_t total = rows * chunks_per_row;
@@ -265,6 +276,18 @@ __global__ void gather_rows_kernel(const bf16_t* __restrict__ src, int64_t ld_sr
 }
 
 }  // namespace
+
+extern "C" int ug_cfg_combine(const void* uncond, const void* text, float guidance_scale, void* out, int64_t n, ug_stream_t stream) {
+    if (n == 0) return UG_OK;
+    UG_REQUIRE(uncond && text && out && n > 0 && n % 8 == 0 && ug_aligned(uncond, 16) && ug_aligned(text, 16) && ug_aligned(out, 16),
+               UG_ERR_BAD_ALIGN, "ug_cfg_combine: n must be a multiple of 8 and pointers 16-byte aligned");
+    const int64_t nchunk = n / 8;
+    const unsigned grid = (unsigned)std::min<int64_t>((nchunk + 255) / 256, 2048);
+    hipLaunchKernelGGL(cfg_combine_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)uncond, (const bf16_t*)text,
+                       guidance_scale, (bf16_t*)out, nchunk);
+    UG_CHECK_LAUNCH("ug_cfg_combine");
+    return UG_OK;
+}
 
 extern "C" int ug_add_rowbcast_f32(void* x, int64_t ldx, const float* table, int64_t ldt, int64_t rows, int64_t rows_per_batch, int64_t D,
                                    ug_stream_t stream) {

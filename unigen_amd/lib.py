@@ -49,6 +49,7 @@ SIGNATURES = {
     "ug_flash_attn_fwd": (i32, [vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, i64, i64, i64, i32, i64, i64, i32, f32, vp]),
     "ug_timestep_embed": (i32, [vp, vp, i64, i64, i32, vp]),
     "ug_euler_step": (i32, [vp, vp, f32, i64, vp]),
+    "ug_cfg_combine": (i32, [vp, vp, f32, vp, i64, vp]),
     "ug_add_bf16": (i32, [vp, i64, vp, i64, vp, i64, i64, i64, vp]),
     "ug_add_rowbcast_f32": (i32, [vp, i64, vp, i64, i64, i64, i64, vp]),
     "ug_gather_rows": (i32, [vp, i64, vp, vp, i64, i64, i64, vp]),

@@ -128,9 +128,12 @@ def small_linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor],
     _chk(x, "x"); _chk(w, "w"); _chk(out, "out")
     M, K = x.shape
     N = w.shape[0]
-    L.check(L.load().ug_small_linear_bf16(x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), _p(bias), _p(residual),
-                                          residual.stride(0) if residual is not None else 0, out.data_ptr(), out.stride(0),
-                                          M, N, K, 1 if silu_in else 0, _stream()), "ug_small_linear_bf16")
+    for m0 in range(0, M, 16):          # the kernel handles up to 16 rows per launch (they live in LDS); more rows re-stream the weights
+        mm = min(16, M - m0)
+        r = residual[m0:] if residual is not None else None
+        L.check(L.load().ug_small_linear_bf16(x[m0:].data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), _p(bias), _p(r),
+                                              residual.stride(0) if residual is not None else 0, out[m0:].data_ptr(), out.stride(0),
+                                              mm, N, K, 1 if silu_in else 0, _stream()), "ug_small_linear_bf16")
     return out
 
 
@@ -185,6 +188,13 @@ def euler_step(x: torch.Tensor, v: torch.Tensor, dt: float) -> torch.Tensor:
     assert x.is_contiguous() and v.is_contiguous() and x.numel() == v.numel()
     L.check(L.load().ug_euler_step(x.data_ptr(), v.data_ptr(), dt, x.numel(), _stream()), "ug_euler_step")
     return x
+
+
+def cfg_combine(uncond: torch.Tensor, text: torch.Tensor, guidance_scale: float, out: torch.Tensor) -> torch.Tensor:
+    _chk(uncond, "uncond"); _chk(text, "text"); _chk(out, "out")
+    assert uncond.is_contiguous() and text.is_contiguous() and out.is_contiguous() and uncond.numel() == text.numel() == out.numel()
+    L.check(L.load().ug_cfg_combine(uncond.data_ptr(), text.data_ptr(), guidance_scale, out.data_ptr(), out.numel(), _stream()), "ug_cfg_combine")
+    return out
 
 
 def add(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor) -> torch.Tensor:

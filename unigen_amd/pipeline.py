@@ -169,3 +169,85 @@ class UniGenFLUXPipeline:
         if not return_dict:
             return (out,)
         return SimpleNamespace(images=out)
+
+
+@torch.no_grad()
+def sd3_denoise_loop(transformer, *, latents: torch.Tensor, control_latents: torch.Tensor, prompt_embeds: torch.Tensor,
+                     pooled_prompt_embeds: torch.Tensor, condition_pooled_prompt_embeds: torch.Tensor, num_inference_steps: int = 28,
+                     guidance_scale: float = 7.0, conditioning_scale: float = 1.0, shift: float = 3.0, sigmas: Optional[Sequence[float]] = None,
+                     gate_uniforms=None) -> torch.Tensor:
+    """UniGenSD3Pipeline.__call__ loop (src/UniGenPipeline.py:375-433). With guidance_scale > 1 the caller passes prompt / pooled / condition
+    embeds already doubled as [negative | positive] (reference :286-290); latents [B, C, H, W] are duplicated per step, the two halves of
+    the prediction are combined with classifier-free guidance, then the flow-match Euler step. The timestep is passed unscaled."""
+    cfg_on = guidance_scale > 1.0
+    if sigmas is None:      # FlowMatchEulerDiscreteScheduler.set_timesteps(num_inference_steps): linspace over timesteps, then the static shift
+        sigmas = [1.0 - i * (1.0 - 1.0 / 1000.0) / max(num_inference_steps - 1, 1) for i in range(num_inference_steps)]
+    sig = flow_match_sigmas(num_inference_steps, sigmas=sigmas, shift=shift)
+    B = latents.shape[0]
+    latents = latents.contiguous()
+    ctrl = torch.cat([control_latents] * 2) if cfg_on and control_latents.shape[0] == B else control_latents
+    pred = torch.empty_like(latents)
+    for i in range(num_inference_steps):
+        x_in = torch.cat([latents] * 2) if cfg_on else latents
+        t = torch.full((x_in.shape[0],), sig[i] * 1000.0, device=latents.device, dtype=torch.float32)
+        uni = None if gate_uniforms is None else gate_uniforms[i]
+        out = transformer(hidden_states=x_in, condition_hidden_states=ctrl, conditioning_scale=conditioning_scale, timestep=t,
+                          encoder_hidden_states=prompt_embeds, pooled_projections=pooled_prompt_embeds,
+                          condition_pooled_projections=condition_pooled_prompt_embeds, gate_uniform=uni)[0]
+        if cfg_on:
+            ops.cfg_combine(out[:B].contiguous(), out[B:].contiguous(), guidance_scale, pred)
+        else:
+            pred = out
+        ops.euler_step(latents, pred, sig[i + 1] - sig[i])
+    return latents
+
+
+class UniGenSD3Pipeline:
+    """Call-surface twin of the reference `UniGenSD3Pipeline` for the transformer side (encoders / VAE out of scope, as above)."""
+
+    def __init__(self, transformer=None, scheduler_config: Optional[dict] = None, vae_scale_factor: int = 8):
+        self.transformer = transformer
+        self.vae_scale_factor = vae_scale_factor
+        self.default_sample_size = 128
+        sc = dict(shift=3.0)
+        sc.update(scheduler_config or {})
+        self.scheduler = SimpleNamespace(config=sc)
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path=None, transformer=None, **kwargs) -> "UniGenSD3Pipeline":
+        return cls(transformer=transformer)
+
+    def to(self, device=None, dtype=None):
+        if self.transformer is not None:
+            self.transformer.to(device=device, dtype=dtype)
+        return self
+
+    @torch.no_grad()
+    def __call__(self, prompt=None, condition_prompt=None, control_image=None, conditioning_scale: float = 1.0, height=None, width=None,
+                 num_inference_steps: int = 28, guidance_scale: float = 7.0, generator=None, latents=None, prompt_embeds=None,
+                 negative_prompt_embeds=None, pooled_prompt_embeds=None, negative_pooled_prompt_embeds=None,
+                 condition_pooled_prompt_embeds=None, output_type: str = "latent", return_dict: bool = True, gate_uniforms=None, **kwargs):
+        if prompt is not None or condition_prompt is not None:
+            raise NotImplementedError("text encoders are outside this package's scope: pass the embeds")
+        if output_type != "latent":
+            raise NotImplementedError("the VAE is outside this package's scope: use output_type='latent'")
+        tr = self.transformer
+        dev = tr.device
+        cast = lambda t: t.to(device=dev, dtype=BF)
+        cfg_on = guidance_scale > 1.0
+        if cfg_on:
+            if negative_prompt_embeds is None or negative_pooled_prompt_embeds is None:
+                raise ValueError("classifier-free guidance needs negative_prompt_embeds and negative_pooled_prompt_embeds")
+            prompt_embeds = torch.cat([cast(negative_prompt_embeds), cast(prompt_embeds)], 0)
+            pooled_prompt_embeds = torch.cat([cast(negative_pooled_prompt_embeds), cast(pooled_prompt_embeds)], 0)
+            condition_pooled_prompt_embeds = torch.cat([cast(condition_pooled_prompt_embeds)] * 2, 0)
+        B = control_image.shape[0]
+        if control_image.ndim != 4 or control_image.shape[1] != tr.config.in_channels:
+            raise ValueError("control_image must be VAE latents [B, C, H/8, W/8] (vae.encode happens upstream)")
+        if latents is None:
+            latents = torch.randn(control_image.shape, generator=generator, device=dev, dtype=torch.float32)
+        out = sd3_denoise_loop(tr, latents=cast(latents).clone(), control_latents=cast(control_image), prompt_embeds=cast(prompt_embeds),
+                               pooled_prompt_embeds=cast(pooled_prompt_embeds), condition_pooled_prompt_embeds=cast(condition_pooled_prompt_embeds),
+                               num_inference_steps=num_inference_steps, guidance_scale=guidance_scale, conditioning_scale=conditioning_scale,
+                               shift=self.scheduler.config["shift"], gate_uniforms=gate_uniforms)
+        return SimpleNamespace(images=out) if return_dict else (out,)
