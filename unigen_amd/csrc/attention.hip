@@ -46,7 +46,11 @@ __device__ __forceinline__ bf16x8 tr_read_pair(const unsigned char* lo, const un
     return (bf16x8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
 }
 
-template <int DH, int NW>   // head dim 128 | 64; waves per workgroup: 8 (256 query rows, 1 workgroup / CU) or 4 (128 rows, 2 / CU)
+// STAGGER (8 waves): waves 0-3 and 4-7 - the two waves of every SIMD - run half a tile apart: in each segment one group does
+// S^T + softmax of a tile while the other does P.V of the previous one, so a wave's softmax VALU work runs under its partner's
+// MFMAs instead of both waves hitting the matrix pipe, then the VALU, together. Two barriers per tile; K(t+1) is written at the
+// end of odd segments and V(t) at the end of even ones, each into the buffer nobody reads in that segment.
+template <int DH, int NW, bool STAGGER>   // head dim 128 | 64; waves per workgroup: 8 (256 query rows, 1 / CU) or 4 (128 rows, 2 / CU)
 __global__ __launch_bounds__(64 * NW, 2) void flash_attn_kernel(
     const bf16_t* __restrict__ q, int64_t q_rs, int64_t q_bs, const bf16_t* __restrict__ k, int64_t k_rs, int64_t k_bs,
     const bf16_t* __restrict__ v, int64_t v_rs, int64_t v_bs, bf16_t* __restrict__ o, int64_t o_rs, int64_t o_bs,
@@ -142,17 +146,10 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn_kernel(
     float m_run = -INFINITY, l_run = 0.f;
 
     const int ntiles = (Lkv + KVB - 1) / KVB;
-    stage_load(0);
-    stage_write(0);
-    __syncthreads();
-
-    for (int t = 0; t < ntiles; ++t) {
-        const int cur = t & 1;
+    bf16x8 pf[2][2];                                   // P^T fragments of the tile between its S and P stages
+    auto do_S = [&](int t) {
         const int kv0 = t * KVB;
-        const unsigned char* Kbuf = smem + cur * 2 * TILE;
-        const unsigned char* Vbuf = Kbuf + TILE;
-        if (t + 1 < ntiles) stage_load(kv0 + KVB);
-
+        const unsigned char* Kbuf = smem + (t & 1) * 2 * TILE;
         // ---- S^T[key][q]: all 8 K fragments of key block 0 first, then block-0 MFMAs with the block-1 reads between them ----
         f32x16 sacc[2];
 #pragma unroll
@@ -204,7 +201,6 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn_kernel(
             m_run = m_new;
         }
         const float mc = m_run * c;
-        bf16x8 pf[2][2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             float p[16];
@@ -221,6 +217,9 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn_kernel(
                 pf[kb][s2] = __builtin_bit_cast(bf16x8, w);
             }
         }
+    };
+    auto do_P = [&](int t) {
+        const unsigned char* Vbuf = smem + (t & 1) * 2 * TILE + TILE;
         // ---- O^T[d][q] += V^T[d][key] P^T[key][q]: the V fragments of d-block db+1 are read between the MFMAs of block db ----
         {
             bf16x8 vf[NDB][4];
@@ -242,8 +241,72 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn_kernel(
             }
             __builtin_amdgcn_sched_group_barrier(0x008, 4, 1);            // last d-block
         }
-        if (t + 1 < ntiles) stage_write(cur ^ 1);
+    };
+    if constexpr (!STAGGER) {
+        stage_load(0);
+        stage_write(0);
         __syncthreads();
+        for (int t = 0; t < ntiles; ++t) {
+            if (t + 1 < ntiles) stage_load((t + 1) * KVB);
+            do_S(t);
+            do_P(t);
+            if (t + 1 < ntiles) stage_write((t + 1) & 1);
+            __syncthreads();
+        }
+    } else {
+        static_assert(!STAGGER || NW == 8, "the stagger pairs waves w and w+4 of one SIMD");
+        // Every wave runs the same program [S(t) | P(t) |]*; waves 4-7 (group B) enter it one segment late, so in every global
+        // segment one wave of each SIMD is in an S stage and its partner in a P stage. Staging follows the GLOBAL segment parity
+        // (even: fetch K(t+1), publish V(t); odd: fetch V(t+1), publish K(t+1)). Seen from a wave that is two register sets:
+        //   X: fetched at the start of S(t), published at the end of P(t)      (group A: K(t+1)   | group B: V(t+1))
+        //   Y: fetched at the start of P(t), published at the end of S(t+1)    (group A: V(t+1)   | group B: K(t+2))
+        // Both groups execute IDENTICAL control flow - only base pointers, LDS offsets and one tile offset differ - so the
+        // compiler keeps each fetch in flight for two segments instead of merging register sets at branch joins.
+        // Global loads cross the barriers, hence raw s_barrier + explicit lgkmcnt(0) (a __syncthreads fence would drain vmcnt).
+        auto seg_barrier = [&]() {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        const bool groupA = __builtin_amdgcn_readfirstlane(wave) < 4;
+        const int yoff = groupA ? 0 : 1;
+        const bf16_t* Xb = groupA ? Kb : Vb;  const int64_t x_rs = groupA ? k_rs : v_rs;  const int x_lds = groupA ? 0 : TILE;
+        const bf16_t* Yb = groupA ? Vb : Kb;  const int64_t y_rs = groupA ? v_rs : k_rs;  const int y_lds = groupA ? TILE : 0;
+        u32x4 xreg[NST], yreg[NST];
+        auto fetch = [&](u32x4 (&reg)[NST], const bf16_t* base, int64_t rs, int tile) {
+#pragma unroll
+            for (int u = 0; u < NST; ++u) {
+                int key = tile * KVB + st_row[u]; if (key > Lkv - 1) key = Lkv - 1;
+                reg[u] = *(const u32x4*)(base + (int64_t)key * rs + st_ch[u] * 8);
+            }
+        };
+        auto publish = [&](const u32x4 (&reg)[NST], int lds_off, int buf) {
+#pragma unroll
+            for (int u = 0; u < NST; ++u) *(u32x4*)(smem + buf * 2 * TILE + lds_off + st_off[u]) = reg[u];
+        };
+        fetch(xreg, Kb, k_rs, 0);
+        publish(xreg, 0, 0);                           // K(0)
+        fetch(xreg, Vb, v_rs, 0);                      // V(0): group B publishes it from X in its lead-in ...
+        fetch(yreg, Vb, v_rs, 0);                      // ... group A from Y at the end of S(0)
+        seg_barrier();
+        if (!groupA) {                                 // B's lead-in = global segment 0 without compute
+            if (1 < ntiles) fetch(yreg, Yb, y_rs, 1);
+            publish(xreg, x_lds, 0);
+            seg_barrier();
+        }
+        for (int t = 0; t < ntiles; ++t) {
+            const bool more = t + 1 < ntiles;
+            if (more) fetch(xreg, Xb, x_rs, t + 1);
+            do_S(t);
+            if (t + yoff < ntiles) publish(yreg, y_lds, (t + yoff) & 1);
+            seg_barrier();
+            if (t + 1 + yoff < ntiles) fetch(yreg, Yb, y_rs, t + 1 + yoff);
+            do_P(t);
+            if (more) publish(xreg, x_lds, (t + 1) & 1);
+            seg_barrier();
+        }
+        if (groupA) seg_barrier();                     // A's trailing (empty) segment pairs with B's last one
     }
 
     // ---- epilogue: O[q][d] = O^T / l ----
@@ -285,12 +348,14 @@ extern "C" int ug_flash_attn_fwd(const void* q, int64_t q_row_stride, int64_t q_
     const int64_t nwg = (int64_t)nQ * heads * batches;
     UG_REQUIRE(nwg < (1ll << 31), UG_ERR_UNSUPPORTED, "ug_flash_attn_fwd: grid too large");
     const float c = softmax_scale * 1.4426950408889634f;
-#define UG_ATTN_LAUNCH(DHV, NWV)                                                                                                     \
-    hipLaunchKernelGGL((flash_attn_kernel<DHV, NWV>), dim3((unsigned)nwg), dim3(64 * NWV), 2 * 2 * KVB * 2 * DHV, (hipStream_t)stream, \
+#define UG_ATTN_LAUNCH(DHV, NWV, STG)                                                                                                \
+    hipLaunchKernelGGL((flash_attn_kernel<DHV, NWV, STG>), dim3((unsigned)nwg), dim3(64 * NWV), 2 * 2 * KVB * 2 * DHV, (hipStream_t)stream, \
                        (const bf16_t*)q, q_row_stride, q_batch_stride, (const bf16_t*)k, k_row_stride, k_batch_stride, (const bf16_t*)v, \
                        v_row_stride, v_batch_stride, (bf16_t*)o, o_row_stride, o_batch_stride, (int)heads, (int)Lq, (int)Lkv, nQ, c)
-    if (dh == 128) { if (nw == 8) UG_ATTN_LAUNCH(128, 8); else UG_ATTN_LAUNCH(128, 4); }
-    else           { if (nw == 8) UG_ATTN_LAUNCH(64, 8); else UG_ATTN_LAUNCH(64, 4); }
+    static int stagger = -1;
+    if (stagger < 0) { const char* e = getenv("UG_ATTN_STAGGER"); stagger = (e && atoi(e) == 1) ? 1 : 0; }   // measured: 812 vs 835 TFLOP/s at L = 4608, dh = 128 -> off by default
+    if (dh == 128) { if (nw == 4) UG_ATTN_LAUNCH(128, 4, false); else if (stagger) UG_ATTN_LAUNCH(128, 8, true); else UG_ATTN_LAUNCH(128, 8, false); }
+    else           { if (nw == 4) UG_ATTN_LAUNCH(64, 4, false); else if (stagger) UG_ATTN_LAUNCH(64, 8, true); else UG_ATTN_LAUNCH(64, 8, false); }
 #undef UG_ATTN_LAUNCH
     UG_CHECK_LAUNCH("ug_flash_attn_fwd");
     return UG_OK;
