@@ -94,13 +94,14 @@ __global__ __launch_bounds__(256) void qk_rmsnorm_rope_kernel(
     const int64_t wave_id = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t vec = wave_id * VPW + vin;
     const bool active = vec < nvec;
-    const int64_t vv = active ? vec : 0;
-    const int h = (int)(vv % heads);
-    const int64_t t1 = vv / heads;
-    const int which = q_off >= 0 ? (int)(t1 % 2) : 1;   // 0 = q, 1 = k
-    const int64_t row = q_off >= 0 ? t1 / 2 : t1;
-    const int64_t bidx = row / rows_per_batch;
-    const int64_t rr = row - bidx * rows_per_batch;
+    const unsigned vv = active ? (unsigned)vec : 0u;      // 32-bit index math (host checks the ranges): 64-bit divisions are slow
+    const unsigned t1 = vv / (unsigned)heads;
+    const int h = (int)(vv - t1 * (unsigned)heads);
+    const int which = q_off >= 0 ? (int)(t1 & 1u) : 1;   // 0 = q, 1 = k
+    const unsigned row = q_off >= 0 ? (t1 >> 1) : t1;
+    const unsigned bidx_u = row / (unsigned)rows_per_batch;
+    const int64_t bidx = bidx_u;
+    const int64_t rr = row - bidx_u * (unsigned)rows_per_batch;
     const int64_t pos = pos_offset + rr;
     bf16_t* p = buf + (bidx * batch_stride_rows + rr) * ld + (which == 0 ? q_off : k_off) + (int64_t)h * DH + sub * 8;
     float x[8];
@@ -348,6 +349,7 @@ extern "C" int ug_qk_rmsnorm_rope(void* buf, int64_t ld, int64_t batches, int64_
     if (haveq) UG_REQUIRE((wq_a == nullptr) == (wk_a == nullptr) && (wq_b == nullptr) == (wk_b == nullptr), UG_ERR_BAD_SHAPE,
                           "ug_qk_rmsnorm_rope: q/k norm weights must come in pairs");
     const int64_t nvec = total_rows * (haveq ? 2 : 1) * heads;
+    UG_REQUIRE(nvec < (1ll << 31) && rows_per_batch < (1ll << 31), UG_ERR_UNSUPPORTED, "ug_qk_rmsnorm_rope: too many head vectors");
     const int vpw = 64 / (dh / 8);
     const int64_t waves = (nvec + vpw - 1) / vpw;
     const unsigned grid = (unsigned)((waves + 3) / 4);

@@ -67,16 +67,36 @@ __device__ __forceinline__ void load_bias4(const bf16_t* bias, int64_t n, float*
     }
 }
 
-// one lane's 4 consecutive n of row m: v = bf16(acc + bias) then the fused elementwise tail, 8-byte store
+// Per-output-row context of the epilogue, computed ONCE per row (the row maps and the gate's sample index are integer
+// divisions; doing them per 4-element chunk cost ~30 us per 256x256 tile).
+struct RowCtx { int64_t coff, roff, goff; };
+
+__device__ __forceinline__ unsigned rowmap32(unsigned m, unsigned rpb, unsigned bstride) {
+    if (rpb == 0) return m;
+    const unsigned b = m / rpb;
+    return b * bstride + (m - b * rpb);
+}
+
 template <int EPI>
-__device__ __forceinline__ void epi_store(const ug_gemm_desc& p, int g, int64_t m, int64_t n, const f32x4 a, const float* bv) {
+__device__ __forceinline__ RowCtx row_ctx(const ug_gemm_desc& p, int g, unsigned m) {
+    RowCtx c;
+    c.coff = (int64_t)g * p.c_gstride + (int64_t)rowmap32(m, (unsigned)p.c_rpb, (unsigned)p.c_bstride) * p.ldc;
+    c.roff = 0; c.goff = 0;
+    if constexpr (EPI == UG_EPI_RES_GATE || EPI == UG_EPI_RES_SCALE)
+        c.roff = (int64_t)g * p.r_gstride + (int64_t)rowmap32(m, (unsigned)p.r_rpb, (unsigned)p.r_bstride) * p.ldr;
+    if constexpr (EPI == UG_EPI_RES_GATE)
+        c.goff = (int64_t)g * p.gate_gstride + (int64_t)(m / (unsigned)p.rows_per_sample) * p.gate_ld;
+    return c;
+}
+
+// one lane's 4 consecutive n of one row: v = bf16(acc + bias) then the fused elementwise tail, 8-byte store
+template <int EPI>
+__device__ __forceinline__ void epi_store(const ug_gemm_desc& p, const RowCtx& rc, int64_t n, const f32x4 a, const float* bv) {
     float v[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[r] = a[r] + bv[r];
-    const int64_t cg = (int64_t)g * p.c_gstride;
-    const int64_t crow = ug_rowmap(m, p.c_rpb, p.c_bstride);
     if constexpr (EPI == UG_EPI_F32) {
-        float* C = (float*)p.C + cg + crow * p.ldc + n;
+        float* C = (float*)p.C + rc.coff + n;
         *(f32x4*)C = (f32x4){v[0], v[1], v[2], v[3]};
     } else {
 #pragma unroll
@@ -85,12 +105,10 @@ __device__ __forceinline__ void epi_store(const ug_gemm_desc& p, int g, int64_t 
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = gelu_tanh(v[r]);
         } else if constexpr (EPI == UG_EPI_RES_GATE || EPI == UG_EPI_RES_SCALE) {
-            const bf16_t* R = (const bf16_t*)p.R + (int64_t)g * p.r_gstride + ug_rowmap(m, p.r_rpb, p.r_bstride) * p.ldr + n;
-            const u32x2 r2 = *(const u32x2*)R;
+            const u32x2 r2 = *(const u32x2*)((const bf16_t*)p.R + rc.roff + n);
             const float rv[4] = {bflo(r2.x), bfhi(r2.x), bflo(r2.y), bfhi(r2.y)};
             if constexpr (EPI == UG_EPI_RES_GATE) {
-                const bf16_t* G = (const bf16_t*)p.gate + (int64_t)g * p.gate_gstride + (m / p.rows_per_sample) * p.gate_ld + n;
-                const u32x2 g2 = *(const u32x2*)G;
+                const u32x2 g2 = *(const u32x2*)((const bf16_t*)p.gate + rc.goff + n);
                 const float gv[4] = {bflo(g2.x), bfhi(g2.x), bflo(g2.y), bfhi(g2.y)};
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = rv[r] + rbf(gv[r] * v[r]);
@@ -99,9 +117,8 @@ __device__ __forceinline__ void epi_store(const ug_gemm_desc& p, int g, int64_t 
                 for (int r = 0; r < 4; ++r) v[r] = rv[r] + rbf(p.alpha * v[r]);
             }
         }
-        bf16_t* C = (bf16_t*)p.C + cg + crow * p.ldc + n;
         u32x2 o; o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]);
-        *(u32x2*)C = o;
+        *(u32x2*)((bf16_t*)p.C + rc.coff + n) = o;
     }
 }
 
@@ -147,7 +164,7 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(const ug_gemm_desc p) {
             const int c = (lane & 7) ^ (row & 7);              // source chunk that lands at linear position lane&7
             int64_t am = m0 + row; if (am > M - 1) am = M - 1;
             int64_t wn = n0 + row; if (wn > N - 1) wn = N - 1;
-            asrc[i] = Ab + ug_rowmap(am, a_rpb, a_bs) * lda + c * 8;
+            asrc[i] = Ab + (int64_t)rowmap32((unsigned)am, (unsigned)a_rpb, (unsigned)a_bs) * lda + c * 8;
             wsrc[i] = Wb + wn * ldw + c * 8;
         }
         const int nk = (int)(Kseg / BK);
@@ -193,19 +210,23 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(const ug_gemm_desc p) {
         }
     }
 
-    // ---- epilogue: lane holds D[row = n (4 consecutive)][col = m] ------------------------------------------
+    // ---- epilogue: lane holds D[row = n (4 consecutive)][col = m]; rows outer so the row context is computed once ----
     const bf16_t* bias = p.bias ? (const bf16_t*)p.bias + (int64_t)g * p.bias_gstride : nullptr;
+    float bv[4][4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int64_t n = n0 + wc * 64 + j * 16 + (lane >> 4) * 4;
-        if (n >= N) continue;
-        float bv[4];
-        load_bias4(bias, n, bv);
+        load_bias4(n < N ? bias : nullptr, n, bv[j]);
+    }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int64_t m = m0 + wr * 64 + i * 16 + (lane & 15);
-            if (m >= M) continue;
-            epi_store<EPI>(p, g, m, n, acc[i][j], bv);
+    for (int i = 0; i < 4; ++i) {
+        const int64_t m = m0 + wr * 64 + i * 16 + (lane & 15);
+        if (m >= M) continue;
+        const RowCtx rc = row_ctx<EPI>(p, g, (unsigned)m);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t n = n0 + wc * 64 + j * 16 + (lane >> 4) * 4;
+            if (n < N) epi_store<EPI>(p, rc, n, acc[i][j], bv[j]);
         }
     }
 }
@@ -265,7 +286,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p) {
             const int c = (lane & 7) ^ (row & 7);
             int64_t am = m0 + h * 128 + row; if (am > M - 1) am = M - 1;
             int64_t wn = n0 + h * 128 + row; if (wn > N - 1) wn = N - 1;
-            srcA[h][i] = Ab + ug_rowmap(am, p.a_rpb, p.a_bstride) * p.lda + c * 8;
+            srcA[h][i] = Ab + (int64_t)rowmap32((unsigned)am, (unsigned)p.a_rpb, (unsigned)p.a_bstride) * p.lda + c * 8;
             srcB[h][i] = Wb + wn * p.ldw + c * 8;
         }
     const int st_off = wave * 16 * 128;
@@ -346,21 +367,27 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p) {
 #undef UG_BARRIER
 
     const bf16_t* bias = p.bias ? (const bf16_t*)p.bias + (int64_t)g * p.bias_gstride : nullptr;
+    float bv[2][2][4];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
             const int64_t n = n0 + j * 128 + wc * 32 + nt * 16 + (lane >> 4) * 4;
-            if (n >= N) continue;
-            float bv[4];
-            load_bias4(bias, n, bv);
+            load_bias4(n < N ? bias : nullptr, n, bv[j][nt]);
+        }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) {
-                    const int64_t m = m0 + i * 128 + wr * 64 + mt * 16 + (lane & 15);
-                    if (m >= M) continue;
-                    epi_store<EPI>(p, g, m, n, acc[i][j][mt][nt], bv);
+        for (int mt = 0; mt < 4; ++mt) {
+            const int64_t m = m0 + i * 128 + wr * 64 + mt * 16 + (lane & 15);
+            if (m >= M) continue;
+            const RowCtx rc = row_ctx<EPI>(p, g, (unsigned)m);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const int64_t n = n0 + j * 128 + wc * 32 + nt * 16 + (lane >> 4) * 4;
+                    if (n < N) epi_store<EPI>(p, rc, n, acc[i][j][mt][nt], bv[j][nt]);
                 }
         }
 }
@@ -379,7 +406,11 @@ template <int EPI>
 int launch(const ug_gemm_desc& d, hipStream_t s) {
     const int groups = d.groups > 0 ? d.groups : 1;
     const int64_t t256 = ((d.M + 255) / 256) * ((d.N + 255) / 256) * groups;
-    bool big = d.lora_r <= 0 && d.M >= 256 && d.N >= 256 && t256 >= 384;     // >= 1.5 tiles per CU
+    const int64_t t128 = ((d.M + 127) / 128) * ((d.N + 127) / 128) * groups;
+    // pick the tile by expected chip fill: 256 CUs x 1 workgroup (256^2) vs 256 x 2 (128^2, ~0.82x the 256^2 kernel's rate)
+    const double e256 = (double)t256 / (double)(((t256 + 255) / 256) * 256);
+    const double e128 = 0.82 * (double)t128 / (double)(((t128 + 511) / 512) * 512);
+    bool big = d.lora_r <= 0 && d.M >= 192 && d.N >= 192 && e256 >= e128;
     const int f = forced_tile();
     if (f == 128) big = false;
     if (f == 256 && d.lora_r <= 0) big = true;
@@ -410,6 +441,9 @@ extern "C" int ug_gemm_bf16(const ug_gemm_desc* dp, ug_stream_t stream) {
     UG_REQUIRE(d.M >= 0 && d.N > 0 && d.K > 0, UG_ERR_BAD_SHAPE, "ug_gemm_bf16: bad M/N/K %lld/%lld/%lld",
                (long long)d.M, (long long)d.N, (long long)d.K);
     if (d.M == 0) return UG_OK;
+    UG_REQUIRE(d.M < (1ll << 31) && d.N < (1ll << 31) && d.a_bstride < (1ll << 31) && d.c_bstride < (1ll << 31) && d.r_bstride < (1ll << 31) &&
+               d.a_rpb < (1ll << 31) && d.c_rpb < (1ll << 31) && d.r_rpb < (1ll << 31) && d.rows_per_sample < (1ll << 31),
+               UG_ERR_UNSUPPORTED, "ug_gemm_bf16: row counts must fit 31 bits");
     UG_REQUIRE(d.K % BK == 0, UG_ERR_UNSUPPORTED, "ug_gemm_bf16: K=%lld must be a multiple of %d", (long long)d.K, BK);
     UG_REQUIRE(d.N % 4 == 0, UG_ERR_UNSUPPORTED, "ug_gemm_bf16: N=%lld must be a multiple of 4", (long long)d.N);
     UG_REQUIRE(d.A && d.W && d.C, UG_ERR_BAD_SHAPE, "ug_gemm_bf16: null operand");
