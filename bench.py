@@ -175,8 +175,16 @@ def main():
             s = timer.summary()
             gm, at = s.get("gemm"), s.get("attn")
             ach = gm["flops"] / (gm["ms"] * 1e-3) / 1e12
+            traffic, traffic_note = None, None
+            tf = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+            if os.path.exists(tf) and not args.small and B == 4:      # PMC passes of this same command (see the file's `source`)
+                with open(tf) as f:
+                    tj = json.load(f)
+                traffic = tj["kernels"]["gemm_all"]["hbm_bytes_per_launch"]
+                traffic_note = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, profiles/r01_hbm_traffic.json): (2*FETCH_SIZE + WRITE_SIZE)*1024 per "
+                                "launch; the L2-fabric counters include Infinity-Cache hits, so this is traffic beyond the XCD L2, an upper bound on HBM bytes")
             line["roofline"] = dict(bound="mfma", kernel="gemm256_kernel / gemm128_kernel (ug_gemm_bf16)", achieved=ach, peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s",
-                                    frac=ach / MFMA_BF16_PEAK_TFLOPS, traffic=None, launches=gm["launches"],
+                                    frac=ach / MFMA_BF16_PEAK_TFLOPS, traffic=traffic, traffic_note=traffic_note, launches=gm["launches"],
                                     avg_launch_us=1000.0 * gm["ms"] / gm["launches"], avg_launch_gflop=gm["flops"] / gm["launches"] / 1e9,
                                     share_of_step_time=gm["ms"] * 1e-3 / elapsed)
             if at:
