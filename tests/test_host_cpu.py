@@ -191,3 +191,19 @@ def test_two_rank_gloo_harness(tmp_path):
                         "--master-port", "29533", str(script)], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "GLOO_OK 2 1.5 10.0" in r.stdout
+
+
+def test_enable_lora_context_manager_semantics():
+    """src/lora_switching_module.py: non-enabled adapters are zeroed inside the context; exit restores THROUGH set_scale, i.e. scales
+    by lora_alpha / r once more - idempotent only when alpha == r, kept as the reference has it."""
+    mod = importlib.import_module("src.lora_switching_module")
+    lin = mod.LoRALinear(64, 32)
+    lin.add_adapter("canny", r=4, lora_alpha=4)
+    lin.add_adapter("depth", r=4, lora_alpha=8)
+    assert mod.module_active_adapters(lin) == ["canny", "depth"] and lin.scaling == {"canny": 1.0, "depth": 2.0}
+    with mod.enable_lora([lin, object()], ["canny"]):
+        assert lin.scaling == {"canny": 1.0, "depth": 0.0}
+        A, Bm = lin._fused_adapters()
+        assert A.shape == (64, 64) and Bm.shape == (32, 64)          # one active adapter, rank padded to 64
+    assert lin.scaling == {"canny": 1.0, "depth": 4.0}                # 2.0 * (alpha / r = 2): the reference's restore quirk
+    assert mod.module_active_adapters(object()) == []

@@ -362,3 +362,28 @@ def test_grouped_residual_gate_gather_rowbcast_plain_dispatch(gpu):
     ops.moe_dispatch_modulate(xs.to(gpu), None, None, tos.to(gpu), o, B=1, E=2, capacity=3, tokens_per_sample=6)
     ref = torch.zeros(2, 3, 64, dtype=BF); ref[0, 0], ref[0, 1], ref[1, 0] = xs[2], xs[5], xs[0]
     assert torch.equal(o.cpu(), ref)
+
+
+def test_lora_linear_switch(gpu):
+    """LoRALinear forward = one fused GEMM (base + adapter K-segment); enable_lora switches adapters per condition."""
+    import importlib
+    mod = importlib.import_module("src.lora_switching_module")
+    g = torch.Generator().manual_seed(4)
+    K, N, M = 128, 192, 100
+    lin = mod.LoRALinear(K, N, device=gpu)
+    w, b = _rand(g, N, K, scale=K ** -0.5), _rand(g, N, scale=0.1)
+    lin.weight.data.copy_(w); lin.bias.data.copy_(b)
+    ads = {"canny": (_rand(g, 8, K, scale=K ** -0.5), _rand(g, N, 8, scale=0.3), 8, 16.0), "depth": (_rand(g, 4, K, scale=K ** -0.5), _rand(g, N, 4, scale=0.3), 4, 4.0)}
+    for name, (A, Bm, r, alpha) in ads.items():
+        lin.add_adapter(name, r=r, lora_alpha=alpha, A=A, B=Bm)
+    x = _rand(g, 2, M // 2, K)
+    both = lin(x.to(gpu))
+    ref = R.lora_linear(x.float(), w.float(), b.float(), [(A.float(), Bm.float(), alpha / r) for (A, Bm, r, alpha) in ads.values()])
+    m = report("lora_linear_both", both, ref)
+    assert m["rel_l2"] <= 3e-3, m
+    with mod.enable_lora([lin], ["depth"]):
+        only = lin(x.to(gpu))
+    A, Bm, r, alpha = ads["depth"]
+    ref = R.lora_linear(x.float(), w.float(), b.float(), [(A.float(), Bm.float(), alpha / r)])
+    m = report("lora_linear_depth_only", only, ref)
+    assert m["rel_l2"] <= 3e-3, m
