@@ -122,6 +122,59 @@ __device__ __forceinline__ void epi_store(const ug_gemm_desc& p, const RowCtx& r
     }
 }
 
+// 16-byte epilogue for two adjacent 16-column n-tiles X (cols c..c+15) and Y (c+16..c+31) of one 16-row m-tile. In the accumulator
+// layout lane (row r = lane & 15, g = lane >> 4) holds columns 4g..4g+3 of each tile (8 bytes of bf16). v_permlane16_swap exchanges the
+// odd 16-lane rows of its first operand with the even rows of the second, after which lane g holds 8 CONTIGUOUS columns of one
+// tile: tile (g & 1), columns 8 (g >> 1) .. +7 -> one dwordx4 load / store per lane instead of two dwordx2 per tile pair. The
+// epilogue is store-issue bound (cdna guide T21), so halving the instruction count at equal bytes shortens it.
+__device__ __forceinline__ void swap16(unsigned& a, unsigned& b) {
+    const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+    a = r[0]; b = r[1];
+}
+
+template <int EPI>
+__device__ __forceinline__ void epi_store_pair16(const ug_gemm_desc& p, const RowCtx& rc, bool row_ok, int64_t n_blk, int64_t N, int lane,
+                                                 const f32x4 ax, const f32x4 ay, const float* bx, const float* by) {
+    const int g = lane >> 4;
+    const int64_t col = n_blk + (g & 1) * 16 + 8 * (g >> 1);          // this lane's 8 contiguous output columns after the swap
+    const bool ok = row_ok && col < N;
+    float vx[4], vy[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { vx[r] = rbf(ax[r] + bx[r]); vy[r] = rbf(ay[r] + by[r]); }
+    if constexpr (EPI == UG_EPI_BIAS_GELU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { vx[r] = gelu_tanh(vx[r]); vy[r] = gelu_tanh(vy[r]); }
+    } else if constexpr (EPI == UG_EPI_RES_GATE || EPI == UG_EPI_RES_SCALE) {
+        u32x4 c = {0u, 0u, 0u, 0u};
+        if (ok) c = *(const u32x4*)((const bf16_t*)p.R + rc.roff + col);
+        unsigned c0 = c.x, c1 = c.y, c2 = c.z, c3 = c.w;
+        swap16(c0, c2); swap16(c1, c3);                               // back to the accumulator layout: (c0, c1) = X, (c2, c3) = Y
+        const float rx[4] = {bflo(c0), bfhi(c0), bflo(c1), bfhi(c1)};
+        const float ry[4] = {bflo(c2), bfhi(c2), bflo(c3), bfhi(c3)};
+        if constexpr (EPI == UG_EPI_RES_GATE) {
+            const int64_t nx = n_blk + g * 4, ny = nx + 16;
+            const bf16_t* G = (const bf16_t*)p.gate + rc.goff;
+            u32x2 gx = {0u, 0u}, gy = {0u, 0u};
+            if (row_ok && nx < N) gx = *(const u32x2*)(G + nx);
+            if (row_ok && ny < N) gy = *(const u32x2*)(G + ny);
+            const float fgx[4] = {bflo(gx.x), bfhi(gx.x), bflo(gx.y), bfhi(gx.y)};
+            const float fgy[4] = {bflo(gy.x), bfhi(gy.x), bflo(gy.y), bfhi(gy.y)};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { vx[r] = rx[r] + rbf(fgx[r] * vx[r]); vy[r] = ry[r] + rbf(fgy[r] * vy[r]); }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { vx[r] = rx[r] + rbf(p.alpha * vx[r]); vy[r] = ry[r] + rbf(p.alpha * vy[r]); }
+        }
+    }
+    unsigned x0 = pack2bf(vx[0], vx[1]), x1 = pack2bf(vx[2], vx[3]);
+    unsigned y0 = pack2bf(vy[0], vy[1]), y1 = pack2bf(vy[2], vy[3]);
+    swap16(x0, y0); swap16(x1, y1);
+    if (ok) {
+        u32x4 o; o.x = x0; o.y = x1; o.z = y0; o.w = y1;
+        *(u32x4*)((bf16_t*)p.C + rc.coff + col) = o;
+    }
+}
+
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm128_kernel(const ug_gemm_desc p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -252,7 +305,10 @@ constexpr int LDS256_BYTES = 2 * KT_BYTES;
 constexpr int SLOT_A0 = 0, SLOT_B0 = HT_BYTES, SLOT_B1 = 2 * HT_BYTES, SLOT_A1 = 3 * HT_BYTES;
 
 template <int EPI>
-__global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p) {
+__global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, const int tiles_per_group, const int total_tiles, const int wide16) {
+    // PERSISTENT: the grid is one workgroup per CU; each walks tiles blockIdx.x, +gridDim.x, ... (same XCD-aware order as a plain
+    // launch would see round by round). The first K-tile of the NEXT tile is put in flight before the epilogue of the current one,
+    // so workgroup relaunch, address set-up and the first DMA latency overlap the C stores instead of preceding the main loop.
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -260,45 +316,43 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p) {
     const int wr = wave >> 2, wc = wave & 3;
     const int64_t M = p.M, N = p.N;
     const int nM = (int)((M + 255) / 256), nN = (int)((N + 255) / 256);
-    const TileCoord tc = tile_of_block(blockIdx.x, nM, nN);
-    const int64_t m0 = (int64_t)tc.tm * 256, n0 = (int64_t)tc.tn * 256;
-    const int g = blockIdx.z;
-    const bf16_t* Ab = (const bf16_t*)p.A + (int64_t)g * p.a_gstride;
-    const bf16_t* Wb = (const bf16_t*)p.W + (int64_t)g * p.w_gstride;
-
-    f32x4 acc[2][2][4][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b = 0; b < 2; ++b) acc[i][j][a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    // staging: each wave moves rows [wave*16, wave*16+16) of every half-tile with two 1-KiB LDS-DMA instructions
-    const bf16_t* srcA[2][2]; const bf16_t* srcB[2][2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int row = wave * 16 + i * 8 + (lane >> 3);
-            const int c = (lane & 7) ^ (row & 7);
-            int64_t am = m0 + h * 128 + row; if (am > M - 1) am = M - 1;
-            int64_t wn = n0 + h * 128 + row; if (wn > N - 1) wn = N - 1;
-            srcA[h][i] = Ab + (int64_t)rowmap32((unsigned)am, (unsigned)p.a_rpb, (unsigned)p.a_bstride) * p.lda + c * 8;
-            srcB[h][i] = Wb + wn * p.ldw + c * 8;
-        }
     const int st_off = wave * 16 * 128;
+    const int frow = lane & 15, fch = lane >> 4, fsw = lane & 7;
+    const int a_off = (wr * 64 + frow) * 128, b_off = (wc * 32 + frow) * 128;
+    const int ch0 = ((fch ^ fsw) << 4), ch1 = (((4 + fch) ^ fsw) << 4);
+    const int nk = (int)(p.K / BK);
+
+    struct TileSrc { const bf16_t* a[2][2]; const bf16_t* b[2][2]; int64_t m0, n0; int g; };
+    auto tile_src = [&](int tile) {
+        TileSrc t;
+        t.g = tile / tiles_per_group;
+        const TileCoord tc = tile_of_block(tile - t.g * tiles_per_group, nM, nN);
+        t.m0 = (int64_t)tc.tm * 256; t.n0 = (int64_t)tc.tn * 256;
+        const bf16_t* Ab = (const bf16_t*)p.A + (int64_t)t.g * p.a_gstride;
+        const bf16_t* Wb = (const bf16_t*)p.W + (int64_t)t.g * p.w_gstride;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = wave * 16 + i * 8 + (lane >> 3);
+                const int c = (lane & 7) ^ (row & 7);
+                int64_t am = t.m0 + h * 128 + row; if (am > M - 1) am = M - 1;
+                int64_t wn = t.n0 + h * 128 + row; if (wn > N - 1) wn = N - 1;
+                t.a[h][i] = Ab + (int64_t)rowmap32((unsigned)am, (unsigned)p.a_rpb, (unsigned)p.a_bstride) * p.lda + c * 8;
+                t.b[h][i] = Wb + wn * p.ldw + c * 8;
+            }
+        return t;
+    };
     auto stage = [&](unsigned char* slot, const bf16_t* const (&src)[2], int64_t ko) {
         glds16(src[0] + ko, slot + st_off);
         glds16(src[1] + ko, slot + st_off + 8 * 128);
     };
-    // fragment reads
-    const int frow = lane & 15, fch = lane >> 4, fsw = lane & 7;
-    const int a_off = (wr * 64 + frow) * 128, b_off = (wc * 32 + frow) * 128;
-    const int ch0 = ((fch ^ fsw) << 4), ch1 = (((4 + fch) ^ fsw) << 4);
-    bf16x8 areg[4][2], breg[2][2];
+    auto stage_first = [&](const TileSrc& t) {
+        stage(smem + SLOT_A0, t.a[0], 0); stage(smem + SLOT_B0, t.b[0], 0);
+        stage(smem + SLOT_B1, t.b[1], 0); stage(smem + SLOT_A1, t.a[1], 0);
+        if (nk > 1) { stage(smem + KT_BYTES + SLOT_A0, t.a[0], BK); stage(smem + KT_BYTES + SLOT_B0, t.b[0], BK); }
+    };
+    bf16x8 areg[4][2], breg[2][2], breg0[2][2];    // breg0: B0 fragments, kept from phase 0 to phase 3
     auto read_A = [&](const unsigned char* slot) {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
@@ -306,90 +360,128 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p) {
             areg[mt][1] = *(const bf16x8*)(slot + a_off + mt * 2048 + ch1);
         }
     };
-    auto read_B = [&](const unsigned char* slot) {
+    auto read_B = [&](bf16x8 (&br)[2][2], const unsigned char* slot) {
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
-            breg[nt][0] = *(const bf16x8*)(slot + b_off + nt * 2048 + ch0);
-            breg[nt][1] = *(const bf16x8*)(slot + b_off + nt * 2048 + ch1);
+            br[nt][0] = *(const bf16x8*)(slot + b_off + nt * 2048 + ch0);
+            br[nt][1] = *(const bf16x8*)(slot + b_off + nt * 2048 + ch1);
         }
     };
-#define UG_MMA_QUADRANT(I, J)                                                                                          \
+#define UG_MMA_QUADRANT(I, J, BR)                                                                                      \
     do {                                                                                                               \
         __builtin_amdgcn_s_setprio(1);                                                                                 \
         _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                               \
             _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                           \
                 _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                       \
-                    acc[I][J][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(breg[nt][ks], areg[mt][ks], acc[I][J][mt][nt], 0, 0, 0); \
+                    acc[I][J][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BR[nt][ks], areg[mt][ks], acc[I][J][mt][nt], 0, 0, 0); \
         __builtin_amdgcn_s_setprio(0);                                                                                 \
     } while (0)
 #define UG_BARRIER() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
 
-    const int nk = (int)(p.K / BK);
-    // prologue: the whole first K-tile
-    stage(smem + SLOT_A0, srcA[0], 0); stage(smem + SLOT_B0, srcB[0], 0);
-    stage(smem + SLOT_B1, srcB[1], 0); stage(smem + SLOT_A1, srcA[1], 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    UG_BARRIER();
-    if (wr == 1) UG_BARRIER();          // waves 4-7 run one barrier behind
-    for (int kt = 0; kt < nk; ++kt) {
-        unsigned char* cb = smem + (kt & 1) * KT_BYTES;
-        unsigned char* nb = smem + ((kt & 1) ^ 1) * KT_BYTES;
-        const bool has_next = kt + 1 < nk;
-        const int64_t kn = (int64_t)(kt + 1) * BK;
-        // phase 0: quadrant (0,0)
-        read_A(cb + SLOT_A0); read_B(cb + SLOT_B0);
-        if (has_next) { stage(nb + SLOT_A0, srcA[0], kn); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }   // B1(kt) landed
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        UG_BARRIER();
-        UG_MMA_QUADRANT(0, 0);
-        UG_BARRIER();
-        // phase 1: quadrant (0,1)
-        read_B(cb + SLOT_B1);
-        if (has_next) { stage(nb + SLOT_B0, srcB[0], kn); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }   // A1(kt) landed
-        UG_BARRIER();
-        UG_MMA_QUADRANT(0, 1);
-        UG_BARRIER();
-        // phase 2: quadrant (1,1)
-        read_A(cb + SLOT_A1);
-        if (has_next) stage(nb + SLOT_B1, srcB[1], kn);
-        UG_BARRIER();
-        UG_MMA_QUADRANT(1, 1);
-        UG_BARRIER();
-        // phase 3: quadrant (1,0)
-        read_B(cb + SLOT_B0);
-        if (has_next) { stage(nb + SLOT_A1, srcA[1], kn); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }   // A0,B0(kt+1) landed
-        UG_BARRIER();
-        UG_MMA_QUADRANT(1, 0);
-        UG_BARRIER();
-    }
-    if (wr == 0) UG_BARRIER();
-#undef UG_MMA_QUADRANT
-#undef UG_BARRIER
-
-    const bf16_t* bias = p.bias ? (const bf16_t*)p.bias + (int64_t)g * p.bias_gstride : nullptr;
-    float bv[2][2][4];
+    int tile = blockIdx.x;
+    if (tile >= total_tiles) return;
+    TileSrc cur = tile_src(tile);
+    stage_first(cur);
+    for (; tile < total_tiles; tile += gridDim.x) {
+        f32x4 acc[2][2][4][2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            const int64_t n = n0 + j * 128 + wc * 32 + nt * 16 + (lane >> 4) * 4;
-            load_bias4(n < N ? bias : nullptr, n, bv[j][nt]);
-        }
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            const int64_t m = m0 + i * 128 + wr * 64 + mt * 16 + (lane & 15);
-            if (m >= M) continue;
-            const RowCtx rc = row_ctx<EPI>(p, g, (unsigned)m);
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
-                    const int64_t n = n0 + j * 128 + wc * 32 + nt * 16 + (lane >> 4) * 4;
-                    if (n < N) epi_store<EPI>(p, rc, n, acc[i][j][mt][nt], bv[j][nt]);
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) acc[i][j][a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // In flight from before (issued ahead of the previous tile's epilogue, or below for the first tile):
+        // A0(0) B0(0) B1(0) A1(0) [A0(1) B0(1)]. The 8 half-tile slots form a ring: a slot is re-staged two K-tiles ahead as soon as
+        // its last ds_read is >= 3 segments old (B0's fragments stay in registers for phase 3, so its slot frees after phase 0):
+        //   phase 0 stages B1(kt+1) | phase 1: A1(kt+1) | phase 2: A0(kt+2) | phase 3: B0(kt+2)
+        // -> every half-tile has 5-6 phases (~1.3 K-tiles) of lead; vmcnt(8) keeps the four youngest half-tiles in flight.
+        if (nk > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // A0(0), B0(0)
+        UG_BARRIER();
+        if (wr == 1) UG_BARRIER();          // waves 4-7 run one barrier behind
+        for (int kt = 0; kt < nk; ++kt) {
+            unsigned char* cb = smem + (kt & 1) * KT_BYTES;
+            unsigned char* nb = smem + ((kt & 1) ^ 1) * KT_BYTES;
+            const bool n1 = kt + 1 < nk, n2 = kt + 2 < nk;
+            const int64_t k1 = (int64_t)(kt + 1) * BK, k2 = (int64_t)(kt + 2) * BK;
+            // phase 0: quadrant (0,0)
+            read_A(cb + SLOT_A0); read_B(breg0, cb + SLOT_B0);
+            if (n1) { stage(nb + SLOT_B1, cur.b[1], k1); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }   // B1(kt) landed
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            UG_BARRIER();
+            UG_MMA_QUADRANT(0, 0, breg0);
+            UG_BARRIER();
+            // phase 1: quadrant (0,1)
+            read_B(breg, cb + SLOT_B1);
+            if (n1) { stage(nb + SLOT_A1, cur.a[1], k1); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }   // A1(kt) landed
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            UG_BARRIER();
+            UG_MMA_QUADRANT(0, 1, breg);
+            UG_BARRIER();
+            // phase 2: quadrant (1,1)
+            read_A(cb + SLOT_A1);
+            if (n2) stage(cb + SLOT_A0, cur.a[0], k2);
+            UG_BARRIER();
+            UG_MMA_QUADRANT(1, 1, breg);
+            UG_BARRIER();
+            // phase 3: quadrant (1,0), B0 from registers
+            if (n2) { stage(cb + SLOT_B0, cur.b[0], k2); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }    // A0, B0(kt+1) landed
+            else if (n1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            UG_BARRIER();
+            UG_MMA_QUADRANT(1, 0, breg0);
+            UG_BARRIER();
+        }
+        if (wr == 0) UG_BARRIER();          // both groups level again; every LDS read of this tile has retired
+
+        // next tile: addresses + first K-tile DMA, then this tile's epilogue runs under it
+        const int64_t m0 = cur.m0, n0 = cur.n0;
+        const int g = cur.g;
+        if (tile + (int)gridDim.x < total_tiles) {
+            cur = tile_src(tile + gridDim.x);
+            stage_first(cur);
+        }
+        const bf16_t* bias = p.bias ? (const bf16_t*)p.bias + (int64_t)g * p.bias_gstride : nullptr;
+        float bv[2][2][4];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int64_t n = n0 + j * 128 + wc * 32 + nt * 16 + (lane >> 4) * 4;
+                load_bias4(n < N ? bias : nullptr, n, bv[j][nt]);
+            }
+        if (EPI != UG_EPI_F32 && wide16) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    const int64_t m = m0 + i * 128 + wr * 64 + mt * 16 + (lane & 15);
+                    const bool row_ok = m < M;                         // lanes l and l^16 share the row: the swaps stay paired
+                    const RowCtx rc = row_ctx<EPI>(p, g, (unsigned)(row_ok ? m : M - 1));
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        epi_store_pair16<EPI>(p, rc, row_ok, n0 + j * 128 + wc * 32, N, lane, acc[i][j][mt][0], acc[i][j][mt][1], bv[j][0], bv[j][1]);
+                }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    const int64_t m = m0 + i * 128 + wr * 64 + mt * 16 + (lane & 15);
+                    if (m >= M) continue;
+                    const RowCtx rc = row_ctx<EPI>(p, g, (unsigned)m);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt) {
+                            const int64_t n = n0 + j * 128 + wc * 32 + nt * 16 + (lane >> 4) * 4;
+                            if (n < N) epi_store<EPI>(p, rc, n, acc[i][j][mt][nt], bv[j][nt]);
+                        }
                 }
         }
+    }
+#undef UG_MMA_QUADRANT
+#undef UG_BARRIER
 }
 
 // UG_GEMM_FORCE_TILE=128|256 pins the kernel choice (tests / A-B timing); default: 256^2 tiles when they fill the chip.
@@ -421,8 +513,19 @@ int launch(const ug_gemm_desc& d, hipStream_t s) {
         attr_set = true;
     }
     if (big) {
-        dim3 grid((unsigned)(t256 / groups), 1, (unsigned)groups);
-        hipLaunchKernelGGL(gemm256_kernel<EPI>, grid, dim3(512), LDS256_BYTES, s, d);
+        static int ncu = 0;
+        if (ncu == 0) {
+            int dev = 0; hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
+            if (ncu <= 0) ncu = 256;
+        }
+        const int total = (int)t256;
+        dim3 grid((unsigned)(total < ncu ? total : ncu), 1, 1);
+        // 16-byte epilogue accesses need 8-column granularity everywhere the epilogue touches
+        const bool res = d.epilogue == UG_EPI_RES_GATE || d.epilogue == UG_EPI_RES_SCALE;
+        const int wide16 = d.N % 8 == 0 && d.ldc % 8 == 0 && d.c_gstride % 8 == 0 && ug_aligned(d.C, 16) &&
+                           (!res || (d.ldr % 8 == 0 && d.r_gstride % 8 == 0 && ug_aligned(d.R, 16)));
+        hipLaunchKernelGGL(gemm256_kernel<EPI>, grid, dim3(512), LDS256_BYTES, s, d, (int)(t256 / groups), total, wide16);
     } else {
         const int nM = (int)((d.M + BM - 1) / BM), nN = (int)((d.N + BN - 1) / BN);
         dim3 grid((unsigned)(nM * nN), 1, (unsigned)groups);
