@@ -105,6 +105,7 @@ def main():
             raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: unigen_amd has no CPU path")
+    local_rank = local_rank % max(torch.cuda.device_count(), 1)      # rehearsal: more ranks than GPUs share devices
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     from unigen_amd import dist_utils as DU

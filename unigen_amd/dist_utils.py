@@ -29,10 +29,11 @@ def init_distributed(device: torch.device):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if not dist.is_initialized():
-            if device.type == "cuda":
+            backend = os.environ.get("UG_DIST_BACKEND", "nccl" if device.type == "cuda" else "gloo")   # nccl = RCCL over xGMI
+            if backend == "nccl":
                 dist.init_process_group("nccl", device_id=device)
             else:
-                dist.init_process_group("gloo")
+                dist.init_process_group(backend)      # rehearsals: several ranks sharing one GPU cannot form an RCCL communicator
     return rank, world
 
 
@@ -44,11 +45,16 @@ def barrier(device: torch.device, world: int) -> None:
         torch.cuda.synchronize(device)
 
 
+def _reduce_device(device: torch.device) -> torch.device:
+    import torch.distributed as dist
+    return device if dist.get_backend() == "nccl" else torch.device("cpu")
+
+
 def max_over_ranks(value: float, device: torch.device, world: int) -> float:
     if world == 1:
         return float(value)
     import torch.distributed as dist
-    t = torch.tensor([value], device=device, dtype=torch.float64)
+    t = torch.tensor([value], device=_reduce_device(device), dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -57,6 +63,6 @@ def sum_over_ranks(value: float, device: torch.device, world: int) -> float:
     if world == 1:
         return float(value)
     import torch.distributed as dist
-    t = torch.tensor([value], device=device, dtype=torch.float64)
+    t = torch.tensor([value], device=_reduce_device(device), dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
