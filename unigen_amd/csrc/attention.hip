@@ -13,6 +13,7 @@
 //                 order, matched by the key order of the transposed V reads) - P never touches LDS or other lanes.
 #include "ug_common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -147,9 +148,12 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn_kernel(
 
     const int ntiles = (Lkv + KVB - 1) / KVB;
     bf16x8 pf[2][2];                                   // P^T fragments of the tile between its S and P stages
-    auto do_S = [&](int t) {
+    // CUR = buffer parity as a compile-time constant: every LDS address below is then a loop-invariant VGPR + an immediate offset
+    // (with a runtime parity hipcc re-materialised ~50 address adds per tile, a quarter of the VALU work of the loop).
+    auto do_S = [&](int t, auto cur_c) {
+        constexpr int CUR = decltype(cur_c)::value;
         const int kv0 = t * KVB;
-        const unsigned char* Kbuf = smem + (t & 1) * 2 * TILE;
+        const unsigned char* Kbuf = smem + CUR * 2 * TILE;
         // ---- S^T[key][q]: all 8 K fragments of key block 0 first, then block-0 MFMAs with the block-1 reads between them ----
         f32x16 sacc[2];
 #pragma unroll
@@ -218,8 +222,9 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn_kernel(
             }
         }
     };
-    auto do_P = [&](int t) {
-        const unsigned char* Vbuf = smem + (t & 1) * 2 * TILE + TILE;
+    auto do_P = [&](int t, auto cur_c) {
+        constexpr int CUR = decltype(cur_c)::value;
+        const unsigned char* Vbuf = smem + CUR * 2 * TILE + TILE;
         // ---- O^T[d][q] += V^T[d][key] P^T[key][q]: the V fragments of d-block db+1 are read between the MFMAs of block db ----
         {
             bf16x8 vf[NDB][4];
@@ -246,12 +251,17 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn_kernel(
         stage_load(0);
         stage_write(0);
         __syncthreads();
-        for (int t = 0; t < ntiles; ++t) {
+        auto tile = [&](int t, auto cur_c) {
+            constexpr int CUR = decltype(cur_c)::value;
             if (t + 1 < ntiles) stage_load((t + 1) * KVB);
-            do_S(t);
-            do_P(t);
-            if (t + 1 < ntiles) stage_write((t + 1) & 1);
+            do_S(t, cur_c);
+            do_P(t, cur_c);
+            if (t + 1 < ntiles) stage_write(CUR ^ 1);
             __syncthreads();
+        };
+        for (int t = 0; t < ntiles; t += 2) {
+            tile(t, std::integral_constant<int, 0>{});
+            if (t + 1 < ntiles) tile(t + 1, std::integral_constant<int, 1>{});
         }
     } else {
         static_assert(!STAGGER || NW == 8, "the stagger pairs waves w and w+4 of one SIMD");
@@ -298,11 +308,11 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn_kernel(
         for (int t = 0; t < ntiles; ++t) {
             const bool more = t + 1 < ntiles;
             if (more) fetch(xreg, Xb, x_rs, t + 1);
-            do_S(t);
+            if (t & 1) do_S(t, std::integral_constant<int, 1>{}); else do_S(t, std::integral_constant<int, 0>{});
             if (t + yoff < ntiles) publish(yreg, y_lds, (t + yoff) & 1);
             seg_barrier();
             if (t + 1 + yoff < ntiles) fetch(yreg, Yb, y_rs, t + 1 + yoff);
-            do_P(t);
+            if (t & 1) do_P(t, std::integral_constant<int, 1>{}); else do_P(t, std::integral_constant<int, 0>{});
             if (more) publish(xreg, x_lds, (t + 1) & 1);
             seg_barrier();
         }
