@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void qk_rmsnorm_rope_kernel(
 // applied), each wave streams whole weight rows from HBM with 16-byte loads. HBM-bound on W.
 // reference: AdaLayerNormZero.linear(silu(emb)), TimestepEmbedding, PixArtAlphaTextProjection (diffusers 0.32.2)
 // ---------------------------------------------------------------------------------------------------------
-constexpr int SL_COLS_PER_WAVE = 8;
+constexpr int SL_COLS_PER_WAVE = 4;
 
 template <int MT>
 __global__ __launch_bounds__(256) void small_linear_kernel(
@@ -171,34 +171,39 @@ __global__ __launch_bounds__(256) void small_linear_kernel(
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t nbase = ((int64_t)blockIdx.x * 4 + wave) * SL_COLS_PER_WAVE;
-    for (int cc = 0; cc < SL_COLS_PER_WAVE; ++cc) {
+    // two weight rows per pass: twice the 16-byte loads in flight per wave (the kernel is HBM-latency bound on the weight stream)
+    for (int cc = 0; cc < SL_COLS_PER_WAVE; cc += 2) {
         const int64_t n = nbase + cc;
         if (n >= N) break;
-        float acc[MT];
+        const bool two = n + 1 < N;
+        float acc0[MT], acc1[MT];
 #pragma unroll
-        for (int m = 0; m < MT; ++m) acc[m] = 0.f;
-        const bf16_t* wr = W + n * ldw;
+        for (int m = 0; m < MT; ++m) { acc0[m] = 0.f; acc1[m] = 0.f; }
+        const bf16_t* wr0 = W + n * ldw;
+        const bf16_t* wr1 = W + (two ? n + 1 : n) * ldw;
         for (int c = lane; c < nchunk; c += 64) {
-            float wf[8];
-            unpack8(*(const u32x4*)(wr + c * 8), wf);
+            float w0[8], w1[8];
+            unpack8(*(const u32x4*)(wr0 + c * 8), w0);
+            unpack8(*(const u32x4*)(wr1 + c * 8), w1);
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 float xf[8];
                 unpack8(*(const u32x4*)(xs + (int64_t)m * K + c * 8), xf);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) acc[m] += xf[e] * wf[e];
+                for (int e = 0; e < 8; ++e) { acc0[m] += xf[e] * w0[e]; acc1[m] += xf[e] * w1[e]; }
             }
         }
 #pragma unroll
-        for (int m = 0; m < MT; ++m) acc[m] = wave_sum(acc[m]);
+        for (int m = 0; m < MT; ++m) { acc0[m] = wave_sum(acc0[m]); acc1[m] = wave_sum(acc1[m]); }
         if (lane < M) {
-            float v = 0.f;
+            float v0 = 0.f, v1 = 0.f;
 #pragma unroll
-            for (int m = 0; m < MT; ++m) if (m == lane) v = acc[m];
-            if (bias) v += bf2f(bias[n]);
-            v = rbf(v);
-            if (R) v += bf2f(R[(int64_t)lane * ldr + n]);
-            out[(int64_t)lane * ldo + n] = f2bf(v);
+            for (int m = 0; m < MT; ++m) if (m == lane) { v0 = acc0[m]; v1 = acc1[m]; }
+            if (bias) { v0 += bf2f(bias[n]); if (two) v1 += bf2f(bias[n + 1]); }
+            v0 = rbf(v0); v1 = rbf(v1);
+            if (R) { v0 += bf2f(R[(int64_t)lane * ldr + n]); if (two) v1 += bf2f(R[(int64_t)lane * ldr + n + 1]); }
+            out[(int64_t)lane * ldo + n] = f2bf(v0);
+            if (two) out[(int64_t)lane * ldo + n + 1] = f2bf(v1);
         }
     }
 }
