@@ -70,7 +70,14 @@ typedef struct ug_gemm_desc {
     int32_t lora_r; int32_t _pad1;
     /* group strides (ELEMENTS) of the residual and gate operands for grouped residual epilogues (per-expert transformer blocks) */
     int64_t r_gstride, gate_gstride;
+    /* optional caller-owned scratch (>= ug_gemm_workspace_bytes(), 16-byte aligned) for the split-K treatment of the last, partially
+     * filled round of tiles; NULL = plain tiles only. Its first 4096 bytes (arrival tickets) must be ZERO before the first call;
+     * every call leaves them zero again. The rest needs no initialisation. One workspace per stream. */
+    void* workspace; int64_t workspace_bytes;
 } ug_gemm_desc;
+
+/* bytes of ug_gemm_desc.workspace that are always sufficient (any shape) */
+int64_t ug_gemm_workspace_bytes(void);
 
 /* replaces every nn.Linear on the path (torch F.linear -> BLAS) incl. fused epilogues. */
 int ug_gemm_bf16(const ug_gemm_desc* d, ug_stream_t stream);

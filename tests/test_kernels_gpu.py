@@ -387,3 +387,25 @@ def test_lora_linear_switch(gpu):
     ref = R.lora_linear(x.float(), w.float(), b.float(), [(A.float(), Bm.float(), alpha / r)])
     m = report("lora_linear_depth_only", only, ref)
     assert m["rel_l2"] <= 3e-3, m
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(2304, 3072, 6144, "res_gate"), (4608, 4096, 8192, "gelu"), (2000, 2900 // 4 * 4, 6208, "bias")])
+def test_gemm_splitk_tail(gpu, M, N, K, epi):
+    """Shapes whose 256x256 tiles leave a partially filled last round: the remainder tiles are split along K, partial sums go through
+    the fp32 workspace and the last arriver reduces them in fixed slice order -> correct AND bitwise repeatable."""
+    from unigen_amd import lib as L, ops
+    g = torch.Generator().manual_seed(M + N + K)
+    a, w, b = _rand(g, M, K), _rand(g, N, K, scale=K ** -0.5), _rand(g, N, scale=0.1)
+    res, gate = _rand(g, M, N), _rand(g, (M + 255) // 256, N)
+    code = dict(bias=L.EPI_BIAS, gelu=L.EPI_BIAS_GELU, res_gate=L.EPI_RES_GATE)[epi]
+    outs = []
+    for _ in range(3):
+        out = torch.empty(M, N, device=gpu, dtype=BF)
+        ops.gemm(a.to(gpu), w.to(gpu), b.to(gpu), out, M=M, epilogue=code, residual=res.to(gpu) if epi == "res_gate" else None,
+                 gate=gate.to(gpu) if epi == "res_gate" else None, gate_ld=N, rows_per_sample=256)
+        outs.append(out.cpu())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), "split-K tail is not bitwise repeatable"
+    acc = a.float() @ w.float().t()
+    ref = _epi_ref(acc, b, epi, res, gate, 256, 1.0)[:M]
+    m = report(f"gemm_splitk_{epi}_{M}x{N}x{K}", outs[0], ref)
+    assert m["rel_l2"] <= TOL, m

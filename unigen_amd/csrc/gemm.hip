@@ -305,10 +305,17 @@ constexpr int LDS256_BYTES = 2 * KT_BYTES;
 constexpr int SLOT_A0 = 0, SLOT_B0 = HT_BYTES, SLOT_B1 = 2 * HT_BYTES, SLOT_A1 = 3 * HT_BYTES;
 
 template <int EPI>
-__global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, const int tiles_per_group, const int total_tiles, const int wide16) {
+__global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, const int tiles_per_group, const int total_tiles, const int wide16,
+                                                          const int full_tiles, const int nslices, float* __restrict__ slabs,
+                                                          unsigned* __restrict__ tickets) {
     // PERSISTENT: the grid is one workgroup per CU; each walks tiles blockIdx.x, +gridDim.x, ... (same XCD-aware order as a plain
     // launch would see round by round). The first K-tile of the NEXT tile is put in flight before the epilogue of the current one,
     // so workgroup relaunch, address set-up and the first DMA latency overlap the C stores instead of preceding the main loop.
+    //
+    // TAIL: tiles [0, full_tiles) fill whole rounds of the grid. When the remaining R tiles would occupy <= half the CUs they
+    // are each cut into `nslices` K-slices that run concurrently in the last round: a slice stores its fp32 accumulators as a
+    // slab, publishes it (agent-scope release + ticket), and the LAST arriver of a tile re-reads every slab in slice order
+    // (agent-scope acquire; fixed order -> bitwise reproducible) and runs the epilogue. Nobody waits on anybody: no spin.
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -322,9 +329,26 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
     const int ch0 = ((fch ^ fsw) << 4), ch1 = (((4 + fch) ^ fsw) << 4);
     const int nk = (int)(p.K / BK);
 
-    struct TileSrc { const bf16_t* a[2][2]; const bf16_t* b[2][2]; int64_t m0, n0; int g; };
-    auto tile_src = [&](int tile) {
+    struct TileSrc { const bf16_t* a[2][2]; const bf16_t* b[2][2]; int64_t m0, n0; int g; int nk; int rem; int slice; };
+    // work item w -> tile and K range. Items >= full_tiles are K-slices of remainder tile `rem`; a tile's slices share blockIdx & 7
+    // (= one XCD under round-robin placement; speed only).
+    const int n_items = full_tiles + (((total_tiles - full_tiles) + 7) / 8) * 8 * nslices;
+    auto tile_src = [&](int w) {
         TileSrc t;
+        int tile = w, kb = 0;
+        t.nk = nk; t.rem = -1; t.slice = 0;
+        if (w >= full_tiles && nslices > 1) {
+            const int j = w - full_tiles;
+            const int xcd = j & 7, kx = j >> 3;
+            t.rem = (kx / nslices) * 8 + xcd;
+            t.slice = kx % nslices;
+            tile = full_tiles + t.rem;
+            if (tile >= total_tiles) { t.nk = 0; tile = total_tiles - 1; }       // padding item of the 8-aligned remainder: no work
+            else {
+                kb = (t.slice * nk) / nslices;
+                t.nk = ((t.slice + 1) * nk) / nslices - kb;
+            }
+        }
         t.g = tile / tiles_per_group;
         const TileCoord tc = tile_of_block(tile - t.g * tiles_per_group, nM, nN);
         t.m0 = (int64_t)tc.tm * 256; t.n0 = (int64_t)tc.tn * 256;
@@ -338,8 +362,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
                 const int c = (lane & 7) ^ (row & 7);
                 int64_t am = t.m0 + h * 128 + row; if (am > M - 1) am = M - 1;
                 int64_t wn = t.n0 + h * 128 + row; if (wn > N - 1) wn = N - 1;
-                t.a[h][i] = Ab + (int64_t)rowmap32((unsigned)am, (unsigned)p.a_rpb, (unsigned)p.a_bstride) * p.lda + c * 8;
-                t.b[h][i] = Wb + wn * p.ldw + c * 8;
+                t.a[h][i] = Ab + (int64_t)rowmap32((unsigned)am, (unsigned)p.a_rpb, (unsigned)p.a_bstride) * p.lda + c * 8 + (int64_t)kb * BK;
+                t.b[h][i] = Wb + wn * p.ldw + c * 8 + (int64_t)kb * BK;
             }
         return t;
     };
@@ -350,7 +374,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
     auto stage_first = [&](const TileSrc& t) {
         stage(smem + SLOT_A0, t.a[0], 0); stage(smem + SLOT_B0, t.b[0], 0);
         stage(smem + SLOT_B1, t.b[1], 0); stage(smem + SLOT_A1, t.a[1], 0);
-        if (nk > 1) { stage(smem + KT_BYTES + SLOT_A0, t.a[0], BK); stage(smem + KT_BYTES + SLOT_B0, t.b[0], BK); }
+        if (t.nk > 1) { stage(smem + KT_BYTES + SLOT_A0, t.a[0], BK); stage(smem + KT_BYTES + SLOT_B0, t.b[0], BK); }
     };
     bf16x8 areg[4][2], breg[2][2], breg0[2][2];    // breg0: B0 fragments, kept from phase 0 to phase 3
     auto read_A = [&](const unsigned char* slot) {
@@ -379,10 +403,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
 #define UG_BARRIER() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
 
     int tile = blockIdx.x;
-    if (tile >= total_tiles) return;
+    if (tile >= n_items) return;
     TileSrc cur = tile_src(tile);
-    stage_first(cur);
-    for (; tile < total_tiles; tile += gridDim.x) {
+    if (cur.nk > 0) stage_first(cur);
+    for (; tile < n_items; tile += gridDim.x) {
+        const int nk = cur.nk;             // K-tiles of THIS work item (shadows the full count)
+        if (nk == 0) break;                // padding item (only ever the last one of a workgroup)
         f32x4 acc[2][2][4][2];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -437,9 +463,61 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
         // next tile: addresses + first K-tile DMA, then this tile's epilogue runs under it
         const int64_t m0 = cur.m0, n0 = cur.n0;
         const int g = cur.g;
-        if (tile + (int)gridDim.x < total_tiles) {
+        const int rem = cur.rem, slice = cur.slice;
+        if (tile + (int)gridDim.x < n_items) {
             cur = tile_src(tile + gridDim.x);
-            stage_first(cur);
+            if (cur.nk > 0) stage_first(cur);
+        } else cur.nk = 0;
+        if (rem >= 0) {
+            // ---- split-K tail: slab out, ticket, last arriver reduces (cdna guide section 5, "in-launch split-K reduction") ----
+            float* my = slabs + ((size_t)rem * nslices + slice) * 65536;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+#pragma unroll
+                        for (int b = 0; b < 2; ++b)
+                            *(f32x4*)(my + ((((i * 2 + j) * 4 + a) * 2 + b) * 512 + tid) * 4) = acc[i][j][a][b];
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // every storing wave
+            __syncthreads();
+            unsigned* flag = (unsigned*)(smem + LDS256_BYTES);
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // keep: hipcc may drop the fence's own wait
+                *flag = __hip_atomic_fetch_add(tickets + rem, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();
+            const bool last = *flag == (unsigned)(nslices - 1);
+            __syncthreads();                                              // flag is re-used by a later item
+            if (!last) continue;
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(tickets + rem, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // all arrivals are in: ready for the next launch
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) acc[i][j][a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int sl = 0; sl < nslices; ++sl) {
+                const float* sp = slabs + ((size_t)rem * nslices + sl) * 65536;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int a = 0; a < 4; ++a)
+#pragma unroll
+                            for (int b = 0; b < 2; ++b)
+                                acc[i][j][a][b] += *(const f32x4*)(sp + ((((i * 2 + j) * 4 + a) * 2 + b) * 512 + tid) * 4);
+            }
         }
         const bf16_t* bias = p.bias ? (const bf16_t*)p.bias + (int64_t)g * p.bias_gstride : nullptr;
         float bv[2][2][4];
@@ -509,7 +587,7 @@ int launch(const ug_gemm_desc& d, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)gemm128_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)gemm256_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm256_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256_BYTES + 16);
         attr_set = true;
     }
     if (big) {
@@ -525,7 +603,27 @@ int launch(const ug_gemm_desc& d, hipStream_t s) {
         const bool res = d.epilogue == UG_EPI_RES_GATE || d.epilogue == UG_EPI_RES_SCALE;
         const int wide16 = d.N % 8 == 0 && d.ldc % 8 == 0 && d.c_gstride % 8 == 0 && ug_aligned(d.C, 16) &&
                            (!res || (d.ldr % 8 == 0 && d.r_gstride % 8 == 0 && ug_aligned(d.R, 16)));
-        hipLaunchKernelGGL(gemm256_kernel<EPI>, grid, dim3(512), LDS256_BYTES, s, d, (int)(t256 / groups), total, wide16);
+        // split-K tail (see the kernel header): needs the caller's workspace for the slabs and tickets
+        int full = total, nsl = 1;
+        float* slabs = nullptr; unsigned* tickets = nullptr;
+        const int G = ncu, rem = total % G;            // total < ncu: every tile is a remainder tile
+        const int nkt = (int)(d.K / BK);
+        static int split_on = -1;
+        if (split_on < 0) { const char* e = getenv("UG_GEMM_SPLITK_TAIL"); split_on = (e && atoi(e) == 0) ? 0 : 1; }
+        // Measured (MI355X): the slab round trip + fences cost ~35 us, so the split only pays when a tile's K loop is long
+        // (K = 15360 single-block proj_out: +3.5 %; K = 3072 shapes: -2...-3 %) -> require >= 96 K-tiles.
+        if (split_on && rem > 0 && rem * 2 <= G && d.workspace && nkt >= 96) {
+            const int rem8 = (rem + 7) / 8 * 8;
+            int cand = G / rem8; if (cand > 8) cand = 8; if (cand > nkt / 4) cand = nkt / 4;
+            const size_t need = 4096 + (size_t)rem8 * cand * 65536 * sizeof(float);
+            if (cand >= 2 && (size_t)d.workspace_bytes >= need && ug_aligned(d.workspace, 16)) {
+                nsl = cand; full = total - rem;
+                if (total < ncu) grid.x = (unsigned)(rem8 * cand);      // one workgroup per K-slice (incl. the 8-alignment padding)
+                tickets = (unsigned*)d.workspace;
+                slabs = (float*)((char*)d.workspace + 4096);
+            }
+        }
+        hipLaunchKernelGGL(gemm256_kernel<EPI>, grid, dim3(512), LDS256_BYTES + 16, s, d, (int)(t256 / groups), total, wide16, full, nsl, slabs, tickets);
     } else {
         const int nM = (int)((d.M + BM - 1) / BM), nN = (int)((d.N + BN - 1) / BN);
         dim3 grid((unsigned)(nM * nN), 1, (unsigned)groups);
@@ -536,6 +634,8 @@ int launch(const ug_gemm_desc& d, hipStream_t s) {
 }
 
 }  // namespace
+
+extern "C" int64_t ug_gemm_workspace_bytes(void) { return 4096 + (int64_t)256 * 65536 * (int64_t)sizeof(float); }
 
 extern "C" int ug_gemm_bf16(const ug_gemm_desc* dp, ug_stream_t stream) {
     UG_REQUIRE(dp != nullptr, UG_ERR_BAD_SHAPE, "ug_gemm_bf16: null descriptor");

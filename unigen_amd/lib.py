@@ -35,6 +35,7 @@ class GemmDesc(C.Structure):
         ("lora_B", vp), ("ldb", i64),
         ("lora_r", i32), ("_pad1", i32),
         ("r_gstride", i64), ("gate_gstride", i64),
+        ("workspace", vp), ("workspace_bytes", i64),
     ]
 
 
@@ -42,6 +43,7 @@ class GemmDesc(C.Structure):
 SIGNATURES = {
     "ug_version": (i32, []),
     "ug_last_error": (C.c_char_p, []),
+    "ug_gemm_workspace_bytes": (i64, []),
     "ug_gemm_bf16": (i32, [C.POINTER(GemmDesc), vp]),
     "ug_small_linear_bf16": (i32, [vp, i64, vp, i64, vp, vp, i64, vp, i64, i64, i64, i64, i32, vp]),
     "ug_adaln_modulate": (i32, [vp, i64, i64, i64, vp, vp, i64, i64, vp, i64, i64, i64, f32, vp]),

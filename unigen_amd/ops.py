@@ -84,6 +84,17 @@ class RowMap:
 
 IDENT = RowMap()
 
+_gemm_ws: dict = {}
+
+
+def _gemm_workspace(device) -> torch.Tensor:
+    """Caller-owned scratch for the GEMM's split-K tail (one per device, allocated once)."""
+    ws = _gemm_ws.get(device)
+    if ws is None:
+        ws = torch.zeros(int(L.load().ug_gemm_workspace_bytes()), dtype=torch.uint8, device=device)   # tickets start at zero
+        _gemm_ws[device] = ws
+    return ws
+
 
 def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, *, M: int,
          epilogue: int = L.EPI_BIAS, lda: Optional[int] = None, ldc: Optional[int] = None, a_map: RowMap = IDENT,
@@ -112,6 +123,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: to
     d.M, d.N, d.K = M, N, K
     d.groups, d.a_gstride, d.w_gstride, d.bias_gstride, d.c_gstride = groups, a_gstride, w_gstride, bias_gstride, c_gstride
     d.r_gstride, d.gate_gstride = r_gstride, gate_gstride
+    ws = _gemm_workspace(a.device)
+    d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
     if lora_t is not None:
         _chk(lora_t, "lora_t"); _chk(lora_b, "lora_b")
         d.lora_T, d.ldt, d.lora_B, d.ldb, d.lora_r = lora_t.data_ptr(), lora_t.stride(-2), lora_b.data_ptr(), lora_b.stride(-2), lora_b.shape[-1]
