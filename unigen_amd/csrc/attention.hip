@@ -83,16 +83,30 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn_kernel(
     // ---- Q fragments (B operand of S^T = K Q^T): lane (r, h) holds Q[q = r][d = 16 s + 8 h + j] ----
     const int q_row = qt * QROWS + wave * 32 + r;
     const int q_ld = q_row < Lq ? q_row : Lq - 1;
-    bf16x8 qf[QS];
+    // Lock-step variant: Q fragments stay in registers. X/Y stagger: they live in LDS (same swizzled row image as K, one
+    // ds_read_b128 per k-step) because S^T must survive a barrier next to the P.V operands and 32 fewer VGPRs avoid spills.
+    constexpr int QBASE = 2 * 2 * KVB * RB;            // byte offset of the Q image behind the two K|V buffers
+    bf16x8 qf[STAGGER ? 1 : QS];
+    const int q_lds = QBASE + RB * (wave * 32 + r);
+    const int qx = h ^ row_swz<DH>(r);                  // wave * 32 keeps row_swz unchanged (multiple of 16)
+    if constexpr (!STAGGER) {
 #pragma unroll
-    for (int s = 0; s < QS; ++s) qf[s] = *(const bf16x8*)(Qb + (int64_t)q_ld * q_rs + 16 * s + 8 * h);
-    // Retire the Q loads HERE: the empty asm takes every fragment as a read-write operand, so hipcc must have the loaded
-    // values in hand before it (it waits vmcnt there) and treats them as fresh afterwards. Without it the loads are sunk to
-    // the loop header and every iteration re-waits for them with vmcnt(7..0), draining the K/V prefetch issued at its top.
-    if constexpr (QS == 8)
-        asm volatile("" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3]), "+v"(qf[4]), "+v"(qf[5]), "+v"(qf[6]), "+v"(qf[7]));
-    else
-        asm volatile("" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3]));
+        for (int s = 0; s < QS; ++s) qf[s] = *(const bf16x8*)(Qb + (int64_t)q_ld * q_rs + 16 * s + 8 * h);
+        // Retire the Q loads HERE: the empty asm takes every fragment as a read-write operand, so hipcc must have the loaded
+        // values in hand before it (it waits vmcnt there) and treats them as fresh afterwards. Without it the loads are sunk to
+        // the loop header and every iteration re-waits for them with vmcnt(7..0), draining the K/V prefetch issued at its top.
+        if constexpr (QS == 8)
+            asm volatile("" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3]), "+v"(qf[4]), "+v"(qf[5]), "+v"(qf[6]), "+v"(qf[7]));
+        else
+            asm volatile("" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3]));
+    } else {
+        // each lane copies the 16-byte chunks (16 s + 8 h) of its own query row; only this wave reads them back
+#pragma unroll
+        for (int s = 0; s < QS; ++s) {
+            const u32x4 v4 = *(const u32x4*)(Qb + (int64_t)q_ld * q_rs + 16 * s + 8 * h);
+            *(u32x4*)(smem + q_lds + 16 * ((2 * s) ^ qx)) = v4;
+        }
+    }
 
     // ---- staging assignment: thread -> 2 chunks of K and 2 of V per tile ----
     int st_row[NST], st_ch[NST], st_off[NST];
@@ -150,17 +164,17 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn_kernel(
     bf16x8 pf[2][2];                                   // P^T fragments of the tile between its S and P stages
     // CUR = buffer parity as a compile-time constant: every LDS address below is then a loop-invariant VGPR + an immediate offset
     // (with a runtime parity hipcc re-materialised ~50 address adds per tile, a quarter of the VALU work of the loop).
-    auto do_S = [&](int t, auto cur_c) {
+    f32x16 sacc[2];                                    // S^T of the tile between its QK^T and its softmax
+    auto do_QK = [&](int t, auto cur_c) {
         constexpr int CUR = decltype(cur_c)::value;
         const int kv0 = t * KVB;
         const unsigned char* Kbuf = smem + CUR * 2 * TILE;
         // ---- S^T[key][q]: all 8 K fragments of key block 0 first, then block-0 MFMAs with the block-1 reads between them ----
-        f32x16 sacc[2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int i = 0; i < 16; ++i) sacc[kb][i] = 0.f;
-        {
+        if constexpr (!STAGGER) {
             bf16x8 kf0[QS], kf1[QS];
 #pragma unroll
             for (int s = 0; s < QS; ++s) kf0[s] = *(const bf16x8*)(Kbuf + k_rowoff + 16 * ((2 * s) ^ kx));
@@ -170,13 +184,35 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn_kernel(
             for (int s = 0; s < QS; ++s) sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0[s], qf[s], sacc[0], 0, 0, 0);
 #pragma unroll
             for (int s = 0; s < QS; ++s) sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1[s], qf[s], sacc[1], 0, 0, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, QS, 0);           // ds_reads of key block 0
+            __builtin_amdgcn_sched_group_barrier(0x100, QS, 0);       // ds_reads of key block 0
 #pragma unroll
             for (int s = 0; s < QS; ++s) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);        // 1 MFMA (block 0)
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);        // 1 ds_read (block 1)
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // 1 MFMA (block 0)
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    // 1 ds_read (block 1)
             }
-            __builtin_amdgcn_sched_group_barrier(0x008, QS, 0);           // MFMAs of block 1
+            __builtin_amdgcn_sched_group_barrier(0x008, QS, 0);       // MFMAs of block 1
+        } else {
+            // Q comes from LDS too: per k-step one Q fragment and the two key blocks' K fragments, read two steps ahead of their
+            // MFMAs (9 fragments = 36 VGPRs live instead of 24 fragments if hipcc hoisted every read).
+            bf16x8 ql[QS], kf0[QS], kf1[QS];
+#pragma unroll
+            for (int s = 0; s < QS; ++s) {
+                ql[s] = *(const bf16x8*)(smem + q_lds + 16 * ((2 * s) ^ qx));
+                kf0[s] = *(const bf16x8*)(Kbuf + k_rowoff + 16 * ((2 * s) ^ kx));
+                kf1[s] = *(const bf16x8*)(Kbuf + 32 * RB + k_rowoff + 16 * ((2 * s) ^ kx));
+            }
+#pragma unroll
+            for (int s = 0; s < QS; ++s) {
+                sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0[s], ql[s], sacc[0], 0, 0, 0);
+                sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1[s], ql[s], sacc[1], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);        // fragments of k-steps 0, 1
+#pragma unroll
+            for (int s = 0; s < QS - 2; ++s) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);    // MFMAs of step s
+                __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);    // fragments of step s + 2
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
         }
         if (kv0 + KVB > Lkv) {   // ragged last tile: keys >= Lkv do not exist
 #pragma unroll
@@ -187,6 +223,8 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn_kernel(
                     if (key >= Lkv) sacc[kb][i] = -INFINITY;
                 }
         }
+    };
+    auto do_SM = [&]() {
         // ---- online softmax, all lane-local (this lane: query r, 32 of the tile's 64 keys; lane^32 has the rest) ----
         float tmax = sacc[0][0];
 #pragma unroll
@@ -254,7 +292,8 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn_kernel(
         auto tile = [&](int t, auto cur_c) {
             constexpr int CUR = decltype(cur_c)::value;
             if (t + 1 < ntiles) stage_load((t + 1) * KVB);
-            do_S(t, cur_c);
+            do_QK(t, cur_c);
+            do_SM();
             do_P(t, cur_c);
             if (t + 1 < ntiles) stage_write(CUR ^ 1);
             __syncthreads();
@@ -265,56 +304,62 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn_kernel(
         }
     } else {
         static_assert(!STAGGER || NW == 8, "the stagger pairs waves w and w+4 of one SIMD");
-        // Every wave runs the same program [S(t) | P(t) |]*; waves 4-7 (group B) enter it one segment late, so in every global
-        // segment one wave of each SIMD is in an S stage and its partner in a P stage. Staging follows the GLOBAL segment parity
-        // (even: fetch K(t+1), publish V(t); odd: fetch V(t+1), publish K(t+1)). Seen from a wave that is two register sets:
-        //   X: fetched at the start of S(t), published at the end of P(t)      (group A: K(t+1)   | group B: V(t+1))
-        //   Y: fetched at the start of P(t), published at the end of S(t+1)    (group A: V(t+1)   | group B: K(t+2))
-        // Both groups execute IDENTICAL control flow - only base pointers, LDS offsets and one tile offset differ - so the
-        // compiler keeps each fetch in flight for two segments instead of merging register sets at branch joins.
-        // Global loads cross the barriers, hence raw s_barrier + explicit lgkmcnt(0) (a __syncthreads fence would drain vmcnt).
+        // X / Y stagger. A wave alternates a MATRIX-only segment X(t) = P.V of tile t followed by S^T = K.Q^T of tile t+1, and a
+        // VALU-only segment Y(t+1) = online softmax of tile t+1. Waves 0-3 (group A) and 4-7 (group B) - the two waves of every
+        // SIMD - run one segment apart, so in every segment a SIMD has one wave feeding the matrix pipe and one feeding the VALU
+        // (PMC on the lock-step loop: matrix pipe busy 42 %, VALU 45 %, hardly overlapping).
+        //   global segment:   0       1       2       3       4
+        //   group A:        QK(0)    Y(0)    X(0)    Y(1)    X(1) ...
+        //   group B:          -     QK(0)    Y(0)    X(0)    Y(1) ...
+        // K(t+1) and V(t) are first needed in segment 2t+2: every thread fetches its share at the START of even segment 2t and
+        // publishes it at the END of odd segment 2t+1 (into buffers nobody reads in 2t / 2t+1). Loads cross barriers: raw s_barrier.
         auto seg_barrier = [&]() {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
         };
-        const bool groupA = __builtin_amdgcn_readfirstlane(wave) < 4;
-        const int yoff = groupA ? 0 : 1;
-        const bf16_t* Xb = groupA ? Kb : Vb;  const int64_t x_rs = groupA ? k_rs : v_rs;  const int x_lds = groupA ? 0 : TILE;
-        const bf16_t* Yb = groupA ? Vb : Kb;  const int64_t y_rs = groupA ? v_rs : k_rs;  const int y_lds = groupA ? TILE : 0;
-        u32x4 xreg[NST], yreg[NST];
-        auto fetch = [&](u32x4 (&reg)[NST], const bf16_t* base, int64_t rs, int tile) {
+        auto fetch = [&](int kt, int vt) {              // K(kt), V(vt) -> registers (tiles beyond the end: nothing)
 #pragma unroll
             for (int u = 0; u < NST; ++u) {
-                int key = tile * KVB + st_row[u]; if (key > Lkv - 1) key = Lkv - 1;
-                reg[u] = *(const u32x4*)(base + (int64_t)key * rs + st_ch[u] * 8);
+                if (kt < ntiles) { int key = kt * KVB + st_row[u]; if (key > Lkv - 1) key = Lkv - 1; kreg[u] = *(const u32x4*)(Kb + (int64_t)key * k_rs + st_ch[u] * 8); }
+                if (vt < ntiles) { int key = vt * KVB + st_row[u]; if (key > Lkv - 1) key = Lkv - 1; vreg[u] = *(const u32x4*)(Vb + (int64_t)key * v_rs + st_ch[u] * 8); }
             }
         };
-        auto publish = [&](const u32x4 (&reg)[NST], int lds_off, int buf) {
+        auto publish = [&](int kt, int vt) {
 #pragma unroll
-            for (int u = 0; u < NST; ++u) *(u32x4*)(smem + buf * 2 * TILE + lds_off + st_off[u]) = reg[u];
+            for (int u = 0; u < NST; ++u) {
+                if (kt < ntiles) *(u32x4*)(smem + (kt & 1) * 2 * TILE + st_off[u]) = kreg[u];
+                if (vt < ntiles) *(u32x4*)(smem + (vt & 1) * 2 * TILE + TILE + st_off[u]) = vreg[u];
+            }
         };
-        fetch(xreg, Kb, k_rs, 0);
-        publish(xreg, 0, 0);                           // K(0)
-        fetch(xreg, Vb, v_rs, 0);                      // V(0): group B publishes it from X in its lead-in ...
-        fetch(yreg, Vb, v_rs, 0);                      // ... group A from Y at the end of S(0)
+        const bool groupA = __builtin_amdgcn_readfirstlane(wave) < 4;
+        fetch(0, ntiles);                              // K(0) only
+        publish(0, ntiles);
         seg_barrier();
-        if (!groupA) {                                 // B's lead-in = global segment 0 without compute
-            if (1 < ntiles) fetch(yreg, Yb, y_rs, 1);
-            publish(xreg, x_lds, 0);
+        fetch(1, 0);                                   // segment 0 (even): K(1), V(0) in flight
+        if (!groupA) seg_barrier();                    // B idles through segment 0
+        do_QK(0, std::integral_constant<int, 0>{});    // A: segment 0 | B: segment 1
+        if (!groupA) publish(1, 0);                    // end of segment 1 (B)
+        seg_barrier();
+        // one tile = Y(t) | X(t); buffer parity is a compile-time constant (two tiles per trip)
+        auto tile = [&](int t, auto cur_c) {
+            constexpr int CUR = decltype(cur_c)::value;
+            // Y(t): A in odd segment 2t+1 (publishes K(t+1), V(t) at its end) | B in even segment 2t+2 (fetches K(t+2), V(t+1) at its start)
+            if (!groupA) fetch(t + 2, t + 1);
+            do_SM();
+            if (groupA) publish(t + 1, t);
             seg_barrier();
-        }
-        for (int t = 0; t < ntiles; ++t) {
-            const bool more = t + 1 < ntiles;
-            if (more) fetch(xreg, Xb, x_rs, t + 1);
-            if (t & 1) do_S(t, std::integral_constant<int, 1>{}); else do_S(t, std::integral_constant<int, 0>{});
-            if (t + yoff < ntiles) publish(yreg, y_lds, (t + yoff) & 1);
+            // X(t) = P.V(t) then K.Q^T(t+1): A in even segment 2t+2 (fetch) | B in odd segment 2t+3 (publish)
+            if (groupA) fetch(t + 2, t + 1);
+            do_P(t, cur_c);
+            if (t + 1 < ntiles) do_QK(t + 1, std::integral_constant<int, CUR ^ 1>{});
+            if (!groupA) publish(t + 2, t + 1);
             seg_barrier();
-            if (t + 1 + yoff < ntiles) fetch(yreg, Yb, y_rs, t + 1 + yoff);
-            if (t & 1) do_P(t, std::integral_constant<int, 1>{}); else do_P(t, std::integral_constant<int, 0>{});
-            if (more) publish(xreg, x_lds, (t + 1) & 1);
-            seg_barrier();
+        };
+        for (int t = 0; t < ntiles; t += 2) {
+            tile(t, std::integral_constant<int, 0>{});
+            if (t + 1 < ntiles) tile(t + 1, std::integral_constant<int, 1>{});
         }
         if (groupA) seg_barrier();                     // A's trailing (empty) segment pairs with B's last one
     }
@@ -359,11 +404,11 @@ extern "C" int ug_flash_attn_fwd(const void* q, int64_t q_row_stride, int64_t q_
     UG_REQUIRE(nwg < (1ll << 31), UG_ERR_UNSUPPORTED, "ug_flash_attn_fwd: grid too large");
     const float c = softmax_scale * 1.4426950408889634f;
 #define UG_ATTN_LAUNCH(DHV, NWV, STG)                                                                                                \
-    hipLaunchKernelGGL((flash_attn_kernel<DHV, NWV, STG>), dim3((unsigned)nwg), dim3(64 * NWV), 2 * 2 * KVB * 2 * DHV, (hipStream_t)stream, \
+    hipLaunchKernelGGL((flash_attn_kernel<DHV, NWV, STG>), dim3((unsigned)nwg), dim3(64 * NWV), 2 * 2 * KVB * 2 * DHV + (STG ? 32 * NWV * 2 * DHV : 0), (hipStream_t)stream, \
                        (const bf16_t*)q, q_row_stride, q_batch_stride, (const bf16_t*)k, k_row_stride, k_batch_stride, (const bf16_t*)v, \
                        v_row_stride, v_batch_stride, (bf16_t*)o, o_row_stride, o_batch_stride, (int)heads, (int)Lq, (int)Lkv, nQ, c)
     static int stagger = -1;
-    if (stagger < 0) { const char* e = getenv("UG_ATTN_STAGGER"); stagger = (e && atoi(e) == 1) ? 1 : 0; }   // measured: 812 vs 835 TFLOP/s at L = 4608, dh = 128 -> off by default
+    if (stagger < 0) { const char* e = getenv("UG_ATTN_STAGGER"); stagger = (e && atoi(e) == 1) ? 1 : 0; }   // X/Y stagger measured 602 vs 842 TFLOP/s at L = 4608, dh = 128 (a lone hipcc-scheduled MFMA stream does not keep the pipe busy) -> off
     if (dh == 128) { if (nw == 4) UG_ATTN_LAUNCH(128, 4, false); else if (stagger) UG_ATTN_LAUNCH(128, 8, true); else UG_ATTN_LAUNCH(128, 8, false); }
     else           { if (nw == 4) UG_ATTN_LAUNCH(64, 4, false); else if (stagger) UG_ATTN_LAUNCH(64, 8, true); else UG_ATTN_LAUNCH(64, 8, false); }
 #undef UG_ATTN_LAUNCH
