@@ -1,0 +1,114 @@
+"""GPU parity at BASELINE.json's FULL sizes (cfg2: B = 4, N = 4096, T = 512, D = 3072, H = 24), where the CPU oracle cannot evaluate the
+whole op in seconds: sampled rows against the fp32 oracle formula, plus size-independent properties (softmax rows sum to one,
+routing is a partial permutation within capacity, dispatch -> combine round trip, bitwise repeatability)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import unigen_ref as R
+from tests.util import report
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+def _randn(gpu, g, *shape, scale=1.0):
+    return (torch.randn(*shape, generator=g, device=gpu) * scale).to(BF)
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(18432, 12288, 3072, "gelu"), (18432, 3072, 15360, "res_gate"), (16384, 9216, 3072, "bias")])
+def test_gemm_full_size_sampled_rows(gpu, M, N, K, epi):
+    from unigen_amd import lib as L, ops
+    g = torch.Generator(device=gpu).manual_seed(M + K)
+    a, w, b = _randn(gpu, g, M, K), _randn(gpu, g, N, K, scale=K ** -0.5), _randn(gpu, g, N, scale=0.1)
+    res, gate = _randn(gpu, g, M, N), _randn(gpu, g, 4, N)
+    out = torch.empty(M, N, device=gpu, dtype=BF)
+    code = dict(bias=L.EPI_BIAS, gelu=L.EPI_BIAS_GELU, res_gate=L.EPI_RES_GATE)[epi]
+    kw = dict(residual=res, gate=gate, gate_ld=N, rows_per_sample=M // 4) if epi == "res_gate" else {}
+    ops.gemm(a, w, b, out, M=M, epilogue=code, **kw)
+    out2 = torch.empty_like(out)
+    ops.gemm(a, w, b, out2, M=M, epilogue=code, **kw)
+    assert torch.equal(out, out2), "not bitwise repeatable"
+    rows = torch.tensor([0, 1, 255, 256, 4607, 4608, 9999, M - 257, M - 1])        # tile edges + interior
+    acc = a[rows].cpu().float() @ w.cpu().float().t()
+    v = (acc + b.cpu().float()).to(BF)
+    if epi == "gelu":
+        ref = F.gelu(v, approximate="tanh")
+    elif epi == "res_gate":
+        ref = res[rows].cpu() + gate.cpu()[rows // (M // 4)] * v
+    else:
+        ref = v
+    m = report(f"full_gemm_{epi}_{M}x{N}x{K}", out[rows], ref)
+    assert m["rel_l2"] <= 1e-3, m
+
+
+def test_attention_full_size_properties(gpu):
+    from unigen_amd import ops
+    B, H, L, dh = 4, 24, 4608, 128
+    D = H * dh
+    g = torch.Generator(device=gpu).manual_seed(1)
+    qkv = _randn(gpu, g, B, L, 3 * D)
+    out = torch.empty(B, L, D, device=gpu, dtype=BF)
+    st = (3 * D, L * 3 * D)
+    run = lambda o: ops.flash_attn(qkv, qkv[0, 0, D:], qkv[0, 0, 2 * D:], o, batches=B, heads=H, dh=dh, Lq=L, Lkv=L, q_strides=st, k_strides=st, v_strides=st, o_strides=(D, L * D))
+    run(out)
+    out2 = torch.empty_like(out); run(out2)
+    assert torch.equal(out, out2), "not bitwise repeatable"
+    # sampled (batch, head, query rows) against the fp32 formula on the CPU
+    for (b, h) in ((0, 0), (3, 23), (1, 7)):
+        rows = torch.tensor([0, 31, 32, 255, 256, 2047, 4095, 4607])
+        q = qkv[b, rows, h * dh:(h + 1) * dh].cpu().float()
+        k = qkv[b, :, D + h * dh:D + (h + 1) * dh].cpu().float()
+        v = qkv[b, :, 2 * D + h * dh:2 * D + (h + 1) * dh].cpu().float()
+        ref = torch.softmax(q @ k.t() * dh ** -0.5, dim=-1) @ v
+        m = report(f"full_attn_b{b}h{h}", out[b, rows, h * dh:(h + 1) * dh], ref)
+        assert m["rel_l2"] <= 4e-3, m
+    # V = 1 -> every output element is the softmax row sum = 1 (bf16(1.0) exactly up to the final rounding)
+    qkv[:, :, 2 * D:] = 1.0
+    run(out)
+    assert float((out.float() - 1.0).abs().max()) <= 2 ** -7
+
+
+def test_comoe_routing_full_size_properties(gpu):
+    from unigen_amd import ops
+    B, N, D, E = 4, 4096, 3072, 6
+    S = B * N
+    C = R.moe_capacity(S, E)
+    g = torch.Generator(device=gpu).manual_seed(2)
+    x, c = _randn(gpu, g, S, D), _randn(gpu, g, S, D)
+    wg = _randn(gpu, g, E, D, scale=0.05)
+    wg[2] *= 3.0                                            # overload one expert so that RTS drops tokens
+    uni = torch.rand(S, E, generator=g, device=gpu)
+    gates = torch.empty(S, E, device=gpu, dtype=torch.float32); idx = torch.empty(S, device=gpu, dtype=torch.int32)
+    ops.moe_gate_top1(x, c, wg, gates, idx)
+    slot = torch.empty(S, device=gpu, dtype=torch.int32); tos = torch.empty(E, C, device=gpu, dtype=torch.int32)
+    cnt = torch.empty(E, device=gpu, dtype=torch.int64); l_aux = torch.empty(1, device=gpu, dtype=torch.float32)
+    ops.moe_capacity_rts(gates, idx, uni, C, slot, tos, cnt, l_aux)
+    idx_c, slot_c, tos_c, cnt_c = idx.cpu().long(), slot.cpu().long(), tos.cpu().long(), cnt.cpu()
+    assert torch.allclose(gates.sum(1).cpu(), torch.ones(S), atol=1e-5) and int(cnt_c.sum()) == S
+    assert torch.equal(cnt_c, torch.bincount(idx_c, minlength=E))
+    kept = slot_c >= 0
+    assert int(cnt_c.max()) > C, "test needs an overloaded expert"
+    for e in range(E):
+        mine = idx_c == e
+        n_keep = int((kept & mine).sum())
+        assert n_keep == min(int(cnt_c[e]), C)
+        s_e = slot_c[kept & mine]
+        assert torch.equal(torch.sort(s_e)[0], torch.arange(n_keep)) and torch.equal(s_e, torch.arange(n_keep))      # slots = rank in token order
+        assert torch.equal(tos_c[e, :n_keep], torch.nonzero(kept & mine).flatten()) and torch.all(tos_c[e, n_keep:] == -1)
+        if int(cnt_c[e]) > C:                                # the kept tokens are the capacity largest uniforms of this expert
+            u = uni[:, e].cpu()
+            assert u[kept & mine].min() >= u[mine & ~kept].max()
+    ref_gates = F.softmax(F.linear((x + c).float(), wg.float()), dim=1)
+    exp_laux = float((ref_gates.mean(0).cpu() * (cnt_c.float() / S)).sum() * E)
+    assert abs(float(l_aux) - exp_laux) <= 1e-4 * abs(exp_laux)
+    # dispatch -> combine round trip with unit modulation: kept tokens come back scaled by bf16(p), dropped tokens as 0
+    mod = torch.ones(E, B, D, device=gpu, dtype=BF)
+    xd = torch.empty(E, C, D, device=gpu, dtype=BF)
+    ops.moe_dispatch_modulate(x, None, mod, tos, xd, B=B, E=E, capacity=C, tokens_per_sample=N)
+    zeros = torch.zeros(E, C, D, device=gpu, dtype=BF)
+    back = torch.empty(S, D, device=gpu, dtype=BF)
+    ops.moe_combine(xd, zeros, gates, idx, slot, back, E=E, capacity=C)
+    p = gates.gather(1, idx.long()[:, None]).to(BF)
+    ref = torch.where(kept.to(gpu)[:, None], (p.float() * x.float()).to(BF), torch.zeros_like(x))
+    assert torch.equal(back, ref)
