@@ -95,6 +95,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--small", action="store_true", help="debug: reduced depth (NOT the headline configuration)")
+    ap.add_argument("--graph", action="store_true", help="capture one step (the 4-step denoise loop) in a HIP graph and replay it (SURVEY 8(f) rank 1)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -145,7 +146,21 @@ def main():
 
     for _ in range(args.warmup):
         out = one_step()
-    timer = None if args.no_kernel_timer else ops.KernelTimer()
+    graph = None
+    if args.graph:
+        # every workspace exists after the warm-up; capture on a side stream as torch requires, then replay on it
+        if args.warmup < 1:
+            raise SystemExit("--graph needs at least one warm-up step (lazy workspace allocation)")
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            graph_out = one_step()
+        eager_step = one_step
+
+        def one_step():                     # noqa: F811
+            graph.replay()
+            return graph_out
+    timer = None if (args.no_kernel_timer or args.graph) else ops.KernelTimer()
     barrier()
     ops.set_timer(timer)
     t0 = time.perf_counter()
@@ -171,7 +186,7 @@ def main():
                                           "random-init weights" + (" [--small DEBUG depth]" if args.small else "")),
                                 per_gpu_batch=B, global_batch=B * world, parallelism=f"dp{world} (independent samples, RCCL barrier only)",
                                 step="one 4-step denoise loop of the per-GPU batch"),
-                    flops_per_image_canonical=fl_img, e2e_mfma_frac=value / world * fl_img / (MFMA_BF16_PEAK_TFLOPS * 1e12))
+                    hip_graph=bool(args.graph), flops_per_image_canonical=fl_img, e2e_mfma_frac=value / world * fl_img / (MFMA_BF16_PEAK_TFLOPS * 1e12))
         if timer is not None:
             s = timer.summary()
             gm, at = s.get("gemm"), s.get("attn")

@@ -128,3 +128,29 @@ def test_denoise_loop_matches_oracle_and_golden(gpu):
                gate_uniforms=[inp["gate_uniform"].to(gpu)] * 2)
     m = report("golden_flux_tiny_single_denoise2", res.images, g["out.denoise2.bf16"])
     assert m["rel_l2"] <= 2e-2, m
+
+
+def test_denoise_step_is_hip_graph_capturable(gpu):
+    """the whole denoise loop (C-ABI launches on torch's stream, no host copies, no allocation after warm-up)
+    captures into one HIP graph; the replay is bitwise identical to the eager run."""
+    from unigen_amd.pipeline import denoise_loop, prepare_latent_image_ids
+    model, state, rcfg = _build(gpu, "UniGenFlux", 1)
+    inp = {k: _to_dev(v, gpu) for k, v in R.make_inputs(rcfg, B=2, grid=8, T=32).items()}
+    ids, txt = prepare_latent_image_ids(8, 8, gpu, BF), torch.zeros(32, 3, device=gpu, dtype=BF)
+    lat0 = inp["hidden_states"].clone()
+
+    def step():
+        return denoise_loop(model, latents=lat0.clone(), control_tokens=inp["condition_hidden_states"], prompt_embeds=inp["encoder_hidden_states"],
+                            pooled_prompt_embeds=inp["pooled_projections"], condition_pooled_prompt_embeds=inp["condition_pooled_projections"],
+                            text_ids=txt, latent_image_ids=ids, condition_ids=ids, num_inference_steps=2, gate_uniforms=[inp["gate_uniform"]] * 2)
+    eager = step().clone()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = step()
+    out.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, eager)
+    g.replay(); torch.cuda.synchronize()
+    assert torch.equal(out, eager)

@@ -80,8 +80,8 @@ def denoise_loop(transformer, *, latents: torch.Tensor, control_tokens, prompt_e
         guidance = torch.full([B], guidance_scale, device=latents.device, dtype=torch.float32)
     latents = latents.contiguous()
     for i in range(num_inference_steps):
-        t = torch.tensor(sig[i] * 1000.0, dtype=torch.float32)
-        timestep = t.expand(B).to(latents.dtype).to(latents.device)
+        # `t.expand(B).to(latents.dtype)`: built on the device (a fill kernel, no host copy -> the loop is HIP-graph capturable)
+        timestep = torch.full((B,), sig[i] * 1000.0, dtype=torch.float32, device=latents.device).to(latents.dtype)
         uni = None if gate_uniforms is None else gate_uniforms[i]
         noise_pred = transformer(hidden_states=latents, condition_hidden_states=control_tokens, conditioning_scale=conditioning_scale,
                                  encoder_hidden_states=prompt_embeds, pooled_projections=pooled_prompt_embeds,
