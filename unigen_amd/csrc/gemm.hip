@@ -52,11 +52,13 @@ __device__ __forceinline__ TileCoord tile_of_block(int bid, int nM, int nN) {
 }
 
 __device__ __forceinline__ float gelu_tanh(float x) {
-    // 0.5 x (1 + tanh( sqrt(2/pi) (x + 0.044715 x^3) ));  tanh(u) = 1 - 2 / (1 + exp(2u))
-    const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
-    const float e = __expf(2.0f * u);
-    const float t = 1.0f - 2.0f / (1.0f + e);
-    return 0.5f * x * (1.0f + t);
+    // 0.5 x (1 + tanh(u)), u = sqrt(2/pi) (x + 0.044715 x^3)  ==  x / (1 + exp(-2u)): 3 multiplies/FMAs, v_exp_f32, add, v_rcp_f32, multiply
+    // (the textbook form with an IEEE division is ~24 VALU instructions per element; the epilogue is VALU-bound). No cancellation
+    // for x << 0, exp -> inf gives rcp -> 0 -> -0.
+    constexpr float C0 = -2.3022081986f;            // -2 sqrt(2/pi) log2(e)
+    constexpr float C1 = C0 * 0.044715f;
+    const float u = x * fmaf(x * x, C1, C0);
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u));
 }
 
 __device__ __forceinline__ void load_bias4(const bf16_t* bias, int64_t n, float* bv) {
@@ -173,6 +175,60 @@ __device__ __forceinline__ void epi_store_pair16(const ug_gemm_desc& p, const Ro
         u32x4 o; o.x = x0; o.y = x1; o.z = y0; o.w = y1;
         *(u32x4*)((bf16_t*)p.C + rc.coff + col) = o;
     }
+}
+
+// Branch-free variant of epi_store_pair16 for FULL tiles: the residual chunk `r` (this lane's 16 bytes of R, store layout) was loaded
+// by the caller a row-group ahead, bias / gate / alpha arrive as floats in the accumulator layout, and the result comes back in the
+// store layout. With no exec-masked blocks and no loads of its own the compiler keeps the row-group loop one basic block with counted
+// vmcnt waits (the masked version put `s_waitcnt vmcnt(0)` after every bias / gate / residual load, draining the next tile's DMA
+// prefetch and every earlier store each time: 7 / 17 / 27 us per tile-round for BIAS / GELU / RES_GATE, now ~3 / 6 / 9).
+// Residual loads of the full-tile epilogue as inline asm: hipcc's waitcnt pass then neither sees them nor waits for them - it put
+// `vmcnt(0)` where `vmcnt(4)` is exact, which also drains the previous row-group's stores - and ug_wait_vm<N> states the wait (loads,
+// stores and LDS-DMA retire in issue order on the VM counter). The "memory" clobbers keep the C stores on their side of each load.
+__device__ __forceinline__ u32x4 gload16_asm(const void* ptr) {
+    u32x4 r;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r) : "v"(ptr) : "memory");
+    return r;
+}
+__device__ __forceinline__ u32x4 gload16_asm_256(const void* ptr) {
+    u32x4 r;
+    asm volatile("global_load_dwordx4 %0, %1, off offset:256" : "=v"(r) : "v"(ptr) : "memory");
+    return r;
+}
+template <int N>
+__device__ __forceinline__ void ug_wait_vm(u32x4& a, u32x4& b) {
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory");
+}
+
+template <int EPI>
+__device__ __forceinline__ u32x4 epi_chunk_full(const float alpha, const f32x4 ax, const f32x4 ay, const float* bx, const float* by,
+                                                const float* gx, const float* gy, const u32x4 r) {
+    float vx[4], vy[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { vx[q] = ax[q] + bx[q]; vy[q] = ay[q] + by[q]; }
+    if constexpr (EPI != UG_EPI_BIAS) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { vx[q] = rbf(vx[q]); vy[q] = rbf(vy[q]); }      // the Linear's bf16 output
+    }
+    if constexpr (EPI == UG_EPI_BIAS_GELU) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { vx[q] = gelu_tanh(vx[q]); vy[q] = gelu_tanh(vy[q]); }
+    } else if constexpr (EPI == UG_EPI_RES_GATE || EPI == UG_EPI_RES_SCALE) {
+        unsigned c0 = r.x, c1 = r.y, c2 = r.z, c3 = r.w;
+        swap16(c0, c2); swap16(c1, c3);                               // back to the accumulator layout: (c0, c1) = X, (c2, c3) = Y
+        const float rx[4] = {bflo(c0), bfhi(c0), bflo(c1), bfhi(c1)};
+        const float ry[4] = {bflo(c2), bfhi(c2), bflo(c3), bfhi(c3)};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float sx = EPI == UG_EPI_RES_GATE ? gx[q] : alpha, sy = EPI == UG_EPI_RES_GATE ? gy[q] : alpha;
+            vx[q] = rx[q] + rbf(sx * vx[q]); vy[q] = ry[q] + rbf(sy * vy[q]);
+        }
+    }
+    unsigned x0 = pack2bf(vx[0], vx[1]), x1 = pack2bf(vx[2], vx[3]);
+    unsigned y0 = pack2bf(vy[0], vy[1]), y1 = pack2bf(vy[2], vy[3]);
+    swap16(x0, y0); swap16(x1, y1);
+    u32x4 o; o.x = x0; o.y = x1; o.z = y0; o.w = y1;
+    return o;
 }
 
 template <int EPI>
@@ -324,16 +380,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
     const int64_t M = p.M, N = p.N;
     const int nM = (int)((M + 255) / 256), nN = (int)((N + 255) / 256);
     const int st_off = wave * 16 * 128;
-    const int frow = lane & 15, fch = lane >> 4, fsw = lane & 7;
-    const int a_off = (wr * 64 + frow) * 128, b_off = (wc * 32 + frow) * 128;
-    const int ch0 = ((fch ^ fsw) << 4), ch1 = (((4 + fch) ^ fsw) << 4);
+    int a_off, b_off, ch0, ch1;          // fragment read offsets; set per tile (see the tile loop)
     const int nk = (int)(p.K / BK);
 
     struct TileSrc { const bf16_t* a[2][2]; const bf16_t* b[2][2]; int64_t m0, n0; int g; int nk; int rem; int slice; };
     // work item w -> tile and K range. Items >= full_tiles are K-slices of remainder tile `rem`; a tile's slices share blockIdx & 7
     // (= one XCD under round-robin placement; speed only).
     const int n_items = full_tiles + (((total_tiles - full_tiles) + 7) / 8) * 8 * nslices;
-    auto tile_src = [&](int w) {
+    auto tile_src = [&](int w, int lane) {
         TileSrc t;
         int tile = w, kb = 0;
         t.nk = nk; t.rem = -1; t.slice = 0;
@@ -404,11 +458,20 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
 
     int tile = blockIdx.x;
     if (tile >= n_items) return;
-    TileSrc cur = tile_src(tile);
+    TileSrc cur = tile_src(tile, lane);
     if (cur.nk > 0) stage_first(cur);
     for (; tile < n_items; tile += gridDim.x) {
         const int nk = cur.nk;             // K-tiles of THIS work item (shadows the full count)
         if (nk == 0) break;                // padding item (only ever the last one of a workgroup)
+        {   // Lane-derived constants of the K loop, re-derived per tile from an opaque copy of the lane id so that they are not live
+            // through the epilogue (kept live across the whole tile loop, hipcc spilled a_off / b_off and reloaded them - with a
+            // vmcnt(0) that drains the DMA ring - in every K-tile).
+            int lane_m = lane;
+            asm volatile("" : "+v"(lane_m));
+            const int frow = lane_m & 15, fch = lane_m >> 4, fsw = lane_m & 7;
+            a_off = (wr * 64 + frow) * 128; b_off = (wc * 32 + frow) * 128;
+            ch0 = ((fch ^ fsw) << 4); ch1 = (((4 + fch) ^ fsw) << 4);
+        }
         f32x4 acc[2][2][4][2];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -464,10 +527,49 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
         const int64_t m0 = cur.m0, n0 = cur.n0;
         const int g = cur.g;
         const int rem = cur.rem, slice = cur.slice;
-        if (tile + (int)gridDim.x < n_items) {
-            cur = tile_src(tile + gridDim.x);
-            if (cur.nk > 0) stage_first(cur);
-        } else cur.nk = 0;
+        // Everything lane-dependent below is re-derived from an opaque copy of the lane id: hoisted out of the tile loop those
+        // values stayed live across the main loop and were spilled around it (scratch traffic + a vmcnt(0) ahead of the K loop).
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));
+        const int tid_e = wave * 64 + lane_e;
+        // Full tiles take the branch-free epilogue: this lane_e's bias (and, when all 256 rows belong to one sample, gate) columns are
+        // fetched NOW, with nothing else on the VM counter, and waited for under the next tile's address arithmetic - before its DMA
+        // prefetch is issued, so no later wait in the epilogue has to drain that prefetch.
+        constexpr bool RES = EPI == UG_EPI_RES_GATE || EPI == UG_EPI_RES_SCALE;
+        bool fast = EPI != UG_EPI_F32 && wide16 && m0 + 256 <= M && n0 + 256 <= N;
+        unsigned sample = 0;
+        if constexpr (EPI == UG_EPI_RES_GATE) {
+            sample = (unsigned)m0 / (unsigned)p.rows_per_sample;
+            fast = fast && ((unsigned)m0 + 255u) / (unsigned)p.rows_per_sample == sample;
+        }
+        float fb[2][2][4] = {}, fg[2][2][4] = {};      // defined on every path: an undef phi became loop-carried and was spilled around the K loop
+        if (fast) {
+            const bf16_t* bias = p.bias ? (const bf16_t*)p.bias + (int64_t)g * p.bias_gstride : nullptr;
+            const bf16_t* gate = nullptr;
+            if constexpr (EPI == UG_EPI_RES_GATE) gate = (const bf16_t*)p.gate + (int64_t)g * p.gate_gstride + (int64_t)sample * p.gate_ld;
+            u32x2 pb[2][2], pg[2][2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const int64_t n = n0 + j * 128 + wc * 32 + nt * 16 + (lane_e >> 4) * 4;
+                    pb[j][nt] = (u32x2){0u, 0u}; pg[j][nt] = (u32x2){0u, 0u};
+                    if (bias) pb[j][nt] = *(const u32x2*)(bias + n);
+                    if constexpr (EPI == UG_EPI_RES_GATE) pg[j][nt] = *(const u32x2*)(gate + n);
+                }
+            if (tile + (int)gridDim.x < n_items) cur = tile_src(tile + gridDim.x, lane_e); else cur.nk = 0;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    fb[j][nt][0] = bflo(pb[j][nt].x); fb[j][nt][1] = bfhi(pb[j][nt].x); fb[j][nt][2] = bflo(pb[j][nt].y); fb[j][nt][3] = bfhi(pb[j][nt].y);
+                    fg[j][nt][0] = bflo(pg[j][nt].x); fg[j][nt][1] = bfhi(pg[j][nt].x); fg[j][nt][2] = bflo(pg[j][nt].y); fg[j][nt][3] = bfhi(pg[j][nt].y);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            if (tile + (int)gridDim.x < n_items) cur = tile_src(tile + gridDim.x, lane_e); else cur.nk = 0;
+        }
+        if (cur.nk > 0) stage_first(cur);
         if (rem >= 0) {
             // ---- split-K tail: slab out, ticket, last arriver reduces (cdna guide section 5, "in-launch split-K reduction") ----
             float* my = slabs + ((size_t)rem * nslices + slice) * 65536;
@@ -479,11 +581,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
                     for (int a = 0; a < 4; ++a)
 #pragma unroll
                         for (int b = 0; b < 2; ++b)
-                            *(f32x4*)(my + ((((i * 2 + j) * 4 + a) * 2 + b) * 512 + tid) * 4) = acc[i][j][a][b];
+                            *(f32x4*)(my + ((((i * 2 + j) * 4 + a) * 2 + b) * 512 + tid_e) * 4) = acc[i][j][a][b];
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // every storing wave
             __syncthreads();
             unsigned* flag = (unsigned*)(smem + LDS256_BYTES);
-            if (tid == 0) {
+            if (tid_e == 0) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // keep: hipcc may drop the fence's own wait
                 *flag = __hip_atomic_fetch_add(tickets + rem, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -492,7 +594,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
             const bool last = *flag == (unsigned)(nslices - 1);
             __syncthreads();                                              // flag is re-used by a later item
             if (!last) continue;
-            if (tid == 0) {
+            if (tid_e == 0) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __hip_atomic_store(tickets + rem, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // all arrivals are in: ready for the next launch
@@ -516,8 +618,47 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
                         for (int a = 0; a < 4; ++a)
 #pragma unroll
                             for (int b = 0; b < 2; ++b)
-                                acc[i][j][a][b] += *(const f32x4*)(sp + ((((i * 2 + j) * 4 + a) * 2 + b) * 512 + tid) * 4);
+                                acc[i][j][a][b] += *(const f32x4*)(sp + ((((i * 2 + j) * 4 + a) * 2 + b) * 512 + tid_e) * 4);
             }
+        }
+        if (fast) {
+            // 8 row-groups of 16 rows x 2 column halves; the residual chunks of row-group rg+1 are loaded before row-group rg is
+            // computed and stored (older than those stores on the in-order VM counter, so waiting for them does not wait for stores).
+            const int lg = lane_e >> 4;
+            const int colb = (int)n0 + wc * 32 + (lg & 1) * 16 + 8 * (lg >> 1);
+            bf16_t* const Cb = (bf16_t*)p.C + (int64_t)g * p.c_gstride + colb;
+            const bf16_t* const Rb = RES ? (const bf16_t*)p.R + (int64_t)g * p.r_gstride + colb : nullptr;
+            const unsigned mrow = (unsigned)m0 + wr * 64 + (lane_e & 15);
+            u32x4 rbuf[2][2];
+            bf16_t* cp[2];
+            auto open_rows = [&](int rg) {
+                const unsigned m = mrow + (rg >> 2) * 128 + (rg & 3) * 16;
+                cp[rg & 1] = Cb + (int64_t)rowmap32(m, (unsigned)p.c_rpb, (unsigned)p.c_bstride) * p.ldc;
+                if constexpr (RES) {
+                    const bf16_t* rp = Rb + (int64_t)rowmap32(m, (unsigned)p.r_rpb, (unsigned)p.r_bstride) * p.ldr;
+                    rbuf[rg & 1][0] = gload16_asm(rp);
+                    rbuf[rg & 1][1] = gload16_asm_256(rp);
+                } else {
+                    rbuf[rg & 1][0] = rbuf[rg & 1][1] = (u32x4){0u, 0u, 0u, 0u};
+                }
+            };
+            open_rows(0);
+#pragma unroll
+            for (int rg = 0; rg < 8; ++rg) {
+                if (rg + 1 < 8) open_rows(rg + 1);
+                if constexpr (RES) {
+                    // younger than this row-group's two loads: the next row-group's two loads and the previous one's two stores
+                    if (rg == 0 || rg == 7) ug_wait_vm<2>(rbuf[rg & 1][0], rbuf[rg & 1][1]);
+                    else ug_wait_vm<4>(rbuf[rg & 1][0], rbuf[rg & 1][1]);
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const u32x4 o = epi_chunk_full<EPI>(p.alpha, acc[rg >> 2][j][rg & 3][0], acc[rg >> 2][j][rg & 3][1], fb[j][0], fb[j][1],
+                                                        fg[j][0], fg[j][1], rbuf[rg & 1][j]);
+                    __builtin_nontemporal_store(o, (u32x4*)(cp[rg & 1] + j * 128));
+                }
+            }
+            continue;
         }
         const bf16_t* bias = p.bias ? (const bf16_t*)p.bias + (int64_t)g * p.bias_gstride : nullptr;
         float bv[2][2][4];
@@ -525,7 +666,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
-                const int64_t n = n0 + j * 128 + wc * 32 + nt * 16 + (lane >> 4) * 4;
+                const int64_t n = n0 + j * 128 + wc * 32 + nt * 16 + (lane_e >> 4) * 4;
                 load_bias4(n < N ? bias : nullptr, n, bv[j][nt]);
             }
         if (EPI != UG_EPI_F32 && wide16) {
@@ -533,26 +674,26 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) {
-                    const int64_t m = m0 + i * 128 + wr * 64 + mt * 16 + (lane & 15);
+                    const int64_t m = m0 + i * 128 + wr * 64 + mt * 16 + (lane_e & 15);
                     const bool row_ok = m < M;                         // lanes l and l^16 share the row: the swaps stay paired
                     const RowCtx rc = row_ctx<EPI>(p, g, (unsigned)(row_ok ? m : M - 1));
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
-                        epi_store_pair16<EPI>(p, rc, row_ok, n0 + j * 128 + wc * 32, N, lane, acc[i][j][mt][0], acc[i][j][mt][1], bv[j][0], bv[j][1]);
+                        epi_store_pair16<EPI>(p, rc, row_ok, n0 + j * 128 + wc * 32, N, lane_e, acc[i][j][mt][0], acc[i][j][mt][1], bv[j][0], bv[j][1]);
                 }
         } else {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) {
-                    const int64_t m = m0 + i * 128 + wr * 64 + mt * 16 + (lane & 15);
+                    const int64_t m = m0 + i * 128 + wr * 64 + mt * 16 + (lane_e & 15);
                     if (m >= M) continue;
                     const RowCtx rc = row_ctx<EPI>(p, g, (unsigned)m);
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
 #pragma unroll
                         for (int nt = 0; nt < 2; ++nt) {
-                            const int64_t n = n0 + j * 128 + wc * 32 + nt * 16 + (lane >> 4) * 4;
+                            const int64_t n = n0 + j * 128 + wc * 32 + nt * 16 + (lane_e >> 4) * 4;
                             if (n < N) epi_store<EPI>(p, rc, n, acc[i][j][mt][nt], bv[j][nt]);
                         }
                 }
