@@ -14,6 +14,7 @@
 // predicating stores; K must be a multiple of 64.
 #include "ug_common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -429,6 +430,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
         stage(smem + SLOT_A0, t.a[0], 0); stage(smem + SLOT_B0, t.b[0], 0);
         stage(smem + SLOT_B1, t.b[1], 0); stage(smem + SLOT_A1, t.a[1], 0);
         if (t.nk > 1) { stage(smem + KT_BYTES + SLOT_A0, t.a[0], BK); stage(smem + KT_BYTES + SLOT_B0, t.b[0], BK); }
+        if (t.nk >= 3) { stage(smem + KT_BYTES + SLOT_B1, t.b[1], BK); stage(smem + KT_BYTES + SLOT_A1, t.a[1], BK); }   // the whole ring
     };
     bf16x8 areg[4][2], breg[2][2], breg0[2][2];    // breg0: B0 fragments, kept from phase 0 to phase 3
     auto read_A = [&](const unsigned char* slot) {
@@ -458,6 +460,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
 
     int tile = blockIdx.x;
     if (tile >= n_items) return;
+    bool stores_in_flight = false;      // the previous tile ended in the full-tile epilogue: exactly 16 C stores per wave behind the prefetch
     TileSrc cur = tile_src(tile, lane);
     if (cur.nk > 0) stage_first(cur);
     for (; tile < n_items; tile += gridDim.x) {
@@ -486,25 +489,42 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
         // its last ds_read is >= 3 segments old (B0's fragments stay in registers for phase 3, so its slot frees after phase 0):
         //   phase 0 stages B1(kt+1) | phase 1: A1(kt+1) | phase 2: A0(kt+2) | phase 3: B0(kt+2)
         // -> every half-tile has 5-6 phases (~1.3 K-tiles) of lead; vmcnt(8) keeps the four youngest half-tiles in flight.
-        if (nk > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // A0(0), B0(0)
+        // Stores of the previous tile's epilogue (16 per wave after the full-tile epilogue) may still be in flight; on the in-order
+        // VM counter they sit BETWEEN the DMAs prefetched ahead of that epilogue and the ones issued below. Waits that only cover
+        // prefetched DMAs allow for them (+16), so the store drain (~3 us when every CU bursts its 128 KB at once) overlaps the
+        // first K-tiles instead of preceding them. `pre` = the whole ring (K-tiles 0 and 1, 16 DMAs) was prefetched (nk >= 3):
+        // nothing is staged in phases 0 / 1 of K-tile 0 and the first wait that covers a post-store DMA is phase 3 of K-tile 1
+        // (~1.9 K-tiles of slack); otherwise (12 DMAs ahead) it is phase 0 of K-tile 1. The selection is a scalar branch per wait:
+        // peeling the K loop instead made hipcc spill inside it.
+#define UG_WAIT_VM(N, RELAXED)                                                                  \
+    do {                                                                                        \
+        if (RELAXED) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((N) + 16) : "memory");            \
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");                           \
+    } while (0)
+        const bool pre = nk >= 3, sif = stores_in_flight;
+        if (pre) UG_WAIT_VM(12, sif); else if (nk > 1) UG_WAIT_VM(8, sif); else UG_WAIT_VM(4, sif);      // A0(0), B0(0) landed
         UG_BARRIER();
         if (wr == 1) UG_BARRIER();          // waves 4-7 run one barrier behind
         for (int kt = 0; kt < nk; ++kt) {
             unsigned char* cb = smem + (kt & 1) * KT_BYTES;
             unsigned char* nb = smem + ((kt & 1) ^ 1) * KT_BYTES;
             const bool n1 = kt + 1 < nk, n2 = kt + 2 < nk;
+            const bool pre0 = pre && kt == 0;
+            const bool x01 = sif && (kt == 0 || (pre && kt == 1)), x3 = sif && kt == 0;
             const int64_t k1 = (int64_t)(kt + 1) * BK, k2 = (int64_t)(kt + 2) * BK;
             // phase 0: quadrant (0,0)
             read_A(cb + SLOT_A0); read_B(breg0, cb + SLOT_B0);
-            if (n1) { stage(nb + SLOT_B1, cur.b[1], k1); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }   // B1(kt) landed
-            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            if (pre0) UG_WAIT_VM(10, x01);
+            else if (n1) { stage(nb + SLOT_B1, cur.b[1], k1); UG_WAIT_VM(8, x01); }   // B1(kt) landed
+            else UG_WAIT_VM(2, x01);
             UG_BARRIER();
             UG_MMA_QUADRANT(0, 0, breg0);
             UG_BARRIER();
             // phase 1: quadrant (0,1)
             read_B(breg, cb + SLOT_B1);
-            if (n1) { stage(nb + SLOT_A1, cur.a[1], k1); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }   // A1(kt) landed
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (pre0) UG_WAIT_VM(8, x01);
+            else if (n1) { stage(nb + SLOT_A1, cur.a[1], k1); UG_WAIT_VM(8, x01); }   // A1(kt) landed
+            else UG_WAIT_VM(0, x01);
             UG_BARRIER();
             UG_MMA_QUADRANT(0, 1, breg);
             UG_BARRIER();
@@ -515,18 +535,20 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
             UG_MMA_QUADRANT(1, 1, breg);
             UG_BARRIER();
             // phase 3: quadrant (1,0), B0 from registers
-            if (n2) { stage(cb + SLOT_B0, cur.b[0], k2); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }    // A0, B0(kt+1) landed
-            else if (n1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            if (n2) { stage(cb + SLOT_B0, cur.b[0], k2); UG_WAIT_VM(8, x3); }    // A0, B0(kt+1) landed
+            else if (n1) UG_WAIT_VM(4, x3);
             UG_BARRIER();
             UG_MMA_QUADRANT(1, 0, breg0);
             UG_BARRIER();
         }
+#undef UG_WAIT_VM
         if (wr == 0) UG_BARRIER();          // both groups level again; every LDS read of this tile has retired
 
         // next tile: addresses + first K-tile DMA, then this tile's epilogue runs under it
         const int64_t m0 = cur.m0, n0 = cur.n0;
         const int g = cur.g;
         const int rem = cur.rem, slice = cur.slice;
+        stores_in_flight = false;
         // Everything lane-dependent below is re-derived from an opaque copy of the lane id: hoisted out of the tile loop those
         // values stayed live across the main loop and were spilled around it (scratch traffic + a vmcnt(0) ahead of the K loop).
         int lane_e = lane;
@@ -536,7 +558,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
         // fetched NOW, with nothing else on the VM counter, and waited for under the next tile's address arithmetic - before its DMA
         // prefetch is issued, so no later wait in the epilogue has to drain that prefetch.
         constexpr bool RES = EPI == UG_EPI_RES_GATE || EPI == UG_EPI_RES_SCALE;
-        bool fast = EPI != UG_EPI_F32 && wide16 && m0 + 256 <= M && n0 + 256 <= N;
+        bool fast = EPI != UG_EPI_F32 && wide16 && m0 + 256 <= M && n0 + 256 <= N && rem < 0;
         unsigned sample = 0;
         if constexpr (EPI == UG_EPI_RES_GATE) {
             sample = (unsigned)m0 / (unsigned)p.rows_per_sample;
@@ -642,6 +664,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
                     rbuf[rg & 1][0] = rbuf[rg & 1][1] = (u32x4){0u, 0u, 0u, 0u};
                 }
             };
+            stores_in_flight = true;
             open_rows(0);
 #pragma unroll
             for (int rg = 0; rg < 8; ++rg) {
