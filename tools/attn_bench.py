@@ -7,10 +7,11 @@ from unigen_amd import ops
 dev = torch.device("cuda:0")
 H, dh = 24, 128
 D = H * dh
-SHAPES = [(4, 4608, 4608, "base joint/single"), (4, 4096, 4608, "control joint (img q)"), (4, 8192, 8192, "shared0"), (4, 8192, 8704, "shared1"),
+SHAPES = [tuple(int(x) for x in a.split(",")) + ("cli",) for a in sys.argv[1:]] or [(4, 4608, 4608, "base joint/single"), (4, 4096, 4608, "control joint (img q)"), (4, 8192, 8192, "shared0"), (4, 8192, 8704, "shared1"),
           (16, 2048, 2048, "2k ref shape")]
 g = torch.Generator(device=dev).manual_seed(0)
 for B, Lq, Lkv, label in SHAPES:
+    assert Lq <= Lkv, "q rows are the last Lq rows of the packed qkv buffer"
     qkv = torch.randn(B, Lkv, 3 * D, generator=g, device=dev).to(torch.bfloat16)
     out = torch.empty(B, Lq, D, device=dev, dtype=torch.bfloat16)
     st = (3 * D, Lkv * 3 * D)
