@@ -489,6 +489,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
         // its last ds_read is >= 3 segments old (B0's fragments stay in registers for phase 3, so its slot frees after phase 0):
         //   phase 0 stages B1(kt+1) | phase 1: A1(kt+1) | phase 2: A0(kt+2) | phase 3: B0(kt+2)
         // -> every half-tile has 5-6 phases (~1.3 K-tiles) of lead; vmcnt(8) keeps the four youngest half-tiles in flight.
+        // (Measured and dropped: 2 segments of 32 MFMAs per K-tile and wave group with all DMA issued by waves 4-7 - 4 barriers per
+        // K-tile instead of 8 - ran 5-8 % slower on the full chip and equal on 16 CUs: the hand-offs are not where the loop loses time,
+        // and the coarser slot lifetimes cut the DMA lead from ~1.3 to 1.0 K-tiles.)
         // Stores of the previous tile's epilogue (16 per wave after the full-tile epilogue) may still be in flight; on the in-order
         // VM counter they sit BETWEEN the DMAs prefetched ahead of that epilogue and the ones issued below. Waits that only cover
         // prefetched DMAs allow for them (+16), so the store drain (~3 us when every CU bursts its 128 KB at once) overlaps the
