@@ -409,3 +409,41 @@ def test_gemm_splitk_tail(gpu, M, N, K, epi):
     ref = _epi_ref(acc, b, epi, res, gate, 256, 1.0)[:M]
     m = report(f"gemm_splitk_{epi}_{M}x{N}x{K}", outs[0], ref)
     assert m["rel_l2"] <= TOL, m
+
+
+_PWG_SNIPPET = r"""
+import sys, torch, torch.nn.functional as F
+sys.path.insert(0, {root!r})
+from unigen_amd import ops
+gpu, BF = torch.device("cuda:0"), torch.bfloat16
+def run(B, H, Lq, Lkv, spike):
+    dh = 128; D = H * dh
+    g = torch.Generator().manual_seed(Lq + 7 * Lkv)
+    qkv = (torch.randn(B, Lkv, 3 * D, generator=g) * (0.5 if spike else 1.0)).to(BF)
+    if spike:
+        qkv[0, 200, D:D + dh] = qkv[0, Lkv - Lq + 17, :dh] * 8.0     # tile 3: far past the lazy-rescale threshold
+        qkv[0, Lkv - 5, D:D + dh] = qkv[0, Lkv - Lq + min(99, Lq - 1), :dh] * 12.0
+    d = qkv.to(gpu)
+    out = torch.zeros(B, Lq, D, device=gpu, dtype=BF)
+    st = (3 * D, Lkv * 3 * D)
+    ops.flash_attn(d[0, Lkv - Lq:], d[0, 0, D:], d[0, 0, 2 * D:], out, batches=B, heads=H, dh=dh, Lq=Lq, Lkv=Lkv, q_strides=st, k_strides=st, v_strides=st, o_strides=(D, Lq * D))
+    q = qkv[:, Lkv - Lq:, :D].view(B, Lq, H, dh).transpose(1, 2).float()
+    k = qkv[:, :, D:2 * D].view(B, Lkv, H, dh).transpose(1, 2).float()
+    v = qkv[:, :, 2 * D:].view(B, Lkv, H, dh).transpose(1, 2).float()
+    ref = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B, Lq, D)
+    rel = ((out.float().cpu() - ref).norm() / ref.norm()).item()
+    print("pwg", B, H, Lq, Lkv, spike, rel)
+    return rel
+worst = max(run(1, 2, 256, 256, False), run(2, 3, 300, 333, False), run(1, 2, 512, 1024, True), run(1, 1, 64, 64, False), run(1, 2, 70, 700, True))
+sys.exit(0 if worst <= 4e-3 else 1)
+"""
+
+
+def test_flash_attn_one_wave_per_simd_variant(gpu):
+    """UG_ATTN_PWG=1 selects flash_attn_pwg_kernel (4 waves x 64 rows, 512 registers, software-pipelined in the wave). The switch is read once
+    per process, so the variant runs in a child: ragged Lq / Lkv, one tile, and keys that force the lazy rescale in a late tile."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, UG_ATTN_PWG="1")
+    r = subprocess.run([sys.executable, "-c", _PWG_SNIPPET.format(root=root)], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr

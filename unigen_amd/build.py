@@ -11,6 +11,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libunigen_hip.so")
 SOURCES = ["core.hip", "gemm.hip", "attention.hip", "elementwise.hip", "moe.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+# attention: scores are finite or -inf, never NaN; without IEEE mode hipcc drops the NaN-quieting v_max x,x it adds per fmaxf operand
+EXTRA = {"attention.hip": ["-fno-honor-nans", "-mno-amdgpu-ieee"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-ffp-contract=off"]
 
 
@@ -30,7 +32,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         o = os.path.join(CSRC, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            jobs.append([HIPCC, *FLAGS, "-c", s, "-o", o])
+            jobs.append([HIPCC, *FLAGS, *EXTRA.get(src, []), "-c", s, "-o", o])
 
     def run(cmd):
         if verbose:

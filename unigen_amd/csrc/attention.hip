@@ -47,6 +47,18 @@ __device__ __forceinline__ bf16x8 tr_read_pair(const unsigned char* lo, const un
     return (bf16x8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
 }
 
+// max of three; without IEEE mode hipcc does not add a NaN-quieting self-max per operand (the scores are finite or -inf here)
+__device__ __forceinline__ float ug_max3(float a, float b, float c) {
+    return __builtin_fmaxf(__builtin_fmaxf(a, b), c);     // v_max3_f32 (attention.hip is built with -fno-honor-nans -mno-amdgpu-ieee)
+}
+// max over the two 32-lane halves (lane l and l ^ 32), in every lane: one v_permlane32_swap (VALU) instead of the ds_bpermute +
+// lgkmcnt(0) that __shfl_xor compiles to (which also waits for every LDS read in flight)
+__device__ __forceinline__ float ug_max_halves(float x) {
+    const unsigned u = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return ug_max3(__uint_as_float(r[0]), __uint_as_float(r[1]), x);
+}
+
 // STAGGER (8 waves): waves 0-3 and 4-7 - the two waves of every SIMD - run half a tile apart: in each segment one group does
 // S^T + softmax of a tile while the other does P.V of the previous one, so a wave's softmax VALU work runs under its partner's
 // MFMAs instead of both waves hitting the matrix pipe, then the VALU, together. Two barriers per tile; K(t+1) is written at the
@@ -231,9 +243,13 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn_kernel(
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int i = 0; i < 16; ++i) tmax = fmaxf(tmax, sacc[kb][i]);
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        const float m_new = fmaxf(m_run, tmax);
-        if (!__all(m_new == m_run)) {
+        tmax = ug_max_halves(tmax);
+        // Lazy reference point: a row's running max moves only when the tile maximum exceeds it by more than 2^8 in the exponent
+        // (softmax is shift-invariant; P and l stay below 2^8 per element: exact in fp32, same relative precision in bf16). With the
+        // exact max some row of the wave moves in most tiles and the 64-register rescale below ran nearly every iteration.
+        const bool up = (tmax - m_run) * c > 8.0f;
+        const float m_new = up ? tmax : m_run;
+        if (!__all(!up)) {
             const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
             l_run *= alpha;
 #pragma unroll
@@ -381,6 +397,369 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn_kernel(
     }
 }
 
+
+// =====================================================================================================================
+// One wave per SIMD ("pwg"): 4 waves x 64 query rows, up to 512 registers per lane, software-pipelined inside the wave.
+//
+// The 8-wave loop above keeps the matrix pipe ~42 % busy: its two waves per SIMD reach the MFMA segments and the softmax
+// segments together. Here a single in-order wave per SIMD overlaps the two itself:
+//     iteration t:   S1 = [ online softmax of S(t) (VALU)  interleaved with  O^T += V^T P^T of tile t-1 (32 MFMAs) ]
+//                    S2 = [ S^T(t+1) = K Q^T (32 MFMAs) ]
+// Per 64-key tile a wave issues 64 MFMAs for 64 query rows (every K / V fragment read from LDS feeds two MFMAs - half the LDS
+// traffic per FLOP of the 32-row waves) against ~260 VALU instructions placed in the MFMA gaps of S1.
+// LDS: 2 K slots + 2 V slots (64 KB), one barrier per tile: iteration t writes K(t+2) and V(t) (fetched to registers one
+// iteration earlier) into the slots whose last readers finished before the barrier at its top, and fetches K(t+3), V(t+1).
+// =====================================================================================================================
+template <int DH>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void flash_attn_pwg_kernel(
+    const bf16_t* __restrict__ q, int64_t q_rs, int64_t q_bs, const bf16_t* __restrict__ k, int64_t k_rs, int64_t k_bs,
+    const bf16_t* __restrict__ v, int64_t v_rs, int64_t v_bs, bf16_t* __restrict__ o, int64_t o_rs, int64_t o_bs,
+    int heads, int Lq, int Lkv, int nQ, float c /* softmax_scale * log2(e) */) {
+    constexpr int RB = 2 * DH, NCH = DH / 8, TILE = KVB * RB, QS = DH / 16, NDB = DH / 32;
+    constexpr int NT = 256, NST = (KVB * NCH) / NT;
+    static_assert(NST >= 1, "tile smaller than the workgroup");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // K slot 0 | K slot 1 | V slot 0 | V slot 1
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+
+    const int nwg = gridDim.x;
+    const int qd = nwg >> 3, rm = nwg & 7;
+    const int xcd = blockIdx.x & 7, kk = blockIdx.x >> 3;
+    const int logical = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + kk;
+    const int qt = logical % nQ;
+    const int bh = logical / nQ;
+    const int head = bh % heads, b = bh / heads;
+    const bf16_t* Qb = q + (int64_t)b * q_bs + head * DH;
+    const bf16_t* Kb = k + (int64_t)b * k_bs + head * DH;
+    const bf16_t* Vb = v + (int64_t)b * v_bs + head * DH;
+
+    // ---- Q fragments of the wave's two 32-row blocks (B operand of S^T = K Q^T): lane (r, h) holds Q[r][16 s + 8 h + j]. They are parked
+    // in AGPRs (hipcc does not feed MFMA B operands from AGPRs) and copied to VGPRs one k-step ahead of their MFMAs, 8 v_accvgpr_read per
+    // step in the MFMA shadow. Re-reading them from LDS instead doubled the QK^T segment's LDS traffic to ~75 % of the LDS array. ----
+    bf16x8 qf[2][QS];
+    int q_row[2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        q_row[qb] = qt * 256 + wave * 64 + qb * 32 + r;
+        const int q_ld = q_row[qb] < Lq ? q_row[qb] : Lq - 1;
+#pragma unroll
+        for (int s = 0; s < QS; ++s) qf[qb][s] = *(const bf16x8*)(Qb + (int64_t)q_ld * q_rs + 16 * s + 8 * h);
+    }
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)      // retire the loads here (see the 8-wave kernel) and pin the class
+#pragma unroll
+        for (int s = 0; s < QS; ++s) asm volatile("" : "+a"(qf[qb][s]));
+    // ---- staging: thread -> NST chunks of K and of V per tile ----
+    int st_off[NST], st_row[NST], st_col[NST];
+#pragma unroll
+    for (int u = 0; u < NST; ++u) {
+        const int cid = tid + NT * u;
+        st_row[u] = cid / NCH;
+        st_col[u] = (cid % NCH) * 8;
+        st_off[u] = img_off<DH>(st_row[u], cid % NCH);
+    }
+    u32x4 kreg[NST], vreg[NST];
+    auto fetch_k = [&](int kv0) {
+#pragma unroll
+        for (int u = 0; u < NST; ++u) { int key = kv0 + st_row[u]; if (key > Lkv - 1) key = Lkv - 1; kreg[u] = *(const u32x4*)(Kb + (int64_t)key * k_rs + st_col[u]); }
+    };
+    auto fetch_v = [&](int kv0) {
+#pragma unroll
+        for (int u = 0; u < NST; ++u) { int key = kv0 + st_row[u]; if (key > Lkv - 1) key = Lkv - 1; vreg[u] = *(const u32x4*)(Vb + (int64_t)key * v_rs + st_col[u]); }
+    };
+    auto write_k = [&](int slot) {
+#pragma unroll
+        for (int u = 0; u < NST; ++u) *(u32x4*)(smem + slot * TILE + st_off[u]) = kreg[u];
+    };
+    auto write_v = [&](int slot) {
+#pragma unroll
+        for (int u = 0; u < NST; ++u) *(u32x4*)(smem + (2 + slot) * TILE + st_off[u]) = vreg[u];
+    };
+
+    // ---- per-lane LDS read offsets (same images as the 8-wave kernel). Every swizzled offset is BASE ^ constant: the XOR only touches
+    // bits 4-7, which the row term (multiple of 256) and the 8-byte term leave free. The segments re-derive their 8-16 addresses from
+    // an opaque copy of the base (one v_xor each) - kept as loop invariants, hipcc held ~40 address registers and spilled them. ----
+    static_assert(DH == 128, "XOR-folded offsets assume 256-byte rows");
+    const int kx = h ^ row_swz<DH>(r);
+    const int k_base = RB * r + 16 * kx;                                   // K fragment s, key block kb: kb * 32 * RB + (k_base ^ 32 s)
+    const int i16 = lane & 15, g16 = lane >> 4;
+    const int v_key = 4 * h + (i16 >> 2);
+    const int v_lowch = 2 * (g16 & 1) + ((i16 & 3) >> 1);
+    const int v_b8 = 8 * (i16 & 1);
+    const int vlo_base = RB * v_key + 16 * (v_lowch ^ row_swz<DH>(v_key)) + v_b8;          // d-block db, k-step ks: ks * 16 * RB + (base ^ 64 db)
+    const int vhi_base = RB * (v_key + 8) + 16 * (v_lowch ^ row_swz<DH>(v_key + 8)) + v_b8;
+
+    f32x16 oacc[2][NDB];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) oacc[qb][db][i] = 0.f;
+    // Register classes are pinned through empty asm operands: O^T accumulators, Q fragments and the staging registers are touched
+    // only by MFMA / memory instructions and live in AGPRs; S^T and P^T are read and written by VALU and stay in VGPRs. Left to
+    // itself hipcc accumulated S^T in AGPRs and moved ~500 registers per tile through v_accvgpr_read / _write.
+    auto pin_o = [&]() {
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+            for (int db = 0; db < NDB; ++db) asm("" : "+a"(oacc[qb][db]));
+    };
+    pin_o();
+    f32x16 sacc[2][2];                                   // [query block][key block] of the tile between its QK^T and its softmax
+    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f}, alpha[2] = {1.f, 1.f};
+    bf16x8 pf[2][2][2][2];                               // P^T fragments [tile parity][query block][key block][half]
+    const int ntiles = (Lkv + KVB - 1) / KVB;
+
+    // The segments below are written as explicit instruction streams: sched_barrier(0) after every piece keeps hipcc from
+    // re-clumping them (left to the scheduler - with or without sched_group_barrier - the softmax VALU work ended up in runs of 60-70
+    // instructions between MFMAs, and a lone wave per SIMD has nobody to cover a stalled pipe). Measured with s_memtime stamps: a
+    // segment that is VALU-bound costs its VALU cycles + ~16 per MFMA, one that is MFMA-bound 32 per MFMA. Hence three segments:
+    //   A: P.V(t-1), 32 MFMAs  | row maxima of both query blocks, then the 32 exp elements of query block 0
+    //   B: S^T(t+1) of query block 0, 16 MFMAs into the S registers block 0 just released | the 32 exp elements of query block 1
+    //   C: S^T(t+1) of query block 1, 16 MFMAs | the staging pieces (8 LDS writes, 8 global loads)
+#define UG_FENCE() __builtin_amdgcn_sched_barrier(0)
+    float mc[2], lsum[2];
+    // one exp element of the lane: query block qb = e / 32, key block (e / 16) % 2; packs a finished group of 8 into pf[PP]
+    auto sm_elems = [&](int e0, int e1, auto pp_c, float (&p)[2][32]) __attribute__((always_inline)) {
+        constexpr int PP = decltype(pp_c)::value;
+#pragma unroll
+        for (int e = e0; e < e1; ++e) {
+            const int qb = e >> 5, kb = (e >> 4) & 1, x = e & 15;
+            const float pe = __builtin_amdgcn_exp2f(fmaf(sacc[qb][kb][x], c, -mc[qb]));
+            p[qb][e & 31] = pe;
+            lsum[qb] += pe;
+            if ((e & 7) == 7) {
+                const int g = e >> 3, s2 = g & 1;
+                const float* pg = &p[qb][(g & 3) * 8];
+                u32x4 w;
+                w.x = pack2bf(pg[0], pg[1]); w.y = pack2bf(pg[2], pg[3]); w.z = pack2bf(pg[4], pg[5]); w.w = pack2bf(pg[6], pg[7]);
+                pf[PP][qb][kb][s2] = __builtin_bit_cast(bf16x8, w);
+            }
+            if ((e & 31) == 31) l_run[qb] = l_run[qb] * alpha[qb] + lsum[qb];
+        }
+    };
+    float pbuf[2][32];
+    // Segment A. Returns whether any lane's reference point moved (then O is rescaled by alpha after this segment).
+    auto do_A = [&](auto slot_c, auto pp_c, auto pv_c) __attribute__((always_inline)) -> int {
+        constexpr int SLOT = decltype(slot_c)::value, PP = decltype(pp_c)::value;
+        constexpr bool HAVE_PV = decltype(pv_c)::value;
+        const unsigned char* Vbuf = smem + (2 + SLOT) * TILE;
+        int vl0 = vlo_base, vh0 = vhi_base;
+        asm volatile("" : "+v"(vl0), "+v"(vh0));
+        // P.V order: k-step outer, then d-block, then query block: the 8 accumulators rotate
+        bf16x8 vf[4][NDB];
+        auto rdv = [&](int ks) {
+#pragma unroll
+            for (int db = 0; db < NDB; ++db)
+                vf[ks][db] = tr_read_pair(Vbuf + ks * 16 * RB + (vl0 ^ (64 * db)), Vbuf + ks * 16 * RB + (vh0 ^ (64 * db)));
+        };
+        if constexpr (HAVE_PV) { rdv(0); UG_FENCE(); }
+        int moved = 0;
+        float tmax[2];
+        lsum[0] = 0.f; lsum[1] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            if constexpr (HAVE_PV) {
+                const int ks = i >> 3, db = (i >> 1) & 3, qb = i & 1;
+                oacc[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[ks][db], pf[PP ^ 1][qb][ks >> 1][ks & 1], oacc[qb][db], 0, 0, 0);
+                UG_FENCE();
+                if ((i & 7) == 1 && ks + 1 < 4) { rdv(ks + 1); UG_FENCE(); }
+            }
+            if (i < 8) {
+                // maxima: piece i covers 8 of the 32 values of query block i / 4
+                const int qb = i >> 2, part = i & 3, kb = part >> 1, o8 = 8 * (part & 1);
+                const f32x16& sv = sacc[qb][kb];
+                float m8 = ug_max3(sv[o8], sv[o8 + 1], sv[o8 + 2]);
+                m8 = ug_max3(m8, sv[o8 + 3], sv[o8 + 4]);
+                m8 = ug_max3(m8, sv[o8 + 5], sv[o8 + 6]);
+                tmax[qb] = part == 0 ? ug_max3(m8, sv[o8 + 7], sv[o8 + 7]) : ug_max3(tmax[qb], m8, sv[o8 + 7]);
+                if (part == 3) {
+                    // Lazy running max: the reference point of a row moves only when the tile maximum exceeds it by more than 2^8 in
+                    // the exponent (softmax is shift-invariant; P and l then stay below 2^8 per element, exact in fp32 / same relative
+                    // precision in bf16). With an exact max some row of the 64 moves in nearly every tile and the O^T rescale - a
+                    // round trip of 128 accumulators through VGPRs, ~2500 cycles - ran every iteration.
+                    const float tm = ug_max_halves(tmax[qb]);
+                    const bool up = (tm - m_run[qb]) * c > 8.0f;
+                    const float m_new = up ? tm : m_run[qb];
+                    moved |= !__all(!up);
+                    alpha[qb] = __builtin_amdgcn_exp2f((m_run[qb] - m_new) * c);     // 1 where the point stayed, 0 on the first tile
+                    m_run[qb] = m_new;
+                    mc[qb] = m_new * c;
+                }
+            } else {
+                const int j = i - 8;                     // 24 pieces x 4/3 elements: query block 0
+                sm_elems((j * 4) / 3, ((j + 1) * 4) / 3, pp_c, pbuf);
+            }
+            UG_FENCE();
+        }
+        if constexpr (HAVE_PV) pin_o();
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) { asm volatile("" : "+v"(pf[PP][0][kb][0])); asm volatile("" : "+v"(pf[PP][0][kb][1])); }
+        return moved;
+    };
+    // S^T(t)[query block QB] = K Q^T from K slot SLOT (16 MFMAs, k-step outer, the 2 key-block accumulators alternate). These MFMAs are
+    // inline asm: S^T accumulates in VGPRs (where the softmax reads it) and the Q fragment comes straight from its AGPRs. As a builtin,
+    // hipcc accumulates in AGPRs in a 512-register kernel and copies Q to VGPRs: +128 v_accvgpr_read and 64 more live registers per
+    // tile. hipcc does not see an MFMA here, so the hazards are ours: operands come from ds_read / AGPRs (waitcnt is tracked through
+    // the asm operands) and the results are first read by VALU behind the s_nops that close segment C or behind the next barrier.
+    // FILL(ks) is called after the MFMAs of k-step ks: the VALU / memory work this segment shadows.
+    auto do_QK = [&](int t, auto slot_c, auto qb_c, auto&& fill) __attribute__((always_inline)) {
+        constexpr int SLOT = decltype(slot_c)::value, QB = decltype(qb_c)::value;
+        const unsigned char* Kbuf = smem + SLOT * TILE;
+        int kb0 = k_base;
+        asm volatile("" : "+v"(kb0));
+        constexpr int AHEAD = 3;
+        bf16x8 kf[QS][2];
+        auto rd = [&](int ks) {
+            kf[ks][0] = *(const bf16x8*)(Kbuf + (kb0 ^ (32 * ks)));
+            kf[ks][1] = *(const bf16x8*)(Kbuf + 32 * RB + (kb0 ^ (32 * ks)));
+        };
+#pragma unroll
+        for (int ks = 0; ks < AHEAD; ++ks) rd(ks);
+        UG_FENCE();
+#pragma unroll
+        for (int ks = 0; ks < QS; ++ks) {
+            if (ks + AHEAD < QS) rd(ks + AHEAD);
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                if (ks == 0) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(sacc[QB][kb]) : "v"(kf[ks][kb]), "a"(qf[QB][ks]));
+                else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(sacc[QB][kb]) : "v"(kf[ks][kb]), "a"(qf[QB][ks]));
+            }
+            UG_FENCE();
+            fill(ks);
+            UG_FENCE();
+        }
+    };
+    auto mask_tail = [&](int t) __attribute__((always_inline)) {        // ragged last tile: keys >= Lkv do not exist
+        asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 7" ::: "memory");   // the last MFMAs' results (8 passes) before any VALU read
+        if (t * KVB + KVB > Lkv) {
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int key = t * KVB + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                        if (key >= Lkv) sacc[qb][kb][i] = -INFINITY;
+                    }
+        }
+    };
+    // one staging piece of segment C of iteration t_it (computing S^T(t_it + 1)): pieces 0-7 publish K(t_it+2) / V(t_it) into the
+    // slots of parity t_it & 1, pieces 8-15 fetch K(t_it+3) / V(t_it+1). Tiles past the end are clamped re-reads nobody consumes.
+    auto stage_piece = [&](int pc, int t_it, int wslot) __attribute__((always_inline)) {
+        constexpr int W = 2 * NST;
+        if (pc < NST) *(u32x4*)(smem + wslot * TILE + st_off[pc]) = kreg[pc];
+        else if (pc < W) *(u32x4*)(smem + (2 + wslot) * TILE + st_off[pc - NST]) = vreg[pc - NST];
+        else if (pc < 2 * W) {
+            const bool isk = pc < W + NST;
+            const int u = isk ? pc - W : pc - W - NST;
+            int tile = isk ? t_it + 3 : t_it + 1; if (tile > ntiles - 1) tile = ntiles - 1;              // wave-uniform
+            const int rmax = Lkv - 1 - tile * KVB;
+            const int row = st_row[u] < rmax ? st_row[u] : rmax;
+            if (isk) kreg[u] = *(const u32x4*)(Kb + (int64_t)tile * KVB * k_rs + (unsigned)(row * (int)k_rs + st_col[u]));
+            else vreg[u] = *(const u32x4*)(Vb + (int64_t)tile * KVB * v_rs + (unsigned)(row * (int)v_rs + st_col[u]));
+        }
+    };
+
+    // ---- prologue: K(0), K(1) in LDS, S(0) computed, K(2) and V(0) in registers ----
+    fetch_k(0);
+    write_k(0);
+    fetch_k(KVB);                                        // clamped re-read when there is a single tile
+    write_k(1);
+    __syncthreads();
+    auto nofill = [&](int) {};
+    do_QK(0, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, nofill);
+    do_QK(0, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, nofill);
+    mask_tail(0);
+    fetch_k(2 * KVB);
+    fetch_v(0);
+
+    auto rescale_o = [&]() __attribute__((always_inline)) {   // rare (a row's reference point moved): one accumulator at a time through VGPRs
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+            for (int db = 0; db < NDB; ++db) {
+                f32x16 x = oacc[qb][db];
+                asm volatile("" : "+v"(x));
+#pragma unroll
+                for (int i = 0; i < 16; ++i) x[i] *= alpha[qb];
+                asm volatile("" : "+a"(x));
+                oacc[qb][db] = x;
+            }
+    };
+    // Iteration t: barrier | A | (rescale) | B | C. C also publishes K(t+2) -> K slot t & 1 and V(t) -> V slot t & 1 (their last
+    // readers, QK(t) and P.V(t-2), finished before the barrier) and fetches K(t+3), V(t+1).
+    auto iter = [&](int t, auto par_c, auto pv_c) __attribute__((always_inline)) {
+        constexpr int PAR = decltype(par_c)::value;     // t & 1
+        using CUR = std::integral_constant<int, PAR>;
+        using OTH = std::integral_constant<int, PAR ^ 1>;
+        __syncthreads();
+        // S^T is "redefined" here so that its softmax cannot be hoisted above the barrier, away from the P.V MFMAs it must shadow
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) asm volatile("" : "+v"(sacc[qb][kb]));
+        const int moved = do_A(OTH{}, CUR{}, pv_c);
+        if (decltype(pv_c)::value && moved) rescale_o();
+        if (t + 1 < ntiles) {
+            // B: 2 exp elements of query block 1 per MFMA (hipcc hoists most of this pure chain up into segment A; pinning it here
+            // measured 3 % slower)
+            do_QK(t + 1, OTH{}, std::integral_constant<int, 0>{}, [&](int ks) __attribute__((always_inline)) { sm_elems(32 + 4 * ks, 36 + 4 * ks, CUR{}, pbuf); });
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) { asm volatile("" : "+v"(pf[PAR][1][kb][0])); asm volatile("" : "+v"(pf[PAR][1][kb][1])); }
+            // C: 2 staging pieces per k-step
+            do_QK(t + 1, OTH{}, std::integral_constant<int, 1>{}, [&](int ks) __attribute__((always_inline)) { stage_piece(2 * ks, t, PAR); stage_piece(2 * ks + 1, t, PAR); });
+            mask_tail(t + 1);
+        } else {
+            sm_elems(32, 64, CUR{}, pbuf);               // last tile: the rest of its softmax, and V(t) is still to be published
+            write_v(PAR);
+        }
+    };
+    iter(0, std::integral_constant<int, 0>{}, std::false_type{});       // no P.V yet (O is zero: nothing to rescale)
+    for (int t = 1; t < ntiles; t += 2) {
+        iter(t, std::integral_constant<int, 1>{}, std::true_type{});
+        if (t + 1 < ntiles) iter(t + 1, std::integral_constant<int, 0>{}, std::true_type{});
+    }
+#undef UG_FENCE
+    __syncthreads();                                     // V(ntiles-1) visible
+    auto tail_PV = [&](auto par_c) {                     // O^T += V^T P^T of the last tile
+        constexpr int PAR = decltype(par_c)::value;
+        const unsigned char* Vbuf = smem + (2 + PAR) * TILE;
+        int vl0 = vlo_base, vh0 = vhi_base;
+        asm volatile("" : "+v"(vl0), "+v"(vh0));
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 vfr = tr_read_pair(Vbuf + ks * 16 * RB + (vl0 ^ (64 * db)), Vbuf + ks * 16 * RB + (vh0 ^ (64 * db)));
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb)
+                    oacc[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr, pf[PAR][qb][ks >> 1][ks & 1], oacc[qb][db], 0, 0, 0);
+            }
+    };
+    if ((ntiles - 1) & 1) tail_PV(std::integral_constant<int, 1>{}); else tail_PV(std::integral_constant<int, 0>{});
+
+    // ---- epilogue: O[q][d] = O^T / l ----
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
+        const float inv = 1.0f / l_tot;
+        if (q_row[qb] < Lq) {
+            bf16_t* Orow = o + (int64_t)b * o_bs + (int64_t)q_row[qb] * o_rs + head * DH;
+#pragma unroll
+            for (int db = 0; db < NDB; ++db)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    u32x2 w;
+                    w.x = pack2bf(oacc[qb][db][4 * g4 + 0] * inv, oacc[qb][db][4 * g4 + 1] * inv);
+                    w.y = pack2bf(oacc[qb][db][4 * g4 + 2] * inv, oacc[qb][db][4 * g4 + 3] * inv);
+                    *(u32x2*)(Orow + 32 * db + 8 * g4 + 4 * h) = w;
+                }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int ug_flash_attn_fwd(const void* q, int64_t q_row_stride, int64_t q_batch_stride, const void* k,
@@ -407,6 +786,19 @@ extern "C" int ug_flash_attn_fwd(const void* q, int64_t q_row_stride, int64_t q_
     hipLaunchKernelGGL((flash_attn_kernel<DHV, NWV, STG>), dim3((unsigned)nwg), dim3(64 * NWV), 2 * 2 * KVB * 2 * DHV + (STG ? 32 * NWV * 2 * DHV : 0), (hipStream_t)stream, \
                        (const bf16_t*)q, q_row_stride, q_batch_stride, (const bf16_t*)k, k_row_stride, k_batch_stride, (const bf16_t*)v, \
                        v_row_stride, v_batch_stride, (bf16_t*)o, o_row_stride, o_batch_stride, (int)heads, (int)Lq, (int)Lkv, nQ, c)
+    static int pwg = -1;
+    if (pwg < 0) { const char* e = getenv("UG_ATTN_PWG"); pwg = e ? atoi(e) : 0; }
+    if (pwg && dh == 128) {
+        const int nQp = (int)((Lq + 255) / 256);
+        const int64_t nwgp = (int64_t)nQp * heads * batches;
+        static bool attr = false;
+        if (!attr) { (void)hipFuncSetAttribute((const void*)flash_attn_pwg_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * KVB * 2 * 128); attr = true; }
+        hipLaunchKernelGGL((flash_attn_pwg_kernel<128>), dim3((unsigned)nwgp), dim3(256), 4 * KVB * 2 * 128, (hipStream_t)stream,
+                           (const bf16_t*)q, q_row_stride, q_batch_stride, (const bf16_t*)k, k_row_stride, k_batch_stride, (const bf16_t*)v,
+                           v_row_stride, v_batch_stride, (bf16_t*)o, o_row_stride, o_batch_stride, (int)heads, (int)Lq, (int)Lkv, nQp, c);
+        UG_CHECK_LAUNCH("ug_flash_attn_fwd");
+        return UG_OK;
+    }
     static int stagger = -1;
     if (stagger < 0) { const char* e = getenv("UG_ATTN_STAGGER"); stagger = (e && atoi(e) == 1) ? 1 : 0; }   // X/Y stagger measured 602 vs 842 TFLOP/s at L = 4608, dh = 128 (a lone hipcc-scheduled MFMA stream does not keep the pipe busy) -> off
     if (dh == 128) { if (nw == 4) UG_ATTN_LAUNCH(128, 4, false); else if (stagger) UG_ATTN_LAUNCH(128, 8, true); else UG_ATTN_LAUNCH(128, 8, false); }
