@@ -416,8 +416,9 @@ import sys, torch, torch.nn.functional as F
 sys.path.insert(0, {root!r})
 from unigen_amd import ops
 gpu, BF = torch.device("cuda:0"), torch.bfloat16
+import os
 def run(B, H, Lq, Lkv, spike):
-    dh = 128; D = H * dh
+    dh = int(os.environ.get("UG_TEST_DH", "128")); D = H * dh
     g = torch.Generator().manual_seed(Lq + 7 * Lkv)
     qkv = (torch.randn(B, Lkv, 3 * D, generator=g) * (0.5 if spike else 1.0)).to(BF)
     if spike:
@@ -439,11 +440,14 @@ sys.exit(0 if worst <= 4e-3 else 1)
 """
 
 
-def test_flash_attn_one_wave_per_simd_variant(gpu):
-    """UG_ATTN_PWG=1 selects flash_attn_pwg_kernel (4 waves x 64 rows, 512 registers, software-pipelined in the wave). The switch is read once
-    per process, so the variant runs in a child: ragged Lq / Lkv, one tile, and keys that force the lazy rescale in a late tile."""
+@pytest.mark.parametrize("env", [{"UG_ATTN_PWG": "1"}, {"UG_ATTN_STAGGER": "0"}, {"UG_ATTN_STAGGER": "1", "UG_TEST_DH": "64"},
+                                 {"UG_ATTN_WAVES": "4"}],
+                         ids=["one-wave-per-simd", "lock-step-dh128", "stagger-dh64", "four-wave-workgroups"])
+def test_flash_attn_selectable_variants(gpu, env):
+    """The non-default attention kernels: UG_ATTN_PWG=1 (4 waves x 64 rows, 512 registers, software-pipelined in the wave), the lock-step
+    loop at dh = 128, the X|Y stagger at dh = 64 and the 4-wave workgroups. The switches are read once per process, so each variant runs
+    in a child: ragged Lq / Lkv, one tile, and keys that force the lazy rescale in a late tile."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, UG_ATTN_PWG="1")
-    r = subprocess.run([sys.executable, "-c", _PWG_SNIPPET.format(root=root)], env=env, capture_output=True, text=True, timeout=300)
+    r = subprocess.run([sys.executable, "-c", _PWG_SNIPPET.format(root=root)], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr

@@ -18,6 +18,7 @@
 namespace {
 
 constexpr int KVB = 64;      // keys per tile
+constexpr bool UG_STAGGER_Q_IN_LDS = false;   // stagger variant: Q fragments from LDS (32 fewer VGPRs) or registers (a third less LDS read traffic in QK^T)
 
 typedef __attribute__((address_space(3))) bf16x4* lds_b64_ptr;
 
@@ -98,10 +99,11 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn_kernel(
     // Lock-step variant: Q fragments stay in registers. X/Y stagger: they live in LDS (same swizzled row image as K, one
     // ds_read_b128 per k-step) because S^T must survive a barrier next to the P.V operands and 32 fewer VGPRs avoid spills.
     constexpr int QBASE = 2 * 2 * KVB * RB;            // byte offset of the Q image behind the two K|V buffers
-    bf16x8 qf[STAGGER ? 1 : QS];
+    constexpr bool QLDS = STAGGER && UG_STAGGER_Q_IN_LDS;
+    bf16x8 qf[QLDS ? 1 : QS];
     const int q_lds = QBASE + RB * (wave * 32 + r);
     const int qx = h ^ row_swz<DH>(r);                  // wave * 32 keeps row_swz unchanged (multiple of 16)
-    if constexpr (!STAGGER) {
+    if constexpr (!QLDS) {
 #pragma unroll
         for (int s = 0; s < QS; ++s) qf[s] = *(const bf16x8*)(Qb + (int64_t)q_ld * q_rs + 16 * s + 8 * h);
         // Retire the Q loads HERE: the empty asm takes every fragment as a read-write operand, so hipcc must have the loaded
@@ -209,7 +211,7 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn_kernel(
             bf16x8 ql[QS], kf0[QS], kf1[QS];
 #pragma unroll
             for (int s = 0; s < QS; ++s) {
-                ql[s] = *(const bf16x8*)(smem + q_lds + 16 * ((2 * s) ^ qx));
+                if constexpr (QLDS) ql[s] = *(const bf16x8*)(smem + q_lds + 16 * ((2 * s) ^ qx)); else ql[s] = qf[s];
                 kf0[s] = *(const bf16x8*)(Kbuf + k_rowoff + 16 * ((2 * s) ^ kx));
                 kf1[s] = *(const bf16x8*)(Kbuf + 32 * RB + k_rowoff + 16 * ((2 * s) ^ kx));
             }
@@ -301,6 +303,63 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn_kernel(
             __builtin_amdgcn_sched_group_barrier(0x008, 4, 1);            // last d-block
         }
     };
+    // X(t) of the stagger variant as an explicit stream (sched_barrier after every piece): P.V(t) - 16 MFMAs, k-step outer so the 4
+    // (8 at dh = 128... NDB) accumulators rotate - then S^T(t+1) = K Q^T - 16 MFMAs. Every LDS fragment is read two or three steps ahead
+    // of its MFMA and the first K / Q fragments of the second half are requested under the last P.V MFMAs: this wave is alone on the
+    // matrix pipe in this segment (its SIMD partner is in the VALU-only Y), so an exposed ds_read latency is an idle pipe. hipcc's
+    // own order (sched_group_barrier hints included) ran the segment at 70-90 cycles per MFMA.
+    auto qx_frag = [&](int s) -> bf16x8 { if constexpr (STAGGER && UG_STAGGER_Q_IN_LDS) return *(const bf16x8*)(smem + q_lds + 16 * ((2 * s) ^ qx)); else return qf[s]; };
+    auto do_X = [&](int t, auto cur_c, bool have_qk) __attribute__((always_inline)) {
+        constexpr int CUR = decltype(cur_c)::value;
+        const unsigned char* Vbuf = smem + CUR * 2 * TILE + TILE;
+        const unsigned char* Kbuf = smem + (CUR ^ 1) * 2 * TILE;
+        bf16x8 vf[4][NDB];
+        auto rdv = [&](int ks) {
+#pragma unroll
+            for (int db = 0; db < NDB; ++db) vf[ks][db] = tr_read_pair(Vbuf + ks * 16 * RB + voff_lo[db], Vbuf + ks * 16 * RB + voff_hi[db]);
+        };
+        bf16x8 kf0[QS], kf1[QS];
+        auto rdk = [&](int s) {
+            kf0[s] = *(const bf16x8*)(Kbuf + k_rowoff + 16 * ((2 * s) ^ kx));
+            kf1[s] = *(const bf16x8*)(Kbuf + 32 * RB + k_rowoff + 16 * ((2 * s) ^ kx));
+        };
+        rdv(0); rdv(1);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);                   // the matrix stream outranks the partner wave's softmax VALU at issue
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+            for (int db = 0; db < NDB; ++db)
+                oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[ks][db], pf[ks >> 1][ks & 1], oacc[db], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks + 2 < 4) rdv(ks + 2);
+            else if (have_qk) { rdk(2 * (ks - 2)); rdk(2 * (ks - 2) + 1); }      // k-steps 0-3 of the second half
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (!have_qk) { __builtin_amdgcn_s_setprio(0); return; }
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sacc[kb][i] = 0.f;
+#pragma unroll
+        for (int s = 0; s < QS; ++s) {
+            sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0[s], qx_frag(s), sacc[0], 0, 0, 0);
+            sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1[s], qx_frag(s), sacc[1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (s + 4 < QS) { rdk(s + 4); __builtin_amdgcn_sched_barrier(0); }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        const int kv0 = (t + 1) * KVB;
+        if (kv0 + KVB > Lkv) {   // ragged last tile: keys >= Lkv do not exist
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int key = kv0 + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    if (key >= Lkv) sacc[kb][i] = -INFINITY;
+                }
+        }
+    };
     if constexpr (!STAGGER) {
         stage_load(0);
         stage_write(0);
@@ -335,18 +394,43 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn_kernel(
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
         };
-        auto fetch = [&](int kt, int vt) {              // K(kt), V(vt) -> registers (tiles beyond the end: nothing)
+        // K(kt), V(vt) -> registers -> LDS. Branch-free on purpose: tiles past the end are clamped re-reads published into buffers whose
+        // last readers are done. With a per-load `if (tile < ntiles)` every global_load sat in its own basic block behind an
+        // `s_waitcnt vmcnt(0)`: the four loads of a fetch ran one after the other at full memory latency (~4400 cycles per fetch
+        // segment, found with s_memtime stamps) - that, not the segment structure, is why this variant first measured 602 TFLOP/s.
+        // Addresses: a wave-uniform tile base (SALU) + a per-thread 32-bit element offset computed once - a fetch is then 2 NST loads and
+        // no VALU (with `key * stride` in 64 bits per load, a fetch cost the matrix segment ~700 cycles before its first MFMA). The
+        // ragged last tile and tiles past the end take the clamped path.
+        unsigned koff[NST], voff[NST];
 #pragma unroll
-            for (int u = 0; u < NST; ++u) {
-                if (kt < ntiles) { int key = kt * KVB + st_row[u]; if (key > Lkv - 1) key = Lkv - 1; kreg[u] = *(const u32x4*)(Kb + (int64_t)key * k_rs + st_ch[u] * 8); }
-                if (vt < ntiles) { int key = vt * KVB + st_row[u]; if (key > Lkv - 1) key = Lkv - 1; vreg[u] = *(const u32x4*)(Vb + (int64_t)key * v_rs + st_ch[u] * 8); }
+        for (int u = 0; u < NST; ++u) {
+            koff[u] = (unsigned)(st_row[u] * (int)k_rs + st_ch[u] * 8);
+            voff[u] = (unsigned)(st_row[u] * (int)v_rs + st_ch[u] * 8);
+        }
+        auto fetch = [&](int kt, int vt) {
+            if (kt * KVB + KVB <= Lkv && vt * KVB + KVB <= Lkv) {       // wave-uniform: both tiles whole
+                const bf16_t* kbase = Kb + (int64_t)kt * KVB * k_rs;
+                const bf16_t* vbase = Vb + (int64_t)vt * KVB * v_rs;
+#pragma unroll
+                for (int u = 0; u < NST; ++u) {
+                    kreg[u] = *(const u32x4*)(kbase + koff[u]);
+                    vreg[u] = *(const u32x4*)(vbase + voff[u]);
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < NST; ++u) {
+                    int key = kt * KVB + st_row[u]; if (key > Lkv - 1) key = Lkv - 1;
+                    kreg[u] = *(const u32x4*)(Kb + (int64_t)key * k_rs + st_ch[u] * 8);
+                    key = vt * KVB + st_row[u]; if (key > Lkv - 1) key = Lkv - 1;
+                    vreg[u] = *(const u32x4*)(Vb + (int64_t)key * v_rs + st_ch[u] * 8);
+                }
             }
         };
         auto publish = [&](int kt, int vt) {
 #pragma unroll
             for (int u = 0; u < NST; ++u) {
-                if (kt < ntiles) *(u32x4*)(smem + (kt & 1) * 2 * TILE + st_off[u]) = kreg[u];
-                if (vt < ntiles) *(u32x4*)(smem + (vt & 1) * 2 * TILE + TILE + st_off[u]) = vreg[u];
+                *(u32x4*)(smem + (kt & 1) * 2 * TILE + st_off[u]) = kreg[u];
+                *(u32x4*)(smem + (vt & 1) * 2 * TILE + TILE + st_off[u]) = vreg[u];
             }
         };
         const bool groupA = __builtin_amdgcn_readfirstlane(wave) < 4;
@@ -364,12 +448,16 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn_kernel(
             // Y(t): A in odd segment 2t+1 (publishes K(t+1), V(t) at its end) | B in even segment 2t+2 (fetches K(t+2), V(t+1) at its start)
             if (!groupA) fetch(t + 2, t + 1);
             do_SM();
+            // P^T is "used" here: hipcc otherwise sinks the (pure) scale / exp2 / pack chain across the barrier to its first use, the
+            // P.V MFMAs - i.e. out of this VALU-only segment into the matrix-only one, which then ran at ~60 cycles per MFMA
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) { asm volatile("" : "+v"(pf[kb][0])); asm volatile("" : "+v"(pf[kb][1])); }
+            asm volatile("" : "+v"(l_run), "+v"(m_run));
             if (groupA) publish(t + 1, t);
             seg_barrier();
             // X(t) = P.V(t) then K.Q^T(t+1): A in even segment 2t+2 (fetch) | B in odd segment 2t+3 (publish)
             if (groupA) fetch(t + 2, t + 1);
-            do_P(t, cur_c);
-            if (t + 1 < ntiles) do_QK(t + 1, std::integral_constant<int, CUR ^ 1>{});
+            do_X(t, cur_c, t + 1 < ntiles);
             if (!groupA) publish(t + 2, t + 1);
             seg_barrier();
         };
@@ -800,9 +888,13 @@ extern "C" int ug_flash_attn_fwd(const void* q, int64_t q_row_stride, int64_t q_
         return UG_OK;
     }
     static int stagger = -1;
-    if (stagger < 0) { const char* e = getenv("UG_ATTN_STAGGER"); stagger = (e && atoi(e) == 1) ? 1 : 0; }   // X/Y stagger measured 602 vs 842 TFLOP/s at L = 4608, dh = 128 (a lone hipcc-scheduled MFMA stream does not keep the pipe busy) -> off
-    if (dh == 128) { if (nw == 4) UG_ATTN_LAUNCH(128, 4, false); else if (stagger) UG_ATTN_LAUNCH(128, 8, true); else UG_ATTN_LAUNCH(128, 8, false); }
-    else           { if (nw == 4) UG_ATTN_LAUNCH(64, 4, false); else if (stagger) UG_ATTN_LAUNCH(64, 8, true); else UG_ATTN_LAUNCH(64, 8, false); }
+    // UG_ATTN_STAGGER: 1 / 0 force the X|Y stagger / the lock-step loop; unset: stagger at dh = 128. Same-box A/B at dh = 128 after the
+    // branch-free fetch and the softmax pin (before them the stagger variant measured 602 vs 842): 989 vs 955 TFLOP/s at L = 4608,
+    // 1027 vs 1007 (4096 x 4608), 1068 vs 1044 (8192), 956 vs 933 (B16, 2048).
+    if (stagger < 0) { const char* e = getenv("UG_ATTN_STAGGER"); stagger = e ? (atoi(e) == 1 ? 1 : 0) : 2; }
+    const bool stg = stagger == 1 || (stagger == 2 && dh == 128);
+    if (dh == 128) { if (nw == 4) UG_ATTN_LAUNCH(128, 4, false); else if (stg) UG_ATTN_LAUNCH(128, 8, true); else UG_ATTN_LAUNCH(128, 8, false); }
+    else           { if (nw == 4) UG_ATTN_LAUNCH(64, 4, false); else if (stg) UG_ATTN_LAUNCH(64, 8, true); else UG_ATTN_LAUNCH(64, 8, false); }
 #undef UG_ATTN_LAUNCH
     UG_CHECK_LAUNCH("ug_flash_attn_fwd");
     return UG_OK;
