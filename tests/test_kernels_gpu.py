@@ -440,12 +440,12 @@ sys.exit(0 if worst <= 4e-3 else 1)
 """
 
 
-@pytest.mark.parametrize("env", [{"UG_ATTN_PWG": "1"}, {"UG_ATTN_STAGGER": "0"}, {"UG_ATTN_STAGGER": "1", "UG_TEST_DH": "64"},
+@pytest.mark.parametrize("env", [{"UG_ATTN_PWG": "1"}, {"UG_ATTN_STAGGER": "0"}, {"UG_ATTN_STAGGER": "0", "UG_TEST_DH": "64"},
                                  {"UG_ATTN_WAVES": "4"}],
-                         ids=["one-wave-per-simd", "lock-step-dh128", "stagger-dh64", "four-wave-workgroups"])
+                         ids=["one-wave-per-simd", "lock-step-dh128", "lock-step-dh64", "four-wave-workgroups"])
 def test_flash_attn_selectable_variants(gpu, env):
     """The non-default attention kernels: UG_ATTN_PWG=1 (4 waves x 64 rows, 512 registers, software-pipelined in the wave), the lock-step
-    loop at dh = 128, the X|Y stagger at dh = 64 and the 4-wave workgroups. The switches are read once per process, so each variant runs
+    loop at both head dims and the 4-wave workgroups (the default is the X|Y stagger). The switches are read once per process, so each variant runs
     in a child: ragged Lq / Lkv, one tile, and keys that force the lazy rescale in a late tile."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

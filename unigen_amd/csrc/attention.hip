@@ -888,11 +888,11 @@ extern "C" int ug_flash_attn_fwd(const void* q, int64_t q_row_stride, int64_t q_
         return UG_OK;
     }
     static int stagger = -1;
-    // UG_ATTN_STAGGER: 1 / 0 force the X|Y stagger / the lock-step loop; unset: stagger at dh = 128. Same-box A/B at dh = 128 after the
-    // branch-free fetch and the softmax pin (before them the stagger variant measured 602 vs 842): 989 vs 955 TFLOP/s at L = 4608,
-    // 1027 vs 1007 (4096 x 4608), 1068 vs 1044 (8192), 956 vs 933 (B16, 2048).
-    if (stagger < 0) { const char* e = getenv("UG_ATTN_STAGGER"); stagger = e ? (atoi(e) == 1 ? 1 : 0) : 2; }
-    const bool stg = stagger == 1 || (stagger == 2 && dh == 128);
+    // UG_ATTN_STAGGER=0 selects the lock-step loop; default: the X|Y stagger. Same-box A/B after the branch-free fetch and the softmax pin
+    // (before them the stagger variant measured 602 vs 842): dh = 128: 989 vs 955 TFLOP/s at L = 4608, 1027 vs 1007 (4096 x 4608),
+    // 1068 vs 1044 (8192), 956 vs 933 (B16, 2048); dh = 64 inside the SD3.5 forward: 795 vs 775.
+    if (stagger < 0) { const char* e = getenv("UG_ATTN_STAGGER"); stagger = (e && atoi(e) == 0) ? 0 : 1; }
+    const bool stg = stagger == 1;
     if (dh == 128) { if (nw == 4) UG_ATTN_LAUNCH(128, 4, false); else if (stg) UG_ATTN_LAUNCH(128, 8, true); else UG_ATTN_LAUNCH(128, 8, false); }
     else           { if (nw == 4) UG_ATTN_LAUNCH(64, 4, false); else if (stg) UG_ATTN_LAUNCH(64, 8, true); else UG_ATTN_LAUNCH(64, 8, false); }
 #undef UG_ATTN_LAUNCH
