@@ -46,6 +46,33 @@ def canonical_flops_per_forward(D, N, T, n_double, n_single, n_cj, n_cs, n_cond,
     return base + ctrl + zero + comoe + embeds
 
 
+def fixture_parity(device):
+    """SURVEY 8(d) `parity`: the HIP forward on the committed golden fixture (tests/golden/flux_tiny_single.safetensors: inputs and the
+    oracle's bf16 / fp32 outputs) with the fixture's seeded weights. The oracle is only the checker here: it re-creates the weights."""
+    import importlib, json as _json
+    from safetensors import safe_open
+    from oracle import unigen_ref as R
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "flux_tiny_single.safetensors")
+    with safe_open(path, "pt") as f:
+        meta = f.metadata()
+        g = {k: f.get_tensor(k) for k in f.keys()}
+    cfg_d, case = _json.loads(meta["config"]), _json.loads(meta["case"])
+    rcfg = R.FluxConfig(condition_nums=case["n_cond"], **cfg_d)
+    state = R.make_state(rcfg, seed=case["state_seed"], std=0.05, bias_std=0.02)
+    model = importlib.import_module("src.UniGenTransformer").UniGenFlux.from_config(cfg_d, device=device, dtype=torch.bfloat16)
+    model.init_condition_block(condition_nums=1, condition_types=["canny"], control_params=dict(
+        use_rope=True, use_shared_expert=True, use_single_trans_blocks=True, single_control_dev=2, single_block_control_method="overall_add",
+        top_num=1, expert_num_each_condition=3))
+    model.load_state_dict({k: v.to(device) for k, v in state.items()}, strict=False)
+    inp = {k[3:]: v.to(device) for k, v in g.items() if k.startswith("in.")}
+    with torch.no_grad():
+        out = model(timestep=g["timestep"].to(device), **inp)[0].float().cpu()
+    rel = lambda a, b: float((a - b.float()).norm() / b.float().norm())
+    return dict(fixture="tests/golden/flux_tiny_single.safetensors", rel_l2_vs_oracle_bf16=rel(out, g["out.bf16"]),
+                max_abs_vs_oracle_bf16=float((out - g["out.bf16"].float()).abs().max()), rel_l2_vs_oracle_fp32=rel(out, g["out.fp32"]),
+                oracle_bf16_vs_fp32=rel(g["out.bf16"].float(), g["out.fp32"]))
+
+
 def cpu_baseline(max_threads: int = 16):
     """Time the CPU oracle (port of the reference) on a bounded, reduced slice of the same workload (rank 0, N=1 only).
     The GPU box grants one GPU's share of the host (16 cores), so at most 16 threads are used whatever the affinity mask says."""
@@ -211,6 +238,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
             line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
+            line["parity"] = fixture_parity(dev)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
