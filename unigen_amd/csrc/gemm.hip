@@ -489,6 +489,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
         // its last ds_read is >= 3 segments old (B0's fragments stay in registers for phase 3, so its slot frees after phase 0):
         //   phase 0 stages B1(kt+1) | phase 1: A1(kt+1) | phase 2: A0(kt+2) | phase 3: B0(kt+2)
         // -> every half-tile has 5-6 phases (~1.3 K-tiles) of lead; vmcnt(8) keeps the four youngest half-tiles in flight.
+        // (Measured and dropped: signalling the hand-off barrier 2-4 MFMAs before the end of a segment, so that the other group is
+        // released while this one still has MFMAs queued: -9 % - the two groups' MFMAs then share the pipe, matrix beside matrix.)
         // (Measured and dropped: 2 segments of 32 MFMAs per K-tile and wave group with all DMA issued by waves 4-7 - 4 barriers per
         // K-tile instead of 8 - ran 5-8 % slower on the full chip and equal on 16 CUs: the hand-offs are not where the loop loses time,
         // and the coarser slot lifetimes cut the DMA lead from ~1.3 to 1.0 K-tiles.)
