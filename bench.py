@@ -218,16 +218,21 @@ def main():
             s = timer.summary()
             gm, at = s.get("gemm"), s.get("attn")
             ach = gm["flops"] / (gm["ms"] * 1e-3) / 1e12
-            traffic, traffic_note = None, None
-            tf = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-            if os.path.exists(tf) and not args.small and B == 4:      # PMC passes of this same command (see the file's `source`)
+            traffic, traffic_note, pmc = None, None, {}
+            cands = sorted(p for p in os.listdir(os.path.join(ROOT, "profiles")) if p.endswith("_pmc.json"))      # newest round's PMC summary
+            tf = os.path.join(ROOT, "profiles", cands[-1] if cands else "r01_hbm_traffic.json")
+            if os.path.exists(tf) and not args.small and B == 4:      # PMC passes of this same command (see the file's `source`, tools/pmc_summary.py)
                 with open(tf) as f:
                     tj = json.load(f)
                 traffic = tj["kernels"]["gemm_all"]["hbm_bytes_per_launch"]
-                traffic_note = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, profiles/r01_hbm_traffic.json): (2*FETCH_SIZE + WRITE_SIZE)*1024 per "
+                traffic_note = (f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, profiles/{os.path.basename(tf)}): (2*FETCH_SIZE + WRITE_SIZE)*1024 per "
                                 "launch; the L2-fabric counters include Infinity-Cache hits, so this is traffic beyond the XCD L2, an upper bound on HBM bytes")
+                g256 = tj["kernels"].get("gemm256", {})
+                if "mfma_busy_frac" in g256:
+                    pmc = dict(mfma_busy=g256["mfma_busy_frac"], effective_clock_ghz=g256["effective_clock_ghz"],
+                               hbm_side_gbps=g256["hbm_bytes_per_launch"] / (g256["avg_launch_us_profiled"] * 1e-6) / 1e9)
             line["roofline"] = dict(bound="mfma", kernel="gemm256_kernel / gemm128_kernel (ug_gemm_bf16)", achieved=ach, peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s",
-                                    frac=ach / MFMA_BF16_PEAK_TFLOPS, traffic=traffic, traffic_note=traffic_note, launches=gm["launches"],
+                                    frac=ach / MFMA_BF16_PEAK_TFLOPS, traffic=traffic, traffic_note=traffic_note, pmc_gemm256=pmc or None, launches=gm["launches"],
                                     avg_launch_us=1000.0 * gm["ms"] / gm["launches"], avg_launch_gflop=gm["flops"] / gm["launches"] / 1e9,
                                     share_of_step_time=gm["ms"] * 1e-3 / elapsed)
             if at:
