@@ -207,3 +207,49 @@ def test_enable_lora_context_manager_semantics():
         assert A.shape == (64, 64) and Bm.shape == (32, 64)          # one active adapter, rank padded to 64
     assert lin.scaling == {"canny": 1.0, "depth": 4.0}                # 2.0 * (alpha / r = 2): the reference's restore quirk
     assert mod.module_active_adapters(object()) == []
+
+
+def test_control_checkpoint_wire_formats(tmp_path):
+    """the reference's `--transformer` formats (infer.py:124-140, src/hook.py:10-27) all reach load_state_dict."""
+    from safetensors.torch import save_file
+    from unigen_amd.checkpoint import load_control_checkpoint, read_control_state_dict
+    m = _model()
+    m.init_synthetic_(seed=5, std=0.05, bias_std=0.02)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    ctrl = {k: v.float() for k, v in sd.items() if k.startswith(("control", "moe.", "shared_expert"))}       # fp32 on disk, like zero_to_fp32
+    assert ctrl
+    # 2. single torch.save file
+    f = tmp_path / "pytorch_model_fp32.bin"
+    torch.save(ctrl, str(f))
+    assert set(read_control_state_dict(str(f))) == set(ctrl)
+    # 1. ZeRO directory with a consolidated file; and the raw one without
+    z = tmp_path / "zero"; z.mkdir(); (z / "latest").write_text("global_step100")
+    with pytest.raises(OSError, match="consolidate"):
+        read_control_state_dict(str(z))
+    torch.save(ctrl, str(z / "pytorch_model_fp32.bin"))
+    assert set(read_control_state_dict(str(z))) == set(ctrl)
+    # 3. safetensors shards
+    s = tmp_path / "st"; s.mkdir()
+    keys = sorted(ctrl)
+    save_file({k: ctrl[k].contiguous() for k in keys[::2]}, str(s / "a.safetensors"))
+    save_file({k: ctrl[k].contiguous() for k in keys[1::2]}, str(s / "b.safetensors"))
+    assert set(read_control_state_dict(str(s))) == set(ctrl)
+    # 4. hook files: one partial dict per module family; overlapping files are an error
+    h = tmp_path / "hook"; h.mkdir()
+    fam = {}
+    for k in keys:
+        fam.setdefault(k.split(".")[0], {})[k] = ctrl[k]
+    for name, part in fam.items():
+        torch.save(part, str(h / f"{name}_weights_0.bin"))
+    assert set(read_control_state_dict(str(h))) == set(ctrl)
+    torch.save(next(iter(fam.values())), str(h / "zz_weights_1.bin"))
+    with pytest.raises(ValueError, match="already defined"):
+        read_control_state_dict(str(h))
+    # loading casts to bf16 and writes through the packed views
+    m2 = _model()
+    res = load_control_checkpoint(m2, str(s))
+    assert not res.unexpected_keys and all(not k.startswith(("control", "moe.", "shared_expert")) for k in res.missing_keys)
+    got = m2.state_dict()
+    assert all(torch.equal(got[k], ctrl[k].to(got[k].dtype)) for k in ctrl)
+    with pytest.raises(OSError):
+        read_control_state_dict(str(tmp_path / "nope"))
