@@ -78,6 +78,10 @@ def load() -> C.CDLL:
             f"{LIB_PATH} not found: build it with `python -m unigen_amd.build` (hipcc --offload-arch=gfx950). "
             "unigen_amd has no CPU fallback for the hot path."
         )
+    # The library links libamdhip64 by SONAME. PyTorch-ROCm ships its own copy of the HIP runtime: it has to be in the process first so
+    # that both resolve to ONE runtime (loaded the other way round, the system runtime and torch's each keep their own device state and
+    # launches fail with "no ROCm-capable device is detected").
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
