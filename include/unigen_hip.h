@@ -74,6 +74,12 @@ typedef struct ug_gemm_desc {
      * filled round of tiles; NULL = plain tiles only. Its first 4096 bytes (arrival tickets) must be ZERO before the first call;
      * every call leaves them zero again. The rest needs no initialisation. One workspace per stream. */
     void* workspace; int64_t workspace_bytes;
+    /* Column split, for one launch over the concatenated weights of two Linear layers that read the same input (the single block's
+     * [to_q; to_k; to_v; proj_mlp], diffusers FluxSingleTransformerBlock, called at src/UniGenTransformer.py:1151):
+     *   UG_EPI_BIAS_GELU applies GELU only to columns n >= gelu_from_n (0: all columns);
+     *   output column n is stored at column n + c_shift when n >= c_shift_from_n > 0 (a gap in the destination row).
+     * Both boundaries must be multiples of 256 (a tile never straddles them); c_shift a multiple of 8. */
+    int64_t gelu_from_n, c_shift_from_n, c_shift;
 } ug_gemm_desc;
 
 /* bytes of ug_gemm_desc.workspace that are always sufficient (any shape) */

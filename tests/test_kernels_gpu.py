@@ -66,6 +66,27 @@ def test_gemm_epilogues(gpu, M, N, K, epi):
     assert m["rel_l2"] <= TOL, m
 
 
+@pytest.mark.parametrize("M,N1,N2,K,force", [(300, 512, 256, 128, 0), (520, 256, 512, 192, 128), (256, 768, 1024, 64, 256)])
+def test_gemm_column_split(gpu, M, N1, N2, K, force):
+    """One launch over two concatenated Linear layers (single block: [to_q; to_k; to_v; proj_mlp]): bias-only columns [0, N1), GELU columns
+    [N1, N1 + N2) stored behind a gap of `shift` columns; both kernels (UG_GEMM_FORCE_TILE is read once, so the shapes pick the kernel)."""
+    from unigen_amd import lib as L, ops
+    g = torch.Generator().manual_seed(M + N1 + K)
+    N, shift = N1 + N2, 64
+    a, w, b = _rand(g, M, K), _rand(g, N, K, scale=K ** -0.5), _rand(g, N, scale=0.1)
+    out = torch.full((M, N + shift), 7.0, device=gpu, dtype=BF)
+    ops.gemm(a.to(gpu), w.to(gpu), b.to(gpu), out, M=M, epilogue=L.EPI_BIAS_GELU, ldc=N + shift, gelu_from_n=N1, c_shift_from_n=N1, c_shift=shift)
+    v = (a.float() @ w.float().t() + b.float()).to(BF).float()
+    ref = torch.full((M, N + shift), 7.0)
+    ref[:, :N1] = v[:, :N1]
+    ref[:, N1 + shift:] = F.gelu(v[:, N1:], approximate="tanh")
+    m = report(f"gemm_split_{M}x{N1}+{N2}x{K}", out, ref.to(BF))
+    assert m["rel_l2"] <= TOL, m
+    assert torch.equal(out[:, N1:N1 + shift].cpu(), torch.full((M, shift), 7.0, dtype=BF)), "the gap was written"
+    with pytest.raises(Exception):
+        ops.gemm(a.to(gpu), w.to(gpu), b.to(gpu), out, M=M, epilogue=L.EPI_BIAS_GELU, ldc=N + shift, gelu_from_n=N1 + 8)
+
+
 def test_gemm_rowmaps_inplace_grouped_lora(gpu):
     from unigen_amd import lib as L, ops
     g = torch.Generator().manual_seed(5)

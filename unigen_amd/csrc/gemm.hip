@@ -92,6 +92,17 @@ __device__ __forceinline__ RowCtx row_ctx(const ug_gemm_desc& p, int g, unsigned
     return c;
 }
 
+// Column split of a launch over two concatenated Linear layers (ug_gemm_desc.gelu_from_n / c_shift_from_n / c_shift): both boundaries are
+// multiples of 256, so they are uniform per tile of either kernel.
+struct TileSplit { bool gelu; int64_t cshift; };
+template <int EPI>
+__device__ __forceinline__ TileSplit tile_split(const ug_gemm_desc& p, int64_t n0) {
+    TileSplit t;
+    t.gelu = EPI == UG_EPI_BIAS_GELU && n0 >= p.gelu_from_n;
+    t.cshift = (p.c_shift_from_n > 0 && n0 >= p.c_shift_from_n) ? p.c_shift : 0;
+    return t;
+}
+
 // one lane's 4 consecutive n of one row: v = bf16(acc + bias) then the fused elementwise tail, 8-byte store
 template <int EPI>
 __device__ __forceinline__ void epi_store(const ug_gemm_desc& p, const RowCtx& rc, int64_t n, const f32x4 a, const float* bv) {
@@ -328,15 +339,19 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(const ug_gemm_desc p) {
         const int64_t n = n0 + wc * 64 + j * 16 + (lane >> 4) * 4;
         load_bias4(n < N ? bias : nullptr, n, bv[j]);
     }
+    const TileSplit ts = tile_split<EPI>(p, n0);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int64_t m = m0 + wr * 64 + i * 16 + (lane & 15);
         if (m >= M) continue;
-        const RowCtx rc = row_ctx<EPI>(p, g, (unsigned)m);
+        RowCtx rc = row_ctx<EPI>(p, g, (unsigned)m);
+        rc.coff += ts.cshift;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int64_t n = n0 + wc * 64 + j * 16 + (lane >> 4) * 4;
-            if (n < N) epi_store<EPI>(p, rc, n, acc[i][j], bv[j]);
+            if (n >= N) continue;
+            if (EPI == UG_EPI_BIAS_GELU && !ts.gelu) epi_store<UG_EPI_BIAS>(p, rc, n, acc[i][j], bv[j]);
+            else epi_store<EPI>(p, rc, n, acc[i][j], bv[j]);
         }
     }
 }
@@ -653,7 +668,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
             // computed and stored (older than those stores on the in-order VM counter, so waiting for them does not wait for stores).
             const int lg = lane_e >> 4;
             const int colb = (int)n0 + wc * 32 + (lg & 1) * 16 + 8 * (lg >> 1);
-            bf16_t* const Cb = (bf16_t*)p.C + (int64_t)g * p.c_gstride + colb;
+            const TileSplit ts = tile_split<EPI>(p, n0);
+            bf16_t* const Cb = (bf16_t*)p.C + (int64_t)g * p.c_gstride + colb + ts.cshift;
             const bf16_t* const Rb = RES ? (const bf16_t*)p.R + (int64_t)g * p.r_gstride + colb : nullptr;
             const unsigned mrow = (unsigned)m0 + wr * 64 + (lane_e & 15);
             u32x4 rbuf[2][2];
@@ -681,8 +697,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
                 }
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    const u32x4 o = epi_chunk_full<EPI>(p.alpha, acc[rg >> 2][j][rg & 3][0], acc[rg >> 2][j][rg & 3][1], fb[j][0], fb[j][1],
-                                                        fg[j][0], fg[j][1], rbuf[rg & 1][j]);
+                    const u32x4 o = (EPI == UG_EPI_BIAS_GELU && !ts.gelu)
+                        ? epi_chunk_full<UG_EPI_BIAS>(p.alpha, acc[rg >> 2][j][rg & 3][0], acc[rg >> 2][j][rg & 3][1], fb[j][0], fb[j][1],
+                                                      fg[j][0], fg[j][1], rbuf[rg & 1][j])
+                        : epi_chunk_full<EPI>(p.alpha, acc[rg >> 2][j][rg & 3][0], acc[rg >> 2][j][rg & 3][1], fb[j][0], fb[j][1],
+                                              fg[j][0], fg[j][1], rbuf[rg & 1][j]);
                     __builtin_nontemporal_store(o, (u32x4*)(cp[rg & 1] + j * 128));
                 }
             }
@@ -697,6 +716,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
                 const int64_t n = n0 + j * 128 + wc * 32 + nt * 16 + (lane_e >> 4) * 4;
                 load_bias4(n < N ? bias : nullptr, n, bv[j][nt]);
             }
+        const TileSplit tsl = tile_split<EPI>(p, n0);
         if (EPI != UG_EPI_F32 && wide16) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -704,10 +724,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
                 for (int mt = 0; mt < 4; ++mt) {
                     const int64_t m = m0 + i * 128 + wr * 64 + mt * 16 + (lane_e & 15);
                     const bool row_ok = m < M;                         // lanes l and l^16 share the row: the swaps stay paired
-                    const RowCtx rc = row_ctx<EPI>(p, g, (unsigned)(row_ok ? m : M - 1));
+                    RowCtx rc = row_ctx<EPI>(p, g, (unsigned)(row_ok ? m : M - 1));
+                    rc.coff += tsl.cshift;
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        epi_store_pair16<EPI>(p, rc, row_ok, n0 + j * 128 + wc * 32, N, lane_e, acc[i][j][mt][0], acc[i][j][mt][1], bv[j][0], bv[j][1]);
+                    for (int j = 0; j < 2; ++j) {
+                        if (EPI == UG_EPI_BIAS_GELU && !tsl.gelu)
+                            epi_store_pair16<UG_EPI_BIAS>(p, rc, row_ok, n0 + j * 128 + wc * 32, N, lane_e, acc[i][j][mt][0], acc[i][j][mt][1], bv[j][0], bv[j][1]);
+                        else
+                            epi_store_pair16<EPI>(p, rc, row_ok, n0 + j * 128 + wc * 32, N, lane_e, acc[i][j][mt][0], acc[i][j][mt][1], bv[j][0], bv[j][1]);
+                    }
                 }
         } else {
 #pragma unroll
@@ -716,13 +741,16 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
                 for (int mt = 0; mt < 4; ++mt) {
                     const int64_t m = m0 + i * 128 + wr * 64 + mt * 16 + (lane_e & 15);
                     if (m >= M) continue;
-                    const RowCtx rc = row_ctx<EPI>(p, g, (unsigned)m);
+                    RowCtx rc = row_ctx<EPI>(p, g, (unsigned)m);
+                    rc.coff += tsl.cshift;
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
 #pragma unroll
                         for (int nt = 0; nt < 2; ++nt) {
                             const int64_t n = n0 + j * 128 + wc * 32 + nt * 16 + (lane_e >> 4) * 4;
-                            if (n < N) epi_store<EPI>(p, rc, n, acc[i][j][mt][nt], bv[j][nt]);
+                            if (n >= N) continue;
+                            if (EPI == UG_EPI_BIAS_GELU && !tsl.gelu) epi_store<UG_EPI_BIAS>(p, rc, n, acc[i][j][mt][nt], bv[j][nt]);
+                            else epi_store<EPI>(p, rc, n, acc[i][j][mt][nt], bv[j][nt]);
                         }
                 }
         }
@@ -818,6 +846,9 @@ extern "C" int ug_gemm_bf16(const ug_gemm_desc* dp, ug_stream_t stream) {
                UG_ERR_UNSUPPORTED, "ug_gemm_bf16: row counts must fit 31 bits");
     UG_REQUIRE(d.K % BK == 0, UG_ERR_UNSUPPORTED, "ug_gemm_bf16: K=%lld must be a multiple of %d", (long long)d.K, BK);
     UG_REQUIRE(d.N % 4 == 0, UG_ERR_UNSUPPORTED, "ug_gemm_bf16: N=%lld must be a multiple of 4", (long long)d.N);
+    UG_REQUIRE(d.gelu_from_n >= 0 && d.c_shift_from_n >= 0 && d.gelu_from_n % 256 == 0 && d.c_shift_from_n % 256 == 0 && d.c_shift % 8 == 0 &&
+               (d.c_shift_from_n > 0 || d.c_shift == 0) && d.ldc >= d.N + (d.c_shift > 0 ? d.c_shift : 0),
+               UG_ERR_BAD_SHAPE, "ug_gemm_bf16: column split needs gelu_from_n, c_shift_from_n multiples of 256, c_shift a multiple of 8 and ldc >= N + c_shift");
     UG_REQUIRE(d.A && d.W && d.C, UG_ERR_BAD_SHAPE, "ug_gemm_bf16: null operand");
     UG_REQUIRE(d.lda >= d.K && d.ldw >= d.K && d.ldc >= d.N, UG_ERR_BAD_SHAPE, "ug_gemm_bf16: leading dims too small");
     UG_REQUIRE(d.lda % 8 == 0 && d.ldw % 8 == 0 && ug_aligned(d.A, 16) && ug_aligned(d.W, 16) &&

@@ -36,6 +36,7 @@ class GemmDesc(C.Structure):
         ("lora_r", i32), ("_pad1", i32),
         ("r_gstride", i64), ("gate_gstride", i64),
         ("workspace", vp), ("workspace_bytes", i64),
+        ("gelu_from_n", i64), ("c_shift_from_n", i64), ("c_shift", i64),
     ]
 
 

@@ -102,7 +102,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: to
          r_map: RowMap = IDENT, gate: Optional[torch.Tensor] = None, gate_ld: int = 0, rows_per_sample: int = 0,
          alpha: float = 1.0, groups: int = 1, a_gstride: int = 0, w_gstride: int = 0, bias_gstride: int = 0,
          c_gstride: int = 0, r_gstride: int = 0, gate_gstride: int = 0, lora_t: Optional[torch.Tensor] = None,
-         lora_b: Optional[torch.Tensor] = None) -> torch.Tensor:
+         lora_b: Optional[torch.Tensor] = None, gelu_from_n: int = 0, c_shift_from_n: int = 0, c_shift: int = 0) -> torch.Tensor:
     """out[m, :N] = epilogue(a[m, :K] @ w[:N, :K]^T + bias). `a`/`out`/`residual` are base tensors whose data_ptr is row 0
     (slices of a bigger buffer are fine); leading dims default to the tensors' row strides."""
     _chk(a, "a"); _chk(w, "w")
@@ -123,6 +123,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: to
     d.M, d.N, d.K = M, N, K
     d.groups, d.a_gstride, d.w_gstride, d.bias_gstride, d.c_gstride = groups, a_gstride, w_gstride, bias_gstride, c_gstride
     d.r_gstride, d.gate_gstride = r_gstride, gate_gstride
+    d.gelu_from_n, d.c_shift_from_n, d.c_shift = gelu_from_n, c_shift_from_n, c_shift
     ws = _gemm_workspace(a.device)
     d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
     if lora_t is not None:
