@@ -60,10 +60,12 @@ __device__ __forceinline__ float ug_max_halves(float x) {
     return ug_max3(__uint_as_float(r[0]), __uint_as_float(r[1]), x);
 }
 
-// STAGGER (8 waves): waves 0-3 and 4-7 - the two waves of every SIMD - run half a tile apart: in each segment one group does
-// S^T + softmax of a tile while the other does P.V of the previous one, so a wave's softmax VALU work runs under its partner's
-// MFMAs instead of both waves hitting the matrix pipe, then the VALU, together. Two barriers per tile; K(t+1) is written at the
-// end of odd segments and V(t) at the end of even ones, each into the buffer nobody reads in that segment.
+// STAGGER (8 waves, the default): waves 0-3 and 4-7 - the two waves of every SIMD - run one segment apart. A wave alternates a
+// matrix-only segment X(t) = P.V(t) then S^T(t+1) = K Q^T (32 MFMAs, an explicit fenced stream) with a VALU-only segment Y(t+1) = the
+// online softmax of tile t+1, so a wave's softmax runs under its partner's MFMAs instead of both waves hitting the matrix pipe, then
+// the VALU, together (the lock-step loop, STAGGER = false, kept for A/B: both phases then serialise and a tile costs the sum).
+// Two barriers per tile; every thread fetches its share of K(t+2), V(t+1) at the start of an even segment and publishes it to LDS at
+// the end of the following odd one, into buffers nobody reads in those two segments.
 template <int DH, int NW, bool STAGGER>   // head dim 128 | 64; waves per workgroup: 8 (256 query rows, 1 / CU) or 4 (128 rows, 2 / CU)
 __global__ __launch_bounds__(64 * NW, 2) void flash_attn_kernel(
     const bf16_t* __restrict__ q, int64_t q_rs, int64_t q_bs, const bf16_t* __restrict__ k, int64_t k_rs, int64_t k_bs,
@@ -444,7 +446,6 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn_kernel(
         seg_barrier();
         // one tile = Y(t) | X(t); buffer parity is a compile-time constant (two tiles per trip)
         auto tile = [&](int t, auto cur_c) {
-            constexpr int CUR = decltype(cur_c)::value;
             // Y(t): A in odd segment 2t+1 (publishes K(t+1), V(t) at its end) | B in even segment 2t+2 (fetches K(t+2), V(t+1) at its start)
             if (!groupA) fetch(t + 2, t + 1);
             do_SM();
