@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void qk_rmsnorm_rope_kernel(
 // applied), each wave streams whole weight rows from HBM with 16-byte loads. HBM-bound on W.
 // reference: AdaLayerNormZero.linear(silu(emb)), TimestepEmbedding, PixArtAlphaTextProjection (diffusers 0.32.2)
 // ---------------------------------------------------------------------------------------------------------
-constexpr int SL_COLS_PER_WAVE = 4;
+constexpr int SL_COLS_PER_WAVE = 8;
 
 template <int MT>
 __global__ __launch_bounds__(256) void small_linear_kernel(
@@ -153,6 +153,23 @@ __global__ __launch_bounds__(256) void small_linear_kernel(
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16_t* xs = (bf16_t*)smem;  // [MT][K]
     const int nchunk = K >> 3;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t nbase = ((int64_t)blockIdx.x * 4 + wave) * SL_COLS_PER_WAVE;
+    // The weight stream is the whole cost (HBM-bound, M <= 16 rows of x against N x K weights): every wave owns 8 weight rows and has
+    // all 8 of their 16-byte chunks in flight per step; the first step's loads are issued before x is staged so that the staging
+    // (SiLU: exp2 + rcp, no IEEE division) runs under their latency. (4 columns per wave, two rows per pass and a division-based
+    // SiLU recomputed by every block streamed at 1.9 TB/s.)
+    const bf16_t* wr[SL_COLS_PER_WAVE];
+#pragma unroll
+    for (int j = 0; j < SL_COLS_PER_WAVE; ++j) {
+        int64_t n = nbase + j; if (n > N - 1) n = N - 1;                // rows past N re-read the last row; their sums are dropped
+        wr[j] = W + n * ldw;
+    }
+    u32x4 wq[SL_COLS_PER_WAVE];
+    if (lane < nchunk) {
+#pragma unroll
+        for (int j = 0; j < SL_COLS_PER_WAVE; ++j) wq[j] = __builtin_nontemporal_load((const u32x4*)(wr[j] + lane * 8));
+    }
     for (int i = threadIdx.x; i < MT * nchunk; i += 256) {
         const int m = i / nchunk, c = i - m * nchunk;
         float f[8];
@@ -160,7 +177,7 @@ __global__ __launch_bounds__(256) void small_linear_kernel(
             unpack8(*(const u32x4*)(x + (int64_t)m * ldx + c * 8), f);
             if (act_in == 1) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) f[e] = f[e] / (1.0f + __expf(-f[e]));   // SiLU, rounded to bf16 below
+                for (int e = 0; e < 8; ++e) f[e] = f[e] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * f[e]));   // SiLU, rounded to bf16 below
             }
         } else {
 #pragma unroll
@@ -169,42 +186,53 @@ __global__ __launch_bounds__(256) void small_linear_kernel(
         *(u32x4*)(xs + (int64_t)m * K + c * 8) = pack8(f);
     }
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t nbase = ((int64_t)blockIdx.x * 4 + wave) * SL_COLS_PER_WAVE;
-    // two weight rows per pass: twice the 16-byte loads in flight per wave (the kernel is HBM-latency bound on the weight stream)
-    for (int cc = 0; cc < SL_COLS_PER_WAVE; cc += 2) {
-        const int64_t n = nbase + cc;
-        if (n >= N) break;
-        const bool two = n + 1 < N;
-        float acc0[MT], acc1[MT];
+    if (nbase >= N) return;
+    float acc[SL_COLS_PER_WAVE][MT];
 #pragma unroll
-        for (int m = 0; m < MT; ++m) { acc0[m] = 0.f; acc1[m] = 0.f; }
-        const bf16_t* wr0 = W + n * ldw;
-        const bf16_t* wr1 = W + (two ? n + 1 : n) * ldw;
-        for (int c = lane; c < nchunk; c += 64) {
-            float w0[8], w1[8];
-            unpack8(*(const u32x4*)(wr0 + c * 8), w0);
-            unpack8(*(const u32x4*)(wr1 + c * 8), w1);
+    for (int j = 0; j < SL_COLS_PER_WAVE; ++j)
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                float xf[8];
-                unpack8(*(const u32x4*)(xs + (int64_t)m * K + c * 8), xf);
+        for (int m = 0; m < MT; ++m) acc[j][m] = 0.f;
+    for (int c = lane; c < nchunk; c += 64) {            // one step ahead (a deeper register ring measured slower: hipcc drains it with vmcnt(0))
+        u32x4 wn[SL_COLS_PER_WAVE];
+        const bool more = c + 64 < nchunk;
+        if (more) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { acc0[m] += xf[e] * w0[e]; acc1[m] += xf[e] * w1[e]; }
-            }
+            for (int j = 0; j < SL_COLS_PER_WAVE; ++j) wn[j] = __builtin_nontemporal_load((const u32x4*)(wr[j] + (c + 64) * 8));
         }
+        float xf[MT][8];
 #pragma unroll
-        for (int m = 0; m < MT; ++m) { acc0[m] = wave_sum(acc0[m]); acc1[m] = wave_sum(acc1[m]); }
-        if (lane < M) {
-            float v0 = 0.f, v1 = 0.f;
+        for (int m = 0; m < MT; ++m) unpack8(*(const u32x4*)(xs + (int64_t)m * K + c * 8), xf[m]);
 #pragma unroll
-            for (int m = 0; m < MT; ++m) if (m == lane) { v0 = acc0[m]; v1 = acc1[m]; }
-            if (bias) { v0 += bf2f(bias[n]); if (two) v1 += bf2f(bias[n + 1]); }
-            v0 = rbf(v0); v1 = rbf(v1);
-            if (R) { v0 += bf2f(R[(int64_t)lane * ldr + n]); if (two) v1 += bf2f(R[(int64_t)lane * ldr + n + 1]); }
-            out[(int64_t)lane * ldo + n] = f2bf(v0);
-            if (two) out[(int64_t)lane * ldo + n + 1] = f2bf(v1);
+        for (int j = 0; j < SL_COLS_PER_WAVE; ++j) {
+            float w[8];
+            unpack8(wq[j], w);
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[j][m] += xf[m][e] * w[e];
         }
+        if (more) {
+#pragma unroll
+            for (int j = 0; j < SL_COLS_PER_WAVE; ++j) wq[j] = wn[j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < SL_COLS_PER_WAVE; ++j)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[j][m] = wave_sum(acc[j][m]);
+    // lane l writes out[l / 8 (+ 8)][nbase + l % 8]
+    const int jo = lane & 7;
+    const int64_t n = nbase + jo;
+    for (int mo = lane >> 3; mo < M && n < N; mo += 8) {
+        float v = 0.f;
+#pragma unroll
+        for (int j = 0; j < SL_COLS_PER_WAVE; ++j)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) if (m == mo && j == jo) v = acc[j][m];
+        if (bias) v += bf2f(bias[n]);
+        v = rbf(v);
+        if (R) v += bf2f(R[(int64_t)mo * ldr + n]);
+        out[(int64_t)mo * ldo + n] = f2bf(v);
     }
 }
 
