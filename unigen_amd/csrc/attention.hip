@@ -454,10 +454,11 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn_kernel(
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) { asm volatile("" : "+v"(pf[kb][0])); asm volatile("" : "+v"(pf[kb][1])); }
             asm volatile("" : "+v"(l_run), "+v"(m_run));
-            if (groupA) publish(t + 1, t);
+            // group A publishes K(t+1), V(t) and at once re-fills the staging registers with K(t+2), V(t+1): its VALU segment has slack
+            // (the partner's matrix segment is longer), whereas a fetch at the head of its own X(t) delayed the first MFMA
+            if (groupA) { publish(t + 1, t); fetch(t + 2, t + 1); }
             seg_barrier();
-            // X(t) = P.V(t) then K.Q^T(t+1): A in even segment 2t+2 (fetch) | B in odd segment 2t+3 (publish)
-            if (groupA) fetch(t + 2, t + 1);
+            // X(t) = P.V(t) then K.Q^T(t+1): A in even segment 2t+2 | B in odd segment 2t+3 (publish)
             do_X(t, cur_c, t + 1 < ntiles);
             if (!groupA) publish(t + 2, t + 1);
             seg_barrier();
