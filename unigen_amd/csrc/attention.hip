@@ -458,7 +458,8 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn_kernel(
             // (the partner's matrix segment is longer), whereas a fetch at the head of its own X(t) delayed the first MFMA
             if (groupA) { publish(t + 1, t); fetch(t + 2, t + 1); }
             seg_barrier();
-            // X(t) = P.V(t) then K.Q^T(t+1): A in even segment 2t+2 | B in odd segment 2t+3 (publish)
+            // X(t) = P.V(t) then K.Q^T(t+1): A in even segment 2t+2 | B in odd segment 2t+3 (publish). (Measured and dropped: group B
+            // reading its first V^T fragments ahead of the barrier, inside its softmax segment: -4 %, -10 % with two k-steps.)
             do_X(t, cur_c, t + 1 < ntiles);
             if (!groupA) publish(t + 2, t + 1);
             seg_barrier();
