@@ -112,3 +112,31 @@ def test_comoe_routing_full_size_properties(gpu):
     p = gates.gather(1, idx.long()[:, None]).to(BF)
     ref = torch.where(kept.to(gpu)[:, None], (p.float() * x.float()).to(BF), torch.zeros_like(x))
     assert torch.equal(back, ref)
+
+
+def test_dominant_kernels_are_run_to_run_deterministic(gpu):
+    """The same launch repeated gives bitwise identical outputs at cfg2 sizes: the GEMM's split-K tail reduces its slabs in a fixed order, and
+    neither the relaxed vmcnt waits around the epilogue nor the LDS rings may race (tools/determinism_check.py runs the longer version)."""
+    from unigen_amd import lib as L, ops
+    g = torch.Generator(device=gpu).manual_seed(1)
+    for (M, N, K, epi) in [(16384, 9216, 3072, L.EPI_BIAS), (18432, 3072, 15360, L.EPI_RES_GATE), (18432, 21504, 3072, L.EPI_BIAS_GELU)]:
+        a = (torch.rand(M, K, generator=g, device=gpu) * 2 - 1).to(torch.bfloat16)
+        w = ((torch.rand(N, K, generator=g, device=gpu) * 2 - 1) * K ** -0.5).to(torch.bfloat16)
+        b = (torch.rand(N, generator=g, device=gpu) * 0.1).to(torch.bfloat16)
+        kw = dict(M=M, epilogue=epi)
+        if epi == L.EPI_RES_GATE:
+            kw.update(residual=torch.rand(M, N, generator=g, device=gpu).to(torch.bfloat16),
+                      gate=torch.rand(M // 512 + 1, N, generator=g, device=gpu).to(torch.bfloat16), gate_ld=N, rows_per_sample=512)
+        if epi == L.EPI_BIAS_GELU:
+            kw.update(gelu_from_n=9216)
+        outs = [ops.gemm(a, w, b, torch.empty(M, N, device=gpu, dtype=torch.bfloat16), **kw) for _ in range(6)]
+        assert all(torch.equal(outs[0], o) for o in outs[1:]), (M, N, K, epi)
+        del outs, a, w
+    H, dh = 24, 128
+    D = H * dh
+    B, Lq, Lkv = 4, 4608, 4608
+    qkv = torch.randn(B, Lkv, 3 * D, generator=g, device=gpu).to(torch.bfloat16)
+    st = (3 * D, Lkv * 3 * D)
+    outs = [ops.flash_attn(qkv[0], qkv[0, 0, D:], qkv[0, 0, 2 * D:], torch.empty(B, Lq, D, device=gpu, dtype=torch.bfloat16), batches=B, heads=H, dh=dh,
+                           Lq=Lq, Lkv=Lkv, q_strides=st, k_strides=st, v_strides=st, o_strides=(D, Lq * D)) for _ in range(6)]
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
