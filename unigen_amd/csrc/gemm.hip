@@ -504,6 +504,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
         // its last ds_read is >= 3 segments old (B0's fragments stay in registers for phase 3, so its slot frees after phase 0):
         //   phase 0 stages B1(kt+1) | phase 1: A1(kt+1) | phase 2: A0(kt+2) | phase 3: B0(kt+2)
         // -> every half-tile has 5-6 phases (~1.3 K-tiles) of lead; vmcnt(8) keeps the four youngest half-tiles in flight.
+        // (Measured on the epilogue, end of round 1: it is STORE-bound - skipping its arithmetic changes nothing, skipping its 16 stores per
+        // wave saves ~5.5 us per tile-round at K = 3072 (7 %). Not the chip-wide burst: a start ramp that keeps the CUs of an XCD up to
+        // 17 us apart for the whole launch (verified with per-CU stamps) gains nothing; not the line pattern either: 8 rows x 128 B per
+        // store instruction instead of 16 x 64 B, or the two half-lines back to back, time the same. What is left is the drain time of the
+        // stores on the in-order VM counter beyond the ~1.9 K-tiles of slack below.)
         // (Measured and dropped: signalling the hand-off barrier 2-4 MFMAs before the end of a segment, so that the other group is
         // released while this one still has MFMAs queued: -9 % - the two groups' MFMAs then share the pipe, matrix beside matrix.)
         // (Measured and dropped: 2 segments of 32 MFMAs per K-tile and wave group with all DMA issued by waves 4-7 - 4 barriers per
