@@ -13,6 +13,10 @@
  *   - asynchronous, stream-ordered on `stream` (a hipStream_t passed as void*);
  *     no allocation, no ownership transfer, no host synchronisation.
  *   - bf16 storage (uint16 bit patterns), fp32 accumulate / statistics / gate / RoPE tables.
+ *   - every compute entry point has an fp32 VERIFICATION twin `<name>_f32` (section at the end): identical argument
+ *     meaning, fp32 storage for every tensor that is bf16 here, no intermediate rounding. Slow, correctness-first
+ *     kernels; the Python host runs the SAME orchestration through them when the model's parameters are fp32, which
+ *     is how forward-level parity with the reference is shown to <= 1e-3 (a bf16 forward cannot be: eps = 7.8e-3).
  *   - return 0 on success, a negative UG_ERR_* otherwise; ug_last_error() gives the
  *     thread-local message of the most recent failure.
  *   - "row map": a logical row m of an operand lives at physical row
@@ -166,9 +170,10 @@ int ug_moe_capacity_rts(const float* gates, const int32_t* idx, const float* uni
 /* Dispatch + expert modulation prologue (replaces einsum("sec,sm->ecm") src/UniGenUtils.py:140 and the s-scaling of
  * modulated_flatten src/UniGenUtils.py:204-228):
  *   out[e][slot][:] = bf16( mod[e][sample(tok)][:] * bf16( x[tok][:] + (add ? add[e][slot][:] : 0) ) ), zeros for empty slots.
- * mod: bf16 [E][B][D] = Linear(768->D)(pooled) per expert, or NULL for a plain dispatch (transformer-block experts).
- * tokens_per_sample = N. */
-int ug_moe_dispatch_modulate(const void* x, int64_t ldx, const void* add, const void* mod, int64_t B,
+ * mod: bf16, row of (expert e, sample b) at mod + e * mod_estride + b * mod_bstride (elements) = Linear(768->D)(pooled) of that
+ * expert (all experts' linears run as ONE launch over their stacked weights, so the natural layout is [B][E][D]); NULL for a plain
+ * dispatch (transformer-block experts). tokens_per_sample = N. */
+int ug_moe_dispatch_modulate(const void* x, int64_t ldx, const void* add, const void* mod, int64_t mod_estride, int64_t mod_bstride,
                              const int32_t* token_of_slot, int32_t E, int64_t capacity, int64_t tokens_per_sample,
                              int64_t D, void* out, ug_stream_t stream);
 
@@ -177,10 +182,57 @@ int ug_moe_dispatch_modulate(const void* x, int64_t ldx, const void* add, const 
  *   eh = bf16(bf16(p) * yh[e][slot]) (0 if dropped), ec likewise from yc;
  *   out = bf16( bf16(xs + eh) + bf16(cs + ec) )    when xs/cs given (shared experts),
  *   out = bf16( eh + ec )                          otherwise.
- * If `accumulate` != 0, out = bf16(out_prev + that)  (MultiCondtionUniGenFlux sum over conditions, :1316). */
+ * If `accumulate` != 0, out = bf16(out_prev + that)  (MultiCondtionUniGenFlux sum over conditions, :1316).
+ * Token s of xs / cs sits at physical row rowmap(s; s_rpb, s_bstride) (file header: "row map"; 0, 0 = identity): the shared experts'
+ * image and condition streams are the two halves of one [B][2N][D] buffer, so all B samples combine in one launch. */
 int ug_moe_combine(const void* yh, const void* yc, const float* gates, const int32_t* idx, const int32_t* slot,
-                   int32_t E, int64_t capacity, const void* xs, const void* cs, int64_t ld_s,
+                   int32_t E, int64_t capacity, const void* xs, const void* cs, int64_t ld_s, int64_t s_rpb, int64_t s_bstride,
                    void* out, int64_t ldo, int64_t S, int64_t D, int32_t accumulate, ug_stream_t stream);
+
+/* FluxPipeline._pack_latents / _unpack_latents (diffusers; called at src/UniGenPipeline.py:641 and :796):
+ *   packed[b][(i, j)][c*4 + dy*2 + dx] = latents[b][c][2i + dy][2j + dx],   latents [B][C][H][W], packed [B][(H/2)(W/2)][4C], contiguous. */
+int ug_pack_latents(const void* latents, void* packed, int64_t B, int64_t C, int64_t H, int64_t W, ug_stream_t stream);
+int ug_unpack_latents(const void* packed, void* latents, int64_t B, int64_t C, int64_t H, int64_t W, ug_stream_t stream);
+
+/* ---- fp32 verification twins (see the conventions at the top). Same arguments as the functions they mirror; every `void*` tensor
+ * that is bf16 there is fp32 here (weights included); fp32 / integer arguments are unchanged. ug_gemm_f32: K, N unconstrained,
+ * the column-split boundaries multiples of 64, no workspace. ug_small_linear_f32: M <= 64. ---- */
+int ug_gemm_f32(const ug_gemm_desc* d, ug_stream_t stream);
+int ug_small_linear_f32(const void* x, int64_t ldx, const void* W, int64_t ldw, const void* bias,
+                        const void* R, int64_t ldr, void* out, int64_t ldo,
+                        int64_t M, int64_t N, int64_t K, int32_t act_in, ug_stream_t stream);
+int ug_adaln_modulate_f32(const void* x, int64_t ldx, int64_t x_rpb, int64_t x_bstride,
+                          const void* shift, const void* scale, int64_t mod_ld, int64_t rows_per_sample,
+                          void* out, int64_t ldo, int64_t rows, int64_t D, float eps, ug_stream_t stream);
+int ug_qk_rmsnorm_rope_f32(void* buf, int64_t ld, int64_t batches, int64_t rows_per_batch, int64_t batch_stride_rows,
+                           int64_t pos_offset, int64_t q_off, int64_t k_off, int32_t heads, int32_t dh,
+                           const void* wq_a, const void* wk_a, const void* wq_b, const void* wk_b, int64_t split,
+                           const float* cos_tab, const float* sin_tab, float eps, ug_stream_t stream);
+int ug_flash_attn_fwd_f32(const void* q, int64_t q_row_stride, int64_t q_batch_stride,
+                          const void* k, int64_t k_row_stride, int64_t k_batch_stride,
+                          const void* v, int64_t v_row_stride, int64_t v_batch_stride,
+                          void* o, int64_t o_row_stride, int64_t o_batch_stride,
+                          int64_t batches, int32_t heads, int64_t Lq, int64_t Lkv, int32_t dh,
+                          float softmax_scale, ug_stream_t stream);
+int ug_timestep_embed_f32(const float* t, void* out, int64_t ldo, int64_t B, int32_t dim, ug_stream_t stream);
+int ug_euler_step_f32(void* x, const void* v, float dt, int64_t n, ug_stream_t stream);
+int ug_cfg_combine_f32(const void* uncond, const void* text, float guidance_scale, void* out, int64_t n, ug_stream_t stream);
+int ug_add_f32(const void* a, int64_t lda, const void* b, int64_t ldb, void* out, int64_t ldo,
+               int64_t rows, int64_t D, ug_stream_t stream);
+int ug_add_rowbcast_f32_f32(void* x, int64_t ldx, const float* table, int64_t ldt, int64_t rows, int64_t rows_per_batch, int64_t D,
+                            ug_stream_t stream);
+int ug_gather_rows_f32(const void* src, int64_t ld_src, const int32_t* idx, void* out, int64_t ld_out, int64_t n, int64_t W,
+                       ug_stream_t stream);
+int ug_moe_gate_top1_f32(const void* x, const void* c, int64_t ld, const void* wg, int64_t S, int64_t D, int32_t E,
+                         float* gates, int32_t* idx, ug_stream_t stream);
+int ug_moe_dispatch_modulate_f32(const void* x, int64_t ldx, const void* add, const void* mod, int64_t mod_estride, int64_t mod_bstride,
+                                 const int32_t* token_of_slot, int32_t E, int64_t capacity, int64_t tokens_per_sample,
+                                 int64_t D, void* out, ug_stream_t stream);
+int ug_moe_combine_f32(const void* yh, const void* yc, const float* gates, const int32_t* idx, const int32_t* slot,
+                       int32_t E, int64_t capacity, const void* xs, const void* cs, int64_t ld_s, int64_t s_rpb, int64_t s_bstride,
+                       void* out, int64_t ldo, int64_t S, int64_t D, int32_t accumulate, ug_stream_t stream);
+int ug_pack_latents_f32(const void* latents, void* packed, int64_t B, int64_t C, int64_t H, int64_t W, ug_stream_t stream);
+int ug_unpack_latents_f32(const void* packed, void* latents, int64_t B, int64_t C, int64_t H, int64_t W, ug_stream_t stream);
 
 int ug_version(void);
 const char* ug_last_error(void);

@@ -34,8 +34,67 @@ def flatten(inp):
     return out
 
 
+SD3_CASES = {
+    # the shipped yaml's transformer-block experts (use_modulate False) and the modulated-linear experts
+    "sd3_tiny_blocks": dict(modulated=False, B=2, hw=16, T=24, state_seed=13, input_seed=12445, timestep=600.0),
+    "sd3_tiny_modulated": dict(modulated=True, B=1, hw=12, T=33, state_seed=14, input_seed=12446, timestep=250.0),
+}
+
+
+def sd3_goldens():
+    from tests.block_cases import SD3_TINY
+    for name, c in SD3_CASES.items():
+        cfg = R.SD3Config(use_modulate=c["modulated"], **SD3_TINY)
+        st = R.make_sd3_state(cfg, seed=c["state_seed"], std=0.05, bias_std=0.02)
+        inp = R.make_sd3_inputs(cfg, B=c["B"], hw=c["hw"], T=c["T"], seed=c["input_seed"])
+        t = torch.full((c["B"],), c["timestep"])
+        out32, _, _ = R.unigen_sd3_forward(st, cfg, timestep=t, dtype=torch.float32, **inp)
+        out16, loss16, cnt16 = R.unigen_sd3_forward(st, cfg, timestep=t, dtype=torch.bfloat16, **inp)
+        tensors = flatten(inp)
+        tensors.update({"timestep": t, "out.fp32": out32.contiguous(), "out.bf16": out16.contiguous(), "out.moe_loss": loss16["moe_loss"].reshape(1),
+                        "out.expert_counts": cnt16["expert_counts"].contiguous()})
+        meta = dict(config=json.dumps(SD3_TINY), case=json.dumps(c), generator="oracle/unigen_ref.py (CPU, torch %s)" % torch.__version__)
+        save_file(tensors, os.path.join(HERE, name + ".safetensors"), metadata=meta)
+        print(name, {k: tuple(v.shape) for k, v in tensors.items() if k.startswith("out")})
+
+
+def block_goldens():
+    """Teacher-forced block fixtures (tests/block_cases.py): O(1) inputs of every block type and the oracle's bf16 / fp32 outputs."""
+    from tests import block_cases as BC
+    cfg = R.FluxConfig(condition_nums=1, **BC.FLUX_TINY)
+    st = R.make_state(cfg, seed=BC.FLUX_CASE["state_seed"], std=BC.STD, bias_std=BC.BIAS_STD)
+    inp = BC.flux_inputs(R, cfg)
+    tensors = {f"in.{k}": v.contiguous() for k, v in inp.items()}
+    for tag, dt in (("bf16", torch.bfloat16), ("fp32", torch.float32)):
+        tensors.update({f"out.{tag}.{k}": v.contiguous() for k, v in BC.flux_oracle(R, st, cfg, inp, dt).items()})
+    save_file(tensors, os.path.join(HERE, "blocks_flux_tiny.safetensors"),
+              metadata=dict(config=json.dumps(BC.FLUX_TINY), case=json.dumps(BC.FLUX_CASE), generator="oracle/unigen_ref.py via tests/block_cases.py"))
+    print("blocks_flux_tiny", sorted(k for k in tensors if k.startswith("out.bf16")))
+    for name, modulated in (("blocks_sd3_tiny", False), ("blocks_sd3_tiny_modulated", True)):
+        scfg = R.SD3Config(use_modulate=modulated, **BC.SD3_TINY)
+        sst = R.make_sd3_state(scfg, seed=BC.SD3_CASE["state_seed"], std=BC.STD, bias_std=BC.BIAS_STD)
+        sinp = BC.sd3_inputs(R, scfg)
+        tensors = {f"in.{k}": v.contiguous() for k, v in sinp.items()}
+        for tag, dt in (("bf16", torch.bfloat16), ("fp32", torch.float32)):
+            o = BC.sd3_oracle(R, sst, scfg, sinp, dt)
+            if modulated:
+                o = {k: v for k, v in o.items() if k.startswith("sd3_comoe")}      # the joint blocks do not depend on the expert variant
+            tensors.update({f"out.{tag}.{k}": v.contiguous() for k, v in o.items()})
+        save_file(tensors, os.path.join(HERE, name + ".safetensors"),
+                  metadata=dict(config=json.dumps(BC.SD3_TINY), case=json.dumps(dict(BC.SD3_CASE, modulated=modulated)),
+                                generator="oracle/unigen_ref.py via tests/block_cases.py"))
+        print(name, sorted(k for k in tensors if k.startswith("out.bf16")))
+
+
 def main():
     torch.set_num_threads(4)
+    if "--only-new" not in sys.argv:
+        flux_goldens()
+    sd3_goldens()
+    block_goldens()
+
+
+def flux_goldens():
     for name, c in CASES.items():
         cfg = R.FluxConfig(condition_nums=c["n_cond"], **TINY)
         st = R.make_state(cfg, seed=c["state_seed"], std=0.05, bias_std=0.02)

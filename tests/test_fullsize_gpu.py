@@ -105,7 +105,7 @@ def test_comoe_routing_full_size_properties(gpu):
     # dispatch -> combine round trip with unit modulation: kept tokens come back scaled by bf16(p), dropped tokens as 0
     mod = torch.ones(E, B, D, device=gpu, dtype=BF)
     xd = torch.empty(E, C, D, device=gpu, dtype=BF)
-    ops.moe_dispatch_modulate(x, None, mod, tos, xd, B=B, E=E, capacity=C, tokens_per_sample=N)
+    ops.moe_dispatch_modulate(x, None, mod, tos, xd, E=E, capacity=C, tokens_per_sample=N, mod_estride=B * D, mod_bstride=D)
     zeros = torch.zeros(E, C, D, device=gpu, dtype=BF)
     back = torch.empty(S, D, device=gpu, dtype=BF)
     ops.moe_combine(xd, zeros, gates, idx, slot, back, E=E, capacity=C)

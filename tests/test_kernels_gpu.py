@@ -299,7 +299,8 @@ def test_moe_routing_dispatch_combine(gpu, S, E, D):
     add_ = _rand(g, E, C, D)
     for use_add in (False, True):
         out = torch.empty(E, C, D, device=gpu, dtype=BF)
-        ops.moe_dispatch_modulate(x.to(gpu), add_.to(gpu) if use_add else None, mod.to(gpu), tos, out, B=B, E=E, capacity=C, tokens_per_sample=N)
+        ops.moe_dispatch_modulate(x.to(gpu), add_.to(gpu) if use_add else None, mod.to(gpu), tos, out, E=E, capacity=C, tokens_per_sample=N,
+                                  mod_estride=B * D, mod_bstride=D)
         ref = torch.zeros(E, C, D, dtype=BF)
         for e in range(E):
             for s_ in range(C):
@@ -324,6 +325,11 @@ def test_moe_routing_dispatch_combine(gpu, S, E, D):
     ops.moe_combine(yh.to(gpu), yc.to(gpu), gates, idx, slot, out, E=E, capacity=C, accumulate=True)
     ref2 = ref + (eh + ec)
     m = report(f"moe_combine_acc_S{S}", out, ref2)
+    assert m["mismatch_frac"] == 0.0, m
+    # shared-expert streams as the two halves of one [B][2N][D] buffer (row map), all samples in one launch
+    xc = torch.cat([xs.view(B, N, D), cs.view(B, N, D)], 1).contiguous().to(gpu).view(B * 2 * N, D)
+    ops.moe_combine(yh.to(gpu), yc.to(gpu), gates, idx, slot, out, E=E, capacity=C, xs=xc, cs=xc[N:], s_map=ops.RowMap(N, 2 * N))
+    m = report(f"moe_combine_rowmap_S{S}", out, ref)
     assert m["mismatch_frac"] == 0.0, m
 
 
@@ -380,7 +386,7 @@ def test_grouped_residual_gate_gather_rowbcast_plain_dispatch(gpu):
     tos = torch.tensor([[2, 5, -1], [0, -1, -1]], dtype=torch.int32)
     xs = _rand(g, 6, 64)
     o = torch.empty(2, 3, 64, device=gpu, dtype=BF)
-    ops.moe_dispatch_modulate(xs.to(gpu), None, None, tos.to(gpu), o, B=1, E=2, capacity=3, tokens_per_sample=6)
+    ops.moe_dispatch_modulate(xs.to(gpu), None, None, tos.to(gpu), o, E=2, capacity=3, tokens_per_sample=6)
     ref = torch.zeros(2, 3, 64, dtype=BF); ref[0, 0], ref[0, 1], ref[1, 0] = xs[2], xs[5], xs[0]
     assert torch.equal(o.cpu(), ref)
 

@@ -166,3 +166,28 @@ def test_lora_formula():
     A, Bm = torch.randn(4, 16, generator=g), torch.randn(8, 4, generator=g)
     y = R.lora_linear(x, w, b, [(A, Bm, 0.5)])
     assert torch.allclose(y, x @ (w + 0.5 * Bm @ A).t() + b, atol=1e-5)
+
+
+def test_oracle_reproduces_block_and_sd3_goldens():
+    """The teacher-forced block fixtures and the SD3 forward fixtures are what the oracle says today (drift pin)."""
+    from tests import block_cases as BC
+    from tests.test_blocks_gpu import _load
+    rel = lambda a, b: float((a.float() - b.float()).norm() / b.float().norm().clamp_min(1e-30))
+    cfg_d, case, t = _load("blocks_flux_tiny")
+    cfg = R.FluxConfig(condition_nums=1, **cfg_d)
+    st = R.make_state(cfg, seed=case["state_seed"], std=BC.STD, bias_std=BC.BIAS_STD)
+    inp = {k[3:]: v for k, v in t.items() if k.startswith("in.")}
+    assert all(torch.equal(v, BC.flux_inputs(R, cfg)[k]) for k, v in inp.items())
+    out = BC.flux_oracle(R, st, cfg, inp, torch.float32)
+    for k, v in out.items():
+        if v.dtype in (torch.float32, torch.bfloat16):
+            assert rel(v, t["out.fp32." + k]) <= 1e-5, k
+        else:
+            assert torch.equal(v, t["out.fp32." + k]), k
+    for name in ("sd3_tiny_blocks", "sd3_tiny_modulated"):
+        cfg_d, case, inp, g = load_golden(name)
+        cfg_d["dual_attention_layers"] = tuple(cfg_d["dual_attention_layers"])
+        scfg = R.SD3Config(use_modulate=case["modulated"], **cfg_d)
+        sst = R.make_sd3_state(scfg, seed=case["state_seed"], std=0.05, bias_std=0.02)
+        o32, _, cnt = R.unigen_sd3_forward(sst, scfg, timestep=g["timestep"], dtype=torch.float32, **inp)
+        assert rel(o32, g["out.fp32"]) <= 1e-4 and torch.equal(cnt["expert_counts"], g["out.expert_counts"])

@@ -57,8 +57,8 @@ def test_sd3_pipeline_cfg_loop(gpu):
                negative_pooled_prompt_embeds=neg["pooled_projections"], condition_pooled_prompt_embeds=inp["condition_pooled_projections"],
                num_inference_steps=steps, guidance_scale=gs, gate_uniforms=[uni2.to(gpu)] * steps).images
     # the same loop on the oracle
-    from unigen_amd.pipeline import flow_match_sigmas
-    sig = flow_match_sigmas(steps, sigmas=[1.0 - i * (1.0 - 1e-3) / (steps - 1) for i in range(steps)], shift=3.0)
+    from unigen_amd.pipeline import flow_match_sigmas, sd3_default_sigmas
+    sig = flow_match_sigmas(steps, sigmas=sd3_default_sigmas(steps, 3.0), shift=3.0)      # the schedule itself is pinned in tests/test_host_cpu.py
     lat = inp["hidden_states"].clone()
     for i in range(steps):
         t = torch.full((2,), sig[i] * 1000.0)

@@ -12,4 +12,4 @@ void ug_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* ug_last_error(void) { return g_err; }
-extern "C" int ug_version(void) { return 100; /* 0.1.0 */ }
+extern "C" int ug_version(void) { return 200; /* 0.2.0: fp32 verification twins, pack/unpack, one-launch combine, strided expert modulation */ }

@@ -1,6 +1,8 @@
 // HBM-bound row kernels of the UniGen forward: AdaLayerNorm-Zero modulate, q/k RMSNorm + RoPE, per-sample
 // (small-M) linears, sinusoidal timestep features, Euler step, add. All bf16 in/out, fp32 math, 16-byte accesses.
 // Rounding points mirror the reference's separate bf16 torch ops so results are comparable element-for-element.
+// Every kernel is a template over the element type (ElemT, ug_common.h): T = bf16_t is the product path, T = float the
+// fp32 VERIFICATION path (`ug_*_f32`: same code, fp32 storage, no intermediate rounding).
 #include "ug_common.h"
 #include <algorithm>
 
@@ -22,22 +24,24 @@ __device__ __forceinline__ u32x4 pack8(const float* f) {
 // ---------------------------------------------------------------------------------------------------------
 constexpr int LN_MAXCH = 8;  // chunks (of 8 elements) per lane -> D <= 4096
 
+template <typename T>
 __global__ __launch_bounds__(256) void adaln_modulate_kernel(
-    const bf16_t* __restrict__ x, int64_t ldx, int64_t x_rpb, int64_t x_bstride,
-    const bf16_t* __restrict__ shift, const bf16_t* __restrict__ scale, int64_t mod_ld, int64_t rows_per_sample,
-    bf16_t* __restrict__ out, int64_t ldo, int64_t rows, int D, float eps) {
+    const T* __restrict__ x, int64_t ldx, int64_t x_rpb, int64_t x_bstride,
+    const T* __restrict__ shift, const T* __restrict__ scale, int64_t mod_ld, int64_t rows_per_sample,
+    T* __restrict__ out, int64_t ldo, int64_t rows, int D, float eps) {
+    using E = ElemT<T>;
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int nchunk = D >> 3;
-    const bf16_t* xr = x + ug_rowmap(row, x_rpb, x_bstride) * ldx;
+    const T* xr = x + ug_rowmap(row, x_rpb, x_bstride) * ldx;
     float v[LN_MAXCH][8];
     float s = 0.f;
 #pragma unroll
     for (int t = 0; t < LN_MAXCH; ++t) {
         const int c = lane + t * 64;
         if (c < nchunk) {
-            unpack8(*(const u32x4*)(xr + c * 8), v[t]);
+            E::load8(xr + c * 8, v[t]);
 #pragma unroll
             for (int e = 0; e < 8; ++e) s += v[t][e];
         }
@@ -54,23 +58,23 @@ __global__ __launch_bounds__(256) void adaln_modulate_kernel(
     }
     const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
     const int64_t b = row / rows_per_sample;
-    const bf16_t* sh = shift + b * mod_ld;
-    const bf16_t* sc = scale + b * mod_ld;
-    bf16_t* orow = out + row * ldo;
+    const T* sh = shift + b * mod_ld;
+    const T* sc = scale + b * mod_ld;
+    T* orow = out + row * ldo;
 #pragma unroll
     for (int t = 0; t < LN_MAXCH; ++t) {
         const int c = lane + t * 64;
         if (c < nchunk) {
             float fs[8], fc[8], o[8];
-            unpack8(*(const u32x4*)(sh + c * 8), fs);
-            unpack8(*(const u32x4*)(sc + c * 8), fc);
+            E::load8(sh + c * 8, fs);
+            E::load8(sc + c * 8, fc);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const float n = rbf((v[t][e] - mean) * rstd);   // LayerNorm output (bf16 tensor in the reference)
-                const float s1 = rbf(1.0f + fc[e]);             // (1 + scale)
-                o[e] = rbf(n * s1) + fs[e];                     // * then +, each a bf16 op in the reference
+                const float n = E::rnd((v[t][e] - mean) * rstd);   // LayerNorm output (bf16 tensor in the reference)
+                const float s1 = E::rnd(1.0f + fc[e]);             // (1 + scale)
+                o[e] = E::rnd(n * s1) + fs[e];                     // * then +, each a bf16 op in the reference
             }
-            *(u32x4*)(orow + c * 8) = pack8(o);
+            E::store8(orow + c * 8, o);
         }
     }
 }
@@ -79,12 +83,13 @@ __global__ __launch_bounds__(256) void adaln_modulate_kernel(
 // q/k RMSNorm + RoPE, in place on the fused projection buffer. DH/8 lanes per head vector.
 // reference: diffusers RMSNorm (Attention.norm_q/k, norm_added_q/k) + apply_rotary_emb; src/UniGenUtils.py:561-599
 // ---------------------------------------------------------------------------------------------------------
-template <int DH>
+template <typename T, int DH>
 __global__ __launch_bounds__(256) void qk_rmsnorm_rope_kernel(
-    bf16_t* __restrict__ buf, int64_t ld, int64_t total_rows, int64_t rows_per_batch, int64_t batch_stride_rows,
-    int64_t pos_offset, int64_t q_off, int64_t k_off, int heads, const bf16_t* __restrict__ wq_a, const bf16_t* __restrict__ wk_a, const bf16_t* __restrict__ wq_b,
-    const bf16_t* __restrict__ wk_b, int64_t split, const float* __restrict__ cos_tab,
+    T* __restrict__ buf, int64_t ld, int64_t total_rows, int64_t rows_per_batch, int64_t batch_stride_rows,
+    int64_t pos_offset, int64_t q_off, int64_t k_off, int heads, const T* __restrict__ wq_a, const T* __restrict__ wk_a, const T* __restrict__ wq_b,
+    const T* __restrict__ wk_b, int64_t split, const float* __restrict__ cos_tab,
     const float* __restrict__ sin_tab, float eps) {
+    using E = ElemT<T>;
     constexpr int LPV = DH / 8;                 // lanes per head vector
     constexpr int VPW = 64 / LPV;               // vectors per wave
     const int lane = threadIdx.x & 63;
@@ -103,10 +108,10 @@ __global__ __launch_bounds__(256) void qk_rmsnorm_rope_kernel(
     const int64_t bidx = bidx_u;
     const int64_t rr = row - bidx_u * (unsigned)rows_per_batch;
     const int64_t pos = pos_offset + rr;
-    bf16_t* p = buf + (bidx * batch_stride_rows + rr) * ld + (which == 0 ? q_off : k_off) + (int64_t)h * DH + sub * 8;
+    T* p = buf + (bidx * batch_stride_rows + rr) * ld + (which == 0 ? q_off : k_off) + (int64_t)h * DH + sub * 8;
     float x[8];
-    unpack8(*(const u32x4*)p, x);
-    const bf16_t* w = (pos < split) ? (which == 0 ? wq_a : wk_a) : (which == 0 ? wq_b : wk_b);
+    E::load8(p, x);
+    const T* w = (pos < split) ? (which == 0 ? wq_a : wk_a) : (which == 0 ? wq_b : wk_b);
     if (w) {
         float ss = 0.f;
 #pragma unroll
@@ -115,9 +120,9 @@ __global__ __launch_bounds__(256) void qk_rmsnorm_rope_kernel(
         for (int o = LPV / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
         const float rs = rsqrtf(ss / (float)DH + eps);
         float wf[8];
-        unpack8(*(const u32x4*)(w + sub * 8), wf);
+        E::load8(w + sub * 8, wf);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) x[e] = rbf(rbf(x[e] * rs) * wf[e]);
+        for (int e = 0; e < 8; ++e) x[e] = E::rnd(E::rnd(x[e] * rs) * wf[e]);
     }
     if (cos_tab) {
         const float* cp = cos_tab + pos * DH + sub * 8;
@@ -135,7 +140,7 @@ __global__ __launch_bounds__(256) void qk_rmsnorm_rope_kernel(
 #pragma unroll
         for (int e = 0; e < 8; ++e) x[e] = o[e];
     }
-    if (active) *(u32x4*)p = pack8(x);
+    if (active) E::store8(p, x);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -236,139 +241,199 @@ __global__ __launch_bounds__(256) void small_linear_kernel(
     }
 }
 
-__global__ void timestep_embed_kernel(const float* __restrict__ t, bf16_t* __restrict__ out, int64_t ldo, int B, int dim) {
+// fp32 verification twin of small_linear_kernel: one wave per output column, fp32 x / W / bias / R / out, no rounding.
+__global__ __launch_bounds__(256) void small_linear_f32_kernel(
+    const float* __restrict__ x, int64_t ldx, const float* __restrict__ W, int64_t ldw, const float* __restrict__ bias,
+    const float* __restrict__ R, int64_t ldr, float* __restrict__ out, int64_t ldo, int M, int64_t N, int K, int act_in) {
+    const int lane = threadIdx.x & 63;
+    const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const float* w = W + n * ldw;
+    for (int m = 0; m < M; ++m) {
+        float acc = 0.f;
+        for (int k = lane; k < K; k += 64) {
+            float xv = x[(int64_t)m * ldx + k];
+            if (act_in == 1) xv = xv / (1.0f + expf(-xv));
+            acc += xv * w[k];
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) {
+            float v = acc + (bias ? bias[n] : 0.f);
+            if (R) v += R[(int64_t)m * ldr + n];
+            out[(int64_t)m * ldo + n] = v;
+        }
+    }
+}
+
+template <typename T>
+__global__ void timestep_embed_kernel(const float* __restrict__ t, T* __restrict__ out, int64_t ldo, int B, int dim) {
     const int half = dim >> 1;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * half) return;
     const int b = i / half, k = i - b * half;
     const float f = expf(-9.210340371976184f * (float)k / (float)half);  // exp(-ln(10000) k / half)
     const float a = t[b] * f;
-    out[(int64_t)b * ldo + k] = f2bf(cosf(a));          // flip_sin_to_cos=True -> [cos | sin]
-    out[(int64_t)b * ldo + half + k] = f2bf(sinf(a));
+    ElemT<T>::st(out + (int64_t)b * ldo + k, cosf(a));          // flip_sin_to_cos=True -> [cos | sin]
+    ElemT<T>::st(out + (int64_t)b * ldo + half + k, sinf(a));
 }
 
-__global__ void euler_step_kernel(bf16_t* __restrict__ x, const bf16_t* __restrict__ v, float dt, int64_t nchunk) {
+template <typename T>
+__global__ void euler_step_kernel(T* __restrict__ x, const T* __restrict__ v, float dt, int64_t nchunk) {
     for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < nchunk; c += (int64_t)gridDim.x * blockDim.x) {
         float a[8], b[8];
-        unpack8(*(const u32x4*)(x + c * 8), a);
-        unpack8(*(const u32x4*)(v + c * 8), b);
+        ElemT<T>::load8(x + c * 8, a);
+        ElemT<T>::load8(v + c * 8, b);
 #pragma unroll
         for (int e = 0; e < 8; ++e) a[e] = a[e] + dt * b[e];
-        *(u32x4*)(x + c * 8) = pack8(a);
+        ElemT<T>::store8(x + c * 8, a);
     }
 }
 
-__global__ void add_kernel(const bf16_t* __restrict__ a, int64_t lda, const bf16_t* __restrict__ b, int64_t ldb,
-                           bf16_t* __restrict__ out, int64_t ldo, int64_t rows, int chunks_per_row) {
+template <typename T>
+__global__ void add_kernel(const T* __restrict__ a, int64_t lda, const T* __restrict__ b, int64_t ldb,
+                           T* __restrict__ out, int64_t ldo, int64_t rows, int chunks_per_row) {
     const int64_t total = rows * chunks_per_row;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = i / chunks_per_row; const int c = (int)(i - r * chunks_per_row);
         float fa[8], fb[8];
-        unpack8(*(const u32x4*)(a + r * lda + c * 8), fa);
-        unpack8(*(const u32x4*)(b + r * ldb + c * 8), fb);
+        ElemT<T>::load8(a + r * lda + c * 8, fa);
+        ElemT<T>::load8(b + r * ldb + c * 8, fb);
 #pragma unroll
         for (int e = 0; e < 8; ++e) fa[e] += fb[e];
-        *(u32x4*)(out + r * ldo + c * 8) = pack8(fa);
+        ElemT<T>::store8(out + r * ldo + c * 8, fa);
     }
 }
 
-__global__ void cfg_combine_kernel(const bf16_t* __restrict__ u, const bf16_t* __restrict__ t, float gs, bf16_t* __restrict__ out, int64_t nchunk) {
+template <typename T>
+__global__ void cfg_combine_kernel(const T* __restrict__ u, const T* __restrict__ t, float gs, T* __restrict__ out, int64_t nchunk) {
+    using E = ElemT<T>;
     for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < nchunk; c += (int64_t)gridDim.x * blockDim.x) {
         float a[8], b[8];
-        unpack8(*(const u32x4*)(u + c * 8), a);
-        unpack8(*(const u32x4*)(t + c * 8), b);
+        E::load8(u + c * 8, a);
+        E::load8(t + c * 8, b);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) a[e] = a[e] + rbf(gs * rbf(b[e] - a[e]));
-        *(u32x4*)(out + c * 8) = pack8(a);
+        for (int e = 0; e < 8; ++e) a[e] = a[e] + E::rnd(gs * E::rnd(b[e] - a[e]));
+        E::store8(out + c * 8, a);
     }
 }
 
-__global__ void add_rowbcast_f32_kernel(bf16_t* __restrict__ x, int64_t ldx, const float* __restrict__ t, int64_t ldt, int64_t rows,
+template <typename T>
+__global__ void add_rowbcast_f32_kernel(T* __restrict__ x, int64_t ldx, const float* __restrict__ t, int64_t ldt, int64_t rows,
                                         int64_t rpb, int chunks_per_row) {
     const int64_t total = rows * chunks_per_row;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = i / chunks_per_row; const int c = (int)(i - r * chunks_per_row);
         float f[8];
-        unpack8(*(const u32x4*)(x + r * ldx + c * 8), f);
+        ElemT<T>::load8(x + r * ldx + c * 8, f);
         const float* tp = t + (r % rpb) * ldt + c * 8;
         const f32x4 a = *(const f32x4*)tp, b = *(const f32x4*)(tp + 4);
         f[0] += a[0]; f[1] += a[1]; f[2] += a[2]; f[3] += a[3]; f[4] += b[0]; f[5] += b[1]; f[6] += b[2]; f[7] += b[3];
-        *(u32x4*)(x + r * ldx + c * 8) = pack8(f);
+        ElemT<T>::store8(x + r * ldx + c * 8, f);
     }
 }
 
-__global__ void gather_rows_kernel(const bf16_t* __restrict__ src, int64_t ld_src, const int32_t* __restrict__ idx, bf16_t* __restrict__ out,
+template <typename T>
+__global__ void gather_rows_kernel(const T* __restrict__ src, int64_t ld_src, const int32_t* __restrict__ idx, T* __restrict__ out,
                                    int64_t ld_out, int64_t n, int chunks_per_row) {
     const int64_t total = n * chunks_per_row;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = i / chunks_per_row; const int c = (int)(i - r * chunks_per_row);
         const int s = idx[r];
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (s >= 0) v = *(const u32x4*)(src + (int64_t)s * ld_src + c * 8);
-        *(u32x4*)(out + r * ld_out + c * 8) = v;
+        if (s >= 0) {
+            float f[8];
+            ElemT<T>::load8(src + (int64_t)s * ld_src + c * 8, f);       // exact: a bf16 -> f32 -> bf16 round trip is the identity
+            ElemT<T>::store8(out + r * ld_out + c * 8, f);
+        } else {
+            ElemT<T>::zero8(out + r * ld_out + c * 8);
+        }
+    }
+}
+
+// FluxPipeline._pack_latents / _unpack_latents (src/UniGenPipeline.py:641,796): [B, C, H, W] <-> [B, (H/2)(W/2), 4C] with
+// packed column c*4 + dy*2 + dx = pixel (2i + dy, 2j + dx) of channel c. One thread per packed element; pure data movement.
+template <typename T, bool PACK>
+__global__ void pack_latents_kernel(const T* __restrict__ src, T* __restrict__ dst, int B, int C, int H, int W) {
+    const int64_t total = (int64_t)B * C * H * W;
+    const int h2 = H >> 1, w2 = W >> 1;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        // i enumerates the PACKED tensor [b][tok][c][dy][dx]
+        int64_t r = i;
+        const int dx = (int)(r & 1); r >>= 1;
+        const int dy = (int)(r & 1); r >>= 1;
+        const int c = (int)(r % C); r /= C;
+        const int tok = (int)(r % ((int64_t)h2 * w2));
+        const int b = (int)(r / ((int64_t)h2 * w2));
+        const int ti = tok / w2, tj = tok - ti * w2;
+        const int64_t img = (((int64_t)b * C + c) * H + (2 * ti + dy)) * W + (2 * tj + dx);
+        if (PACK) dst[i] = src[img]; else dst[img] = src[i];
     }
 }
 
 }  // namespace
 
-extern "C" int ug_cfg_combine(const void* uncond, const void* text, float guidance_scale, void* out, int64_t n, ug_stream_t stream) {
+// ---------------------------------------------------------------------------------------------------------------------
+// host side: one implementation per op, instantiated for bf16 (product) and fp32 (verification)
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+
+template <typename T>
+int cfg_combine_impl(const void* uncond, const void* text, float guidance_scale, void* out, int64_t n, ug_stream_t stream) {
     if (n == 0) return UG_OK;
     UG_REQUIRE(uncond && text && out && n > 0 && n % 8 == 0 && ug_aligned(uncond, 16) && ug_aligned(text, 16) && ug_aligned(out, 16),
                UG_ERR_BAD_ALIGN, "ug_cfg_combine: n must be a multiple of 8 and pointers 16-byte aligned");
     const int64_t nchunk = n / 8;
     const unsigned grid = (unsigned)std::min<int64_t>((nchunk + 255) / 256, 2048);
-    hipLaunchKernelGGL(cfg_combine_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)uncond, (const bf16_t*)text,
-                       guidance_scale, (bf16_t*)out, nchunk);
+    hipLaunchKernelGGL(cfg_combine_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)uncond, (const T*)text,
+                       guidance_scale, (T*)out, nchunk);
     UG_CHECK_LAUNCH("ug_cfg_combine");
     return UG_OK;
 }
 
-extern "C" int ug_add_rowbcast_f32(void* x, int64_t ldx, const float* table, int64_t ldt, int64_t rows, int64_t rows_per_batch, int64_t D,
-                                   ug_stream_t stream) {
+template <typename T>
+int add_rowbcast_impl(void* x, int64_t ldx, const float* table, int64_t ldt, int64_t rows, int64_t rows_per_batch, int64_t D, ug_stream_t stream) {
     if (rows == 0 || D == 0) return UG_OK;
     UG_REQUIRE(x && table && rows > 0 && rows_per_batch > 0 && D > 0, UG_ERR_BAD_SHAPE, "ug_add_rowbcast_f32: bad arguments");
     UG_REQUIRE(D % 8 == 0 && ldx % 8 == 0 && ldt % 4 == 0 && ug_aligned(x, 16) && ug_aligned(table, 16), UG_ERR_BAD_ALIGN,
                "ug_add_rowbcast_f32: 16-byte alignment required");
     const int64_t total = rows * (D / 8);
     const unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, 2048);
-    hipLaunchKernelGGL(add_rowbcast_f32_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (bf16_t*)x, ldx, table, ldt, rows, rows_per_batch, (int)(D / 8));
+    hipLaunchKernelGGL(add_rowbcast_f32_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (T*)x, ldx, table, ldt, rows, rows_per_batch, (int)(D / 8));
     UG_CHECK_LAUNCH("ug_add_rowbcast_f32");
     return UG_OK;
 }
 
-extern "C" int ug_gather_rows(const void* src, int64_t ld_src, const int32_t* idx, void* out, int64_t ld_out, int64_t n, int64_t W,
-                              ug_stream_t stream) {
+template <typename T>
+int gather_rows_impl(const void* src, int64_t ld_src, const int32_t* idx, void* out, int64_t ld_out, int64_t n, int64_t W, ug_stream_t stream) {
     if (n == 0 || W == 0) return UG_OK;
     UG_REQUIRE(src && idx && out && n > 0 && W > 0, UG_ERR_BAD_SHAPE, "ug_gather_rows: bad arguments");
     UG_REQUIRE(W % 8 == 0 && ld_src % 8 == 0 && ld_out % 8 == 0 && ug_aligned(src, 16) && ug_aligned(out, 16), UG_ERR_BAD_ALIGN,
                "ug_gather_rows: 16-byte alignment required");
     const int64_t total = n * (W / 8);
     const unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, 4096);
-    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, ld_src, idx, (bf16_t*)out, ld_out, n, (int)(W / 8));
+    hipLaunchKernelGGL(gather_rows_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)src, ld_src, idx, (T*)out, ld_out, n, (int)(W / 8));
     UG_CHECK_LAUNCH("ug_gather_rows");
     return UG_OK;
 }
 
-extern "C" int ug_adaln_modulate(const void* x, int64_t ldx, int64_t x_rpb, int64_t x_bstride, const void* shift,
-                                 const void* scale, int64_t mod_ld, int64_t rows_per_sample, void* out, int64_t ldo,
-                                 int64_t rows, int64_t D, float eps, ug_stream_t stream) {
+template <typename T>
+int adaln_modulate_impl(const void* x, int64_t ldx, int64_t x_rpb, int64_t x_bstride, const void* shift, const void* scale, int64_t mod_ld,
+                        int64_t rows_per_sample, void* out, int64_t ldo, int64_t rows, int64_t D, float eps, ug_stream_t stream) {
     if (rows == 0) return UG_OK;
     UG_REQUIRE(x && shift && scale && out && rows > 0 && rows_per_sample > 0, UG_ERR_BAD_SHAPE, "ug_adaln_modulate: bad arguments");
     UG_REQUIRE(D % 8 == 0 && D > 0 && D <= LN_MAXCH * 64 * 8, UG_ERR_UNSUPPORTED, "ug_adaln_modulate: D=%lld must be a multiple of 8 and <= 4096", (long long)D);
     UG_REQUIRE(ldx % 8 == 0 && ldo % 8 == 0 && mod_ld % 8 == 0 && ug_aligned(x, 16) && ug_aligned(out, 16) &&
                ug_aligned(shift, 16) && ug_aligned(scale, 16), UG_ERR_BAD_ALIGN, "ug_adaln_modulate: 16-byte alignment required");
     const unsigned grid = (unsigned)((rows + 3) / 4);
-    hipLaunchKernelGGL(adaln_modulate_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, x_rpb,
-                       x_bstride, (const bf16_t*)shift, (const bf16_t*)scale, mod_ld, rows_per_sample, (bf16_t*)out, ldo,
-                       rows, (int)D, eps);
+    hipLaunchKernelGGL(adaln_modulate_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)x, ldx, x_rpb,
+                       x_bstride, (const T*)shift, (const T*)scale, mod_ld, rows_per_sample, (T*)out, ldo, rows, (int)D, eps);
     UG_CHECK_LAUNCH("ug_adaln_modulate");
     return UG_OK;
 }
 
-extern "C" int ug_qk_rmsnorm_rope(void* buf, int64_t ld, int64_t batches, int64_t rows_per_batch, int64_t batch_stride_rows,
-                                  int64_t pos_offset, int64_t q_off, int64_t k_off, int32_t heads, int32_t dh, const void* wq_a, const void* wk_a,
-                                  const void* wq_b, const void* wk_b, int64_t split, const float* cos_tab,
-                                  const float* sin_tab, float eps, ug_stream_t stream) {
+template <typename T>
+int qk_rmsnorm_rope_impl(void* buf, int64_t ld, int64_t batches, int64_t rows_per_batch, int64_t batch_stride_rows, int64_t pos_offset,
+                         int64_t q_off, int64_t k_off, int32_t heads, int32_t dh, const void* wq_a, const void* wk_a, const void* wq_b,
+                         const void* wk_b, int64_t split, const float* cos_tab, const float* sin_tab, float eps, ug_stream_t stream) {
     const int64_t total_rows = batches * rows_per_batch;
     if (total_rows == 0) return UG_OK;
     UG_REQUIRE(buf && heads > 0 && k_off >= 0 && batch_stride_rows >= rows_per_batch && pos_offset >= 0, UG_ERR_BAD_SHAPE,
@@ -388,15 +453,108 @@ extern "C" int ug_qk_rmsnorm_rope(void* buf, int64_t ld, int64_t batches, int64_
     const unsigned grid = (unsigned)((waves + 3) / 4);
     hipStream_t s = (hipStream_t)stream;
     if (dh == 128)
-        hipLaunchKernelGGL(qk_rmsnorm_rope_kernel<128>, dim3(grid), dim3(256), 0, s, (bf16_t*)buf, ld, total_rows, rows_per_batch,
-                           batch_stride_rows, pos_offset, q_off, k_off, heads, (const bf16_t*)wq_a, (const bf16_t*)wk_a, (const bf16_t*)wq_b,
-                           (const bf16_t*)wk_b, split, cos_tab, sin_tab, eps);
+        hipLaunchKernelGGL((qk_rmsnorm_rope_kernel<T, 128>), dim3(grid), dim3(256), 0, s, (T*)buf, ld, total_rows, rows_per_batch,
+                           batch_stride_rows, pos_offset, q_off, k_off, heads, (const T*)wq_a, (const T*)wk_a, (const T*)wq_b,
+                           (const T*)wk_b, split, cos_tab, sin_tab, eps);
     else
-        hipLaunchKernelGGL(qk_rmsnorm_rope_kernel<64>, dim3(grid), dim3(256), 0, s, (bf16_t*)buf, ld, total_rows, rows_per_batch,
-                           batch_stride_rows, pos_offset, q_off, k_off, heads, (const bf16_t*)wq_a, (const bf16_t*)wk_a, (const bf16_t*)wq_b,
-                           (const bf16_t*)wk_b, split, cos_tab, sin_tab, eps);
+        hipLaunchKernelGGL((qk_rmsnorm_rope_kernel<T, 64>), dim3(grid), dim3(256), 0, s, (T*)buf, ld, total_rows, rows_per_batch,
+                           batch_stride_rows, pos_offset, q_off, k_off, heads, (const T*)wq_a, (const T*)wk_a, (const T*)wq_b,
+                           (const T*)wk_b, split, cos_tab, sin_tab, eps);
     UG_CHECK_LAUNCH("ug_qk_rmsnorm_rope");
     return UG_OK;
+}
+
+template <typename T>
+int timestep_embed_impl(const float* t, void* out, int64_t ldo, int64_t B, int32_t dim, ug_stream_t stream) {
+    if (B == 0) return UG_OK;
+    UG_REQUIRE(t && out && B > 0 && dim > 0 && dim % 2 == 0 && ldo >= dim, UG_ERR_BAD_SHAPE, "ug_timestep_embed: bad arguments");
+    const int total = (int)B * (dim / 2);
+    hipLaunchKernelGGL(timestep_embed_kernel<T>, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, t, (T*)out, ldo, (int)B, dim);
+    UG_CHECK_LAUNCH("ug_timestep_embed");
+    return UG_OK;
+}
+
+template <typename T>
+int euler_step_impl(void* x, const void* v, float dt, int64_t n, ug_stream_t stream) {
+    if (n == 0) return UG_OK;
+    UG_REQUIRE(x && v && n > 0 && n % 8 == 0 && ug_aligned(x, 16) && ug_aligned(v, 16), UG_ERR_BAD_ALIGN,
+               "ug_euler_step: n must be a multiple of 8 and pointers 16-byte aligned");
+    const int64_t nchunk = n / 8;
+    const unsigned grid = (unsigned)std::min<int64_t>((nchunk + 255) / 256, 2048);
+    hipLaunchKernelGGL(euler_step_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (T*)x, (const T*)v, dt, nchunk);
+    UG_CHECK_LAUNCH("ug_euler_step");
+    return UG_OK;
+}
+
+template <typename T>
+int add_impl(const void* a, int64_t lda, const void* b, int64_t ldb, void* out, int64_t ldo, int64_t rows, int64_t D, ug_stream_t stream) {
+    if (rows == 0 || D == 0) return UG_OK;
+    UG_REQUIRE(a && b && out && rows > 0 && D > 0, UG_ERR_BAD_SHAPE, "ug_add: bad arguments");
+    UG_REQUIRE(D % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldo % 8 == 0 && ug_aligned(a, 16) && ug_aligned(b, 16) && ug_aligned(out, 16),
+               UG_ERR_BAD_ALIGN, "ug_add: 16-byte alignment required");
+    const int64_t total = rows * (D / 8);
+    const unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, 2048);
+    hipLaunchKernelGGL(add_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)a, lda, (const T*)b, ldb, (T*)out, ldo, rows, (int)(D / 8));
+    UG_CHECK_LAUNCH("ug_add");
+    return UG_OK;
+}
+
+template <typename T, bool PACK>
+int pack_latents_impl(const void* src, void* dst, int64_t B, int64_t C, int64_t H, int64_t W, ug_stream_t stream) {
+    if (B == 0) return UG_OK;
+    UG_REQUIRE(src && dst && B > 0 && C > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, UG_ERR_BAD_SHAPE,
+               "ug_pack_latents: need [B, C, H, W] with even H and W");
+    UG_REQUIRE(B * C * H * W < (1ll << 40) && H < (1 << 20) && W < (1 << 20) && C < (1 << 20) && B < (1 << 20), UG_ERR_UNSUPPORTED, "ug_pack_latents: too large");
+    const int64_t total = B * C * H * W;
+    const unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL((pack_latents_kernel<T, PACK>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)src, (T*)dst, (int)B, (int)C, (int)H, (int)W);
+    UG_CHECK_LAUNCH("ug_pack_latents");
+    return UG_OK;
+}
+
+}  // namespace
+
+extern "C" int ug_cfg_combine(const void* u, const void* t, float gs, void* out, int64_t n, ug_stream_t s) { return cfg_combine_impl<bf16_t>(u, t, gs, out, n, s); }
+extern "C" int ug_cfg_combine_f32(const void* u, const void* t, float gs, void* out, int64_t n, ug_stream_t s) { return cfg_combine_impl<float>(u, t, gs, out, n, s); }
+
+extern "C" int ug_add_rowbcast_f32(void* x, int64_t ldx, const float* table, int64_t ldt, int64_t rows, int64_t rpb, int64_t D, ug_stream_t s) {
+    return add_rowbcast_impl<bf16_t>(x, ldx, table, ldt, rows, rpb, D, s);
+}
+extern "C" int ug_add_rowbcast_f32_f32(void* x, int64_t ldx, const float* table, int64_t ldt, int64_t rows, int64_t rpb, int64_t D, ug_stream_t s) {
+    return add_rowbcast_impl<float>(x, ldx, table, ldt, rows, rpb, D, s);
+}
+
+extern "C" int ug_gather_rows(const void* src, int64_t ld_src, const int32_t* idx, void* out, int64_t ld_out, int64_t n, int64_t W, ug_stream_t s) {
+    return gather_rows_impl<bf16_t>(src, ld_src, idx, out, ld_out, n, W, s);
+}
+extern "C" int ug_gather_rows_f32(const void* src, int64_t ld_src, const int32_t* idx, void* out, int64_t ld_out, int64_t n, int64_t W, ug_stream_t s) {
+    return gather_rows_impl<float>(src, ld_src, idx, out, ld_out, n, W, s);
+}
+
+extern "C" int ug_adaln_modulate(const void* x, int64_t ldx, int64_t x_rpb, int64_t x_bstride, const void* shift,
+                                 const void* scale, int64_t mod_ld, int64_t rows_per_sample, void* out, int64_t ldo,
+                                 int64_t rows, int64_t D, float eps, ug_stream_t stream) {
+    return adaln_modulate_impl<bf16_t>(x, ldx, x_rpb, x_bstride, shift, scale, mod_ld, rows_per_sample, out, ldo, rows, D, eps, stream);
+}
+extern "C" int ug_adaln_modulate_f32(const void* x, int64_t ldx, int64_t x_rpb, int64_t x_bstride, const void* shift,
+                                     const void* scale, int64_t mod_ld, int64_t rows_per_sample, void* out, int64_t ldo,
+                                     int64_t rows, int64_t D, float eps, ug_stream_t stream) {
+    return adaln_modulate_impl<float>(x, ldx, x_rpb, x_bstride, shift, scale, mod_ld, rows_per_sample, out, ldo, rows, D, eps, stream);
+}
+
+extern "C" int ug_qk_rmsnorm_rope(void* buf, int64_t ld, int64_t batches, int64_t rows_per_batch, int64_t batch_stride_rows,
+                                  int64_t pos_offset, int64_t q_off, int64_t k_off, int32_t heads, int32_t dh, const void* wq_a, const void* wk_a,
+                                  const void* wq_b, const void* wk_b, int64_t split, const float* cos_tab,
+                                  const float* sin_tab, float eps, ug_stream_t stream) {
+    return qk_rmsnorm_rope_impl<bf16_t>(buf, ld, batches, rows_per_batch, batch_stride_rows, pos_offset, q_off, k_off, heads, dh, wq_a, wk_a, wq_b, wk_b,
+                                        split, cos_tab, sin_tab, eps, stream);
+}
+extern "C" int ug_qk_rmsnorm_rope_f32(void* buf, int64_t ld, int64_t batches, int64_t rows_per_batch, int64_t batch_stride_rows,
+                                      int64_t pos_offset, int64_t q_off, int64_t k_off, int32_t heads, int32_t dh, const void* wq_a, const void* wk_a,
+                                      const void* wq_b, const void* wk_b, int64_t split, const float* cos_tab,
+                                      const float* sin_tab, float eps, ug_stream_t stream) {
+    return qk_rmsnorm_rope_impl<float>(buf, ld, batches, rows_per_batch, batch_stride_rows, pos_offset, q_off, k_off, heads, dh, wq_a, wk_a, wq_b, wk_b,
+                                       split, cos_tab, sin_tab, eps, stream);
 }
 
 extern "C" int ug_small_linear_bf16(const void* x, int64_t ldx, const void* W, int64_t ldw, const void* bias,
@@ -427,36 +585,40 @@ extern "C" int ug_small_linear_bf16(const void* x, int64_t ldx, const void* W, i
     return UG_OK;
 }
 
-extern "C" int ug_timestep_embed(const float* t, void* out, int64_t ldo, int64_t B, int32_t dim, ug_stream_t stream) {
-    if (B == 0) return UG_OK;
-    UG_REQUIRE(t && out && B > 0 && dim > 0 && dim % 2 == 0 && ldo >= dim, UG_ERR_BAD_SHAPE, "ug_timestep_embed: bad arguments");
-    const int total = (int)B * (dim / 2);
-    hipLaunchKernelGGL(timestep_embed_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, t, (bf16_t*)out, ldo, (int)B, dim);
-    UG_CHECK_LAUNCH("ug_timestep_embed");
+extern "C" int ug_small_linear_f32(const void* x, int64_t ldx, const void* W, int64_t ldw, const void* bias,
+                                   const void* R, int64_t ldr, void* out, int64_t ldo, int64_t M, int64_t N, int64_t K,
+                                   int32_t act_in, ug_stream_t stream) {
+    if (M == 0 || N == 0) return UG_OK;
+    UG_REQUIRE(x && W && out && M > 0 && N > 0 && K > 0 && M <= 64, UG_ERR_BAD_SHAPE, "ug_small_linear_f32: bad arguments");
+    UG_REQUIRE(act_in == 0 || act_in == 1, UG_ERR_UNSUPPORTED, "ug_small_linear_f32: act_in %d", act_in);
+    hipLaunchKernelGGL(small_linear_f32_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx,
+                       (const float*)W, ldw, (const float*)bias, (const float*)R, ldr, (float*)out, ldo, (int)M, N, (int)K, act_in);
+    UG_CHECK_LAUNCH("ug_small_linear_f32");
     return UG_OK;
 }
 
-extern "C" int ug_euler_step(void* x, const void* v, float dt, int64_t n, ug_stream_t stream) {
-    if (n == 0) return UG_OK;
-    UG_REQUIRE(x && v && n > 0 && n % 8 == 0 && ug_aligned(x, 16) && ug_aligned(v, 16), UG_ERR_BAD_ALIGN,
-               "ug_euler_step: n must be a multiple of 8 and pointers 16-byte aligned");
-    const int64_t nchunk = n / 8;
-    const unsigned grid = (unsigned)std::min<int64_t>((nchunk + 255) / 256, 2048);
-    hipLaunchKernelGGL(euler_step_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (bf16_t*)x, (const bf16_t*)v, dt, nchunk);
-    UG_CHECK_LAUNCH("ug_euler_step");
-    return UG_OK;
+extern "C" int ug_timestep_embed(const float* t, void* out, int64_t ldo, int64_t B, int32_t dim, ug_stream_t s) { return timestep_embed_impl<bf16_t>(t, out, ldo, B, dim, s); }
+extern "C" int ug_timestep_embed_f32(const float* t, void* out, int64_t ldo, int64_t B, int32_t dim, ug_stream_t s) { return timestep_embed_impl<float>(t, out, ldo, B, dim, s); }
+
+extern "C" int ug_euler_step(void* x, const void* v, float dt, int64_t n, ug_stream_t s) { return euler_step_impl<bf16_t>(x, v, dt, n, s); }
+extern "C" int ug_euler_step_f32(void* x, const void* v, float dt, int64_t n, ug_stream_t s) { return euler_step_impl<float>(x, v, dt, n, s); }
+
+extern "C" int ug_add_bf16(const void* a, int64_t lda, const void* b, int64_t ldb, void* out, int64_t ldo, int64_t rows, int64_t D, ug_stream_t s) {
+    return add_impl<bf16_t>(a, lda, b, ldb, out, ldo, rows, D, s);
+}
+extern "C" int ug_add_f32(const void* a, int64_t lda, const void* b, int64_t ldb, void* out, int64_t ldo, int64_t rows, int64_t D, ug_stream_t s) {
+    return add_impl<float>(a, lda, b, ldb, out, ldo, rows, D, s);
 }
 
-extern "C" int ug_add_bf16(const void* a, int64_t lda, const void* b, int64_t ldb, void* out, int64_t ldo, int64_t rows,
-                           int64_t D, ug_stream_t stream) {
-    if (rows == 0 || D == 0) return UG_OK;
-    UG_REQUIRE(a && b && out && rows > 0 && D > 0, UG_ERR_BAD_SHAPE, "ug_add_bf16: bad arguments");
-    UG_REQUIRE(D % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldo % 8 == 0 && ug_aligned(a, 16) && ug_aligned(b, 16) && ug_aligned(out, 16),
-               UG_ERR_BAD_ALIGN, "ug_add_bf16: 16-byte alignment required");
-    const int64_t total = rows * (D / 8);
-    const unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, 2048);
-    hipLaunchKernelGGL(add_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a, lda, (const bf16_t*)b, ldb,
-                       (bf16_t*)out, ldo, rows, (int)(D / 8));
-    UG_CHECK_LAUNCH("ug_add_bf16");
-    return UG_OK;
+extern "C" int ug_pack_latents(const void* latents, void* packed, int64_t B, int64_t C, int64_t H, int64_t W, ug_stream_t s) {
+    return pack_latents_impl<bf16_t, true>(latents, packed, B, C, H, W, s);
+}
+extern "C" int ug_unpack_latents(const void* packed, void* latents, int64_t B, int64_t C, int64_t H, int64_t W, ug_stream_t s) {
+    return pack_latents_impl<bf16_t, false>(packed, latents, B, C, H, W, s);
+}
+extern "C" int ug_pack_latents_f32(const void* latents, void* packed, int64_t B, int64_t C, int64_t H, int64_t W, ug_stream_t s) {
+    return pack_latents_impl<float, true>(latents, packed, B, C, H, W, s);
+}
+extern "C" int ug_unpack_latents_f32(const void* packed, void* latents, int64_t B, int64_t C, int64_t H, int64_t W, ug_stream_t s) {
+    return pack_latents_impl<float, false>(packed, latents, B, C, H, W, s);
 }

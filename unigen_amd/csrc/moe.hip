@@ -8,22 +8,14 @@
 
 namespace {
 
-__device__ __forceinline__ void unpack8(const u32x4 v, float* f) {
-    f[0] = bflo(v.x); f[1] = bfhi(v.x); f[2] = bflo(v.y); f[3] = bfhi(v.y);
-    f[4] = bflo(v.z); f[5] = bfhi(v.z); f[6] = bflo(v.w); f[7] = bfhi(v.w);
-}
-__device__ __forceinline__ u32x4 pack8(const float* f) {
-    u32x4 v;
-    v.x = pack2bf(f[0], f[1]); v.y = pack2bf(f[2], f[3]); v.z = pack2bf(f[4], f[5]); v.w = pack2bf(f[6], f[7]);
-    return v;
-}
-
 constexpr int GATE_MAXE = 16;
 
 // one wave per token: logits[e] = sum_d bf16(x+c)[d] * wg[e][d] in fp32 (TopKGate: F.linear(input.float(), wg.float()))
-__global__ __launch_bounds__(256) void moe_gate_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ c, int64_t ld,
-                                                       const bf16_t* __restrict__ wg, int64_t S, int D, int E,
+template <typename T>
+__global__ __launch_bounds__(256) void moe_gate_kernel(const T* __restrict__ x, const T* __restrict__ c, int64_t ld,
+                                                       const T* __restrict__ wg, int64_t S, int D, int E,
                                                        float* __restrict__ gates, int32_t* __restrict__ idx) {
+    using EL = ElemT<T>;
     const int lane = threadIdx.x & 63;
     const int64_t s = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (s >= S) return;
@@ -33,15 +25,15 @@ __global__ __launch_bounds__(256) void moe_gate_kernel(const bf16_t* __restrict_
     const int nchunk = D >> 3;
     for (int ch = lane; ch < nchunk; ch += 64) {
         float a[8], b[8];
-        unpack8(*(const u32x4*)(x + s * ld + ch * 8), a);
-        unpack8(*(const u32x4*)(c + s * ld + ch * 8), b);
+        EL::load8(x + s * ld + ch * 8, a);
+        EL::load8(c + s * ld + ch * 8, b);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) a[i] = rbf(a[i] + b[i]);     // choice_expert_input = hidden + condition (bf16 add)
+        for (int i = 0; i < 8; ++i) a[i] = EL::rnd(a[i] + b[i]);     // choice_expert_input = hidden + condition (bf16 add)
 #pragma unroll
         for (int e = 0; e < GATE_MAXE; ++e) {
             if (e < E) {
                 float w[8];
-                unpack8(*(const u32x4*)(wg + (int64_t)e * D + ch * 8), w);
+                EL::load8(wg + (int64_t)e * D + ch * 8, w);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) acc[e] += a[i] * w[i];
             }
@@ -185,102 +177,152 @@ __global__ __launch_bounds__(1024) void moe_laux_kernel(const float* __restrict_
 }
 
 // one wave per (expert, slot) row
-__global__ __launch_bounds__(256) void moe_dispatch_kernel(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ add,
-                                                           const bf16_t* __restrict__ mod, int B, const int32_t* __restrict__ token_of_slot,
+template <typename T>
+__global__ __launch_bounds__(256) void moe_dispatch_kernel(const T* __restrict__ x, int64_t ldx, const T* __restrict__ add,
+                                                           const T* __restrict__ mod, int64_t mod_estride, int64_t mod_bstride,
+                                                           const int32_t* __restrict__ token_of_slot,
                                                            int64_t nslots, int capacity, int tokens_per_sample, int D,
-                                                           bf16_t* __restrict__ out) {
+                                                           T* __restrict__ out) {
+    using EL = ElemT<T>;
     const int lane = threadIdx.x & 63;
     const int64_t sl = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (sl >= nslots) return;
     const int tok = token_of_slot[sl];
-    bf16_t* orow = out + sl * D;
+    T* orow = out + sl * D;
     const int nchunk = D >> 3;
     if (tok < 0) {
-        const u32x4 z = {0u, 0u, 0u, 0u};
-        for (int ch = lane; ch < nchunk; ch += 64) *(u32x4*)(orow + ch * 8) = z;
+        for (int ch = lane; ch < nchunk; ch += 64) EL::zero8(orow + ch * 8);
         return;
     }
     const int e = (int)(sl / capacity);
     const int b = tok / tokens_per_sample;
-    const bf16_t* xr = x + (int64_t)tok * ldx;
-    const bf16_t* mr = mod ? mod + ((int64_t)e * B + b) * D : nullptr;
-    const bf16_t* ar = add ? add + sl * D : nullptr;
+    const T* xr = x + (int64_t)tok * ldx;
+    const T* mr = mod ? mod + (int64_t)e * mod_estride + (int64_t)b * mod_bstride : nullptr;
+    const T* ar = add ? add + sl * D : nullptr;
     for (int ch = lane; ch < nchunk; ch += 64) {
         float a[8], m[8];
-        unpack8(*(const u32x4*)(xr + ch * 8), a);
-        if (mr) unpack8(*(const u32x4*)(mr + ch * 8), m);
+        EL::load8(xr + ch * 8, a);
+        if (mr) EL::load8(mr + ch * 8, m);
         if (ar) {
             float t[8];
-            unpack8(*(const u32x4*)(ar + ch * 8), t);
+            EL::load8(ar + ch * 8, t);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) a[i] = rbf(a[i] + t[i]);
+            for (int i = 0; i < 8; ++i) a[i] = EL::rnd(a[i] + t[i]);
         }
         if (mr) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) a[i] *= m[i];
         }
-        *(u32x4*)(orow + ch * 8) = pack8(a);
+        EL::store8(orow + ch * 8, a);
     }
 }
 
 // one wave per token
-__global__ __launch_bounds__(256) void moe_combine_kernel(const bf16_t* __restrict__ yh, const bf16_t* __restrict__ yc,
+template <typename T>
+__global__ __launch_bounds__(256) void moe_combine_kernel(const T* __restrict__ yh, const T* __restrict__ yc,
                                                           const float* __restrict__ gates, const int32_t* __restrict__ idx,
                                                           const int32_t* __restrict__ slot, int E, int capacity,
-                                                          const bf16_t* __restrict__ xs, const bf16_t* __restrict__ cs, int64_t ld_s,
-                                                          bf16_t* __restrict__ out, int64_t ldo, int64_t S, int D, int accumulate) {
+                                                          const T* __restrict__ xs, const T* __restrict__ cs, int64_t ld_s,
+                                                          int64_t s_rpb, int64_t s_bstride,
+                                                          T* __restrict__ out, int64_t ldo, int64_t S, int D, int accumulate) {
+    using EL = ElemT<T>;
     const int lane = threadIdx.x & 63;
     const int64_t s = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (s >= S) return;
     const int e = idx[s];
     const int sl = slot[s];
-    const float p = rbf(gates[s * E + e]);                 // combine_weights.type_as(input)
+    const float p = EL::rnd(gates[s * E + e]);             // combine_weights.type_as(input)
+    const int64_t srow = ug_rowmap(s, s_rpb, s_bstride);   // token s of the shared-expert streams (they live in a [B][2N] buffer)
     const int64_t yrow = ((int64_t)e * capacity + (sl < 0 ? 0 : sl)) * D;
     const int nchunk = D >> 3;
     for (int ch = lane; ch < nchunk; ch += 64) {
         float h[8], c[8], o[8];
         if (sl >= 0) {
-            unpack8(*(const u32x4*)(yh + yrow + ch * 8), h);
-            unpack8(*(const u32x4*)(yc + yrow + ch * 8), c);
+            EL::load8(yh + yrow + ch * 8, h);
+            EL::load8(yc + yrow + ch * 8, c);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) { h[i] = rbf(p * h[i]); c[i] = rbf(p * c[i]); }
+            for (int i = 0; i < 8; ++i) { h[i] = EL::rnd(p * h[i]); c[i] = EL::rnd(p * c[i]); }
         } else {
 #pragma unroll
             for (int i = 0; i < 8; ++i) { h[i] = 0.f; c[i] = 0.f; }
         }
         if (xs) {
             float a[8], b[8];
-            unpack8(*(const u32x4*)(xs + s * ld_s + ch * 8), a);
-            unpack8(*(const u32x4*)(cs + s * ld_s + ch * 8), b);
+            EL::load8(xs + srow * ld_s + ch * 8, a);
+            EL::load8(cs + srow * ld_s + ch * 8, b);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) o[i] = rbf(a[i] + h[i]) + rbf(b[i] + c[i]);
+            for (int i = 0; i < 8; ++i) o[i] = EL::rnd(a[i] + h[i]) + EL::rnd(b[i] + c[i]);
         } else {
 #pragma unroll
             for (int i = 0; i < 8; ++i) o[i] = h[i] + c[i];
         }
         if (accumulate) {
             float prev[8];
-            unpack8(*(const u32x4*)(out + s * ldo + ch * 8), prev);
+            EL::load8(out + s * ldo + ch * 8, prev);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) o[i] = prev[i] + rbf(o[i]);
+            for (int i = 0; i < 8; ++i) o[i] = prev[i] + EL::rnd(o[i]);
         }
-        *(u32x4*)(out + s * ldo + ch * 8) = pack8(o);
+        EL::store8(out + s * ldo + ch * 8, o);
     }
 }
 
 }  // namespace
 
-extern "C" int ug_moe_gate_top1(const void* x, const void* c, int64_t ld, const void* wg, int64_t S, int64_t D, int32_t E,
-                                float* gates, int32_t* idx, ug_stream_t stream) {
+namespace {
+
+template <typename T>
+int moe_gate_impl(const void* x, const void* c, int64_t ld, const void* wg, int64_t S, int64_t D, int32_t E, float* gates, int32_t* idx, ug_stream_t stream) {
     if (S == 0) return UG_OK;
     UG_REQUIRE(x && c && wg && gates && idx && S > 0 && D > 0, UG_ERR_BAD_SHAPE, "ug_moe_gate_top1: bad arguments");
     UG_REQUIRE(E >= 1 && E <= GATE_MAXE, UG_ERR_UNSUPPORTED, "ug_moe_gate_top1: E=%d not in [1,%d]", E, GATE_MAXE);
     UG_REQUIRE(D % 8 == 0 && ld % 8 == 0 && ug_aligned(x, 16) && ug_aligned(c, 16) && ug_aligned(wg, 16), UG_ERR_BAD_ALIGN,
                "ug_moe_gate_top1: 16-byte alignment required");
-    hipLaunchKernelGGL(moe_gate_kernel, dim3((unsigned)((S + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
-                       (const bf16_t*)c, ld, (const bf16_t*)wg, S, (int)D, (int)E, gates, idx);
+    hipLaunchKernelGGL(moe_gate_kernel<T>, dim3((unsigned)((S + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const T*)x,
+                       (const T*)c, ld, (const T*)wg, S, (int)D, (int)E, gates, idx);
     UG_CHECK_LAUNCH("ug_moe_gate_top1");
     return UG_OK;
+}
+
+template <typename T>
+int moe_dispatch_impl(const void* x, int64_t ldx, const void* add, const void* mod, int64_t mod_estride, int64_t mod_bstride,
+                      const int32_t* token_of_slot, int32_t E, int64_t capacity, int64_t tokens_per_sample, int64_t D, void* out, ug_stream_t stream) {
+    UG_REQUIRE(x && token_of_slot && out && E > 0 && capacity > 0 && tokens_per_sample > 0, UG_ERR_BAD_SHAPE,
+               "ug_moe_dispatch_modulate: bad arguments");
+    UG_REQUIRE(D % 8 == 0 && ldx % 8 == 0 && ug_aligned(x, 16) && (!mod || (ug_aligned(mod, 16) && mod_estride % 8 == 0 && mod_bstride % 8 == 0)) &&
+               ug_aligned(out, 16) && (!add || ug_aligned(add, 16)),
+               UG_ERR_BAD_ALIGN, "ug_moe_dispatch_modulate: 16-byte alignment required");
+    const int64_t nslots = (int64_t)E * capacity;
+    hipLaunchKernelGGL(moe_dispatch_kernel<T>, dim3((unsigned)((nslots + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const T*)x, ldx,
+                       (const T*)add, (const T*)mod, mod_estride, mod_bstride, token_of_slot, nslots, (int)capacity, (int)tokens_per_sample,
+                       (int)D, (T*)out);
+    UG_CHECK_LAUNCH("ug_moe_dispatch_modulate");
+    return UG_OK;
+}
+
+template <typename T>
+int moe_combine_impl(const void* yh, const void* yc, const float* gates, const int32_t* idx, const int32_t* slot, int32_t E,
+                     int64_t capacity, const void* xs, const void* cs, int64_t ld_s, int64_t s_rpb, int64_t s_bstride, void* out, int64_t ldo, int64_t S,
+                     int64_t D, int32_t accumulate, ug_stream_t stream) {
+    if (S == 0) return UG_OK;
+    UG_REQUIRE(yh && yc && gates && idx && slot && out && E > 0 && capacity > 0, UG_ERR_BAD_SHAPE, "ug_moe_combine: bad arguments");
+    UG_REQUIRE((xs == nullptr) == (cs == nullptr), UG_ERR_BAD_SHAPE, "ug_moe_combine: xs and cs must both be given or both NULL");
+    UG_REQUIRE(s_rpb >= 0 && s_bstride >= 0, UG_ERR_BAD_SHAPE, "ug_moe_combine: bad row map");
+    UG_REQUIRE(D % 8 == 0 && ldo % 8 == 0 && (!xs || ld_s % 8 == 0) && ug_aligned(yh, 16) && ug_aligned(yc, 16) && ug_aligned(out, 16) &&
+               (!xs || (ug_aligned(xs, 16) && ug_aligned(cs, 16))), UG_ERR_BAD_ALIGN, "ug_moe_combine: 16-byte alignment required");
+    hipLaunchKernelGGL(moe_combine_kernel<T>, dim3((unsigned)((S + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const T*)yh,
+                       (const T*)yc, gates, idx, slot, (int)E, (int)capacity, (const T*)xs, (const T*)cs, ld_s, s_rpb, s_bstride,
+                       (T*)out, ldo, S, (int)D, (int)accumulate);
+    UG_CHECK_LAUNCH("ug_moe_combine");
+    return UG_OK;
+}
+
+}  // namespace
+
+extern "C" int ug_moe_gate_top1(const void* x, const void* c, int64_t ld, const void* wg, int64_t S, int64_t D, int32_t E, float* gates, int32_t* idx, ug_stream_t s) {
+    return moe_gate_impl<bf16_t>(x, c, ld, wg, S, D, E, gates, idx, s);
+}
+extern "C" int ug_moe_gate_top1_f32(const void* x, const void* c, int64_t ld, const void* wg, int64_t S, int64_t D, int32_t E, float* gates, int32_t* idx, ug_stream_t s) {
+    return moe_gate_impl<float>(x, c, ld, wg, S, D, E, gates, idx, s);
 }
 
 extern "C" int ug_moe_capacity_rts(const float* gates, const int32_t* idx, const float* uniform, int64_t S, int32_t E,
@@ -298,32 +340,24 @@ extern "C" int ug_moe_capacity_rts(const float* gates, const int32_t* idx, const
     return UG_OK;
 }
 
-extern "C" int ug_moe_dispatch_modulate(const void* x, int64_t ldx, const void* add, const void* mod, int64_t B,
+extern "C" int ug_moe_dispatch_modulate(const void* x, int64_t ldx, const void* add, const void* mod, int64_t mod_estride, int64_t mod_bstride,
                                         const int32_t* token_of_slot, int32_t E, int64_t capacity, int64_t tokens_per_sample,
-                                        int64_t D, void* out, ug_stream_t stream) {
-    UG_REQUIRE(x && token_of_slot && out && E > 0 && capacity > 0 && tokens_per_sample > 0 && B > 0, UG_ERR_BAD_SHAPE,
-               "ug_moe_dispatch_modulate: bad arguments");
-    UG_REQUIRE(D % 8 == 0 && ldx % 8 == 0 && ug_aligned(x, 16) && (!mod || ug_aligned(mod, 16)) && ug_aligned(out, 16) && (!add || ug_aligned(add, 16)),
-               UG_ERR_BAD_ALIGN, "ug_moe_dispatch_modulate: 16-byte alignment required");
-    const int64_t nslots = (int64_t)E * capacity;
-    hipLaunchKernelGGL(moe_dispatch_kernel, dim3((unsigned)((nslots + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx,
-                       (const bf16_t*)add, (const bf16_t*)mod, (int)B, token_of_slot, nslots, (int)capacity, (int)tokens_per_sample,
-                       (int)D, (bf16_t*)out);
-    UG_CHECK_LAUNCH("ug_moe_dispatch_modulate");
-    return UG_OK;
+                                        int64_t D, void* out, ug_stream_t s) {
+    return moe_dispatch_impl<bf16_t>(x, ldx, add, mod, mod_estride, mod_bstride, token_of_slot, E, capacity, tokens_per_sample, D, out, s);
+}
+extern "C" int ug_moe_dispatch_modulate_f32(const void* x, int64_t ldx, const void* add, const void* mod, int64_t mod_estride, int64_t mod_bstride,
+                                            const int32_t* token_of_slot, int32_t E, int64_t capacity, int64_t tokens_per_sample,
+                                            int64_t D, void* out, ug_stream_t s) {
+    return moe_dispatch_impl<float>(x, ldx, add, mod, mod_estride, mod_bstride, token_of_slot, E, capacity, tokens_per_sample, D, out, s);
 }
 
 extern "C" int ug_moe_combine(const void* yh, const void* yc, const float* gates, const int32_t* idx, const int32_t* slot, int32_t E,
-                              int64_t capacity, const void* xs, const void* cs, int64_t ld_s, void* out, int64_t ldo, int64_t S,
-                              int64_t D, int32_t accumulate, ug_stream_t stream) {
-    if (S == 0) return UG_OK;
-    UG_REQUIRE(yh && yc && gates && idx && slot && out && E > 0 && capacity > 0, UG_ERR_BAD_SHAPE, "ug_moe_combine: bad arguments");
-    UG_REQUIRE((xs == nullptr) == (cs == nullptr), UG_ERR_BAD_SHAPE, "ug_moe_combine: xs and cs must both be given or both NULL");
-    UG_REQUIRE(D % 8 == 0 && ldo % 8 == 0 && (!xs || ld_s % 8 == 0) && ug_aligned(yh, 16) && ug_aligned(yc, 16) && ug_aligned(out, 16) &&
-               (!xs || (ug_aligned(xs, 16) && ug_aligned(cs, 16))), UG_ERR_BAD_ALIGN, "ug_moe_combine: 16-byte alignment required");
-    hipLaunchKernelGGL(moe_combine_kernel, dim3((unsigned)((S + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)yh,
-                       (const bf16_t*)yc, gates, idx, slot, (int)E, (int)capacity, (const bf16_t*)xs, (const bf16_t*)cs, ld_s,
-                       (bf16_t*)out, ldo, S, (int)D, (int)accumulate);
-    UG_CHECK_LAUNCH("ug_moe_combine");
-    return UG_OK;
+                              int64_t capacity, const void* xs, const void* cs, int64_t ld_s, int64_t s_rpb, int64_t s_bstride, void* out, int64_t ldo,
+                              int64_t S, int64_t D, int32_t accumulate, ug_stream_t s) {
+    return moe_combine_impl<bf16_t>(yh, yc, gates, idx, slot, E, capacity, xs, cs, ld_s, s_rpb, s_bstride, out, ldo, S, D, accumulate, s);
+}
+extern "C" int ug_moe_combine_f32(const void* yh, const void* yc, const float* gates, const int32_t* idx, const int32_t* slot, int32_t E,
+                                  int64_t capacity, const void* xs, const void* cs, int64_t ld_s, int64_t s_rpb, int64_t s_bstride, void* out, int64_t ldo,
+                                  int64_t S, int64_t D, int32_t accumulate, ug_stream_t s) {
+    return moe_combine_impl<float>(yh, yc, gates, idx, slot, E, capacity, xs, cs, ld_s, s_rpb, s_bstride, out, ldo, S, D, accumulate, s);
 }

@@ -41,6 +41,42 @@ __device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
 __device__ __forceinline__ float bflo(unsigned u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bfhi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
 
+// ---- element traits: one kernel source for the product path (bf16 storage, the reference's bf16 rounding points) and the
+// fp32 VERIFICATION path (`*_f32` entry points: fp32 storage, no intermediate rounding). 8 elements per access in both. ------
+template <typename T> struct ElemT;
+template <> struct ElemT<bf16_t> {
+    static constexpr bool kF32 = false;
+    static __device__ __forceinline__ void load8(const bf16_t* p, float* f) {
+        const u32x4 v = *(const u32x4*)p;
+        f[0] = bflo(v.x); f[1] = bfhi(v.x); f[2] = bflo(v.y); f[3] = bfhi(v.y);
+        f[4] = bflo(v.z); f[5] = bfhi(v.z); f[6] = bflo(v.w); f[7] = bfhi(v.w);
+    }
+    static __device__ __forceinline__ void store8(bf16_t* p, const float* f) {
+        u32x4 v;
+        v.x = pack2bf(f[0], f[1]); v.y = pack2bf(f[2], f[3]); v.z = pack2bf(f[4], f[5]); v.w = pack2bf(f[6], f[7]);
+        *(u32x4*)p = v;
+    }
+    static __device__ __forceinline__ void zero8(bf16_t* p) { *(u32x4*)p = (u32x4){0u, 0u, 0u, 0u}; }
+    static __device__ __forceinline__ float rnd(float x) { return rbf(x); }          // a bf16 tensor op's output
+    static __device__ __forceinline__ float ld(const bf16_t* p) { return bf2f(*p); }
+    static __device__ __forceinline__ void st(bf16_t* p, float x) { *p = f2bf(x); }
+};
+template <> struct ElemT<float> {
+    static constexpr bool kF32 = true;
+    static __device__ __forceinline__ void load8(const float* p, float* f) {
+        const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+        f[0] = a[0]; f[1] = a[1]; f[2] = a[2]; f[3] = a[3]; f[4] = b[0]; f[5] = b[1]; f[6] = b[2]; f[7] = b[3];
+    }
+    static __device__ __forceinline__ void store8(float* p, const float* f) {
+        *(f32x4*)p = (f32x4){f[0], f[1], f[2], f[3]};
+        *(f32x4*)(p + 4) = (f32x4){f[4], f[5], f[6], f[7]};
+    }
+    static __device__ __forceinline__ void zero8(float* p) { *(f32x4*)p = (f32x4){0.f, 0.f, 0.f, 0.f}; *(f32x4*)(p + 4) = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    static __device__ __forceinline__ float rnd(float x) { return x; }
+    static __device__ __forceinline__ float ld(const float* p) { return *p; }
+    static __device__ __forceinline__ void st(float* p, float x) { *p = x; }
+};
+
 // logical row -> physical row of a concatenated buffer (see unigen_hip.h "row map")
 __device__ __forceinline__ int64_t ug_rowmap(int64_t m, int64_t rpb, int64_t bstride) {
     if (rpb <= 0) return m;

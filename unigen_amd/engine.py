@@ -74,7 +74,19 @@ class HipModule(nn.Module):
         super().__init__()
         self._ws = _Workspace()
         self._packed: Dict[str, torch.Tensor] = {}
+        self._emb_tab: Dict[str, torch.Tensor] = {}       # AdaLN linear outputs of the current step, by module prefix (_adaln_group)
         self.trainable_control_modules: Dict[str, nn.Module] = {}
+
+    def _check_dtype(self, *inputs: torch.Tensor):
+        """bf16 = the product path; fp32 = the verification path (every C-ABI call goes to its `_f32` twin, unigen_amd/ops.py).
+        Returns the activation dtype; inputs are cast to it by the caller (bf16 -> fp32 is exact)."""
+        dt = self.dtype
+        if dt not in (BF, torch.float32):
+            raise TypeError("the HIP engine computes in bf16 (or fp32 for verification): cast the model to torch.bfloat16")
+        for t in inputs:
+            if t is not None and t.dtype not in (BF, torch.float32):
+                raise TypeError(f"inputs must be torch.bfloat16 (or torch.float32), got {t.dtype}")
+        return dt
 
     def _probe(self) -> torch.Tensor:
         return next(self.parameters())
@@ -151,8 +163,8 @@ class HipModule(nn.Module):
                 self._pack(p + ".aqkv.b", [f"{p}.add_q_proj.bias", f"{p}.add_k_proj.bias", f"{p}.add_v_proj.bias"]))
 
     # ------------------------------------------------------------------ small pieces ----------------------------------
-    def _w(self, name, shape, dtype=BF):
-        return self._ws.get(name, shape, dtype, self.device)
+    def _w(self, name, shape, dtype=None):
+        return self._ws.get(name, shape, dtype if dtype is not None else self.dtype, self.device)
 
     def _time_text_embed(self, prefix: str, t_f32: torch.Tensor, pooled: torch.Tensor, g_f32: Optional[torch.Tensor], tag: str) -> torch.Tensor:
         """CombinedTimestep(Guidance)TextProjEmbeddings (diffusers embeddings.py)."""
@@ -171,9 +183,29 @@ class HipModule(nn.Module):
                                 self._w("temb_" + tag, (B, D)), silu_in=True, residual=emb)
 
     def _adaln_emb(self, prefix: str, temb: torch.Tensor, nchunks: int, tag: str) -> torch.Tensor:
-        """AdaLayerNormZero*.linear(silu(emb)) -> [B, nchunks * D]."""
+        """AdaLayerNormZero*.linear(silu(emb)) -> [B, nchunks * D]: a column slice of this step's grouped table when the module was
+        part of an _adaln_group call, otherwise its own launch."""
+        hit = self._emb_tab.get(prefix)
+        if hit is not None:
+            assert hit.shape[1] == nchunks * self.inner_dim, (prefix, hit.shape, nchunks)
+            return hit
         B, D = temb.shape[0], self.inner_dim
         return ops.small_linear(temb, self._P(prefix + ".linear.weight"), self._P(prefix + ".linear.bias"), self._w("emb_" + tag, (B, nchunks * D)), silu_in=True)
+
+    def _adaln_group(self, key: str, temb: torch.Tensor, prefixes: Sequence[str]) -> None:
+        """Every AdaLN linear that reads the same vector (`temb`, `condition_temb` or `control_temb`: only three distinct inputs per
+        step, src/UniGenTransformer.py:1048-1049,1222) as ONE launch over their stacked weights [sum N_i, D] (the parameters become views
+        of the stack): ~170 per-block launches per forward become 3-4, and the 6.5 GB of AdaLN weights stream in one go. The per-module
+        results are column slices of the [B, sum N_i] table (leading dimension sum N_i), looked up by _adaln_emb."""
+        prefixes = list(prefixes)
+        w = self._pack("adaln." + key + ".w", [p + ".linear.weight" for p in prefixes])
+        b = self._pack("adaln." + key + ".b", [p + ".linear.bias" for p in prefixes])
+        tab = ops.small_linear(temb, w, b, self._w("adaln_tab_" + key, (temb.shape[0], w.shape[0])), silu_in=True)
+        off = 0
+        for p in prefixes:
+            n = self.get_parameter(p + ".linear.weight").shape[0]
+            self._emb_tab[p] = tab[:, off:off + n]
+            off += n
 
     def _modulate(self, s: _Stream, emb: torch.Tensor, shift_chunk: int, scale_chunk: int, B: int, tag: str) -> torch.Tensor:
         D = self.inner_dim
@@ -207,6 +239,9 @@ class HipModule(nn.Module):
         # sample stream: AdaLN-Zero -> fused QKV
         emb_s = self._adaln_emb(p + ".norm1", temb, 9 if dual else 6, tag + "s")
         ns = self._modulate(s_in, emb_s, 0, 1, B, "s")
+        # SD35AdaLayerNormZeroX (src/UniGenUtils.py:340-352): norm_hidden_states2 is derived from the block's INPUT. It is taken here,
+        # before the to_out GEMM below overwrites the sample stream (s_in and s_out are the same buffer for in-place blocks).
+        n2 = self._modulate(s_in, emb_s, 6, 7, B, "s2") if dual else None
         w_qkv, b_qkv = self._attn_qkv(a)
         ops.gemm(ns, w_qkv, b_qkv, qkv2[Lc:], M=B * Ls, ldc=3 * D, c_map=RowMap(Ls, Lj))
         # context stream
@@ -252,7 +287,6 @@ class HipModule(nn.Module):
         if dual:
             # x = x + gate_msa2 * attn2(LN(x_in) * (1 + scale_msa2) + shift_msa2): self-attention over the sample tokens only
             a2 = p + ".attn2"
-            n2 = self._modulate(s_in, emb_s, 6, 7, B, "s")
             q2 = self._w("qkv2_" + tag, (B * Ls, 3 * D))
             w2, b2 = self._attn_qkv(a2)
             ops.gemm(n2, w2, b2, q2, M=B * Ls)

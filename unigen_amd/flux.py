@@ -241,10 +241,13 @@ class UniGenFlux(HipModule):
     def _rope(self, ids_list: Sequence[torch.Tensor], round_to: Optional[torch.dtype]) -> Tuple[torch.Tensor, torch.Tensor]:
         """FluxPosEmbed(theta=10000, axes_dims_rope) on cat(ids): fp32 cos/sin [S, dh]; `round_to` applies the control path's
         cast to the ids dtype (src/UniGenUtils.py:597). Tables are tiny and cached per ids identity."""
-        key = tuple((t.data_ptr(), tuple(t.shape), t.dtype) for t in ids_list) + (round_to,)
+        # Keyed on tensor identity AND kept alive by the entry: while an ids tensor is referenced here its storage cannot be recycled for
+        # another grid's ids of the same shape, and `_version` catches in-place edits (a cache keyed on data_ptr alone returned the tables
+        # of a freed 1024x512 grid for a fresh 512x1024 one of equal N).
+        key = tuple((id(t), t.data_ptr(), tuple(t.shape), t.dtype, t._version) for t in ids_list) + (round_to,)
         hit = self._rope_cache.get(key)
         if hit is not None:
-            return hit
+            return hit[0]
         ids = torch.cat([t.to(self.device) for t in ids_list], dim=0).float()
         cos_out, sin_out = [], []
         for i, d in enumerate(self.config.axes_dims_rope):
@@ -258,7 +261,7 @@ class UniGenFlux(HipModule):
         out = (cos.contiguous(), sin.contiguous())
         if len(self._rope_cache) > 64:
             self._rope_cache.clear()
-        self._rope_cache[key] = out
+        self._rope_cache[key] = (out, tuple(ids_list))      # the ids tensors stay referenced (see the key)
         return out
 
     def _single_block(self, p: str, B: int, h_in: _Stream, h_out: _Stream, temb: torch.Tensor,
@@ -313,23 +316,28 @@ class UniGenFlux(HipModule):
         exp_counts = torch.empty(E, device=dev, dtype=torch.int64)
         l_aux = torch.empty(1, device=dev, dtype=torch.float32)
         ops.moe_capacity_rts(gates, idx, uniform.contiguous(), C, slot, tos, exp_counts, l_aux)
-        # expert modulation: s = Linear(768 -> D)(pooled) per (expert, sample)
+        # expert modulation: s = Linear(768 -> D)(pooled) per (expert, sample): all E experts' linears as one launch over their stacked
+        # weights [E*D, 768] -> [B, E*D] (row of (expert e, sample b) at e*D + b*E*D)
         pe = "moe.moe_layer.experts.deepspeed_experts."
-        mod_c, mod_h = self._w("moe_modc", (E, B, D)), self._w("moe_modh", (E, B, D))
-        for e in range(E):
-            ops.small_linear(cond_pooled, self._P(f"{pe}{e}.0.1.weight"), self._P(f"{pe}{e}.0.1.bias"), mod_c[e])
-            ops.small_linear(pooled, self._P(f"{pe}{e}.1.1.weight"), self._P(f"{pe}{e}.1.1.bias"), mod_h[e])
+        wmc = self._pack("moe.modc.w", [f"{pe}{e}.0.1.weight" for e in range(E)])
+        bmc = self._pack("moe.modc.b", [f"{pe}{e}.0.1.bias" for e in range(E)])
+        wmh = self._pack("moe.modh.w", [f"{pe}{e}.1.1.weight" for e in range(E)])
+        bmh = self._pack("moe.modh.b", [f"{pe}{e}.1.1.bias" for e in range(E)])
+        mod_c = ops.small_linear(cond_pooled, wmc, bmc, self._w("moe_modc", (B, E * D)))
+        mod_h = ops.small_linear(pooled, wmh, bmh, self._w("moe_modh", (B, E * D)))
         w_c = self._pack_stack("moe.wc", [f"{pe}{e}.0.0.weight" for e in range(E)])
         b_c = self._pack_stack("moe.bc", [f"{pe}{e}.0.0.bias" for e in range(E)])
         w_h = self._pack_stack("moe.wh", [f"{pe}{e}.1.0.weight" for e in range(E)])
         b_h = self._pack_stack("moe.bh", [f"{pe}{e}.1.0.bias" for e in range(E)])
         xd, yc, yh = self._w("moe_xd", (E, C, D)), self._w("moe_yc", (E, C, D)), self._w("moe_yh", (E, C, D))
         # c' = W_c (s_c * c) + b_c ;  h' = W_h (s_h * (h + c')) + b_h      (expert_forward :957-959)
-        ops.moe_dispatch_modulate(c, None, mod_c, tos, xd, B=B, E=E, capacity=C, tokens_per_sample=N)
+        mk = dict(E=E, capacity=C, tokens_per_sample=N, mod_estride=D, mod_bstride=E * D)
+        ops.moe_dispatch_modulate(c, None, mod_c, tos, xd, **mk)
         ops.gemm(xd, w_c, b_c, yc, M=C, groups=E, a_gstride=C * D, w_gstride=D * D, bias_gstride=D, c_gstride=C * D)
-        ops.moe_dispatch_modulate(x, yc, mod_h, tos, xd, B=B, E=E, capacity=C, tokens_per_sample=N)
+        ops.moe_dispatch_modulate(x, yc, mod_h, tos, xd, **mk)
         ops.gemm(xd, w_h, b_h, yh, M=C, groups=E, a_gstride=C * D, w_gstride=D * D, bias_gstride=D, c_gstride=C * D)
         xs = cs = None
+        s_map = ops.IDENT
         if ctl.use_shared_expert:
             xc = self._w("moe_xc", (B, 2 * N, D))
             xc2 = xc.view(B * 2 * N, D)
@@ -342,11 +350,9 @@ class UniGenFlux(HipModule):
             rope1 = self._rope([txt_ids, img_ids, cond_ids], round_to) if ctl.use_rope else None
             xcs = _Stream(xc2, 2 * N)
             self._double_block("shared_expert.1", B, xcs, xcs, _Stream(ctrl_enc, T), None, control_temb, rope1, "se1")
-        for b in range(B):
-            sl = slice(b * N, (b + 1) * N)
-            if ctl.use_shared_expert:
-                xs, cs = xc[b, :N], xc[b, N:]
-            ops.moe_combine(yh, yc, gates[sl], idx[sl], slot[sl], z0[sl], E=E, capacity=C, xs=xs, cs=cs, accumulate=accumulate)
+            xs, cs, s_map = xc2, xc2[N:], RowMap(N, 2 * N)      # token (b, n): image half at row b*2N + n, condition half N rows further
+        # combine + CoMoE residual sums for all B samples in one launch (:1024, 1089)
+        ops.moe_combine(yh, yc, gates, idx, slot, z0, E=E, capacity=C, xs=xs, cs=cs, s_map=s_map, accumulate=accumulate)
         return l_aux, exp_counts
 
     # ------------------------------------------------------------------ forward ---------------------------------------
@@ -365,8 +371,8 @@ class UniGenFlux(HipModule):
         multi = isinstance(condition_hidden_states, (list, tuple))
         if multi != self.multi_condition:
             raise ValueError(f"{type(self).__name__} expects {'lists of' if self.multi_condition else 'single'} condition tensors")
-        if hidden_states.dtype != BF or self.dtype != BF:
-            raise TypeError("the HIP engine computes in bf16: cast the model and inputs to torch.bfloat16")
+        dt = self._check_dtype(hidden_states, encoder_hidden_states)       # bf16, or fp32 = verification mode
+        self._emb_tab.clear()
         if txt_ids.ndim == 3:
             txt_ids = txt_ids[0]
         if img_ids.ndim == 3:
@@ -381,13 +387,17 @@ class UniGenFlux(HipModule):
             raise ValueError("guidance is required when config.guidance_embeds is True")
         if not cfg.guidance_embeds:
             g_f32 = None
-        pooled = pooled_projections.to(BF).contiguous()
+        pooled = pooled_projections.to(dt).contiguous()
 
         x = self._w("x", (B * N, D))
-        ops.gemm(hidden_states.reshape(B * N, -1), self._P("x_embedder.weight"), self._P("x_embedder.bias"), x, M=B * N)
+        ops.gemm(hidden_states.to(dt).reshape(B * N, -1), self._P("x_embedder.weight"), self._P("x_embedder.bias"), x, M=B * N)
         temb = self._time_text_embed("time_text_embed", t_f32, pooled, g_f32, "base")
         enc = self._w("enc", (B * T, D))
-        ops.gemm(encoder_hidden_states.reshape(B * T, -1), self._P("context_embedder.weight"), self._P("context_embedder.bias"), enc, M=B * T)
+        ops.gemm(encoder_hidden_states.to(dt).reshape(B * T, -1), self._P("context_embedder.weight"), self._P("context_embedder.bias"), enc, M=B * T)
+        n_d, n_cj, n_s, n_cs = cfg.num_layers, ctl.cn_joint_layers, cfg.num_single_layers, ctl.cn_single_layers
+        # every AdaLN linear driven by temb, in one launch (engine._adaln_group)
+        self._adaln_group("base", temb, [f"transformer_blocks.{i}.{n}" for i in range(n_d) for n in ("norm1", "norm1_context")]
+                          + [f"single_transformer_blocks.{j}.norm" for j in range(n_s)] + ["norm_out"])
         rope_base = self._rope([txt_ids, img_ids], None)                         # base path: fp32 tables (:1238-1239)
         rope_ctl = self._rope([txt_ids, img_ids], img_ids.dtype) if ctl.use_rope else None
 
@@ -396,7 +406,6 @@ class UniGenFlux(HipModule):
         zs = _Stream(z, N)
         moe = None
         last_m = -1
-        n_d, n_cj = cfg.num_layers, ctl.cn_joint_layers
         for i in range(n_d):
             self._double_block(f"transformer_blocks.{i}", B, xs, xs, es, es, temb, rope_base, "base")
             m = int(i / (n_d / n_cj))                                             # (:1126-1127)
@@ -404,6 +413,8 @@ class UniGenFlux(HipModule):
                 # preprocess_moe_forward, once per step, on the text stream AFTER base block 0 (:1137 -> :1051)
                 control_pooled = pooled if ctl.use_pooled_prompt_embeds else torch.zeros_like(pooled)
                 control_temb = self._time_text_embed("control_time_text_embed", t_f32, control_pooled, g_f32, "ctl")
+                if ctl.use_shared_expert:
+                    self._adaln_group("ctl", control_temb, ["shared_expert.1.norm1", "shared_expert.1.norm1_context"])
                 ctrl_enc = self._w("ctrl_enc", (B * T, D))
                 ops.gemm(enc, self._P("control_context_embedder.weight"), self._P("control_context_embedder.bias"), ctrl_enc, M=B * T)
                 if multi:
@@ -418,16 +429,21 @@ class UniGenFlux(HipModule):
                         cp = cp.unsqueeze(0)
                     if ct.ndim == 2:
                         ct = ct.unsqueeze(0)
-                    cp = cp.to(BF).contiguous()
+                    cp = cp.to(dt).contiguous()
                     cid = cid[0] if cid.ndim == 3 else cid
                     cond_temb = self._time_text_embed("control_condition_embed", t_f32, cp, g_f32, f"cond{k}")
-                    l_aux, exp_counts = self._comoe(B, N, T, x, ct.to(BF), ctrl_enc, control_temb, cond_temb, pooled, cp, img_ids, txt_ids, cid,
+                    if ctl.use_shared_expert:       # shared_expert[0] is driven by THIS condition's temb (:1015), the control blocks by the sum
+                        self._adaln_group("se0", cond_temb, ["shared_expert.0.norm1", "shared_expert.0.norm1_context"])
+                    l_aux, exp_counts = self._comoe(B, N, T, x, ct.to(dt), ctrl_enc, control_temb, cond_temb, pooled, cp, img_ids, txt_ids, cid,
                                                     uni, z0, accumulate=k > 0)
                     if cond_temb_sum is None:
                         cond_temb_sum = cond_temb
                     else:                                                         # sum(merge_condition_temb) (:1319)
                         cond_temb_sum = ops.add(cond_temb_sum, cond_temb, self._w("cond_temb_sum", cond_temb.shape))
                 moe = dict(ctrl_enc=_Stream(ctrl_enc, T), condition_temb=cond_temb_sum, l_aux=l_aux, exp_counts=exp_counts)
+                # every control block's AdaLN linear reads the (summed) condition temb (:1092, 1319): one launch
+                self._adaln_group("cond", cond_temb_sum, [f"control_joint_trans_blocks.{m_}.{n}" for m_ in range(n_cj) for n in ("norm1", "norm1_context")]
+                                  + ([f"control_single_trans_blocks.{m_}.norm" for m_ in range(n_cs)] if ctl.use_single_trans_blocks else []))
                 z_in = _Stream(z0, N)
             else:
                 z_in = xs                                                         # control blocks read the BASE stream (:1085-1097)
@@ -446,7 +462,6 @@ class UniGenFlux(HipModule):
         hs = _Stream(h2, Lj)
         zj = self._w("zj", (B * Lj, D))
         zjs = _Stream(zj, Lj)
-        n_s, n_cs = cfg.num_single_layers, ctl.cn_single_layers
         for j in range(n_s):
             self._single_block(f"single_transformer_blocks.{j}", B, hs, hs, temb, rope_base)
             if ctl.use_single_trans_blocks:
@@ -464,7 +479,7 @@ class UniGenFlux(HipModule):
         img = _Stream(h2[T:], N, Lj)
         no = self._w("norm_s", (B * N, D))
         ops.adaln_modulate(img.base, emb_o[:, D:], emb_o, no, rows=B * N, D=D, rows_per_sample=N, mod_ld=emb_o.stride(0), ldx=D, x_map=img.map)
-        out = torch.empty(B, N, self.out_channels, device=dev, dtype=BF)
+        out = torch.empty(B, N, self.out_channels, device=dev, dtype=dt)
         ops.gemm(no, self._P("proj_out.weight"), self._P("proj_out.bias"), out.view(B * N, -1), M=B * N)
         return out, dict(moe_loss=moe["l_aux"][0] * 0.1), dict(expert_counts=moe["exp_counts"])
 

@@ -58,9 +58,20 @@ SIGNATURES = {
     "ug_gather_rows": (i32, [vp, i64, vp, vp, i64, i64, i64, vp]),
     "ug_moe_gate_top1": (i32, [vp, vp, i64, vp, i64, i64, i32, vp, vp, vp]),
     "ug_moe_capacity_rts": (i32, [vp, vp, vp, i64, i32, i64, vp, vp, vp, vp, vp]),
-    "ug_moe_dispatch_modulate": (i32, [vp, i64, vp, vp, i64, vp, i32, i64, i64, i64, vp, vp]),
-    "ug_moe_combine": (i32, [vp, vp, vp, vp, vp, i32, i64, vp, vp, i64, vp, i64, i64, i64, i32, vp]),
+    "ug_moe_dispatch_modulate": (i32, [vp, i64, vp, vp, i64, i64, vp, i32, i64, i64, i64, vp, vp]),
+    "ug_moe_combine": (i32, [vp, vp, vp, vp, vp, i32, i64, vp, vp, i64, i64, i64, vp, i64, i64, i64, i32, vp]),
+    "ug_pack_latents": (i32, [vp, vp, i64, i64, i64, i64, vp]),
+    "ug_unpack_latents": (i32, [vp, vp, i64, i64, i64, i64, vp]),
 }
+# fp32 verification twins: `<name>_f32` has the signature of the function it mirrors (include/unigen_hip.h, last section)
+_F32_TWINS = {"ug_gemm_f32": "ug_gemm_bf16", "ug_small_linear_f32": "ug_small_linear_bf16", "ug_adaln_modulate_f32": "ug_adaln_modulate",
+              "ug_qk_rmsnorm_rope_f32": "ug_qk_rmsnorm_rope", "ug_flash_attn_fwd_f32": "ug_flash_attn_fwd", "ug_timestep_embed_f32": "ug_timestep_embed",
+              "ug_euler_step_f32": "ug_euler_step", "ug_cfg_combine_f32": "ug_cfg_combine", "ug_add_f32": "ug_add_bf16",
+              "ug_add_rowbcast_f32_f32": "ug_add_rowbcast_f32", "ug_gather_rows_f32": "ug_gather_rows", "ug_moe_gate_top1_f32": "ug_moe_gate_top1",
+              "ug_moe_dispatch_modulate_f32": "ug_moe_dispatch_modulate", "ug_moe_combine_f32": "ug_moe_combine",
+              "ug_pack_latents_f32": "ug_pack_latents", "ug_unpack_latents_f32": "ug_unpack_latents"}
+for _twin, _base in _F32_TWINS.items():
+    SIGNATURES[_twin] = SIGNATURES[_base]
 
 _lib = None
 

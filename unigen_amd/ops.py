@@ -2,6 +2,10 @@
 
 torch is used only for device memory and the current HIP stream; every computation below runs in libunigen_hip.so.
 All tensors must be bf16 CUDA(HIP) tensors with a contiguous last dimension unless stated otherwise.
+
+fp32 verification mode: when the activation tensors are torch.float32 the SAME call goes to the entry point's `_f32` twin
+(include/unigen_hip.h, last section) - fp32 storage, no intermediate rounding - so a model whose parameters are fp32 runs the
+identical host orchestration in exact arithmetic. Mixed dtypes in one call are an error.
 """
 from __future__ import annotations
 
@@ -64,6 +68,9 @@ def _p(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
+f32 = torch.float32
+
+
 def _chk(t: torch.Tensor, name: str, dtype=bf16) -> None:
     if not t.is_cuda:
         raise L.UniGenHipError(f"{name}: expected a GPU tensor (unigen_amd has no CPU path)")
@@ -71,6 +78,22 @@ def _chk(t: torch.Tensor, name: str, dtype=bf16) -> None:
         raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
     if t.dim() > 0 and t.stride(-1) != 1:
         raise ValueError(f"{name}: last dimension must be contiguous")
+
+
+def _act(t: torch.Tensor, name: str):
+    """Activation dtype of a call, taken from its first tensor: bf16 (product path) or fp32 (verification twins)."""
+    if t.dtype not in (bf16, f32):
+        raise TypeError(f"{name}: expected torch.bfloat16 (or torch.float32 for the verification path), got {t.dtype}")
+    return t.dtype
+
+
+def _fn(base: str, dt):
+    """The C-ABI function for activation dtype `dt`: `base` itself for bf16, its `_f32` twin otherwise."""
+    lib = L.load()
+    return getattr(lib, base) if dt == bf16 else getattr(lib, _TWIN[base])
+
+
+_TWIN = {v: k for k, v in L._F32_TWINS.items()}
 
 
 class RowMap:
@@ -87,12 +110,14 @@ IDENT = RowMap()
 _gemm_ws: dict = {}
 
 
-def _gemm_workspace(device) -> torch.Tensor:
-    """Caller-owned scratch for the GEMM's split-K tail (one per device, allocated once)."""
-    ws = _gemm_ws.get(device)
+def _gemm_workspace(device, stream: int) -> torch.Tensor:
+    """Caller-owned scratch for the GEMM's split-K tail: one per (device, stream), allocated once - launches on one stream are ordered, two
+    streams must not share arrival tickets or slabs (include/unigen_hip.h: "One workspace per stream")."""
+    key = (device, stream)
+    ws = _gemm_ws.get(key)
     if ws is None:
         ws = torch.zeros(int(L.load().ug_gemm_workspace_bytes()), dtype=torch.uint8, device=device)   # tickets start at zero
-        _gemm_ws[device] = ws
+        _gemm_ws[key] = ws
     return ws
 
 
@@ -105,8 +130,11 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: to
          lora_b: Optional[torch.Tensor] = None, gelu_from_n: int = 0, c_shift_from_n: int = 0, c_shift: int = 0) -> torch.Tensor:
     """out[m, :N] = epilogue(a[m, :K] @ w[:N, :K]^T + bias). `a`/`out`/`residual` are base tensors whose data_ptr is row 0
     (slices of a bigger buffer are fine); leading dims default to the tensors' row strides."""
-    _chk(a, "a"); _chk(w, "w")
-    _chk(out, "out", torch.float32 if epilogue == L.EPI_F32 else bf16)
+    dt = _act(a, "a")
+    _chk(w, "w", dt)
+    _chk(out, "out", torch.float32 if epilogue == L.EPI_F32 else dt)
+    if bias is not None:
+        _chk(bias, "bias", dt)
     N, K = (w.shape[-2], w.shape[-1])
     d = L.GemmDesc()
     d.A, d.lda, d.a_rpb, d.a_bstride = a.data_ptr(), (lda if lda is not None else a.stride(-2)), a_map.rpb, a_map.bstride
@@ -114,23 +142,24 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: to
     d.bias = _p(bias)
     d.C, d.ldc, d.c_rpb, d.c_bstride = out.data_ptr(), (ldc if ldc is not None else out.stride(-2)), c_map.rpb, c_map.bstride
     if residual is not None:
-        _chk(residual, "residual")
+        _chk(residual, "residual", dt)
         d.R, d.ldr, d.r_rpb, d.r_bstride = residual.data_ptr(), (ldr if ldr is not None else residual.stride(-2)), r_map.rpb, r_map.bstride
     if gate is not None:
-        _chk(gate, "gate")
+        _chk(gate, "gate", dt)
         d.gate, d.gate_ld, d.rows_per_sample = gate.data_ptr(), gate_ld, rows_per_sample
     d.alpha, d.epilogue = alpha, epilogue
     d.M, d.N, d.K = M, N, K
     d.groups, d.a_gstride, d.w_gstride, d.bias_gstride, d.c_gstride = groups, a_gstride, w_gstride, bias_gstride, c_gstride
     d.r_gstride, d.gate_gstride = r_gstride, gate_gstride
     d.gelu_from_n, d.c_shift_from_n, d.c_shift = gelu_from_n, c_shift_from_n, c_shift
-    ws = _gemm_workspace(a.device)
+    stream = _stream()
+    ws = _gemm_workspace(a.device, stream)
     d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
     if lora_t is not None:
-        _chk(lora_t, "lora_t"); _chk(lora_b, "lora_b")
+        _chk(lora_t, "lora_t", dt); _chk(lora_b, "lora_b", dt)
         d.lora_T, d.ldt, d.lora_B, d.ldb, d.lora_r = lora_t.data_ptr(), lora_t.stride(-2), lora_b.data_ptr(), lora_b.stride(-2), lora_b.shape[-1]
     ev = _timer.begin("gemm") if _timer is not None else None
-    L.check(L.load().ug_gemm_bf16(C.byref(d), _stream()), "ug_gemm_bf16")
+    L.check(_fn("ug_gemm_bf16", dt)(C.byref(d), stream), "ug_gemm_bf16")
     if ev is not None:
         _timer.end("gemm", 2.0 * M * N * (K + (d.lora_r or 0)) * max(groups, 1), ev)
     return out
@@ -138,23 +167,31 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: to
 
 def small_linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, *, silu_in: bool = False,
                  residual: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """out[m] = residual[m] + bf16(act(x[m]) @ w^T + bias), M = x.shape[0] <= 16."""
-    _chk(x, "x"); _chk(w, "w"); _chk(out, "out")
+    """out[m] = residual[m] + bf16(act(x[m]) @ w^T + bias), M = x.shape[0] (chunks of <= 16 rows per launch)."""
+    dt = _act(x, "x")
+    _chk(w, "w", dt); _chk(out, "out", dt)
+    if bias is not None:
+        _chk(bias, "bias", dt)
+    if residual is not None:
+        _chk(residual, "residual", dt)
     M, K = x.shape
     N = w.shape[0]
-    for m0 in range(0, M, 16):          # the kernel handles up to 16 rows per launch (they live in LDS); more rows re-stream the weights
-        mm = min(16, M - m0)
+    fn = _fn("ug_small_linear_bf16", dt)
+    step = 16 if dt == bf16 else 64     # the bf16 kernel keeps up to 16 rows of x in LDS; more rows re-stream the weights
+    for m0 in range(0, M, step):
+        mm = min(step, M - m0)
         r = residual[m0:] if residual is not None else None
-        L.check(L.load().ug_small_linear_bf16(x[m0:].data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), _p(bias), _p(r),
-                                              residual.stride(0) if residual is not None else 0, out[m0:].data_ptr(), out.stride(0),
-                                              mm, N, K, 1 if silu_in else 0, _stream()), "ug_small_linear_bf16")
+        L.check(fn(x[m0:].data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), _p(bias), _p(r),
+                   residual.stride(0) if residual is not None else 0, out[m0:].data_ptr(), out.stride(0),
+                   mm, N, K, 1 if silu_in else 0, _stream()), "ug_small_linear_bf16")
     return out
 
 
 def adaln_modulate(x: torch.Tensor, shift: torch.Tensor, scale: torch.Tensor, out: torch.Tensor, *, rows: int, D: int,
                    rows_per_sample: int, mod_ld: int, ldx: Optional[int] = None, x_map: RowMap = IDENT, eps: float = 1e-6) -> torch.Tensor:
-    _chk(x, "x"); _chk(shift, "shift"); _chk(scale, "scale"); _chk(out, "out")
-    L.check(L.load().ug_adaln_modulate(x.data_ptr(), ldx if ldx is not None else x.stride(-2), x_map.rpb, x_map.bstride,
+    dt = _act(x, "x")
+    _chk(shift, "shift", dt); _chk(scale, "scale", dt); _chk(out, "out", dt)
+    L.check(_fn("ug_adaln_modulate", dt)(x.data_ptr(), ldx if ldx is not None else x.stride(-2), x_map.rpb, x_map.bstride,
                                        shift.data_ptr(), scale.data_ptr(), mod_ld, rows_per_sample, out.data_ptr(),
                                        out.stride(-2), rows, D, eps, _stream()), "ug_adaln_modulate")
     return out
@@ -164,14 +201,17 @@ def qk_rmsnorm_rope(buf: torch.Tensor, *, batches: int, rows_per_batch: int, ld:
                     batch_stride_rows: Optional[int] = None, pos_offset: int = 0, wq_a=None, wk_a=None, wq_b=None, wk_b=None,
                     split: int = 0, cos: Optional[torch.Tensor] = None, sin: Optional[torch.Tensor] = None, eps: float = 1e-6) -> torch.Tensor:
     """buf.data_ptr() is row 0 of batch 0 of the processed row range."""
-    _chk(buf, "buf")
+    dt = _act(buf, "buf")
+    for wt in (wq_a, wk_a, wq_b, wk_b):
+        if wt is not None:
+            _chk(wt, "qk-norm weight", dt)
     if batch_stride_rows is None:
         batch_stride_rows = rows_per_batch
     if cos is not None:
         _chk(cos, "cos", torch.float32); _chk(sin, "sin", torch.float32)
         assert cos.shape[0] >= pos_offset + rows_per_batch and cos.shape[1] == dh and cos.is_contiguous() and sin.is_contiguous(), \
             (cos.shape, pos_offset, rows_per_batch, dh)
-    L.check(L.load().ug_qk_rmsnorm_rope(buf.data_ptr(), ld, batches, rows_per_batch, batch_stride_rows, pos_offset, q_off, k_off, heads, dh,
+    L.check(_fn("ug_qk_rmsnorm_rope", dt)(buf.data_ptr(), ld, batches, rows_per_batch, batch_stride_rows, pos_offset, q_off, k_off, heads, dh,
                                         _p(wq_a), _p(wk_a), _p(wq_b), _p(wk_b), split, _p(cos), _p(sin), eps, _stream()), "ug_qk_rmsnorm_rope")
     return buf
 
@@ -179,11 +219,12 @@ def qk_rmsnorm_rope(buf: torch.Tensor, *, batches: int, rows_per_batch: int, ld:
 def flash_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, *, batches: int, heads: int, dh: int,
                Lq: int, Lkv: int, q_strides, k_strides, v_strides, o_strides, scale: Optional[float] = None) -> torch.Tensor:
     """q/k/v/out are base tensors (data_ptr = element [batch 0, row 0, head 0, 0]); *_strides = (row_stride, batch_stride)."""
-    _chk(q, "q"); _chk(k, "k"); _chk(v, "v"); _chk(out, "out")
+    dt = _act(q, "q")
+    _chk(k, "k", dt); _chk(v, "v", dt); _chk(out, "out", dt)
     if scale is None:
         scale = dh ** -0.5
     ev = _timer.begin("attn") if _timer is not None else None
-    L.check(L.load().ug_flash_attn_fwd(q.data_ptr(), q_strides[0], q_strides[1], k.data_ptr(), k_strides[0], k_strides[1],
+    L.check(_fn("ug_flash_attn_fwd", dt)(q.data_ptr(), q_strides[0], q_strides[1], k.data_ptr(), k_strides[0], k_strides[1],
                                        v.data_ptr(), v_strides[0], v_strides[1], out.data_ptr(), o_strides[0], o_strides[1],
                                        batches, heads, Lq, Lkv, dh, scale, _stream()), "ug_flash_attn_fwd")
     if ev is not None:
@@ -192,58 +233,65 @@ def flash_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Ten
 
 
 def timestep_embed(t: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
-    _chk(t, "t", torch.float32); _chk(out, "out")
-    L.check(L.load().ug_timestep_embed(t.data_ptr(), out.data_ptr(), out.stride(0), t.shape[0], out.shape[1], _stream()), "ug_timestep_embed")
+    _chk(t, "t", torch.float32)
+    dt = _act(out, "out")
+    L.check(_fn("ug_timestep_embed", dt)(t.data_ptr(), out.data_ptr(), out.stride(0), t.shape[0], out.shape[1], _stream()), "ug_timestep_embed")
     return out
 
 
 def euler_step(x: torch.Tensor, v: torch.Tensor, dt: float) -> torch.Tensor:
-    _chk(x, "x"); _chk(v, "v")
+    dt = _act(x, "x")
+    _chk(v, "v", dt)
     assert x.is_contiguous() and v.is_contiguous() and x.numel() == v.numel()
-    L.check(L.load().ug_euler_step(x.data_ptr(), v.data_ptr(), dt, x.numel(), _stream()), "ug_euler_step")
+    L.check(_fn("ug_euler_step", dt)(x.data_ptr(), v.data_ptr(), dt, x.numel(), _stream()), "ug_euler_step")
     return x
 
 
 def cfg_combine(uncond: torch.Tensor, text: torch.Tensor, guidance_scale: float, out: torch.Tensor) -> torch.Tensor:
-    _chk(uncond, "uncond"); _chk(text, "text"); _chk(out, "out")
+    dt = _act(uncond, "uncond")
+    _chk(text, "text", dt); _chk(out, "out", dt)
     assert uncond.is_contiguous() and text.is_contiguous() and out.is_contiguous() and uncond.numel() == text.numel() == out.numel()
-    L.check(L.load().ug_cfg_combine(uncond.data_ptr(), text.data_ptr(), guidance_scale, out.data_ptr(), out.numel(), _stream()), "ug_cfg_combine")
+    L.check(_fn("ug_cfg_combine", dt)(uncond.data_ptr(), text.data_ptr(), guidance_scale, out.data_ptr(), out.numel(), _stream()), "ug_cfg_combine")
     return out
 
 
 def add(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
-    _chk(a, "a"); _chk(b, "b"); _chk(out, "out")
+    dt = _act(a, "a")
+    _chk(b, "b", dt); _chk(out, "out", dt)
     D = a.shape[-1]
     rows = a.numel() // D
     a2, b2, o2 = a.reshape(rows, D), b.reshape(rows, D), out.view(rows, D)
-    L.check(L.load().ug_add_bf16(a2.data_ptr(), a2.stride(0), b2.data_ptr(), b2.stride(0), o2.data_ptr(), o2.stride(0), rows, D, _stream()), "ug_add_bf16")
+    L.check(_fn("ug_add_bf16", dt)(a2.data_ptr(), a2.stride(0), b2.data_ptr(), b2.stride(0), o2.data_ptr(), o2.stride(0), rows, D, _stream()), "ug_add_bf16")
     return out
 
 
 def add_rowbcast_f32(x: torch.Tensor, table: torch.Tensor, rows_per_batch: int) -> torch.Tensor:
     """x[r] = bf16(x[r] + table[r % rows_per_batch]) in place; x [rows, D] bf16, table [rows_per_batch, D] fp32."""
-    _chk(x, "x"); _chk(table, "table", torch.float32)
+    dt = _act(x, "x")
+    _chk(table, "table", torch.float32)
     rows, D = x.shape
     assert table.shape == (rows_per_batch, D)
-    L.check(L.load().ug_add_rowbcast_f32(x.data_ptr(), x.stride(0), table.data_ptr(), table.stride(0), rows, rows_per_batch, D, _stream()), "ug_add_rowbcast_f32")
+    L.check(_fn("ug_add_rowbcast_f32", dt)(x.data_ptr(), x.stride(0), table.data_ptr(), table.stride(0), rows, rows_per_batch, D, _stream()), "ug_add_rowbcast_f32")
     return x
 
 
 def gather_rows(src: torch.Tensor, idx: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
     """out[i] = src[idx[i]] (zeros where idx[i] < 0); src [R, W], idx int32 [n], out [n, W]."""
-    _chk(src, "src"); _chk(idx, "idx", torch.int32); _chk(out, "out")
+    dt = _act(src, "src")
+    _chk(idx, "idx", torch.int32); _chk(out, "out", dt)
     n, W = out.shape
     assert idx.numel() == n and src.shape[1] == W and idx.is_contiguous()
-    L.check(L.load().ug_gather_rows(src.data_ptr(), src.stride(0), idx.data_ptr(), out.data_ptr(), out.stride(0), n, W, _stream()), "ug_gather_rows")
+    L.check(_fn("ug_gather_rows", dt)(src.data_ptr(), src.stride(0), idx.data_ptr(), out.data_ptr(), out.stride(0), n, W, _stream()), "ug_gather_rows")
     return out
 
 
 def moe_gate_top1(x: torch.Tensor, c: torch.Tensor, wg: torch.Tensor, gates: torch.Tensor, idx: torch.Tensor) -> None:
-    _chk(x, "x"); _chk(c, "c"); _chk(wg, "wg"); _chk(gates, "gates", torch.float32); _chk(idx, "idx", torch.int32)
+    dt = _act(x, "x")
+    _chk(c, "c", dt); _chk(wg, "wg", dt); _chk(gates, "gates", torch.float32); _chk(idx, "idx", torch.int32)
     S, D = x.shape
     E = wg.shape[0]
     assert x.stride(0) == c.stride(0) and wg.is_contiguous() and gates.is_contiguous()
-    L.check(L.load().ug_moe_gate_top1(x.data_ptr(), c.data_ptr(), x.stride(0), wg.data_ptr(), S, D, E, gates.data_ptr(), idx.data_ptr(), _stream()),
+    L.check(_fn("ug_moe_gate_top1", dt)(x.data_ptr(), c.data_ptr(), x.stride(0), wg.data_ptr(), S, D, E, gates.data_ptr(), idx.data_ptr(), _stream()),
             "ug_moe_gate_top1")
 
 
@@ -257,25 +305,55 @@ def moe_capacity_rts(gates, idx, uniform, capacity: int, slot, token_of_slot, ex
                                          token_of_slot.data_ptr(), exp_counts.data_ptr(), l_aux.data_ptr(), _stream()), "ug_moe_capacity_rts")
 
 
-def moe_dispatch_modulate(x, add_, mod, token_of_slot, out, *, B: int, E: int, capacity: int, tokens_per_sample: int) -> torch.Tensor:
-    _chk(x, "x"); _chk(out, "out"); _chk(token_of_slot, "token_of_slot", torch.int32)
+def moe_dispatch_modulate(x, add_, mod, token_of_slot, out, *, E: int, capacity: int, tokens_per_sample: int,
+                          mod_estride: int = 0, mod_bstride: int = 0) -> torch.Tensor:
+    """mod: the expert-modulation vectors, row of (expert e, sample b) at element offset e * mod_estride + b * mod_bstride."""
+    dt = _act(x, "x")
+    _chk(out, "out", dt); _chk(token_of_slot, "token_of_slot", torch.int32)
     D = x.shape[-1]
     assert out.is_contiguous() and out.numel() == E * capacity * D
     if mod is not None:
-        _chk(mod, "mod"); assert mod.is_contiguous() and mod.numel() == E * B * D
+        _chk(mod, "mod", dt)
     if add_ is not None:
-        _chk(add_, "add"); assert add_.is_contiguous()
-    L.check(L.load().ug_moe_dispatch_modulate(x.data_ptr(), x.stride(-2), _p(add_), _p(mod), B, token_of_slot.data_ptr(), E, capacity,
-                                              tokens_per_sample, D, out.data_ptr(), _stream()), "ug_moe_dispatch_modulate")
+        _chk(add_, "add", dt); assert add_.is_contiguous()
+    L.check(_fn("ug_moe_dispatch_modulate", dt)(x.data_ptr(), x.stride(-2), _p(add_), _p(mod), mod_estride, mod_bstride, token_of_slot.data_ptr(),
+                                                 E, capacity, tokens_per_sample, D, out.data_ptr(), _stream()), "ug_moe_dispatch_modulate")
     return out
 
 
-def moe_combine(yh, yc, gates, idx, slot, out, *, E: int, capacity: int, xs=None, cs=None, accumulate: bool = False) -> torch.Tensor:
-    _chk(yh, "yh"); _chk(yc, "yc"); _chk(out, "out")
+def moe_combine(yh, yc, gates, idx, slot, out, *, E: int, capacity: int, xs=None, cs=None, s_map: RowMap = IDENT, accumulate: bool = False) -> torch.Tensor:
+    """xs / cs: base tensors of the shared experts' image / condition streams; token s is row s_map(s) of them."""
+    dt = _act(yh, "yh")
+    _chk(yc, "yc", dt); _chk(out, "out", dt)
     S, D = out.shape[-2], out.shape[-1]
     if xs is not None:
-        _chk(xs, "xs"); _chk(cs, "cs"); assert xs.stride(-2) == cs.stride(-2)
-    L.check(L.load().ug_moe_combine(yh.data_ptr(), yc.data_ptr(), gates.data_ptr(), idx.data_ptr(), slot.data_ptr(), E, capacity, _p(xs), _p(cs),
-                                    xs.stride(-2) if xs is not None else 0, out.data_ptr(), out.stride(-2), S, D, 1 if accumulate else 0, _stream()),
-            "ug_moe_combine")
+        _chk(xs, "xs", dt); _chk(cs, "cs", dt); assert xs.stride(-2) == cs.stride(-2)
+    L.check(_fn("ug_moe_combine", dt)(yh.data_ptr(), yc.data_ptr(), gates.data_ptr(), idx.data_ptr(), slot.data_ptr(), E, capacity, _p(xs), _p(cs),
+                                       xs.stride(-2) if xs is not None else 0, s_map.rpb, s_map.bstride, out.data_ptr(), out.stride(-2), S, D,
+                                       1 if accumulate else 0, _stream()), "ug_moe_combine")
+    return out
+
+
+def pack_latents(latents: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """FluxPipeline._pack_latents: [B, C, H, W] -> [B, (H/2)(W/2), 4C] (src/UniGenPipeline.py:641)."""
+    dt = _act(latents, "latents")
+    B, Cc, H, W = latents.shape
+    latents = latents.contiguous()
+    if out is None:
+        out = torch.empty(B, (H // 2) * (W // 2), Cc * 4, device=latents.device, dtype=dt)
+    _chk(out, "out", dt); assert out.is_contiguous() and out.numel() == latents.numel()
+    L.check(_fn("ug_pack_latents", dt)(latents.data_ptr(), out.data_ptr(), B, Cc, H, W, _stream()), "ug_pack_latents")
+    return out
+
+
+def unpack_latents(packed: torch.Tensor, H: int, W: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """FluxPipeline._unpack_latents: [B, (H/2)(W/2), 4C] -> [B, C, H, W] (H, W = latent height / width; src/UniGenPipeline.py:796)."""
+    dt = _act(packed, "packed")
+    B, n, ch = packed.shape
+    assert n == (H // 2) * (W // 2) and ch % 4 == 0, (packed.shape, H, W)
+    packed = packed.contiguous()
+    if out is None:
+        out = torch.empty(B, ch // 4, H, W, device=packed.device, dtype=dt)
+    _chk(out, "out", dt); assert out.is_contiguous()
+    L.check(_fn("ug_unpack_latents", dt)(packed.data_ptr(), out.data_ptr(), B, ch // 4, H, W, _stream()), "ug_unpack_latents")
     return out

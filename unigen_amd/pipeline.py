@@ -43,6 +43,18 @@ def flow_match_sigmas(num_inference_steps: int, *, sigmas: Optional[Sequence[flo
     return out + [0.0]
 
 
+def sd3_default_sigmas(num_inference_steps: int, shift: float = 3.0, num_train_timesteps: int = 1000) -> List[float]:
+    """The un-shifted sigmas FlowMatchEulerDiscreteScheduler.set_timesteps(num_inference_steps) starts from when the caller passes none
+    (diffusers 0.32.2, the release pinned in the reference's environment.yaml; UniGenSD3Pipeline, src/UniGenPipeline.py:355-357):
+    `linspace(sigma_to_t(sigma_max), sigma_to_t(sigma_min), n) / num_train_timesteps`, where the scheduler's __init__ has ALREADY applied the
+    static shift to its training sigmas, so sigma_max = 1 and sigma_min = shift * (1/T) / (1 + (shift - 1) / T) (0.002994 for shift 3) - and
+    set_timesteps then applies the shift a second time (flow_match_sigmas)."""
+    s_min = shift * (1.0 / num_train_timesteps) / (1.0 + (shift - 1.0) / num_train_timesteps)
+    s_max = shift * 1.0 / (1.0 + (shift - 1.0) * 1.0)
+    n = num_inference_steps
+    return [s_max + i * (s_min - s_max) / max(n - 1, 1) for i in range(n)]
+
+
 def prepare_latent_image_ids(height: int, width: int, device, dtype) -> torch.Tensor:
     """FluxPipeline._prepare_latent_image_ids: [h*w, 3], [:,1] = row, [:,2] = col."""
     ids = torch.zeros(height, width, 3)
@@ -180,8 +192,8 @@ def sd3_denoise_loop(transformer, *, latents: torch.Tensor, control_latents: tor
     embeds already doubled as [negative | positive] (reference :286-290); latents [B, C, H, W] are duplicated per step, the two halves of
     the prediction are combined with classifier-free guidance, then the flow-match Euler step. The timestep is passed unscaled."""
     cfg_on = guidance_scale > 1.0
-    if sigmas is None:      # FlowMatchEulerDiscreteScheduler.set_timesteps(num_inference_steps): linspace over timesteps, then the static shift
-        sigmas = [1.0 - i * (1.0 - 1.0 / 1000.0) / max(num_inference_steps - 1, 1) for i in range(num_inference_steps)]
+    if sigmas is None:
+        sigmas = sd3_default_sigmas(num_inference_steps, shift)
     sig = flow_match_sigmas(num_inference_steps, sigmas=sigmas, shift=shift)
     B = latents.shape[0]
     latents = latents.contiguous()

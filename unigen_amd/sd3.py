@@ -226,7 +226,7 @@ class UniGenSD3(HipModule):
         B, C, Hh, Ww = latents.shape
         p = cfg.patch_size
         h, w = Hh // p, Ww // p
-        patches = latents.to(BF).view(B, C, h, p, w, p).permute(0, 2, 4, 1, 3, 5).reshape(B * h * w, C * p * p).contiguous()   # layout only
+        patches = latents.to(self.dtype).view(B, C, h, p, w, p).permute(0, 2, 4, 1, 3, 5).reshape(B * h * w, C * p * p).contiguous()   # layout only
         K = C * p * p
         wt = self._P(prefix + ".proj.weight").view(D, K)
         x = self._w(out_name, (B * h * w, D))
@@ -246,19 +246,22 @@ class UniGenSD3(HipModule):
         """expert_forward with modulated linears (:252-259): c' = W_c (s_c * c) + b_c ; h' = W_h (s_h * (h + c')) + b_h."""
         E, D = self._ctl.expert_nums, self.inner_dim
         pe = "moe.moe_layer.experts.deepspeed_experts."
-        mod_c, mod_h = self._w("moe_modc", (E, B, D)), self._w("moe_modh", (E, B, D))
-        for e in range(E):
-            ops.small_linear(cond_pooled, self._P(f"{pe}{e}.0.1.weight"), self._P(f"{pe}{e}.0.1.bias"), mod_c[e])
-            ops.small_linear(pooled, self._P(f"{pe}{e}.1.1.weight"), self._P(f"{pe}{e}.1.1.bias"), mod_h[e])
+        wmc = self._pack("moe.modc.w", [f"{pe}{e}.0.1.weight" for e in range(E)])
+        bmc = self._pack("moe.modc.b", [f"{pe}{e}.0.1.bias" for e in range(E)])
+        wmh = self._pack("moe.modh.w", [f"{pe}{e}.1.1.weight" for e in range(E)])
+        bmh = self._pack("moe.modh.b", [f"{pe}{e}.1.1.bias" for e in range(E)])
+        mod_c = ops.small_linear(cond_pooled, wmc, bmc, self._w("moe_modc", (B, E * D)))      # all experts' Linear(pooled) in one launch
+        mod_h = ops.small_linear(pooled, wmh, bmh, self._w("moe_modh", (B, E * D)))
         w_c = self._pack_stack("moe.wc", [f"{pe}{e}.0.0.weight" for e in range(E)])
         b_c = self._pack_stack("moe.bc", [f"{pe}{e}.0.0.bias" for e in range(E)])
         w_h = self._pack_stack("moe.wh", [f"{pe}{e}.1.0.weight" for e in range(E)])
         b_h = self._pack_stack("moe.bh", [f"{pe}{e}.1.0.bias" for e in range(E)])
         xd, yc, yh = self._w("moe_xd", (E, C, D)), self._w("moe_yc", (E, C, D)), self._w("moe_yh", (E, C, D))
         gk = dict(M=C, groups=E, a_gstride=C * D, w_gstride=D * D, bias_gstride=D, c_gstride=C * D)
-        ops.moe_dispatch_modulate(c, None, mod_c, tos, xd, B=B, E=E, capacity=C, tokens_per_sample=N)
+        mk = dict(E=E, capacity=C, tokens_per_sample=N, mod_estride=D, mod_bstride=E * D)
+        ops.moe_dispatch_modulate(c, None, mod_c, tos, xd, **mk)
         ops.gemm(xd, w_c, b_c, yc, **gk)
-        ops.moe_dispatch_modulate(x, yc, mod_h, tos, xd, B=B, E=E, capacity=C, tokens_per_sample=N)
+        ops.moe_dispatch_modulate(x, yc, mod_h, tos, xd, **mk)
         ops.gemm(xd, w_h, b_h, yh, **gk)
         return yh, yc
 
@@ -274,13 +277,13 @@ class UniGenSD3(HipModule):
         tz = self._w("exp_tz", (B + 1, D))
         tz[:B].copy_(temb)
         tz[B].zero_()
-        emb_tab = self._w("exp_embtab", (E, B + 1, 6 * D))
-        for e in range(E):
-            ops.small_linear(tz, self._P(blk(e) + ".norm1.linear.weight"), self._P(blk(e) + ".norm1.linear.bias"), emb_tab[e], silu_in=True)
+        wn = self._pack(f"exp{which}.n1w", [blk(e) + ".norm1.linear.weight" for e in range(E)])
+        bn = self._pack(f"exp{which}.n1b", [blk(e) + ".norm1.linear.bias" for e in range(E)])
+        emb_tab = ops.small_linear(tz, wn, bn, self._w("exp_embtab", (B + 1, E * 6 * D)), silu_in=True)     # all experts' AdaLN linears, one launch
         emb = self._w("exp_emb", (E * C, 6 * D))                                  # per-slot modulation rows
-        ops.gather_rows(emb_tab.view(E * (B + 1), 6 * D), sidx, emb)
+        ops.gather_rows(emb_tab.view((B + 1) * E, 6 * D), sidx, emb)
         xd = self._w(out_name, (E, C, D))
-        ops.moe_dispatch_modulate(src, None, None, tos, xd, B=B, E=E, capacity=C, tokens_per_sample=N)
+        ops.moe_dispatch_modulate(src, None, None, tos, xd, E=E, capacity=C, tokens_per_sample=N)
         x2 = xd.view(E * C, D)
         n = self._w("exp_norm", (E * C, D))
         ops.adaln_modulate(x2, emb, emb[:, D:], n, rows=E * C, D=D, rows_per_sample=1, mod_ld=6 * D)
@@ -327,12 +330,13 @@ class UniGenSD3(HipModule):
         if ctl.modulated:
             yh, yc = self._experts_modulated(B, N, x, c, pooled, cond_pooled, tos, C)
         else:
-            # row of the per-expert AdaLN table each slot reads: e * (B + 1) + sample(token), or the zero-temb row for empty slots
-            e_ar = torch.arange(E, device=dev, dtype=torch.int32).view(E, 1) * (B + 1)
-            sidx = (e_ar + torch.where(tos >= 0, torch.div(tos, N, rounding_mode="floor"), torch.full_like(tos, B))).to(torch.int32).reshape(-1).contiguous()
+            # row of the [B + 1][E] AdaLN table each slot reads: sample(token) * E + e, with the zero-temb row B for empty slots
+            e_ar = torch.arange(E, device=dev, dtype=torch.int32).view(E, 1)
+            sidx = (e_ar + E * torch.where(tos >= 0, torch.div(tos, N, rounding_mode="floor"), torch.full_like(tos, B))).to(torch.int32).reshape(-1).contiguous()
             yh = self._expert_blocks(0, B, N, x, control_temb, tos, sidx, C, "moe_yh")          # expert[0](hidden, temb)
             yc = self._expert_blocks(1, B, N, c, condition_temb, tos, sidx, C, "moe_yc")        # expert[1](condition, condition_temb)
         xs = cs = None
+        s_map = ops.IDENT
         if ctl.use_shared_expert:
             xc = self._w("moe_xc", (B, 2 * N, D))
             xc2 = xc.view(B * 2 * N, D)
@@ -340,11 +344,8 @@ class UniGenSD3(HipModule):
                                condition_temb, None, "se0")
             xcs = _Stream(xc2, 2 * N)
             self._double_block("shared_expert.1", B, xcs, xcs, _Stream(ctrl_enc, T), None, control_temb, None, "se1", dual=True, ctx_continuous=True)
-        for b in range(B):
-            sl = slice(b * N, (b + 1) * N)
-            if ctl.use_shared_expert:
-                xs, cs = xc[b, :N], xc[b, N:]
-            ops.moe_combine(yh, yc, gates[sl], idx[sl], slot[sl], z0[sl], E=E, capacity=C, xs=xs, cs=cs)
+            xs, cs, s_map = xc2, xc2[N:], ops.RowMap(N, 2 * N)
+        ops.moe_combine(yh, yc, gates, idx, slot, z0, E=E, capacity=C, xs=xs, cs=cs, s_map=s_map)      # all B samples in one launch
         return l_aux, exp_counts
 
     # ------------------------------------------------------------------ forward ---------------------------------------
@@ -358,21 +359,22 @@ class UniGenSD3(HipModule):
             raise RuntimeError("call init_condition_block(...) before forward")
         if joint_attention_kwargs and any(k != "scale" for k in joint_attention_kwargs):
             raise ValueError("joint_attention_kwargs other than 'scale' are not supported")
-        if self.dtype != BF:
-            raise TypeError("the HIP engine computes in bf16")
+        dt = self._check_dtype(hidden_states, encoder_hidden_states)       # bf16, or fp32 = verification mode
+        self._emb_tab.clear()
         cfg, ctl, D, dev = self.config, self._ctl, self.inner_dim, self.device
         B, _, height, width = hidden_states.shape
         p = cfg.patch_size
         h, w = height // p, width // p
         N, T, Lyr = h * w, encoder_hidden_states.shape[1], cfg.num_layers
         t_f32 = timestep.to(dev).float().expand(B).contiguous()                    # used as given: SD3 does not rescale the timestep
-        pooled = pooled_projections.to(BF).contiguous()
-        cpooled = condition_pooled_projections.to(BF).contiguous()
+        pooled = pooled_projections.to(dt).contiguous()
+        cpooled = condition_pooled_projections.to(dt).contiguous()
 
         x = self._patch_embed("pos_embed", hidden_states, "x")
         temb = self._time_text_embed("time_text_embed", t_f32, pooled, None, "base")
         enc = self._w("enc", (B * T, D))
-        ops.gemm(encoder_hidden_states.to(BF).reshape(B * T, -1), self._P("context_embedder.weight"), self._P("context_embedder.bias"), enc, M=B * T)
+        ops.gemm(encoder_hidden_states.to(dt).reshape(B * T, -1), self._P("context_embedder.weight"), self._P("context_embedder.bias"), enc, M=B * T)
+        self._adaln_group("base", temb, [f"transformer_blocks.{i}.{n}" for i in range(Lyr) for n in ("norm1", "norm1_context")] + ["norm_out"])
         xs, es = _Stream(x, N), _Stream(enc, T)
         z = self._w("z", (B * N, D))
         zs = _Stream(z, N)
@@ -386,6 +388,10 @@ class UniGenSD3(HipModule):
                 control_pooled = pooled if ctl.use_pooled_prompt_embeds else torch.zeros_like(pooled)
                 control_temb = self._time_text_embed("control_time_text_embed", t_f32, control_pooled, None, "ctl")
                 condition_temb = self._time_text_embed("control_condition_embed", t_f32, cpooled, None, "cond")
+                self._adaln_group("cond", condition_temb, [f"control_transformer_blocks.{i_}.{n}" for i_ in range(Lyr) for n in ("norm1", "norm1_context")]
+                                  + (["shared_expert.0.norm1", "shared_expert.0.norm1_context"] if ctl.use_shared_expert else []))
+                if ctl.use_shared_expert:
+                    self._adaln_group("ctl", control_temb, ["shared_expert.1.norm1", "shared_expert.1.norm1_context"])
                 ctrl_enc = self._w("ctrl_enc", (B * T, D))
                 ops.gemm(enc, self._P("control_context_embedder.weight"), self._P("control_context_embedder.bias"), ctrl_enc, M=B * T)
                 z0 = self._w("z0", (B * N, D))
