@@ -240,10 +240,10 @@ def timestep_embed(t: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
 
 
 def euler_step(x: torch.Tensor, v: torch.Tensor, dt: float) -> torch.Tensor:
-    dt = _act(x, "x")
-    _chk(v, "v", dt)
+    adt = _act(x, "x")
+    _chk(v, "v", adt)
     assert x.is_contiguous() and v.is_contiguous() and x.numel() == v.numel()
-    L.check(_fn("ug_euler_step", dt)(x.data_ptr(), v.data_ptr(), dt, x.numel(), _stream()), "ug_euler_step")
+    L.check(_fn("ug_euler_step", adt)(x.data_ptr(), v.data_ptr(), dt, x.numel(), _stream()), "ug_euler_step")
     return x
 
 
