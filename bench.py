@@ -11,8 +11,9 @@ excluded. Multi-GPU is batch-parallel: every rank holds a weight r
 are the barriers around the timed region and one MAX all-reduce of the elapsed time (weak scaling).
 
 The JSON line carries `roofline` (dominant kernel = the bf16 MFMA GEMM: algorithmic FLOPs per launch / HIP-event duration of
-the launches inside the timed region) and `cpu_baseline` (the oracle = CPU restatement of the reference, timed on this box's host
-cores on a bounded, reduced-depth slice of the same workload and scaled by algorithmic FLOPs).
+the launches inside the timed region, against the 2.5 PFLOP/s datasheet peak and against the MFMA-only rate measured on this chip) and
+`cpu_baseline` (the oracle = CPU restatement of the reference, timed on this box's host cores on ONE full-depth forward of the same
+workload at B = 1 with the GPU run's own weights; an image = 4 such forwards).
 """
 from __future__ import annotations
 
@@ -73,44 +74,77 @@ def fixture_parity(device):
                 oracle_bf16_vs_fp32=rel(g["out.bf16"].float(), g["out.fp32"]))
 
 
-def cpu_baseline(max_threads: int = 16):
-    """Time the CPU oracle (port of the reference) on a bounded, reduced slice of the same workload (rank 0, N=1 only).
-    The GPU box grants one GPU's share of the host (16 cores), so at most 16 threads are used whatever the affinity mask says."""
-    from oracle import unigen_ref as R
+def _host_info(max_threads: int):
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
     cores = max(1, min(avail, max_threads))
-    torch.set_num_threads(cores)
-    n_d, n_s = 6, 8                                                # depth cut: 6 of 19 double + 8 of 38 single base blocks, 3 + 4 control blocks
-    cfg = R.FluxConfig(num_layers=n_d, num_single_layers=n_s)      # FLUX width (D=3072, H=24, dh=128), full CoMoE
-    B, grid, T = 1, 64, 512                                        # one 1024x1024 sample: ~10-20 s of CPU work on 16 Zen5 cores
-    st = R.make_state(cfg, seed=0, fast=True)
-    inp = R.make_inputs(cfg, B=B, grid=grid, T=T)
-    t = torch.full((B,), 1.0, dtype=torch.bfloat16)
-    t0 = time.perf_counter()
-    with torch.no_grad():
-        R.unigen_flux_forward(st, cfg, timestep=t, dtype=torch.bfloat16, **inp)
-    dt = time.perf_counter() - t0
-    sample_flops = canonical_flops_per_forward(cfg.inner_dim, grid * grid, T, n_d, n_s, cfg.cn_joint_layers, cfg.cn_single_layers, 1)
-    full_flops_per_image = 4 * canonical_flops_per_forward(3072, 4096, 512, 19, 38, 9, 19, 1)
-    img_per_s = (sample_flops / dt) / full_flops_per_image
-    cpu_model = ""
+    cpu_model, mem_gb = "", 0.0
     try:
         with open("/proc/cpuinfo") as f:
             for ln in f:
                 if ln.startswith("model name"):
                     cpu_model = ln.split(":", 1)[1].strip()
                     break
+        with open("/proc/meminfo") as f:
+            for ln in f:
+                if ln.startswith("MemAvailable"):
+                    mem_gb = int(ln.split()[1]) / 1e6
+                    break
     except OSError:
         pass
-    return dict(value=img_per_s, unit="images/s", cores=cores, kind="port", cpu=cpu_model,
-                sample=(f"oracle (bf16 torch CPU restatement of the reference) on ONE forward, B=1, 1024^2 (N=4096, T=512), FLUX width, depth cut to "
-                        f"{n_d} double + {n_s} single base blocks (+{cfg.cn_joint_layers}+{cfg.cn_single_layers} control blocks, full CoMoE): {sample_flops / 1e12:.2f} TFLOP in {dt:.1f} s = "
-                        f"{sample_flops / dt / 1e12:.3f} TFLOP/s on {cores} threads; scaled by algorithmic FLOPs to the full 1024^2 4-step image "
-                        f"({full_flops_per_image / 1e12:.1f} TFLOP)"),
-                sample_seconds=dt, sample_tflops=sample_flops / 1e12)
+    return cores, cpu_model, mem_gb
+
+
+def cpu_baseline(model, mode: str = "auto", max_threads: int = 16):
+    """The CPU oracle (port of the reference) timed on this box's host cores, rank 0, N = 1 only.
+
+    full  : ONE full-depth 1024^2 forward (B = 1, N = 4096, T = 512, 19 + 38 base blocks, 9 + 19 control blocks, full CoMoE) in the
+            reference's bf16 arithmetic, on the SAME weights the GPU run used (the model's state dict copied to the host: 37 GB); an image
+            is 4 such forwards + 4 Euler steps, so images/s = 1 / (4 x that time) - a timing of the stated workload's step, not a
+            FLOP-scaled extrapolation (SURVEY 8(d) "time one full step x4 and state that").
+    slice : the round-1 estimate (depth cut to 6 + 8 base blocks, tiled weights, scaled by canonical FLOPs) for hosts without the RAM.
+    The GPU box grants one GPU's share of the host (16 cores), so at most 16 threads are used whatever the affinity mask says."""
+    from oracle import unigen_ref as R
+    cores, cpu_model, mem_gb = _host_info(max_threads)
+    torch.set_num_threads(cores)
+    if mode == "auto":
+        mode = "full" if mem_gb >= 90.0 else "slice"
+    B, grid, T = 1, 64, 512
+    full_flops_per_image = 4 * canonical_flops_per_forward(3072, 4096, 512, 19, 38, 9, 19, 1)
+    if mode == "full":
+        cfg = R.FluxConfig()
+        t_copy = time.perf_counter()
+        st = {k: v.detach().to("cpu") for k, v in model.state_dict().items()}
+        t_copy = time.perf_counter() - t_copy
+        n_d, n_s = cfg.num_layers, cfg.num_single_layers
+    else:
+        n_d, n_s = 6, 8
+        cfg = R.FluxConfig(num_layers=n_d, num_single_layers=n_s)
+        st, t_copy = R.make_state(cfg, seed=0, fast=True), 0.0
+    inp = R.make_inputs(cfg, B=B, grid=grid, T=T)
+    t = torch.full((B,), 1.0, dtype=torch.bfloat16)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        out = R.unigen_flux_forward(st, cfg, timestep=t, dtype=torch.bfloat16, **inp)[0]
+    dt = time.perf_counter() - t0
+    assert torch.isfinite(out.float()).all()
+    del st
+    sample_flops = canonical_flops_per_forward(cfg.inner_dim, grid * grid, T, n_d, n_s, cfg.cn_joint_layers, cfg.cn_single_layers, 1)
+    if mode == "full":
+        img_per_s = 1.0 / (4.0 * dt)
+        sample = (f"oracle (bf16 torch CPU restatement of the reference) timed on ONE FULL-DEPTH forward of the cfg2 workload at B=1: 1024^2 (N=4096, T=512), "
+                  f"19 double + 38 single base blocks, 9+19 control blocks, CoMoE E=6, the GPU run's own random-init weights (state dict copied to the host in "
+                  f"{t_copy:.1f} s): {sample_flops / 1e12:.1f} TFLOP in {dt:.1f} s = {sample_flops / dt / 1e12:.2f} TFLOP/s on {cores} threads; "
+                  f"an image = 4 such forwards (+4 Euler steps) -> images/s = 1 / (4 x {dt:.1f} s)")
+    else:
+        img_per_s = (sample_flops / dt) / full_flops_per_image
+        sample = (f"ESTIMATE (host has {mem_gb:.0f} GB free, the full model needs ~90): oracle on ONE forward, B=1, 1024^2, FLUX width, depth cut to {n_d} double + "
+                  f"{n_s} single base blocks, tiled weights: {sample_flops / 1e12:.2f} TFLOP in {dt:.1f} s on {cores} threads, scaled by algorithmic FLOPs to "
+                  f"the full 4-step image ({full_flops_per_image / 1e12:.1f} TFLOP)")
+    return dict(value=img_per_s, unit="images/s", cores=cores, kind="port", cpu=cpu_model, mode=mode, sample=sample, sample_seconds=dt,
+                sample_tflops=sample_flops / 1e12, cpu_tflops_per_s=sample_flops / dt / 1e12)
 
 
 def main():
@@ -118,8 +152,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=4, help="samples per GPU per step (cfg2: 4)")
+    ap.add_argument("--batch", type=int, default=0, help="samples per GPU per step; default 4 at N = 1 (cfg2, the metric's configuration) and 8 at "
+                    "N > 1 (cfg4: global batch 64 = 8 x 8, reference infer.py:173 shards the samples by rank)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline", choices=["auto", "full", "slice"], default="auto", help="full = one full-depth 1024^2 oracle forward x 4 (needs ~90 GB host RAM)")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--small", action="store_true", help="debug: reduced depth (NOT the headline configuration)")
     ap.add_argument("--graph", action="store_true", help="capture one step (the 4-step denoise loop) in a HIP graph and replay it (SURVEY 8(f) rank 1)")
@@ -150,6 +186,8 @@ def main():
     model.init_condition_block(condition_nums=1, condition_types=["canny"], control_params=dict(CONTROL_PARAMS))
     model.init_synthetic_(seed=0, std=0.02)
 
+    if args.batch <= 0:
+        args.batch = 4 if world == 1 else 8
     B, grid, T, steps_per_image = args.batch, 64, 512, 4
     N = grid * grid
     g = torch.Generator(device=dev).manual_seed(DU.rank_seed(12443, rank))   # reference default seed (infer.py:61) + rank
@@ -208,9 +246,10 @@ def main():
         line = dict(metric="images/sec at 1024^2, FLUX-schnell+canny, 4-step", value=value, unit="images/s", n_gpus=world, steps=args.steps,
                     warmup=args.warmup, ms_per_step=1000.0 * elapsed / args.steps, higher_is_better=True, scaling="weak", vs_baseline=None,
                     dtype="bf16", data="synthetic",
-                    config=dict(workload=("cfg2: UniGenFlux canny single-condition, 1024x1024 (N=4096, T=512), FLUX-schnell geometry "
-                                          "19 double + 38 single blocks D=3072 H=24, 9+19 control blocks, CoMoE E=6, 4 denoise steps, bf16, "
-                                          "random-init weights" + (" [--small DEBUG depth]" if args.small else "")),
+                    config=dict(workload=((f"cfg4: UniGenFlux canny, 1024x1024, global batch {B * world} sharded over {world} x MI355X (B={B} per GPU; 64 = 8 x 8 at N=8), "
+                                           if world > 1 else f"cfg2: UniGenFlux canny single-condition, 1024x1024, batch={B}, ") +
+                                          "N=4096 image + T=512 text tokens, FLUX-schnell geometry 19 double + 38 single blocks D=3072 H=24, 9+19 control blocks, "
+                                          "CoMoE E=6, 4 denoise steps, bf16, random-init weights" + (" [--small DEBUG depth]" if args.small else "")),
                                 per_gpu_batch=B, global_batch=B * world, parallelism=f"dp{world} (independent samples, RCCL barrier only)",
                                 step="one 4-step denoise loop of the per-GPU batch"),
                     hip_graph=bool(args.graph), flops_per_image_canonical=fl_img, e2e_mfma_frac=value / world * fl_img / (MFMA_BF16_PEAK_TFLOPS * 1e12))
@@ -231,17 +270,24 @@ def main():
                 if "mfma_busy_frac" in g256:
                     pmc = dict(mfma_busy=g256["mfma_busy_frac"], effective_clock_ghz=g256["effective_clock_ghz"],
                                hbm_side_gbps=g256["hbm_bytes_per_launch"] / (g256["avg_launch_us_profiled"] * 1e-6) / 1e9)
+            # second denominator: the measured MFMA-only rate of this chip, at the clock it holds under matrix load
+            pk16 = ops.probe_mfma_peak(dev, shape=1)
+            pk32 = ops.probe_mfma_peak(dev, shape=0)
             line["roofline"] = dict(bound="mfma", kernel="gemm256_kernel / gemm128_kernel (ug_gemm_bf16)", achieved=ach, peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s",
-                                    frac=ach / MFMA_BF16_PEAK_TFLOPS, traffic=traffic, traffic_note=traffic_note, pmc_gemm256=pmc or None, launches=gm["launches"],
+                                    frac=ach / MFMA_BF16_PEAK_TFLOPS, peak_measured=pk16, frac_of_measured=ach / pk16,
+                                    peak_measured_note=("ug_probe_mfma_bf16: bare v_mfma_f32_16x16x32_bf16 loop (the GEMM's shape), register operands with random values, "
+                                                        f"one wave per SIMD on every CU, HIP events; the 32x32x16 shape (attention) measures {pk32:.0f}"),
+                                    traffic=traffic, traffic_note=traffic_note, pmc_gemm256=pmc or None, launches=gm["launches"],
                                     avg_launch_us=1000.0 * gm["ms"] / gm["launches"], avg_launch_gflop=gm["flops"] / gm["launches"] / 1e9,
                                     share_of_step_time=gm["ms"] * 1e-3 / elapsed)
             if at:
                 a2 = at["flops"] / (at["ms"] * 1e-3) / 1e12
                 line["roofline_attention"] = dict(bound="mfma", kernel="flash_attn128_kernel (ug_flash_attn_fwd)", achieved=a2, peak=MFMA_BF16_PEAK_TFLOPS,
-                                                  unit="TFLOP/s", frac=a2 / MFMA_BF16_PEAK_TFLOPS, launches=at["launches"],
+                                                  unit="TFLOP/s", frac=a2 / MFMA_BF16_PEAK_TFLOPS, peak_measured=pk32, frac_of_measured=a2 / pk32,
+                                                  launches=at["launches"],
                                                   avg_launch_us=1000.0 * at["ms"] / at["launches"], share_of_step_time=at["ms"] * 1e-3 / elapsed)
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline()
+            line["cpu_baseline"] = cpu_baseline(model, args.cpu_baseline)
             line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
             line["parity"] = fixture_parity(dev)
         print(json.dumps(line), flush=True)

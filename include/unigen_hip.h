@@ -234,6 +234,12 @@ int ug_moe_combine_f32(const void* yh, const void* yc, const float* gates, const
 int ug_pack_latents_f32(const void* latents, void* packed, int64_t B, int64_t C, int64_t H, int64_t W, ug_stream_t stream);
 int ug_unpack_latents_f32(const void* packed, void* latents, int64_t B, int64_t C, int64_t H, int64_t W, ug_stream_t stream);
 
+/* Diagnostic, not on the hot path: one launch of a bare bf16 MFMA loop (operands in registers, one wave per SIMD, pseudo-random
+ * operand values) on `blocks` workgroups of 256 threads; shape 0 = v_mfma_f32_32x32x16_bf16, 1 = v_mfma_f32_16x16x32_bf16. The caller
+ * times it (HIP events) to get the measured MFMA peak that bench.py reports as `roofline.peak_measured`.
+ * scratch: blocks * 256 floats (device). *flops_out_host (HOST pointer, may be NULL) receives the FLOPs of the launch. */
+int ug_probe_mfma_bf16(int32_t shape, int64_t blocks, int64_t iters, void* scratch, double* flops_out_host, ug_stream_t stream);
+
 int ug_version(void);
 const char* ug_last_error(void);
 

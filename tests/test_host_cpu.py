@@ -160,8 +160,71 @@ def test_pipeline_schedule_and_pack_roundtrip():
     assert torch.equal(ids, R.make_ids(3, 4))
     pipe = importlib.import_module("src.UniGenPipeline").UniGenFLUXPipeline.from_pretrained(None, transformer=None)
     assert pipe.transformer is None and pipe.vae_scale_factor == 8
-    with pytest.raises(NotImplementedError):
+    pipe.transformer = _model()
+    with pytest.raises(NotImplementedError, match="encode_prompt"):           # text given, no encoder attached
         pipe(prompt="a cat", condition_prompt="canny", control_image=torch.zeros(1, 4, 64))
+    with pytest.raises(NotImplementedError, match="VAE"):                      # pixels given, no VAE attached
+        pipe(prompt_embeds=torch.zeros(1, 8, 64), pooled_prompt_embeds=torch.zeros(1, 64), condition_pooled_prompt_embeds=torch.zeros(1, 64),
+             control_image=torch.zeros(1, 3, 64, 64))
+
+
+def test_pipeline_call_delegates_to_attached_encoders_and_vae(monkeypatch):
+    """infer.py:204-216 call shape: pipe(prompt=, condition_prompt=, control_image=<pixels>, height, width, num_inference_steps, guidance_scale,
+    max_sequence_length, dtype, generator).images with the caller's text encoders and VAE attached. The denoise loop itself needs the GPU
+    (tests/test_flux_gpu.py); here it is replaced by a recorder so the delegation runs on the CPU."""
+    from types import SimpleNamespace
+    from unigen_amd import pipeline as P
+    calls = []
+
+    def encode_prompt(prompt=None, prompt_2=None, prompt_embeds=None, pooled_prompt_embeds=None, device=None, num_images_per_prompt=1,
+                      max_sequence_length=512, lora_scale=None):
+        calls.append(("encode", prompt, max_sequence_length))
+        n = len(prompt) if isinstance(prompt, (list, tuple)) else 1
+        return torch.full((n, max_sequence_length, 64), 0.5), torch.full((n, 64), 0.25), torch.zeros(max_sequence_length, 3)
+
+    class VAE:
+        dtype = torch.bfloat16
+        config = SimpleNamespace(scaling_factor=0.3611, shift_factor=0.1159)
+
+        def encode(self, x):
+            calls.append(("vae.encode", tuple(x.shape)))
+            z = torch.arange(x.shape[0] * 16 * (x.shape[2] // 8) * (x.shape[3] // 8), dtype=torch.float32).view(x.shape[0], 16, x.shape[2] // 8, x.shape[3] // 8) / 100
+            return SimpleNamespace(latent_dist=SimpleNamespace(sample=lambda generator=None: z.to(torch.bfloat16)))
+
+        def decode(self, z, return_dict=False):
+            calls.append(("vae.decode", tuple(z.shape)))
+            return (z[:, :3].repeat_interleave(8, 2).repeat_interleave(8, 3),)
+
+    def fake_loop(tr, **kw):
+        calls.append(("loop", {k: (tuple(v.shape) if torch.is_tensor(v) else v) for k, v in kw.items() if k in
+                               ("latents", "control_tokens", "prompt_embeds", "pooled_prompt_embeds", "condition_pooled_prompt_embeds", "num_inference_steps")}))
+        fake_loop.control = kw["control_tokens"]
+        return kw["latents"]
+
+    monkeypatch.setattr(P, "denoise_loop", fake_loop)
+    pipe = importlib.import_module("src.UniGenPipeline").UniGenFLUXPipeline.from_pretrained(None, transformer=None)
+    pipe.transformer = _model()
+    pipe.encode_prompt, pipe.vae = encode_prompt, VAE()
+    g = torch.Generator().manual_seed(0)
+    img = torch.rand(2, 3, 64, 96) * 2 - 1
+    res = pipe(prompt=["a cat", "a dog"], condition_prompt=["canny", "canny"], control_image=img, height=64, width=96, num_inference_steps=4,
+               guidance_scale=3.5, max_sequence_length=16, dtype=torch.bfloat16, generator=g, output_type="pt")
+    kinds = [c[0] for c in calls]
+    assert kinds == ["encode", "encode", "vae.encode", "loop", "vae.decode"], kinds
+    assert calls[0][1] == ["a cat", "a dog"] and calls[1][1] == ["canny", "canny"] and calls[0][2] == 16
+    loop = calls[3][1]
+    assert loop["latents"] == (2, 4 * 6, 64) and loop["control_tokens"] == (2, 24, 64) and loop["prompt_embeds"] == (2, 16, 64)
+    assert loop["condition_pooled_prompt_embeds"] == (2, 64) and loop["num_inference_steps"] == 4
+    # the control tokens are pack((z - shift) * scale) of what the VAE returned (src/UniGenPipeline.py:635-647)
+    z = VAE().encode(img).latent_dist.sample()
+    exp = P.pack_latents(((z - 0.1159) * 0.3611).to(torch.bfloat16))
+    assert torch.equal(fake_loop.control, exp)
+    assert res.images.shape == (2, 3, 64, 96)                                  # unpack -> / scale + shift -> decode
+    # pre-computed embeds + packed latents still work without any attachment, as in round 1
+    pipe2 = importlib.import_module("src.UniGenPipeline").UniGenFLUXPipeline.from_pretrained(None, transformer=_model())
+    out = pipe2(prompt_embeds=torch.zeros(1, 8, 64), pooled_prompt_embeds=torch.zeros(1, 64), condition_pooled_prompt_embeds=torch.zeros(1, 64),
+                control_image=torch.zeros(1, 16, 64), height=64, width=64, num_inference_steps=2)
+    assert out.images.shape == (1, 16, 64)
 
 
 def test_sd3_default_sigmas_match_diffusers_0_32_2():
@@ -243,9 +306,9 @@ def test_control_checkpoint_wire_formats(tmp_path):
     f = tmp_path / "pytorch_model_fp32.bin"
     torch.save(ctrl, str(f))
     assert set(read_control_state_dict(str(f))) == set(ctrl)
-    # 1. ZeRO directory with a consolidated file; and the raw one without
+    # 1. ZeRO directory with a consolidated file; a raw one with a missing tag directory is an error (the merge: test_zero_shard_merge)
     z = tmp_path / "zero"; z.mkdir(); (z / "latest").write_text("global_step100")
-    with pytest.raises(OSError, match="consolidate"):
+    with pytest.raises(OSError, match="tag directory"):
         read_control_state_dict(str(z))
     torch.save(ctrl, str(z / "pytorch_model_fp32.bin"))
     assert set(read_control_state_dict(str(z))) == set(ctrl)
@@ -274,3 +337,86 @@ def test_control_checkpoint_wire_formats(tmp_path):
     assert all(torch.equal(got[k], ctrl[k].to(got[k].dtype)) for k in ctrl)
     with pytest.raises(OSError):
         read_control_state_dict(str(tmp_path / "nope"))
+
+
+class _FakeLossScaler:          # a non-torch object pickled beside the tensors, as DeepSpeed's shards carry
+    def __init__(self):
+        self.cur_scale = 65536.0
+
+
+def _write_zero_checkpoint(root, tag, params, frozen, buffers, world, stage, ngroups=2):
+    """Restates the SAVE side of deepspeed 0.16.5 (stage3.py / stage_1_and_2.py + engine._save_zero_checkpoint): trainable fp32 master
+    weights flattened per param group and partitioned over ranks (stage 3: every parameter padded to a multiple of world and split
+    rank-major; stages 1/2: the group's flat buffer padded to 2*world alignment and split evenly), frozen params as per-rank fragments."""
+    import collections
+    d = root / tag
+    d.mkdir(parents=True)
+    (root / "latest").write_text(tag)
+    names = list(params)
+    groups = [names[i::ngroups] for i in range(ngroups)]
+    shapes = [collections.OrderedDict((n, params[n].shape) for n in g) for g in groups]
+    for r in range(world):
+        if stage == 3:
+            flat_groups = []
+            for g in groups:
+                parts = []
+                for n in g:
+                    t = params[n].reshape(-1).float()
+                    part = -(-t.numel() // world)
+                    t = torch.cat([t, t.new_zeros(part * world - t.numel())])
+                    parts.append(t[r * part:(r + 1) * part])
+                flat_groups.append(torch.cat(parts))
+            osd = dict(zero_stage=3, partition_count=world, fp32_flat_groups=flat_groups, loss_scaler=_FakeLossScaler())
+            frag = {}
+            for n, v in frozen.items():
+                t = v.reshape(-1)
+                part = -(-t.numel() // world)
+                t = torch.cat([t, t.new_zeros(part * world - t.numel())])
+                frag[n] = t[r * part:(r + 1) * part].clone()
+            msd = dict(module={**buffers}, buffer_names=list(buffers), param_shapes=shapes, shared_params=[["alias.weight", names[0]]],
+                       frozen_param_shapes=collections.OrderedDict((n, v.shape) for n, v in frozen.items()), frozen_param_fragments=frag,
+                       ds_config=_FakeLossScaler(), ds_version="0.16.5")
+            torch.save(msd, str(d / f"zero_pp_rank_{r}_mp_rank_00_model_states.pt"))
+        else:
+            parts = []
+            for g in groups:
+                flat = torch.cat([params[n].reshape(-1).float() for n in g])
+                align = 2 * world
+                flat = torch.cat([flat, flat.new_zeros(-(-flat.numel() // align) * align - flat.numel())])
+                per = flat.numel() // world
+                parts.append(flat[r * per:(r + 1) * per].clone())
+            osd = dict(zero_stage=stage, partition_count=[world] * ngroups, single_partition_of_fp32_groups=parts, loss_scaler=_FakeLossScaler())
+            if r == 0:
+                msd = dict(module={**buffers}, buffer_names=list(buffers), param_shapes=shapes, shared_params=[["alias.weight", names[0]]],
+                           frozen_param_shapes=collections.OrderedDict((n, v.shape) for n, v in frozen.items()),
+                           frozen_param_fragments={n: v.clone() for n, v in frozen.items()}, ds_version="0.16.5")
+                torch.save(msd, str(d / "mp_rank_00_model_states.pt"))
+        torch.save(dict(optimizer_state_dict=osd), str(d / f"bf16_zero_pp_rank_{r}_mp_rank_00_optim_states.pt"))
+
+
+@pytest.mark.parametrize("stage,world", [(3, 4), (3, 3), (2, 4), (1, 2)])
+def test_zero_shard_merge(tmp_path, stage, world):
+    """infer.py:124-128 `get_fp32_state_dict_from_zero_checkpoint`: the per-rank ZeRO shards merge back to the full fp32 state dict
+    (odd sizes exercise the padding; a pickled non-torch object exercises the stub unpickler; no deepspeed import)."""
+    from unigen_amd.checkpoint import load_control_checkpoint, merge_zero_checkpoint, read_control_state_dict
+    m = _model()
+    m.init_synthetic_(seed=9, std=0.05, bias_std=0.02)
+    sd = {k: v.detach().float().clone() for k, v in m.state_dict().items()}
+    ctrl = {k: v for k, v in sd.items() if k.startswith(("control", "moe.", "shared_expert"))}
+    ctrl["odd.weight"] = torch.randn(7, 5)                                                    # numel 35: not a multiple of any world size
+    frozen = {"x_embedder.weight": sd["x_embedder.weight"], "frozen.odd": torch.randn(11)}
+    buffers = {"some.buffer": torch.arange(6, dtype=torch.bfloat16)}
+    _write_zero_checkpoint(tmp_path, "global_step7", ctrl, frozen, buffers, world, stage)
+    got = merge_zero_checkpoint(str(tmp_path))
+    assert set(got) == set(ctrl) | set(frozen) | set(buffers) | {"alias.weight"}
+    for k, v in {**ctrl, **frozen}.items():
+        assert got[k].dtype == torch.float32 and torch.equal(got[k], v), k
+    assert torch.equal(got["alias.weight"], ctrl[next(iter(ctrl))]) and torch.equal(got["some.buffer"], buffers["some.buffer"].float())
+    assert "deepspeed" not in sys.modules
+    # the reference's resolution order picks the directory up through its `latest` file, and the model loads it
+    assert set(read_control_state_dict(str(tmp_path))) == set(got)
+    m2 = _model()
+    res = load_control_checkpoint(m2, str(tmp_path))
+    assert set(res.unexpected_keys) == {"odd.weight", "frozen.odd", "some.buffer", "alias.weight"}
+    g2 = m2.state_dict()
+    assert all(torch.equal(g2[k], ctrl[k].to(g2[k].dtype)) for k in ctrl if k in g2)

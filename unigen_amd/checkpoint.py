@@ -3,15 +3,21 @@
 The reference resolves `--transformer` three ways (infer.py:124-140) and `train.py` saves a fourth (src/hook.py:10-27):
 
   1. a DeepSpeed ZeRO checkpoint directory (has a `latest` file): the reference calls
-     `deepspeed.utils.zero_to_fp32.get_fp32_state_dict_from_zero_checkpoint`. Its documented offline product is one consolidated
-     `pytorch_model_fp32.bin` (script/infer.sh:44-46); this loader reads that file when it sits in the directory and otherwise says how
-     to make it - re-implementing the ZeRO shard merge is out of scope;
+     `deepspeed.utils.zero_to_fp32.get_fp32_state_dict_from_zero_checkpoint` (infer.py:124-128). A consolidated `pytorch_model_fp32.bin`
+     (script/infer.sh:44-46) is read when it sits in the directory; otherwise the per-rank shards of `<dir>/<tag>/` are merged here
+     (`merge_zero_checkpoint`: the algorithm of deepspeed 0.16.5 zero_to_fp32.py restated, stages 1/2 and 3, frozen parameters, shared
+     parameters, buffers) - deepspeed itself is neither needed nor imported;
   2. a single `torch.save`d state dict (`*.bin` / `*.pt`);
   3. a directory of `*.safetensors` shards;
   4. `{module}_weights_{idx}.bin` files written by `save_all_model_hook`: one partial state dict per trainable module family.
 
 Tensors are returned on the CPU in their stored dtype; the model's `load_state_dict` casts to bf16 and writes through its packed
-(fused QKV / stacked expert) views. No network access, no pickle code execution (`weights_only=True`).
+(fused QKV / stacked expert) views. No network access. Plain state-dict files load with `weights_only=True`; ZeRO shard files pickle
+DeepSpeed objects (loss scaler, config) beside the tensors, so they are read with an unpickler that replaces every non-torch,
+non-builtin class by an inert stub (nothing from the checkpoint is imported or executed).
+
+Parity note: no DeepSpeed checkpoint exists in this container (no deepspeed, no weights), so the merge is pinned only by a writer that
+restates the SAVE side of the same release (tests/test_host_cpu.py::test_zero_shard_merge) - format parity unpinned.
 """
 from __future__ import annotations
 
@@ -39,8 +45,7 @@ def read_control_state_dict(path: str) -> Dict[str, torch.Tensor]:
                 f = os.path.join(path, name)
                 if os.path.exists(f):
                     return _torch_load(f)
-            raise OSError(f"{path} is a raw DeepSpeed ZeRO checkpoint; consolidate it first (python zero_to_fp32.py {path} "
-                          f"{path}/pytorch_model_fp32.bin, as script/infer.sh of the reference does) and point here again")
+            return merge_zero_checkpoint(path)
         sd: Dict[str, torch.Tensor] = {}
         st = sorted(glob.glob(os.path.join(path, "*.safetensors")))
         if st:                                                                              # 3. safetensors shards
@@ -64,6 +69,125 @@ def read_control_state_dict(path: str) -> Dict[str, torch.Tensor]:
             return load_file(path)
         return _torch_load(path)
     raise OSError(f"{path}: no such checkpoint")
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# DeepSpeed ZeRO shard merge (deepspeed 0.16.5 utils/zero_to_fp32.py, restated)
+# ----------------------------------------------------------------------------------------------------------------------
+
+class _Stub:
+    """Stands in for any class a ZeRO shard pickles that is not a tensor / container (LossScaler, DeepSpeedConfig, ...)."""
+
+    def __init__(self, *a, **k):
+        pass
+
+    def __setstate__(self, state):
+        self.__dict__["_state"] = state
+
+    def __call__(self, *a, **k):
+        return self
+
+
+class _SafePickle:
+    """pickle_module for torch.load: torch / collections / builtins resolve normally, everything else becomes _Stub."""
+    import pickle as _p
+    __name__ = "unigen_amd.checkpoint._SafePickle"
+    load, loads, dump, dumps = _p.load, _p.loads, _p.dump, _p.dumps
+    HIGHEST_PROTOCOL, DEFAULT_PROTOCOL, PickleError, UnpicklingError = _p.HIGHEST_PROTOCOL, _p.DEFAULT_PROTOCOL, _p.PickleError, _p.UnpicklingError
+    Pickler = _p.Pickler
+
+    class Unpickler(_p.Unpickler):
+        _OK = ("torch", "collections", "builtins", "numpy", "_codecs", "copyreg")
+
+        def find_class(self, module, name):
+            if module.split(".")[0] in self._OK:
+                return super().find_class(module, name)
+            return type(name, (_Stub,), {"__module__": module})
+
+
+def _zero_load(path: str):
+    return torch.load(path, map_location="cpu", weights_only=False, pickle_module=_SafePickle)
+
+
+def _natural(files):
+    import re
+    return sorted(files, key=lambda f: [int(t) if t.isdigit() else t for t in re.split(r"(\d+)", os.path.basename(f))])
+
+
+def merge_zero_checkpoint(checkpoint_dir: str, tag: str = None) -> Dict[str, torch.Tensor]:
+    """get_fp32_state_dict_from_zero_checkpoint(checkpoint_dir, tag): fp32 master weights of every trainable parameter re-assembled from
+    the per-rank optimizer shards, plus frozen parameters, buffers and shared-parameter aliases."""
+    if tag is None:
+        with open(os.path.join(checkpoint_dir, "latest")) as f:
+            tag = f.read().strip()
+    ds_dir = os.path.join(checkpoint_dir, tag)
+    if not os.path.isdir(ds_dir):
+        raise OSError(f"{ds_dir}: ZeRO checkpoint tag directory not found")
+    optim_files = _natural(glob.glob(os.path.join(ds_dir, "*_optim_states.pt")))
+    if not optim_files:
+        raise OSError(f"{ds_dir}: no *_optim_states.pt shards")
+    optim = [_zero_load(f)["optimizer_state_dict"] for f in optim_files]
+    stage = int(optim[0]["zero_stage"])
+    world = optim[0]["partition_count"]
+    world = int(max(world)) if isinstance(world, (list, tuple)) else int(world)
+    if world != len(optim_files):
+        raise ValueError(f"{ds_dir}: {len(optim_files)} optimizer shards but partition_count = {world}")
+    model_files = _natural(glob.glob(os.path.join(ds_dir, "zero_pp_rank_*_mp_rank_00_model_states.pt"))) if stage == 3 else \
+        _natural(glob.glob(os.path.join(ds_dir, "mp_rank_00_model_states.pt")))
+    if not model_files:
+        raise OSError(f"{ds_dir}: no *_model_states.pt for ZeRO stage {stage}")
+    models = [_zero_load(f) for f in model_files]
+    m0 = models[0]
+    param_shapes = m0["param_shapes"]                      # list (one dict name -> shape per optimizer param group)
+    if isinstance(param_shapes, dict):
+        param_shapes = [param_shapes]
+    numel = lambda shp: int(torch.Size(shp).numel())
+    sd: Dict[str, torch.Tensor] = {}
+    # buffers (fp32 copies)
+    buffer_names = set(m0.get("buffer_names", []))
+    for k, v in (m0.get("module") or {}).items():
+        if k in buffer_names:
+            sd[k] = v.float()
+    # frozen parameters
+    frozen_shapes = m0.get("frozen_param_shapes") or {}
+    for name, shp in frozen_shapes.items():
+        if stage == 3:
+            frag = torch.cat([m["frozen_param_fragments"][name].reshape(-1) for m in models], 0)
+            sd[name] = frag.narrow(0, 0, numel(shp)).view(torch.Size(shp)).float()
+        else:
+            sd[name] = m0["frozen_param_fragments"][name].float()
+    if stage == 3:
+        flats = [torch.cat([g.reshape(-1) for g in o["fp32_flat_groups"]], 0) for o in optim]      # per rank: its partitions of every param, in order
+        offset = 0
+        for shapes in param_shapes:
+            for name, shp in shapes.items():
+                n = numel(shp)
+                part = -(-n // world)                                                           # ceil: each rank holds `part` elements (zero padded)
+                sd[name] = torch.cat([fl.narrow(0, offset, part) for fl in flats], 0).narrow(0, 0, n).view(torch.Size(shp))
+                offset += part
+        if offset > flats[0].numel():
+            raise ValueError(f"{ds_dir}: shards hold {flats[0].numel()} elements per rank, the parameter list needs {offset}")
+    elif stage in (1, 2):
+        align = 2 * world
+        up = lambda x: align * -(-x // align)
+        ngroups = len(optim[0]["single_partition_of_fp32_groups"])
+        if ngroups != len(param_shapes):
+            raise ValueError(f"{ds_dir}: {ngroups} flat groups but {len(param_shapes)} parameter groups")
+        for gi, shapes in enumerate(param_shapes):
+            full = torch.cat([o["single_partition_of_fp32_groups"][gi].reshape(-1) for o in optim], 0)
+            offset = 0
+            for name, shp in shapes.items():
+                n = numel(shp)
+                sd[name] = full.narrow(0, offset, n).view(torch.Size(shp))
+                offset += n
+            if up(offset) != up(full.numel()):
+                raise ValueError(f"{ds_dir}: group {gi} consumed {offset} of {full.numel()} elements")
+    else:
+        raise ValueError(f"{ds_dir}: unknown zero stage {stage}")
+    for pair in m0.get("shared_params") or []:
+        if pair[1] in sd:
+            sd[pair[0]] = sd[pair[1]]
+    return sd
 
 
 def load_control_checkpoint(model, path: str):

@@ -60,6 +60,7 @@ SIGNATURES = {
     "ug_moe_capacity_rts": (i32, [vp, vp, vp, i64, i32, i64, vp, vp, vp, vp, vp]),
     "ug_moe_dispatch_modulate": (i32, [vp, i64, vp, vp, i64, i64, vp, i32, i64, i64, i64, vp, vp]),
     "ug_moe_combine": (i32, [vp, vp, vp, vp, vp, i32, i64, vp, vp, i64, i64, i64, vp, i64, i64, i64, i32, vp]),
+    "ug_probe_mfma_bf16": (i32, [i32, i64, i64, vp, C.POINTER(C.c_double), vp]),
     "ug_pack_latents": (i32, [vp, vp, i64, i64, i64, i64, vp]),
     "ug_unpack_latents": (i32, [vp, vp, i64, i64, i64, i64, vp]),
 }

@@ -357,3 +357,28 @@ def unpack_latents(packed: torch.Tensor, H: int, W: int, out: Optional[torch.Ten
     _chk(out, "out", dt); assert out.is_contiguous()
     L.check(_fn("ug_unpack_latents", dt)(packed.data_ptr(), out.data_ptr(), B, ch // 4, H, W, _stream()), "ug_unpack_latents")
     return out
+
+
+def probe_mfma_peak(device, shape: int = 1, seconds: float = 0.4) -> float:
+    """Measured dense bf16 MFMA rate (TFLOP/s) of a bare register-operand MFMA loop on every CU (ug_probe_mfma_bf16), timed with HIP
+    events on the current stream over ~`seconds` of back-to-back launches so the chip settles at the clock it holds under matrix load.
+    shape 0 = 32x32x16, 1 = 16x16x32 (the shape the GEMM uses)."""
+    props = torch.cuda.get_device_properties(device)
+    blocks = props.multi_processor_count
+    scratch = torch.empty(blocks * 256, dtype=torch.float32, device=device)
+    fl = C.c_double(0.0)
+    iters = 100_000
+    lib = L.load()
+    launch = lambda: L.check(lib.ug_probe_mfma_bf16(shape, blocks, iters, scratch.data_ptr(), C.byref(fl), _stream()), "ug_probe_mfma_bf16")
+    launch()
+    torch.cuda.synchronize(device)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); launch(); e1.record(); e1.synchronize()
+    n = max(3, int(seconds * 1e3 / max(e0.elapsed_time(e1), 1e-3)))
+    for _ in range(n):          # settle the clock
+        launch()
+    e0.record()
+    for _ in range(n):
+        launch()
+    e1.record(); e1.synchronize()
+    return fl.value * n / (e0.elapsed_time(e1) * 1e-3) / 1e12

@@ -1,11 +1,14 @@
 """Denoise loop of UniGenFLUXPipeline on MI355X (reference: src/UniGenPipeline.py:452-1133, loop :721-789 / :1048-1116).
 
 Scope: the timestep schedule, the transformer call with the reference's kwargs and the Euler step.
-Text encoders (CLIP/T5) and the VAE are the rows either side of the hot path and are NOT part of this package: the pipeline
-accepts what they produce - prompt embeds, pooled embeds, packed condition latents - exactly as the reference's `__call__`
-does through its `prompt_embeds=`, `pooled_prompt_embeds=`, `condition_pooled_prompt_embeds=`, `latents=` arguments, and returns
-latents (`output_type="latent"`). The reference defines `__call__` twice (single- and multi-condition; the second shadows the
-first); here one `__call__` serves both: nested lists select the multi-condition path.
+Text encoders (CLIP/T5) are the row before the hot path and are NOT part of this package: the pipeline accepts what they produce
+- prompt embeds, pooled embeds - exactly as the reference's `__call__` does through its `prompt_embeds=`, `pooled_prompt_embeds=`,
+`condition_pooled_prompt_embeds=` arguments, or DELEGATES to an injected `encode_prompt` callable with the reference's own keyword
+arguments (src/UniGenPipeline.py:575-619), so `infer.py:204`'s call shape `pipe(prompt=..., condition_prompt=..., control_image=<image>)`
+runs once the caller attaches its encoders. The VAE either side (:635-636, :797-798) is likewise an attribute: any object with the
+diffusers AutoencoderKL surface (`encode(x).latent_dist.sample()`, `decode(z, return_dict=False)[0]`, `config.scaling_factor /
+shift_factor`) - the native one of unigen_amd/vae.py or the caller's. The reference defines `__call__` twice (single- and
+multi-condition; the second shadows the first); here one `__call__` serves both: lists select the multi-condition path.
 """
 from __future__ import annotations
 
@@ -64,7 +67,10 @@ def prepare_latent_image_ids(height: int, width: int, device, dtype) -> torch.Te
 
 
 def pack_latents(latents: torch.Tensor) -> torch.Tensor:
-    """FluxPipeline._pack_latents: [B, C, H, W] -> [B, H/2*W/2, 4C] (layout change outside the hot loop)."""
+    """FluxPipeline._pack_latents: [B, C, H, W] -> [B, H/2*W/2, 4C]. GPU tensors go through ug_pack_latents (C ABI); the view/permute
+    formula below is the definition (and what host-side tensors take)."""
+    if latents.is_cuda:
+        return ops.pack_latents(latents)
     B, C, H, W = latents.shape
     return latents.view(B, C, H // 2, 2, W // 2, 2).permute(0, 2, 4, 1, 3, 5).reshape(B, (H // 2) * (W // 2), C * 4)
 
@@ -74,6 +80,8 @@ def unpack_latents(latents: torch.Tensor, height: int, width: int, vae_scale_fac
     B, _, ch = latents.shape
     h = 2 * (int(height) // (vae_scale_factor * 2))
     w = 2 * (int(width) // (vae_scale_factor * 2))
+    if latents.is_cuda:
+        return ops.unpack_latents(latents, h, w)
     return latents.view(B, h // 2, w // 2, ch // 4, 2, 2).permute(0, 3, 1, 4, 2, 5).reshape(B, ch // 4, h, w)
 
 
@@ -104,9 +112,11 @@ def denoise_loop(transformer, *, latents: torch.Tensor, control_tokens, prompt_e
 
 
 class UniGenFLUXPipeline:
-    """Call-surface twin of the reference `UniGenFLUXPipeline(FluxPipeline)` for the transformer-side of the pipeline."""
+    """Call-surface twin of the reference `UniGenFLUXPipeline(FluxPipeline)`: the denoise loop runs here; text encoding and the VAE are
+    delegated to attributes the caller attaches (`encode_prompt`, `vae`, `image_processor`), with the reference's keyword arguments."""
 
-    def __init__(self, transformer=None, scheduler_config: Optional[dict] = None, vae_scale_factor: int = 8):
+    def __init__(self, transformer=None, scheduler_config: Optional[dict] = None, vae_scale_factor: int = 8, encode_prompt=None, vae=None,
+                 image_processor=None):
         self.transformer = transformer
         self.vae_scale_factor = vae_scale_factor
         self.default_sample_size = 128
@@ -114,20 +124,28 @@ class UniGenFLUXPipeline:
         sc.update(scheduler_config or {})
         self.scheduler = SimpleNamespace(config=sc)
         self._device, self._dtype = None, BF
+        self.encode_prompt = encode_prompt      # callable(prompt=, prompt_2=, prompt_embeds=, pooled_prompt_embeds=, device=, ...) -> (embeds, pooled, text_ids)
+        self.vae = vae                          # AutoencoderKL surface
+        self.image_processor = image_processor  # .preprocess(image, height=, width=) / .postprocess(image, output_type=)
 
     @classmethod
     def from_pretrained(cls, pretrained_model_name_or_path=None, transformer=None, **kwargs) -> "UniGenFLUXPipeline":
-        """infer.py:146-149 builds the pipeline with `transformer=None` and assigns `.transformer` afterwards. Only the scheduler
-        config is read from disk (model_index-style layout); encoders and VAE are out of scope and are not loaded."""
+        """infer.py:146-149 builds the pipeline with `transformer=None` and assigns `.transformer` afterwards. The scheduler config is read
+        from disk (model_index-style layout); `vae/` is loaded into the native VAE when present; text encoders are attached by the caller."""
         import json, os
-        sc = {}
+        sc, vae = {}, kwargs.get("vae")
         if pretrained_model_name_or_path is not None:
-            p = os.path.join(os.fspath(pretrained_model_name_or_path), "scheduler", "scheduler_config.json")
+            root = os.fspath(pretrained_model_name_or_path)
+            p = os.path.join(root, "scheduler", "scheduler_config.json")
             if os.path.exists(p):
                 with open(p) as f:
                     raw = json.load(f)
                 sc = {k: raw[k] for k in ("shift", "use_dynamic_shifting") if k in raw}
-        return cls(transformer=transformer, scheduler_config=sc)
+            if vae is None and os.path.exists(os.path.join(root, "vae", "config.json")):
+                from .vae import AutoencoderKL
+                vae = AutoencoderKL.from_pretrained(os.path.join(root, "vae"))
+        return cls(transformer=transformer, scheduler_config=sc, encode_prompt=kwargs.get("encode_prompt"), vae=vae,
+                   image_processor=kwargs.get("image_processor"))
 
     def to(self, device=None, dtype=None):
         if device is not None:
@@ -136,48 +154,97 @@ class UniGenFLUXPipeline:
             self._dtype = dtype
         if self.transformer is not None:
             self.transformer.to(device=device, dtype=dtype)
+        if self.vae is not None and hasattr(self.vae, "to"):
+            self.vae.to(device=device, dtype=dtype)
         return self
+
+    # ---- the two delegated stages -----------------------------------------------------------------------------------
+    def _encode(self, what: str, prompt, prompt_2, prompt_embeds, pooled_prompt_embeds, device, num_images_per_prompt, max_sequence_length):
+        """self.encode_prompt(...) with the reference's kwargs (src/UniGenPipeline.py:575-619). Pre-computed embeds pass through."""
+        if prompt is None:
+            return prompt_embeds, pooled_prompt_embeds
+        if self.encode_prompt is None:
+            raise NotImplementedError(f"`{what}` given as text but no text encoder is attached: set `pipe.encode_prompt` to a callable with "
+                                      "FluxPipeline.encode_prompt's signature (CLIP/T5 are outside this package), or pass the embeds")
+        out = self.encode_prompt(prompt=prompt, prompt_2=prompt_2, prompt_embeds=prompt_embeds, pooled_prompt_embeds=pooled_prompt_embeds, device=device,
+                                 num_images_per_prompt=num_images_per_prompt, max_sequence_length=max_sequence_length, lora_scale=None)
+        return out[0], out[1]
+
+    def _encode_control(self, image: torch.Tensor, height, width, dtype, generator):
+        """prepare_image -> vae.encode -> (x - shift) * scale -> _pack_latents (:622-647). Packed latents [B, N, 4C] pass through."""
+        if image.ndim == 3:
+            return image
+        if image.ndim != 4:
+            raise ValueError("control_image must be an image batch [B, 3, H, W] or packed condition latents [B, N, 4*C]")
+        if self.vae is None:
+            raise NotImplementedError("control_image given as pixels but no VAE is attached: set `pipe.vae` (AutoencoderKL surface) or pass packed latents")
+        if self.image_processor is not None:
+            image = self.image_processor.preprocess(image, height=height, width=width)
+        vdt = getattr(self.vae, "dtype", dtype)
+        z = self.vae.encode(image.to(device=self.transformer.device, dtype=vdt)).latent_dist.sample(generator=generator)
+        z = (z - self.vae.config.shift_factor) * self.vae.config.scaling_factor
+        return pack_latents(z.to(dtype).contiguous())
+
+    def _decode(self, latents: torch.Tensor, height, width, output_type):
+        """_unpack_latents -> z / scale + shift -> vae.decode -> postprocess (:796-799)."""
+        if self.vae is None:
+            raise NotImplementedError("output_type other than 'latent' needs a VAE: set `pipe.vae` (AutoencoderKL surface)")
+        z = unpack_latents(latents, height, width, self.vae_scale_factor)
+        z = (z / self.vae.config.scaling_factor) + self.vae.config.shift_factor
+        image = self.vae.decode(z.to(getattr(self.vae, "dtype", z.dtype)), return_dict=False)[0]
+        if self.image_processor is not None:
+            return self.image_processor.postprocess(image, output_type=output_type)
+        return image
 
     @torch.no_grad()
     def __call__(self, prompt=None, prompt_2=None, condition_prompt=None, control_image=None, conditioning_scale: float = 1.0,
                  height: Optional[int] = None, width: Optional[int] = None, num_inference_steps: int = 28, sigmas=None,
-                 guidance_scale: float = 3.5, generator=None, latents: Optional[torch.Tensor] = None,
+                 guidance_scale: float = 3.5, num_images_per_prompt: int = 1, generator=None, latents: Optional[torch.Tensor] = None,
                  prompt_embeds: Optional[torch.Tensor] = None, pooled_prompt_embeds: Optional[torch.Tensor] = None,
-                 condition_pooled_prompt_embeds=None, condition_ids=None, output_type: str = "latent", return_dict: bool = True,
-                 max_sequence_length: int = 512, dtype: torch.dtype = BF, gate_uniforms=None, **kwargs):
-        if prompt is not None or condition_prompt is not None:
-            raise NotImplementedError("text encoders are outside this package's scope: pass prompt_embeds, pooled_prompt_embeds and "
-                                      "condition_pooled_prompt_embeds (as the reference's __call__ also accepts)")
-        if output_type != "latent":
-            raise NotImplementedError("the VAE is outside this package's scope: use output_type='latent'")
-        if prompt_embeds is None or pooled_prompt_embeds is None or condition_pooled_prompt_embeds is None or control_image is None:
-            raise ValueError("prompt_embeds, pooled_prompt_embeds, condition_pooled_prompt_embeds and control_image (packed latents) are required")
+                 condition_prompt_embeds=None, condition_pooled_prompt_embeds=None, condition_ids=None, output_type: str = "latent",
+                 return_dict: bool = True, max_sequence_length: int = 512, dtype: torch.dtype = BF, gate_uniforms=None, **kwargs):
         tr = self.transformer
         dev = tr.device
+        if control_image is None:
+            raise ValueError("control_image is required (pixels [B, 3, H, W] with a VAE attached, or packed condition latents [B, N, 4*C])")
         multi = isinstance(control_image, (list, tuple))
+        prompt_embeds, pooled_prompt_embeds = self._encode("prompt", prompt, prompt_2, prompt_embeds, pooled_prompt_embeds, dev, num_images_per_prompt,
+                                                           max_sequence_length)
+        if multi:       # one condition prompt (or pooled embed) per condition (second __call__ of the reference, :927-946)
+            cps = condition_prompt if isinstance(condition_prompt, (list, tuple)) else [condition_prompt] * len(control_image)
+            cpe = condition_pooled_prompt_embeds if isinstance(condition_pooled_prompt_embeds, (list, tuple)) else [condition_pooled_prompt_embeds] * len(control_image)
+            condition_pooled_prompt_embeds = [self._encode("condition_prompt", cp, None, None, ce, dev, num_images_per_prompt, max_sequence_length)[1]
+                                              for cp, ce in zip(cps, cpe)]
+        else:
+            condition_pooled_prompt_embeds = self._encode("condition_prompt", condition_prompt, None, condition_prompt_embeds, condition_pooled_prompt_embeds,
+                                                          dev, num_images_per_prompt, max_sequence_length)[1]
+        if prompt_embeds is None or pooled_prompt_embeds is None or condition_pooled_prompt_embeds is None or \
+                (multi and any(c is None for c in condition_pooled_prompt_embeds)):
+            raise ValueError("prompt (or prompt_embeds + pooled_prompt_embeds) and condition_prompt (or condition_pooled_prompt_embeds) are required")
         height = height or self.default_sample_size * self.vae_scale_factor
         width = width or self.default_sample_size * self.vae_scale_factor
         hl, wl = height // (self.vae_scale_factor * 2), width // (self.vae_scale_factor * 2)
         B = prompt_embeds.shape[0]
-        first = control_image[0] if multi else control_image
-        if first.ndim != 3:
-            raise ValueError("control_image must be packed condition latents [B, N, 4*C] (VAE encode + _pack_latents happen upstream)")
+        control = [self._encode_control(c, height, width, dtype, generator) for c in control_image] if multi else \
+            self._encode_control(control_image, height, width, dtype, generator)
         if latents is None:
             latents = torch.randn(B, hl * wl, tr.config.in_channels, generator=generator, device=dev if generator is None or generator.device.type != "cpu" else "cpu",
                                   dtype=torch.float32).to(dev)
         latents = latents.to(device=dev, dtype=dtype).clone()
         ids = prepare_latent_image_ids(hl, wl, dev, dtype)
         if condition_ids is None:
-            condition_ids = [ids for _ in control_image] if multi else ids
+            condition_ids = [ids for _ in control] if multi else ids
         text_ids = torch.zeros(prompt_embeds.shape[1], 3, device=dev, dtype=dtype)
         cast = lambda t: t.to(device=dev, dtype=dtype)
-        out = denoise_loop(tr, latents=latents, control_tokens=[cast(c) for c in control_image] if multi else cast(control_image),
+        out = denoise_loop(tr, latents=latents, control_tokens=[cast(c) for c in control] if multi else cast(control),
                            prompt_embeds=cast(prompt_embeds), pooled_prompt_embeds=cast(pooled_prompt_embeds),
                            condition_pooled_prompt_embeds=[cast(c) for c in condition_pooled_prompt_embeds] if multi else cast(condition_pooled_prompt_embeds),
                            text_ids=text_ids, latent_image_ids=ids, condition_ids=condition_ids, num_inference_steps=num_inference_steps,
                            sigmas=sigmas, guidance_scale=guidance_scale, conditioning_scale=conditioning_scale,
                            shift=self.scheduler.config["shift"], use_dynamic_shifting=self.scheduler.config["use_dynamic_shifting"],
                            gate_uniforms=gate_uniforms)
+        if output_type != "latent":
+            out = self._decode(out, height, width, output_type)
         if not return_dict:
             return (out,)
         return SimpleNamespace(images=out)
@@ -217,13 +284,17 @@ def sd3_denoise_loop(transformer, *, latents: torch.Tensor, control_latents: tor
 class UniGenSD3Pipeline:
     """Call-surface twin of the reference `UniGenSD3Pipeline` for the transformer side (encoders / VAE out of scope, as above)."""
 
-    def __init__(self, transformer=None, scheduler_config: Optional[dict] = None, vae_scale_factor: int = 8):
+    def __init__(self, transformer=None, scheduler_config: Optional[dict] = None, vae_scale_factor: int = 8, encode_prompt=None, vae=None,
+                 image_processor=None):
         self.transformer = transformer
         self.vae_scale_factor = vae_scale_factor
         self.default_sample_size = 128
         sc = dict(shift=3.0)
         sc.update(scheduler_config or {})
         self.scheduler = SimpleNamespace(config=sc)
+        # delegated stages, as in UniGenFLUXPipeline: encode_prompt(prompt=, ..., do_classifier_free_guidance=) -> (embeds, negative embeds,
+        # pooled, negative pooled) like StableDiffusion3Pipeline.encode_prompt; vae = AutoencoderKL surface
+        self.encode_prompt, self.vae, self.image_processor = encode_prompt, vae, image_processor
 
     @classmethod
     def from_pretrained(cls, pretrained_model_name_or_path=None, transformer=None, **kwargs) -> "UniGenSD3Pipeline":
@@ -239,14 +310,27 @@ class UniGenSD3Pipeline:
                  num_inference_steps: int = 28, guidance_scale: float = 7.0, generator=None, latents=None, prompt_embeds=None,
                  negative_prompt_embeds=None, pooled_prompt_embeds=None, negative_pooled_prompt_embeds=None,
                  condition_pooled_prompt_embeds=None, output_type: str = "latent", return_dict: bool = True, gate_uniforms=None, **kwargs):
-        if prompt is not None or condition_prompt is not None:
-            raise NotImplementedError("text encoders are outside this package's scope: pass the embeds")
-        if output_type != "latent":
-            raise NotImplementedError("the VAE is outside this package's scope: use output_type='latent'")
         tr = self.transformer
         dev = tr.device
-        cast = lambda t: t.to(device=dev, dtype=BF)
+        cast = lambda t: t.to(device=dev, dtype=tr.dtype)
         cfg_on = guidance_scale > 1.0
+        if prompt is not None or condition_prompt is not None:
+            if self.encode_prompt is None:
+                raise NotImplementedError("prompts given as text but no text encoder is attached: set `pipe.encode_prompt` (StableDiffusion3Pipeline.encode_prompt "
+                                          "signature; CLIP/T5 are outside this package), or pass the embeds")
+            if prompt is not None:
+                prompt_embeds, negative_prompt_embeds, pooled_prompt_embeds, negative_pooled_prompt_embeds = self.encode_prompt(
+                    prompt=prompt, prompt_2=None, prompt_3=None, do_classifier_free_guidance=cfg_on, device=dev)[:4]
+            if condition_prompt is not None:
+                condition_pooled_prompt_embeds = self.encode_prompt(prompt=condition_prompt, prompt_2=None, prompt_3=None, do_classifier_free_guidance=False,
+                                                                    device=dev)[2]
+        if control_image is not None and control_image.ndim == 4 and control_image.shape[1] != tr.config.in_channels:
+            if self.vae is None:
+                raise NotImplementedError("control_image given as pixels but no VAE is attached: set `pipe.vae` or pass VAE latents [B, C, H/8, W/8]")
+            z = self.vae.encode(control_image.to(device=dev, dtype=getattr(self.vae, "dtype", tr.dtype))).latent_dist.sample(generator=generator)
+            control_image = (z - self.vae.config.shift_factor) * self.vae.config.scaling_factor
+        if output_type != "latent" and self.vae is None:
+            raise NotImplementedError("output_type other than 'latent' needs a VAE: set `pipe.vae` (AutoencoderKL surface)")
         if cfg_on:
             if negative_prompt_embeds is None or negative_pooled_prompt_embeds is None:
                 raise ValueError("classifier-free guidance needs negative_prompt_embeds and negative_pooled_prompt_embeds")
@@ -262,4 +346,9 @@ class UniGenSD3Pipeline:
                                pooled_prompt_embeds=cast(pooled_prompt_embeds), condition_pooled_prompt_embeds=cast(condition_pooled_prompt_embeds),
                                num_inference_steps=num_inference_steps, guidance_scale=guidance_scale, conditioning_scale=conditioning_scale,
                                shift=self.scheduler.config["shift"], gate_uniforms=gate_uniforms)
+        if output_type != "latent":
+            z = (out / self.vae.config.scaling_factor) + self.vae.config.shift_factor
+            out = self.vae.decode(z.to(getattr(self.vae, "dtype", z.dtype)), return_dict=False)[0]
+            if self.image_processor is not None:
+                out = self.image_processor.postprocess(out, output_type=output_type)
         return SimpleNamespace(images=out) if return_dict else (out,)
