@@ -27,33 +27,36 @@ __global__ __launch_bounds__(256) void mfma_probe_kernel(float* __restrict__ out
     const unsigned tid = blockIdx.x * 256u + threadIdx.x;
     const bf16x8 a = rand_frag(tid * 3u), b0 = rand_frag(tid * 3u + 1u), b1 = rand_frag(tid * 3u + 2u);
     float s = 0.f;
+    // inline asm: the chains stay exactly as written (as builtins hipcc merges accumulators that compute equal values and shuffles the
+    // rest through v_accvgpr copies); back-to-back accumulate chains need no nops (MFMA -> same-shape MFMA taking the result as C)
     if constexpr (SHAPE == 0) {
         f32x16 c0, c1, c2, c3;
 #pragma unroll
         for (int i = 0; i < 16; ++i) { c0[i] = 0.f; c1[i] = 0.f; c2[i] = 0.f; c3[i] = 0.f; }
         for (int it = 0; it < iters; ++it) {
-            c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b0, c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1, c1, 0, 0, 0);
-            c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, a, c2, 0, 0, 0);
-            c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a, c3, 0, 0, 0);
+            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c0) : "v"(a), "v"(b0));
+            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c1) : "v"(a), "v"(b1));
+            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c2) : "v"(b0), "v"(a));
+            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c3) : "v"(b1), "v"(a));
         }
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 #pragma unroll
         for (int i = 0; i < 16; ++i) s += c0[i] + c1[i] + c2[i] + c3[i];
     } else {
-        f32x4 c[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) c[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0, c2 = c0, c3 = c0, c4 = c0, c5 = c0, c6 = c0, c7 = c0;
         for (int it = 0; it < iters; ++it) {
-#pragma unroll
-            for (int j = 0; j < 8; j += 4) {
-                c[j + 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b0, c[j + 0], 0, 0, 0);
-                c[j + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b1, c[j + 1], 0, 0, 0);
-                c[j + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, a, c[j + 2], 0, 0, 0);
-                c[j + 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1, a, c[j + 3], 0, 0, 0);
-            }
+            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c0) : "v"(a), "v"(b0));
+            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c1) : "v"(a), "v"(b1));
+            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c2) : "v"(b0), "v"(a));
+            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c3) : "v"(b1), "v"(a));
+            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c4) : "v"(b0), "v"(b1));
+            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c5) : "v"(b1), "v"(b0));
+            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c6) : "v"(a), "v"(a));
+            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c7) : "v"(b0), "v"(b0));
         }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) s += c[j][0] + c[j][1] + c[j][2] + c[j][3];
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+        const f32x4 t = c0 + c1 + c2 + c3 + c4 + c5 + c6 + c7;
+        s = t[0] + t[1] + t[2] + t[3];
     }
     out[tid] = s;       // keeps the chain alive; never read
 }
