@@ -468,8 +468,8 @@ sys.exit(0 if worst <= 4e-3 else 1)
 
 
 @pytest.mark.parametrize("env", [{"UG_ATTN_PWG": "1"}, {"UG_ATTN_STAGGER": "0"}, {"UG_ATTN_STAGGER": "0", "UG_TEST_DH": "64"},
-                                 {"UG_ATTN_WAVES": "4"}],
-                         ids=["one-wave-per-simd", "lock-step-dh128", "lock-step-dh64", "four-wave-workgroups"])
+                                 {"UG_ATTN_WAVES": "4"}, {"UG_ATTN_PRIO": "1", "UG_ATTN_WIDE": "0"}, {"UG_ATTN_PRIO": "2", "UG_ATTN_WIDE": "1", "UG_TEST_DH": "64"}],
+                         ids=["one-wave-per-simd", "lock-step-dh128", "lock-step-dh64", "four-wave-workgroups", "r1-default-prio1-narrow", "static-prio-wide-dh64"])
 def test_flash_attn_selectable_variants(gpu, env):
     """The non-default attention kernels: UG_ATTN_PWG=1 (4 waves x 64 rows, 512 registers, software-pipelined in the wave), the lock-step
     loop at both head dims and the 4-wave workgroups (the default is the X|Y stagger). The switches are read once per process, so each variant runs
@@ -477,4 +477,50 @@ def test_flash_attn_selectable_variants(gpu, env):
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", _PWG_SNIPPET.format(root=root)], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_gemm_one_wave_per_simd_variants_match_default(gpu):
+    """gemm_pwg.hip (UG_GEMM_PWG=1: 4 waves x 128x128, 512 registers; =2: 8 waves x 128x64): selectable alternatives to the 8-phase 256^2
+    kernel, kept because they are the measurement that located the GEMM's bound (the L2 -> LDS intake). Same MFMA
+    shape and K order -> bit-identical results, all epilogues, ragged edges, row maps, grouped, column split. UG_ENV_DYNAMIC re-reads the switch."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import os, sys
+os.environ["UG_ENV_DYNAMIC"] = "1"
+sys.path.insert(0, %r)
+import torch
+from unigen_amd import ops, lib as L
+dev = torch.device("cuda:0")
+g = torch.Generator(device=dev).manual_seed(0)
+rn = lambda *s: torch.randn(*s, generator=g, device=dev).to(torch.bfloat16)
+bad = 0
+for (M, N, K, epi, grp) in [(600, 520, 192, L.EPI_BIAS, 1), (512, 768, 3072, L.EPI_BIAS_GELU, 1), (1000, 256, 96, L.EPI_RES_GATE, 1), (300, 512, 64, L.EPI_RES_SCALE, 1),
+                            (260, 256, 128, L.EPI_BIAS, 3), (512, 1024, 256, "split", 1)]:
+    a, w, b = rn(grp, M, K), rn(grp, N, K) * 0.1, rn(grp, N)
+    r, gate = rn(grp, M, N), rn(grp, (M + 99) // 100, N)
+    outs = []
+    for mode in ("0", "1", "2"):
+        os.environ["UG_GEMM_PWG"] = mode
+        out = torch.zeros(grp, M, N + 64, device=dev, dtype=torch.bfloat16)
+        kw = dict(M=M, groups=grp, a_gstride=M * K, w_gstride=N * K, bias_gstride=N, c_gstride=M * (N + 64), ldc=N + 64)
+        if epi == "split":
+            kw.update(epilogue=L.EPI_BIAS_GELU, gelu_from_n=512, c_shift_from_n=512, c_shift=64)
+        else:
+            kw.update(epilogue=epi)
+        if epi in (L.EPI_RES_GATE, L.EPI_RES_SCALE):
+            kw.update(residual=r, r_gstride=M * N, alpha=0.7)
+        if epi == L.EPI_RES_GATE:
+            kw.update(gate=gate, gate_ld=N, rows_per_sample=100, gate_gstride=gate.shape[1] * N)
+        ops.gemm(a, w, b, out, **kw)
+        outs.append(out)
+    torch.cuda.synchronize()
+    for o in outs[1:]:
+        if not torch.equal(o, outs[0]):
+            bad += 1
+            print("MISMATCH", M, N, K, epi, grp, float((o.float() - outs[0].float()).abs().max()))
+sys.exit(1 if bad else 0)
+""" % root
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr

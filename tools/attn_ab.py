@@ -1,0 +1,44 @@
+"""Interleaved A/B of ug_flash_attn_fwd variants in ONE process (cdna guide rule 24): UG_ENV_DYNAMIC=1 makes the library re-read its
+tuning switches on every call. Usage: python tools/attn_ab.py [dh] ; prints median / min TFLOP/s per (variant, shape) and checks that
+every variant returns the same bits as the default."""
+import os, sys
+os.environ["UG_ENV_DYNAMIC"] = "1"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from unigen_amd import ops
+
+dev = torch.device("cuda:0")
+dh = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+H = 24
+D = H * dh
+VARIANTS = [dict(UG_ATTN_PRIO="1", UG_ATTN_WIDE="0"), dict(UG_ATTN_PRIO="0", UG_ATTN_WIDE="0"), dict(UG_ATTN_PRIO="2", UG_ATTN_WIDE="0"),
+            dict(UG_ATTN_PRIO="1", UG_ATTN_WIDE="1"), dict(UG_ATTN_PRIO="0", UG_ATTN_WIDE="1"), dict(UG_ATTN_PRIO="2", UG_ATTN_WIDE="1")]
+SHAPES = [(4, 4608, 4608), (4, 4096, 4608), (4, 8192, 8704)] if dh == 128 else [(16, 4096, 4429), (16, 4096, 4096)]
+g = torch.Generator(device=dev).manual_seed(0)
+for B, Lq, Lkv in SHAPES:
+    qkv = torch.randn(B, Lkv, 3 * D, generator=g, device=dev).to(torch.bfloat16)
+    st = (3 * D, Lkv * 3 * D)
+    outs = [torch.empty(B, Lq, D, device=dev, dtype=torch.bfloat16) for _ in VARIANTS]
+
+    def run(i):
+        os.environ.update(VARIANTS[i])
+        ops.flash_attn(qkv[0, Lkv - Lq:], qkv[0, 0, D:], qkv[0, 0, 2 * D:], outs[i], batches=B, heads=H, dh=dh, Lq=Lq, Lkv=Lkv,
+                       q_strides=st, k_strides=st, v_strides=st, o_strides=(D, Lq * D))
+    for i in range(len(VARIANTS)):
+        run(i); run(i)
+    torch.cuda.synchronize()
+    for i in range(1, len(VARIANTS)):
+        assert torch.equal(outs[i], outs[0]), f"variant {VARIANTS[i]} differs from the default"
+    times = [[] for _ in VARIANTS]
+    for rnd in range(7):
+        for i in range(len(VARIANTS)):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(4):
+                run(i)
+            e1.record(); e1.synchronize()
+            times[i].append(e0.elapsed_time(e1) / 4)
+    fl = 4.0 * B * H * Lq * Lkv * dh
+    for i, v in enumerate(VARIANTS):
+        t = sorted(times[i])
+        print(f"dh{dh} B{B} {Lq}x{Lkv} prio={v['UG_ATTN_PRIO']} wide={v['UG_ATTN_WIDE']}: median {fl / t[len(t) // 2] / 1e9:7.1f}  best {fl / t[0] / 1e9:7.1f} TFLOP/s", flush=True)

@@ -9,7 +9,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libunigen_hip.so")
-SOURCES = ["core.hip", "gemm.hip", "attention.hip", "elementwise.hip", "moe.hip", "verify_f32.hip", "probe.hip"]
+SOURCES = ["core.hip", "gemm.hip", "gemm_pwg.hip", "attention.hip", "elementwise.hip", "moe.hip", "verify_f32.hip", "probe.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # attention: scores are finite or -inf, never NaN; without IEEE mode hipcc drops the NaN-quieting v_max x,x it adds per fmaxf operand
 EXTRA = {"attention.hip": ["-fno-honor-nans", "-mno-amdgpu-ieee"]}
@@ -25,7 +25,7 @@ def _stale(target: str, deps: list[str]) -> bool:
 
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile every .hip source to an object and link the shared library. Returns the library path."""
-    hdrs = [os.path.join(CSRC, "ug_common.h"), os.path.join(HERE, "..", "include", "unigen_hip.h")]
+    hdrs = [os.path.join(CSRC, "ug_common.h"), os.path.join(CSRC, "gemm_epilogue.h"), os.path.join(HERE, "..", "include", "unigen_hip.h")]
     objs, jobs = [], []
     for src in SOURCES:
         s = os.path.join(CSRC, src)

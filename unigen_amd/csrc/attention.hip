@@ -66,7 +66,9 @@ __device__ __forceinline__ float ug_max_halves(float x) {
 // the VALU, together (the lock-step loop, STAGGER = false, kept for A/B: both phases then serialise and a tile costs the sum).
 // Two barriers per tile; every thread fetches its share of K(t+2), V(t+1) at the start of an even segment and publishes it to LDS at
 // the end of the following odd one, into buffers nobody reads in those two segments.
-template <int DH, int NW, bool STAGGER>   // head dim 128 | 64; waves per workgroup: 8 (256 query rows, 1 / CU) or 4 (128 rows, 2 / CU)
+template <int DH, int NW, bool STAGGER, int PRIO = 1, bool WIDE = false>   // head dim 128 | 64; waves per workgroup: 8 (256 query rows, 1 / CU) or 4 (128 rows, 2 / CU)
+// PRIO (stagger only): 0 = no priority games; 1 = s_setprio 1 around the matrix stream of every X segment; 2 = ONE static s_setprio 1 for
+// the younger wave group (waves 4-7) before the loop (cdna guide T5, static form). WIDE: 16-byte epilogue stores (T21).
 __global__ __launch_bounds__(64 * NW, 2) void flash_attn_kernel(
     const bf16_t* __restrict__ q, int64_t q_rs, int64_t q_bs, const bf16_t* __restrict__ k, int64_t k_rs, int64_t k_bs,
     const bf16_t* __restrict__ v, int64_t v_rs, int64_t v_bs, bf16_t* __restrict__ o, int64_t o_rs, int64_t o_bs,
@@ -327,7 +329,7 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn_kernel(
         };
         rdv(0); rdv(1);
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);                   // the matrix stream outranks the partner wave's softmax VALU at issue
+        if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(1);                   // the matrix stream outranks the partner wave's softmax VALU at issue
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
@@ -338,7 +340,7 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn_kernel(
             else if (have_qk) { rdk(2 * (ks - 2)); rdk(2 * (ks - 2) + 1); }      // k-steps 0-3 of the second half
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (!have_qk) { __builtin_amdgcn_s_setprio(0); return; }
+        if (!have_qk) { if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(0); return; }
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -350,7 +352,7 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn_kernel(
             __builtin_amdgcn_sched_barrier(0);
             if (s + 4 < QS) { rdk(s + 4); __builtin_amdgcn_sched_barrier(0); }
         }
-        __builtin_amdgcn_s_setprio(0);
+        if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(0);
         const int kv0 = (t + 1) * KVB;
         if (kv0 + KVB > Lkv) {   // ragged last tile: keys >= Lkv do not exist
 #pragma unroll
@@ -436,6 +438,7 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn_kernel(
             }
         };
         const bool groupA = __builtin_amdgcn_readfirstlane(wave) < 4;
+        if constexpr (PRIO == 2) { if (!groupA) __builtin_amdgcn_s_setprio(1); }
         fetch(0, ntiles);                              // K(0) only
         publish(0, ntiles);
         seg_barrier();
@@ -474,7 +477,24 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn_kernel(
     // ---- epilogue: O[q][d] = O^T / l ----
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
-    if (q_row < Lq) {
+    if constexpr (WIDE) {
+        // Lane (r, h) holds, per 8-column group g4 of a 32-wide d block, columns 8 g4 + 4 h .. + 3 of its query row (8 bytes). One
+        // v_permlane32_swap per dword on the group pair (k, k + 1) moves the upper half-wave's group-k data down and the lower half's
+        // group-(k + 1) data up: lanes 0-31 then hold columns 8k .. 8k + 7 and lanes 32-63 columns 8k + 8 .. 8k + 15 of the row: ONE
+        // 16-byte store per pair instead of two 8-byte ones (cdna guide T21: the store tail is issue-bound). Rows past Lq only skip the store.
+        bf16_t* Orow = o + (int64_t)b * o_bs + (int64_t)(q_row < Lq ? q_row : Lq - 1) * o_rs + head * DH + 8 * h;
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+#pragma unroll
+            for (int k2 = 0; k2 < 4; k2 += 2) {
+                unsigned ax = pack2bf(oacc[db][4 * k2 + 0] * inv, oacc[db][4 * k2 + 1] * inv), ay = pack2bf(oacc[db][4 * k2 + 2] * inv, oacc[db][4 * k2 + 3] * inv);
+                unsigned bx = pack2bf(oacc[db][4 * k2 + 4] * inv, oacc[db][4 * k2 + 5] * inv), by = pack2bf(oacc[db][4 * k2 + 6] * inv, oacc[db][4 * k2 + 7] * inv);
+                auto rx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
+                auto ry = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
+                u32x4 w; w.x = rx[0]; w.y = ry[0]; w.z = rx[1]; w.w = ry[1];
+                if (q_row < Lq) *(u32x4*)(Orow + 32 * db + 8 * k2) = w;
+            }
+    } else if (q_row < Lq) {
         bf16_t* Orow = o + (int64_t)b * o_bs + (int64_t)q_row * o_rs + head * DH;
 #pragma unroll
         for (int db = 0; db < NDB; ++db)
@@ -873,8 +893,8 @@ extern "C" int ug_flash_attn_fwd(const void* q, int64_t q_row_stride, int64_t q_
     const int64_t nwg = (int64_t)nQ * heads * batches;
     UG_REQUIRE(nwg < (1ll << 31), UG_ERR_UNSUPPORTED, "ug_flash_attn_fwd: grid too large");
     const float c = softmax_scale * 1.4426950408889634f;
-#define UG_ATTN_LAUNCH(DHV, NWV, STG)                                                                                                \
-    hipLaunchKernelGGL((flash_attn_kernel<DHV, NWV, STG>), dim3((unsigned)nwg), dim3(64 * NWV), 2 * 2 * KVB * 2 * DHV + (STG ? 32 * NWV * 2 * DHV : 0), (hipStream_t)stream, \
+#define UG_ATTN_LAUNCH(DHV, NWV, STG, ...)                                                                                           \
+    hipLaunchKernelGGL((flash_attn_kernel<DHV, NWV, STG, ##__VA_ARGS__>), dim3((unsigned)nwg), dim3(64 * NWV), 2 * 2 * KVB * 2 * DHV + (STG ? 32 * NWV * 2 * DHV : 0), (hipStream_t)stream, \
                        (const bf16_t*)q, q_row_stride, q_batch_stride, (const bf16_t*)k, k_row_stride, k_batch_stride, (const bf16_t*)v, \
                        v_row_stride, v_batch_stride, (bf16_t*)o, o_row_stride, o_batch_stride, (int)heads, (int)Lq, (int)Lkv, nQ, c)
     static int pwg = -1;
@@ -896,8 +916,19 @@ extern "C" int ug_flash_attn_fwd(const void* q, int64_t q_row_stride, int64_t q_
     // 1068 vs 1044 (8192), 956 vs 933 (B16, 2048); dh = 64 inside the SD3.5 forward: 795 vs 775.
     if (stagger < 0) { const char* e = getenv("UG_ATTN_STAGGER"); stagger = (e && atoi(e) == 0) ? 0 : 1; }
     const bool stg = stagger == 1;
-    if (dh == 128) { if (nw == 4) UG_ATTN_LAUNCH(128, 4, false); else if (stg) UG_ATTN_LAUNCH(128, 8, true); else UG_ATTN_LAUNCH(128, 8, false); }
-    else           { if (nw == 4) UG_ATTN_LAUNCH(64, 4, false); else if (stg) UG_ATTN_LAUNCH(64, 8, true); else UG_ATTN_LAUNCH(64, 8, false); }
+    // UG_ATTN_PRIO = 0 | 1 | 2, UG_ATTN_WIDE = 0 | 1: A/B switches of the stagger kernel (re-read per call when UG_ENV_DYNAMIC=1)
+    // Interleaved A/B, round 2 (tools/attn_ab.py, same process): prio 0 + wide stores is the fastest form everywhere - dh 128: 1137 / 1147 / 1178
+    // vs 1124 / 1133 / 1172 TFLOP/s for the round-1 default (prio 1, narrow) at 4608^2 / 4096x4608 / 8192x8704; dh 64: 880-885 vs 856-871; the
+    // static young-half priority (2) loses 1-2 % at dh 128.
+    const int prio = ug_env_int("UG_ATTN_PRIO", 0), wide = ug_env_int("UG_ATTN_WIDE", 1);
+#define UG_ATTN_STG(DHV)                                                                          \
+    do {                                                                                          \
+        if (wide) { if (prio == 0) UG_ATTN_LAUNCH(DHV, 8, true, 0, true); else if (prio == 2) UG_ATTN_LAUNCH(DHV, 8, true, 2, true); else UG_ATTN_LAUNCH(DHV, 8, true, 1, true); } \
+        else { if (prio == 0) UG_ATTN_LAUNCH(DHV, 8, true, 0, false); else if (prio == 2) UG_ATTN_LAUNCH(DHV, 8, true, 2, false); else UG_ATTN_LAUNCH(DHV, 8, true, 1, false); } \
+    } while (0)
+    if (dh == 128) { if (nw == 4) UG_ATTN_LAUNCH(128, 4, false); else if (stg) UG_ATTN_STG(128); else UG_ATTN_LAUNCH(128, 8, false); }
+    else           { if (nw == 4) UG_ATTN_LAUNCH(64, 4, false); else if (stg) UG_ATTN_STG(64); else UG_ATTN_LAUNCH(64, 8, false); }
+#undef UG_ATTN_STG
 #undef UG_ATTN_LAUNCH
     UG_CHECK_LAUNCH("ug_flash_attn_fwd");
     return UG_OK;

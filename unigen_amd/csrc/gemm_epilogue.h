@@ -1,0 +1,231 @@
+// Device helpers shared by the bf16 GEMM kernels (gemm.hip: 128^2 and 256^2 8-wave kernels; gemm_pwg.hip: one wave per SIMD):
+// LDS-DMA staging, XCD-aware tile order, row maps and the fused epilogues (bias / GELU-tanh / residual + gate / residual + scale / fp32).
+#pragma once
+#include "ug_common.h"
+
+// one-wave-per-SIMD 256^2 kernel (gemm_pwg.hip); the dispatcher in gemm.hip decides when it runs
+int ug_gemm_launch_pwg(const ug_gemm_desc& d, hipStream_t s);
+
+namespace {
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__device__ __forceinline__ void glds16(const void* g, unsigned char* l) {
+    __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 16, 0, 0);
+}
+
+struct TileCoord { int tm, tn; };
+
+// XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch), so give each XCD a contiguous chunk of
+// the tile sequence, and walk that sequence in groups of 8 M-tiles x all N-tiles so co-resident tiles share A/W panels
+// in the XCD's L2. Only affects speed.
+__device__ __forceinline__ TileCoord tile_of_block(int bid, int nM, int nN) {
+    const int nwg = nM * nN;
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = bid & 7, k = bid >> 3;
+    const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;  // bijective for any nwg
+    constexpr int GROUP_M = 8;
+    const int per_group = GROUP_M * nN;
+    const int gid = id / per_group;
+    const int first_m = gid * GROUP_M;
+    const int gsz = min(nM - first_m, GROUP_M);
+    const int rem = id - gid * per_group;
+    TileCoord t;
+    t.tm = first_m + rem % gsz;
+    t.tn = rem / gsz;
+    return t;
+}
+
+__device__ __forceinline__ float gelu_tanh(float x) {
+    // 0.5 x (1 + tanh(u)), u = sqrt(2/pi) (x + 0.044715 x^3)  ==  x / (1 + exp(-2u)): 3 multiplies/FMAs, v_exp_f32, add, v_rcp_f32, multiply
+    // (the textbook form with an IEEE division is ~24 VALU instructions per element; the epilogue is VALU-bound). No cancellation
+    // for x << 0, exp -> inf gives rcp -> 0 -> -0.
+    constexpr float C0 = -2.3022081986f;            // -2 sqrt(2/pi) log2(e)
+    constexpr float C1 = C0 * 0.044715f;
+    const float u = x * fmaf(x * x, C1, C0);
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u));
+}
+
+__device__ __forceinline__ void load_bias4(const bf16_t* bias, int64_t n, float* bv) {
+    bv[0] = bv[1] = bv[2] = bv[3] = 0.f;
+    if (bias) {
+        const u32x2 b2 = *(const u32x2*)(bias + n);
+        bv[0] = bflo(b2.x); bv[1] = bfhi(b2.x); bv[2] = bflo(b2.y); bv[3] = bfhi(b2.y);
+    }
+}
+
+// Per-output-row context of the epilogue, computed ONCE per row (the row maps and the gate's sample index are integer
+// divisions; doing them per 4-element chunk cost ~30 us per 256x256 tile).
+struct RowCtx { int64_t coff, roff, goff; };
+
+__device__ __forceinline__ unsigned rowmap32(unsigned m, unsigned rpb, unsigned bstride) {
+    if (rpb == 0) return m;
+    const unsigned b = m / rpb;
+    return b * bstride + (m - b * rpb);
+}
+
+template <int EPI>
+__device__ __forceinline__ RowCtx row_ctx(const ug_gemm_desc& p, int g, unsigned m) {
+    RowCtx c;
+    c.coff = (int64_t)g * p.c_gstride + (int64_t)rowmap32(m, (unsigned)p.c_rpb, (unsigned)p.c_bstride) * p.ldc;
+    c.roff = 0; c.goff = 0;
+    if constexpr (EPI == UG_EPI_RES_GATE || EPI == UG_EPI_RES_SCALE)
+        c.roff = (int64_t)g * p.r_gstride + (int64_t)rowmap32(m, (unsigned)p.r_rpb, (unsigned)p.r_bstride) * p.ldr;
+    if constexpr (EPI == UG_EPI_RES_GATE)
+        c.goff = (int64_t)g * p.gate_gstride + (int64_t)(m / (unsigned)p.rows_per_sample) * p.gate_ld;
+    return c;
+}
+
+// Column split of a launch over two concatenated Linear layers (ug_gemm_desc.gelu_from_n / c_shift_from_n / c_shift): both boundaries are
+// multiples of 256, so they are uniform per tile of either kernel.
+struct TileSplit { bool gelu; int64_t cshift; };
+template <int EPI>
+__device__ __forceinline__ TileSplit tile_split(const ug_gemm_desc& p, int64_t n0) {
+    TileSplit t;
+    t.gelu = EPI == UG_EPI_BIAS_GELU && n0 >= p.gelu_from_n;
+    t.cshift = (p.c_shift_from_n > 0 && n0 >= p.c_shift_from_n) ? p.c_shift : 0;
+    return t;
+}
+
+// one lane's 4 consecutive n of one row: v = bf16(acc + bias) then the fused elementwise tail, 8-byte store
+template <int EPI>
+__device__ __forceinline__ void epi_store(const ug_gemm_desc& p, const RowCtx& rc, int64_t n, const f32x4 a, const float* bv) {
+    float v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = a[r] + bv[r];
+    if constexpr (EPI == UG_EPI_F32) {
+        float* C = (float*)p.C + rc.coff + n;
+        *(f32x4*)C = (f32x4){v[0], v[1], v[2], v[3]};
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = rbf(v[r]);
+        if constexpr (EPI == UG_EPI_BIAS_GELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = gelu_tanh(v[r]);
+        } else if constexpr (EPI == UG_EPI_RES_GATE || EPI == UG_EPI_RES_SCALE) {
+            const u32x2 r2 = *(const u32x2*)((const bf16_t*)p.R + rc.roff + n);
+            const float rv[4] = {bflo(r2.x), bfhi(r2.x), bflo(r2.y), bfhi(r2.y)};
+            if constexpr (EPI == UG_EPI_RES_GATE) {
+                const u32x2 g2 = *(const u32x2*)((const bf16_t*)p.gate + rc.goff + n);
+                const float gv[4] = {bflo(g2.x), bfhi(g2.x), bflo(g2.y), bfhi(g2.y)};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = rv[r] + rbf(gv[r] * v[r]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = rv[r] + rbf(p.alpha * v[r]);
+            }
+        }
+        u32x2 o; o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]);
+        *(u32x2*)((bf16_t*)p.C + rc.coff + n) = o;
+    }
+}
+
+// 16-byte epilogue for two adjacent 16-column n-tiles X (cols c..c+15) and Y (c+16..c+31) of one 16-row m-tile. In the accumulator
+// layout lane (row r = lane & 15, g = lane >> 4) holds columns 4g..4g+3 of each tile (8 bytes of bf16). v_permlane16_swap exchanges the
+// odd 16-lane rows of its first operand with the even rows of the second, after which lane g holds 8 CONTIGUOUS columns of one
+// tile: tile (g & 1), columns 8 (g >> 1) .. +7 -> one dwordx4 load / store per lane instead of two dwordx2 per tile pair. The
+// epilogue is store-issue bound (cdna guide T21), so halving the instruction count at equal bytes shortens it.
+__device__ __forceinline__ void swap16(unsigned& a, unsigned& b) {
+    const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+    a = r[0]; b = r[1];
+}
+
+template <int EPI>
+__device__ __forceinline__ void epi_store_pair16(const ug_gemm_desc& p, const RowCtx& rc, bool row_ok, int64_t n_blk, int64_t N, int lane,
+                                                 const f32x4 ax, const f32x4 ay, const float* bx, const float* by) {
+    const int g = lane >> 4;
+    const int64_t col = n_blk + (g & 1) * 16 + 8 * (g >> 1);          // this lane's 8 contiguous output columns after the swap
+    const bool ok = row_ok && col < N;
+    float vx[4], vy[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { vx[r] = rbf(ax[r] + bx[r]); vy[r] = rbf(ay[r] + by[r]); }
+    if constexpr (EPI == UG_EPI_BIAS_GELU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { vx[r] = gelu_tanh(vx[r]); vy[r] = gelu_tanh(vy[r]); }
+    } else if constexpr (EPI == UG_EPI_RES_GATE || EPI == UG_EPI_RES_SCALE) {
+        u32x4 c = {0u, 0u, 0u, 0u};
+        if (ok) c = *(const u32x4*)((const bf16_t*)p.R + rc.roff + col);
+        unsigned c0 = c.x, c1 = c.y, c2 = c.z, c3 = c.w;
+        swap16(c0, c2); swap16(c1, c3);                               // back to the accumulator layout: (c0, c1) = X, (c2, c3) = Y
+        const float rx[4] = {bflo(c0), bfhi(c0), bflo(c1), bfhi(c1)};
+        const float ry[4] = {bflo(c2), bfhi(c2), bflo(c3), bfhi(c3)};
+        if constexpr (EPI == UG_EPI_RES_GATE) {
+            const int64_t nx = n_blk + g * 4, ny = nx + 16;
+            const bf16_t* G = (const bf16_t*)p.gate + rc.goff;
+            u32x2 gx = {0u, 0u}, gy = {0u, 0u};
+            if (row_ok && nx < N) gx = *(const u32x2*)(G + nx);
+            if (row_ok && ny < N) gy = *(const u32x2*)(G + ny);
+            const float fgx[4] = {bflo(gx.x), bfhi(gx.x), bflo(gx.y), bfhi(gx.y)};
+            const float fgy[4] = {bflo(gy.x), bfhi(gy.x), bflo(gy.y), bfhi(gy.y)};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { vx[r] = rx[r] + rbf(fgx[r] * vx[r]); vy[r] = ry[r] + rbf(fgy[r] * vy[r]); }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { vx[r] = rx[r] + rbf(p.alpha * vx[r]); vy[r] = ry[r] + rbf(p.alpha * vy[r]); }
+        }
+    }
+    unsigned x0 = pack2bf(vx[0], vx[1]), x1 = pack2bf(vx[2], vx[3]);
+    unsigned y0 = pack2bf(vy[0], vy[1]), y1 = pack2bf(vy[2], vy[3]);
+    swap16(x0, y0); swap16(x1, y1);
+    if (ok) {
+        u32x4 o; o.x = x0; o.y = x1; o.z = y0; o.w = y1;
+        *(u32x4*)((bf16_t*)p.C + rc.coff + col) = o;
+    }
+}
+
+// Branch-free variant of epi_store_pair16 for FULL tiles: the residual chunk `r` (this lane's 16 bytes of R, store layout) was loaded
+// by the caller a row-group ahead, bias / gate / alpha arrive as floats in the accumulator layout, and the result comes back in the
+// store layout. With no exec-masked blocks and no loads of its own the compiler keeps the row-group loop one basic block with counted
+// vmcnt waits (the masked version put `s_waitcnt vmcnt(0)` after every bias / gate / residual load, draining the next tile's DMA
+// prefetch and every earlier store each time: 7 / 17 / 27 us per tile-round for BIAS / GELU / RES_GATE, now ~3 / 6 / 9).
+// Residual loads of the full-tile epilogue as inline asm: hipcc's waitcnt pass then neither sees them nor waits for them - it put
+// `vmcnt(0)` where `vmcnt(4)` is exact, which also drains the previous row-group's stores - and ug_wait_vm<N> states the wait (loads,
+// stores and LDS-DMA retire in issue order on the VM counter). The "memory" clobbers keep the C stores on their side of each load.
+__device__ __forceinline__ u32x4 gload16_asm(const void* ptr) {
+    u32x4 r;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r) : "v"(ptr) : "memory");
+    return r;
+}
+__device__ __forceinline__ u32x4 gload16_asm_256(const void* ptr) {
+    u32x4 r;
+    asm volatile("global_load_dwordx4 %0, %1, off offset:256" : "=v"(r) : "v"(ptr) : "memory");
+    return r;
+}
+template <int N>
+__device__ __forceinline__ void ug_wait_vm(u32x4& a, u32x4& b) {
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory");
+}
+
+template <int EPI>
+__device__ __forceinline__ u32x4 epi_chunk_full(const float alpha, const f32x4 ax, const f32x4 ay, const float* bx, const float* by,
+                                                const float* gx, const float* gy, const u32x4 r) {
+    float vx[4], vy[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { vx[q] = ax[q] + bx[q]; vy[q] = ay[q] + by[q]; }
+    if constexpr (EPI != UG_EPI_BIAS) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { vx[q] = rbf(vx[q]); vy[q] = rbf(vy[q]); }      // the Linear's bf16 output
+    }
+    if constexpr (EPI == UG_EPI_BIAS_GELU) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { vx[q] = gelu_tanh(vx[q]); vy[q] = gelu_tanh(vy[q]); }
+    } else if constexpr (EPI == UG_EPI_RES_GATE || EPI == UG_EPI_RES_SCALE) {
+        unsigned c0 = r.x, c1 = r.y, c2 = r.z, c3 = r.w;
+        swap16(c0, c2); swap16(c1, c3);                               // back to the accumulator layout: (c0, c1) = X, (c2, c3) = Y
+        const float rx[4] = {bflo(c0), bfhi(c0), bflo(c1), bfhi(c1)};
+        const float ry[4] = {bflo(c2), bfhi(c2), bflo(c3), bfhi(c3)};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float sx = EPI == UG_EPI_RES_GATE ? gx[q] : alpha, sy = EPI == UG_EPI_RES_GATE ? gy[q] : alpha;
+            vx[q] = rx[q] + rbf(sx * vx[q]); vy[q] = ry[q] + rbf(sy * vy[q]);
+        }
+    }
+    unsigned x0 = pack2bf(vx[0], vx[1]), x1 = pack2bf(vx[2], vx[3]);
+    unsigned y0 = pack2bf(vy[0], vy[1]), y1 = pack2bf(vy[2], vy[3]);
+    swap16(x0, y0); swap16(x1, y1);
+    u32x4 o; o.x = x0; o.y = x1; o.z = y0; o.w = y1;
+    return o;
+}
+
+}  // namespace

@@ -22,6 +22,9 @@ void ug_set_error(const char* fmt, ...);
 #define UG_CHECK_LAUNCH(name) do { hipError_t e_ = hipGetLastError(); \
     if (e_ != hipSuccess) UG_FAIL(UG_ERR_HIP, "%s: launch failed: %s", name, hipGetErrorString(e_)); } while (0)
 
+// integer tuning switch from the environment: cached per call site name, re-read on every call when UG_ENV_DYNAMIC=1 (A/B tools)
+int ug_env_int(const char* name, int dflt);
+
 static inline bool ug_aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
 // ---- bf16 <-> f32 (device) -------------------------------------------------------------
