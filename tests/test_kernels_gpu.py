@@ -496,7 +496,7 @@ dev = torch.device("cuda:0")
 g = torch.Generator(device=dev).manual_seed(0)
 rn = lambda *s: torch.randn(*s, generator=g, device=dev).to(torch.bfloat16)
 bad = 0
-for (M, N, K, epi, grp) in [(600, 520, 192, L.EPI_BIAS, 1), (512, 768, 3072, L.EPI_BIAS_GELU, 1), (1000, 256, 96, L.EPI_RES_GATE, 1), (300, 512, 64, L.EPI_RES_SCALE, 1),
+for (M, N, K, epi, grp) in [(600, 520, 192, L.EPI_BIAS, 1), (512, 768, 3072, L.EPI_BIAS_GELU, 1), (1000, 256, 320, L.EPI_RES_GATE, 1), (300, 512, 64, L.EPI_RES_SCALE, 1),
                             (260, 256, 128, L.EPI_BIAS, 3), (512, 1024, 256, "split", 1)]:
     a, w, b = rn(grp, M, K), rn(grp, N, K) * 0.1, rn(grp, N)
     r, gate = rn(grp, M, N), rn(grp, (M + 99) // 100, N)

@@ -1,6 +1,6 @@
 """Summarise rocprofv3 --pmc passes of bench.py into profiles/<tag>_pmc.json.
 
-usage: python tools/pmc_summary.py TAG FETCH_CSV WRITE_CSV BUSY_CSV
+usage: python tools/pmc_summary.py TAG FETCH_CSV WRITE_CSV BUSY_CSV [TCC_CSV]
 Each CSV is a *_counter_collection.csv of one pass (`rocprofv3 --kernel-trace --pmc <counters> --output-format csv -- python3 bench.py
 --steps 1 --warmup 0 --no-cpu-baseline --no-kernel-timer`; counters in separate passes as MI355X_MICROARCH.md prescribes).
 HBM-side bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE under-counts wide coalesced reads by 2x; KiB units).
@@ -12,6 +12,7 @@ from collections import defaultdict
 
 def classify(name: str):
     if "gemm256_kernel" in name: return "gemm256"
+    if "gemm_pwg_kernel" in name: return "gemm_pwg"
     if "gemm128_kernel" in name: return "gemm128"
     if "flash_attn" in name: return "attn"
     return None
@@ -31,6 +32,7 @@ def load(path):
 def main():
     tag, fcsv, wcsv, bcsv = sys.argv[1:5]
     F, W, Bz = load(fcsv), load(wcsv), load(bcsv)
+    T = load(sys.argv[5]) if len(sys.argv) > 5 else {}
     out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE (separate passes) -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-kernel-timer",
            "correction": "bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 FETCH_SIZE correction; KiB units); counters beyond the XCD L2 include Infinity-Cache hits",
            "kernels": {}}
@@ -46,6 +48,10 @@ def main():
             k["mfma_busy_frac"] = bs / (cyc * 256 * 4) * 8 if False else bs / (gs / 8.0 * 1024)
             k["effective_clock_ghz"] = cyc / bns
             k["avg_launch_us_profiled"] = bns / bn / 1e3
+        if c in T and "TCC_HIT_sum" in T[c]:
+            hs, _, _ = T[c]["TCC_HIT_sum"]; ms, _, _ = T[c]["TCC_MISS_sum"]
+            k["l2_hit_rate"] = hs / max(hs + ms, 1.0)
+            k["l2_requests_per_launch"] = (hs + ms) / fn
         out["kernels"][c] = k
         if c.startswith("gemm"):
             tot_b += k["hbm_bytes_per_launch"] * fn; tot_n += fn
