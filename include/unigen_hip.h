@@ -194,6 +194,46 @@ int ug_moe_combine(const void* yh, const void* yc, const float* gates, const int
 int ug_pack_latents(const void* latents, void* packed, int64_t B, int64_t C, int64_t H, int64_t W, ug_stream_t stream);
 int ug_unpack_latents(const void* packed, void* latents, int64_t B, int64_t C, int64_t H, int64_t W, ug_stream_t stream);
 
+/* ---- AutoencoderKL (the VAE either side of the hot path; reference src/UniGenPipeline.py:635-636 vae.encode of the
+ * condition image, :797-798 vae.decode of the latents; diffusers 0.32.2 Encoder / Decoder / ResnetBlock2D / Upsample2D / Downsample2D /
+ * Attention). Activations are NHWC [B][H][W][C]; 1x1 convolutions and the attention projections are ug_gemm_bf16 on [B H W][C]. ---- */
+
+typedef struct ug_conv_desc {
+    /* out[b][oy][ox][n] = R[..] + bf16( bias[n] + sum_{ky,kx,c} x[b][(oy*stride + ky - pad_t) >> up][(ox*stride + kx - pad_l) >> up][c] * w[n][ky][kx][c] ),
+     * taps whose (virtual) coordinate falls outside [0, H << up) x [0, W << up) contribute zero. up = 1 folds Upsample2D's nearest-2x
+     * interpolation into the gather; Downsample2D(padding=0)'s F.pad(x, (0, 1, 0, 1)) + stride-2 conv is pad_t = pad_l = 0, stride = 2. */
+    const void* x; int64_t B, H, W, Cin;        /* NHWC input; Cin a multiple of 64 (zero-pad the channels) */
+    const void* w;                              /* [Cout][KH][KW][Cin] (torch's [Cout][Cin][KH][KW] permuted once at load time) */
+    const void* bias;                           /* [Cout] or NULL */
+    const void* R;                              /* residual, NHWC [B][Ho][Wo][Cout] or NULL (may alias out) */
+    void* out; int64_t Ho, Wo, Cout;            /* Cout a multiple of 4 */
+    int32_t KH, KW, stride, pad_t, pad_l, up;
+    const void* zero_page;                      /* >= 128 bytes of zeros, 16-byte aligned (device): what padding taps read */
+} ug_conv_desc;
+
+/* torch F.conv2d (called by diffusers Conv2d layers of the VAE) as an implicit GEMM on MFMA. */
+int ug_conv2d_nhwc(const ug_conv_desc* d, ug_stream_t stream);
+
+/* out = [SiLU](GroupNorm(x; G groups, eps, gamma, beta)), x / out NHWC [B][HW][C] (F.group_norm + F.silu in ResnetBlock2D / Attention.group_norm /
+ * conv_norm_out). Deterministic two-pass statistics in fp64; workspace >= ug_groupnorm_workspace_bytes(B, HW, G), 8-byte aligned, no init needed. */
+int64_t ug_groupnorm_workspace_bytes(int64_t B, int64_t HW, int32_t G);
+int ug_groupnorm_nhwc(const void* x, const void* gamma, const void* beta, void* out, void* workspace, int64_t workspace_bytes,
+                      int64_t B, int64_t HW, int64_t C, int32_t G, float eps, int32_t silu, ug_stream_t stream);
+
+/* P[r][c] = softmax_c(scale * S[r][c]), S fp32 (ug_gemm_bf16 with UG_EPI_F32), P bf16: the VAE mid-block attention has one head of dim C
+ * (F.scaled_dot_product_attention in AttnProcessor2_0), run as scores GEMM -> this -> P.V GEMM. */
+int ug_softmax_rows(const float* S, int64_t ld_s, void* P, int64_t ld_p, int64_t rows, int64_t cols, float scale, ug_stream_t stream);
+
+/* Layout changes at the VAE boundary: NCHW [B][C][HW] <-> NHWC [B][HW][Cp], Cp >= C (extra channels zero / ignored). div != 0 applies the
+ * decode side's latent un-scaling on the way in: v -> bf16(bf16(v / div) + add)  (latents / scaling_factor + shift_factor, :797). */
+int ug_nchw_to_nhwc(const void* in, void* out, int64_t B, int64_t C, int64_t HW, int64_t Cp, float div, float add, ug_stream_t stream);
+int ug_nhwc_to_nchw(const void* in, void* out, int64_t B, int64_t C, int64_t HW, int64_t Cp, ug_stream_t stream);
+
+/* z = ((mean + exp(0.5 clamp(logvar, -30, 20)) * noise) - shift) * scale: DiagonalGaussianDistribution.sample() and the latent scaling of
+ * :635-636. moments NHWC [B][HW][Cp] (mean = channels [0, L), logvar = [L, 2L)); noise, z NCHW [B][L][HW]. */
+int ug_vae_sample(const void* moments, int64_t Cp, const void* noise, void* z, int64_t B, int64_t L, int64_t HW, float shift, float scale,
+                  ug_stream_t stream);
+
 /* ---- fp32 verification twins (see the conventions at the top). Same arguments as the functions they mirror; every `void*` tensor
  * that is bf16 there is fp32 here (weights included); fp32 / integer arguments are unchanged. ug_gemm_f32: K, N unconstrained,
  * the column-split boundaries multiples of 64, no workspace. ug_small_linear_f32: M <= 64. ---- */
@@ -231,6 +271,14 @@ int ug_moe_dispatch_modulate_f32(const void* x, int64_t ldx, const void* add, co
 int ug_moe_combine_f32(const void* yh, const void* yc, const float* gates, const int32_t* idx, const int32_t* slot,
                        int32_t E, int64_t capacity, const void* xs, const void* cs, int64_t ld_s, int64_t s_rpb, int64_t s_bstride,
                        void* out, int64_t ldo, int64_t S, int64_t D, int32_t accumulate, ug_stream_t stream);
+int ug_conv2d_nhwc_f32(const ug_conv_desc* d, ug_stream_t stream);      /* any Cin / Cout, no zero_page */
+int ug_groupnorm_nhwc_f32(const void* x, const void* gamma, const void* beta, void* out, void* workspace, int64_t workspace_bytes,
+                          int64_t B, int64_t HW, int64_t C, int32_t G, float eps, int32_t silu, ug_stream_t stream);
+int ug_softmax_rows_f32(const float* S, int64_t ld_s, void* P, int64_t ld_p, int64_t rows, int64_t cols, float scale, ug_stream_t stream);
+int ug_nchw_to_nhwc_f32(const void* in, void* out, int64_t B, int64_t C, int64_t HW, int64_t Cp, float div, float add, ug_stream_t stream);
+int ug_nhwc_to_nchw_f32(const void* in, void* out, int64_t B, int64_t C, int64_t HW, int64_t Cp, ug_stream_t stream);
+int ug_vae_sample_f32(const void* moments, int64_t Cp, const void* noise, void* z, int64_t B, int64_t L, int64_t HW, float shift, float scale,
+                      ug_stream_t stream);
 int ug_pack_latents_f32(const void* latents, void* packed, int64_t B, int64_t C, int64_t H, int64_t W, ug_stream_t stream);
 int ug_unpack_latents_f32(const void* packed, void* latents, int64_t B, int64_t C, int64_t H, int64_t W, ug_stream_t stream);
 

@@ -86,12 +86,34 @@ def block_goldens():
         print(name, sorted(k for k in tensors if k.startswith("out.bf16")))
 
 
+def vae_golden():
+    """AutoencoderKL fixture (oracle/vae_ref.py): tiny config, image -> scaled latent sample, latents -> image, bf16 and fp32."""
+    from oracle import vae_ref as V
+    cfg_d = dict(block_out_channels=(64, 128), layers_per_block=1, norm_num_groups=32)
+    case = dict(state_seed=31, input_seed=12447, B=2, H=32, W=32)
+    cfg = V.VAEConfig(**cfg_d)
+    st = V.make_vae_state(cfg, seed=case["state_seed"])
+    g = torch.Generator().manual_seed(case["input_seed"])
+    img = (torch.rand(case["B"], 3, case["H"], case["W"], generator=g) * 2 - 1).to(torch.bfloat16)
+    noise = torch.randn(case["B"], 16, case["H"] // 2, case["W"] // 2, generator=g).to(torch.bfloat16)
+    lat = torch.randn(case["B"], 16, 8, 8, generator=g).to(torch.bfloat16)
+    tensors = {"in.image": img, "in.noise": noise, "in.latents": lat}
+    for tag, dt in (("bf16", torch.bfloat16), ("fp32", torch.float32)):
+        tensors[f"out.{tag}.z"] = V.encode_condition(st, cfg, img, noise, dt).contiguous()
+        tensors[f"out.{tag}.image"] = V.decode_latents(st, cfg, lat, dt).contiguous()
+    save_file(tensors, os.path.join(HERE, "vae_tiny.safetensors"), metadata=dict(config=json.dumps(cfg_d), case=json.dumps(case), generator="oracle/vae_ref.py"))
+    print("vae_tiny", {k: tuple(v.shape) for k, v in tensors.items()})
+
+
 def main():
     torch.set_num_threads(4)
+    if "--vae-only" in sys.argv:
+        return vae_golden()
     if "--only-new" not in sys.argv:
         flux_goldens()
     sd3_goldens()
     block_goldens()
+    vae_golden()
 
 
 def flux_goldens():

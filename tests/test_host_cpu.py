@@ -240,6 +240,34 @@ def test_sd3_default_sigmas_match_diffusers_0_32_2():
     assert max(abs(a - b) for a, b in zip(sig, lit)) < 1e-6
 
 
+def test_vae_dropin_names_and_loading(tmp_path):
+    """unigen_amd.vae.AutoencoderKL keeps diffusers' parameter names / shapes (FLUX VAE: 83.8 M parameters) and loads the diffusers directory layout."""
+    from types import SimpleNamespace
+    from oracle import vae_ref as V
+    from safetensors.torch import save_file
+    from unigen_amd.vae import AutoencoderKL, FLUX_VAE_CONFIG, vae_param_shapes
+    full = vae_param_shapes(SimpleNamespace(**FLUX_VAE_CONFIG))
+    assert full == V.vae_state_shapes(V.VAEConfig()) and sum(int(torch.Size(s).numel()) for s in full.values()) == 83819683
+    for k in ("encoder.down_blocks.1.resnets.0.conv_shortcut.weight", "encoder.down_blocks.2.downsamplers.0.conv.bias", "decoder.mid_block.attentions.0.to_out.0.weight",
+              "decoder.up_blocks.2.upsamplers.0.conv.weight", "decoder.conv_norm_out.bias", "encoder.conv_out.weight"):
+        assert k in full
+    tiny = dict(block_out_channels=(64, 128), layers_per_block=1)
+    m = AutoencoderKL.from_config(tiny)
+    assert m.config.scaling_factor == 0.3611 and m.config.shift_factor == 0.1159 and m.dtype == torch.bfloat16
+    st = V.make_vae_state(V.VAEConfig(**tiny), seed=1)
+    d = tmp_path / "vae"; d.mkdir()
+    save_file({k: v.contiguous() for k, v in st.items()}, str(d / "diffusion_pytorch_model.safetensors"))
+    (d / "config.json").write_text(json.dumps(dict(tiny, latent_channels=16, scaling_factor=1.5305, shift_factor=0.0609, _class_name="AutoencoderKL")))
+    m2 = AutoencoderKL.from_pretrained(str(tmp_path), subfolder="vae")
+    assert m2.config.scaling_factor == 1.5305 and all(torch.equal(m2.state_dict()[k], st[k]) for k in st)
+    wp, bp = m2._conv_w("encoder.conv_in")                # packed [Cout_p, KH, KW, Cin_p]: channels zero-padded to the conv's K granularity
+    assert wp.shape == (64, 3, 3, 64) and torch.equal(wp[:, :, :, :3], st["encoder.conv_in.weight"].permute(0, 2, 3, 1)) and float(wp[:, :, :, 3:].abs().max()) == 0
+    pipe = importlib.import_module("src.UniGenPipeline").UniGenFLUXPipeline.from_pretrained(str(tmp_path), transformer=None)
+    assert isinstance(pipe.vae, AutoencoderKL)
+    with pytest.raises(Exception):
+        m2.encode(torch.zeros(1, 3, 32, 32))              # no CPU path
+
+
 def test_shard_ranges_cover_the_global_batch():
     from unigen_amd.dist_utils import shard_range
     for G, W in ((64, 8), (64, 1), (10, 4), (3, 8)):

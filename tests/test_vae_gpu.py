@@ -1,0 +1,189 @@
+"""GPU parity of the AutoencoderKL row: the implicit-GEMM convolution, GroupNorm(+SiLU), row softmax, layout / sampling
+kernels against plain torch on the CPU, and the whole encode / decode against the oracle (oracle/vae_ref.py) and the committed fixture
+(tests/golden/vae_tiny.safetensors) - in the product arithmetic (bf16) and through the fp32 verification twins.
+
+Stated tolerances: kernels: convolution / GroupNorm relL2 <= 1e-3 vs torch's fp32-accumulate-round-once result on the same bf16 inputs (most are
+bit-exact up to summation order); fp32 twins <= 1e-5. Whole VAE: fp32 path relL2 <= 1e-3 vs the oracle's fp32 evaluation (north star's figure;
+measured ~1e-6), bf16 path no further from that truth than 1.25x the oracle's own bf16 evaluation.
+"""
+import importlib
+import json
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+from safetensors import safe_open
+
+from oracle import vae_ref as V
+from tests.util import rel_l2, report
+
+pytestmark = pytest.mark.gpu
+BF, F32 = torch.bfloat16, torch.float32
+TINY = dict(block_out_channels=(64, 128), layers_per_block=1, norm_num_groups=32)
+
+
+def _r(g, *shape, scale=1.0):
+    return (scale * torch.randn(*shape, generator=g)).to(BF)
+
+
+@pytest.mark.parametrize("case", [
+    dict(B=2, H=12, W=10, Cin=64, Cout=64, mode="same"), dict(B=1, H=16, W=16, Cin=128, Cout=192, mode="same", res=True),
+    dict(B=2, H=14, W=12, Cin=64, Cout=128, mode="down"), dict(B=1, H=9, W=7, Cin=192, Cout=8, mode="up"), dict(B=3, H=8, W=8, Cin=64, Cout=32, mode="up", res=True)])
+@pytest.mark.parametrize("dt", [BF, F32])
+def test_conv2d_nhwc_matches_torch(gpu, case, dt):
+    from unigen_amd import ops
+    g = torch.Generator().manual_seed(1)
+    B, H, W, Cin, Cout, mode = case["B"], case["H"], case["W"], case["Cin"], case["Cout"], case["mode"]
+    x = _r(g, B, Cin, H, W)
+    w = _r(g, Cout, Cin, 3, 3, scale=(9 * Cin) ** -0.5)
+    b = _r(g, Cout, scale=0.1)
+    xf, wf, bf_ = x.float(), w.float(), b.float()
+    if mode == "same":
+        ref = F.conv2d(xf, wf, bf_, padding=1); kw = dict(stride=1, pad_t=1, pad_l=1, up=0)
+    elif mode == "down":
+        ref = F.conv2d(F.pad(xf, (0, 1, 0, 1)), wf, bf_, stride=2); kw = dict(stride=2, pad_t=0, pad_l=0, up=0)
+    else:
+        ref = F.conv2d(F.interpolate(xf, scale_factor=2.0, mode="nearest"), wf, bf_, padding=1); kw = dict(stride=1, pad_t=1, pad_l=1, up=1)
+    Ho, Wo = ref.shape[-2:]
+    if dt == BF:
+        ref = ref.to(BF).float()
+    res = _r(g, B, Cout, Ho, Wo) if case.get("res") else None
+    if res is not None:
+        ref = ref + res.float()
+    xh = x.permute(0, 2, 3, 1).reshape(B * H * W, Cin).contiguous().to(gpu, dt)
+    wh = w.permute(0, 2, 3, 1).contiguous().to(gpu, dt)
+    out = torch.empty(B * Ho * Wo, Cout, device=gpu, dtype=dt)
+    rh = res.permute(0, 2, 3, 1).reshape(B * Ho * Wo, Cout).contiguous().to(gpu, dt) if res is not None else None
+    ops.conv2d_nhwc(xh, wh, b.to(gpu, dt), out, B=B, H=H, W=W, Ho=Ho, Wo=Wo, KH=3, KW=3, residual=rh, **kw)
+    got = out.view(B, Ho, Wo, Cout).permute(0, 3, 1, 2)
+    m = report(f"conv2d_{mode}_{Cin}x{Cout}_{'bf16' if dt == BF else 'f32'}", got, ref if dt == F32 else ref.to(BF))
+    assert m["rel_l2"] <= (1e-3 if dt == BF else 1e-5), m
+
+
+@pytest.mark.parametrize("dt", [BF, F32])
+def test_groupnorm_softmax_layout_sample(gpu, dt):
+    from unigen_amd import ops
+    g = torch.Generator().manual_seed(2)
+    B, HW, Cc, G = 2, 200, 128, 32
+    x, ga, be = _r(g, B, HW, Cc) * 2 + 0.5, 1 + _r(g, Cc, scale=0.1), _r(g, Cc, scale=0.1)
+    for silu in (False, True):
+        ref = F.group_norm(x.float().transpose(1, 2), G, ga.float(), be.float(), eps=1e-6).transpose(1, 2)
+        if dt == BF:
+            ref = ref.to(BF).float()
+        if silu:
+            ref = F.silu(ref)
+        out = torch.empty(B * HW, Cc, device=gpu, dtype=dt)
+        ops.groupnorm_nhwc(x.reshape(B * HW, Cc).to(gpu, dt), ga.to(gpu, dt), be.to(gpu, dt), out, B=B, HW=HW, groups=G, silu=silu)
+        m = report(f"groupnorm_silu{int(silu)}_{'bf16' if dt == BF else 'f32'}", out.view(B, HW, Cc), ref if dt == F32 else ref.to(BF))
+        assert m["rel_l2"] <= (1e-3 if dt == BF else 1e-5), m
+    s = torch.randn(70, 333, generator=g) * 3
+    p = torch.empty(70, 333, device=gpu, dtype=dt)
+    ops.softmax_rows(s.to(gpu), p, 0.7)
+    assert report("softmax_rows", p, F.softmax(0.7 * s, dim=1))["rel_l2"] <= (4e-3 if dt == BF else 1e-5)
+    z = _r(g, 2, 16, 6, 5)
+    nh = ops.nchw_to_nhwc(z.to(gpu, dt), 64)
+    assert torch.equal(nh.view(2, 30, 64)[:, :, :16].cpu().float(), z.float().permute(0, 2, 3, 1).reshape(2, 30, 16)) and float(nh.view(2, 30, 64)[:, :, 16:].abs().max()) == 0
+    assert torch.equal(ops.nhwc_to_nchw(nh, 2, 16, 6, 5).cpu().float(), z.float())
+    nh2 = ops.nchw_to_nhwc(z.to(gpu, dt), 64, 0.3611, 0.1159).view(2, 30, 64)[:, :, :16]
+    exp = (z / 0.3611 + 0.1159) if dt == BF else (z.float() / 0.3611 + 0.1159)
+    assert rel_l2(nh2, exp.float().permute(0, 2, 3, 1).reshape(2, 30, 16)) <= (1e-6 if dt == F32 else 0.0) + 1e-7
+    mom, noise = _r(g, 2 * 30, 32), _r(g, 2, 16, 6, 5)
+    zz = ops.vae_sample(mom.to(gpu, dt), noise.to(gpu, dt), B=2, latent=16, H=6, W=5, shift=0.1159, scale=0.3611)
+    mm = mom.to(dt).view(2, 6, 5, 32).permute(0, 3, 1, 2)
+    exp = (V.gaussian_sample(mm, noise.to(dt)) - 0.1159) * 0.3611
+    assert rel_l2(zz, exp) <= (1e-6 if dt == F32 else 4e-3)
+
+
+def _models(gpu, seed=3):
+    cls = importlib.import_module("unigen_amd.vae").AutoencoderKL
+    m16 = cls.from_config(dict(TINY), device=gpu, dtype=BF).init_synthetic_(seed)
+    m32 = cls.from_config(dict(TINY), device=gpu, dtype=F32)
+    res = m32.load_state_dict({k: v.float() for k, v in m16.state_dict().items()})
+    assert not res.missing_keys and not res.unexpected_keys
+    state = {k: v.detach().cpu() for k, v in m16.state_dict().items()}
+    cfg = V.VAEConfig(**TINY)
+    assert set(state) == set(V.vae_state_shapes(cfg))
+    return m16, m32, state, cfg
+
+
+def test_vae_encode_decode_match_oracle(gpu):
+    m16, m32, state, cfg = _models(gpu)
+    g = torch.Generator().manual_seed(4)
+    B, H, W = 2, 32, 48
+    img = (torch.rand(B, 3, H, W, generator=g) * 2 - 1).to(BF)
+    noise = torch.randn(B, 16, H // 2, W // 2, generator=g).to(BF)
+    z_t = V.encode_condition(state, cfg, img, noise, F32)
+    z_r = V.encode_condition(state, cfg, img, noise, BF)
+    z32 = m32.encode_scaled(img.to(gpu), noise=noise.to(gpu))
+    m = report("vae_encode_f32", z32, z_t)
+    assert z32.shape == z_t.shape and m["rel_l2"] <= 1e-3, m
+    z16 = m16.encode_scaled(img.to(gpu), noise=noise.to(gpu))
+    e_hip, e_ref = rel_l2(z16, z_t), rel_l2(z_r, z_t)
+    report("vae_encode_bf16", z16, z_r, err_hip_vs_fp32=e_hip, err_oraclebf16_vs_fp32=e_ref)
+    assert e_hip <= 1.25 * e_ref, (e_hip, e_ref)
+    # the generic diffusers surface gives the same numbers: encode(x).latent_dist.sample(), then the pipeline's affine
+    z_gen = m32.encode(img.to(gpu)).latent_dist.sample(noise=noise.to(gpu))
+    assert rel_l2((z_gen - cfg.shift_factor) * cfg.scaling_factor, z_t) <= 1e-3
+    lat = torch.randn(B, 16, 8, 8, generator=g).to(BF)
+    d_t, d_r = V.decode_latents(state, cfg, lat, F32), V.decode_latents(state, cfg, lat, BF)
+    d32 = m32.decode_scaled(lat.to(gpu))
+    m = report("vae_decode_f32", d32, d_t)
+    assert d32.shape == (B, 3, 16, 16) and m["rel_l2"] <= 1e-3, m
+    d16 = m16.decode_scaled(lat.to(gpu))
+    e_hip, e_ref = rel_l2(d16, d_t), rel_l2(d_r, d_t)
+    report("vae_decode_bf16", d16, d_r, err_hip_vs_fp32=e_hip, err_oraclebf16_vs_fp32=e_ref)
+    assert e_hip <= 1.25 * e_ref, (e_hip, e_ref)
+    assert rel_l2(m32.decode(lat.to(gpu).float() / cfg.scaling_factor + cfg.shift_factor, return_dict=False)[0], d_t) <= 1e-3
+
+
+def test_vae_golden_fixture(gpu):
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vae_tiny.safetensors")
+    t = {}
+    with safe_open(path, "pt") as f:
+        meta = f.metadata()
+        for k in f.keys():
+            t[k] = f.get_tensor(k)
+    cfg_d, case = json.loads(meta["config"]), json.loads(meta["case"])
+    cfg_d["block_out_channels"] = tuple(cfg_d["block_out_channels"])
+    cfg = V.VAEConfig(**cfg_d)
+    state = V.make_vae_state(cfg, seed=case["state_seed"])
+    cls = importlib.import_module("unigen_amd.vae").AutoencoderKL
+    for dt in (BF, F32):
+        model = cls.from_config(cfg_d, device=gpu, dtype=dt)
+        res = model.load_state_dict({k: v.to(gpu, dt) for k, v in state.items()})
+        assert not res.missing_keys and not res.unexpected_keys
+        z = model.encode_scaled(t["in.image"].to(gpu), noise=t["in.noise"].to(gpu))
+        img = model.decode_scaled(t["in.latents"].to(gpu))
+        if dt == F32:
+            assert report("golden_vae_encode_f32", z, t["out.fp32.z"])["rel_l2"] <= 1e-3
+            assert report("golden_vae_decode_f32", img, t["out.fp32.image"])["rel_l2"] <= 1e-3
+        else:
+            for name, got, k in (("encode", z, "z"), ("decode", img, "image")):
+                e_hip, e_ref = rel_l2(got, t["out.fp32." + k]), rel_l2(t["out.bf16." + k], t["out.fp32." + k])
+                report(f"golden_vae_{name}_bf16", got, t["out.bf16." + k], err_hip_vs_fp32=e_hip, err_oraclebf16_vs_fp32=e_ref)
+                assert e_hip <= 1.25 * e_ref, (name, e_hip, e_ref)
+
+
+def test_pipeline_pixels_in_pixels_out_with_native_vae(gpu):
+    """infer.py:204 call shape with control_image given as PIXELS and output_type != 'latent': vae.encode -> pack -> denoise loop -> unpack ->
+    vae.decode, all on the HIP path (text embeds supplied, as the reference's __call__ also accepts)."""
+    from oracle import unigen_ref as R
+    tcfg = dict(num_layers=2, num_single_layers=2, attention_head_dim=128, num_attention_heads=2, joint_attention_dim=64, pooled_projection_dim=64)
+    tr = importlib.import_module("src.UniGenTransformer").UniGenFlux.from_config(tcfg, device=gpu, dtype=BF)
+    tr.init_condition_block(condition_nums=1, condition_types=["canny"], control_params=dict(use_rope=True, use_shared_expert=True, use_single_trans_blocks=True,
+                                                                                               single_control_dev=2))
+    tr.init_synthetic_(seed=1, std=0.05, bias_std=0.02)
+    vae = importlib.import_module("unigen_amd.vae").AutoencoderKL.from_config(dict(block_out_channels=(64, 128, 128, 128), layers_per_block=1), device=gpu, dtype=BF).init_synthetic_(2)
+    pipe = importlib.import_module("src.UniGenPipeline").UniGenFLUXPipeline.from_pretrained(None, transformer=tr)
+    pipe.vae = vae
+    g = torch.Generator().manual_seed(0)
+    B, H, W = 2, 128, 128
+    img = (torch.rand(B, 3, H, W, generator=g) * 2 - 1).to(BF)
+    out = pipe(prompt_embeds=_r(g, B, 16, 64, scale=0.1), pooled_prompt_embeds=_r(g, B, 64), condition_pooled_prompt_embeds=_r(g, B, 64), control_image=img, height=H,
+               width=W, num_inference_steps=2, generator=g, output_type="pt").images
+    assert out.shape == (B, 3, H, W) and torch.isfinite(out.float()).all()
+    # the condition tokens the loop saw are pack(encode_scaled(img)): check the packing against the host formula
+    from unigen_amd import pipeline as P
+    z = vae.encode_scaled(img.to(gpu), noise=torch.zeros(B, 16, H // 8, W // 8, device=gpu, dtype=BF))
+    assert torch.equal(P.pack_latents(z).cpu(), P.pack_latents(z.cpu()))

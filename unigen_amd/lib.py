@@ -40,6 +40,13 @@ class GemmDesc(C.Structure):
     ]
 
 
+class ConvDesc(C.Structure):
+    """Mirror of struct ug_conv_desc (include/unigen_hip.h)."""
+
+    _fields_ = [("x", vp), ("B", i64), ("H", i64), ("W", i64), ("Cin", i64), ("w", vp), ("bias", vp), ("R", vp), ("out", vp), ("Ho", i64), ("Wo", i64),
+                ("Cout", i64), ("KH", i32), ("KW", i32), ("stride", i32), ("pad_t", i32), ("pad_l", i32), ("up", i32), ("zero_page", vp)]
+
+
 # name -> (restype, argtypes); must list every symbol declared in include/unigen_hip.h
 SIGNATURES = {
     "ug_version": (i32, []),
@@ -60,6 +67,13 @@ SIGNATURES = {
     "ug_moe_capacity_rts": (i32, [vp, vp, vp, i64, i32, i64, vp, vp, vp, vp, vp]),
     "ug_moe_dispatch_modulate": (i32, [vp, i64, vp, vp, i64, i64, vp, i32, i64, i64, i64, vp, vp]),
     "ug_moe_combine": (i32, [vp, vp, vp, vp, vp, i32, i64, vp, vp, i64, i64, i64, vp, i64, i64, i64, i32, vp]),
+    "ug_conv2d_nhwc": (i32, [C.POINTER(ConvDesc), vp]),
+    "ug_groupnorm_workspace_bytes": (i64, [i64, i64, i32]),
+    "ug_groupnorm_nhwc": (i32, [vp, vp, vp, vp, vp, i64, i64, i64, i64, i32, f32, i32, vp]),
+    "ug_softmax_rows": (i32, [vp, i64, vp, i64, i64, i64, f32, vp]),
+    "ug_nchw_to_nhwc": (i32, [vp, vp, i64, i64, i64, i64, f32, f32, vp]),
+    "ug_nhwc_to_nchw": (i32, [vp, vp, i64, i64, i64, i64, vp]),
+    "ug_vae_sample": (i32, [vp, i64, vp, vp, i64, i64, i64, f32, f32, vp]),
     "ug_probe_mfma_bf16": (i32, [i32, i64, i64, vp, C.POINTER(C.c_double), vp]),
     "ug_pack_latents": (i32, [vp, vp, i64, i64, i64, i64, vp]),
     "ug_unpack_latents": (i32, [vp, vp, i64, i64, i64, i64, vp]),
@@ -70,7 +84,9 @@ _F32_TWINS = {"ug_gemm_f32": "ug_gemm_bf16", "ug_small_linear_f32": "ug_small_li
               "ug_euler_step_f32": "ug_euler_step", "ug_cfg_combine_f32": "ug_cfg_combine", "ug_add_f32": "ug_add_bf16",
               "ug_add_rowbcast_f32_f32": "ug_add_rowbcast_f32", "ug_gather_rows_f32": "ug_gather_rows", "ug_moe_gate_top1_f32": "ug_moe_gate_top1",
               "ug_moe_dispatch_modulate_f32": "ug_moe_dispatch_modulate", "ug_moe_combine_f32": "ug_moe_combine",
-              "ug_pack_latents_f32": "ug_pack_latents", "ug_unpack_latents_f32": "ug_unpack_latents"}
+              "ug_pack_latents_f32": "ug_pack_latents", "ug_unpack_latents_f32": "ug_unpack_latents",
+              "ug_conv2d_nhwc_f32": "ug_conv2d_nhwc", "ug_groupnorm_nhwc_f32": "ug_groupnorm_nhwc", "ug_softmax_rows_f32": "ug_softmax_rows",
+              "ug_nchw_to_nhwc_f32": "ug_nchw_to_nhwc", "ug_nhwc_to_nchw_f32": "ug_nhwc_to_nchw", "ug_vae_sample_f32": "ug_vae_sample"}
 for _twin, _base in _F32_TWINS.items():
     SIGNATURES[_twin] = SIGNATURES[_base]
 

@@ -382,3 +382,98 @@ def probe_mfma_peak(device, shape: int = 1, seconds: float = 0.4) -> float:
         launch()
     e1.record(); e1.synchronize()
     return fl.value * n / (e0.elapsed_time(e1) * 1e-3) / 1e12
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# AutoencoderKL ops (unigen_amd/vae.py): NHWC activations as 2-D tensors [B * H * W, C]
+# ---------------------------------------------------------------------------------------------------------------------
+_zero_pages: dict = {}
+
+
+def _zero_page(device) -> torch.Tensor:
+    z = _zero_pages.get(device)
+    if z is None:
+        z = torch.zeros(256, dtype=torch.uint8, device=device)
+        _zero_pages[device] = z
+    return z
+
+
+def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, *, B: int, H: int, W: int, Ho: int, Wo: int, KH: int, KW: int,
+                stride: int = 1, pad_t: int = 1, pad_l: int = 1, up: int = 0, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[B*Ho*Wo, Cout] = residual + conv(x[B*H*W, Cin]; w[Cout, KH, KW, Cin]) + bias (ug_conv2d_nhwc: implicit GEMM, see include/unigen_hip.h)."""
+    dt = _act(x, "x")
+    _chk(w, "w", dt); _chk(out, "out", dt)
+    Cin, Cout = x.shape[-1], out.shape[-1]
+    assert x.is_contiguous() and w.is_contiguous() and out.is_contiguous() and w.numel() == Cout * KH * KW * Cin, (x.shape, w.shape, out.shape)
+    assert x.numel() == B * H * W * Cin and out.numel() == B * Ho * Wo * Cout
+    d = L.ConvDesc()
+    d.x, d.B, d.H, d.W, d.Cin = x.data_ptr(), B, H, W, Cin
+    d.w, d.bias = w.data_ptr(), _p(bias)
+    if bias is not None:
+        _chk(bias, "bias", dt)
+    if residual is not None:
+        _chk(residual, "residual", dt); assert residual.is_contiguous() and residual.numel() == out.numel()
+        d.R = residual.data_ptr()
+    d.out, d.Ho, d.Wo, d.Cout = out.data_ptr(), Ho, Wo, Cout
+    d.KH, d.KW, d.stride, d.pad_t, d.pad_l, d.up = KH, KW, stride, pad_t, pad_l, up
+    d.zero_page = _zero_page(x.device).data_ptr()
+    L.check(_fn("ug_conv2d_nhwc", dt)(C.byref(d), _stream()), "ug_conv2d_nhwc")
+    return out
+
+
+_gn_ws: dict = {}
+
+
+def groupnorm_nhwc(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out: torch.Tensor, *, B: int, HW: int, groups: int, eps: float = 1e-6,
+                   silu: bool = False) -> torch.Tensor:
+    dt = _act(x, "x")
+    _chk(gamma, "gamma", dt); _chk(beta, "beta", dt); _chk(out, "out", dt)
+    Cc = x.shape[-1]
+    assert x.is_contiguous() and out.is_contiguous() and x.numel() == B * HW * Cc
+    need = int(L.load().ug_groupnorm_workspace_bytes(B, HW, groups))
+    key = (x.device, _stream())
+    ws = _gn_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+        _gn_ws[key] = ws
+    L.check(_fn("ug_groupnorm_nhwc", dt)(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(), B, HW, Cc, groups, eps,
+                                          1 if silu else 0, _stream()), "ug_groupnorm_nhwc")
+    return out
+
+
+def softmax_rows(scores: torch.Tensor, probs: torch.Tensor, scale: float) -> torch.Tensor:
+    """probs[r] = softmax(scale * scores[r]); scores fp32 [rows, cols], probs bf16 (or fp32: verification) [rows, cols]."""
+    _chk(scores, "scores", torch.float32)
+    dt = _act(probs, "probs")
+    rows, cols = scores.shape
+    L.check(_fn("ug_softmax_rows", dt)(scores.data_ptr(), scores.stride(0), probs.data_ptr(), probs.stride(0), rows, cols, scale, _stream()), "ug_softmax_rows")
+    return probs
+
+
+def nchw_to_nhwc(x: torch.Tensor, Cp: int, div: float = 0.0, add: float = 0.0) -> torch.Tensor:
+    """[B, C, H, W] -> [B*H*W, Cp] (channels >= C zero); div != 0: v -> (v / div) + add on the way (latents / scaling_factor + shift_factor)."""
+    dt = _act(x, "x")
+    B, Cc, H, W = x.shape
+    x = x.contiguous()
+    out = torch.empty(B * H * W, Cp, device=x.device, dtype=dt)
+    L.check(_fn("ug_nchw_to_nhwc", dt)(x.data_ptr(), out.data_ptr(), B, Cc, H * W, Cp, div, add, _stream()), "ug_nchw_to_nhwc")
+    return out
+
+
+def nhwc_to_nchw(x: torch.Tensor, B: int, Cc: int, H: int, W: int) -> torch.Tensor:
+    """[B*H*W, Cp] -> [B, C, H, W] (first C channels)."""
+    dt = _act(x, "x")
+    assert x.is_contiguous() and x.shape[0] == B * H * W and x.shape[1] >= Cc
+    out = torch.empty(B, Cc, H, W, device=x.device, dtype=dt)
+    L.check(_fn("ug_nhwc_to_nchw", dt)(x.data_ptr(), out.data_ptr(), B, Cc, H * W, x.shape[1], _stream()), "ug_nhwc_to_nchw")
+    return out
+
+
+def vae_sample(moments: torch.Tensor, noise: torch.Tensor, *, B: int, latent: int, H: int, W: int, shift: float = 0.0, scale: float = 1.0) -> torch.Tensor:
+    """z [B, L, H, W] = ((mean + exp(0.5 clamp(logvar)) * noise) - shift) * scale from NHWC moments [B*H*W, Cp >= 2L] and NCHW noise."""
+    dt = _act(moments, "moments")
+    _chk(noise, "noise", dt)
+    assert moments.is_contiguous() and noise.is_contiguous() and noise.numel() == B * latent * H * W
+    z = torch.empty(B, latent, H, W, device=moments.device, dtype=dt)
+    L.check(_fn("ug_vae_sample", dt)(moments.data_ptr(), moments.shape[1], noise.data_ptr(), z.data_ptr(), B, latent, H * W, shift, scale, _stream()), "ug_vae_sample")
+    return z

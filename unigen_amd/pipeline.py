@@ -181,8 +181,12 @@ class UniGenFLUXPipeline:
         if self.image_processor is not None:
             image = self.image_processor.preprocess(image, height=height, width=width)
         vdt = getattr(self.vae, "dtype", dtype)
-        z = self.vae.encode(image.to(device=self.transformer.device, dtype=vdt)).latent_dist.sample(generator=generator)
-        z = (z - self.vae.config.shift_factor) * self.vae.config.scaling_factor
+        image = image.to(device=self.transformer.device, dtype=vdt)
+        if hasattr(self.vae, "encode_scaled"):           # native VAE (unigen_amd/vae.py): sampling and the affine run in ug_vae_sample
+            z = self.vae.encode_scaled(image, generator=generator)
+        else:
+            z = self.vae.encode(image).latent_dist.sample(generator=generator)
+            z = (z - self.vae.config.shift_factor) * self.vae.config.scaling_factor
         return pack_latents(z.to(dtype).contiguous())
 
     def _decode(self, latents: torch.Tensor, height, width, output_type):
@@ -190,8 +194,11 @@ class UniGenFLUXPipeline:
         if self.vae is None:
             raise NotImplementedError("output_type other than 'latent' needs a VAE: set `pipe.vae` (AutoencoderKL surface)")
         z = unpack_latents(latents, height, width, self.vae_scale_factor)
-        z = (z / self.vae.config.scaling_factor) + self.vae.config.shift_factor
-        image = self.vae.decode(z.to(getattr(self.vae, "dtype", z.dtype)), return_dict=False)[0]
+        if hasattr(self.vae, "decode_scaled"):           # native VAE: the un-scaling is folded into the NCHW -> NHWC conversion
+            image = self.vae.decode_scaled(z.to(getattr(self.vae, "dtype", z.dtype)))
+        else:
+            z = (z / self.vae.config.scaling_factor) + self.vae.config.shift_factor
+            image = self.vae.decode(z.to(getattr(self.vae, "dtype", z.dtype)), return_dict=False)[0]
         if self.image_processor is not None:
             return self.image_processor.postprocess(image, output_type=output_type)
         return image
