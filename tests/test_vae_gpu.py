@@ -86,7 +86,10 @@ def test_groupnorm_softmax_layout_sample(gpu, dt):
     assert torch.equal(nh.view(2, 30, 64)[:, :, :16].cpu().float(), z.float().permute(0, 2, 3, 1).reshape(2, 30, 16)) and float(nh.view(2, 30, 64)[:, :, 16:].abs().max()) == 0
     assert torch.equal(ops.nhwc_to_nchw(nh, 2, 16, 6, 5).cpu().float(), z.float())
     nh2 = ops.nchw_to_nhwc(z.to(gpu, dt), 64, 0.3611, 0.1159).view(2, 30, 64)[:, :, :16]
-    exp = (z / 0.3611 + 0.1159) if dt == BF else (z.float() / 0.3611 + 0.1159)
+    # `latents / scaling_factor + shift_factor` with the Python scalars in fp32 (what torch's GPU kernels do: a * (1 / b) in opmath precision;
+    # its CPU kernels round the scalar to bf16 first, which moves isolated elements by one bf16 ulp)
+    inv = torch.tensor(1.0, dtype=F32) / torch.tensor(0.3611, dtype=F32)
+    exp = ((z.float() * inv).to(dt).float() + torch.tensor(0.1159, dtype=F32)).to(dt)
     assert rel_l2(nh2, exp.float().permute(0, 2, 3, 1).reshape(2, 30, 16)) <= (1e-6 if dt == F32 else 0.0) + 1e-7
     mom, noise = _r(g, 2 * 30, 32), _r(g, 2, 16, 6, 5)
     zz = ops.vae_sample(mom.to(gpu, dt), noise.to(gpu, dt), B=2, latent=16, H=6, W=5, shift=0.1159, scale=0.3611)

@@ -267,7 +267,8 @@ __global__ void nchw_to_nhwc_kernel(const T* __restrict__ in, T* __restrict__ ou
         float v = 0.f;
         if (c < C) {
             v = ElemT<T>::ld(in + ((int64_t)b * C + c) * HW + pix);
-            if (div != 0.f) v = ElemT<T>::rnd(ElemT<T>::rnd(v / div) + add);
+            // torch divides a tensor by a Python scalar as a multiplication by the fp32 reciprocal (BinaryDivTrueKernel: "a * (1 / b)")
+            if (div != 0.f) v = ElemT<T>::rnd(ElemT<T>::rnd(v * (1.0f / div)) + add);
         }
         ElemT<T>::st(out + i, v);
     }
