@@ -169,3 +169,33 @@ def test_vae_full_size_decode_and_encode(gpu):
     print(f"VAE 1024^2: decode {t_dec * 1e3:.1f} ms, encode {t_enc * 1e3:.1f} ms per image")
     from tests.util import report
     report("vae_fullsize_timing", img2, img, decode_ms=t_dec * 1e3, encode_ms=t_enc * 1e3)
+
+
+def test_cfg4_per_gpu_shape_b8_forward_properties(gpu):
+    """cfg4's per-GPU share (global batch 64 = 8 GPUs x B = 8; reference infer.py:173 shards samples by rank) on ONE GPU at FULL size: the
+    FLUX-schnell geometry forward at B = 8, 1024^2. No oracle can evaluate it, so size-independent properties: finite output, every token
+    routed (expert counts sum to B N), run-to-run bitwise repeatability. (Samples of one batch are NOT independent in the reference either:
+    deepspeed's capacity = ceil(B N / E) and the Random Token Selection run over the whole batch.) This is what each rank of the 8-GPU run computes."""
+    from unigen_amd.flux import UniGenFlux
+    from unigen_amd.pipeline import prepare_latent_image_ids
+    model = UniGenFlux.from_config({}, device=gpu, dtype=BF)
+    model.init_condition_block(condition_nums=1, condition_types=["canny"], control_params=dict(
+        use_rope=True, use_shared_expert=True, use_consis_module=False, use_single_trans_blocks=True, single_control_dev=2,
+        single_block_control_method="overall_add", top_num=1, expert_num_each_condition=3))
+    model.init_synthetic_(seed=0, std=0.02)
+    B, grid, T = 8, 64, 512
+    N = grid * grid
+    g = torch.Generator(device=gpu).manual_seed(5)
+    rn = lambda *s: torch.randn(*s, generator=g, device=gpu)
+    inp = dict(hidden_states=rn(B, N, 64).to(BF), condition_hidden_states=rn(B, N, 64).to(BF), encoder_hidden_states=(0.1 * rn(B, T, 4096)).to(BF),
+               pooled_projections=rn(B, 768).to(BF), condition_pooled_projections=rn(B, 768).to(BF))
+    ids = prepare_latent_image_ids(grid, grid, gpu, BF)
+    txt = torch.zeros(T, 3, device=gpu, dtype=BF)
+    t = torch.full((B,), 0.75, device=gpu, dtype=BF)
+    uni = torch.rand(B * N, model._ctl.expert_nums, generator=g, device=gpu)
+    full = model(timestep=t, img_ids=ids, txt_ids=txt, condition_ids=ids, gate_uniform=uni, **inp)
+    out8, cnt8 = full[0].clone(), full[2]["expert_counts"].clone()
+    assert out8.shape == (B, N, 64) and torch.isfinite(out8.float()).all() and int(cnt8.sum()) == B * N
+    again = model(timestep=t, img_ids=ids, txt_ids=txt, condition_ids=ids, gate_uniform=uni, **inp)[0]
+    assert torch.equal(again, out8), "B = 8 forward is not bitwise repeatable"
+    report("cfg4_b8_forward", again, out8)
