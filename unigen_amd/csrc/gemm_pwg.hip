@@ -21,8 +21,6 @@ namespace {
 constexpr int PK = 32;                         // K per step
 constexpr int PHALF = 256 * PK * 2;            // bytes of one operand of a step (16 KiB)
 constexpr int PSLOT = 2 * PHALF;               // 32 KiB
-constexpr int PRING = 4;
-constexpr int PLDS = PRING * PSLOT;            // 128 KiB
 
 __device__ __forceinline__ int swz32(int row) { return (4 - ((row >> 2) & 3)) & 3; }
 
@@ -31,7 +29,7 @@ __device__ __forceinline__ int swz32(int row) { return (4 - ((row >> 2) & 3)) & 
 // by building the NW = 4 loop without its DMAs, 1340 -> 1620 TFLOP/s at 8192^3) now runs under the SIMD partner's MFMAs.
 // VAR (diagnostic builds, UG_PWG_VAR): bit 0 = no DMA in the loop (WRONG results, timing only), bit 1 = waves 4-7 issue their DMAs in the
 // second half of the step (stagger against waves 0-3); bit 2 = every wave issues all its LDS reads in the first half of the step.
-template <int EPI, int NW, int VAR>
+template <int EPI, int NW, int VAR, int PRING = 4>      // PRING: LDS ring slots (32 KiB each); 5 = all 160 KiB
 __global__ __launch_bounds__(64 * NW, NW / 4) void gemm_pwg_kernel(const ug_gemm_desc p, const int tiles_per_group, const int total_tiles) {
     constexpr int NT = 32 / NW;                    // 16-column blocks per wave: 8 (128 columns) or 4 (64 columns)
     constexpr int RPW = 256 / NW;                  // rows of A (and of W) a wave stages per step
@@ -71,7 +69,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gemm_pwg_kernel(const ug_gemm
         }
         // one LDS-DMA piece (1 KiB) of K-step `src_step`, into ring slot `slot_step` % 4: pieces [0, NPC) = this wave's A rows, then its W rows
         auto stage_piece = [&](int piece, int slot_step, int src_step) {
-            unsigned char* slot = smem + (slot_step & (PRING - 1)) * PSLOT + wave * RPW * 64;
+            unsigned char* slot = smem + (slot_step % PRING) * PSLOT + wave * RPW * 64;
             const int64_t ko = (int64_t)src_step * PK;
             if (piece < NPC) glds16(asrc[piece] + ko, slot + piece * 1024);
             else glds16(bsrc[piece - NPC] + ko, slot + PHALF + (piece - NPC) * 1024);
@@ -90,10 +88,10 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gemm_pwg_kernel(const ug_gemm
         __builtin_amdgcn_s_barrier();
         const int last = nsteps - 1;
 #pragma unroll
-        for (int st = 0; st < 4; ++st)
+        for (int st = 0; st < PRING; ++st)
 #pragma unroll
             for (int pc = 0; pc < 2 * NPC; ++pc) stage_piece(pc, st, st < last ? st : last);      // steps past the end: clamped re-reads nobody consumes
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * NPC) : "memory");                           // step 0 landed (3 younger steps may fly)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PRING - 1) * 2 * NPC) : "memory");             // step 0 landed (the younger steps may fly)
         __builtin_amdgcn_s_barrier();
 #pragma unroll
         for (int t = 0; t < 8; ++t) af[0][t] = *(const bf16x8*)(smem + a_off + t * 1024);
@@ -103,20 +101,20 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gemm_pwg_kernel(const ug_gemm
         auto step = [&](auto set_c, int s) __attribute__((always_inline)) {
             constexpr int SET = decltype(set_c)::value;
             // top of step s: this step's fragments (set SET) were requested during step s - 1; step s + 1's slot must have landed before
-            // anybody reads it below: issued so far are steps <= s + 3, so all but the two youngest steps must be complete.
+            // anybody reads it below: issued so far are steps <= s + PRING - 1, so all but the PRING - 2 youngest steps must be complete.
             if constexpr (VAR & 8) {
                 // paired refill: DMAs only in odd steps (steps s + 3 and s + 4 = the two 64-byte halves of the same 128-byte lines, back to back)
                 if constexpr (SET == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * NPC) : "memory");
                 else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPC) : "memory");
             } else {
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * NPC) : "memory");
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PRING - 2) * 2 * NPC) : "memory");
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();           // every wave has its set-SET fragments in registers: slot s % 4 is free, slot (s+1) % 4 visible
             __builtin_amdgcn_sched_barrier(0);
-            const unsigned char* nslot = smem + ((s + 1) & (PRING - 1)) * PSLOT;       // past the end: a stale slot, read and never used
-            const int src4 = s + 4 < nsteps ? s + 4 : last;
+            const unsigned char* nslot = smem + ((s + 1) % PRING) * PSLOT;       // past the end: a stale slot, read and never used
+            const int src4 = s + PRING < nsteps ? s + PRING : last;     // the step refilled now: s + PRING (named src4 for the 4-slot ring)
             // per group of 4 MFMAs: fragment reads of the next step (8 A + NT W over the groups), and the 2 NPC DMA pieces of step s + 4
             auto reads = [&](int i) __attribute__((always_inline)) {          // read slot i of 0 .. NG - 1
                 constexpr int NR = 8 + NT;
@@ -138,7 +136,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gemm_pwg_kernel(const ug_gemm
                     }
                 } else if constexpr (!(VAR & 1)) {
                     constexpr int ND = 2 * NPC;
-                    for (int d = (i * ND) / NG; d < ((i + 1) * ND) / NG; ++d) stage_piece(d, s + 4, src4);
+                    for (int d = (i * ND) / NG; d < ((i + 1) * ND) / NG; ++d) stage_piece(d, s + PRING, src4);
                 }
             };
 #pragma unroll
@@ -189,13 +187,14 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gemm_pwg_kernel(const ug_gemm
     }
 }
 
-template <int EPI, int NW, int VAR>
+template <int EPI, int NW, int VAR, int PRING = 4>
 int launch_pwg_t(const ug_gemm_desc& d, hipStream_t s) {
+    constexpr int PLDS = PRING * PSLOT;
     const int groups = d.groups > 0 ? d.groups : 1;
     const int64_t t256 = ((d.M + 255) / 256) * ((d.N + 255) / 256) * groups;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_pwg_kernel<EPI, NW, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
+        (void)hipFuncSetAttribute((const void*)gemm_pwg_kernel<EPI, NW, VAR, PRING>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
         attr_set = true;
     }
     static int ncu = 0;
@@ -206,7 +205,7 @@ int launch_pwg_t(const ug_gemm_desc& d, hipStream_t s) {
     }
     const int total = (int)t256;
     dim3 grid((unsigned)(total < ncu ? total : ncu), 1, 1);
-    hipLaunchKernelGGL((gemm_pwg_kernel<EPI, NW, VAR>), grid, dim3(64 * NW), PLDS, s, d, (int)(t256 / groups), total);
+    hipLaunchKernelGGL((gemm_pwg_kernel<EPI, NW, VAR, PRING>), grid, dim3(64 * NW), PLDS, s, d, (int)(t256 / groups), total);
     UG_CHECK_LAUNCH("ug_gemm_bf16(pwg)");
     return UG_OK;
 }
@@ -224,6 +223,13 @@ int ug_gemm_launch_pwg(const ug_gemm_desc& d, hipStream_t s) {
         return launch_pwg_t<E, 4, 0>(d, s);
     switch (d.epilogue) {
         case UG_EPI_BIAS:
+            if (mode == 1 && var >= 100) {        // ring-depth probes: var = 100 * slots + (16: DMA only | 0: full kernel)
+                if (var == 216) return launch_pwg_t<UG_EPI_BIAS, 4, 16, 2>(d, s);
+                if (var == 316) return launch_pwg_t<UG_EPI_BIAS, 4, 16, 3>(d, s);
+                if (var == 516) return launch_pwg_t<UG_EPI_BIAS, 4, 16, 5>(d, s);
+                if (var == 300) return launch_pwg_t<UG_EPI_BIAS, 4, 0, 3>(d, s);
+                if (var == 500) return launch_pwg_t<UG_EPI_BIAS, 4, 0, 5>(d, s);
+            }
             if (mode == 2) return var == 1 ? launch_pwg_t<UG_EPI_BIAS, 8, 1>(d, s) : var == 2 ? launch_pwg_t<UG_EPI_BIAS, 8, 2>(d, s) :
                                   var == 4 ? launch_pwg_t<UG_EPI_BIAS, 8, 4>(d, s) : var == 6 ? launch_pwg_t<UG_EPI_BIAS, 8, 6>(d, s) : launch_pwg_t<UG_EPI_BIAS, 8, 0>(d, s);
             return var == 1 ? launch_pwg_t<UG_EPI_BIAS, 4, 1>(d, s) : var == 4 ? launch_pwg_t<UG_EPI_BIAS, 4, 4>(d, s) : var == 5 ? launch_pwg_t<UG_EPI_BIAS, 4, 5>(d, s) :
