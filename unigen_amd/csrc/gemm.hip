@@ -243,6 +243,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
             br[nt][1] = *(const bf16x8*)(slot + b_off + nt * 2048 + ch1);
         }
     };
+#ifdef UG_DIAG_NOMMA      /* diagnostic build (tools only, WRONG results): the whole data movement of the kernel without its MFMAs */
+#define UG_MMA_QUADRANT(I, J, BR)                                                                                      \
+    do {                                                                                                               \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                             \
+            _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) asm volatile("" ::"v"(areg[mt][ks]));                    \
+            _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) asm volatile("" ::"v"(BR[nt][ks]));                      \
+        }                                                                                                              \
+    } while (0)
+#else
 #define UG_MMA_QUADRANT(I, J, BR)                                                                                      \
     do {                                                                                                               \
         __builtin_amdgcn_s_setprio(1);                                                                                 \
@@ -252,6 +261,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
                     acc[I][J][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BR[nt][ks], areg[mt][ks], acc[I][J][mt][nt], 0, 0, 0); \
         __builtin_amdgcn_s_setprio(0);                                                                                 \
     } while (0)
+#endif
 #define UG_BARRIER() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
 
     int tile = blockIdx.x;

@@ -81,7 +81,10 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gemm_pwg_kernel(const ug_gemm
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
-            for (int j = 0; j < NT; ++j) { acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; asm volatile("" : "+a"(acc[i][j])); }
+            for (int j = 0; j < NT; ++j) {
+                acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if constexpr (VAR & 32) asm volatile("" : "+v"(acc[i][j])); else asm volatile("" : "+a"(acc[i][j]));
+            }
         bf16x8 af[2][8], bf[2][NT];
         // The previous tile's last step left every LDS read retired (its MFMAs consumed them); its epilogue stores may still be in
         // flight, which only makes the counted waits below wait a little longer (stores retire in issue order ahead of these DMAs).
@@ -145,6 +148,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gemm_pwg_kernel(const ug_gemm
                 for (int q = 4 * i; q < 4 * i + 4; ++q) {
                     const int mt = q / NT, nt = q % NT;
                     if constexpr (VAR & 16) asm volatile("" :: "v"(bf[SET][nt]), "v"(af[SET][mt]));      // diagnostic: DMA + LDS reads only, no MFMA
+                    else if constexpr (VAR & 32) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[mt][nt]) : "v"(bf[SET][nt]), "v"(af[SET][mt]));
                     else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[mt][nt]) : "v"(bf[SET][nt]), "v"(af[SET][mt]));
                 }
                 reads(i);
@@ -230,6 +234,8 @@ int ug_gemm_launch_pwg(const ug_gemm_desc& d, hipStream_t s) {
                 if (var == 300) return launch_pwg_t<UG_EPI_BIAS, 4, 0, 3>(d, s);
                 if (var == 500) return launch_pwg_t<UG_EPI_BIAS, 4, 0, 5>(d, s);
             }
+            if (mode == 2 && var == 32) return launch_pwg_t<UG_EPI_BIAS, 8, 32>(d, s);
+            if (mode == 2 && var == 33) return launch_pwg_t<UG_EPI_BIAS, 8, 33>(d, s);
             if (mode == 2) return var == 1 ? launch_pwg_t<UG_EPI_BIAS, 8, 1>(d, s) : var == 2 ? launch_pwg_t<UG_EPI_BIAS, 8, 2>(d, s) :
                                   var == 4 ? launch_pwg_t<UG_EPI_BIAS, 8, 4>(d, s) : var == 6 ? launch_pwg_t<UG_EPI_BIAS, 8, 6>(d, s) : launch_pwg_t<UG_EPI_BIAS, 8, 0>(d, s);
             return var == 1 ? launch_pwg_t<UG_EPI_BIAS, 4, 1>(d, s) : var == 4 ? launch_pwg_t<UG_EPI_BIAS, 4, 4>(d, s) : var == 5 ? launch_pwg_t<UG_EPI_BIAS, 4, 5>(d, s) :

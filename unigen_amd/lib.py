@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libunigen_hip.so")
+LIB_PATH = os.environ.get("UG_LIB_PATH") or os.path.join(_HERE, "libunigen_hip.so")      # UG_LIB_PATH: an alternative build (A/B tools only)
 
 UG_OK, UG_ERR_BAD_SHAPE, UG_ERR_BAD_ALIGN, UG_ERR_UNSUPPORTED, UG_ERR_HIP = 0, -1, -2, -3, -4
 EPI_BIAS, EPI_BIAS_GELU, EPI_RES_GATE, EPI_RES_SCALE, EPI_F32 = 0, 1, 2, 3, 4
