@@ -48,6 +48,19 @@ def test_error_codes_without_gpu_compute():
     assert cdll.ug_flash_attn_fwd(1, 8, 8, 1, 8, 8, 1, 8, 8, 1, 8, 8, 1, 1, 8, 8, 96, 1.0, None) == lib.UG_ERR_UNSUPPORTED
     with pytest.raises(lib.UniGenHipError):
         lib.check(lib.UG_ERR_UNSUPPORTED, "x")
+    # round-2 entry points validate before launching too
+    c = lib.ConvDesc()
+    assert cdll.ug_conv2d_nhwc(None, None) == lib.UG_ERR_BAD_SHAPE and cdll.ug_conv2d_nhwc(ctypes.byref(c), None) == lib.UG_ERR_BAD_SHAPE
+    c.x, c.w, c.out, c.B, c.H, c.W, c.Cin, c.Ho, c.Wo, c.Cout, c.KH, c.KW, c.stride, c.pad_t, c.pad_l = 16, 16, 16, 1, 8, 8, 48, 8, 8, 64, 3, 3, 1, 1, 1
+    assert cdll.ug_conv2d_nhwc(ctypes.byref(c), None) == lib.UG_ERR_UNSUPPORTED and b"multiple of 64" in cdll.ug_last_error()
+    c.Cin, c.Ho = 64, 12
+    assert cdll.ug_conv2d_nhwc(ctypes.byref(c), None) == lib.UG_ERR_BAD_SHAPE and b"output larger" in cdll.ug_last_error()
+    assert cdll.ug_groupnorm_nhwc(16, 16, 16, 16, 16, 1 << 20, 1, 64, 96, 32, 1e-6, 0, None) == lib.UG_ERR_UNSUPPORTED      # 3 channels per group
+    assert cdll.ug_groupnorm_nhwc(16, 16, 16, 16, 16, 8, 1, 64, 64, 32, 1e-6, 0, None) == lib.UG_ERR_BAD_SHAPE             # workspace too small
+    assert cdll.ug_groupnorm_workspace_bytes(2, 1000, 32) >= 2 * 16 * 32 * 16
+    assert cdll.ug_pack_latents(16, 16, 1, 16, 7, 8, None) == lib.UG_ERR_BAD_SHAPE                                           # odd height
+    assert cdll.ug_probe_mfma_bf16(2, 256, 10, 16, None, None) == lib.UG_ERR_BAD_SHAPE
+    assert cdll.ug_gemm_f32(None, None) == lib.UG_ERR_BAD_SHAPE and cdll.ug_flash_attn_fwd_f32(16, 4, 4, 16, 4, 4, 16, 4, 4, 16, 4, 4, 1, 1, 8, 8, 96, 1.0, None) == lib.UG_ERR_UNSUPPORTED
 
 
 def test_no_cpu_fallback():
@@ -225,6 +238,29 @@ def test_pipeline_call_delegates_to_attached_encoders_and_vae(monkeypatch):
     out = pipe2(prompt_embeds=torch.zeros(1, 8, 64), pooled_prompt_embeds=torch.zeros(1, 64), condition_pooled_prompt_embeds=torch.zeros(1, 64),
                 control_image=torch.zeros(1, 16, 64), height=64, width=64, num_inference_steps=2)
     assert out.images.shape == (1, 16, 64)
+
+
+def test_rope_cache_is_keyed_on_content_identity():
+    """RoPE tables were cached by (data_ptr, shape, dtype) of the ids tensors; a freed 4 x 2 grid's ids and a fresh 2 x 4
+    grid's (same N, same shape) can share an address. The cache entry now keeps the ids alive and tracks `_version`."""
+    from unigen_amd import pipeline as P
+    m = _model()
+    txt = torch.zeros(4, 3, dtype=torch.bfloat16)
+    ids1 = P.prepare_latent_image_ids(4, 2, "cpu", torch.bfloat16)
+    c1, s1 = m._rope([txt, ids1], None)
+    c1, s1 = c1.clone(), s1.clone()
+    p1 = ids1.data_ptr()
+    del ids1                                            # the cache still references it: its storage cannot be recycled
+    ids2 = P.prepare_latent_image_ids(2, 4, "cpu", torch.bfloat16)
+    assert ids2.data_ptr() != p1
+    c2, s2 = m._rope([txt, ids2], None)
+    from oracle import unigen_ref as R
+    rc, rs = R.flux_pos_embed(torch.cat([txt, ids2], 0), m.config.axes_dims_rope)
+    assert torch.equal(c2, rc) and torch.equal(s2, rs) and not torch.equal(c2, c1)
+    assert m._rope([txt, ids2], None)[0] is c2          # a hit on the same tensors
+    ids2[:, 1] += 1                                     # in-place edit: _version moves, the entry is not reused
+    c3, _ = m._rope([txt, ids2], None)
+    assert torch.equal(c3, R.flux_pos_embed(torch.cat([txt, ids2], 0), m.config.axes_dims_rope)[0]) and not torch.equal(c3, c2)
 
 
 def test_sd3_default_sigmas_match_diffusers_0_32_2():
