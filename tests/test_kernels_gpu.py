@@ -524,3 +524,50 @@ sys.exit(1 if bad else 0)
 """ % root
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_gemm_lora_segment_in_256_kernel_matches_128(gpu):
+    """The LoRA K-segment (T . B^T appended to the K loop, src/lora_switching_module.py:11-38) runs in BOTH tile kernels; same MFMA shape and
+    K order -> bit-identical. Shapes where the dispatcher picks the 256^2 kernel, ragged M, 1-2 LoRA K-tiles, K = 128 (shortest) .. 320."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import os, sys
+os.environ["UG_ENV_DYNAMIC"] = "1"
+sys.path.insert(0, %r)
+import torch
+from unigen_amd import ops, lib as L
+dev = torch.device("cuda:0")
+g = torch.Generator(device=dev).manual_seed(0)
+rn = lambda *s: torch.randn(*s, generator=g, device=dev).to(torch.bfloat16)
+bad = 0
+for (M, N, K, r, epi) in [(4000, 4096, 128, 64, L.EPI_BIAS), (4096, 4096, 192, 128, L.EPI_BIAS_GELU), (4090, 4096, 320, 64, L.EPI_RES_GATE),
+                          (4096, 3840, 256, 192, L.EPI_RES_SCALE), (8192, 2048, 1024, 64, L.EPI_BIAS)]:
+    a, w, b = rn(M, K), rn(N, K) * 0.1, rn(N)
+    t, lb = rn(M, r), rn(N, r) * 0.1
+    res, gate = rn(M, N), rn((M + 999) // 1000, N)
+    outs = []
+    for tile in ("128", "256", "0"):
+        os.environ["UG_GEMM_FORCE_TILE"] = tile
+        out = torch.zeros(M, N, device=dev, dtype=torch.bfloat16)
+        kw = dict(M=M, epilogue=epi, lora_t=t, lora_b=lb)
+        if epi in (L.EPI_RES_GATE, L.EPI_RES_SCALE):
+            kw.update(residual=res, alpha=0.7)
+        if epi == L.EPI_RES_GATE:
+            kw.update(gate=gate, gate_ld=N, rows_per_sample=1000)
+        ops.gemm(a, w, b, out, **kw)
+        outs.append(out)
+    torch.cuda.synchronize()
+    ref = (a.float() @ w.float().t() + t.float() @ lb.float().t() + b.float())
+    if epi == L.EPI_BIAS:
+        e = float((outs[1].float() - ref).norm() / ref.norm())
+        if e > 4e-3:
+            bad += 1; print("REF MISMATCH", M, N, K, r, e)
+    for o in outs[1:]:
+        if not torch.equal(o, outs[0]):
+            bad += 1
+            print("MISMATCH", M, N, K, r, epi, float((o.float() - outs[0].float()).abs().max()))
+sys.exit(1 if bad else 0)
+""" % root
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout + p.stderr

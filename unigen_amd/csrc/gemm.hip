@@ -157,7 +157,7 @@ constexpr int KT_BYTES = 4 * HT_BYTES;
 constexpr int LDS256_BYTES = 2 * KT_BYTES;
 constexpr int SLOT_A0 = 0, SLOT_B0 = HT_BYTES, SLOT_B1 = 2 * HT_BYTES, SLOT_A1 = 3 * HT_BYTES;
 
-template <int EPI>
+template <int EPI, bool LORA>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, const int tiles_per_group, const int total_tiles, const int wide16,
                                                           const int full_tiles, const int nslices, float* __restrict__ slabs,
                                                           unsigned* __restrict__ tickets) {
@@ -178,7 +178,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
     const int nM = (int)((M + 255) / 256), nN = (int)((N + 255) / 256);
     const int st_off = wave * 16 * 128;
     int a_off, b_off, ch0, ch1;          // fragment read offsets; set per tile (see the tile loop)
-    const int nk = (int)(p.K / BK);
+    // LORA: the K loop runs on through a second segment, T[m][0..r) . B[n][0..r) (the same K-segment the 128^2 kernel appends), with
+    // the staging pointers of a half-tile pair swapped to the LoRA operands (pre-biased by -K) just before their first LoRA K-tile.
+    const int nkA = (int)(p.K / BK);
+    const int nk = nkA + (LORA ? p.lora_r / BK : 0);
 
     struct TileSrc { const bf16_t* a[2][2]; const bf16_t* b[2][2]; int64_t m0, n0; int g; int nk; int rem; int slice; };
     // work item w -> tile and K range. Items >= full_tiles are K-slices of remainder tile `rem`; a tile's slices share blockIdx & 7
@@ -217,6 +220,19 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
                 t.b[h][i] = Wb + wn * p.ldw + c * 8 + (int64_t)kb * BK;
             }
         return t;
+    };
+    auto lora_src = [&](TileSrc& t, int h) {
+        int lane_l = lane;
+        asm volatile("" : "+v"(lane_l));       // keeps these addresses from being hoisted (and held in registers) across the K loop
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = wave * 16 + i * 8 + (lane_l >> 3);
+            const int c = (lane_l & 7) ^ (row & 7);
+            int64_t am = t.m0 + h * 128 + row; if (am > M - 1) am = M - 1;
+            int64_t wn = t.n0 + h * 128 + row; if (wn > N - 1) wn = N - 1;
+            t.a[h][i] = (const bf16_t*)p.lora_T + am * p.ldt + c * 8 - p.K;
+            t.b[h][i] = (const bf16_t*)p.lora_B + wn * p.ldb + c * 8 - p.K;
+        }
     };
     auto stage = [&](unsigned char* slot, const bf16_t* const (&src)[2], int64_t ko) {
         glds16(src[0] + ko, slot + st_off);
@@ -328,6 +344,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
             const bool pre0 = pre && kt == 0;
             const bool x01 = sif && (kt == 0 || (pre && kt == 1)), x3 = sif && kt == 0;
             const int64_t k1 = (int64_t)(kt + 1) * BK, k2 = (int64_t)(kt + 2) * BK;
+            if (LORA && kt + 1 == nkA) lora_src(cur, 1);
             // phase 0: quadrant (0,0)
             read_A(cb + SLOT_A0); read_B(breg0, cb + SLOT_B0);
             if (pre0) UG_WAIT_VM(10, x01);
@@ -346,6 +363,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
             UG_BARRIER();
             // phase 2: quadrant (1,1)
             read_A(cb + SLOT_A1);
+            if (LORA && kt + 2 == nkA) lora_src(cur, 0);
             if (n2) stage(cb + SLOT_A0, cur.a[0], k2);
             UG_BARRIER();
             UG_MMA_QUADRANT(1, 1, breg);
@@ -556,14 +574,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
 }
 
 // UG_GEMM_FORCE_TILE=128|256 pins the kernel choice (tests / A-B timing); default: 256^2 tiles when they fill the chip.
-int forced_tile() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("UG_GEMM_FORCE_TILE");
-        v = e ? atoi(e) : 0;
-    }
-    return v;
-}
+int forced_tile() { return ug_env_int("UG_GEMM_FORCE_TILE", 0); }
 
 template <int EPI>
 int launch(const ug_gemm_desc& d, hipStream_t s) {
@@ -573,14 +584,17 @@ int launch(const ug_gemm_desc& d, hipStream_t s) {
     // pick the tile by expected chip fill: 256 CUs x 1 workgroup (256^2) vs 256 x 2 (128^2, ~0.82x the 256^2 kernel's rate)
     const double e256 = (double)t256 / (double)(((t256 + 255) / 256) * 256);
     const double e128 = 0.82 * (double)t128 / (double)(((t128 + 511) / 512) * 512);
-    bool big = d.lora_r <= 0 && d.M >= 192 && d.N >= 192 && e256 >= e128;
+    const bool lora = d.lora_r > 0;
+    bool big = (!lora || (d.K >= 2 * BK && EPI != UG_EPI_F32)) && d.M >= 192 && d.N >= 192 && e256 >= e128;
     const int f = forced_tile();
     if (f == 128) big = false;
-    if (f == 256 && d.lora_r <= 0) big = true;
+    if (f == 256 && (!lora || (d.K >= 2 * BK && EPI != UG_EPI_F32))) big = true;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)gemm128_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)gemm256_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256_BYTES + 16);
+        (void)hipFuncSetAttribute((const void*)gemm256_kernel<EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256_BYTES + 16);
+        if (EPI != UG_EPI_F32)
+            (void)hipFuncSetAttribute((const void*)gemm256_kernel<EPI, EPI != UG_EPI_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256_BYTES + 16);
         attr_set = true;
     }
     if (big) {
@@ -597,7 +611,7 @@ int launch(const ug_gemm_desc& d, hipStream_t s) {
         const int wide16 = d.N % 8 == 0 && d.ldc % 8 == 0 && d.c_gstride % 8 == 0 && ug_aligned(d.C, 16) &&
                            (!res || (d.ldr % 8 == 0 && d.r_gstride % 8 == 0 && ug_aligned(d.R, 16)));
         // UG_GEMM_PWG=1: the one-wave-per-SIMD kernel (gemm_pwg.hip) takes every shape it supports
-        if (EPI != UG_EPI_F32 && wide16 && ug_env_int("UG_GEMM_PWG", 0)) return ug_gemm_launch_pwg(d, s);
+        if (EPI != UG_EPI_F32 && wide16 && !lora && ug_env_int("UG_GEMM_PWG", 0)) return ug_gemm_launch_pwg(d, s);
         // split-K tail (see the kernel header): needs the caller's workspace for the slabs and tickets
         int full = total, nsl = 1;
         float* slabs = nullptr; unsigned* tickets = nullptr;
@@ -607,7 +621,7 @@ int launch(const ug_gemm_desc& d, hipStream_t s) {
         if (split_on < 0) { const char* e = getenv("UG_GEMM_SPLITK_TAIL"); split_on = (e && atoi(e) == 0) ? 0 : 1; }
         // Measured (MI355X): the slab round trip + fences cost ~35 us, so the split only pays when a tile's K loop is long
         // (K = 15360 single-block proj_out: +3.5 %; K = 3072 shapes: -2...-3 %) -> require >= 96 K-tiles.
-        if (split_on && rem > 0 && rem * 2 <= G && d.workspace && nkt >= 96) {
+        if (split_on && !lora && rem > 0 && rem * 2 <= G && d.workspace && nkt >= 96) {
             const int rem8 = (rem + 7) / 8 * 8;
             int cand = G / rem8; if (cand > 8) cand = 8; if (cand > nkt / 4) cand = nkt / 4;
             const size_t need = 4096 + (size_t)rem8 * cand * 65536 * sizeof(float);
@@ -618,7 +632,10 @@ int launch(const ug_gemm_desc& d, hipStream_t s) {
                 slabs = (float*)((char*)d.workspace + 4096);
             }
         }
-        hipLaunchKernelGGL(gemm256_kernel<EPI>, grid, dim3(512), LDS256_BYTES + 16, s, d, (int)(t256 / groups), total, wide16, full, nsl, slabs, tickets);
+        if (lora)       // (EPI_F32 never gets here with LoRA; its second instantiation is the plain kernel again)
+            hipLaunchKernelGGL((gemm256_kernel<EPI, EPI != UG_EPI_F32>), grid, dim3(512), LDS256_BYTES + 16, s, d, (int)(t256 / groups), total, wide16, full, nsl, slabs, tickets);
+        else
+            hipLaunchKernelGGL((gemm256_kernel<EPI, false>), grid, dim3(512), LDS256_BYTES + 16, s, d, (int)(t256 / groups), total, wide16, full, nsl, slabs, tickets);
     } else {
         const int nM = (int)((d.M + BM - 1) / BM), nN = (int)((d.N + BN - 1) / BN);
         dim3 grid((unsigned)(nM * nN), 1, (unsigned)groups);
