@@ -50,7 +50,10 @@ enum {
     UG_EPI_BIAS_GELU = 1,  /* C = gelu_tanh(v)                                 FeedForward net.0 (diffusers GELU approximate="tanh") */
     UG_EPI_RES_GATE = 2,   /* C = R + gate[sample(m)][n] * v                   x + gate.unsqueeze(1) * attn/ff  (FluxTransformerBlock) */
     UG_EPI_RES_SCALE = 3,  /* C = R + alpha * v                                x + cn_block(z) * conditioning_scale (UniGenTransformer.py:1104,1141) */
-    UG_EPI_F32 = 4         /* C(fp32) = acc + bias (no rounding; verification / gate logits) */
+    UG_EPI_F32 = 4,        /* C(fp32) = acc + bias (no rounding; verification / gate logits) */
+    UG_EPI_QKV_ROPE = 5    /* fused [to_q; to_k; to_v (; proj_mlp)] projection: columns [0, qk_until_n) are q | k heads of 128 and get
+                              Attention.norm_q / norm_k (RMSNorm) + apply_rotary_emb in the epilogue (src/UniGenUtils.py:561-599, the work of
+                              ug_qk_rmsnorm_rope); the other columns behave as UG_EPI_BIAS, or GELU from gelu_from_n > 0 on */
 };
 
 typedef struct ug_gemm_desc {
@@ -84,6 +87,13 @@ typedef struct ug_gemm_desc {
      *   output column n is stored at column n + c_shift when n >= c_shift_from_n > 0 (a gap in the destination row).
      * Both boundaries must be multiples of 256 (a tile never straddles them); c_shift a multiple of 8. */
     int64_t gelu_from_n, c_shift_from_n, c_shift;
+    /* UG_EPI_QKV_ROPE only. Heads are 128 wide; q heads fill columns [0, qk_until_n / 2), k heads [qk_until_n / 2, qk_until_n).
+     *   qk_wq, qk_wk : [128] bf16 RMSNorm weights;  rope_cs : fp32 [positions][64][2] = (cos, sin) of each rotation pair;
+     *   row m sits at position rope_pos0 + (m % rope_rpb) (rope_rpb 0: m itself).
+     * Needs M, N, qk_until_n multiples of 256, groups 1, no LoRA segment, 16-byte aligned C rows. */
+    const void* qk_wq; const void* qk_wk; const float* rope_cs;
+    int64_t rope_rpb, rope_pos0, qk_until_n;
+    float qk_eps; int32_t _pad2;
 } ug_gemm_desc;
 
 /* bytes of ug_gemm_desc.workspace that are always sufficient (any shape) */

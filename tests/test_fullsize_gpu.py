@@ -171,7 +171,7 @@ def test_vae_full_size_decode_and_encode(gpu):
     report("vae_fullsize_timing", img2, img, decode_ms=t_dec * 1e3, encode_ms=t_enc * 1e3)
 
 
-def test_cfg4_per_gpu_shape_b8_forward_properties(gpu):
+def test_cfg4_per_gpu_shape_b8_forward_properties(gpu, monkeypatch):
     """cfg4's per-GPU share (global batch 64 = 8 GPUs x B = 8; reference infer.py:173 shards samples by rank) on ONE GPU at FULL size: the
     FLUX-schnell geometry forward at B = 8, 1024^2. No oracle can evaluate it, so size-independent properties: finite output, every token
     routed (expert counts sum to B N), run-to-run bitwise repeatability. (Samples of one batch are NOT independent in the reference either:
@@ -199,3 +199,49 @@ def test_cfg4_per_gpu_shape_b8_forward_properties(gpu):
     again = model(timestep=t, img_ids=ids, txt_ids=txt, condition_ids=ids, gate_uniform=uni, **inp)[0]
     assert torch.equal(again, out8), "B = 8 forward is not bitwise repeatable"
     report("cfg4_b8_forward", again, out8)
+    # At this size every image-stream / joint QKV projection takes q/k RMSNorm + RoPE in its epilogue (UG_EPI_QKV_ROPE). The same forward with
+    # the stand-alone ug_qk_rmsnorm_rope pass differs in ~1e-6 of the q/k elements by one bf16 step per block (tests/test_kernels_gpu.py);
+    # this synthetic model turns ANY one-step nudge of one element into a 1-2e-2 change of the output (top-1 routing / capacity decisions
+    # flip; measured with one input element moved by one bf16 step), so only that scale can be asserted here. The fused path's accuracy is
+    # pinned against the fp32 verification path in test_fused_qk_rope_forward_vs_fp32_verification below.
+    monkeypatch.setenv("UG_GEMM_FUSE_QKROPE", "0")
+    two = model(timestep=t, img_ids=ids, txt_ids=txt, condition_ids=ids, gate_uniform=uni, **inp)
+    m = report("cfg4_b8_fused_vs_two_launch_qk", out8, two[0])
+    assert m["rel_l2"] <= 5e-2 and int(two[2]["expert_counts"].sum()) == B * N, m
+
+
+def test_fused_qk_rope_forward_vs_fp32_verification(gpu, monkeypatch):
+    """FLUX width (D = 3072, 24 heads), 1024^2 tokens, depth cut to 2 + 2 blocks (+ their control twins), B = 1: the bf16 forward with the
+    fused QKV epilogue and the one with the stand-alone q/k pass are both compared with the SAME forward on the fp32 verification twins
+    (fp32 parameters -> *_f32 entry points; that path is pinned to the fp32 oracle at 4e-6, tests/test_verify_f32_gpu.py). The fused path
+    must be as close to fp32 as the two-launch path."""
+    from unigen_amd.flux import UniGenFlux
+    from unigen_amd.pipeline import prepare_latent_image_ids
+    cfg = {"num_layers": 2, "num_single_layers": 2}
+    ctl = dict(use_rope=True, use_shared_expert=True, use_consis_module=False, use_single_trans_blocks=True, single_control_dev=2,
+               single_block_control_method="overall_add", top_num=1, expert_num_each_condition=3)
+    model = UniGenFlux.from_config(cfg, device=gpu, dtype=BF)
+    model.init_condition_block(condition_nums=1, condition_types=["canny"], control_params=ctl)
+    model.init_synthetic_(seed=0, std=0.02)
+    ref = UniGenFlux.from_config(cfg, device=gpu, dtype=torch.float32)
+    ref.init_condition_block(condition_nums=1, condition_types=["canny"], control_params=ctl)
+    ref.load_state_dict({k: v.float() for k, v in model.state_dict().items()})
+    B, grid, T = 1, 64, 512
+    N = grid * grid
+    g = torch.Generator(device=gpu).manual_seed(9)
+    rn = lambda *s: torch.randn(*s, generator=g, device=gpu)
+    inp = dict(hidden_states=rn(B, N, 64).to(BF), condition_hidden_states=rn(B, N, 64).to(BF), encoder_hidden_states=(0.1 * rn(B, T, 4096)).to(BF),
+               pooled_projections=rn(B, 768).to(BF), condition_pooled_projections=rn(B, 768).to(BF))
+    ids = prepare_latent_image_ids(grid, grid, gpu, BF)
+    txt = torch.zeros(T, 3, device=gpu, dtype=BF)
+    t = torch.full((B,), 0.75, device=gpu, dtype=BF)
+    uni = torch.rand(B * N, model._ctl.expert_nums, generator=g, device=gpu)
+    run = lambda m, cast: m(timestep=cast(t), img_ids=cast(ids), txt_ids=cast(txt), condition_ids=cast(ids), gate_uniform=uni,
+                            **{k: cast(v) for k, v in inp.items()})[0].float().clone()
+    truth = run(ref, lambda x: x.float())
+    fused = run(model, lambda x: x)
+    monkeypatch.setenv("UG_GEMM_FUSE_QKROPE", "0")
+    two = run(model, lambda x: x)
+    e1 = report("flux_width_fused_qk_vs_fp32", fused, truth)["rel_l2"]
+    e2 = report("flux_width_two_launch_qk_vs_fp32", two, truth)["rel_l2"]
+    assert torch.isfinite(truth).all() and e1 <= 1.25 * e2 + 1e-4 and e1 <= 5e-2, (e1, e2)

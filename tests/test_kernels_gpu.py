@@ -571,3 +571,81 @@ sys.exit(1 if bad else 0)
 """ % root
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout + p.stderr
+
+
+def test_gemm_fused_qk_rmsnorm_rope_epilogue(gpu):
+    """UG_EPI_QKV_ROPE = ug_gemm_bf16 + ug_qk_rmsnorm_rope in one launch (Attention.norm_q/k + apply_rotary_emb, src/UniGenUtils.py:561-599):
+    the single block's [q | k | v | gelu(mlp)] launch with the column shift, and a double block's sample rows written through a row map into
+    the joint buffer at position offset Lc. v / mlp columns must be bit-identical to the two-launch path; q / k columns may differ by the
+    fp32 summation order of the row's sum of squares (a last-bit effect on rstd): one bf16 step on a handful of elements, and as close to
+    the fp32 restatement as the two-launch path."""
+    from unigen_amd import lib as L, ops
+    g = torch.Generator().manual_seed(11)
+    D, dh = 512, 128
+    H = D // dh
+
+    def tables(S):
+        ang = torch.rand(S, dh // 2, generator=g) * 6.28
+        cos, sin = ang.cos().repeat_interleave(2, 1).contiguous(), ang.sin().repeat_interleave(2, 1).contiguous()
+        cs = torch.stack([cos[:, 0::2], sin[:, 0::2]], -1).contiguous()
+        return cos.to(gpu), sin.to(gpu), cs.to(gpu)
+
+    def ref_qk(y, wn, cos, sin):          # y [rows, H*dh] fp32 of bf16 values, positions = rows
+        x = y.view(y.shape[0], H, dh)
+        rs = torch.rsqrt((x * x).mean(-1, keepdim=True) + 1e-6)
+        x = ((x * rs).to(BF).float() * wn.float()).to(BF).float()
+        xr = torch.stack([-x[..., 1::2], x[..., 0::2]], -1).flatten(-2)
+        return (x * cos[:, None] + xr * sin[:, None]).reshape(y.shape[0], H * dh)
+
+    wq, wk = (1 + 0.2 * torch.randn(dh, generator=g)).to(BF), (1 + 0.2 * torch.randn(dh, generator=g)).to(BF)
+    # --- single block: M = B * Lj rows, N = 7D, GELU from 3D on, stored behind the attention slot --------------------------------------
+    B, Lj, K = 2, 1280, 256
+    M = B * Lj
+    x, w, b = _rand(g, M, K), _rand(g, 7 * D, K, scale=K ** -0.5), _rand(g, 7 * D, scale=0.1)
+    cos, sin, cs = tables(Lj)
+    xd, wd, bd, wqd, wkd = x.to(gpu), w.to(gpu), b.to(gpu), wq.to(gpu), wk.to(gpu)
+    two = torch.zeros(M, 8 * D, device=gpu, dtype=BF)
+    ops.gemm(xd, wd, bd, two, M=M, ldc=8 * D, epilogue=L.EPI_BIAS_GELU, gelu_from_n=3 * D, c_shift_from_n=3 * D, c_shift=D)
+    lin = two.clone()
+    ops.qk_rmsnorm_rope(two, batches=B, rows_per_batch=Lj, ld=8 * D, q_off=0, k_off=D, heads=H, dh=dh, wq_b=wqd, wk_b=wkd, split=0, cos=cos, sin=sin)
+    one = torch.zeros(M, 8 * D, device=gpu, dtype=BF)
+    ops.gemm(xd, wd, bd, one, M=M, ldc=8 * D, epilogue=L.EPI_BIAS_GELU, gelu_from_n=3 * D, c_shift_from_n=3 * D, c_shift=D,
+             qk_rope=ops.QkRope(wqd, wkd, cs, Lj, 0, 2 * D))
+    torch.cuda.synchronize()
+    assert torch.equal(one[:, 2 * D:], two[:, 2 * D:]), "v / mlp columns differ"
+    pos = torch.arange(M, device=gpu) % Lj
+    for name, c0, wn in (("q", 0, wqd), ("k", D, wkd)):
+        ref = ref_qk(lin[:, c0:c0 + D].float(), wn, cos[pos], sin[pos])
+        e1 = float((one[:, c0:c0 + D].float() - ref).norm() / ref.norm())
+        e2 = float((two[:, c0:c0 + D].float() - ref).norm() / ref.norm())
+        diff = (one[:, c0:c0 + D].float() - two[:, c0:c0 + D].float()).abs()
+        frac = float((diff > 0).float().mean())
+        ulp = float(diff.max())            # values are O(1): one bf16 step of the normalised value (a rotated sum may land near zero)
+        print(f"fused qk-rope single {name}: rel_l2 fused {e1:.3e} two-launch {e2:.3e}; differing elements {frac:.2e}, max abs diff {ulp:.3e}")
+        assert e1 <= 3e-3 and e1 <= 1.05 * e2 + 1e-5 and frac < 2e-2 and ulp <= 0.04, (name, e1, e2, frac, ulp)
+    # --- double block sample rows: row map into the joint buffer [B, Lc + Ls, 3D], positions Lc + m % Ls ------------------------------
+    B, Lc, Ls = 3, 128, 768
+    Ljn = Lc + Ls
+    M = B * Ls
+    x, w, b = _rand(g, M, K), _rand(g, 3 * D, K, scale=K ** -0.5), _rand(g, 3 * D, scale=0.1)
+    cos, sin, cs = tables(Ljn)
+    xd, wd, bd = x.to(gpu), w.to(gpu), b.to(gpu)
+    junk = _rand(g, B * Ljn, 3 * D).to(gpu)
+    two, one = junk.clone(), junk.clone()
+    ops.gemm(xd, wd, bd, two[Lc:], M=M, ldc=3 * D, c_map=ops.RowMap(Ls, Ljn))
+    ops.qk_rmsnorm_rope(two[Lc:], batches=B, rows_per_batch=Ls, batch_stride_rows=Ljn, pos_offset=Lc, ld=3 * D, q_off=0, k_off=D, heads=H, dh=dh,
+                        wq_b=wqd, wk_b=wkd, split=0, cos=cos, sin=sin)
+    ops.gemm(xd, wd, bd, one[Lc:], M=M, ldc=3 * D, c_map=ops.RowMap(Ls, Ljn), qk_rope=ops.QkRope(wqd, wkd, cs, Ls, Lc, 2 * D))
+    torch.cuda.synchronize()
+    o3, t3 = one.view(B, Ljn, 3 * D), two.view(B, Ljn, 3 * D)
+    assert torch.equal(o3[:, :Lc], junk.view(B, Ljn, 3 * D)[:, :Lc]) and torch.equal(o3[:, Lc:, 2 * D:], t3[:, Lc:, 2 * D:])
+    diff = (o3[:, Lc:, :2 * D].float() - t3[:, Lc:, :2 * D].float()).abs()
+    rel = float(diff.norm() / t3[:, Lc:, :2 * D].float().norm())
+    frac = float((diff > 0).float().mean())
+    print(f"fused qk-rope double: rel_l2 vs two-launch {rel:.3e}, differing elements {frac:.2e}")
+    assert rel <= 5e-4 and frac < 2e-2, (rel, frac)
+    # --- argument checks ----------------------------------------------------------------------------------------------------------------
+    with pytest.raises(L.UniGenHipError, match="multiples of 256"):
+        ops.gemm(xd[:300], wd, bd, torch.empty(300, 3 * D, device=gpu, dtype=BF), M=300, qk_rope=ops.QkRope(wqd, wkd, cs, 0, 0, 2 * D))
+    with pytest.raises(ValueError, match="positions"):
+        ops.gemm(xd, wd, bd, one[Lc:], M=M, ldc=3 * D, c_map=ops.RowMap(Ls, Ljn), qk_rope=ops.QkRope(wqd, wkd, cs, Ls, Ljn, 2 * D))

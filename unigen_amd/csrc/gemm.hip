@@ -392,6 +392,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
         // fetched NOW, with nothing else on the VM counter, and waited for under the next tile's address arithmetic - before its DMA
         // prefetch is issued, so no later wait in the epilogue has to drain that prefetch.
         constexpr bool RES = EPI == UG_EPI_RES_GATE || EPI == UG_EPI_RES_SCALE;
+        constexpr int EPI_A = EPI == UG_EPI_QKV_ROPE ? UG_EPI_BIAS_GELU : EPI;      // what a tile outside the q | k columns runs
+        bool qk_tile = false;
+        if constexpr (EPI == UG_EPI_QKV_ROPE) qk_tile = n0 < p.qk_until_n;
         bool fast = EPI != UG_EPI_F32 && wide16 && m0 + 256 <= M && n0 + 256 <= N && rem < 0;
         unsigned sample = 0;
         if constexpr (EPI == UG_EPI_RES_GATE) {
@@ -412,6 +415,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
                     pb[j][nt] = (u32x2){0u, 0u}; pg[j][nt] = (u32x2){0u, 0u};
                     if (bias) pb[j][nt] = *(const u32x2*)(bias + n);
                     if constexpr (EPI == UG_EPI_RES_GATE) pg[j][nt] = *(const u32x2*)(gate + n);
+                    if constexpr (EPI == UG_EPI_QKV_ROPE) {        // fg[0][nt]: this lane's 4 RMSNorm weights (column within the head)
+                        if (qk_tile && j == 0)
+                            pg[0][nt] = *(const u32x2*)((const bf16_t*)(2 * n0 >= p.qk_until_n ? p.qk_wk : p.qk_wq) + wc * 32 + nt * 16 + (lane_e >> 4) * 4);
+                    }
                 }
             if (tile + (int)gridDim.x < n_items) cur = tile_src(tile + gridDim.x, lane_e); else cur.nk = 0;
 #pragma unroll
@@ -477,6 +484,83 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
                                 acc[i][j][a][b] += *(const f32x4*)(sp + ((((i * 2 + j) * 4 + a) * 2 + b) * 512 + tid_e) * 4);
             }
         }
+        if constexpr (EPI == UG_EPI_QKV_ROPE) {
+            if (fast && qk_tile) {
+                // q | k tile: the tile is two heads wide (j = 0, 1); a row of a head is spread over the 4 waves wc = 0..3 (32 columns each)
+                // and, inside a wave, over 4 lane groups of 4 columns x 2 n-tiles.
+                const int lg = lane_e >> 4;
+                float* const part = (float*)(smem + LDS256_BYTES + 16) + ((wr * 64 + (lane_e & 15)) * 8);   // [row 256][head 2][wc 4]
+                // (1) the Linear's bf16 output, in place, and the per-row sums of squares: lane groups by permlane swaps, waves through LDS
+#pragma unroll
+                for (int rg = 0; rg < 8; ++rg)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        float ss = 0.f;
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const float v = rbf(acc[rg >> 2][j][rg & 3][nt][q] + fb[j][nt][q]);
+                                acc[rg >> 2][j][rg & 3][nt][q] = v;
+                                ss += v * v;
+                            }
+                        part[((rg >> 2) * 128 + (rg & 3) * 16) * 8 + j * 4 + wc] = sum_row_groups(ss);
+                    }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                UG_BARRIER();
+                // (2) normalise, rotate, store. (cos, sin) pairs of row-group rg+1 are loaded before row-group rg is computed and stored.
+                const int colb = (int)n0 + wc * 32 + (lg & 1) * 16 + 8 * (lg >> 1);
+                bf16_t* const Cb = (bf16_t*)p.C + colb;
+                const float* const csb = p.rope_cs + wc * 32 + lg * 4;
+                const unsigned mrow = (unsigned)m0 + wr * 64 + (lane_e & 15);
+                // position of a row: ONE division per tile (its divisor made opaque, or the reciprocal is hoisted out of the tile loop and
+                // spilled across the K loop); the other 7 rows are < 256 <= rope_rpb further on, so a conditional subtract wraps them.
+                unsigned rpb = (unsigned)p.rope_rpb;
+                asm volatile("" : "+s"(rpb));
+                const unsigned wrap = rpb ? rpb : 0xffffffffu;
+                const unsigned rr0 = rpb ? mrow % rpb : mrow;
+                u32x4 cbuf[2][2];
+                bf16_t* cp[2];
+                auto open_rows = [&](int rg) {
+                    const unsigned m = mrow + (rg >> 2) * 128 + (rg & 3) * 16;
+                    cp[rg & 1] = Cb + (int64_t)rowmap32(m, (unsigned)p.c_rpb, (unsigned)p.c_bstride) * p.ldc;
+                    unsigned rr = rr0 + (rg >> 2) * 128 + (rg & 3) * 16;
+                    if (rr >= wrap) rr -= wrap;
+                    const float* q = csb + ((int64_t)p.rope_pos0 + rr) * 128;
+                    cbuf[rg & 1][0] = gload16_asm(q);
+                    cbuf[rg & 1][1] = gload16_asm_64(q);
+                };
+                stores_in_flight = true;
+                open_rows(0);
+#pragma unroll
+                for (int rg = 0; rg < 8; ++rg) {
+                    if (rg + 1 < 8) open_rows(rg + 1);
+                    if (rg == 0 || rg == 7) ug_wait_vm<2>(cbuf[rg & 1][0], cbuf[rg & 1][1]);
+                    else ug_wait_vm<4>(cbuf[rg & 1][0], cbuf[rg & 1][1]);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const f32x4 t = *(const f32x4*)(part + ((rg >> 2) * 128 + (rg & 3) * 16) * 8 + j * 4);
+                        const float rs = __builtin_amdgcn_rsqf((t[0] + t[1] + t[2] + t[3]) * (1.0f / 128.0f) + p.qk_eps);
+                        unsigned pk[2][2];
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt) {
+                            const u32x4 cs = cbuf[rg & 1][nt];
+                            const float c0 = __builtin_bit_cast(float, (unsigned)cs.x), s0 = __builtin_bit_cast(float, (unsigned)cs.y);
+                            const float c1 = __builtin_bit_cast(float, (unsigned)cs.z), s1 = __builtin_bit_cast(float, (unsigned)cs.w);
+                            float x[4];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) x[q] = rbf(rbf(acc[rg >> 2][j][rg & 3][nt][q] * rs) * fg[0][nt][q]);
+                            pk[nt][0] = pack2bf(x[0] * c0 + (-x[1]) * s0, x[1] * c0 + x[0] * s0);
+                            pk[nt][1] = pack2bf(x[2] * c1 + (-x[3]) * s1, x[3] * c1 + x[2] * s1);
+                        }
+                        swap16(pk[0][0], pk[1][0]); swap16(pk[0][1], pk[1][1]);
+                        u32x4 o; o.x = pk[0][0]; o.y = pk[0][1]; o.z = pk[1][0]; o.w = pk[1][1];
+                        __builtin_nontemporal_store(o, (u32x4*)(cp[rg & 1] + j * 128));
+                    }
+                }
+                continue;
+            }
+        }
         if (fast) {
             // 8 row-groups of 16 rows x 2 column halves; the residual chunks of row-group rg+1 are loaded before row-group rg is
             // computed and stored (older than those stores on the in-order VM counter, so waiting for them does not wait for stores).
@@ -511,10 +595,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
                 }
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    const u32x4 o = (EPI == UG_EPI_BIAS_GELU && !ts.gelu)
+                    const u32x4 o = (EPI_A == UG_EPI_BIAS_GELU && !ts.gelu)
                         ? epi_chunk_full<UG_EPI_BIAS>(p.alpha, acc[rg >> 2][j][rg & 3][0], acc[rg >> 2][j][rg & 3][1], fb[j][0], fb[j][1],
                                                       fg[j][0], fg[j][1], rbuf[rg & 1][j])
-                        : epi_chunk_full<EPI>(p.alpha, acc[rg >> 2][j][rg & 3][0], acc[rg >> 2][j][rg & 3][1], fb[j][0], fb[j][1],
+                        : epi_chunk_full<EPI_A>(p.alpha, acc[rg >> 2][j][rg & 3][0], acc[rg >> 2][j][rg & 3][1], fb[j][0], fb[j][1],
                                               fg[j][0], fg[j][1], rbuf[rg & 1][j]);
                     __builtin_nontemporal_store(o, (u32x4*)(cp[rg & 1] + j * 128));
                 }
@@ -538,14 +622,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
                 for (int mt = 0; mt < 4; ++mt) {
                     const int64_t m = m0 + i * 128 + wr * 64 + mt * 16 + (lane_e & 15);
                     const bool row_ok = m < M;                         // lanes l and l^16 share the row: the swaps stay paired
-                    RowCtx rc = row_ctx<EPI>(p, g, (unsigned)(row_ok ? m : M - 1));
+                    RowCtx rc = row_ctx<EPI_A>(p, g, (unsigned)(row_ok ? m : M - 1));
                     rc.coff += tsl.cshift;
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
-                        if (EPI == UG_EPI_BIAS_GELU && !tsl.gelu)
+                        if (EPI_A == UG_EPI_BIAS_GELU && !tsl.gelu)
                             epi_store_pair16<UG_EPI_BIAS>(p, rc, row_ok, n0 + j * 128 + wc * 32, N, lane_e, acc[i][j][mt][0], acc[i][j][mt][1], bv[j][0], bv[j][1]);
                         else
-                            epi_store_pair16<EPI>(p, rc, row_ok, n0 + j * 128 + wc * 32, N, lane_e, acc[i][j][mt][0], acc[i][j][mt][1], bv[j][0], bv[j][1]);
+                            epi_store_pair16<EPI_A>(p, rc, row_ok, n0 + j * 128 + wc * 32, N, lane_e, acc[i][j][mt][0], acc[i][j][mt][1], bv[j][0], bv[j][1]);
                     }
                 }
         } else {
@@ -555,7 +639,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
                 for (int mt = 0; mt < 4; ++mt) {
                     const int64_t m = m0 + i * 128 + wr * 64 + mt * 16 + (lane_e & 15);
                     if (m >= M) continue;
-                    RowCtx rc = row_ctx<EPI>(p, g, (unsigned)m);
+                    RowCtx rc = row_ctx<EPI_A>(p, g, (unsigned)m);
                     rc.coff += tsl.cshift;
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
@@ -563,8 +647,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
                         for (int nt = 0; nt < 2; ++nt) {
                             const int64_t n = n0 + j * 128 + wc * 32 + nt * 16 + (lane_e >> 4) * 4;
                             if (n >= N) continue;
-                            if (EPI == UG_EPI_BIAS_GELU && !tsl.gelu) epi_store<UG_EPI_BIAS>(p, rc, n, acc[i][j][mt][nt], bv[j][nt]);
-                            else epi_store<EPI>(p, rc, n, acc[i][j][mt][nt], bv[j][nt]);
+                            if (EPI_A == UG_EPI_BIAS_GELU && !tsl.gelu) epi_store<UG_EPI_BIAS>(p, rc, n, acc[i][j][mt][nt], bv[j][nt]);
+                            else epi_store<EPI_A>(p, rc, n, acc[i][j][mt][nt], bv[j][nt]);
                         }
                 }
         }
@@ -645,6 +729,36 @@ int launch(const ug_gemm_desc& d, hipStream_t s) {
     return UG_OK;
 }
 
+// UG_EPI_QKV_ROPE: 256^2 kernel only, whole tiles only (the q | k epilogue reduces rows across the four column waves of a tile)
+int launch_qkrope(const ug_gemm_desc& d, hipStream_t s) {
+    UG_REQUIRE(d.M % 256 == 0 && d.N % 256 == 0 && d.qk_until_n > 0 && d.qk_until_n % 256 == 0 && d.qk_until_n <= d.N, UG_ERR_UNSUPPORTED,
+               "ug_gemm_bf16: UG_EPI_QKV_ROPE needs M, N, qk_until_n multiples of 256 (M=%lld N=%lld qk_until_n=%lld)", (long long)d.M,
+               (long long)d.N, (long long)d.qk_until_n);
+    UG_REQUIRE(d.groups == 1 && d.lora_r <= 0, UG_ERR_UNSUPPORTED, "ug_gemm_bf16: UG_EPI_QKV_ROPE is neither grouped nor LoRA-extended");
+    UG_REQUIRE(d.qk_wq && d.qk_wk && d.rope_cs && ug_aligned(d.qk_wq, 8) && ug_aligned(d.qk_wk, 8) && ug_aligned(d.rope_cs, 16) &&
+               d.ldc % 8 == 0 && ug_aligned(d.C, 16), UG_ERR_BAD_ALIGN, "ug_gemm_bf16: UG_EPI_QKV_ROPE operands missing/misaligned");
+    UG_REQUIRE((d.rope_rpb == 0 || d.rope_rpb >= 256) && d.rope_rpb < (1ll << 31) && d.rope_pos0 >= 0 && d.rope_pos0 < (1ll << 31) &&
+               (d.gelu_from_n == 0 || d.gelu_from_n >= d.qk_until_n) && (d.c_shift_from_n == 0 || d.c_shift_from_n >= d.qk_until_n),
+               UG_ERR_BAD_SHAPE, "ug_gemm_bf16: UG_EPI_QKV_ROPE bad positions / column split");
+    constexpr int LDS = LDS256_BYTES + 16 + 256 * 8 * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm256_kernel<UG_EPI_QKV_ROPE, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+    }
+    static int ncu = 0;
+    if (ncu == 0) {
+        int dev = 0; hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
+        if (ncu <= 0) ncu = 256;
+    }
+    const int total = (int)((d.M / 256) * (d.N / 256));
+    hipLaunchKernelGGL((gemm256_kernel<UG_EPI_QKV_ROPE, false>), dim3((unsigned)(total < ncu ? total : ncu)), dim3(512), LDS, s, d, total, total, 1,
+                       total, 1, (float*)nullptr, (unsigned*)nullptr);
+    UG_CHECK_LAUNCH("ug_gemm_bf16");
+    return UG_OK;
+}
+
 }  // namespace
 
 extern "C" int64_t ug_gemm_workspace_bytes(void) { return 4096 + (int64_t)256 * 65536 * (int64_t)sizeof(float); }
@@ -692,6 +806,7 @@ extern "C" int ug_gemm_bf16(const ug_gemm_desc* dp, ug_stream_t stream) {
         case UG_EPI_RES_GATE: return launch<UG_EPI_RES_GATE>(d, s);
         case UG_EPI_RES_SCALE: return launch<UG_EPI_RES_SCALE>(d, s);
         case UG_EPI_F32: return launch<UG_EPI_F32>(d, s);
+        case UG_EPI_QKV_ROPE: return launch_qkrope(d, s);
         default: UG_FAIL(UG_ERR_UNSUPPORTED, "ug_gemm_bf16: unknown epilogue %d", d.epilogue);
     }
 }

@@ -83,7 +83,7 @@ struct TileSplit { bool gelu; int64_t cshift; };
 template <int EPI>
 __device__ __forceinline__ TileSplit tile_split(const ug_gemm_desc& p, int64_t n0) {
     TileSplit t;
-    t.gelu = EPI == UG_EPI_BIAS_GELU && n0 >= p.gelu_from_n;
+    t.gelu = (EPI == UG_EPI_BIAS_GELU && n0 >= p.gelu_from_n) || (EPI == UG_EPI_QKV_ROPE && p.gelu_from_n > 0 && n0 >= p.gelu_from_n);
     t.cshift = (p.c_shift_from_n > 0 && n0 >= p.c_shift_from_n) ? p.c_shift : 0;
     return t;
 }
@@ -191,6 +191,20 @@ __device__ __forceinline__ u32x4 gload16_asm_256(const void* ptr) {
     u32x4 r;
     asm volatile("global_load_dwordx4 %0, %1, off offset:256" : "=v"(r) : "v"(ptr) : "memory");
     return r;
+}
+__device__ __forceinline__ u32x4 gload16_asm_64(const void* ptr) {
+    u32x4 r;
+    asm volatile("global_load_dwordx4 %0, %1, off offset:64" : "=v"(r) : "v"(ptr) : "memory");
+    return r;
+}
+// sum of the values lanes l, l ^ 16, l ^ 32, l ^ 48 hold (the four 4-column groups of one accumulator row), without LDS
+__device__ __forceinline__ float sum_row_groups(float x) {
+    unsigned u = __builtin_bit_cast(unsigned, x);
+    auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    x = __builtin_bit_cast(float, (unsigned)a[0]) + __builtin_bit_cast(float, (unsigned)a[1]);
+    u = __builtin_bit_cast(unsigned, x);
+    auto b = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __builtin_bit_cast(float, (unsigned)b[0]) + __builtin_bit_cast(float, (unsigned)b[1]);
 }
 template <int N>
 __device__ __forceinline__ void ug_wait_vm(u32x4& a, u32x4& b) {

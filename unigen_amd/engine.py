@@ -243,7 +243,11 @@ class HipModule(nn.Module):
         # before the to_out GEMM below overwrites the sample stream (s_in and s_out are the same buffer for in-place blocks).
         n2 = self._modulate(s_in, emb_s, 6, 7, B, "s2") if dual else None
         w_qkv, b_qkv = self._attn_qkv(a)
-        ops.gemm(ns, w_qkv, b_qkv, qkv2[Lc:], M=B * Ls, ldc=3 * D, c_map=RowMap(Ls, Lj))
+        # sample rows: q / k RMSNorm + RoPE in the projection's epilogue when the shapes allow it (whole 256^2 tiles, heads of 128)
+        cs = getattr(rope, "cs", None)
+        fused = (cs is not None and wq is not None and ops.qk_rope_fusable(B * Ls, 3 * D, 2 * D, dh, ns.dtype))
+        ops.gemm(ns, w_qkv, b_qkv, qkv2[Lc:], M=B * Ls, ldc=3 * D, c_map=RowMap(Ls, Lj),
+                 qk_rope=ops.QkRope(wq, wk, cs, Ls, Lc, 2 * D) if fused else None)
         # context stream
         emb_c = None
         if c_out is not None or not ctx_cached:
@@ -259,12 +263,16 @@ class HipModule(nn.Module):
             else:
                 ops.gemm(nc, w_a[D:], b_a[D:], qkv2[0, D:], M=B * Lc, ldc=3 * D, c_map=RowMap(Lc, Lj))
         if touch:
-            if c_out is not None:
+            if c_out is not None and not fused:
                 ops.qk_rmsnorm_rope(qkv2, batches=B, rows_per_batch=Lj, ld=3 * D, q_off=0, k_off=D, heads=H, dh=dh, wq_a=waq, wk_a=wak,
                                     wq_b=wq, wk_b=wk, split=Lc, cos=cos, sin=sin)
+            elif c_out is not None:                           # the context rows only
+                ops.qk_rmsnorm_rope(qkv2, batches=B, rows_per_batch=Lc, batch_stride_rows=Lj, pos_offset=0, ld=3 * D, q_off=0, k_off=D,
+                                    heads=H, dh=dh, wq_a=waq, wk_a=wak, split=Lc, cos=cos, sin=sin)
             else:
-                ops.qk_rmsnorm_rope(qkv2[Lc:], batches=B, rows_per_batch=Ls, batch_stride_rows=Lj, pos_offset=Lc, ld=3 * D, q_off=0, k_off=D,
-                                    heads=H, dh=dh, wq_b=wq, wk_b=wk, split=0, cos=cos, sin=sin)
+                if not fused:
+                    ops.qk_rmsnorm_rope(qkv2[Lc:], batches=B, rows_per_batch=Ls, batch_stride_rows=Lj, pos_offset=Lc, ld=3 * D, q_off=0,
+                                        k_off=D, heads=H, dh=dh, wq_b=wq, wk_b=wk, split=0, cos=cos, sin=sin)
                 if not ctx_cached:
                     ops.qk_rmsnorm_rope(qkv2, batches=B, rows_per_batch=Lc, batch_stride_rows=Lj, pos_offset=0, ld=3 * D, q_off=-1, k_off=D,
                                         heads=H, dh=dh, wk_a=wak, split=Lc, cos=cos, sin=sin)

@@ -54,6 +54,11 @@ def _double_block_shapes(s: dict, p: str, D: int, dh: int) -> None:
         _lin(s, f"{p}.{n}.net.2", D, 4 * D)
 
 
+class _RopeTab(tuple):
+    """(cos, sin) [S, dh] fp32 as the callers unpack it, plus `.cs` [S, dh/2, 2]: the same values once per rotation pair."""
+    cs = None
+
+
 def _single_block_shapes(s: dict, p: str, D: int, dh: int) -> None:
     _lin(s, f"{p}.norm.linear", 3 * D, D)
     _lin(s, f"{p}.proj_mlp", 4 * D, D)
@@ -258,7 +263,9 @@ class UniGenFlux(HipModule):
         cos, sin = torch.cat(cos_out, -1), torch.cat(sin_out, -1)
         if round_to is not None and round_to != torch.float32:
             cos, sin = cos.to(round_to).float(), sin.to(round_to).float()
-        out = (cos.contiguous(), sin.contiguous())
+        out = _RopeTab((cos.contiguous(), sin.contiguous()))
+        # one (cos, sin) per rotation pair, interleaved: the table the fused QKV epilogue reads (UG_EPI_QKV_ROPE)
+        out.cs = torch.stack([out[0][:, 0::2], out[1][:, 0::2]], dim=-1).contiguous()
         if len(self._rope_cache) > 64:
             self._rope_cache.clear()
         self._rope_cache[key] = (out, tuple(ids_list))      # the ids tensors stay referenced (see the key)
@@ -277,17 +284,24 @@ class UniGenFlux(HipModule):
         # to_q / to_k / to_v and proj_mlp read the same input: one launch over their concatenated weights [7D, D]; GELU from column 3D on,
         # and those columns land behind the attention slot (column shift D). One launch of 84 column tiles instead of 36 + 48 also
         # saves a partially filled round of tiles (M = B * Lj = 72 row tiles: 23.6 rounds instead of 10.1 + 13.5).
+        wq, wk = self._P(a + ".norm_q.weight"), self._P(a + ".norm_k.weight")
+        cs = getattr(rope, "cs", None)
+        fused = False
         if (3 * D) % 256 == 0:                         # the split must fall on a tile boundary
             names = [f"{a}.to_q", f"{a}.to_k", f"{a}.to_v", f"{p}.proj_mlp"]
             w7 = self._pack(p + ".qkv_mlp.w", [x + ".weight" for x in names])
             b7 = self._pack(p + ".qkv_mlp.b", [x + ".bias" for x in names])
-            ops.gemm(n, w7, b7, sb, M=B * Lj, ldc=8 * D, epilogue=L.EPI_BIAS_GELU, gelu_from_n=3 * D, c_shift_from_n=3 * D, c_shift=D)
+            # q / k RMSNorm + RoPE ride in the same launch's epilogue when the shapes allow (whole 256^2 tiles)
+            fused = cs is not None and ops.qk_rope_fusable(B * Lj, 7 * D, 2 * D, dh, n.dtype)
+            ops.gemm(n, w7, b7, sb, M=B * Lj, ldc=8 * D, epilogue=L.EPI_BIAS_GELU, gelu_from_n=3 * D, c_shift_from_n=3 * D, c_shift=D,
+                     qk_rope=ops.QkRope(wq, wk, cs, Lj, 0, 2 * D) if fused else None)
         else:
             w_qkv, b_qkv = self._attn_qkv(a)
             ops.gemm(n, w_qkv, b_qkv, sb, M=B * Lj, ldc=8 * D)
             ops.gemm(n, self._P(p + ".proj_mlp.weight"), self._P(p + ".proj_mlp.bias"), sb[0, 4 * D:], M=B * Lj, epilogue=L.EPI_BIAS_GELU, ldc=8 * D)
-        ops.qk_rmsnorm_rope(sb, batches=B, rows_per_batch=Lj, ld=8 * D, q_off=0, k_off=D, heads=H, dh=dh, wq_b=self._P(a + ".norm_q.weight"),
-                            wk_b=self._P(a + ".norm_k.weight"), split=0, cos=cos, sin=sin)
+        if not fused:
+            ops.qk_rmsnorm_rope(sb, batches=B, rows_per_batch=Lj, ld=8 * D, q_off=0, k_off=D, heads=H, dh=dh, wq_b=wq, wk_b=wk, split=0,
+                                cos=cos, sin=sin)
         st = (8 * D, Lj * 8 * D)
         ops.flash_attn(sb, sb[0, D:], sb[0, 2 * D:], sb[0, 3 * D:], batches=B, heads=H, dh=dh, Lq=Lj, Lkv=Lj, q_strides=st, k_strides=st,
                        v_strides=st, o_strides=st)

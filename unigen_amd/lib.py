@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("UG_LIB_PATH") or os.path.join(_HERE, "libunigen_hip.so")      # UG_LIB_PATH: an alternative build (A/B tools only)
 
 UG_OK, UG_ERR_BAD_SHAPE, UG_ERR_BAD_ALIGN, UG_ERR_UNSUPPORTED, UG_ERR_HIP = 0, -1, -2, -3, -4
-EPI_BIAS, EPI_BIAS_GELU, EPI_RES_GATE, EPI_RES_SCALE, EPI_F32 = 0, 1, 2, 3, 4
+EPI_BIAS, EPI_BIAS_GELU, EPI_RES_GATE, EPI_RES_SCALE, EPI_F32, EPI_QKV_ROPE = 0, 1, 2, 3, 4, 5
 
 i64, i32, f32, vp = C.c_int64, C.c_int32, C.c_float, C.c_void_p
 
@@ -37,6 +37,9 @@ class GemmDesc(C.Structure):
         ("r_gstride", i64), ("gate_gstride", i64),
         ("workspace", vp), ("workspace_bytes", i64),
         ("gelu_from_n", i64), ("c_shift_from_n", i64), ("c_shift", i64),
+        ("qk_wq", vp), ("qk_wk", vp), ("rope_cs", vp),
+        ("rope_rpb", i64), ("rope_pos0", i64), ("qk_until_n", i64),
+        ("qk_eps", f32), ("_pad2", i32),
     ]
 
 

@@ -10,6 +10,7 @@ identical host orchestration in exact arithmetic. Mixed dtypes in one call are a
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional
 
 import torch
@@ -107,6 +108,26 @@ class RowMap:
 
 IDENT = RowMap()
 
+
+class QkRope:
+    """Operands of the UG_EPI_QKV_ROPE epilogue: RMSNorm weights of the q / k heads [128], the (cos, sin) pair table [positions, 64, 2]
+    fp32, and the position of output row m = pos0 + m % rows_per_batch. Columns [0, until_n) of the projection are q | k heads."""
+
+    __slots__ = ("wq", "wk", "cs", "rpb", "pos0", "until_n", "eps")
+
+    def __init__(self, wq, wk, cs, rows_per_batch: int, pos0: int, until_n: int, eps: float = 1e-6):
+        self.wq, self.wk, self.cs, self.rpb, self.pos0, self.until_n, self.eps = wq, wk, cs, rows_per_batch, pos0, until_n, eps
+
+
+def qk_rope_fusable(M: int, N: int, until_n: int, dh: int, dtype: torch.dtype) -> bool:
+    """Whether ug_gemm_bf16 can take q/k RMSNorm + RoPE in its epilogue for this projection: bf16, heads of 128, whole 256^2 tiles, and
+    at least one full round of them (below that the dispatcher prefers the 128^2 kernel, which has no such epilogue).
+    UG_GEMM_FUSE_QKROPE=0 keeps the stand-alone ug_qk_rmsnorm_rope pass (A/B measurements)."""
+    if os.environ.get("UG_GEMM_FUSE_QKROPE", "1") == "0":
+        return False
+    return (dtype == torch.bfloat16 and dh == 128 and M % 256 == 0 and N % 256 == 0 and until_n % 256 == 0 and (M // 256) * (N // 256) >= 256)
+
+
 _gemm_ws: dict = {}
 
 
@@ -127,10 +148,16 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: to
          r_map: RowMap = IDENT, gate: Optional[torch.Tensor] = None, gate_ld: int = 0, rows_per_sample: int = 0,
          alpha: float = 1.0, groups: int = 1, a_gstride: int = 0, w_gstride: int = 0, bias_gstride: int = 0,
          c_gstride: int = 0, r_gstride: int = 0, gate_gstride: int = 0, lora_t: Optional[torch.Tensor] = None,
-         lora_b: Optional[torch.Tensor] = None, gelu_from_n: int = 0, c_shift_from_n: int = 0, c_shift: int = 0) -> torch.Tensor:
+         lora_b: Optional[torch.Tensor] = None, gelu_from_n: int = 0, c_shift_from_n: int = 0, c_shift: int = 0,
+         qk_rope: Optional[QkRope] = None) -> torch.Tensor:
     """out[m, :N] = epilogue(a[m, :K] @ w[:N, :K]^T + bias). `a`/`out`/`residual` are base tensors whose data_ptr is row 0
-    (slices of a bigger buffer are fine); leading dims default to the tensors' row strides."""
+    (slices of a bigger buffer are fine); leading dims default to the tensors' row strides. `qk_rope` selects UG_EPI_QKV_ROPE
+    (with gelu_from_n > 0 the columns from there on still get GELU)."""
     dt = _act(a, "a")
+    if qk_rope is not None:
+        if dt != torch.bfloat16:
+            raise ValueError("the fused q/k RMSNorm + RoPE epilogue is bf16 only")
+        epilogue = L.EPI_QKV_ROPE
     _chk(w, "w", dt)
     _chk(out, "out", torch.float32 if epilogue == L.EPI_F32 else dt)
     if bias is not None:
@@ -152,6 +179,15 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: to
     d.groups, d.a_gstride, d.w_gstride, d.bias_gstride, d.c_gstride = groups, a_gstride, w_gstride, bias_gstride, c_gstride
     d.r_gstride, d.gate_gstride = r_gstride, gate_gstride
     d.gelu_from_n, d.c_shift_from_n, d.c_shift = gelu_from_n, c_shift_from_n, c_shift
+    if qk_rope is not None:
+        q = qk_rope
+        _chk(q.wq, "qk_rope.wq", dt); _chk(q.wk, "qk_rope.wk", dt); _chk(q.cs, "qk_rope.cs", torch.float32)
+        if q.wq.numel() != 128 or q.wk.numel() != 128 or q.cs.dim() != 3 or tuple(q.cs.shape[1:]) != (64, 2) or not q.cs.is_contiguous():
+            raise ValueError("qk_rope: weights must be [128], the pair table [positions, 64, 2] contiguous")
+        if q.cs.shape[0] < q.pos0 + (q.rpb if q.rpb else M):
+            raise ValueError(f"qk_rope: the pair table has {q.cs.shape[0]} positions, rows reach {q.pos0 + (q.rpb if q.rpb else M)}")
+        d.qk_wq, d.qk_wk, d.rope_cs = q.wq.data_ptr(), q.wk.data_ptr(), q.cs.data_ptr()
+        d.rope_rpb, d.rope_pos0, d.qk_until_n, d.qk_eps = q.rpb, q.pos0, q.until_n, q.eps
     stream = _stream()
     ws = _gemm_workspace(a.device, stream)
     d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
