@@ -11,9 +11,11 @@ dev = torch.device("cuda:0")
 dh = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 H = 24
 D = H * dh
-VARIANTS = [dict(UG_ATTN_PRIO="1", UG_ATTN_WIDE="0"), dict(UG_ATTN_PRIO="0", UG_ATTN_WIDE="0"), dict(UG_ATTN_PRIO="2", UG_ATTN_WIDE="0"),
-            dict(UG_ATTN_PRIO="1", UG_ATTN_WIDE="1"), dict(UG_ATTN_PRIO="0", UG_ATTN_WIDE="1"), dict(UG_ATTN_PRIO="2", UG_ATTN_WIDE="1")]
-SHAPES = [(4, 4608, 4608), (4, 4096, 4608), (4, 8192, 8704)] if dh == 128 else [(16, 4096, 4429), (16, 4096, 4096)]
+VARIANTS = [dict(UG_ATTN_PRIO="1", UG_ATTN_WIDE="0", UG_ATTN_DMA="0"), dict(UG_ATTN_PRIO="0", UG_ATTN_WIDE="0", UG_ATTN_DMA="0"),
+            dict(UG_ATTN_PRIO="0", UG_ATTN_WIDE="1", UG_ATTN_DMA="0"), dict(UG_ATTN_PRIO="0", UG_ATTN_WIDE="1", UG_ATTN_DMA="1")]
+if os.environ.get("ATTN_AB_VARIANTS"):        # e.g. "0,1,0;0,1,1" = prio,wide,dma per variant
+    VARIANTS = [dict(zip(("UG_ATTN_PRIO", "UG_ATTN_WIDE", "UG_ATTN_DMA"), v.split(","))) for v in os.environ["ATTN_AB_VARIANTS"].split(";")]
+SHAPES = [(4, 4608, 4608), (4, 4096, 4608), (4, 8192, 8704), (2, 1000, 1003)] if dh == 128 else [(16, 4096, 4429), (16, 4096, 4096)]
 g = torch.Generator(device=dev).manual_seed(0)
 for B, Lq, Lkv in SHAPES:
     qkv = torch.randn(B, Lkv, 3 * D, generator=g, device=dev).to(torch.bfloat16)
@@ -41,4 +43,4 @@ for B, Lq, Lkv in SHAPES:
     fl = 4.0 * B * H * Lq * Lkv * dh
     for i, v in enumerate(VARIANTS):
         t = sorted(times[i])
-        print(f"dh{dh} B{B} {Lq}x{Lkv} prio={v['UG_ATTN_PRIO']} wide={v['UG_ATTN_WIDE']}: median {fl / t[len(t) // 2] / 1e9:7.1f}  best {fl / t[0] / 1e9:7.1f} TFLOP/s", flush=True)
+        print(f"dh{dh} B{B} {Lq}x{Lkv} prio={v['UG_ATTN_PRIO']} wide={v['UG_ATTN_WIDE']} dma={v['UG_ATTN_DMA']}: median {fl / t[len(t) // 2] / 1e9:7.1f}  best {fl / t[0] / 1e9:7.1f} TFLOP/s", flush=True)

@@ -21,6 +21,23 @@ constexpr int KVB = 64;      // keys per tile
 constexpr bool UG_STAGGER_Q_IN_LDS = false;   // stagger variant: Q fragments from LDS (32 fewer VGPRs) or registers (a third less LDS read traffic in QK^T)
 
 typedef __attribute__((address_space(3))) bf16x4* lds_b64_ptr;
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+// LDS-DMA as inline asm: hipcc's waitcnt pass then does not know DMAs are in flight (with the builtin it put `s_waitcnt vmcnt(0)` ahead of
+// the first ds_read behind every barrier, i.e. one segment after the issue instead of two); the kernel states the one wait itself.
+// M0 = LDS byte address of the wave's 1 KiB run (lane l lands at + 16 l); one wait state between the SALU write of M0 and the DMA.
+__device__ __forceinline__ unsigned lds_addr(const unsigned char* l) { return (unsigned)(size_t)(lptr_t)l; }
+__device__ __forceinline__ const void* uniform_ptr(const void* p) {      // pin a wave-uniform pointer into an SGPR pair
+    const unsigned long long a = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return (const void*)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ void glds16_off(const void* base /* uniform_ptr() */, unsigned off_bytes, unsigned lds) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off_bytes), "s"(base), "s"(lds) : "memory");
+}
+__device__ __forceinline__ void glds16_ptr(const void* g, unsigned lds) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds) : "memory");
+}
 
 // Row swizzle of the K/V tile images. f(row) is XORed into the 16-byte chunk index.
 //   DH = 128 (256-byte rows): f = ((row & 3) << 2) | ((row >> 2) & 3)          (cdna guide T10, image (b))
@@ -66,9 +83,12 @@ __device__ __forceinline__ float ug_max_halves(float x) {
 // the VALU, together (the lock-step loop, STAGGER = false, kept for A/B: both phases then serialise and a tile costs the sum).
 // Two barriers per tile; every thread fetches its share of K(t+2), V(t+1) at the start of an even segment and publishes it to LDS at
 // the end of the following odd one, into buffers nobody reads in those two segments.
-template <int DH, int NW, bool STAGGER, int PRIO = 1, bool WIDE = false>   // head dim 128 | 64; waves per workgroup: 8 (256 query rows, 1 / CU) or 4 (128 rows, 2 / CU)
+template <int DH, int NW, bool STAGGER, int PRIO = 1, bool WIDE = false, bool DMA = false>   // head dim 128 | 64; waves per workgroup: 8 (256 query rows, 1 / CU) or 4 (128 rows, 2 / CU)
 // PRIO (stagger only): 0 = no priority games; 1 = s_setprio 1 around the matrix stream of every X segment; 2 = ONE static s_setprio 1 for
 // the younger wave group (waves 4-7) before the loop (cdna guide T5, static form). WIDE: 16-byte epilogue stores (T21).
+// DMA (stagger only): K / V tiles go HBM -> LDS with global_load_lds_dwordx4 (no staging registers, no ds_write): the swizzled image is
+// produced on the SOURCE side (lane l of an instruction lands at byte 16 l of a 1 KiB run = 4 rows at dh 128, so it fetches chunk
+// (l % 16) ^ f(row) of its row), and group B (waves 4-7) issues all of it at the start of its softmax segment, two segments ahead of use.
 __global__ __launch_bounds__(64 * NW, 2) void flash_attn_kernel(
     const bf16_t* __restrict__ q, int64_t q_rs, int64_t q_bs, const bf16_t* __restrict__ k, int64_t k_rs, int64_t k_bs,
     const bf16_t* __restrict__ v, int64_t v_rs, int64_t v_bs, bf16_t* __restrict__ o, int64_t o_rs, int64_t o_bs,
@@ -265,6 +285,8 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn_kernel(
             m_run = m_new;
         }
         const float mc = m_run * c;
+        // (Measured and dropped, same box: the scale / shift and the row sums two elements per instruction, v_pk_fma_f32 / v_pk_add_f32 -
+        // 5 % SLOWER at dh 128 (1086 vs 1146, 1118 vs 1179 TFLOP/s), +1 % at dh 64: the packed forms buy no issue cycles here.)
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             float p[16];
@@ -438,19 +460,59 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn_kernel(
             }
         };
         const bool groupA = __builtin_amdgcn_readfirstlane(wave) < 4;
+        // LDS-DMA staging: a tile image is NI runs of 1 KiB (RPI rows each); wave wb of group B owns runs wb * NIW .. + NIW - 1
+        constexpr int RPI = 1024 / RB, NI = TILE / 1024, NIW = NI / 4;
+        const int wb = __builtin_amdgcn_readfirstlane(wave) & 3;
+        unsigned dko[NIW], dvo[NIW];
+#pragma unroll
+        for (int u = 0; u < NIW; ++u) {
+            const int row = (wb * NIW + u) * RPI + lane / NCH;
+            const int ch = (lane % NCH) ^ row_swz<DH>(row);
+            dko[u] = (unsigned)(row * (int)k_rs + ch * 8) * 2u;        // bytes
+            dvo[u] = (unsigned)(row * (int)v_rs + ch * 8) * 2u;
+        }
+        auto dma_tile = [&](const bf16_t* base, int64_t rs, const unsigned (&off)[NIW], int tile, unsigned dst) {
+            if (tile * KVB + KVB <= Lkv) {             // whole tile: wave-uniform base (SGPR pair) + per-lane 32-bit byte offset
+                const void* tb = uniform_ptr(base + (int64_t)tile * KVB * rs);
+#pragma unroll
+                for (int u = 0; u < NIW; ++u) glds16_off(tb, off[u], dst + u * 1024);
+            } else {                                   // ragged last tile: rows past the end re-read the last key (masked in S^T)
+                int lane_r = lane;
+                asm volatile("" : "+v"(lane_r));      // row / chunk re-derived here, not kept live through the loop
+#pragma unroll
+                for (int u = 0; u < NIW; ++u) {
+                    const int row = (wb * NIW + u) * RPI + lane_r / NCH;
+                    const int ch = (lane_r % NCH) ^ row_swz<DH>(row);
+                    int key = tile * KVB + row; if (key > Lkv - 1) key = Lkv - 1;
+                    glds16_ptr(base + (int64_t)key * rs + ch * 8, dst + u * 1024);
+                }
+            }
+        };
+        auto dma_fetch = [&](int kt, int vt) {         // tiles past the end are simply not fetched
+            const unsigned l0 = __builtin_amdgcn_readfirstlane(lds_addr(smem)) + wb * NIW * 1024;
+            if (kt < ntiles) dma_tile(Kb, k_rs, dko, kt, l0 + (kt & 1) * 2 * TILE);
+            if (vt < ntiles) dma_tile(Vb, v_rs, dvo, vt, l0 + (vt & 1) * 2 * TILE + TILE);
+        };
+        auto dma_wait = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
         if constexpr (PRIO == 2) { if (!groupA) __builtin_amdgcn_s_setprio(1); }
-        fetch(0, ntiles);                              // K(0) only
-        publish(0, ntiles);
-        seg_barrier();
-        fetch(1, 0);                                   // segment 0 (even): K(1), V(0) in flight
+        if constexpr (DMA) {
+            if (!groupA) { dma_fetch(0, ntiles); dma_wait(); }     // K(0) only
+            seg_barrier();
+            if (!groupA) dma_fetch(1, 0);
+        } else {
+            fetch(0, ntiles);                          // K(0) only
+            publish(0, ntiles);
+            seg_barrier();
+            fetch(1, 0);                               // segment 0 (even): K(1), V(0) in flight
+        }
         if (!groupA) seg_barrier();                    // B idles through segment 0
         do_QK(0, std::integral_constant<int, 0>{});    // A: segment 0 | B: segment 1
-        if (!groupA) publish(1, 0);                    // end of segment 1 (B)
+        if (!groupA) { if constexpr (DMA) dma_wait(); else publish(1, 0); }    // end of segment 1 (B)
         seg_barrier();
         // one tile = Y(t) | X(t); buffer parity is a compile-time constant (two tiles per trip)
         auto tile = [&](int t, auto cur_c) {
             // Y(t): A in odd segment 2t+1 (publishes K(t+1), V(t) at its end) | B in even segment 2t+2 (fetches K(t+2), V(t+1) at its start)
-            if (!groupA) fetch(t + 2, t + 1);
+            if (!groupA) { if constexpr (DMA) dma_fetch(t + 2, t + 1); else fetch(t + 2, t + 1); }
             do_SM();
             // P^T is "used" here: hipcc otherwise sinks the (pure) scale / exp2 / pack chain across the barrier to its first use, the
             // P.V MFMAs - i.e. out of this VALU-only segment into the matrix-only one, which then ran at ~60 cycles per MFMA
@@ -459,12 +521,12 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn_kernel(
             asm volatile("" : "+v"(l_run), "+v"(m_run));
             // group A publishes K(t+1), V(t) and at once re-fills the staging registers with K(t+2), V(t+1): its VALU segment has slack
             // (the partner's matrix segment is longer), whereas a fetch at the head of its own X(t) delayed the first MFMA
-            if (groupA) { publish(t + 1, t); fetch(t + 2, t + 1); }
+            if constexpr (!DMA) { if (groupA) { publish(t + 1, t); fetch(t + 2, t + 1); } }
             seg_barrier();
             // X(t) = P.V(t) then K.Q^T(t+1): A in even segment 2t+2 | B in odd segment 2t+3 (publish). (Measured and dropped: group B
             // reading its first V^T fragments ahead of the barrier, inside its softmax segment: -4 %, -10 % with two k-steps.)
             do_X(t, cur_c, t + 1 < ntiles);
-            if (!groupA) publish(t + 2, t + 1);
+            if (!groupA) { if constexpr (DMA) dma_wait(); else publish(t + 2, t + 1); }
             seg_barrier();
         };
         for (int t = 0; t < ntiles; t += 2) {
@@ -920,9 +982,10 @@ extern "C" int ug_flash_attn_fwd(const void* q, int64_t q_row_stride, int64_t q_
     // Interleaved A/B, round 2 (tools/attn_ab.py, same process): prio 0 + wide stores is the fastest form everywhere - dh 128: 1137 / 1147 / 1178
     // vs 1124 / 1133 / 1172 TFLOP/s for the round-1 default (prio 1, narrow) at 4608^2 / 4096x4608 / 8192x8704; dh 64: 880-885 vs 856-871; the
     // static young-half priority (2) loses 1-2 % at dh 128.
-    const int prio = ug_env_int("UG_ATTN_PRIO", 0), wide = ug_env_int("UG_ATTN_WIDE", 1);
+    const int prio = ug_env_int("UG_ATTN_PRIO", 0), wide = ug_env_int("UG_ATTN_WIDE", 1), dma = ug_env_int("UG_ATTN_DMA", 1);
 #define UG_ATTN_STG(DHV)                                                                          \
     do {                                                                                          \
+        if (dma) { UG_ATTN_LAUNCH(DHV, 8, true, 0, true, true); break; }                          \
         if (wide) { if (prio == 0) UG_ATTN_LAUNCH(DHV, 8, true, 0, true); else if (prio == 2) UG_ATTN_LAUNCH(DHV, 8, true, 2, true); else UG_ATTN_LAUNCH(DHV, 8, true, 1, true); } \
         else { if (prio == 0) UG_ATTN_LAUNCH(DHV, 8, true, 0, false); else if (prio == 2) UG_ATTN_LAUNCH(DHV, 8, true, 2, false); else UG_ATTN_LAUNCH(DHV, 8, true, 1, false); } \
     } while (0)
