@@ -298,6 +298,53 @@ int ug_unpack_latents_f32(const void* packed, void* latents, int64_t B, int64_t 
  * scratch: blocks * 256 floats (device). *flops_out_host (HOST pointer, may be NULL) receives the FLOPs of the launch. */
 int ug_probe_mfma_bf16(int32_t shape, int64_t blocks, int64_t iters, void* scratch, double* flops_out_host, ug_stream_t stream);
 
+/* ---- Backward pass of the control-module training step (reference train.py:622-662 `accelerator.backward(loss)` over the same
+ * forward). The matrix work of the backward is ug_gemm_bf16 again (dX = dY W through a transposed copy of W, dW = dY^T X through transposed copies
+ * of dY and X, the attention backward as grouped GEMMs per sample); these entry points are what sits between those GEMMs. Each replaces the
+ * autograd formula of the torch op named; each has an `_f32` twin like the forward entry points. ---- */
+/* dst[b][c][r] = src[b][r][c] for r < rows, c < cols; dst[b][c][rows .. rows_pad) = 0. (Tensor.t().contiguous() of an operand) */
+int ug_transpose(const void* src, int64_t ld_src, int64_t src_bstride, void* dst, int64_t ld_dst, int64_t dst_bstride, int64_t batch, int64_t rows,
+                 int64_t cols, int64_t rows_pad, ug_stream_t stream);
+/* out[g][c] = alpha * sum over the rows r of group g (rows_per_group consecutive rows) of a[r][c] * (b ? b[r][c] : 1), fp32 accumulation.
+ * (grad of a bias / a per-sample gate, shift, scale: `.sum(dim)` in the backward of a broadcast) */
+int ug_colsum(const void* a, int64_t lda, const void* b, int64_t ldb, void* out, int64_t ldo, int64_t rows, int64_t cols, int64_t rows_per_group,
+              float alpha, ug_stream_t stream);
+/* y = gelu_tanh(x); dx = dy * gelu_tanh'(x)   (F.gelu(approximate="tanh") of FeedForward net.0 / proj_mlp and its backward) */
+int ug_gelu_tanh(const void* x, void* y, int64_t n, ug_stream_t stream);
+int ug_gelu_tanh_bwd(const void* x, const void* dy, void* dx, int64_t n, ug_stream_t stream);
+/* backward of ug_adaln_modulate (LayerNorm(x) * (1 + scale) + shift): dx, and dyx = dy * xhat whose per-sample column sum is d scale (that of dy
+ * is d shift). scale: [samples][mod_ld] as in the forward. */
+int ug_adaln_modulate_bwd(const void* x, int64_t ldx, const void* dy, int64_t lddy, const void* scale, int64_t mod_ld, int64_t rows_per_sample,
+                          void* dx, int64_t lddx, void* dyx, int64_t lddyx, int64_t rows, int64_t D, float eps, ug_stream_t stream);
+/* backward of ug_qk_rmsnorm_rope for ONE of q / k: x = the projection's output (pre-norm) [rows][heads * dh] at ldx, dy = gradient of the
+ * normalised + rotated heads; dx likewise; dwx [rows * heads][dh] = d(un) * xhat whose column sum is d weight (w NULL: no RMSNorm; cos NULL: no RoPE).
+ * Row r sits at position pos_offset + r % rows_per_batch; cos / sin tables [positions][dh] fp32 as in the forward. */
+int ug_qk_rmsnorm_rope_bwd(const void* x, int64_t ldx, const void* dy, int64_t lddy, void* dx, int64_t lddx, void* dwx, const void* w,
+                           const float* cos_tab, const float* sin_tab, int64_t rows, int64_t rows_per_batch, int64_t pos_offset, int32_t heads,
+                           int32_t dh, float eps, ug_stream_t stream);
+/* attention backward between its GEMMs (F.scaled_dot_product_attention, src/UniGenUtils.py:601): lse[r] = logsumexp(scale * S[r][:]);
+ * P = exp(scale * S - lse); delta[g][r] = sum_c dO[r][g*cols + c] * O[r][g*cols + c]; dS = scale * P * (dP - delta). S, dP fp32. */
+int ug_row_lse(const float* S, int64_t ld, float* lse, int64_t rows, int64_t cols, float scale, ug_stream_t stream);
+int ug_attn_prob(const float* S, int64_t ld_s, const float* lse, void* P, int64_t ld_p, int64_t rows, int64_t cols, float scale, ug_stream_t stream);
+int ug_attn_dscore(const void* P, int64_t ld_p, const float* dP, int64_t ld_dp, const float* delta, void* dS, int64_t ld_ds, int64_t rows, int64_t cols,
+                   float scale, ug_stream_t stream);
+int ug_rowdot(const void* a, int64_t lda, const void* b, int64_t ldb, float* out, int64_t rows, int64_t groups, int64_t cols, ug_stream_t stream);
+int ug_transpose_f32(const void* src, int64_t ld_src, int64_t src_bstride, void* dst, int64_t ld_dst, int64_t dst_bstride, int64_t batch, int64_t rows,
+                     int64_t cols, int64_t rows_pad, ug_stream_t stream);
+int ug_colsum_f32(const void* a, int64_t lda, const void* b, int64_t ldb, void* out, int64_t ldo, int64_t rows, int64_t cols, int64_t rows_per_group,
+                  float alpha, ug_stream_t stream);
+int ug_gelu_tanh_f32(const void* x, void* y, int64_t n, ug_stream_t stream);
+int ug_gelu_tanh_bwd_f32(const void* x, const void* dy, void* dx, int64_t n, ug_stream_t stream);
+int ug_adaln_modulate_bwd_f32(const void* x, int64_t ldx, const void* dy, int64_t lddy, const void* scale, int64_t mod_ld, int64_t rows_per_sample,
+                              void* dx, int64_t lddx, void* dyx, int64_t lddyx, int64_t rows, int64_t D, float eps, ug_stream_t stream);
+int ug_qk_rmsnorm_rope_bwd_f32(const void* x, int64_t ldx, const void* dy, int64_t lddy, void* dx, int64_t lddx, void* dwx, const void* w,
+                               const float* cos_tab, const float* sin_tab, int64_t rows, int64_t rows_per_batch, int64_t pos_offset, int32_t heads,
+                               int32_t dh, float eps, ug_stream_t stream);
+int ug_attn_prob_f32(const float* S, int64_t ld_s, const float* lse, void* P, int64_t ld_p, int64_t rows, int64_t cols, float scale, ug_stream_t stream);
+int ug_attn_dscore_f32(const void* P, int64_t ld_p, const float* dP, int64_t ld_dp, const float* delta, void* dS, int64_t ld_ds, int64_t rows,
+                       int64_t cols, float scale, ug_stream_t stream);
+int ug_rowdot_f32(const void* a, int64_t lda, const void* b, int64_t ldb, float* out, int64_t rows, int64_t groups, int64_t cols, ug_stream_t stream);
+
 int ug_version(void);
 const char* ug_last_error(void);
 

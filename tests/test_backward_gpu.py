@@ -1,0 +1,116 @@
+"""Backward pass of the hot ops: every autograd.Function of unigen_amd/autograd.py against torch autograd of the
+oracle's formulas on the CPU. fp32 tensors run the `_f32` verification twins (tolerance 1e-4: same math, different summation order); bf16 tensors
+run the product kernels and must be as close to the fp32 gradients as torch's own bf16 autograd is (ratio <= 1.5, floor 2e-3)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import unigen_ref as R
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+def rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def run_case(gpu, hip_fn, ref_fn, inputs, grad_mask=None, name="", keep_f32=()):
+    """inputs: list of fp32 CPU tensors (None allowed). Returns nothing; asserts forward + gradients in both precisions."""
+    g = torch.Generator().manual_seed(123)
+    grad_mask = grad_mask or [t is not None and t.is_floating_point() for t in inputs]
+
+    def leafs(dtype, device):
+        out = []
+        for i, (t, m) in enumerate(zip(inputs, grad_mask)):
+            if t is None or not t.is_floating_point() or i in keep_f32:
+                out.append(t if t is None else t.detach().clone().to(device))
+            elif not m:
+                out.append(t.detach().clone().to(dtype).to(device))
+            else:
+                out.append(t.detach().clone().to(dtype).to(device).requires_grad_(True))
+        return out
+
+    truth_in = leafs(torch.float32, "cpu")
+    y32 = ref_fn(*truth_in)
+    dy = torch.randn(y32.shape, generator=g)
+    y32.backward(dy)
+    truth = [t.grad if (t is not None and t.requires_grad) else None for t in truth_in]
+    for dtype, tol in ((torch.float32, 1e-4), (BF, None)):
+        hin = leafs(dtype, gpu)
+        y = hip_fn(*hin)
+        y.backward(dy.to(dtype).to(gpu))
+        if dtype == BF:
+            rin = leafs(BF, "cpu")
+            yr = ref_fn(*rin)
+            yr.backward(dy.to(BF))
+        e_fwd = rel(y, y32)
+        assert e_fwd <= (tol if tol else max(1.5 * rel(yr, y32), 2e-3)), (name, dtype, "forward", e_fwd)
+        for i, (t, tr) in enumerate(zip(hin, truth)):
+            if tr is None:
+                continue
+            e = rel(t.grad, tr)
+            bound = tol if tol else max(1.5 * rel(rin[i].grad, tr), 2e-3)
+            print(f"backward {name} {str(dtype)[6:]} grad[{i}] rel_l2 {e:.3e} (bound {bound:.3e})")
+            assert e <= bound, (name, dtype, i, e, bound)
+
+
+def test_linear_backward(gpu):
+    from unigen_amd import autograd as A
+    g = torch.Generator().manual_seed(1)
+    for (M, K, N) in ((200, 128, 192), (64, 64, 64), (130, 256, 320)):
+        x, w, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * K ** -0.5, torch.randn(N, generator=g) * 0.1
+        run_case(gpu, lambda x, w, b: A.linear(x, w, b), lambda x, w, b: F.linear(x, w, b), [x, w, b], name=f"linear{M}x{K}x{N}")
+    # frozen weight: only dX
+    x, w = torch.randn(100, 128, generator=g), torch.randn(64, 128, generator=g) * 0.1
+    run_case(gpu, lambda x, w, b: A.linear(x, w, None), lambda x, w, b: F.linear(x, w), [x, w, None], grad_mask=[True, False, False], name="linear_frozen")
+
+
+def test_gelu_and_adaln_backward(gpu):
+    from unigen_amd import autograd as A
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(3, 70, 192, generator=g) * 2
+    run_case(gpu, lambda x: A.GeluTanh.apply(x), lambda x: F.gelu(x, approximate="tanh"), [x], name="gelu")
+    sh, sc = torch.randn(3, 192, generator=g) * 0.3, torch.randn(3, 192, generator=g) * 0.3
+    ref = lambda x, sh, sc: R.layer_norm(x) * (1 + sc[:, None]) + sh[:, None]
+    run_case(gpu, lambda x, sh, sc: A.adaln_modulate(x, sh, sc), ref, [x, sh, sc], name="adaln")
+
+
+def test_qk_norm_rope_backward(gpu):
+    from unigen_amd import autograd as A
+    g = torch.Generator().manual_seed(3)
+    for dh, H in ((128, 2), (64, 3)):
+        B, Ls, off = 2, 40, 24
+        x = torch.randn(B, Ls, H * dh, generator=g)
+        w = 1 + 0.2 * torch.randn(dh, generator=g)
+        ang = torch.rand(off + Ls, dh // 2, generator=g) * 6.28
+        cos, sin = ang.cos().repeat_interleave(2, 1).contiguous(), ang.sin().repeat_interleave(2, 1).contiguous()
+
+        def ref(x, w, cos, sin):
+            xh = R._heads(x, H)                                   # [B, H, L, dh]
+            xh = R.rms_norm(xh, w)
+            xh = R.apply_rotary_emb(xh, cos[off:off + Ls], sin[off:off + Ls])
+            return xh.transpose(1, 2).reshape(B, Ls, H * dh)
+
+        hip = lambda x, w, cos, sin: A.qk_norm_rope(x, w, (cos, sin), H, pos_offset=off)
+        run_case(gpu, hip, ref, [x, w, cos, sin], grad_mask=[True, True, False, False], name=f"qk_norm_rope_dh{dh}", keep_f32=(2, 3))
+        run_case(gpu, lambda x, w: A.qk_norm_rope(x, w, None, H), lambda x, w: R.rms_norm(R._heads(x, H), w).transpose(1, 2).reshape(B, Ls, H * dh),
+                 [x, w], name=f"qk_norm_only_dh{dh}")
+
+
+def test_attention_backward(gpu):
+    from unigen_amd import autograd as A
+    g = torch.Generator().manual_seed(4)
+    for dh, H, Lq, Lkv in ((128, 2, 128, 192), (64, 3, 64, 64)):
+        B = 2
+        qkv = torch.randn(B, Lkv, 3 * H * dh, generator=g)
+        D = H * dh
+
+        def ref(qkv):
+            q, k, v = qkv[:, Lkv - Lq:, :D], qkv[:, :, D:2 * D], qkv[:, :, 2 * D:]
+            o = R._sdpa(R._heads(q, H), R._heads(k, H), R._heads(v, H))
+            return o.transpose(1, 2).reshape(B, Lq, D)
+
+        hip = lambda qkv: A.attention(qkv[:, Lkv - Lq:, :D], qkv[:, :, D:2 * D], qkv[:, :, 2 * D:], H)
+        run_case(gpu, hip, ref, [qkv], name=f"attention_dh{dh}_{Lq}x{Lkv}")

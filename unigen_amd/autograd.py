@@ -1,0 +1,199 @@
+"""torch.autograd.Function wrappers of the HIP hot ops: the second caller of the forward (reference train.py:622-662:
+`accelerator.backward(loss)` through the same transformer). torch.autograd is the tape (as it is in the reference); every matrix product of the
+backward is ug_gemm_bf16 again - dX = dY W through a transposed copy of W, dW = dY^T X through transposed copies of dY and X, and the attention
+backward as five grouped GEMMs per sample around the elementwise kernels of csrc/backward.hip. fp32 tensors select the `_f32` verification twins,
+as in the forward. There is no CPU path."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import lib as L
+from . import ops
+
+_wt_cache: dict = {}
+
+
+def _pad64(n: int) -> int:
+    return (n + 63) // 64 * 64
+
+
+def _w_transposed(w: torch.Tensor) -> torch.Tensor:
+    """[N, K] -> [K, N] (N must be a multiple of 64: it becomes the contraction length). Frozen weights are transposed once."""
+    if w.requires_grad:
+        return ops.transpose(w.detach())
+    key = (w.data_ptr(), tuple(w.shape), w.dtype, w._version)
+    hit = _wt_cache.get(key)
+    if hit is None:
+        if len(_wt_cache) > 4096:
+            _wt_cache.clear()
+        hit = _wt_cache[key] = ops.transpose(w.detach())
+    return hit
+
+
+class Linear(torch.autograd.Function):
+    """F.linear on [M, K] rows: ug_gemm_bf16 forward; backward = two more GEMMs and a column sum."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        M, K = x.shape
+        N = w.shape[0]
+        out = torch.empty(M, N, device=x.device, dtype=x.dtype)
+        ops.gemm(x, w, b, out, M=M)
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        M, K = x.shape
+        N = w.shape[0]
+        dx = dw = db = None
+        if N % 64 != 0:
+            raise L.UniGenHipError(f"Linear backward: out_features={N} must be a multiple of 64 (it is the contraction length of dX = dY W)")
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(M, K, device=x.device, dtype=x.dtype)
+            ops.gemm(dy, _w_transposed(w), None, dx, M=M)
+        if ctx.needs_input_grad[1]:
+            Mp = _pad64(M)
+            dyt, xt = ops.transpose(dy, Mp), ops.transpose(x, Mp)          # [N, Mp], [K, Mp]
+            dw = torch.empty(N, K, device=x.device, dtype=x.dtype)
+            ops.gemm(dyt, xt, None, dw, M=N)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = ops.colsum(dy).view(N)
+        return dx, dw, db
+
+
+def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor]) -> torch.Tensor:
+    lead = x.shape[:-1]
+    return Linear.apply(x.reshape(-1, x.shape[-1]).contiguous(), w, b).view(*lead, w.shape[0])
+
+
+class GeluTanh(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return ops.gelu_tanh(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return ops.gelu_tanh_bwd(x, dy)
+
+
+class AdaLNModulate(torch.autograd.Function):
+    """LayerNorm(x; eps, no affine) * (1 + scale[:, None]) + shift[:, None]: x [B, L, D], shift / scale [B, D]."""
+
+    @staticmethod
+    def forward(ctx, x, shift, scale, eps):
+        B, Ls, D = x.shape
+        x2 = x.reshape(B * Ls, D).contiguous()
+        shift, scale = shift.contiguous(), scale.contiguous()
+        out = torch.empty(B * Ls, D, device=x.device, dtype=x.dtype)
+        ops.adaln_modulate(x2, shift, scale, out, rows=B * Ls, D=D, rows_per_sample=Ls, mod_ld=D, eps=eps)
+        ctx.save_for_backward(x2, scale)
+        ctx.geom, ctx.eps = (B, Ls, D), eps
+        return out.view(B, Ls, D)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, scale = ctx.saved_tensors
+        B, Ls, D = ctx.geom
+        dy2 = dy.reshape(B * Ls, D).contiguous()
+        dx, dyx = ops.adaln_modulate_bwd(x2, dy2, scale, rows_per_sample=Ls, eps=ctx.eps)
+        dshift = ops.colsum(dy2, rows_per_group=Ls)
+        dscale = ops.colsum(dyx, rows_per_group=Ls)
+        return dx.view(B, Ls, D), dshift, dscale, None
+
+
+def adaln_modulate(x, shift, scale, eps: float = 1e-6):
+    return AdaLNModulate.apply(x, shift, scale, eps)
+
+
+class QKNormRope(torch.autograd.Function):
+    """RMSNorm over each head (weight w [dh] or None) followed by apply_rotary_emb (cos / sin [positions, dh] fp32 or None) of one of q / k:
+    x [B, L, H * dh]; row l of a sample sits at position pos_offset + l."""
+
+    @staticmethod
+    def forward(ctx, x, w, cos, sin, heads, pos_offset, eps):
+        B, Ls, HD = x.shape
+        dh = HD // heads
+        out = x.reshape(B * Ls, HD).clone()
+        ops.qk_rmsnorm_rope(out, batches=B, rows_per_batch=Ls, ld=HD, q_off=-1, k_off=0, heads=heads, dh=dh, pos_offset=pos_offset, wk_b=w, split=0,
+                            cos=cos, sin=sin, eps=eps)
+        ctx.save_for_backward(x.reshape(B * Ls, HD), w, cos, sin)
+        ctx.geom = (B, Ls, heads, dh, pos_offset, eps)
+        return out.view(B, Ls, HD)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w, cos, sin = ctx.saved_tensors
+        B, Ls, heads, dh, pos_offset, eps = ctx.geom
+        dy2 = dy.reshape(B * Ls, heads * dh).contiguous()
+        dx, dwx = ops.qk_rmsnorm_rope_bwd(x2.contiguous(), dy2, w, cos, sin, rows_per_batch=Ls, pos_offset=pos_offset, heads=heads, dh=dh, eps=eps)
+        dw = ops.colsum(dwx).view(dh) if (w is not None and ctx.needs_input_grad[1]) else None
+        return dx.view(B, Ls, heads * dh), dw, None, None, None, None, None
+
+
+def qk_norm_rope(x, w, rope, heads: int, pos_offset: int = 0, eps: float = 1e-6):
+    cos, sin = rope if rope is not None else (None, None)
+    if w is None and cos is None:
+        return x
+    return QKNormRope.apply(x, w, cos, sin, heads, pos_offset, eps)
+
+
+class FlashAttention(torch.autograd.Function):
+    """F.scaled_dot_product_attention over heads packed as [B, L, H * dh] (any row stride). Forward: ug_flash_attn_fwd. Backward, per sample and
+    for all heads at once (grouped GEMMs): S = Q K^T (fp32) -> lse -> P; dP = dO V^T; dS = scale P (dP - rowsum(dO O));
+    dV = P^T dO, dK = dS^T Q, dQ = dS K. Lq and Lkv must be multiples of 64 (they become contraction lengths)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, heads):
+        B, Lq, HD = q.shape
+        Lkv = k.shape[1]
+        dh = HD // heads
+        o = torch.empty(B, Lq, HD, device=q.device, dtype=q.dtype)
+        ops.flash_attn(q, k, v, o, batches=B, heads=heads, dh=dh, Lq=Lq, Lkv=Lkv, q_strides=(q.stride(1), q.stride(0)), k_strides=(k.stride(1), k.stride(0)),
+                       v_strides=(v.stride(1), v.stride(0)), o_strides=(HD, Lq * HD))
+        ctx.save_for_backward(q, k, v, o)
+        ctx.heads = heads
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, o = ctx.saved_tensors
+        H = ctx.heads
+        B, Lq, HD = q.shape
+        Lkv = k.shape[1]
+        dh = HD // H
+        if Lq % 64 or Lkv % 64:
+            raise L.UniGenHipError(f"attention backward: sequence lengths ({Lq}, {Lkv}) must be multiples of 64")
+        dt, dev = q.dtype, q.device
+        scale = dh ** -0.5
+        do = do.contiguous()
+        dq, dk, dv = torch.empty(B, Lq, HD, device=dev, dtype=dt), torch.empty(B, Lkv, HD, device=dev, dtype=dt), torch.empty(B, Lkv, HD, device=dev, dtype=dt)
+        S, dP = torch.empty(H, Lq, Lkv, device=dev, dtype=torch.float32), torch.empty(H, Lq, Lkv, device=dev, dtype=torch.float32)
+        for b in range(B):
+            qb, kb, vb, ob, dob = q[b], k[b], v[b], o[b], do[b]
+            ops.gemm(qb[:, :dh], kb[:, :dh], None, S, M=Lq, epilogue=L.EPI_F32, groups=H, a_gstride=dh, w_gstride=dh, c_gstride=Lq * Lkv, ldc=Lkv)
+            lse = ops.row_lse(S.view(H * Lq, Lkv), scale)
+            P = ops.attn_prob(S.view(H * Lq, Lkv), lse, scale, dt)
+            ops.gemm(dob[:, :dh], vb[:, :dh], None, dP, M=Lq, epilogue=L.EPI_F32, groups=H, a_gstride=dh, w_gstride=dh, c_gstride=Lq * Lkv, ldc=Lkv)
+            delta = ops.rowdot(dob, ob, H)                                   # [H, Lq]
+            dS = ops.attn_dscore(P, dP.view(H * Lq, Lkv), delta.view(-1), scale)
+            P3, dS3 = P.view(H, Lq, Lkv), dS.view(H, Lq, Lkv)
+            per_head = lambda t, Lr: torch.as_strided(t, (H, Lr, dh), (dh, t.stride(0), 1))
+            PT, dST = ops.transpose(P3), ops.transpose(dS3)                   # [H, Lkv, Lq]
+            dOT, QT, KT = ops.transpose(per_head(dob, Lq)), ops.transpose(per_head(qb, Lq)), ops.transpose(per_head(kb, Lkv))   # [H, dh, L]
+            g = dict(groups=H, c_gstride=dh, ldc=HD)
+            ops.gemm(PT, dOT, None, dv[b], M=Lkv, a_gstride=Lkv * Lq, w_gstride=dh * Lq, **g)
+            ops.gemm(dST, QT, None, dk[b], M=Lkv, a_gstride=Lkv * Lq, w_gstride=dh * Lq, **g)
+            ops.gemm(dS3, KT, None, dq[b], M=Lq, a_gstride=Lq * Lkv, w_gstride=dh * Lkv, **g)
+        return dq, dk, dv, None
+
+
+def attention(q, k, v, heads: int):
+    return FlashAttention.apply(q, k, v, heads)

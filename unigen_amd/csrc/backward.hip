@@ -1,0 +1,339 @@
+// Backward-pass kernels of the control-module training step (reference train.py:622-662 calls
+// accelerator.backward(loss) on the same forward). The matrix work of the backward runs through ug_gemm_bf16 (dX = dY W, dW = dY^T X,
+// and the attention backward as five grouped GEMMs per sample, see unigen_amd/autograd.py); this file holds what sits between those GEMMs:
+//   ug_transpose            batched 2-D transpose with zero padding of the new row length (operand layouts of dgrad / wgrad)
+//   ug_colsum               per-group column sums of a or a (.) b, fp32 accumulation (bias / gate / shift / scale / RMSNorm-weight gradients)
+//   ug_gelu_tanh(_bwd)      GELU(tanh) and its derivative (FeedForward net.0, proj_mlp)
+//   ug_adaln_modulate_bwd   LayerNorm(x) (1 + scale) + shift  ->  dx, and dy (.) xhat for the scale gradient
+//   ug_qk_rmsnorm_rope_bwd  RMSNorm(q|k) . weight, apply_rotary_emb  ->  d(q|k), and du (.) xhat for the weight gradient
+//   ug_row_lse, ug_attn_prob, ug_attn_dscore, ug_rowdot   softmax statistics and the elementwise steps of the attention backward
+// Every kernel is a template over the element type (bf16 product / fp32 verification twin); arithmetic in fp32, outputs rounded once.
+#include "ug_common.h"
+#include <algorithm>
+
+namespace {
+
+// gelu_tanh(x) = x / (1 + exp(-2u)), u = sqrt(2/pi) (x + 0.044715 x^3); same formulation as the GEMM epilogue (gemm_epilogue.h)
+__device__ __forceinline__ float gelu_f(float x) {
+    constexpr float C0 = -2.3022081986f, C1 = C0 * 0.044715f;
+    const float u = x * fmaf(x * x, C1, C0);
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u));
+}
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    // y = x s, s = sigmoid(2u): dy/dx = s + x s (1 - s) 2 du/dx, 2 du/dx = 2 sqrt(2/pi) (1 + 3 * 0.044715 x^2)
+    constexpr float K2 = 1.5957691216f;           // 2 sqrt(2/pi)
+    const float u2 = K2 * x * fmaf(0.044715f * x, x, 1.0f);
+    const float s = 1.0f / (1.0f + __expf(-u2));
+    return s + x * s * (1.0f - s) * K2 * fmaf(3.0f * 0.044715f * x, x, 1.0f);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ src, int64_t ld_src, int64_t src_bstride, T* __restrict__ dst,
+                                                        int64_t ld_dst, int64_t dst_bstride, int rows, int cols, int rows_pad) {
+    __shared__ T tile[64][65];
+    const T* s = src + (int64_t)blockIdx.z * src_bstride;
+    T* d = dst + (int64_t)blockIdx.z * dst_bstride;
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int r = r0 + i, c = c0 + tx;
+        T v; ElemT<T>::st(&v, 0.f);
+        if (r < rows && c < cols) v = s[(int64_t)r * ld_src + c];
+        tile[i][tx] = v;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int c = c0 + i, r = r0 + tx;       // dst row = c, dst column = r
+        if (c < cols && r < rows_pad) d[(int64_t)c * ld_dst + r] = tile[tx][i];
+    }
+}
+
+// out[g][c] = rnd(alpha * sum_{r in group g} a[r][c] * (b ? b[r][c] : 1)); one block = 64 columns of one group, 4 waves split the rows
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ a, int64_t lda, const T* __restrict__ b, int64_t ldb, T* __restrict__ out,
+                                                     int64_t ldo, int64_t rows_per_group, int cols, float alpha) {
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_group;
+    float acc = 0.f;
+    if (c < cols) {
+        for (int64_t r = w; r < rows_per_group; r += 4) {
+            float v = ElemT<T>::ld(a + (r0 + r) * lda + c);
+            if (b) v *= ElemT<T>::ld(b + (r0 + r) * ldb + c);
+            acc += v;
+        }
+    }
+    red[w][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (w == 0 && c < cols) ElemT<T>::st(out + (int64_t)blockIdx.y * ldo + c, alpha * (red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]));
+}
+
+template <typename T>
+__global__ void gelu_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        ElemT<T>::st(y + i, gelu_f(ElemT<T>::ld(x + i)));
+}
+template <typename T>
+__global__ void gelu_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        ElemT<T>::st(dx + i, ElemT<T>::ld(dy + i) * gelu_grad_f(ElemT<T>::ld(x + i)));
+}
+
+// One wave per row. y = xhat (1 + s) + sh, xhat = (x - mu) rstd:
+//   g = dy (1 + s);  dx = rstd (g - mean(g) - xhat mean(g xhat));  dyx = dy xhat  (its per-sample column sum is d scale; that of dy is d shift)
+template <typename T>
+__global__ __launch_bounds__(256) void adaln_bwd_kernel(const T* __restrict__ x, int64_t ldx, const T* __restrict__ dy, int64_t lddy,
+                                                        const T* __restrict__ scale, int64_t mod_ld, int64_t rows_per_sample, T* __restrict__ dx,
+                                                        int64_t lddx, T* __restrict__ dyx, int64_t lddyx, int64_t rows, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const T* xr = x + row * ldx; const T* gr = dy + row * lddy;
+    const T* sc = scale + (row / rows_per_sample) * mod_ld;
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = lane; c < D; c += 64) { const float v = ElemT<T>::ld(xr + c); s1 += v; s2 += v * v; }
+    s1 = wave_sum(s1); s2 = wave_sum(s2);
+    const float mu = s1 / D;
+    const float rstd = rsqrtf(fmaxf(s2 / D - mu * mu, 0.f) + eps);
+    float a = 0.f, bsum = 0.f;
+    for (int c = lane; c < D; c += 64) {
+        const float xh = (ElemT<T>::ld(xr + c) - mu) * rstd;
+        const float g = ElemT<T>::ld(gr + c) * (1.0f + ElemT<T>::ld(sc + c));
+        a += g; bsum += g * xh;
+    }
+    a = wave_sum(a) / D; bsum = wave_sum(bsum) / D;
+    for (int c = lane; c < D; c += 64) {
+        const float xh = (ElemT<T>::ld(xr + c) - mu) * rstd;
+        const float d = ElemT<T>::ld(gr + c);
+        const float g = d * (1.0f + ElemT<T>::ld(sc + c));
+        ElemT<T>::st(dx + row * lddx + c, rstd * (g - a - xh * bsum));
+        ElemT<T>::st(dyx + row * lddyx + c, d * xh);
+    }
+}
+
+// One wave per (row, head) vector of DH elements (DH / 64 per lane... lanes cover pairs): forward was u = x rs, un = u w, y = rope(un).
+//   dun = rope^T(dy);  du = dun w;  dx = rs (du - u mean(du u));  dwx = dun u  (summed over rows and heads: d weight)
+template <typename T>
+__global__ __launch_bounds__(256) void qk_bwd_kernel(const T* __restrict__ x, int64_t ldx, const T* __restrict__ dy, int64_t lddy, T* __restrict__ dx,
+                                                     int64_t lddx, T* __restrict__ dwx /* [vectors][DH] */, const T* __restrict__ w,
+                                                     const float* __restrict__ cos_tab, const float* __restrict__ sin_tab, int64_t rows_per_batch,
+                                                     int64_t pos_offset, int64_t nvec, int heads, int DH, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t vec = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (vec >= nvec) return;
+    const int64_t row = vec / heads; const int h = (int)(vec - row * heads);
+    const int64_t pos = pos_offset + row % rows_per_batch;
+    const T* xr = x + row * ldx + (int64_t)h * DH; const T* gr = dy + row * lddy + (int64_t)h * DH;
+    // this lane: pairs p = lane, lane + 64, ... < DH / 2
+    float ss = 0.f;
+    for (int p = lane; p < DH / 2; p += 64) { const float a = ElemT<T>::ld(xr + 2 * p), b = ElemT<T>::ld(xr + 2 * p + 1); ss += a * a + b * b; }
+    ss = wave_sum(ss);
+    const float rs = w ? rsqrtf(ss / DH + eps) : 1.0f;
+    float dot = 0.f;
+    for (int p = lane; p < DH / 2; p += 64) {
+        float g0 = ElemT<T>::ld(gr + 2 * p), g1 = ElemT<T>::ld(gr + 2 * p + 1);
+        if (cos_tab) {
+            const float c0 = cos_tab[pos * DH + 2 * p], c1 = cos_tab[pos * DH + 2 * p + 1], s0 = sin_tab[pos * DH + 2 * p], s1 = sin_tab[pos * DH + 2 * p + 1];
+            // y0 = a c0 - b s0, y1 = b c1 + a s1  ->  da = g0 c0 + g1 s1, db = g1 c1 - g0 s0
+            const float t0 = g0 * c0 + g1 * s1, t1 = g1 * c1 - g0 * s0;
+            g0 = t0; g1 = t1;
+        }
+        if (w) {
+            const float u0 = ElemT<T>::ld(xr + 2 * p) * rs, u1 = ElemT<T>::ld(xr + 2 * p + 1) * rs;
+            dot += g0 * ElemT<T>::ld(w + 2 * p) * u0 + g1 * ElemT<T>::ld(w + 2 * p + 1) * u1;
+        }
+    }
+    dot = wave_sum(dot) / DH;
+    for (int p = lane; p < DH / 2; p += 64) {
+        float g0 = ElemT<T>::ld(gr + 2 * p), g1 = ElemT<T>::ld(gr + 2 * p + 1);
+        if (cos_tab) {
+            const float c0 = cos_tab[pos * DH + 2 * p], c1 = cos_tab[pos * DH + 2 * p + 1], s0 = sin_tab[pos * DH + 2 * p], s1 = sin_tab[pos * DH + 2 * p + 1];
+            const float t0 = g0 * c0 + g1 * s1, t1 = g1 * c1 - g0 * s0;
+            g0 = t0; g1 = t1;
+        }
+        float o0 = g0, o1 = g1;
+        if (w) {
+            const float u0 = ElemT<T>::ld(xr + 2 * p) * rs, u1 = ElemT<T>::ld(xr + 2 * p + 1) * rs;
+            ElemT<T>::st(dwx + vec * DH + 2 * p, g0 * u0); ElemT<T>::st(dwx + vec * DH + 2 * p + 1, g1 * u1);
+            o0 = rs * (g0 * ElemT<T>::ld(w + 2 * p) - u0 * dot); o1 = rs * (g1 * ElemT<T>::ld(w + 2 * p + 1) - u1 * dot);
+        }
+        ElemT<T>::st(dx + row * lddx + (int64_t)h * DH + 2 * p, o0); ElemT<T>::st(dx + row * lddx + (int64_t)h * DH + 2 * p + 1, o1);
+    }
+}
+
+// lse[r] = log(sum_c exp(scale S[r][c])), natural log; one block per row
+__global__ __launch_bounds__(256) void row_lse_kernel(const float* __restrict__ S, int64_t ld, float* __restrict__ lse, int cols, float scale) {
+    __shared__ float red[256];
+    const float* s = S + (int64_t)blockIdx.x * ld;
+    float mx = -INFINITY;
+    for (int c = threadIdx.x; c < cols; c += 256) mx = fmaxf(mx, s[c] * scale);
+    red[threadIdx.x] = mx; __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]); __syncthreads(); }
+    mx = red[0]; __syncthreads();
+    float sum = 0.f;
+    for (int c = threadIdx.x; c < cols; c += 256) sum += expf(s[c] * scale - mx);
+    red[threadIdx.x] = sum; __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) lse[blockIdx.x] = mx + logf(red[0]);
+}
+// P[r][c] = exp(scale S[r][c] - lse[r])
+template <typename T>
+__global__ void attn_prob_kernel(const float* __restrict__ S, int64_t ld_s, const float* __restrict__ lse, T* __restrict__ P, int64_t ld_p, int64_t rows, int cols, float scale) {
+    const int64_t total = rows * cols;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / cols; const int c = (int)(i - r * cols);
+        ElemT<T>::st(P + r * ld_p + c, expf(S[r * ld_s + c] * scale - lse[r]));
+    }
+}
+// dS[r][c] = scale P[r][c] (dP[r][c] - delta[r])
+template <typename T>
+__global__ void attn_dscore_kernel(const T* __restrict__ P, int64_t ld_p, const float* __restrict__ dP, int64_t ld_dp, const float* __restrict__ delta,
+                                   T* __restrict__ dS, int64_t ld_ds, int64_t rows, int cols, float scale) {
+    const int64_t total = rows * cols;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / cols; const int c = (int)(i - r * cols);
+        ElemT<T>::st(dS + r * ld_ds + c, scale * ElemT<T>::ld(P + r * ld_p + c) * (dP[r * ld_dp + c] - delta[r]));
+    }
+}
+// out[g][r] = sum_c a[r][g * cols + c] b[r][g * cols + c]   (delta = rowsum(dO . O) per head): one wave per (row, group)
+template <typename T>
+__global__ __launch_bounds__(256) void rowdot_kernel(const T* __restrict__ a, int64_t lda, const T* __restrict__ b, int64_t ldb, float* __restrict__ out,
+                                                     int64_t rows, int groups, int cols) {
+    const int lane = threadIdx.x & 63;
+    const int64_t id = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (id >= rows * groups) return;
+    const int64_t r = id / groups; const int g = (int)(id - r * groups);
+    float acc = 0.f;
+    for (int c = lane; c < cols; c += 64) acc += ElemT<T>::ld(a + r * lda + (int64_t)g * cols + c) * ElemT<T>::ld(b + r * ldb + (int64_t)g * cols + c);
+    acc = wave_sum(acc);
+    if (lane == 0) out[(int64_t)g * rows + r] = acc;
+}
+
+unsigned grid1d(int64_t n, int per) { return (unsigned)std::min<int64_t>((n + per - 1) / per, 65535 * 16); }
+
+template <typename T>
+int transpose_impl(const void* src, int64_t ld_src, int64_t src_bstride, void* dst, int64_t ld_dst, int64_t dst_bstride, int64_t batch, int64_t rows,
+                   int64_t cols, int64_t rows_pad, ug_stream_t stream) {
+    if (batch == 0 || rows == 0 || cols == 0) return UG_OK;
+    UG_REQUIRE(src && dst && rows > 0 && cols > 0 && batch > 0 && batch < 65536 && rows_pad >= rows && ld_src >= cols && ld_dst >= rows_pad, UG_ERR_BAD_SHAPE,
+               "ug_transpose: bad arguments");
+    dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((rows_pad + 63) / 64), (unsigned)batch);
+    UG_REQUIRE(grid.y < 65536, UG_ERR_UNSUPPORTED, "ug_transpose: too many rows");
+    hipLaunchKernelGGL(transpose_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)src, ld_src, src_bstride, (T*)dst, ld_dst, dst_bstride,
+                       (int)rows, (int)cols, (int)rows_pad);
+    UG_CHECK_LAUNCH("ug_transpose");
+    return UG_OK;
+}
+template <typename T>
+int colsum_impl(const void* a, int64_t lda, const void* b, int64_t ldb, void* out, int64_t ldo, int64_t rows, int64_t cols, int64_t rows_per_group,
+                float alpha, ug_stream_t stream) {
+    if (rows == 0 || cols == 0) return UG_OK;
+    UG_REQUIRE(a && out && rows > 0 && cols > 0 && rows_per_group > 0 && rows % rows_per_group == 0 && rows / rows_per_group < 65536 && lda >= cols &&
+               ldo >= cols && (!b || ldb >= cols), UG_ERR_BAD_SHAPE, "ug_colsum: bad arguments");
+    dim3 grid((unsigned)((cols + 63) / 64), (unsigned)(rows / rows_per_group));
+    hipLaunchKernelGGL(colsum_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)a, lda, (const T*)b, ldb, (T*)out, ldo, rows_per_group, (int)cols, alpha);
+    UG_CHECK_LAUNCH("ug_colsum");
+    return UG_OK;
+}
+template <typename T>
+int gelu_impl(const void* x, const void* dy, void* out, int64_t n, ug_stream_t stream) {
+    if (n == 0) return UG_OK;
+    UG_REQUIRE(x && out && n > 0, UG_ERR_BAD_SHAPE, "ug_gelu_tanh: bad arguments");
+    if (dy) hipLaunchKernelGGL(gelu_bwd_kernel<T>, dim3(grid1d(n, 256 * 8)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)dy, (T*)out, n);
+    else hipLaunchKernelGGL(gelu_kernel<T>, dim3(grid1d(n, 256 * 8)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)out, n);
+    UG_CHECK_LAUNCH("ug_gelu_tanh");
+    return UG_OK;
+}
+template <typename T>
+int adaln_bwd_impl(const void* x, int64_t ldx, const void* dy, int64_t lddy, const void* scale, int64_t mod_ld, int64_t rows_per_sample, void* dx,
+                   int64_t lddx, void* dyx, int64_t lddyx, int64_t rows, int64_t D, float eps, ug_stream_t stream) {
+    if (rows == 0) return UG_OK;
+    UG_REQUIRE(x && dy && scale && dx && dyx && rows > 0 && D > 0 && rows_per_sample > 0 && ldx >= D && lddy >= D && lddx >= D && lddyx >= D, UG_ERR_BAD_SHAPE,
+               "ug_adaln_modulate_bwd: bad arguments");
+    hipLaunchKernelGGL(adaln_bwd_kernel<T>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const T*)x, ldx, (const T*)dy, lddy,
+                       (const T*)scale, mod_ld, rows_per_sample, (T*)dx, lddx, (T*)dyx, lddyx, rows, (int)D, eps);
+    UG_CHECK_LAUNCH("ug_adaln_modulate_bwd");
+    return UG_OK;
+}
+template <typename T>
+int qk_bwd_impl(const void* x, int64_t ldx, const void* dy, int64_t lddy, void* dx, int64_t lddx, void* dwx, const void* w, const float* cos_tab,
+                const float* sin_tab, int64_t rows, int64_t rows_per_batch, int64_t pos_offset, int32_t heads, int32_t dh, float eps, ug_stream_t stream) {
+    if (rows == 0) return UG_OK;
+    UG_REQUIRE(x && dy && dx && rows > 0 && heads > 0 && dh > 0 && dh % 2 == 0 && rows_per_batch > 0 && (!w || dwx) && (cos_tab == nullptr) == (sin_tab == nullptr),
+               UG_ERR_BAD_SHAPE, "ug_qk_rmsnorm_rope_bwd: bad arguments");
+    const int64_t nvec = rows * heads;
+    hipLaunchKernelGGL(qk_bwd_kernel<T>, dim3((unsigned)((nvec + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const T*)x, ldx, (const T*)dy, lddy, (T*)dx,
+                       lddx, (T*)dwx, (const T*)w, cos_tab, sin_tab, rows_per_batch, pos_offset, nvec, (int)heads, (int)dh, eps);
+    UG_CHECK_LAUNCH("ug_qk_rmsnorm_rope_bwd");
+    return UG_OK;
+}
+template <typename T>
+int attn_prob_impl(const float* S, int64_t ld_s, const float* lse, void* P, int64_t ld_p, int64_t rows, int64_t cols, float scale, ug_stream_t stream) {
+    if (rows == 0) return UG_OK;
+    UG_REQUIRE(S && lse && P && rows > 0 && cols > 0 && ld_s >= cols && ld_p >= cols, UG_ERR_BAD_SHAPE, "ug_attn_prob: bad arguments");
+    hipLaunchKernelGGL(attn_prob_kernel<T>, dim3(grid1d(rows * cols, 256 * 8)), dim3(256), 0, (hipStream_t)stream, S, ld_s, lse, (T*)P, ld_p, rows, (int)cols, scale);
+    UG_CHECK_LAUNCH("ug_attn_prob");
+    return UG_OK;
+}
+template <typename T>
+int attn_dscore_impl(const void* P, int64_t ld_p, const float* dP, int64_t ld_dp, const float* delta, void* dS, int64_t ld_ds, int64_t rows, int64_t cols,
+                     float scale, ug_stream_t stream) {
+    if (rows == 0) return UG_OK;
+    UG_REQUIRE(P && dP && delta && dS && rows > 0 && cols > 0 && ld_p >= cols && ld_dp >= cols && ld_ds >= cols, UG_ERR_BAD_SHAPE, "ug_attn_dscore: bad arguments");
+    hipLaunchKernelGGL(attn_dscore_kernel<T>, dim3(grid1d(rows * cols, 256 * 8)), dim3(256), 0, (hipStream_t)stream, (const T*)P, ld_p, dP, ld_dp, delta, (T*)dS,
+                       ld_ds, rows, (int)cols, scale);
+    UG_CHECK_LAUNCH("ug_attn_dscore");
+    return UG_OK;
+}
+template <typename T>
+int rowdot_impl(const void* a, int64_t lda, const void* b, int64_t ldb, float* out, int64_t rows, int64_t groups, int64_t cols, ug_stream_t stream) {
+    if (rows == 0) return UG_OK;
+    UG_REQUIRE(a && b && out && rows > 0 && groups > 0 && cols > 0 && lda >= groups * cols && ldb >= groups * cols, UG_ERR_BAD_SHAPE, "ug_rowdot: bad arguments");
+    hipLaunchKernelGGL(rowdot_kernel<T>, dim3((unsigned)((rows * groups + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const T*)a, lda, (const T*)b, ldb, out,
+                       rows, (int)groups, (int)cols);
+    UG_CHECK_LAUNCH("ug_rowdot");
+    return UG_OK;
+}
+
+}  // namespace
+
+#define UG_TWINS(NAME, IMPL, PARAMS, ARGS)                                              \
+    extern "C" int NAME PARAMS { return IMPL<bf16_t> ARGS; }                            \
+    extern "C" int NAME##_f32 PARAMS { return IMPL<float> ARGS; }
+
+UG_TWINS(ug_transpose, transpose_impl,
+         (const void* src, int64_t ld_src, int64_t src_bstride, void* dst, int64_t ld_dst, int64_t dst_bstride, int64_t batch, int64_t rows, int64_t cols,
+          int64_t rows_pad, ug_stream_t stream),
+         (src, ld_src, src_bstride, dst, ld_dst, dst_bstride, batch, rows, cols, rows_pad, stream))
+UG_TWINS(ug_colsum, colsum_impl,
+         (const void* a, int64_t lda, const void* b, int64_t ldb, void* out, int64_t ldo, int64_t rows, int64_t cols, int64_t rows_per_group, float alpha,
+          ug_stream_t stream),
+         (a, lda, b, ldb, out, ldo, rows, cols, rows_per_group, alpha, stream))
+UG_TWINS(ug_gelu_tanh, gelu_impl, (const void* x, void* y, int64_t n, ug_stream_t stream), (x, nullptr, y, n, stream))
+UG_TWINS(ug_gelu_tanh_bwd, gelu_impl, (const void* x, const void* dy, void* dx, int64_t n, ug_stream_t stream), (x, dy, dx, n, stream))
+UG_TWINS(ug_adaln_modulate_bwd, adaln_bwd_impl,
+         (const void* x, int64_t ldx, const void* dy, int64_t lddy, const void* scale, int64_t mod_ld, int64_t rows_per_sample, void* dx, int64_t lddx,
+          void* dyx, int64_t lddyx, int64_t rows, int64_t D, float eps, ug_stream_t stream),
+         (x, ldx, dy, lddy, scale, mod_ld, rows_per_sample, dx, lddx, dyx, lddyx, rows, D, eps, stream))
+UG_TWINS(ug_qk_rmsnorm_rope_bwd, qk_bwd_impl,
+         (const void* x, int64_t ldx, const void* dy, int64_t lddy, void* dx, int64_t lddx, void* dwx, const void* w, const float* cos_tab,
+          const float* sin_tab, int64_t rows, int64_t rows_per_batch, int64_t pos_offset, int32_t heads, int32_t dh, float eps, ug_stream_t stream),
+         (x, ldx, dy, lddy, dx, lddx, dwx, w, cos_tab, sin_tab, rows, rows_per_batch, pos_offset, heads, dh, eps, stream))
+UG_TWINS(ug_attn_prob, attn_prob_impl,
+         (const float* S, int64_t ld_s, const float* lse, void* P, int64_t ld_p, int64_t rows, int64_t cols, float scale, ug_stream_t stream),
+         (S, ld_s, lse, P, ld_p, rows, cols, scale, stream))
+UG_TWINS(ug_attn_dscore, attn_dscore_impl,
+         (const void* P, int64_t ld_p, const float* dP, int64_t ld_dp, const float* delta, void* dS, int64_t ld_ds, int64_t rows, int64_t cols, float scale,
+          ug_stream_t stream),
+         (P, ld_p, dP, ld_dp, delta, dS, ld_ds, rows, cols, scale, stream))
+UG_TWINS(ug_rowdot, rowdot_impl,
+         (const void* a, int64_t lda, const void* b, int64_t ldb, float* out, int64_t rows, int64_t groups, int64_t cols, ug_stream_t stream),
+         (a, lda, b, ldb, out, rows, groups, cols, stream))
+
+extern "C" int ug_row_lse(const float* S, int64_t ld, float* lse, int64_t rows, int64_t cols, float scale, ug_stream_t stream) {
+    if (rows == 0) return UG_OK;
+    UG_REQUIRE(S && lse && rows > 0 && cols > 0 && ld >= cols && rows < (1ll << 31), UG_ERR_BAD_SHAPE, "ug_row_lse: bad arguments");
+    hipLaunchKernelGGL(row_lse_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, S, ld, lse, (int)cols, scale);
+    UG_CHECK_LAUNCH("ug_row_lse");
+    return UG_OK;
+}

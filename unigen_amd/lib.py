@@ -82,7 +82,22 @@ SIGNATURES = {
     "ug_unpack_latents": (i32, [vp, vp, i64, i64, i64, i64, vp]),
 }
 # fp32 verification twins: `<name>_f32` has the signature of the function it mirrors (include/unigen_hip.h, last section)
-_F32_TWINS = {"ug_gemm_f32": "ug_gemm_bf16", "ug_small_linear_f32": "ug_small_linear_bf16", "ug_adaln_modulate_f32": "ug_adaln_modulate",
+SIGNATURES.update({
+    "ug_transpose": (i32, [vp, i64, i64, vp, i64, i64, i64, i64, i64, i64, vp]),
+    "ug_colsum": (i32, [vp, i64, vp, i64, vp, i64, i64, i64, i64, f32, vp]),
+    "ug_gelu_tanh": (i32, [vp, vp, i64, vp]),
+    "ug_gelu_tanh_bwd": (i32, [vp, vp, vp, i64, vp]),
+    "ug_adaln_modulate_bwd": (i32, [vp, i64, vp, i64, vp, i64, i64, vp, i64, vp, i64, i64, i64, f32, vp]),
+    "ug_qk_rmsnorm_rope_bwd": (i32, [vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, i64, i64, i64, i32, i32, f32, vp]),
+    "ug_row_lse": (i32, [vp, i64, vp, i64, i64, f32, vp]),
+    "ug_attn_prob": (i32, [vp, i64, vp, vp, i64, i64, i64, f32, vp]),
+    "ug_attn_dscore": (i32, [vp, i64, vp, i64, vp, vp, i64, i64, i64, f32, vp]),
+    "ug_rowdot": (i32, [vp, i64, vp, i64, vp, i64, i64, i64, vp]),
+})
+_F32_TWINS = {"ug_transpose_f32": "ug_transpose", "ug_colsum_f32": "ug_colsum", "ug_gelu_tanh_f32": "ug_gelu_tanh", "ug_gelu_tanh_bwd_f32": "ug_gelu_tanh_bwd",
+              "ug_adaln_modulate_bwd_f32": "ug_adaln_modulate_bwd", "ug_qk_rmsnorm_rope_bwd_f32": "ug_qk_rmsnorm_rope_bwd",
+              "ug_attn_prob_f32": "ug_attn_prob", "ug_attn_dscore_f32": "ug_attn_dscore", "ug_rowdot_f32": "ug_rowdot",
+              "ug_gemm_f32": "ug_gemm_bf16", "ug_small_linear_f32": "ug_small_linear_bf16", "ug_adaln_modulate_f32": "ug_adaln_modulate",
               "ug_qk_rmsnorm_rope_f32": "ug_qk_rmsnorm_rope", "ug_flash_attn_fwd_f32": "ug_flash_attn_fwd", "ug_timestep_embed_f32": "ug_timestep_embed",
               "ug_euler_step_f32": "ug_euler_step", "ug_cfg_combine_f32": "ug_cfg_combine", "ug_add_f32": "ug_add_bf16",
               "ug_add_rowbcast_f32_f32": "ug_add_rowbcast_f32", "ug_gather_rows_f32": "ug_gather_rows", "ug_moe_gate_top1_f32": "ug_moe_gate_top1",

@@ -513,3 +513,116 @@ def vae_sample(moments: torch.Tensor, noise: torch.Tensor, *, B: int, latent: in
     z = torch.empty(B, latent, H, W, device=moments.device, dtype=dt)
     L.check(_fn("ug_vae_sample", dt)(moments.data_ptr(), moments.shape[1], noise.data_ptr(), z.data_ptr(), B, latent, H * W, shift, scale, _stream()), "ug_vae_sample")
     return z
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# backward-pass entry points (include/unigen_hip.h "Backward pass of the control-module training step")
+# ---------------------------------------------------------------------------------------------------------------------
+def transpose(src: torch.Tensor, rows_pad: Optional[int] = None) -> torch.Tensor:
+    """src [..., rows, cols] (any row stride, uniform batch stride) -> [..., cols, rows_pad] contiguous, zero beyond `rows`."""
+    dt = _act(src, "src")
+    rows, cols = src.shape[-2], src.shape[-1]
+    rows_pad = rows if rows_pad is None else rows_pad
+    lead = src.shape[:-2]
+    batch = 1
+    for d in lead:
+        batch *= d
+    if len(lead) > 1:
+        raise ValueError("transpose: at most one batch dimension")
+    bstride = src.stride(0) if lead else 0
+    out = torch.empty(*lead, cols, rows_pad, device=src.device, dtype=dt)
+    L.check(_fn("ug_transpose", dt)(src.data_ptr(), src.stride(-2), bstride, out.data_ptr(), rows_pad, cols * rows_pad, batch, rows, cols, rows_pad, _stream()),
+            "ug_transpose")
+    return out
+
+
+def colsum(a: torch.Tensor, b: Optional[torch.Tensor] = None, *, rows_per_group: Optional[int] = None, alpha: float = 1.0) -> torch.Tensor:
+    """a (and b) [rows, cols] -> [rows / rows_per_group, cols]: per-group column sums of a (* b), fp32 accumulation."""
+    dt = _act(a, "a")
+    rows, cols = a.shape
+    g = rows if rows_per_group is None else rows_per_group
+    if b is not None:
+        _chk(b, "b", dt)
+    out = torch.empty(rows // g, cols, device=a.device, dtype=dt)
+    L.check(_fn("ug_colsum", dt)(a.data_ptr(), a.stride(0), _p(b), b.stride(0) if b is not None else 0, out.data_ptr(), cols, rows, cols, g, alpha, _stream()),
+            "ug_colsum")
+    return out
+
+
+def gelu_tanh(x: torch.Tensor) -> torch.Tensor:
+    dt = _act(x, "x")
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    L.check(_fn("ug_gelu_tanh", dt)(x.data_ptr(), out.data_ptr(), x.numel(), _stream()), "ug_gelu_tanh")
+    return out
+
+
+def gelu_tanh_bwd(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
+    dt = _act(x, "x")
+    x, dy = x.contiguous(), dy.contiguous()
+    _chk(dy, "dy", dt)
+    out = torch.empty_like(x)
+    L.check(_fn("ug_gelu_tanh_bwd", dt)(x.data_ptr(), dy.data_ptr(), out.data_ptr(), x.numel(), _stream()), "ug_gelu_tanh_bwd")
+    return out
+
+
+def adaln_modulate_bwd(x: torch.Tensor, dy: torch.Tensor, scale: torch.Tensor, *, rows_per_sample: int, eps: float = 1e-6):
+    """x, dy [rows, D]; scale [samples, D] (row stride = its stride(0)) -> (dx, dy * xhat)."""
+    dt = _act(x, "x")
+    _chk(dy, "dy", dt); _chk(scale, "scale", dt)
+    rows, D = x.shape
+    dx, dyx = torch.empty(rows, D, device=x.device, dtype=dt), torch.empty(rows, D, device=x.device, dtype=dt)
+    L.check(_fn("ug_adaln_modulate_bwd", dt)(x.data_ptr(), x.stride(0), dy.data_ptr(), dy.stride(0), scale.data_ptr(), scale.stride(0), rows_per_sample,
+                                           dx.data_ptr(), D, dyx.data_ptr(), D, rows, D, eps, _stream()), "ug_adaln_modulate_bwd")
+    return dx, dyx
+
+
+def qk_rmsnorm_rope_bwd(x: torch.Tensor, dy: torch.Tensor, w: Optional[torch.Tensor], cos: Optional[torch.Tensor], sin: Optional[torch.Tensor], *,
+                        rows_per_batch: int, pos_offset: int, heads: int, dh: int, eps: float = 1e-6):
+    """x, dy [rows, heads * dh] (any row stride) -> (dx [rows, heads * dh], dwx [rows * heads, dh] or None)."""
+    dt = _act(x, "x")
+    _chk(dy, "dy", dt)
+    rows = x.shape[0]
+    dx = torch.empty(rows, heads * dh, device=x.device, dtype=dt)
+    dwx = torch.empty(rows * heads, dh, device=x.device, dtype=dt) if w is not None else None
+    if cos is not None:
+        _chk(cos, "cos", torch.float32); _chk(sin, "sin", torch.float32)
+        assert cos.shape[0] >= pos_offset + rows_per_batch and cos.shape[1] == dh and cos.is_contiguous() and sin.is_contiguous()
+    L.check(_fn("ug_qk_rmsnorm_rope_bwd", dt)(x.data_ptr(), x.stride(0), dy.data_ptr(), dy.stride(0), dx.data_ptr(), heads * dh, _p(dwx), _p(w), _p(cos),
+                                            _p(sin), rows, rows_per_batch, pos_offset, heads, dh, eps, _stream()), "ug_qk_rmsnorm_rope_bwd")
+    return dx, dwx
+
+
+def row_lse(S: torch.Tensor, scale: float) -> torch.Tensor:
+    _chk(S, "S", torch.float32)
+    rows, cols = S.shape
+    out = torch.empty(rows, device=S.device, dtype=torch.float32)
+    L.check(L.load().ug_row_lse(S.data_ptr(), S.stride(0), out.data_ptr(), rows, cols, scale, _stream()), "ug_row_lse")
+    return out
+
+
+def attn_prob(S: torch.Tensor, lse: torch.Tensor, scale: float, dtype) -> torch.Tensor:
+    rows, cols = S.shape
+    P = torch.empty(rows, cols, device=S.device, dtype=dtype)
+    L.check(_fn("ug_attn_prob", dtype)(S.data_ptr(), S.stride(0), lse.data_ptr(), P.data_ptr(), cols, rows, cols, scale, _stream()), "ug_attn_prob")
+    return P
+
+
+def attn_dscore(P: torch.Tensor, dP: torch.Tensor, delta: torch.Tensor, scale: float) -> torch.Tensor:
+    dt = _act(P, "P")
+    rows, cols = P.shape
+    dS = torch.empty_like(P)
+    L.check(_fn("ug_attn_dscore", dt)(P.data_ptr(), P.stride(0), dP.data_ptr(), dP.stride(0), delta.data_ptr(), dS.data_ptr(), cols, rows, cols, scale, _stream()),
+            "ug_attn_dscore")
+    return dS
+
+
+def rowdot(a: torch.Tensor, b: torch.Tensor, groups: int) -> torch.Tensor:
+    """a, b [rows, groups * cols] -> [groups, rows] fp32: per-group row dot products."""
+    dt = _act(a, "a")
+    _chk(b, "b", dt)
+    rows = a.shape[0]
+    cols = a.shape[1] // groups
+    out = torch.empty(groups, rows, device=a.device, dtype=torch.float32)
+    L.check(_fn("ug_rowdot", dt)(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(), rows, groups, cols, _stream()), "ug_rowdot")
+    return out
