@@ -1,0 +1,88 @@
+"""Backward of the control modules (reference train.py:622-662): one training step's loss and the gradients of every
+parameter of `trainable_control_modules` from the HIP path (unigen_amd/training.py + autograd.py) against torch autograd of the CPU oracle on the
+same weights, inputs, RTS draw and target. fp32 parameters run the `_f32` verification twins: gradients must agree to 1e-3 (measured ~1e-5).
+bf16: the HIP gradients must be as close to the fp32 gradients as the oracle's own bf16 autograd."""
+import pytest
+import torch
+
+from oracle import unigen_ref as R
+from tests.util import report
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+TINY = dict(num_layers=2, num_single_layers=2, attention_head_dim=128, num_attention_heads=2, joint_attention_dim=64, pooled_projection_dim=64)
+CONTROL = dict(use_rope=True, use_shared_expert=True, use_single_trans_blocks=True, single_control_dev=2, single_block_control_method="overall_add",
+               top_num=1, expert_num_each_condition=3)
+
+
+def _dev(v, gpu, dt=None):
+    if isinstance(v, (list, tuple)):
+        return [_dev(t, gpu, dt) for t in v]
+    return v.to(gpu) if (dt is None or not v.is_floating_point()) else v.to(gpu).to(dt)
+
+
+def _step(fwd, target, dtype):
+    out, losses, extra = fwd()
+    flow = ((out.float() - target.to(out.device).float()) ** 2).reshape(out.shape[0], -1).mean(1)       # train.py:644-650 with weighting = 1
+    loss = flow.mean() + losses["moe_loss"]
+    loss.backward()
+    return out.detach(), float(loss), extra
+
+
+@pytest.mark.parametrize("n_cond,cls_name", [(1, "UniGenFlux"), (2, "MultiCondtionUniGenFlux")])
+def test_control_module_gradients_match_oracle_autograd(gpu, n_cond, cls_name):
+    import importlib
+    cls = getattr(importlib.import_module("src.UniGenTransformer"), cls_name)
+    B, grid, T = 2, 8, 64                     # N = 64 image tokens, every joint length a multiple of 64 (attention backward contraction lengths)
+    rcfg = R.FluxConfig(condition_nums=n_cond, **TINY)
+    base = cls.from_config(dict(TINY), device=gpu, dtype=BF)
+    base.init_condition_block(condition_nums=n_cond, condition_types=["canny", "depth"][:n_cond], control_params=dict(CONTROL))
+    base.init_synthetic_(seed=3, std=0.05, bias_std=0.02)
+    state = {k: v.detach().cpu() for k, v in base.state_dict().items()}
+    inp = R.make_inputs(rcfg, B=B, grid=grid, T=T, n_cond=n_cond)
+    t = torch.full((B,), 0.75, dtype=BF)
+    target = torch.randn(B, grid * grid, 64, generator=torch.Generator().manual_seed(5))
+    base.init_trainable_param()
+    names = [n for n, p in base.named_parameters() if p.requires_grad]
+    assert any(n.startswith("control_joint_trans_blocks.") for n in names) and not any(n.startswith("transformer_blocks.") for n in names)
+
+    def oracle_grads(dtype):
+        st = {k: (v.to(dtype).clone().requires_grad_(True) if k in names else v.to(dtype)) for k, v in state.items()}
+        out, loss, _ = _step(lambda: R.unigen_flux_forward(st, rcfg, timestep=t, dtype=dtype, **inp), target, dtype)
+        return out, loss, {k: st[k].grad for k in names}
+
+    def hip_grads(dtype):
+        model = cls.from_config(dict(TINY), device=gpu, dtype=dtype)
+        model.init_condition_block(condition_nums=n_cond, condition_types=["canny", "depth"][:n_cond], control_params=dict(CONTROL))
+        model.load_state_dict({k: v.to(dtype) for k, v in state.items()})
+        model.init_trainable_param()
+        kw = {k: _dev(v, gpu, dtype if k != "gate_uniform" and not k.endswith("_ids") else None) for k, v in inp.items()}
+        out, loss, extra = _step(lambda: model(timestep=t.to(gpu), **kw), target, dtype)
+        return out, loss, {k: model.get_parameter(k).grad for k in names}, extra
+
+    truth_out, truth_loss, truth = oracle_grads(torch.float32)
+    # Parameters that only feed a DISCARDED context output (to_add_out / ff_context / add_q_proj ... of the control joint blocks and of
+    # shared_expert[1], src/UniGenTransformer.py:1097,1022) get no gradient, or an all-zero one, in the reference too: compared as zeros.
+    dead = {k for k in names if truth[k] is None or float(truth[k].abs().max()) == 0.0}
+    live = [k for k in names if k not in dead]
+    assert len(live) > len(names) // 2 and all(torch.isfinite(truth[k]).all() for k in live)
+    z = lambda d, k: (d[k].detach().float().cpu() if d[k] is not None else torch.zeros(state[k].shape))
+    cat = lambda d: torch.cat([z(d, k).flatten() for k in names])
+    rel = lambda a, b: float((a - b).norm() / b.norm())
+    # fp32 verification path
+    out32, loss32, g32, _ = hip_grads(torch.float32)
+    m = report(f"train_{cls_name}_f32_forward", out32, truth_out)
+    e_all = rel(cat(g32), cat(truth))
+    worst = max((rel(z(g32, k), truth[k]), k) for k in live)
+    assert all(float(z(g32, k).abs().max()) == 0.0 for k in dead), "a parameter behind a discarded output received a gradient"
+    print(f"training fp32: loss {loss32:.6f} vs {truth_loss:.6f}; all gradients rel_l2 {e_all:.3e}; worst parameter {worst[1]} {worst[0]:.3e}")
+    assert m["rel_l2"] <= 1e-4 and abs(loss32 - truth_loss) <= 1e-5 * abs(truth_loss) + 1e-7 and e_all <= 1e-3 and worst[0] <= 5e-3, (m, e_all, worst)
+    # bf16 product path vs the oracle's own bf16 autograd
+    ref_out, ref_loss, gref = oracle_grads(BF)
+    out16, loss16, g16, extra = hip_grads(BF)
+    e_hip, e_ref = rel(cat(g16), cat(truth)), rel(cat(gref), cat(truth))
+    print(f"training bf16: loss {loss16:.5f} (oracle bf16 {ref_loss:.5f}, fp32 {truth_loss:.5f}); gradients vs fp32: hip {e_hip:.3e}, oracle bf16 {e_ref:.3e}")
+    report(f"train_{cls_name}_bf16_grads", cat(g16), cat(truth), err_hip_vs_fp32=e_hip, err_oraclebf16_vs_fp32=e_ref)
+    assert e_hip <= 1.5 * e_ref + 5e-3 and abs(loss16 - truth_loss) <= 3e-2 * abs(truth_loss), (e_hip, e_ref, loss16, truth_loss)
+    assert int(extra["expert_counts"].sum()) == B * grid * grid

@@ -370,8 +370,16 @@ class UniGenFlux(HipModule):
         return l_aux, exp_counts
 
     # ------------------------------------------------------------------ forward ---------------------------------------
-    @torch.no_grad()
-    def forward(self, hidden_states: torch.Tensor, condition_hidden_states=None, conditioning_scale: float = 1.0,
+    def forward(self, *args, **kwargs):
+        """Inference (no autograd: the in-place HIP engine below) or, when autograd is on and some parameter requires a gradient - the reference's
+        train.py:622-662 after `init_trainable_param()` - the differentiable forward of unigen_amd/training.py. Same arguments, same 3-tuple."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            from . import training
+            return training.flux_forward(self, *args, **kwargs)
+        with torch.no_grad():
+            return self._forward_inference(*args, **kwargs)
+
+    def _forward_inference(self, hidden_states: torch.Tensor, condition_hidden_states=None, conditioning_scale: float = 1.0,
                 encoder_hidden_states: torch.Tensor = None, pooled_projections: torch.Tensor = None, condition_pooled_projections=None,
                 timestep: torch.Tensor = None, img_ids: torch.Tensor = None, txt_ids: torch.Tensor = None, guidance: torch.Tensor = None,
                 condition_ids=None, joint_attention_kwargs: Optional[Dict[str, Any]] = None, skip_layers=None, gate_uniform=None, **kwargs):
