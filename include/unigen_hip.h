@@ -308,7 +308,9 @@ int ug_transpose(const void* src, int64_t ld_src, int64_t src_bstride, void* dst
 /* out[g][c] = alpha * sum over the rows r of group g (rows_per_group consecutive rows) of a[r][c] * (b ? b[r][c] : 1), fp32 accumulation.
  * (grad of a bias / a per-sample gate, shift, scale: `.sum(dim)` in the backward of a broadcast) */
 int ug_colsum(const void* a, int64_t lda, const void* b, int64_t ldb, void* out, int64_t ldo, int64_t rows, int64_t cols, int64_t rows_per_group,
-              float alpha, ug_stream_t stream);
+              float alpha, void* workspace, int64_t workspace_bytes, ug_stream_t stream);
+/* bytes of the caller-owned fp32 scratch of ug_colsum (per-chunk partial sums, added in a fixed order: run-to-run reproducible) */
+int64_t ug_colsum_workspace_bytes(int64_t rows, int64_t cols, int64_t rows_per_group);
 /* y = gelu_tanh(x); dx = dy * gelu_tanh'(x)   (F.gelu(approximate="tanh") of FeedForward net.0 / proj_mlp and its backward) */
 int ug_gelu_tanh(const void* x, void* y, int64_t n, ug_stream_t stream);
 int ug_gelu_tanh_bwd(const void* x, const void* dy, void* dx, int64_t n, ug_stream_t stream);
@@ -332,7 +334,7 @@ int ug_rowdot(const void* a, int64_t lda, const void* b, int64_t ldb, float* out
 int ug_transpose_f32(const void* src, int64_t ld_src, int64_t src_bstride, void* dst, int64_t ld_dst, int64_t dst_bstride, int64_t batch, int64_t rows,
                      int64_t cols, int64_t rows_pad, ug_stream_t stream);
 int ug_colsum_f32(const void* a, int64_t lda, const void* b, int64_t ldb, void* out, int64_t ldo, int64_t rows, int64_t cols, int64_t rows_per_group,
-                  float alpha, ug_stream_t stream);
+                  float alpha, void* workspace, int64_t workspace_bytes, ug_stream_t stream);
 int ug_gelu_tanh_f32(const void* x, void* y, int64_t n, ug_stream_t stream);
 int ug_gelu_tanh_bwd_f32(const void* x, const void* dy, void* dx, int64_t n, ug_stream_t stream);
 int ug_adaln_modulate_bwd_f32(const void* x, int64_t ldx, const void* dy, int64_t lddy, const void* scale, int64_t mod_ld, int64_t rows_per_sample,

@@ -1,0 +1,56 @@
+"""One training step (forward + backward of the control modules, reference train.py:622-662) at the FLUX-schnell geometry + canny control,
+random weights and inputs: seconds per step, samples/s, peak memory. Not the headline metric (BASELINE.json measures inference); the
+SURVEY 8(f) rank-4 row. usage: python tools/train_bench.py [--batch 1] [--size 1024] [--ckpt] [--layers 19 38]"""
+import argparse, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from unigen_amd.flux import UniGenFlux
+from unigen_amd.pipeline import prepare_latent_image_ids
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=1)
+ap.add_argument("--size", type=int, default=1024)
+ap.add_argument("--ckpt", action="store_true")
+ap.add_argument("--layers", type=int, nargs=2, default=None)
+ap.add_argument("--steps", type=int, default=2)
+a = ap.parse_args()
+dev, BF = torch.device("cuda:0"), torch.bfloat16
+cfg = {} if a.layers is None else {"num_layers": a.layers[0], "num_single_layers": a.layers[1]}
+model = UniGenFlux.from_config(cfg, device=dev, dtype=BF)
+model.init_condition_block(condition_nums=1, condition_types=["canny"], control_params=dict(
+    use_rope=True, use_shared_expert=True, use_consis_module=False, use_single_trans_blocks=True, single_control_dev=2,
+    single_block_control_method="overall_add", top_num=1, expert_num_each_condition=3))
+model.init_synthetic_(seed=0, std=0.02)
+model.init_trainable_param()
+if a.ckpt:
+    model.enable_gradient_checkpointing()
+B, grid, T = a.batch, a.size // 16, 512
+N = grid * grid
+g = torch.Generator(device=dev).manual_seed(5)
+rn = lambda *s: torch.randn(*s, generator=g, device=dev)
+inp = dict(hidden_states=rn(B, N, 64).to(BF), condition_hidden_states=rn(B, N, 64).to(BF), encoder_hidden_states=(0.1 * rn(B, T, 4096)).to(BF),
+           pooled_projections=rn(B, 768).to(BF), condition_pooled_projections=rn(B, 768).to(BF))
+ids = prepare_latent_image_ids(grid, grid, dev, BF)
+txt = torch.zeros(T, 3, device=dev, dtype=BF)
+t = torch.full((B,), 0.75, device=dev, dtype=BF)
+target = rn(B, N, 64)
+n_train = sum(p.numel() for p in model.parameters() if p.requires_grad)
+n_all = sum(p.numel() for p in model.parameters())
+times = []
+for step in range(a.steps + 1):
+    for p in model.parameters():
+        p.grad = None
+    torch.cuda.synchronize(); t0 = time.time()
+    out, losses, _ = model(timestep=t, img_ids=ids, txt_ids=txt, condition_ids=ids, **inp)
+    torch.cuda.synchronize(); t1 = time.time()
+    loss = ((out.float() - target) ** 2).reshape(B, -1).mean(1).mean() + losses["moe_loss"]
+    loss.backward()
+    torch.cuda.synchronize(); t2 = time.time()
+    if step:
+        times.append((t1 - t0, t2 - t1))
+    gn = float(torch.sqrt(sum((p.grad.float() ** 2).sum() for p in model.parameters() if p.grad is not None)))
+    print(f"step {step}: loss {float(loss):.5f} grad-norm {gn:.4e} forward {t1 - t0:.3f}s backward {t2 - t1:.3f}s", flush=True)
+fw, bw = min(x[0] for x in times), min(x[1] for x in times)
+print("TRAIN_BENCH", json.dumps(dict(batch=B, size=a.size, layers=[model.config.num_layers, model.config.num_single_layers], checkpointing=bool(a.ckpt),
+      params_total=n_all, params_trainable=n_train, forward_s=round(fw, 3), backward_s=round(bw, 3), samples_per_s=round(B / (fw + bw), 3),
+      peak_mem_gb=round(torch.cuda.max_memory_allocated() / 2 ** 30, 1))))

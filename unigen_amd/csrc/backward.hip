@@ -48,24 +48,50 @@ __global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ sr
     }
 }
 
-// out[g][c] = rnd(alpha * sum_{r in group g} a[r][c] * (b ? b[r][c] : 1)); one block = 64 columns of one group, 4 waves split the rows
+// out[g][c] = rnd(alpha * sum_{r in group g} a[r][c] * (b ? b[r][c] : 1)) in two deterministic stages: a block sums COLSUM_ROWS rows of 512 columns
+// (8 per lane, 16-byte loads; its 4 waves take every 4th row, then meet in LDS) into an fp32 partial; the second stage adds the partials of a
+// group in order.
+constexpr int COLSUM_ROWS = 128;
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ a, int64_t lda, const T* __restrict__ b, int64_t ldb, T* __restrict__ out,
-                                                     int64_t ldo, int64_t rows_per_group, int cols, float alpha) {
-    __shared__ float red[4][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
-    const int64_t r0 = (int64_t)blockIdx.y * rows_per_group;
-    float acc = 0.f;
-    if (c < cols) {
-        for (int64_t r = w; r < rows_per_group; r += 4) {
-            float v = ElemT<T>::ld(a + (r0 + r) * lda + c);
-            if (b) v *= ElemT<T>::ld(b + (r0 + r) * ldb + c);
-            acc += v;
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ a, int64_t lda, const T* __restrict__ b, int64_t ldb, float* __restrict__ part,
+                                                             int64_t rows_per_group, int cols, int nchunks) {
+    __shared__ float red[4][512];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c0 = blockIdx.x * 512 + lane * 8;
+    const int64_t r0 = (int64_t)blockIdx.z * rows_per_group + (int64_t)blockIdx.y * COLSUM_ROWS;
+    const int64_t r1 = min((int64_t)blockIdx.z * rows_per_group + rows_per_group, r0 + COLSUM_ROWS);
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (c0 < cols) {
+        for (int64_t r = r0 + w; r < r1; r += 4) {
+            float va[8], vb[8];
+            ElemT<T>::load8(a + r * lda + c0, va);
+            if (b) {
+                ElemT<T>::load8(b + r * ldb + c0, vb);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[i] += va[i] * vb[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[i] += va[i];
+            }
         }
     }
-    red[w][threadIdx.x & 63] = acc;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) red[w][lane * 8 + i] = acc[i];
     __syncthreads();
-    if (w == 0 && c < cols) ElemT<T>::st(out + (int64_t)blockIdx.y * ldo + c, alpha * (red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]));
+    for (int c = threadIdx.x; c < 512; c += 256) {
+        const int col = blockIdx.x * 512 + c;
+        if (col < cols) part[((int64_t)blockIdx.z * nchunks + blockIdx.y) * cols + col] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+    }
+}
+template <typename T>
+__global__ void colsum_final_kernel(const float* __restrict__ part, T* __restrict__ out, int64_t ldo, int cols, int nchunks, int groups, float alpha) {
+    const int64_t total = (int64_t)groups * cols;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int g = (int)(i / cols), c = (int)(i - (int64_t)g * cols);
+        float s = 0.f;
+        for (int k = 0; k < nchunks; ++k) s += part[((int64_t)g * nchunks + k) * cols + c];
+        ElemT<T>::st(out + (int64_t)g * ldo + c, alpha * s);
+    }
 }
 
 template <typename T>
@@ -226,12 +252,22 @@ int transpose_impl(const void* src, int64_t ld_src, int64_t src_bstride, void* d
 }
 template <typename T>
 int colsum_impl(const void* a, int64_t lda, const void* b, int64_t ldb, void* out, int64_t ldo, int64_t rows, int64_t cols, int64_t rows_per_group,
-                float alpha, ug_stream_t stream) {
+                float alpha, void* workspace, int64_t workspace_bytes, ug_stream_t stream) {
     if (rows == 0 || cols == 0) return UG_OK;
     UG_REQUIRE(a && out && rows > 0 && cols > 0 && rows_per_group > 0 && rows % rows_per_group == 0 && rows / rows_per_group < 65536 && lda >= cols &&
                ldo >= cols && (!b || ldb >= cols), UG_ERR_BAD_SHAPE, "ug_colsum: bad arguments");
-    dim3 grid((unsigned)((cols + 63) / 64), (unsigned)(rows / rows_per_group));
-    hipLaunchKernelGGL(colsum_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)a, lda, (const T*)b, ldb, (T*)out, ldo, rows_per_group, (int)cols, alpha);
+    constexpr int EB = ElemT<T>::kF32 ? 4 : 2;
+    UG_REQUIRE(cols % 8 == 0 && lda % 8 == 0 && (!b || ldb % 8 == 0) && ug_aligned(a, 8 * EB > 16 ? 16 : 8 * EB) && (!b || ug_aligned(b, 8 * EB > 16 ? 16 : 8 * EB)),
+               UG_ERR_BAD_ALIGN, "ug_colsum: cols and leading dimensions must be multiples of 8, bases 16-byte aligned");
+    const int64_t groups = rows / rows_per_group;
+    const int nchunks = (int)((rows_per_group + COLSUM_ROWS - 1) / COLSUM_ROWS);
+    UG_REQUIRE(workspace && workspace_bytes >= groups * nchunks * cols * (int64_t)sizeof(float) && nchunks < 65536, UG_ERR_BAD_SHAPE,
+               "ug_colsum: workspace of ug_colsum_workspace_bytes() needed");
+    dim3 grid((unsigned)((cols + 511) / 512), (unsigned)nchunks, (unsigned)groups);
+    hipLaunchKernelGGL(colsum_partial_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)a, lda, (const T*)b, ldb, (float*)workspace, rows_per_group,
+                       (int)cols, nchunks);
+    hipLaunchKernelGGL(colsum_final_kernel<T>, dim3(grid1d(groups * cols, 256)), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, (T*)out, ldo, (int)cols,
+                       nchunks, (int)groups, alpha);
     UG_CHECK_LAUNCH("ug_colsum");
     return UG_OK;
 }
@@ -307,8 +343,12 @@ UG_TWINS(ug_transpose, transpose_impl,
          (src, ld_src, src_bstride, dst, ld_dst, dst_bstride, batch, rows, cols, rows_pad, stream))
 UG_TWINS(ug_colsum, colsum_impl,
          (const void* a, int64_t lda, const void* b, int64_t ldb, void* out, int64_t ldo, int64_t rows, int64_t cols, int64_t rows_per_group, float alpha,
-          ug_stream_t stream),
-         (a, lda, b, ldb, out, ldo, rows, cols, rows_per_group, alpha, stream))
+          void* workspace, int64_t workspace_bytes, ug_stream_t stream),
+         (a, lda, b, ldb, out, ldo, rows, cols, rows_per_group, alpha, workspace, workspace_bytes, stream))
+extern "C" int64_t ug_colsum_workspace_bytes(int64_t rows, int64_t cols, int64_t rows_per_group) {
+    if (rows <= 0 || cols <= 0 || rows_per_group <= 0) return 0;
+    return (rows / rows_per_group) * ((rows_per_group + COLSUM_ROWS - 1) / COLSUM_ROWS) * cols * (int64_t)sizeof(float);
+}
 UG_TWINS(ug_gelu_tanh, gelu_impl, (const void* x, void* y, int64_t n, ug_stream_t stream), (x, nullptr, y, n, stream))
 UG_TWINS(ug_gelu_tanh_bwd, gelu_impl, (const void* x, const void* dy, void* dx, int64_t n, ug_stream_t stream), (x, dy, dx, n, stream))
 UG_TWINS(ug_adaln_modulate_bwd, adaln_bwd_impl,

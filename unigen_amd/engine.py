@@ -104,7 +104,8 @@ class HipModule(nn.Module):
             module.requires_grad_(True)
 
     def enable_gradient_checkpointing(self):
-        pass  # forward-only engine
+        """train.py:317: transformer blocks are recomputed in the backward (torch.utils.checkpoint around each block of unigen_amd/training.py)."""
+        self._grad_checkpoint = True
 
     def init_synthetic_(self, seed: int = 0, std: float = 0.02, bias_std: float = 0.0) -> "HipModule":
         """Seeded N(0, std^2) weights, zero (or N(0, bias_std^2)) biases, unit RMSNorm weights; the zero-res projections are

@@ -84,7 +84,8 @@ SIGNATURES = {
 # fp32 verification twins: `<name>_f32` has the signature of the function it mirrors (include/unigen_hip.h, last section)
 SIGNATURES.update({
     "ug_transpose": (i32, [vp, i64, i64, vp, i64, i64, i64, i64, i64, i64, vp]),
-    "ug_colsum": (i32, [vp, i64, vp, i64, vp, i64, i64, i64, i64, f32, vp]),
+    "ug_colsum": (i32, [vp, i64, vp, i64, vp, i64, i64, i64, i64, f32, vp, i64, vp]),
+    "ug_colsum_workspace_bytes": (i64, [i64, i64, i64]),
     "ug_gelu_tanh": (i32, [vp, vp, i64, vp]),
     "ug_gelu_tanh_bwd": (i32, [vp, vp, vp, i64, vp]),
     "ug_adaln_modulate_bwd": (i32, [vp, i64, vp, i64, vp, i64, i64, vp, i64, vp, i64, i64, i64, f32, vp]),

@@ -544,8 +544,9 @@ def colsum(a: torch.Tensor, b: Optional[torch.Tensor] = None, *, rows_per_group:
     if b is not None:
         _chk(b, "b", dt)
     out = torch.empty(rows // g, cols, device=a.device, dtype=dt)
-    L.check(_fn("ug_colsum", dt)(a.data_ptr(), a.stride(0), _p(b), b.stride(0) if b is not None else 0, out.data_ptr(), cols, rows, cols, g, alpha, _stream()),
-            "ug_colsum")
+    ws = torch.empty(int(L.load().ug_colsum_workspace_bytes(rows, cols, g)), device=a.device, dtype=torch.uint8)
+    L.check(_fn("ug_colsum", dt)(a.data_ptr(), a.stride(0), _p(b), b.stride(0) if b is not None else 0, out.data_ptr(), cols, rows, cols, g, alpha,
+                                 ws.data_ptr(), ws.numel(), _stream()), "ug_colsum")
     return out
 
 

@@ -73,7 +73,23 @@ def _attention(model, prefix: str, x, enc, rope, text_first: bool):
     return _lin(model, prefix + ".to_out.0", xo), _lin(model, prefix + ".to_add_out", eo)
 
 
+def _ckpt(model, fn, *tensors):
+    """Block-level activation checkpointing when `enable_gradient_checkpointing()` was called (train.py:317), as diffusers does per block."""
+    if getattr(model, "_grad_checkpoint", False):
+        from torch.utils.checkpoint import checkpoint
+        return checkpoint(fn, *tensors, use_reentrant=False)
+    return fn(*tensors)
+
+
 def _double_block(model, prefix: str, x, enc, temb, rope, text_first: bool = True):
+    return _ckpt(model, lambda x_, enc_, temb_: _double_block_body(model, prefix, x_, enc_, temb_, rope, text_first), x, enc, temb)
+
+
+def _single_block(model, prefix: str, h, temb, rope):
+    return _ckpt(model, lambda h_, temb_: _single_block_body(model, prefix, h_, temb_, rope), h, temb)
+
+
+def _double_block_body(model, prefix: str, x, enc, temb, rope, text_first: bool = True):
     """diffusers FluxTransformerBlock.forward. Returns (enc, x)."""
     n, g, sh, sc, gm = _adaln(model, prefix + ".norm1", x, temb, 6)
     nc, cg, csh, csc, cgm = _adaln(model, prefix + ".norm1_context", enc, temb, 6)
@@ -85,7 +101,7 @@ def _double_block(model, prefix: str, x, enc, temb, rope, text_first: bool = Tru
     return enc, x
 
 
-def _single_block(model, prefix: str, h, temb, rope):
+def _single_block_body(model, prefix: str, h, temb, rope):
     """diffusers FluxSingleTransformerBlock.forward."""
     n, gate = _adaln(model, prefix + ".norm", h, temb, 3)
     mlp = A.GeluTanh.apply(_lin(model, prefix + ".proj_mlp", n))
