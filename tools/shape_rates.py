@@ -1,0 +1,39 @@
+"""Per-shape GEMM / attention rates INSIDE the cfg2 forward (KernelTimer events around every launch, grouped by the launch's FLOP count):
+which shapes run below the stand-alone micro-benchmark numbers, and by how much. usage: python tools/shape_rates.py [--batch 4]"""
+import argparse, collections, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from unigen_amd import ops
+from unigen_amd.flux import UniGenFlux
+from unigen_amd.pipeline import prepare_latent_image_ids
+
+ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=4); a = ap.parse_args()
+dev, BF = torch.device("cuda:0"), torch.bfloat16
+model = UniGenFlux.from_config({}, device=dev, dtype=BF)
+model.init_condition_block(condition_nums=1, condition_types=["canny"], control_params=dict(
+    use_rope=True, use_shared_expert=True, use_consis_module=False, use_single_trans_blocks=True, single_control_dev=2,
+    single_block_control_method="overall_add", top_num=1, expert_num_each_condition=3))
+model.init_synthetic_(seed=0, std=0.02)
+B, grid, T = a.batch, 64, 512
+N = grid * grid
+g = torch.Generator(device=dev).manual_seed(5)
+rn = lambda *s: torch.randn(*s, generator=g, device=dev)
+inp = dict(hidden_states=rn(B, N, 64).to(BF), condition_hidden_states=rn(B, N, 64).to(BF), encoder_hidden_states=(0.1 * rn(B, T, 4096)).to(BF),
+           pooled_projections=rn(B, 768).to(BF), condition_pooled_projections=rn(B, 768).to(BF))
+ids = prepare_latent_image_ids(grid, grid, dev, BF)
+txt = torch.zeros(T, 3, device=dev, dtype=BF)
+t = torch.full((B,), 0.75, device=dev, dtype=BF)
+run = lambda: model(timestep=t, img_ids=ids, txt_ids=txt, condition_ids=ids, **inp)
+run(); run()
+timer = ops.KernelTimer(); ops.set_timer(timer)
+for _ in range(3):
+    run()
+torch.cuda.synchronize(); ops.set_timer(None)
+groups = collections.defaultdict(list)
+for kind, flops, e0, e1 in timer.records:
+    groups[(kind, round(flops / 1e9))].append(e0.elapsed_time(e1))
+tot = sum(sum(v) for v in groups.values())
+print(f"{'kind':5s} {'GFLOP/launch':>13s} {'launches':>8s} {'avg us':>9s} {'TFLOP/s':>9s} {'share':>7s}")
+for (kind, gf), v in sorted(groups.items(), key=lambda kv: -sum(kv[1])):
+    avg = sum(v) / len(v)
+    print(f"{kind:5s} {gf:13d} {len(v) // 3:8d} {avg * 1e3:9.1f} {gf / avg:9.1f} {sum(v) / tot:7.1%}")
