@@ -26,6 +26,7 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // LDS-DMA as inline asm: hipcc's waitcnt pass then does not know DMAs are in flight (with the builtin it put `s_waitcnt vmcnt(0)` ahead of
 // the first ds_read behind every barrier, i.e. one segment after the issue instead of two); the kernel states the one wait itself.
 // M0 = LDS byte address of the wave's 1 KiB run (lane l lands at + 16 l); one wait state between the SALU write of M0 and the DMA.
+// (M0 is a reserved register for hipcc - it never keeps a value there across statements and rejects it on a clobber list - so writing it here is safe.)
 __device__ __forceinline__ unsigned lds_addr(const unsigned char* l) { return (unsigned)(size_t)(lptr_t)l; }
 __device__ __forceinline__ const void* uniform_ptr(const void* p) {      // pin a wave-uniform pointer into an SGPR pair
     const unsigned long long a = (unsigned long long)p;
