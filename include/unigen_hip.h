@@ -325,9 +325,11 @@ int ug_qk_rmsnorm_rope_bwd(const void* x, int64_t ldx, const void* dy, int64_t l
                            const float* cos_tab, const float* sin_tab, int64_t rows, int64_t rows_per_batch, int64_t pos_offset, int32_t heads,
                            int32_t dh, float eps, ug_stream_t stream);
 /* attention backward between its GEMMs (F.scaled_dot_product_attention, src/UniGenUtils.py:601): lse[r] = logsumexp(scale * S[r][:]);
- * P = exp(scale * S - lse); delta[g][r] = sum_c dO[r][g*cols + c] * O[r][g*cols + c]; dS = scale * P * (dP - delta). S, dP fp32. */
+ * P = exp(scale * S - lse) for the first valid_cols columns, 0 for the rest (zero-padded keys: sequence lengths are padded to the GEMM's
+ * contraction granularity); delta[g][r] = sum_c dO[r][g*cols + c] * O[r][g*cols + c]; dS = scale * P * (dP - delta). S, dP fp32. */
 int ug_row_lse(const float* S, int64_t ld, float* lse, int64_t rows, int64_t cols, float scale, ug_stream_t stream);
-int ug_attn_prob(const float* S, int64_t ld_s, const float* lse, void* P, int64_t ld_p, int64_t rows, int64_t cols, float scale, ug_stream_t stream);
+int ug_attn_prob(const float* S, int64_t ld_s, const float* lse, void* P, int64_t ld_p, int64_t rows, int64_t cols, int64_t valid_cols, float scale,
+                 ug_stream_t stream);
 int ug_attn_dscore(const void* P, int64_t ld_p, const float* dP, int64_t ld_dp, const float* delta, void* dS, int64_t ld_ds, int64_t rows, int64_t cols,
                    float scale, ug_stream_t stream);
 int ug_rowdot(const void* a, int64_t lda, const void* b, int64_t ldb, float* out, int64_t rows, int64_t groups, int64_t cols, ug_stream_t stream);
@@ -342,7 +344,8 @@ int ug_adaln_modulate_bwd_f32(const void* x, int64_t ldx, const void* dy, int64_
 int ug_qk_rmsnorm_rope_bwd_f32(const void* x, int64_t ldx, const void* dy, int64_t lddy, void* dx, int64_t lddx, void* dwx, const void* w,
                                const float* cos_tab, const float* sin_tab, int64_t rows, int64_t rows_per_batch, int64_t pos_offset, int32_t heads,
                                int32_t dh, float eps, ug_stream_t stream);
-int ug_attn_prob_f32(const float* S, int64_t ld_s, const float* lse, void* P, int64_t ld_p, int64_t rows, int64_t cols, float scale, ug_stream_t stream);
+int ug_attn_prob_f32(const float* S, int64_t ld_s, const float* lse, void* P, int64_t ld_p, int64_t rows, int64_t cols, int64_t valid_cols, float scale,
+                     ug_stream_t stream);
 int ug_attn_dscore_f32(const void* P, int64_t ld_p, const float* dP, int64_t ld_dp, const float* delta, void* dS, int64_t ld_ds, int64_t rows,
                        int64_t cols, float scale, ug_stream_t stream);
 int ug_rowdot_f32(const void* a, int64_t lda, const void* b, int64_t ldb, float* out, int64_t rows, int64_t groups, int64_t cols, ug_stream_t stream);

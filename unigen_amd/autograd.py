@@ -104,8 +104,11 @@ class AdaLNModulate(torch.autograd.Function):
         B, Ls, D = ctx.geom
         dy2 = dy.reshape(B * Ls, D).contiguous()
         dx, dyx = ops.adaln_modulate_bwd(x2, dy2, scale, rows_per_sample=Ls, eps=ctx.eps)
-        dshift = ops.colsum(dy2, rows_per_group=Ls)
-        dscale = ops.colsum(dyx, rows_per_group=Ls)
+        if Ls == 1:                       # per-token modulation (SD3 transformer-block experts): nothing to sum
+            dshift, dscale = dy2, dyx
+        else:
+            dshift = ops.colsum(dy2, rows_per_group=Ls)
+            dscale = ops.colsum(dyx, rows_per_group=Ls)
         return dx.view(B, Ls, D), dshift, dscale, None
 
 
@@ -148,7 +151,8 @@ def qk_norm_rope(x, w, rope, heads: int, pos_offset: int = 0, eps: float = 1e-6)
 class FlashAttention(torch.autograd.Function):
     """F.scaled_dot_product_attention over heads packed as [B, L, H * dh] (any row stride). Forward: ug_flash_attn_fwd. Backward, per sample and
     for all heads at once (grouped GEMMs): S = Q K^T (fp32) -> lse -> P; dP = dO V^T; dS = scale P (dP - rowsum(dO O));
-    dV = P^T dO, dK = dS^T Q, dQ = dS K. Lq and Lkv must be multiples of 64 (they become contraction lengths)."""
+    dV = P^T dO, dK = dS^T Q, dQ = dS K. Lq and Lkv become contraction lengths: other lengths are zero-padded to multiples of 64 (padded keys get
+    P = 0, padded queries carry dO = 0)."""
 
     @staticmethod
     def forward(ctx, q, k, v, heads):
@@ -169,18 +173,22 @@ class FlashAttention(torch.autograd.Function):
         B, Lq, HD = q.shape
         Lkv = k.shape[1]
         dh = HD // H
-        if Lq % 64 or Lkv % 64:
-            raise L.UniGenHipError(f"attention backward: sequence lengths ({Lq}, {Lkv}) must be multiples of 64")
         dt, dev = q.dtype, q.device
         scale = dh ** -0.5
         do = do.contiguous()
+        Lq0, Lkv0 = Lq, Lkv
+        if Lq % 64 or Lkv % 64:
+            Lq, Lkv = _pad64(Lq), _pad64(Lkv)
+            padr = lambda t, n: torch.nn.functional.pad(t, (0, 0, 0, n - t.shape[1]))
+            q, o, do = padr(q, Lq), padr(o, Lq), padr(do, Lq)
+            k, v = padr(k, Lkv), padr(v, Lkv)
         dq, dk, dv = torch.empty(B, Lq, HD, device=dev, dtype=dt), torch.empty(B, Lkv, HD, device=dev, dtype=dt), torch.empty(B, Lkv, HD, device=dev, dtype=dt)
         S, dP = torch.empty(H, Lq, Lkv, device=dev, dtype=torch.float32), torch.empty(H, Lq, Lkv, device=dev, dtype=torch.float32)
         for b in range(B):
             qb, kb, vb, ob, dob = q[b], k[b], v[b], o[b], do[b]
             ops.gemm(qb[:, :dh], kb[:, :dh], None, S, M=Lq, epilogue=L.EPI_F32, groups=H, a_gstride=dh, w_gstride=dh, c_gstride=Lq * Lkv, ldc=Lkv)
-            lse = ops.row_lse(S.view(H * Lq, Lkv), scale)
-            P = ops.attn_prob(S.view(H * Lq, Lkv), lse, scale, dt)
+            lse = ops.row_lse(S.view(H * Lq, Lkv), scale, Lkv0)
+            P = ops.attn_prob(S.view(H * Lq, Lkv), lse, scale, dt, Lkv0)
             ops.gemm(dob[:, :dh], vb[:, :dh], None, dP, M=Lq, epilogue=L.EPI_F32, groups=H, a_gstride=dh, w_gstride=dh, c_gstride=Lq * Lkv, ldc=Lkv)
             delta = ops.rowdot(dob, ob, H)                                   # [H, Lq]
             dS = ops.attn_dscore(P, dP.view(H * Lq, Lkv), delta.view(-1), scale)
@@ -192,7 +200,7 @@ class FlashAttention(torch.autograd.Function):
             ops.gemm(PT, dOT, None, dv[b], M=Lkv, a_gstride=Lkv * Lq, w_gstride=dh * Lq, **g)
             ops.gemm(dST, QT, None, dk[b], M=Lkv, a_gstride=Lkv * Lq, w_gstride=dh * Lq, **g)
             ops.gemm(dS3, KT, None, dq[b], M=Lq, a_gstride=Lq * Lkv, w_gstride=dh * Lkv, **g)
-        return dq, dk, dv, None
+        return dq[:, :Lq0], dk[:, :Lkv0], dv[:, :Lkv0], None
 
 
 def attention(q, k, v, heads: int):

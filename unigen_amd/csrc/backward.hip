@@ -202,13 +202,14 @@ __global__ __launch_bounds__(256) void row_lse_kernel(const float* __restrict__ 
     for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
     if (threadIdx.x == 0) lse[blockIdx.x] = mx + logf(red[0]);
 }
-// P[r][c] = exp(scale S[r][c] - lse[r])
+// P[r][c] = c < valid_cols ? exp(scale S[r][c] - lse[r]) : 0   (columns past valid_cols are zero-padded keys)
 template <typename T>
-__global__ void attn_prob_kernel(const float* __restrict__ S, int64_t ld_s, const float* __restrict__ lse, T* __restrict__ P, int64_t ld_p, int64_t rows, int cols, float scale) {
+__global__ void attn_prob_kernel(const float* __restrict__ S, int64_t ld_s, const float* __restrict__ lse, T* __restrict__ P, int64_t ld_p, int64_t rows, int cols,
+                                 int valid_cols, float scale) {
     const int64_t total = rows * cols;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = i / cols; const int c = (int)(i - r * cols);
-        ElemT<T>::st(P + r * ld_p + c, expf(S[r * ld_s + c] * scale - lse[r]));
+        ElemT<T>::st(P + r * ld_p + c, c < valid_cols ? expf(S[r * ld_s + c] * scale - lse[r]) : 0.f);
     }
 }
 // dS[r][c] = scale P[r][c] (dP[r][c] - delta[r])
@@ -304,10 +305,13 @@ int qk_bwd_impl(const void* x, int64_t ldx, const void* dy, int64_t lddy, void* 
     return UG_OK;
 }
 template <typename T>
-int attn_prob_impl(const float* S, int64_t ld_s, const float* lse, void* P, int64_t ld_p, int64_t rows, int64_t cols, float scale, ug_stream_t stream) {
+int attn_prob_impl(const float* S, int64_t ld_s, const float* lse, void* P, int64_t ld_p, int64_t rows, int64_t cols, int64_t valid_cols, float scale,
+                   ug_stream_t stream) {
     if (rows == 0) return UG_OK;
-    UG_REQUIRE(S && lse && P && rows > 0 && cols > 0 && ld_s >= cols && ld_p >= cols, UG_ERR_BAD_SHAPE, "ug_attn_prob: bad arguments");
-    hipLaunchKernelGGL(attn_prob_kernel<T>, dim3(grid1d(rows * cols, 256 * 8)), dim3(256), 0, (hipStream_t)stream, S, ld_s, lse, (T*)P, ld_p, rows, (int)cols, scale);
+    UG_REQUIRE(S && lse && P && rows > 0 && cols > 0 && valid_cols > 0 && valid_cols <= cols && ld_s >= cols && ld_p >= cols, UG_ERR_BAD_SHAPE,
+               "ug_attn_prob: bad arguments");
+    hipLaunchKernelGGL(attn_prob_kernel<T>, dim3(grid1d(rows * cols, 256 * 8)), dim3(256), 0, (hipStream_t)stream, S, ld_s, lse, (T*)P, ld_p, rows, (int)cols,
+                       (int)valid_cols, scale);
     UG_CHECK_LAUNCH("ug_attn_prob");
     return UG_OK;
 }
@@ -360,8 +364,9 @@ UG_TWINS(ug_qk_rmsnorm_rope_bwd, qk_bwd_impl,
           const float* sin_tab, int64_t rows, int64_t rows_per_batch, int64_t pos_offset, int32_t heads, int32_t dh, float eps, ug_stream_t stream),
          (x, ldx, dy, lddy, dx, lddx, dwx, w, cos_tab, sin_tab, rows, rows_per_batch, pos_offset, heads, dh, eps, stream))
 UG_TWINS(ug_attn_prob, attn_prob_impl,
-         (const float* S, int64_t ld_s, const float* lse, void* P, int64_t ld_p, int64_t rows, int64_t cols, float scale, ug_stream_t stream),
-         (S, ld_s, lse, P, ld_p, rows, cols, scale, stream))
+         (const float* S, int64_t ld_s, const float* lse, void* P, int64_t ld_p, int64_t rows, int64_t cols, int64_t valid_cols, float scale,
+          ug_stream_t stream),
+         (S, ld_s, lse, P, ld_p, rows, cols, valid_cols, scale, stream))
 UG_TWINS(ug_attn_dscore, attn_dscore_impl,
          (const void* P, int64_t ld_p, const float* dP, int64_t ld_dp, const float* delta, void* dS, int64_t ld_ds, int64_t rows, int64_t cols, float scale,
           ug_stream_t stream),

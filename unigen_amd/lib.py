@@ -91,7 +91,7 @@ SIGNATURES.update({
     "ug_adaln_modulate_bwd": (i32, [vp, i64, vp, i64, vp, i64, i64, vp, i64, vp, i64, i64, i64, f32, vp]),
     "ug_qk_rmsnorm_rope_bwd": (i32, [vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, i64, i64, i64, i32, i32, f32, vp]),
     "ug_row_lse": (i32, [vp, i64, vp, i64, i64, f32, vp]),
-    "ug_attn_prob": (i32, [vp, i64, vp, vp, i64, i64, i64, f32, vp]),
+    "ug_attn_prob": (i32, [vp, i64, vp, vp, i64, i64, i64, i64, f32, vp]),
     "ug_attn_dscore": (i32, [vp, i64, vp, i64, vp, vp, i64, i64, i64, f32, vp]),
     "ug_rowdot": (i32, [vp, i64, vp, i64, vp, i64, i64, i64, vp]),
 })

@@ -594,18 +594,19 @@ def qk_rmsnorm_rope_bwd(x: torch.Tensor, dy: torch.Tensor, w: Optional[torch.Ten
     return dx, dwx
 
 
-def row_lse(S: torch.Tensor, scale: float) -> torch.Tensor:
+def row_lse(S: torch.Tensor, scale: float, valid_cols: Optional[int] = None) -> torch.Tensor:
     _chk(S, "S", torch.float32)
     rows, cols = S.shape
     out = torch.empty(rows, device=S.device, dtype=torch.float32)
-    L.check(L.load().ug_row_lse(S.data_ptr(), S.stride(0), out.data_ptr(), rows, cols, scale, _stream()), "ug_row_lse")
+    L.check(L.load().ug_row_lse(S.data_ptr(), S.stride(0), out.data_ptr(), rows, valid_cols or cols, scale, _stream()), "ug_row_lse")
     return out
 
 
-def attn_prob(S: torch.Tensor, lse: torch.Tensor, scale: float, dtype) -> torch.Tensor:
+def attn_prob(S: torch.Tensor, lse: torch.Tensor, scale: float, dtype, valid_cols: Optional[int] = None) -> torch.Tensor:
     rows, cols = S.shape
     P = torch.empty(rows, cols, device=S.device, dtype=dtype)
-    L.check(_fn("ug_attn_prob", dtype)(S.data_ptr(), S.stride(0), lse.data_ptr(), P.data_ptr(), cols, rows, cols, scale, _stream()), "ug_attn_prob")
+    L.check(_fn("ug_attn_prob", dtype)(S.data_ptr(), S.stride(0), lse.data_ptr(), P.data_ptr(), cols, rows, cols, valid_cols or cols, scale, _stream()),
+            "ug_attn_prob")
     return P
 
 

@@ -349,8 +349,16 @@ class UniGenSD3(HipModule):
         return l_aux, exp_counts
 
     # ------------------------------------------------------------------ forward ---------------------------------------
-    @torch.no_grad()
-    def forward(self, hidden_states: torch.Tensor, condition_hidden_states: torch.Tensor = None, conditioning_scale: float = 1.0,
+    def forward(self, *args, **kwargs):
+        """Inference (the in-place HIP engine below, no autograd) or - autograd on and some parameter requiring a gradient, train.py:622-662 after
+        `init_trainable_param()` - the differentiable forward of unigen_amd/training.py. Same arguments, same 3-tuple."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            from . import training
+            return training.sd3_forward(self, *args, **kwargs)
+        with torch.no_grad():
+            return self._forward_inference(*args, **kwargs)
+
+    def _forward_inference(self, hidden_states: torch.Tensor, condition_hidden_states: torch.Tensor = None, conditioning_scale: float = 1.0,
                 encoder_hidden_states: torch.Tensor = None, pooled_projections: torch.Tensor = None,
                 condition_pooled_projections: torch.Tensor = None, timestep: torch.Tensor = None,
                 joint_attention_kwargs: Optional[Dict[str, Any]] = None, skip_layers=None, gate_uniform=None, **kwargs):

@@ -109,16 +109,13 @@ def _single_block_body(model, prefix: str, h, temb, rope):
     return h + gate.unsqueeze(1) * _lin(model, prefix + ".proj_out", torch.cat([a, mlp], dim=2))
 
 
-def _comoe(model, x, cond_tokens, ctrl_enc, control_temb, condition_temb, pooled, cond_pooled, img_ids, txt_ids, cond_ids, uniform):
-    """preprocess_moe_forward + moe_forward for one condition (src/UniGenTransformer.py:969-1068; deepspeed top1gating).
-    Routing decisions (argmax, capacity, Random Token Selection) are the HIP kernel's; what is differentiable - the gate probabilities in
-    the combine weights and in l_aux - stays on the tape."""
-    ctl, dt = model._ctl, x.dtype
+def _route(model, x, c, uniform):
+    """TopKGate + top1gating (deepspeed 0.16.5): fp32 gate softmax on (x + c); routing decisions (argmax, capacity, Random Token
+    Selection) from the HIP kernel; what is differentiable - the gate probabilities in the combine weights and in l_aux - stays on the tape."""
     B, N, D = x.shape
-    E, S = ctl.expert_nums, B * N
+    E, S = model._ctl.expert_nums, B * N
     C = max(int(math.ceil(S / E)), 4)
-    c = _lin(model, "control_x_embedder", cond_tokens)
-    logits = F.linear((x + c).reshape(S, D).float(), model.get_parameter("moe.moe_layer.gate.wg.weight").float())     # TopKGate: fp32
+    logits = F.linear((x + c).reshape(S, D).float(), model.get_parameter("moe.moe_layer.gate.wg.weight").float())
     gates = F.softmax(logits, dim=1)
     idx = torch.argmax(gates, dim=1).to(torch.int32)
     if uniform is None:
@@ -126,32 +123,40 @@ def _comoe(model, x, cond_tokens, ctrl_enc, control_temb, condition_temb, pooled
     slot, tos = torch.empty(S, device=x.device, dtype=torch.int32), torch.empty(E, C, device=x.device, dtype=torch.int32)
     exp_counts, l_aux_k = torch.empty(E, device=x.device, dtype=torch.int64), torch.empty(1, device=x.device, dtype=torch.float32)
     ops.moe_capacity_rts(gates.detach().contiguous(), idx, uniform.contiguous(), C, slot, tos, exp_counts, l_aux_k)
-    ce = F.one_hot(idx.long(), E).float().mean(0)
-    l_aux = torch.sum(gates.mean(0) * ce) * E
-    # dispatch = row gather (einsum("sec,sm->ecm") with a one-hot mask), zeros in empty slots
+    l_aux = torch.sum(gates.mean(0) * F.one_hot(idx.long(), E).float().mean(0)) * E
     tos_l = tos.view(-1).long()
-    valid = tos_l >= 0
-    src = tos_l.clamp_min(0)
+    valid, src = tos_l >= 0, tos_l.clamp_min(0)
+    dispatch = lambda t2d: (t2d[src] * valid.unsqueeze(1).to(t2d.dtype)).view(E, C, -1)      # einsum("sec,sm->ecm") with a one-hot mask
+    kept = slot >= 0
+    flat = (idx.long() * C + slot.long()).clamp_min(0)
+    w = (gates.gather(1, idx.long().unsqueeze(1)).squeeze(1) * kept.float()).to(x.dtype).unsqueeze(1)    # combine weight, rounded as `cw.to(dt)`
+    combine = lambda y: (w * y.reshape(E * C, D)[flat]).view(B, N, D)                          # einsum("sec,ecm->sm")
+    return dispatch, combine, src // N, l_aux, exp_counts, E, C
 
-    def dispatch(t2d):
-        return (t2d[src] * valid.unsqueeze(1).to(t2d.dtype)).view(E, C, -1)
 
-    xd, cd = dispatch(x.reshape(S, D)), dispatch(c.reshape(S, D))
-    sample_of = (src // N)
+def _experts_modulated(model, x, c, pooled, cond_pooled, uniform):
+    """expert_forward with modulated linears (src/UniGenTransformer.py:957-959): c' = W_c (s_c * c) + b_c ; h' = W_h (s_h * (h + c')) + b_h."""
+    B, N, D = x.shape
+    dispatch, combine, sample_of, l_aux, exp_counts, E, C = _route(model, x, c, uniform)
+    xd, cd = dispatch(x.reshape(B * N, D)), dispatch(c.reshape(B * N, D))
     pe = "moe.moe_layer.experts.deepspeed_experts."
     yh, yc = [], []
     for e in range(E):
         rows = slice(e * C, (e + 1) * C)
         s_c = _lin(model, f"{pe}{e}.0.1", cond_pooled)[sample_of[rows]]          # the modulation vector of each slot's sample
         s_h = _lin(model, f"{pe}{e}.1.1", pooled)[sample_of[rows]]
-        c_e = _lin(model, f"{pe}{e}.0.0", s_c * cd[e])                          # expert_forward :957-959: Linear_W(s * x) + b
+        c_e = _lin(model, f"{pe}{e}.0.0", s_c * cd[e])
         h_e = _lin(model, f"{pe}{e}.1.0", s_h * (xd[e] + c_e))
         yh.append(h_e); yc.append(c_e)
-    yh, yc = torch.stack(yh).view(E * C, D), torch.stack(yc).view(E * C, D)
-    kept = slot >= 0
-    flat = (idx.long() * C + slot.long()).clamp_min(0)
-    w = (gates.gather(1, idx.long().unsqueeze(1)).squeeze(1) * kept.float()).to(dt).unsqueeze(1)     # combine weight, rounded as `cw.to(dt)`
-    eh, ec = (w * yh[flat]).view(B, N, D), (w * yc[flat]).view(B, N, D)
+    return combine(torch.stack(yh)), combine(torch.stack(yc)), l_aux, exp_counts
+
+
+def _comoe(model, x, cond_tokens, ctrl_enc, control_temb, condition_temb, pooled, cond_pooled, img_ids, txt_ids, cond_ids, uniform):
+    """preprocess_moe_forward + moe_forward for one condition (src/UniGenTransformer.py:969-1068)."""
+    ctl = model._ctl
+    N = x.shape[1]
+    c = _lin(model, "control_x_embedder", cond_tokens)
+    eh, ec, l_aux, exp_counts = _experts_modulated(model, x, c, pooled, cond_pooled, uniform)
     if not ctl.use_shared_expert:
         return eh, ec, l_aux, exp_counts
     round_to = img_ids.dtype if ctl.use_rope else None
@@ -224,4 +229,139 @@ def flux_forward(model, hidden_states, condition_hidden_states=None, conditionin
     e = _lin(model, "norm_out.linear", F.silu(temb).to(dt))                     # AdaLayerNormContinuous: (scale, shift)
     scale, shift = e.chunk(2, dim=1)
     out = _lin(model, "proj_out", A.adaln_modulate(x.contiguous(), shift, scale))
+    return out, dict(moe_loss=moe["l_aux"] * 0.1), dict(expert_counts=moe["exp_counts"])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# UniGenSD3 (src/UniGenTransformer.py:625-710; blocks as restated by the reference at src/UniGenUtils.py:340-522)
+# ---------------------------------------------------------------------------------------------------------------------
+def _gate(g, y):
+    return g * y if g.dim() == y.dim() else g.unsqueeze(1) * y
+
+
+def _mod(x, shift, scale):
+    """LayerNorm(x) * (1 + scale) + shift with per-sample [B, D] or per-token [B, L, D] modulation (the reference's extension, :354-363)."""
+    if scale.dim() == 3:
+        B, Ls, D = x.shape
+        return A.adaln_modulate(x.reshape(B * Ls, 1, D), shift.reshape(B * Ls, D), scale.reshape(B * Ls, D)).view(B, Ls, D)
+    return A.adaln_modulate(x, shift, scale)
+
+
+def _sd3_attention(model, prefix: str, x, enc, context_pre_only: bool = False):
+    """Attention + JointAttnProcessor2_0 (sample-first concat, no RoPE); q/k RMSNorm when the weights exist."""
+    H, N = model._heads, x.shape[1]
+    nrm = lambda t, name: A.qk_norm_rope(t, _p(model, f"{prefix}.{name}.weight"), None, H)
+    q, k, v = nrm(_lin(model, prefix + ".to_q", x), "norm_q"), nrm(_lin(model, prefix + ".to_k", x), "norm_k"), _lin(model, prefix + ".to_v", x)
+    if enc is None:
+        return _lin(model, prefix + ".to_out.0", A.attention(q, k, v, H)), None
+    eq, ek = nrm(_lin(model, prefix + ".add_q_proj", enc), "norm_added_q"), nrm(_lin(model, prefix + ".add_k_proj", enc), "norm_added_k")
+    ev = _lin(model, prefix + ".add_v_proj", enc)
+    o = A.attention(torch.cat([q, eq], 1), torch.cat([k, ek], 1), torch.cat([v, ev], 1), H)
+    xo = _lin(model, prefix + ".to_out.0", o[:, :N])
+    return xo, (None if context_pre_only else _lin(model, prefix + ".to_add_out", o[:, N:]))
+
+
+def _sd3_joint_block(model, prefix: str, x, enc, temb, context_pre_only: bool = False, dual: bool = False):
+    """JointTransformerBlock.forward as restated by the reference (src/UniGenUtils.py:440-522). Returns (enc or None, x)."""
+    ch = _lin(model, prefix + ".norm1.linear", F.silu(temb)).chunk(9 if dual else 6, dim=-1)
+    n = _mod(x, ch[0], ch[1])
+    g, shm, scm, gm = ch[2:6]
+    if context_pre_only:                                        # AdaLayerNormContinuous: (scale, shift)
+        e = _lin(model, prefix + ".norm1_context.linear", F.silu(temb).to(enc.dtype)).chunk(2, dim=-1)
+        nc = _mod(enc, e[1], e[0])
+    else:
+        cc = _lin(model, prefix + ".norm1_context.linear", F.silu(temb)).chunk(6, dim=-1)
+        nc = _mod(enc, cc[0], cc[1])
+    a, ca = _sd3_attention(model, prefix + ".attn", n, nc, context_pre_only)
+    if dual:                                                    # SD35AdaLayerNormZeroX: norm_hidden_states2 from the block's INPUT
+        a2, _ = _sd3_attention(model, prefix + ".attn2", _mod(x, ch[6], ch[7]), None)
+    x = x + _gate(g, a)
+    if dual:
+        x = x + _gate(ch[8], a2)
+    x = x + _gate(gm, _feed_forward(model, prefix + ".ff", _mod(x, shm, scm)))
+    if context_pre_only:
+        return None, x
+    enc = enc + _gate(cc[2], ca)
+    enc = enc + _gate(cc[5], _feed_forward(model, prefix + ".ff_context", _mod(enc, cc[3], cc[4])))
+    return enc, x
+
+
+def _sd3_single_block(model, prefix: str, x, temb):
+    """SD3SingleTransformerBlock.forward (src/UniGenUtils.py:386-414); temb per sample [B, D] or per token [B, L, D]."""
+    ch = _lin(model, prefix + ".norm1.linear", F.silu(temb)).chunk(6, dim=-1)
+    a, _ = _sd3_attention(model, prefix + ".attn", _mod(x, ch[0], ch[1]), None)
+    x = x + _gate(ch[2], a)
+    return x + _gate(ch[5], _feed_forward(model, prefix + ".ff", _mod(x, ch[3], ch[4])))
+
+
+def _sd3_patch_embed(model, prefix: str, latents):
+    """PatchEmbed: Conv2d(k = s = patch) as a GEMM over unfolded patches, + the centre-cropped sincos table (fp32 add, cast back)."""
+    cfg, D = model.config, model.inner_dim
+    B, C, Hh, Ww = latents.shape
+    p = cfg.patch_size
+    h, w = Hh // p, Ww // p
+    patches = latents.view(B, C, h, p, w, p).permute(0, 2, 4, 1, 3, 5).reshape(B, h * w, C * p * p)
+    x = A.linear(patches, model.get_parameter(prefix + ".proj.weight").view(D, C * p * p), model.get_parameter(prefix + ".proj.bias"))
+    mx = cfg.pos_embed_max_size
+    top, left = (mx - h) // 2, (mx - w) // 2
+    tab = getattr(model, prefix).pos_embed.reshape(mx, mx, D)[top:top + h, left:left + w].reshape(1, h * w, D).float()
+    return (x + tab).to(x.dtype)
+
+
+def _sd3_comoe(model, x, c, ctrl_enc, control_temb, condition_temb, pooled, cond_pooled, uniform):
+    """UniGenBase.moe_forward + expert_forward (src/UniGenTransformer.py:225-296): experts = modulated linears, or two SD3 single blocks per
+    expert fed the dispatched per-token tembs and attending over the expert's capacity slots; then the two shared joint blocks."""
+    ctl = model._ctl
+    B, N, D = x.shape
+    if ctl.modulated:
+        eh, ec, l_aux, exp_counts = _experts_modulated(model, x, c, pooled, cond_pooled, uniform)
+    else:
+        dispatch, combine, sample_of, l_aux, exp_counts, E, C = _route(model, x, c, uniform)
+        xd, cd = dispatch(x.reshape(B * N, D)), dispatch(c.reshape(B * N, D))
+        td, ctd = dispatch(control_temb[:, None].expand(-1, N, -1).reshape(B * N, D)), dispatch(condition_temb[:, None].expand(-1, N, -1).reshape(B * N, D))
+        pe = "moe.moe_layer.experts.deepspeed_experts."
+        yh = [_sd3_single_block(model, f"{pe}{e}.0", xd[e][None], td[e][None])[0] for e in range(E)]
+        yc = [_sd3_single_block(model, f"{pe}{e}.1", cd[e][None], ctd[e][None])[0] for e in range(E)]
+        eh, ec = combine(torch.stack(yh)), combine(torch.stack(yc))
+    if not ctl.use_shared_expert:
+        return eh, ec, l_aux, exp_counts
+    cond_s, x_s = _sd3_joint_block(model, "shared_expert.0", x, c, condition_temb)
+    _, hc = _sd3_joint_block(model, "shared_expert.1", torch.cat([x_s, cond_s], 1), ctrl_enc, control_temb, context_pre_only=True, dual=True)
+    return hc[:, :N] + eh, hc[:, N:] + ec, l_aux, exp_counts
+
+
+def sd3_forward(model, hidden_states, condition_hidden_states=None, conditioning_scale: float = 1.0, encoder_hidden_states=None,
+                pooled_projections=None, condition_pooled_projections=None, timestep=None, gate_uniform=None, **_):
+    """UniGenSD3.forward (src/UniGenTransformer.py:625-710) under autograd: NCHW latents in, NCHW out; the timestep is used as given."""
+    cfg, ctl = model.config, model._ctl
+    dt = model._check_dtype(hidden_states, encoder_hidden_states)
+    B, _, height, width = hidden_states.shape
+    p, Lyr = cfg.patch_size, cfg.num_layers
+    h, w = height // p, width // p
+    t_f32 = timestep.to(hidden_states.device).float().expand(B).contiguous()
+    pooled, cpooled = pooled_projections.to(dt).contiguous(), condition_pooled_projections.to(dt).contiguous()
+    x = _sd3_patch_embed(model, "pos_embed", hidden_states.to(dt))
+    temb = _time_text_embed(model, "time_text_embed", t_f32, pooled, None)
+    enc = _lin(model, "context_embedder", encoder_hidden_states.to(dt))
+    moe = None
+    for i in range(Lyr):
+        last, dual = i == Lyr - 1, i in cfg.dual_attention_layers
+        enc_new, x = _sd3_joint_block(model, f"transformer_blocks.{i}", x, enc, temb, context_pre_only=last, dual=dual)
+        if moe is None:
+            c = _sd3_patch_embed(model, "control_pos_embed_input", condition_hidden_states.to(dt))
+            control_pooled = pooled if ctl.use_pooled_prompt_embeds else torch.zeros_like(pooled)
+            control_temb = _time_text_embed(model, "control_time_text_embed", t_f32, control_pooled, None)
+            condition_temb = _time_text_embed(model, "control_condition_embed", t_f32, cpooled, None)
+            ctrl_enc = _lin(model, "control_context_embedder", enc_new)
+            eh, ec, l_aux, exp_counts = _sd3_comoe(model, x, c, ctrl_enc, control_temb, condition_temb, pooled, cpooled, gate_uniform)
+            moe = dict(ctrl_enc=ctrl_enc, condition_temb=condition_temb, l_aux=l_aux, exp_counts=exp_counts)
+            z_in = eh + ec
+        else:
+            z_in = x
+        enc = enc_new
+        _, z = _sd3_joint_block(model, f"control_transformer_blocks.{i}", z_in, moe["ctrl_enc"], moe["condition_temb"], dual=dual)
+        x = x + _lin(model, f"controlnet_add_blocks.{i}", z) * conditioning_scale
+    e = _lin(model, "norm_out.linear", F.silu(temb).to(dt)).chunk(2, dim=1)
+    out = _lin(model, "proj_out", A.adaln_modulate(x.contiguous(), e[1], e[0]))
+    out = out.view(B, h, w, p, p, model.out_channels).permute(0, 5, 1, 3, 2, 4).reshape(B, model.out_channels, h * p, w * p)
     return out, dict(moe_loss=moe["l_aux"] * 0.1), dict(expert_counts=moe["exp_counts"])
