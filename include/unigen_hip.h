@@ -333,6 +333,17 @@ int ug_attn_prob(const float* S, int64_t ld_s, const float* lse, void* P, int64_
 int ug_attn_dscore(const void* P, int64_t ld_p, const float* dP, int64_t ld_dp, const float* delta, void* dS, int64_t ld_ds, int64_t rows, int64_t cols,
                    float scale, ug_stream_t stream);
 int ug_rowdot(const void* a, int64_t lda, const void* b, int64_t ldb, float* out, int64_t rows, int64_t groups, int64_t cols, ug_stream_t stream);
+/* F.scaled_dot_product_attention backward on the forward kernel's tiling (bf16): dq, dk, dv from q, k, v, o, dout in the forward's [batch][row][head*dh]
+ * strided layout. Four launches of one kernel (row statistics lse, then dQ, dK, dV, each recomputing its score tiles; csrc/attention.hip) plus
+ * delta = rowsum(dout * o). workspace: ug_flash_attn_bwd_workspace_bytes() bytes, 16-byte aligned (lse and delta, fp32 per (batch, head, query)).
+ * The fp32 verification path keeps the GEMM-based formulation of unigen_amd/autograd.py. */
+int64_t ug_flash_attn_bwd_workspace_bytes(int64_t batches, int32_t heads, int64_t Lq);
+int ug_flash_attn_bwd(const void* q, int64_t q_row_stride, int64_t q_batch_stride, const void* k, int64_t k_row_stride, int64_t k_batch_stride,
+                      const void* v, int64_t v_row_stride, int64_t v_batch_stride, const void* o, int64_t o_row_stride, int64_t o_batch_stride,
+                      const void* dout, int64_t do_row_stride, int64_t do_batch_stride, void* dq, int64_t dq_row_stride, int64_t dq_batch_stride,
+                      void* dk, int64_t dk_row_stride, int64_t dk_batch_stride, void* dv, int64_t dv_row_stride, int64_t dv_batch_stride,
+                      int64_t batches, int32_t heads, int64_t Lq, int64_t Lkv, int32_t dh, float softmax_scale, void* workspace,
+                      int64_t workspace_bytes, ug_stream_t stream);
 int ug_transpose_f32(const void* src, int64_t ld_src, int64_t src_bstride, void* dst, int64_t ld_dst, int64_t dst_bstride, int64_t batch, int64_t rows,
                      int64_t cols, int64_t rows_pad, ug_stream_t stream);
 int ug_colsum_f32(const void* a, int64_t lda, const void* b, int64_t ldb, void* out, int64_t ldo, int64_t rows, int64_t cols, int64_t rows_per_group,

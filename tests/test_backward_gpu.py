@@ -114,3 +114,46 @@ def test_attention_backward(gpu):
 
         hip = lambda qkv: A.attention(qkv[:, Lkv - Lq:, :D], qkv[:, :, D:2 * D], qkv[:, :, 2 * D:], H)
         run_case(gpu, hip, ref, [qkv], name=f"attention_dh{dh}_{Lq}x{Lkv}")
+
+
+@pytest.mark.parametrize("dh,H,B,Lq,Lkv", [(128, 3, 2, 300, 333), (64, 2, 1, 64, 64), (128, 2, 2, 600, 520), (64, 4, 2, 257, 129)])
+def test_flash_attention_backward_kernels(gpu, dh, H, B, Lq, Lkv, monkeypatch):
+    """ug_flash_attn_bwd (lse / dQ / dK / dV kernels on the forward's tiling) against torch autograd of SDPA in fp32 on the CPU, ragged lengths,
+    strided q / k / v inside one [B, L, 3 H dh] buffer; and against the GEMM formulation of the same backward (UG_ATTN_BWD=gemm)."""
+    from unigen_amd import autograd as A
+    g = torch.Generator().manual_seed(Lq + Lkv)
+    D = H * dh
+    qkv = torch.randn(B, Lkv, 3 * D, generator=g)
+    dy = torch.randn(B, Lq, D, generator=g)
+
+    def ref(qkv):
+        q, k, v = qkv[:, :Lq, :D] if Lq <= Lkv else None, qkv[:, :, D:2 * D], qkv[:, :, 2 * D:]
+        o = R._sdpa(R._heads(q, H), R._heads(k, H), R._heads(v, H))
+        return o.transpose(1, 2).reshape(B, Lq, D)
+
+    if Lq > Lkv:          # queries from their own buffer
+        qsrc = torch.randn(B, Lq, D, generator=g)
+        t_in = [qsrc.clone().requires_grad_(True), qkv.clone().requires_grad_(True)]
+        o = R._sdpa(R._heads(t_in[0], H), R._heads(t_in[1][:, :, D:2 * D], H), R._heads(t_in[1][:, :, 2 * D:], H)).transpose(1, 2).reshape(B, Lq, D)
+    else:
+        t_in = [qkv.clone().requires_grad_(True)]
+        o = ref(t_in[0])
+    o.backward(dy)
+    truth = [t.grad for t in t_in]
+
+    def run():
+        h_in = [t.detach().clone().to(BF).to(gpu).requires_grad_(True) for t in t_in]
+        if Lq > Lkv:
+            out = A.attention(h_in[0], h_in[1][:, :, D:2 * D], h_in[1][:, :, 2 * D:], H)
+        else:
+            out = A.attention(h_in[0][:, :Lq, :D], h_in[0][:, :, D:2 * D], h_in[0][:, :, 2 * D:], H)
+        out.backward(dy.to(BF).to(gpu))
+        return [t.grad for t in h_in]
+
+    flash = run()
+    monkeypatch.setenv("UG_ATTN_BWD", "gemm")
+    gemm = run()
+    for i, (f, gm, tr) in enumerate(zip(flash, gemm, truth)):
+        e_f, e_g = rel(f, tr), rel(gm, tr)
+        print(f"backward flash attention dh{dh} {Lq}x{Lkv} grad[{i}]: flash {e_f:.3e}, gemm formulation {e_g:.3e}")
+        assert torch.isfinite(f.float()).all() and e_f <= max(1.5 * e_g, 6e-3), (i, e_f, e_g)

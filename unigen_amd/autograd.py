@@ -5,6 +5,7 @@ backward as five grouped GEMMs per sample around the elementwise kernels of csrc
 as in the forward. There is no CPU path."""
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -176,6 +177,10 @@ class FlashAttention(torch.autograd.Function):
         dt, dev = q.dtype, q.device
         scale = dh ** -0.5
         do = do.contiguous()
+        if dt == torch.bfloat16 and os.environ.get("UG_ATTN_BWD", "flash") != "gemm":
+            # product path: the tiled backward kernels (csrc/attention.hip); UG_ATTN_BWD=gemm keeps the GEMM formulation below (A/B, and what fp32 runs)
+            dq, dk, dv = ops.flash_attn_bwd(q, k, v, o, do, heads=H)
+            return dq, dk, dv, None
         Lq0, Lkv0 = Lq, Lkv
         if Lq % 64 or Lkv % 64:
             Lq, Lkv = _pad64(Lq), _pad64(Lkv)

@@ -934,6 +934,218 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
 }
 
+
+// =====================================================================================================================
+// Attention BACKWARD (the autograd of F.scaled_dot_product_attention, src/UniGenUtils.py:601) on the forward kernel's
+// tiling. One kernel, four modes; a workgroup OWNS 256 rows of one side (each wave 32, their fragments in registers as the B operand, the owned
+// row index on the LANE) and STREAMS 64-row tiles of the other side through the forward's swizzled LDS image (row reads for the score-like
+// products, transposed reads for the accumulating product):
+//   LSE : owns queries,  streams K       : S^T = K Q^T                         -> lse2[q] = log2 sum_k 2^(c S)          (lane-local statistics)
+//   DQ  : owns queries,  streams K, V    : S^T = K Q^T, dP^T = V dO^T, dS^T = scale P^T (dP^T - delta)  -> dQ^T += K^T dS^T
+//   DK  : owns keys,     streams Q, dO   : S   = Q K^T, dP   = dO V^T, dS   = scale P   (dP   - delta)  -> dK^T += Q^T dS
+//   DV  : owns keys,     streams Q, dO   : S   = Q K^T, P                                               -> dV^T += dO^T P
+// with P = 2^(c S - lse2[q]), c = scale log2(e), delta[q] = sum_d dO[q][d] O[q][d]. In every mode the 32x32 accumulator of a score-like product
+// has the streamed index on its rows and the owned index on its lanes, so its registers, packed to bf16, ARE the B operand of the accumulating
+// product (the forward's P^T trick); lse / delta are per lane when queries are owned and per accumulator row when they are streamed. S is
+// recomputed per mode (8 product units against the minimum of 5) - still ~4x less time than moving fp32 score matrices through HBM.
+// =====================================================================================================================
+enum { BWD_LSE = 0, BWD_DQ = 1, BWD_DK = 2, BWD_DV = 3 };
+
+template <int DH, int MODE>
+__global__ __launch_bounds__(512, 2) void attn_bwd_kernel(
+    const bf16_t* __restrict__ own1, int64_t o1_rs, int64_t o1_bs, const bf16_t* __restrict__ own2, int64_t o2_rs, int64_t o2_bs,
+    const bf16_t* __restrict__ st1, int64_t s1_rs, int64_t s1_bs, const bf16_t* __restrict__ st2, int64_t s2_rs, int64_t s2_bs,
+    float* __restrict__ lse2, const float* __restrict__ delta, int64_t stat_ld /* queries per (b, h) row of lse2 / delta */,
+    bf16_t* __restrict__ out, int64_t out_rs, int64_t out_bs, int heads, int Lown, int Lst, int nOwn, float c, float scale) {
+    constexpr int RB = 2 * DH, NCH = DH / 8, TILE = KVB * RB, QS = DH / 16, NDB = DH / 32, NT = 512, NST = (KVB * NCH) / NT;
+    constexpr bool OWN_Q = MODE == BWD_LSE || MODE == BWD_DQ;          // queries owned (statistics lane-local) or streamed
+    constexpr bool TWO = MODE == BWD_DQ || MODE == BWD_DK;             // second score-like product (dP)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [2][tile of st1 | tile of st2]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int ot = blockIdx.x % nOwn, bh = blockIdx.x / nOwn;
+    const int head = bh % heads, b = bh / heads;
+    const bf16_t* O1 = own1 + (int64_t)b * o1_bs + head * DH;
+    const bf16_t* O2 = TWO ? own2 + (int64_t)b * o2_bs + head * DH : nullptr;
+    const bf16_t* S1 = st1 + (int64_t)b * s1_bs + head * DH;
+    const bf16_t* S2 = (MODE != BWD_LSE) ? st2 + (int64_t)b * s2_bs + head * DH : nullptr;
+    const int own_row = ot * 256 + wave * 32 + r;
+    const int own_ld = own_row < Lown ? own_row : Lown - 1;
+    bf16x8 f1[QS], f2[TWO ? QS : 1];
+#pragma unroll
+    for (int s = 0; s < QS; ++s) {
+        f1[s] = *(const bf16x8*)(O1 + (int64_t)own_ld * o1_rs + 16 * s + 8 * h);
+        if constexpr (TWO) f2[s] = *(const bf16x8*)(O2 + (int64_t)own_ld * o2_rs + 16 * s + 8 * h);
+    }
+    const float* stat_l = lse2 + (int64_t)bh * stat_ld;
+    const float* stat_d = (MODE == BWD_DQ || MODE == BWD_DK) ? delta + (int64_t)bh * stat_ld : nullptr;
+    float my_lse = 0.f, my_delta = 0.f;
+    if constexpr (MODE == BWD_DQ) { my_lse = stat_l[own_ld]; my_delta = stat_d[own_ld]; }
+    // staging: thread -> NST chunks of each streamed tile
+    int st_row[NST], st_ch[NST], st_off[NST];
+#pragma unroll
+    for (int u = 0; u < NST; ++u) {
+        const int cid = tid + NT * u;
+        st_row[u] = cid / NCH; st_ch[u] = cid % NCH;
+        st_off[u] = img_off<DH>(st_row[u], st_ch[u]);
+    }
+    u32x4 r1[NST], r2[NST];
+    auto stage_load = [&](int row0) {
+#pragma unroll
+        for (int u = 0; u < NST; ++u) {
+            int row = row0 + st_row[u]; if (row > Lst - 1) row = Lst - 1;
+            r1[u] = *(const u32x4*)(S1 + (int64_t)row * s1_rs + st_ch[u] * 8);
+            if constexpr (MODE != BWD_LSE) r2[u] = *(const u32x4*)(S2 + (int64_t)row * s2_rs + st_ch[u] * 8);
+        }
+    };
+    auto stage_write = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < NST; ++u) {
+            *(u32x4*)(smem + buf * 2 * TILE + st_off[u]) = r1[u];
+            if constexpr (MODE != BWD_LSE) *(u32x4*)(smem + buf * 2 * TILE + TILE + st_off[u]) = r2[u];
+        }
+    };
+    const int rowoff = RB * r;
+    const int kx = h ^ row_swz<DH>(r);
+    const int i16 = lane & 15, g16 = lane >> 4;
+    const int t_key = 4 * h + (i16 >> 2), t_lowch = 2 * (g16 & 1) + ((i16 & 3) >> 1), t_b8 = 8 * (i16 & 1);
+    int toff_lo[NDB], toff_hi[NDB];
+#pragma unroll
+    for (int db = 0; db < NDB; ++db) {
+        const int ch = 4 * db + t_lowch;
+        toff_lo[db] = RB * t_key + 16 * (ch ^ row_swz<DH>(t_key)) + t_b8;
+        toff_hi[db] = RB * (t_key + 8) + 16 * (ch ^ row_swz<DH>(t_key + 8)) + t_b8;
+    }
+    f32x16 acc[MODE == BWD_LSE ? 1 : NDB];
+    if constexpr (MODE != BWD_LSE) {
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[db][i] = 0.f;
+    }
+    float m_run = -INFINITY, l_run = 0.f;
+    const int ntiles = (Lst + KVB - 1) / KVB;
+    stage_load(0);
+    stage_write(0);
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < ntiles) stage_load((t + 1) * KVB);
+        const unsigned char* B1 = smem + cur * 2 * TILE;
+        const unsigned char* B2 = B1 + TILE;
+        bf16x8 zf[2][2];
+        float tmax = -INFINITY;
+        f32x16 x1k[MODE == BWD_LSE ? 2 : 1];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            f32x16 x1, x2;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { x1[i] = 0.f; x2[i] = 0.f; }
+#pragma unroll
+            for (int s = 0; s < QS; ++s) {
+                const bf16x8 a1 = *(const bf16x8*)(B1 + kb * 32 * RB + rowoff + 16 * ((2 * s) ^ kx));
+                x1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, f1[s], x1, 0, 0, 0);
+                if constexpr (TWO) {
+                    const bf16x8 a2 = *(const bf16x8*)(B2 + kb * 32 * RB + rowoff + 16 * ((2 * s) ^ kx));
+                    x2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, f2[s], x2, 0, 0, 0);
+                }
+            }
+            // streamed row of accumulator element i
+            const int srow0 = t * KVB + kb * 32 + 4 * h;
+            if constexpr (MODE == BWD_LSE) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    if (srow0 + (i & 3) + 8 * (i >> 2) >= Lst) x1[i] = -INFINITY;
+                    tmax = fmaxf(tmax, x1[i]);
+                }
+                x1k[kb] = x1;
+            } else {
+                float z[16];
+                float sl[16], sd[16];
+                if constexpr (!OWN_Q) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        int q0 = srow0 + 8 * g; if (q0 > (int)stat_ld - 4) q0 = (int)stat_ld - 4;       // stat rows are padded to a multiple of 64
+                        const f32x4 a = *(const f32x4*)(stat_l + q0);
+                        sl[4 * g] = a[0]; sl[4 * g + 1] = a[1]; sl[4 * g + 2] = a[2]; sl[4 * g + 3] = a[3];
+                        if constexpr (MODE == BWD_DK) {
+                            const f32x4 d4 = *(const f32x4*)(stat_d + q0);
+                            sd[4 * g] = d4[0]; sd[4 * g + 1] = d4[1]; sd[4 * g + 2] = d4[2]; sd[4 * g + 3] = d4[3];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const bool valid = srow0 + (i & 3) + 8 * (i >> 2) < Lst;
+                    const float p = __builtin_amdgcn_exp2f(fmaf(x1[i], c, -(OWN_Q ? my_lse : sl[i])));
+                    float v = p;
+                    if constexpr (TWO) v = p * (x2[i] - (OWN_Q ? my_delta : sd[i])) * scale;
+                    z[i] = valid ? v : 0.f;
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    u32x4 w;
+                    w.x = pack2bf(z[8 * s2 + 0], z[8 * s2 + 1]); w.y = pack2bf(z[8 * s2 + 2], z[8 * s2 + 3]);
+                    w.z = pack2bf(z[8 * s2 + 4], z[8 * s2 + 5]); w.w = pack2bf(z[8 * s2 + 6], z[8 * s2 + 7]);
+                    zf[kb][s2] = __builtin_bit_cast(bf16x8, w);
+                }
+            }
+        }
+        if constexpr (MODE == BWD_LSE) {
+            tmax = ug_max_halves(tmax);
+            const float m_new = fmaxf(m_run, tmax);
+            float sum = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) sum += __builtin_amdgcn_exp2f((x1k[kb][i] - m_new) * c);
+            l_run = l_run * __builtin_amdgcn_exp2f((m_run - m_new) * c) + sum;
+            m_run = m_new;
+        } else {
+            // acc^T[d][own] += T^T[d][streamed] Z[streamed][own], T = st1 (DQ: K, DK: Q) or st2 (DV: dO)
+            const unsigned char* Tb = (MODE == BWD_DV) ? B2 : B1;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int db = 0; db < NDB; ++db) {
+                    const bf16x8 tf = tr_read_pair(Tb + ks * 16 * RB + toff_lo[db], Tb + ks * 16 * RB + toff_hi[db]);
+                    acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf, zf[ks >> 1][ks & 1], acc[db], 0, 0, 0);
+                }
+        }
+        if (t + 1 < ntiles) stage_write(cur ^ 1);
+        __syncthreads();
+    }
+    if constexpr (MODE == BWD_LSE) {
+        const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+        if (own_row < Lown && h == 0) lse2[(int64_t)bh * stat_ld + own_row] = __builtin_amdgcn_logf(l_tot) + m_run * c;     // v_log_f32 = log2
+    } else if (own_row < Lown) {
+        bf16_t* Orow = out + (int64_t)b * out_bs + (int64_t)own_row * out_rs + head * DH;
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                u32x2 w;
+                w.x = pack2bf(acc[db][4 * g4 + 0], acc[db][4 * g4 + 1]);
+                w.y = pack2bf(acc[db][4 * g4 + 2], acc[db][4 * g4 + 3]);
+                *(u32x2*)(Orow + 32 * db + 8 * g4 + 4 * h) = w;
+            }
+    }
+}
+
+// delta[bh][q] = sum_d dO[b][q][h*DH + d] * O[b][q][h*DH + d]; one wave per (b, q, h)
+__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ o, int64_t o_rs, int64_t o_bs, const bf16_t* __restrict__ dout, int64_t d_rs,
+                                                         int64_t d_bs, float* __restrict__ delta, int64_t stat_ld, int64_t total, int heads, int Lq, int dh) {
+    const int lane = threadIdx.x & 63;
+    const int64_t id = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (id >= total) return;
+    const int hd = (int)(id % heads); const int64_t t = id / heads; const int q = (int)(t % Lq); const int64_t b = t / Lq;
+    float acc = 0.f;
+    for (int d = lane; d < dh; d += 64)
+        acc += bf2f(o[b * o_bs + (int64_t)q * o_rs + hd * dh + d]) * bf2f(dout[b * d_bs + (int64_t)q * d_rs + hd * dh + d]);
+    acc = wave_sum(acc);
+    if (lane == 0) delta[(b * heads + hd) * stat_ld + q] = acc;
+}
+
 }  // namespace
 
 extern "C" int ug_flash_attn_fwd(const void* q, int64_t q_row_stride, int64_t q_batch_stride, const void* k,
@@ -995,5 +1207,59 @@ extern "C" int ug_flash_attn_fwd(const void* q, int64_t q_row_stride, int64_t q_
 #undef UG_ATTN_STG
 #undef UG_ATTN_LAUNCH
     UG_CHECK_LAUNCH("ug_flash_attn_fwd");
+    return UG_OK;
+}
+
+extern "C" int64_t ug_flash_attn_bwd_workspace_bytes(int64_t batches, int32_t heads, int64_t Lq) {
+    if (batches <= 0 || heads <= 0 || Lq <= 0) return 0;
+    return 2 * batches * heads * ((Lq + 63) / 64 * 64) * (int64_t)sizeof(float);
+}
+
+extern "C" int ug_flash_attn_bwd(const void* q, int64_t q_rs, int64_t q_bs, const void* k, int64_t k_rs, int64_t k_bs, const void* v, int64_t v_rs,
+                                 int64_t v_bs, const void* o, int64_t o_rs, int64_t o_bs, const void* dout, int64_t do_rs, int64_t do_bs, void* dq,
+                                 int64_t dq_rs, int64_t dq_bs, void* dk, int64_t dk_rs, int64_t dk_bs, void* dv, int64_t dv_rs, int64_t dv_bs,
+                                 int64_t batches, int32_t heads, int64_t Lq, int64_t Lkv, int32_t dh, float softmax_scale, void* workspace,
+                                 int64_t workspace_bytes, ug_stream_t stream) {
+    if (batches == 0 || Lq == 0) return UG_OK;
+    UG_REQUIRE(q && k && v && o && dout && dq && dk && dv && batches > 0 && heads > 0 && Lq > 0 && Lkv > 0, UG_ERR_BAD_SHAPE, "ug_flash_attn_bwd: bad arguments");
+    UG_REQUIRE(dh == 128 || dh == 64, UG_ERR_UNSUPPORTED, "ug_flash_attn_bwd: head dim %d not in {64, 128}", dh);
+    UG_REQUIRE(Lq < (1 << 30) && Lkv < (1 << 30), UG_ERR_UNSUPPORTED, "ug_flash_attn_bwd: sequence too long");
+    const int64_t strides[] = {q_rs, q_bs, k_rs, k_bs, v_rs, v_bs, o_rs, o_bs, do_rs, do_bs, dq_rs, dq_bs, dk_rs, dk_bs, dv_rs, dv_bs};
+    for (int64_t sgl : strides) UG_REQUIRE(sgl % 8 == 0, UG_ERR_BAD_ALIGN, "ug_flash_attn_bwd: strides must be multiples of 8 elements");
+    UG_REQUIRE(ug_aligned(q, 16) && ug_aligned(k, 16) && ug_aligned(v, 16) && ug_aligned(o, 16) && ug_aligned(dout, 16) && ug_aligned(dq, 8) &&
+               ug_aligned(dk, 8) && ug_aligned(dv, 8), UG_ERR_BAD_ALIGN, "ug_flash_attn_bwd: bases must be 16-byte aligned");
+    const int64_t stat_ld = (Lq + 63) / 64 * 64;
+    UG_REQUIRE(workspace && ug_aligned(workspace, 16) && workspace_bytes >= ug_flash_attn_bwd_workspace_bytes(batches, heads, Lq), UG_ERR_BAD_SHAPE,
+               "ug_flash_attn_bwd: workspace of ug_flash_attn_bwd_workspace_bytes() needed");
+    float* lse2 = (float*)workspace;
+    float* delta = lse2 + batches * heads * stat_ld;
+    hipStream_t s = (hipStream_t)stream;
+    const float c = softmax_scale * 1.4426950408889634f;
+    const int nQ = (int)((Lq + 255) / 256), nK = (int)((Lkv + 255) / 256);
+    const int64_t gq = (int64_t)nQ * heads * batches, gk = (int64_t)nK * heads * batches;
+    UG_REQUIRE(gq < (1ll << 31) && gk < (1ll << 31), UG_ERR_UNSUPPORTED, "ug_flash_attn_bwd: grid too large");
+    (void)hipMemsetAsync(workspace, 0, (size_t)(2 * batches * heads * stat_ld) * sizeof(float), s);     // padded statistics rows read as 0
+    const int64_t total = batches * Lq * heads;
+    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, s, (const bf16_t*)o, o_rs, o_bs, (const bf16_t*)dout, do_rs, do_bs, delta,
+                       stat_ld, total, (int)heads, (int)Lq, (int)dh);
+#define UG_BWD(DHV, MODEV, GRID, O1, O1R, O1B, O2, O2R, O2B, S1, S1R, S1B, S2, S2R, S2B, OUT, OR, OB, LOWN, LST, NOWN)                                   \
+    do {                                                                                                                                                \
+        const int lds_ = 2 * 2 * KVB * 2 * DHV;                                                                                                        \
+        (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<DHV, MODEV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_);                       \
+        hipLaunchKernelGGL((attn_bwd_kernel<DHV, MODEV>), dim3((unsigned)(GRID)), dim3(512), lds_, s, (const bf16_t*)(O1), O1R, O1B, (const bf16_t*)(O2), O2R, O2B, \
+                           (const bf16_t*)(S1), S1R, S1B, (const bf16_t*)(S2), S2R, S2B, lse2, delta, stat_ld, (bf16_t*)(OUT), OR, OB, (int)heads, (int)(LOWN),   \
+                           (int)(LST), (int)(NOWN), c, softmax_scale);                                                                                 \
+    } while (0)
+#define UG_BWD_ALL(DHV)                                                                                                                              \
+    do {                                                                                                                                              \
+        UG_BWD(DHV, BWD_LSE, gq, q, q_rs, q_bs, nullptr, 0, 0, k, k_rs, k_bs, nullptr, 0, 0, nullptr, 0, 0, Lq, Lkv, nQ);                          \
+        UG_BWD(DHV, BWD_DQ, gq, q, q_rs, q_bs, dout, do_rs, do_bs, k, k_rs, k_bs, v, v_rs, v_bs, dq, dq_rs, dq_bs, Lq, Lkv, nQ);                   \
+        UG_BWD(DHV, BWD_DK, gk, k, k_rs, k_bs, v, v_rs, v_bs, q, q_rs, q_bs, dout, do_rs, do_bs, dk, dk_rs, dk_bs, Lkv, Lq, nK);                   \
+        UG_BWD(DHV, BWD_DV, gk, k, k_rs, k_bs, nullptr, 0, 0, q, q_rs, q_bs, dout, do_rs, do_bs, dv, dv_rs, dv_bs, Lkv, Lq, nK);                   \
+    } while (0)
+    if (dh == 128) UG_BWD_ALL(128); else UG_BWD_ALL(64);
+#undef UG_BWD_ALL
+#undef UG_BWD
+    UG_CHECK_LAUNCH("ug_flash_attn_bwd");
     return UG_OK;
 }

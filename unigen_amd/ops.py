@@ -628,3 +628,20 @@ def rowdot(a: torch.Tensor, b: torch.Tensor, groups: int) -> torch.Tensor:
     out = torch.empty(groups, rows, device=a.device, dtype=torch.float32)
     L.check(_fn("ug_rowdot", dt)(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(), rows, groups, cols, _stream()), "ug_rowdot")
     return out
+
+
+def flash_attn_bwd(q, k, v, o, do, *, heads: int):
+    """q, o, do [B, Lq, H * dh], k, v [B, Lkv, H * dh] (any row / batch strides, bf16) -> (dq, dk, dv) contiguous."""
+    _chk(q, "q"); _chk(k, "k"); _chk(v, "v"); _chk(o, "o"); _chk(do, "do")
+    B, Lq, HD = q.shape
+    Lkv, dh = k.shape[1], HD // heads
+    dq, dk, dv = torch.empty(B, Lq, HD, device=q.device, dtype=bf16), torch.empty(B, Lkv, HD, device=q.device, dtype=bf16), torch.empty(B, Lkv, HD, device=q.device, dtype=bf16)
+    lib = L.load()
+    ws = torch.empty(int(lib.ug_flash_attn_bwd_workspace_bytes(B, heads, Lq)), device=q.device, dtype=torch.uint8)
+    st = lambda t: (t.data_ptr(), t.stride(1), t.stride(0))
+    ev = _timer.begin("attn_bwd") if _timer is not None else None
+    L.check(lib.ug_flash_attn_bwd(*st(q), *st(k), *st(v), *st(o), *st(do), *st(dq), *st(dk), *st(dv), B, heads, Lq, Lkv, dh, dh ** -0.5, ws.data_ptr(), ws.numel(),
+                                  _stream()), "ug_flash_attn_bwd")
+    if ev is not None:
+        _timer.end("attn_bwd", 10.0 * B * heads * Lq * Lkv * dh, ev)
+    return dq, dk, dv
