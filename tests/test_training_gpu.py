@@ -146,3 +146,31 @@ def test_sd3_control_module_gradients_match_oracle_autograd(gpu, modulated):
     print(f"training sd3 mod={int(modulated)} bf16: loss {loss16:.5f} (oracle bf16 {ref_loss:.5f}, fp32 {truth_loss:.5f}); gradients vs fp32: hip {e_hip:.3e}, oracle bf16 {e_ref:.3e}")
     report(f"train_sd3_mod{int(modulated)}_bf16_grads", cat(g16), cat(truth), err_hip_vs_fp32=e_hip, err_oraclebf16_vs_fp32=e_ref)
     assert e_hip <= 1.5 * e_ref + 5e-3 and abs(loss16 - truth_loss) <= 3e-2 * abs(truth_loss), (e_hip, e_ref, loss16, truth_loss)
+
+
+def test_gradient_checkpointing_gives_identical_gradients(gpu):
+    """train.py:317 `transformer.enable_gradient_checkpointing()`: blocks are recomputed in the backward; every kernel is deterministic, so the
+    gradients must be bit-identical to the stored-activation run."""
+    import importlib
+    cls = importlib.import_module("src.UniGenTransformer").UniGenFlux
+    rcfg = R.FluxConfig(condition_nums=1, **TINY)
+    model = cls.from_config(dict(TINY), device=gpu, dtype=BF)
+    model.init_condition_block(condition_nums=1, condition_types=["canny"], control_params=dict(CONTROL))
+    model.init_synthetic_(seed=3, std=0.05, bias_std=0.02)
+    model.init_trainable_param()
+    inp = {k: _dev(v, gpu) for k, v in R.make_inputs(rcfg, B=2, grid=8, T=64).items()}
+    t = torch.full((2,), 0.5, dtype=BF, device=gpu)
+    target = torch.randn(2, 64, 64, generator=torch.Generator().manual_seed(1))
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
+
+    def grads():
+        for p in model.parameters():
+            p.grad = None
+        _step(lambda: model(timestep=t, **inp), target, BF)
+        return {k: (None if model.get_parameter(k).grad is None else model.get_parameter(k).grad.clone()) for k in names}
+
+    plain = grads()
+    model.enable_gradient_checkpointing()
+    ckpt = grads()
+    for k in names:
+        assert (plain[k] is None) == (ckpt[k] is None) and (plain[k] is None or torch.equal(plain[k], ckpt[k])), k
