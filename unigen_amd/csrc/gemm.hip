@@ -259,6 +259,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
             br[nt][1] = *(const bf16x8*)(slot + b_off + nt * 2048 + ch1);
         }
     };
+/* s_setprio 1 around the MFMA segments (round 1) measured 0.3-1.7 % SLOWER than none on every cfg2 shape (round 2, two libraries on one box:
+ * 1167 vs 1149, 1364 vs 1353, 1395 vs 1380, 1507 vs 1479 TFLOP/s), as in the attention kernel: -DUG_DIAG_PRIO restores it for A/B. */
+#ifdef UG_DIAG_PRIO
+#define UG_GEMM_PRIO(X) __builtin_amdgcn_s_setprio(X)
+#else
+#define UG_GEMM_PRIO(X) do { } while (0)
+#endif
 #ifdef UG_DIAG_NOMMA      /* diagnostic build (tools only, WRONG results): the whole data movement of the kernel without its MFMAs */
 #define UG_MMA_QUADRANT(I, J, BR)                                                                                      \
     do {                                                                                                               \
@@ -270,12 +277,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
 #else
 #define UG_MMA_QUADRANT(I, J, BR)                                                                                      \
     do {                                                                                                               \
-        __builtin_amdgcn_s_setprio(1);                                                                                 \
+        UG_GEMM_PRIO(1);                                                                                               \
         _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                               \
             _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                           \
                 _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                       \
                     acc[I][J][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BR[nt][ks], areg[mt][ks], acc[I][J][mt][nt], 0, 0, 0); \
-        __builtin_amdgcn_s_setprio(0);                                                                                 \
+        UG_GEMM_PRIO(0);                                                                                               \
     } while (0)
 #endif
 #define UG_BARRIER() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
