@@ -158,7 +158,7 @@ constexpr int LDS256_BYTES = 2 * KT_BYTES;
 constexpr int SLOT_A0 = 0, SLOT_B0 = HT_BYTES, SLOT_B1 = 2 * HT_BYTES, SLOT_A1 = 3 * HT_BYTES;
 
 template <int EPI, bool LORA>
-__global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, const int tiles_per_group, const int total_tiles, const int wide16,
+__global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, const int tiles_per_group, const int total_tiles, const int wide16_gm,
                                                           const int full_tiles, const int nslices, float* __restrict__ slabs,
                                                           unsigned* __restrict__ tickets) {
     // PERSISTENT: the grid is one workgroup per CU; each walks tiles blockIdx.x, +gridDim.x, ... (same XCD-aware order as a plain
@@ -177,6 +177,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
     const int64_t M = p.M, N = p.N;
     const int nM = (int)((M + 255) / 256), nN = (int)((N + 255) / 256);
     const int st_off = wave * 16 * 128;
+    const int wide16 = wide16_gm & 1;            // bits 8.. of the argument: GROUP_M of the tile walk (0 = 8)
     int a_off, b_off, ch0, ch1;          // fragment read offsets; set per tile (see the tile loop)
     // LORA: the K loop runs on through a second segment, T[m][0..r) . B[n][0..r) (the same K-segment the 128^2 kernel appends), with
     // the staging pointers of a half-tile pair swapped to the LoRA operands (pre-biased by -K) just before their first LoRA K-tile.
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
             }
         }
         t.g = tile / tiles_per_group;
-        const TileCoord tc = tile_of_block(tile - t.g * tiles_per_group, nM, nN);
+        const TileCoord tc = tile_of_block(tile - t.g * tiles_per_group, nM, nN, (wide16_gm >> 8) ? (wide16_gm >> 8) : 8);
         t.m0 = (int64_t)tc.tm * 256; t.n0 = (int64_t)tc.tn * 256;
         const bf16_t* Ab = (const bf16_t*)p.A + (int64_t)t.g * p.a_gstride;
         const bf16_t* Wb = (const bf16_t*)p.W + (int64_t)t.g * p.w_gstride;
@@ -705,6 +706,9 @@ int launch(const ug_gemm_desc& d, hipStream_t s) {
         if (EPI != UG_EPI_F32 && wide16 && !lora && ug_env_int("UG_GEMM_PWG", 0)) return ug_gemm_launch_pwg(d, s);
         // split-K tail (see the kernel header): needs the caller's workspace for the slabs and tickets
         int full = total, nsl = 1;
+        // M-tiles per group of the tile walk. In the cfg2 forward (same box, bench.py x 2 each): 4 -> 2.014 images/s / GEMM 1337 TFLOP/s,
+        // 8 (rounds 1-2) 1.991-2.004 / 1322-1330, 6: 2.006, 3 / 5 / 2: 2.002-2.004, 16: 1.965, 32: 1.905 (profiles/r02c_group_m.log)
+        const int gm = (ug_env_int("UG_GEMM_GROUP_M", 4) & 0xff) << 8;
         float* slabs = nullptr; unsigned* tickets = nullptr;
         const int G = ncu, rem = total % G;            // total < ncu: every tile is a remainder tile
         const int nkt = (int)(d.K / BK);
@@ -724,9 +728,9 @@ int launch(const ug_gemm_desc& d, hipStream_t s) {
             }
         }
         if (lora)       // (EPI_F32 never gets here with LoRA; its second instantiation is the plain kernel again)
-            hipLaunchKernelGGL((gemm256_kernel<EPI, EPI != UG_EPI_F32>), grid, dim3(512), LDS256_BYTES + 16, s, d, (int)(t256 / groups), total, wide16, full, nsl, slabs, tickets);
+            hipLaunchKernelGGL((gemm256_kernel<EPI, EPI != UG_EPI_F32>), grid, dim3(512), LDS256_BYTES + 16, s, d, (int)(t256 / groups), total, wide16 | gm, full, nsl, slabs, tickets);
         else
-            hipLaunchKernelGGL((gemm256_kernel<EPI, false>), grid, dim3(512), LDS256_BYTES + 16, s, d, (int)(t256 / groups), total, wide16, full, nsl, slabs, tickets);
+            hipLaunchKernelGGL((gemm256_kernel<EPI, false>), grid, dim3(512), LDS256_BYTES + 16, s, d, (int)(t256 / groups), total, wide16 | gm, full, nsl, slabs, tickets);
     } else {
         const int nM = (int)((d.M + BM - 1) / BM), nN = (int)((d.N + BN - 1) / BN);
         dim3 grid((unsigned)(nM * nN), 1, (unsigned)groups);
@@ -760,8 +764,8 @@ int launch_qkrope(const ug_gemm_desc& d, hipStream_t s) {
         if (ncu <= 0) ncu = 256;
     }
     const int total = (int)((d.M / 256) * (d.N / 256));
-    hipLaunchKernelGGL((gemm256_kernel<UG_EPI_QKV_ROPE, false>), dim3((unsigned)(total < ncu ? total : ncu)), dim3(512), LDS, s, d, total, total, 1,
-                       total, 1, (float*)nullptr, (unsigned*)nullptr);
+    hipLaunchKernelGGL((gemm256_kernel<UG_EPI_QKV_ROPE, false>), dim3((unsigned)(total < ncu ? total : ncu)), dim3(512), LDS, s, d, total, total,
+                       1 | ((ug_env_int("UG_GEMM_GROUP_M", 4) & 0xff) << 8), total, 1, (float*)nullptr, (unsigned*)nullptr);
     UG_CHECK_LAUNCH("ug_gemm_bf16");
     return UG_OK;
 }

@@ -20,12 +20,11 @@ struct TileCoord { int tm, tn; };
 // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch), so give each XCD a contiguous chunk of
 // the tile sequence, and walk that sequence in groups of 8 M-tiles x all N-tiles so co-resident tiles share A/W panels
 // in the XCD's L2. Only affects speed.
-__device__ __forceinline__ TileCoord tile_of_block(int bid, int nM, int nN) {
+__device__ __forceinline__ TileCoord tile_of_block(int bid, int nM, int nN, int GROUP_M = 8) {
     const int nwg = nM * nN;
     const int q = nwg >> 3, r = nwg & 7;
     const int xcd = bid & 7, k = bid >> 3;
     const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;  // bijective for any nwg
-    constexpr int GROUP_M = 8;
     const int per_group = GROUP_M * nN;
     const int gid = id / per_group;
     const int first_m = gid * GROUP_M;
