@@ -24,13 +24,15 @@ def _w_transposed(w: torch.Tensor) -> torch.Tensor:
     """[N, K] -> [K, N] (N must be a multiple of 64: it becomes the contraction length). Frozen weights are transposed once."""
     if w.requires_grad:
         return ops.transpose(w.detach())
-    key = (w.data_ptr(), tuple(w.shape), w.dtype, w._version)
+    # keyed on identity AND kept alive by the entry (a freed weight's address can be recycled for another of the same shape); `_version`
+    # catches in-place updates (load_state_dict, optimizer steps on a weight that was frozen before)
+    key = (id(w), w.data_ptr(), tuple(w.shape), w.dtype, w._version)
     hit = _wt_cache.get(key)
     if hit is None:
         if len(_wt_cache) > 4096:
             _wt_cache.clear()
-        hit = _wt_cache[key] = ops.transpose(w.detach())
-    return hit
+        hit = _wt_cache[key] = (ops.transpose(w.detach()), w)
+    return hit[0]
 
 
 class Linear(torch.autograd.Function):
