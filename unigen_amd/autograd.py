@@ -24,9 +24,9 @@ def _w_transposed(w: torch.Tensor) -> torch.Tensor:
     """[N, K] -> [K, N] (N must be a multiple of 64: it becomes the contraction length). Frozen weights are transposed once."""
     if w.requires_grad:
         return ops.transpose(w.detach())
-    # keyed on identity AND kept alive by the entry (a freed weight's address can be recycled for another of the same shape); `_version`
-    # catches in-place updates (load_state_dict, optimizer steps on a weight that was frozen before)
-    key = (id(w), w.data_ptr(), tuple(w.shape), w.dtype, w._version)
+    # the entry keeps the weight alive, so its address cannot be recycled for another tensor of the same shape while the entry exists;
+    # `_version` catches in-place updates (load_state_dict, optimizer steps on a weight that was frozen before)
+    key = (w.data_ptr(), tuple(w.shape), w.dtype, w._version)
     hit = _wt_cache.get(key)
     if hit is None:
         if len(_wt_cache) > 4096:
