@@ -338,12 +338,19 @@ int ug_rowdot(const void* a, int64_t lda, const void* b, int64_t ldb, float* out
  * delta = rowsum(dout * o). workspace: ug_flash_attn_bwd_workspace_bytes() bytes, 16-byte aligned (lse and delta, fp32 per (batch, head, query)).
  * The fp32 verification path keeps the GEMM-based formulation of unigen_amd/autograd.py. */
 int64_t ug_flash_attn_bwd_workspace_bytes(int64_t batches, int32_t heads, int64_t Lq);
+/* ug_flash_attn_fwd that also writes lse2[b][h][q] = log2 sum_k 2^(scale log2(e) s_qk) (fp32, row length lse_ld >= Lq, typically Lq rounded up to 64
+ * with the padding zeroed by the caller): the forward of a training step; hand the buffer to ug_flash_attn_bwd as lse_in. */
+int ug_flash_attn_fwd_lse(const void* q, int64_t q_row_stride, int64_t q_batch_stride, const void* k, int64_t k_row_stride, int64_t k_batch_stride,
+                          const void* v, int64_t v_row_stride, int64_t v_batch_stride, void* o, int64_t o_row_stride, int64_t o_batch_stride,
+                          int64_t batches, int32_t heads, int64_t Lq, int64_t Lkv, int32_t dh, float softmax_scale, float* lse2, int64_t lse_ld,
+                          ug_stream_t stream);
 int ug_flash_attn_bwd(const void* q, int64_t q_row_stride, int64_t q_batch_stride, const void* k, int64_t k_row_stride, int64_t k_batch_stride,
                       const void* v, int64_t v_row_stride, int64_t v_batch_stride, const void* o, int64_t o_row_stride, int64_t o_batch_stride,
                       const void* dout, int64_t do_row_stride, int64_t do_batch_stride, void* dq, int64_t dq_row_stride, int64_t dq_batch_stride,
                       void* dk, int64_t dk_row_stride, int64_t dk_batch_stride, void* dv, int64_t dv_row_stride, int64_t dv_batch_stride,
-                      int64_t batches, int32_t heads, int64_t Lq, int64_t Lkv, int32_t dh, float softmax_scale, void* workspace,
-                      int64_t workspace_bytes, ug_stream_t stream);
+                      int64_t batches, int32_t heads, int64_t Lq, int64_t Lkv, int32_t dh, float softmax_scale,
+                      const float* lse_in /* [batches][heads][Lq rounded up to 64], or NULL: recomputed */, void* workspace, int64_t workspace_bytes,
+                      ug_stream_t stream);
 int ug_transpose_f32(const void* src, int64_t ld_src, int64_t src_bstride, void* dst, int64_t ld_dst, int64_t dst_bstride, int64_t batch, int64_t rows,
                      int64_t cols, int64_t rows_pad, ug_stream_t stream);
 int ug_colsum_f32(const void* a, int64_t lda, const void* b, int64_t ldb, void* out, int64_t ldo, int64_t rows, int64_t cols, int64_t rows_per_group,

@@ -70,8 +70,9 @@ def test_error_codes_without_gpu_compute():
     assert cdll.ug_qk_rmsnorm_rope_bwd(16, 128, 16, 128, 16, 128, None, 16, None, None, 4, 4, 0, 1, 128, 1e-6, None) == lib.UG_ERR_BAD_SHAPE   # weight without dwx
     assert cdll.ug_attn_prob(16, 64, 16, 16, 64, 4, 64, 65, 1.0, None) == lib.UG_ERR_BAD_SHAPE                               # valid_cols > cols
     args = [16, 128, 1024] * 8
-    assert cdll.ug_flash_attn_bwd(*args, 1, 1, 8, 8, 96, 1.0, 16, 1 << 20, None) == lib.UG_ERR_UNSUPPORTED                  # head dim
-    assert cdll.ug_flash_attn_bwd(*args, 1, 1, 8, 8, 128, 1.0, 16, 8, None) == lib.UG_ERR_BAD_SHAPE and b"workspace" in cdll.ug_last_error()
+    assert cdll.ug_flash_attn_bwd(*args, 1, 1, 8, 8, 96, 1.0, None, 16, 1 << 20, None) == lib.UG_ERR_UNSUPPORTED            # head dim
+    assert cdll.ug_flash_attn_bwd(*args, 1, 1, 8, 8, 128, 1.0, None, 16, 8, None) == lib.UG_ERR_BAD_SHAPE and b"workspace" in cdll.ug_last_error()
+    assert cdll.ug_flash_attn_fwd_lse(16, 128, 1024, 16, 128, 1024, 16, 128, 1024, 16, 128, 1024, 1, 1, 8, 8, 128, 1.0, 16, 4, None) == lib.UG_ERR_BAD_SHAPE   # lse_ld < Lq
     assert cdll.ug_flash_attn_bwd_workspace_bytes(2, 24, 4608) == 2 * 2 * 24 * 4608 * 4
     assert cdll.ug_gelu_tanh_bwd_f32(None, 16, 16, 8, None) == lib.UG_ERR_BAD_SHAPE
 

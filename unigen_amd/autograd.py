@@ -163,10 +163,14 @@ class FlashAttention(torch.autograd.Function):
         Lkv = k.shape[1]
         dh = HD // heads
         o = torch.empty(B, Lq, HD, device=q.device, dtype=q.dtype)
+        # bf16: the forward kernel also leaves the rows' log-sum-exp for the backward kernels (zero padding up to a multiple of 64 rows)
+        lse = None
+        if q.dtype == torch.bfloat16 and os.environ.get("UG_ATTN_BWD", "flash") != "gemm":
+            lse = torch.zeros(B, heads, _pad64(Lq), device=q.device, dtype=torch.float32)
         ops.flash_attn(q, k, v, o, batches=B, heads=heads, dh=dh, Lq=Lq, Lkv=Lkv, q_strides=(q.stride(1), q.stride(0)), k_strides=(k.stride(1), k.stride(0)),
-                       v_strides=(v.stride(1), v.stride(0)), o_strides=(HD, Lq * HD))
+                       v_strides=(v.stride(1), v.stride(0)), o_strides=(HD, Lq * HD), lse=lse)
         ctx.save_for_backward(q, k, v, o)
-        ctx.heads = heads
+        ctx.heads, ctx.lse = heads, lse
         return o
 
     @staticmethod
@@ -181,7 +185,7 @@ class FlashAttention(torch.autograd.Function):
         do = do.contiguous()
         if dt == torch.bfloat16 and os.environ.get("UG_ATTN_BWD", "flash") != "gemm":
             # product path: the tiled backward kernels (csrc/attention.hip); UG_ATTN_BWD=gemm keeps the GEMM formulation below (A/B, and what fp32 runs)
-            dq, dk, dv = ops.flash_attn_bwd(q, k, v, o, do, heads=H)
+            dq, dk, dv = ops.flash_attn_bwd(q, k, v, o, do, heads=H, lse=ctx.lse)
             return dq, dk, dv, None
         Lq0, Lkv0 = Lq, Lkv
         if Lq % 64 or Lkv % 64:

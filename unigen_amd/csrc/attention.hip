@@ -93,7 +93,7 @@ template <int DH, int NW, bool STAGGER, int PRIO = 1, bool WIDE = false, bool DM
 __global__ __launch_bounds__(64 * NW, 2) void flash_attn_kernel(
     const bf16_t* __restrict__ q, int64_t q_rs, int64_t q_bs, const bf16_t* __restrict__ k, int64_t k_rs, int64_t k_bs,
     const bf16_t* __restrict__ v, int64_t v_rs, int64_t v_bs, bf16_t* __restrict__ o, int64_t o_rs, int64_t o_bs,
-    int heads, int Lq, int Lkv, int nQ, float c /* softmax_scale * log2(e) */) {
+    int heads, int Lq, int Lkv, int nQ, float c /* softmax_scale * log2(e) */, float* __restrict__ lse_out /* nullable */, int64_t lse_ld) {
     constexpr int RB = 2 * DH;                       // row bytes
     constexpr int NCH = DH / 8;                      // 16-byte chunks per row
     constexpr int TILE = KVB * RB;                   // bytes of one K (or V) tile image
@@ -539,6 +539,8 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn_kernel(
 
     // ---- epilogue: O[q][d] = O^T / l ----
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    // training: log2 sum_k 2^(c s) of the row for the backward kernels (m_run is the row's reference point, shared by both lane halves)
+    if (lse_out != nullptr && h == 0 && q_row < Lq) lse_out[(int64_t)bh * lse_ld + q_row] = __builtin_amdgcn_logf(l_tot) + m_run * c;
     const float inv = 1.0f / l_tot;
     if constexpr (WIDE) {
         // Lane (r, h) holds, per 8-column group g4 of a 32-wide d block, columns 8 g4 + 4 h .. + 3 of its query row (8 bytes). One
@@ -1148,11 +1150,11 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
 
 }  // namespace
 
-extern "C" int ug_flash_attn_fwd(const void* q, int64_t q_row_stride, int64_t q_batch_stride, const void* k,
-                                 int64_t k_row_stride, int64_t k_batch_stride, const void* v, int64_t v_row_stride,
-                                 int64_t v_batch_stride, void* o, int64_t o_row_stride, int64_t o_batch_stride,
-                                 int64_t batches, int32_t heads, int64_t Lq, int64_t Lkv, int32_t dh, float softmax_scale,
-                                 ug_stream_t stream) {
+static int flash_attn_fwd_impl(const void* q, int64_t q_row_stride, int64_t q_batch_stride, const void* k,
+                               int64_t k_row_stride, int64_t k_batch_stride, const void* v, int64_t v_row_stride,
+                               int64_t v_batch_stride, void* o, int64_t o_row_stride, int64_t o_batch_stride,
+                               int64_t batches, int32_t heads, int64_t Lq, int64_t Lkv, int32_t dh, float softmax_scale,
+                               float* lse_out, int64_t lse_ld, ug_stream_t stream) {
     if (batches == 0 || Lq == 0) return UG_OK;
     UG_REQUIRE(q && k && v && o && batches > 0 && heads > 0 && Lq > 0 && Lkv > 0, UG_ERR_BAD_SHAPE, "ug_flash_attn_fwd: bad arguments");
     UG_REQUIRE(dh == 128 || dh == 64, UG_ERR_UNSUPPORTED, "ug_flash_attn_fwd: head dim %d not in {64, 128}", dh);
@@ -1171,10 +1173,10 @@ extern "C" int ug_flash_attn_fwd(const void* q, int64_t q_row_stride, int64_t q_
 #define UG_ATTN_LAUNCH(DHV, NWV, STG, ...)                                                                                           \
     hipLaunchKernelGGL((flash_attn_kernel<DHV, NWV, STG, ##__VA_ARGS__>), dim3((unsigned)nwg), dim3(64 * NWV), 2 * 2 * KVB * 2 * DHV + (STG ? 32 * NWV * 2 * DHV : 0), (hipStream_t)stream, \
                        (const bf16_t*)q, q_row_stride, q_batch_stride, (const bf16_t*)k, k_row_stride, k_batch_stride, (const bf16_t*)v, \
-                       v_row_stride, v_batch_stride, (bf16_t*)o, o_row_stride, o_batch_stride, (int)heads, (int)Lq, (int)Lkv, nQ, c)
+                       v_row_stride, v_batch_stride, (bf16_t*)o, o_row_stride, o_batch_stride, (int)heads, (int)Lq, (int)Lkv, nQ, c, lse_out, lse_ld)
     static int pwg = -1;
     if (pwg < 0) { const char* e = getenv("UG_ATTN_PWG"); pwg = e ? atoi(e) : 0; }
-    if (pwg && dh == 128) {
+    if (pwg && dh == 128 && !lse_out) {
         const int nQp = (int)((Lq + 255) / 256);
         const int64_t nwgp = (int64_t)nQp * heads * batches;
         static bool attr = false;
@@ -1210,6 +1212,25 @@ extern "C" int ug_flash_attn_fwd(const void* q, int64_t q_row_stride, int64_t q_
     return UG_OK;
 }
 
+extern "C" int ug_flash_attn_fwd(const void* q, int64_t q_row_stride, int64_t q_batch_stride, const void* k,
+                                 int64_t k_row_stride, int64_t k_batch_stride, const void* v, int64_t v_row_stride,
+                                 int64_t v_batch_stride, void* o, int64_t o_row_stride, int64_t o_batch_stride,
+                                 int64_t batches, int32_t heads, int64_t Lq, int64_t Lkv, int32_t dh, float softmax_scale,
+                                 ug_stream_t stream) {
+    return flash_attn_fwd_impl(q, q_row_stride, q_batch_stride, k, k_row_stride, k_batch_stride, v, v_row_stride, v_batch_stride, o, o_row_stride,
+                               o_batch_stride, batches, heads, Lq, Lkv, dh, softmax_scale, nullptr, 0, stream);
+}
+
+extern "C" int ug_flash_attn_fwd_lse(const void* q, int64_t q_row_stride, int64_t q_batch_stride, const void* k,
+                                     int64_t k_row_stride, int64_t k_batch_stride, const void* v, int64_t v_row_stride,
+                                     int64_t v_batch_stride, void* o, int64_t o_row_stride, int64_t o_batch_stride,
+                                     int64_t batches, int32_t heads, int64_t Lq, int64_t Lkv, int32_t dh, float softmax_scale,
+                                     float* lse2, int64_t lse_ld, ug_stream_t stream) {
+    UG_REQUIRE(lse2 && lse_ld >= Lq, UG_ERR_BAD_SHAPE, "ug_flash_attn_fwd_lse: lse2 [batches][heads][lse_ld >= Lq] needed");
+    return flash_attn_fwd_impl(q, q_row_stride, q_batch_stride, k, k_row_stride, k_batch_stride, v, v_row_stride, v_batch_stride, o, o_row_stride,
+                               o_batch_stride, batches, heads, Lq, Lkv, dh, softmax_scale, lse2, lse_ld, stream);
+}
+
 extern "C" int64_t ug_flash_attn_bwd_workspace_bytes(int64_t batches, int32_t heads, int64_t Lq) {
     if (batches <= 0 || heads <= 0 || Lq <= 0) return 0;
     return 2 * batches * heads * ((Lq + 63) / 64 * 64) * (int64_t)sizeof(float);
@@ -1218,8 +1239,8 @@ extern "C" int64_t ug_flash_attn_bwd_workspace_bytes(int64_t batches, int32_t he
 extern "C" int ug_flash_attn_bwd(const void* q, int64_t q_rs, int64_t q_bs, const void* k, int64_t k_rs, int64_t k_bs, const void* v, int64_t v_rs,
                                  int64_t v_bs, const void* o, int64_t o_rs, int64_t o_bs, const void* dout, int64_t do_rs, int64_t do_bs, void* dq,
                                  int64_t dq_rs, int64_t dq_bs, void* dk, int64_t dk_rs, int64_t dk_bs, void* dv, int64_t dv_rs, int64_t dv_bs,
-                                 int64_t batches, int32_t heads, int64_t Lq, int64_t Lkv, int32_t dh, float softmax_scale, void* workspace,
-                                 int64_t workspace_bytes, ug_stream_t stream) {
+                                 int64_t batches, int32_t heads, int64_t Lq, int64_t Lkv, int32_t dh, float softmax_scale, const float* lse_in,
+                                 void* workspace, int64_t workspace_bytes, ug_stream_t stream) {
     if (batches == 0 || Lq == 0) return UG_OK;
     UG_REQUIRE(q && k && v && o && dout && dq && dk && dv && batches > 0 && heads > 0 && Lq > 0 && Lkv > 0, UG_ERR_BAD_SHAPE, "ug_flash_attn_bwd: bad arguments");
     UG_REQUIRE(dh == 128 || dh == 64, UG_ERR_UNSUPPORTED, "ug_flash_attn_bwd: head dim %d not in {64, 128}", dh);
@@ -1231,8 +1252,9 @@ extern "C" int ug_flash_attn_bwd(const void* q, int64_t q_rs, int64_t q_bs, cons
     const int64_t stat_ld = (Lq + 63) / 64 * 64;
     UG_REQUIRE(workspace && ug_aligned(workspace, 16) && workspace_bytes >= ug_flash_attn_bwd_workspace_bytes(batches, heads, Lq), UG_ERR_BAD_SHAPE,
                "ug_flash_attn_bwd: workspace of ug_flash_attn_bwd_workspace_bytes() needed");
-    float* lse2 = (float*)workspace;
-    float* delta = lse2 + batches * heads * stat_ld;
+    // lse_in: the statistics ug_flash_attn_fwd_lse wrote, [batches][heads][stat_ld] with the padding zero (saves the LSE launch); else computed here
+    float* lse2 = lse_in ? const_cast<float*>(lse_in) : (float*)workspace;
+    float* delta = (float*)workspace + batches * heads * stat_ld;
     hipStream_t s = (hipStream_t)stream;
     const float c = softmax_scale * 1.4426950408889634f;
     const int nQ = (int)((Lq + 255) / 256), nK = (int)((Lkv + 255) / 256);
@@ -1252,7 +1274,7 @@ extern "C" int ug_flash_attn_bwd(const void* q, int64_t q_rs, int64_t q_bs, cons
     } while (0)
 #define UG_BWD_ALL(DHV)                                                                                                                              \
     do {                                                                                                                                              \
-        UG_BWD(DHV, BWD_LSE, gq, q, q_rs, q_bs, nullptr, 0, 0, k, k_rs, k_bs, nullptr, 0, 0, nullptr, 0, 0, Lq, Lkv, nQ);                          \
+        if (!lse_in) UG_BWD(DHV, BWD_LSE, gq, q, q_rs, q_bs, nullptr, 0, 0, k, k_rs, k_bs, nullptr, 0, 0, nullptr, 0, 0, Lq, Lkv, nQ);             \
         UG_BWD(DHV, BWD_DQ, gq, q, q_rs, q_bs, dout, do_rs, do_bs, k, k_rs, k_bs, v, v_rs, v_bs, dq, dq_rs, dq_bs, Lq, Lkv, nQ);                   \
         UG_BWD(DHV, BWD_DK, gk, k, k_rs, k_bs, v, v_rs, v_bs, q, q_rs, q_bs, dout, do_rs, do_bs, dk, dk_rs, dk_bs, Lkv, Lq, nK);                   \
         UG_BWD(DHV, BWD_DV, gk, k, k_rs, k_bs, nullptr, 0, 0, q, q_rs, q_bs, dout, do_rs, do_bs, dv, dv_rs, dv_bs, Lkv, Lq, nK);                   \

@@ -95,7 +95,8 @@ SIGNATURES.update({
     "ug_attn_dscore": (i32, [vp, i64, vp, i64, vp, vp, i64, i64, i64, f32, vp]),
     "ug_rowdot": (i32, [vp, i64, vp, i64, vp, i64, i64, i64, vp]),
     "ug_flash_attn_bwd_workspace_bytes": (i64, [i64, i32, i64]),
-    "ug_flash_attn_bwd": (i32, [vp, i64, i64] * 8 + [i64, i32, i64, i64, i32, f32, vp, i64, vp]),
+    "ug_flash_attn_bwd": (i32, [vp, i64, i64] * 8 + [i64, i32, i64, i64, i32, f32, vp, vp, i64, vp]),
+    "ug_flash_attn_fwd_lse": (i32, [vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, i64, i64, i64, i32, i64, i64, i32, f32, vp, i64, vp]),
 })
 _F32_TWINS = {"ug_transpose_f32": "ug_transpose", "ug_colsum_f32": "ug_colsum", "ug_gelu_tanh_f32": "ug_gelu_tanh", "ug_gelu_tanh_bwd_f32": "ug_gelu_tanh_bwd",
               "ug_adaln_modulate_bwd_f32": "ug_adaln_modulate_bwd", "ug_qk_rmsnorm_rope_bwd_f32": "ug_qk_rmsnorm_rope_bwd",

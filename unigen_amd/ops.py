@@ -253,16 +253,25 @@ def qk_rmsnorm_rope(buf: torch.Tensor, *, batches: int, rows_per_batch: int, ld:
 
 
 def flash_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, *, batches: int, heads: int, dh: int,
-               Lq: int, Lkv: int, q_strides, k_strides, v_strides, o_strides, scale: Optional[float] = None) -> torch.Tensor:
-    """q/k/v/out are base tensors (data_ptr = element [batch 0, row 0, head 0, 0]); *_strides = (row_stride, batch_stride)."""
+               Lq: int, Lkv: int, q_strides, k_strides, v_strides, o_strides, scale: Optional[float] = None,
+               lse: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """q/k/v/out are base tensors (data_ptr = element [batch 0, row 0, head 0, 0]); *_strides = (row_stride, batch_stride).
+    lse (bf16 path only): fp32 [batches, heads, >= Lq], receives the rows' base-2 log-sum-exp for flash_attn_bwd."""
     dt = _act(q, "q")
     _chk(k, "k", dt); _chk(v, "v", dt); _chk(out, "out", dt)
     if scale is None:
         scale = dh ** -0.5
     ev = _timer.begin("attn") if _timer is not None else None
-    L.check(_fn("ug_flash_attn_fwd", dt)(q.data_ptr(), q_strides[0], q_strides[1], k.data_ptr(), k_strides[0], k_strides[1],
-                                       v.data_ptr(), v_strides[0], v_strides[1], out.data_ptr(), o_strides[0], o_strides[1],
-                                       batches, heads, Lq, Lkv, dh, scale, _stream()), "ug_flash_attn_fwd")
+    if lse is not None:
+        _chk(lse, "lse", torch.float32)
+        assert dt == bf16 and lse.is_contiguous() and lse.shape[0] == batches and lse.shape[1] == heads and lse.shape[2] >= Lq
+        L.check(L.load().ug_flash_attn_fwd_lse(q.data_ptr(), q_strides[0], q_strides[1], k.data_ptr(), k_strides[0], k_strides[1],
+                                               v.data_ptr(), v_strides[0], v_strides[1], out.data_ptr(), o_strides[0], o_strides[1],
+                                               batches, heads, Lq, Lkv, dh, scale, lse.data_ptr(), lse.shape[2], _stream()), "ug_flash_attn_fwd_lse")
+    else:
+        L.check(_fn("ug_flash_attn_fwd", dt)(q.data_ptr(), q_strides[0], q_strides[1], k.data_ptr(), k_strides[0], k_strides[1],
+                                           v.data_ptr(), v_strides[0], v_strides[1], out.data_ptr(), o_strides[0], o_strides[1],
+                                           batches, heads, Lq, Lkv, dh, scale, _stream()), "ug_flash_attn_fwd")
     if ev is not None:
         _timer.end("attn", 4.0 * batches * heads * Lq * Lkv * dh, ev)
     return out
@@ -630,8 +639,9 @@ def rowdot(a: torch.Tensor, b: torch.Tensor, groups: int) -> torch.Tensor:
     return out
 
 
-def flash_attn_bwd(q, k, v, o, do, *, heads: int):
-    """q, o, do [B, Lq, H * dh], k, v [B, Lkv, H * dh] (any row / batch strides, bf16) -> (dq, dk, dv) contiguous."""
+def flash_attn_bwd(q, k, v, o, do, *, heads: int, lse: Optional[torch.Tensor] = None):
+    """q, o, do [B, Lq, H * dh], k, v [B, Lkv, H * dh] (any row / batch strides, bf16) -> (dq, dk, dv) contiguous.
+    lse: what flash_attn(..., lse=) wrote, fp32 [B, H, Lq rounded up to 64] with zero padding (None: recomputed)."""
     _chk(q, "q"); _chk(k, "k"); _chk(v, "v"); _chk(o, "o"); _chk(do, "do")
     B, Lq, HD = q.shape
     Lkv, dh = k.shape[1], HD // heads
@@ -640,8 +650,10 @@ def flash_attn_bwd(q, k, v, o, do, *, heads: int):
     ws = torch.empty(int(lib.ug_flash_attn_bwd_workspace_bytes(B, heads, Lq)), device=q.device, dtype=torch.uint8)
     st = lambda t: (t.data_ptr(), t.stride(1), t.stride(0))
     ev = _timer.begin("attn_bwd") if _timer is not None else None
-    L.check(lib.ug_flash_attn_bwd(*st(q), *st(k), *st(v), *st(o), *st(do), *st(dq), *st(dk), *st(dv), B, heads, Lq, Lkv, dh, dh ** -0.5, ws.data_ptr(), ws.numel(),
-                                  _stream()), "ug_flash_attn_bwd")
+    if lse is not None:
+        assert lse.dtype == torch.float32 and lse.is_contiguous() and tuple(lse.shape) == (B, heads, (Lq + 63) // 64 * 64), lse.shape
+    L.check(lib.ug_flash_attn_bwd(*st(q), *st(k), *st(v), *st(o), *st(do), *st(dq), *st(dk), *st(dv), B, heads, Lq, Lkv, dh, dh ** -0.5, _p(lse),
+                                  ws.data_ptr(), ws.numel(), _stream()), "ug_flash_attn_bwd")
     if ev is not None:
         _timer.end("attn_bwd", 10.0 * B * heads * Lq * Lkv * dh, ev)
     return dq, dk, dv
