@@ -35,6 +35,22 @@ def _w_transposed(w: torch.Tensor) -> torch.Tensor:
     return hit[0]
 
 
+_xt_cache: list = []        # the last few activation transposes of this backward pass: (source tensor, padded length, transposed copy)
+
+
+def _x_transposed(x: torch.Tensor, Mp: int) -> torch.Tensor:
+    """X^T for wgrad. to_q / to_k / to_v (+ proj_mlp), the added projections and the expert linears read the same input: their backward nodes
+    run back to back, so a 4-entry cache removes most of the repeated transposes. Entries pin their source (no address reuse while cached)."""
+    for src, mp, xt in _xt_cache:
+        if src.data_ptr() == x.data_ptr() and src.shape == x.shape and src._version == x._version and mp == Mp and src.stride() == x.stride():
+            return xt
+    xt = ops.transpose(x, Mp)
+    _xt_cache.append((x, Mp, xt))
+    if len(_xt_cache) > 4:
+        _xt_cache.pop(0)
+    return xt
+
+
 class Linear(torch.autograd.Function):
     """F.linear on [M, K] rows: ug_gemm_bf16 forward; backward = two more GEMMs and a column sum."""
 
@@ -62,7 +78,7 @@ class Linear(torch.autograd.Function):
             ops.gemm(dy, _w_transposed(w), None, dx, M=M)
         if ctx.needs_input_grad[1]:
             Mp = _pad64(M)
-            dyt, xt = ops.transpose(dy, Mp), ops.transpose(x, Mp)          # [N, Mp], [K, Mp]
+            dyt, xt = ops.transpose(dy, Mp), _x_transposed(x, Mp)          # [N, Mp], [K, Mp]
             dw = torch.empty(N, K, device=x.device, dtype=x.dtype)
             ops.gemm(dyt, xt, None, dw, M=N)
         if ctx.has_bias and ctx.needs_input_grad[2]:

@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ sr
 // out[g][c] = rnd(alpha * sum_{r in group g} a[r][c] * (b ? b[r][c] : 1)) in two deterministic stages: a block sums COLSUM_ROWS rows of 512 columns
 // (8 per lane, 16-byte loads; its 4 waves take every 4th row, then meet in LDS) into an fp32 partial; the second stage adds the partials of a
 // group in order.
-constexpr int COLSUM_ROWS = 128;
+constexpr int COLSUM_ROWS = 256;
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ a, int64_t lda, const T* __restrict__ b, int64_t ldb, float* __restrict__ part,
                                                              int64_t rows_per_group, int cols, int nchunks) {
@@ -88,9 +88,14 @@ __global__ void colsum_final_kernel(const float* __restrict__ part, T* __restric
     const int64_t total = (int64_t)groups * cols;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int g = (int)(i / cols), c = (int)(i - (int64_t)g * cols);
-        float s = 0.f;
-        for (int k = 0; k < nchunks; ++k) s += part[((int64_t)g * nchunks + k) * cols + c];
-        ElemT<T>::st(out + (int64_t)g * ldo + c, alpha * s);
+        const float* pp = part + (int64_t)g * nchunks * cols + c;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;          // four loads in flight per lane; the order of the additions is still fixed
+        int k = 0;
+        for (; k + 4 <= nchunks; k += 4) {
+            s0 += pp[(int64_t)k * cols]; s1 += pp[(int64_t)(k + 1) * cols]; s2 += pp[(int64_t)(k + 2) * cols]; s3 += pp[(int64_t)(k + 3) * cols];
+        }
+        for (; k < nchunks; ++k) s0 += pp[(int64_t)k * cols];
+        ElemT<T>::st(out + (int64_t)g * ldo + c, alpha * ((s0 + s1) + (s2 + s3)));
     }
 }
 
