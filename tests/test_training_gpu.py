@@ -174,3 +174,33 @@ def test_gradient_checkpointing_gives_identical_gradients(gpu):
     ckpt = grads()
     for k in names:
         assert (plain[k] is None) == (ckpt[k] is None) and (plain[k] is None or torch.equal(plain[k], ckpt[k])), k
+
+
+@pytest.mark.parametrize("over", [dict(single_block_control_method="single_add"), dict(use_shared_expert=False), dict(use_single_trans_blocks=False)],
+                         ids=["single_add", "no_shared_expert", "no_single_control"])
+def test_training_variants_fp32(gpu, over):
+    """Control-path variants of the differentiable forward (image-token-only single-block injection, no shared experts, no control single blocks):
+    fp32 verification twins vs the oracle's autograd."""
+    import importlib
+    cls = importlib.import_module("src.UniGenTransformer").UniGenFlux
+    cp = dict(CONTROL); cp.update(over)
+    rcfg = R.FluxConfig(condition_nums=1, **TINY, **over)
+    model = cls.from_config(dict(TINY), device=gpu, dtype=torch.float32)
+    model.init_condition_block(condition_nums=1, condition_types=["canny"], control_params=cp)
+    model.init_synthetic_(seed=4, std=0.05, bias_std=0.02)
+    state = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    model.init_trainable_param()
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
+    inp = R.make_inputs(rcfg, B=1, grid=8, T=64)
+    t = torch.full((1,), 0.25, dtype=BF)
+    target = torch.randn(1, 64, 64, generator=torch.Generator().manual_seed(2))
+    kw = {k: _dev(v, gpu, torch.float32 if k != "gate_uniform" and not k.endswith("_ids") else None) for k, v in inp.items()}
+    _, loss_h, _ = _step(lambda: model(timestep=t.to(gpu), **kw), target, torch.float32)
+    st = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in state.items()}
+    _, loss_r, _ = _step(lambda: R.unigen_flux_forward(st, rcfg, timestep=t, dtype=torch.float32, **inp), target, torch.float32)
+    z = lambda g, k: (g.detach().float().cpu() if g is not None else torch.zeros(state[k].shape))
+    gh = torch.cat([z(model.get_parameter(k).grad, k).flatten() for k in names])
+    gr = torch.cat([z(st[k].grad, k).flatten() for k in names])
+    e = float((gh - gr).norm() / gr.norm())
+    print(f"training variant {list(over)[0]}: loss {loss_h:.6f} vs {loss_r:.6f}, gradients rel_l2 {e:.3e}")
+    assert abs(loss_h - loss_r) <= 1e-5 * abs(loss_r) + 1e-7 and e <= 1e-3, (loss_h, loss_r, e)
