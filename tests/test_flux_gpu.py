@@ -154,3 +154,36 @@ def test_denoise_step_is_hip_graph_capturable(gpu):
     assert torch.equal(out, eager)
     g.replay(); torch.cuda.synchronize()
     assert torch.equal(out, eager)
+
+
+def test_full_depth_block_schedule_fp32(gpu):
+    """FLUX-schnell DEPTH (19 double + 38 single base blocks, single_control_dev = 2 -> 9 + 19 control blocks whose index map
+    m = int(i / (n / n_c)) is not a clean ratio: [0,0,0,1,1,2,...], src/UniGenTransformer.py:1126-1127,1159-1160; ctx K/V reuse between
+    consecutive base blocks that share a control block) at toy width, through the fp32 verification twins against the fp32 oracle."""
+    import importlib
+    cls = importlib.import_module("src.UniGenTransformer").UniGenFlux
+    cfg = dict(TINY, num_layers=19, num_single_layers=38)
+    model = cls.from_config(cfg, device=gpu, dtype=torch.float32)
+    model.init_condition_block(condition_nums=1, condition_types=["canny"], control_params=dict(CONTROL))
+    model.init_synthetic_(seed=11, std=0.03, bias_std=0.01)
+    state = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    rcfg = R.FluxConfig(condition_nums=1, **cfg)
+    assert rcfg.cn_joint_layers == 9 and rcfg.cn_single_layers == 19 and set(state) == set(R.state_shapes(rcfg))
+    inp = R.make_inputs(rcfg, B=2, grid=8, T=32)
+    t = torch.full((2,), 0.75, dtype=BF)
+    truth, loss_t, cnt_t = R.unigen_flux_forward(state, rcfg, timestep=t, dtype=torch.float32, **inp)
+    out, losses, outs = model(timestep=t.to(gpu), **{k: (_to_dev(v, gpu).float() if (not isinstance(v, list) and v.is_floating_point() and k != "gate_uniform") else _to_dev(v, gpu))
+                                                     for k, v in inp.items()})
+    m = report("flux_full_depth_f32", out, truth)
+    assert m["rel_l2"] <= 1e-3 and torch.equal(outs["expert_counts"].cpu(), cnt_t["expert_counts"]), m
+    # and the bf16 product path at the same depth against the oracle's bf16
+    m16 = cls.from_config(cfg, device=gpu, dtype=BF)
+    m16.init_condition_block(condition_nums=1, condition_types=["canny"], control_params=dict(CONTROL))
+    m16.load_state_dict({k: v.to(BF) for k, v in state.items()})
+    state16 = {k: v.to(BF) for k, v in state.items()}
+    ref16 = R.unigen_flux_forward(state16, rcfg, timestep=t, dtype=BF, **inp)[0]
+    truth16 = R.unigen_flux_forward(state16, rcfg, timestep=t, dtype=torch.float32, **inp)[0]
+    out16 = m16(timestep=t.to(gpu), **{k: _to_dev(v, gpu) for k, v in inp.items()})[0]
+    e_hip, e_ref = rel_l2(out16, truth16), rel_l2(ref16, truth16)
+    report("flux_full_depth_bf16", out16, ref16, err_hip_vs_fp32=e_hip, err_oraclebf16_vs_fp32=e_ref)
+    assert e_hip <= 1.25 * e_ref + 1e-3, (e_hip, e_ref)
