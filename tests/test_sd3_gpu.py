@@ -71,3 +71,22 @@ def test_sd3_pipeline_cfg_loop(gpu):
         lat = R.euler_step(lat, pred, sig[i], sig[i + 1])
     m = report("sd3_pipeline_cfg_2steps", res, lat)
     assert m["rel_l2"] <= 3e-2, m
+
+
+def test_sd3_full_depth_fp32(gpu):
+    """SD3.5-medium DEPTH (24 joint blocks, dual attention in 0-12, the last block context_pre_only; 24 control blocks) at toy width through
+    the fp32 verification twins against the fp32 oracle."""
+    cls = importlib.import_module("src.UniGenTransformer").UniGenSD3
+    cfg = dict(TINY, num_layers=24, dual_attention_layers=tuple(range(13)))
+    model = cls.from_config(cfg, device=gpu, dtype=torch.float32)
+    model.init_condition_block(condition_nums=1, condition_types=["depth"], control_params=dict(use_shared_expert=True, use_modulate=False))
+    model.init_synthetic_(seed=9, std=0.03, bias_std=0.01)
+    state = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    rcfg = R.SD3Config(use_modulate=False, **cfg)
+    assert set(state) == set(R.sd3_state_shapes(rcfg))
+    inp = R.make_sd3_inputs(rcfg, B=2, hw=16, T=24)
+    t = torch.full((2,), 600.0)
+    truth, _, cnt = R.unigen_sd3_forward(state, rcfg, timestep=t, dtype=torch.float32, **inp)
+    out, _, outs = model(timestep=t.to(gpu), **{k: (v.to(gpu).float() if (v.is_floating_point() and k != "gate_uniform") else v.to(gpu)) for k, v in inp.items()})
+    m = report("sd3_full_depth_f32", out, truth)
+    assert m["rel_l2"] <= 1e-3 and torch.equal(outs["expert_counts"].cpu(), cnt["expert_counts"]), m
