@@ -311,6 +311,13 @@ int ug_colsum(const void* a, int64_t lda, const void* b, int64_t ldb, void* out,
               float alpha, void* workspace, int64_t workspace_bytes, ug_stream_t stream);
 /* bytes of the caller-owned fp32 scratch of ug_colsum (per-chunk partial sums, added in a fixed order: run-to-run reproducible) */
 int64_t ug_colsum_workspace_bytes(int64_t rows, int64_t cols, int64_t rows_per_group);
+/* y[r] = (x ? x[r] : 0) + gate[r / rows_per_sample] * a[r], the product rounded first: `x + gate.unsqueeze(1) * a` of every transformer block
+ * (FluxTransformerBlock / FluxSingleTransformerBlock, called at src/UniGenTransformer.py:1129,1151) as one op of the training forward; with x = NULL
+ * its backward d a = gate * d y (d x = d y; d gate = ug_colsum(d y, a) per sample). */
+int ug_gate_residual(const void* x, int64_t ldx, const void* a, int64_t lda, const void* gate, int64_t gate_ld, int64_t rows_per_sample, void* y,
+                     int64_t ldy, int64_t rows, int64_t D, ug_stream_t stream);
+int ug_gate_residual_f32(const void* x, int64_t ldx, const void* a, int64_t lda, const void* gate, int64_t gate_ld, int64_t rows_per_sample, void* y,
+                         int64_t ldy, int64_t rows, int64_t D, ug_stream_t stream);
 /* y = gelu_tanh(x); dx = dy * gelu_tanh'(x)   (F.gelu(approximate="tanh") of FeedForward net.0 / proj_mlp and its backward) */
 int ug_gelu_tanh(const void* x, void* y, int64_t n, ug_stream_t stream);
 int ug_gelu_tanh_bwd(const void* x, const void* dy, void* dx, int64_t n, ug_stream_t stream);

@@ -157,3 +157,10 @@ def test_flash_attention_backward_kernels(gpu, dh, H, B, Lq, Lkv, monkeypatch):
         e_f, e_g = rel(f, tr), rel(gm, tr)
         print(f"backward flash attention dh{dh} {Lq}x{Lkv} grad[{i}]: flash {e_f:.3e}, gemm formulation {e_g:.3e}")
         assert torch.isfinite(f.float()).all() and e_f <= max(1.5 * e_g, 6e-3), (i, e_f, e_g)
+
+
+def test_gate_residual_backward(gpu):
+    from unigen_amd import autograd as A
+    g = torch.Generator().manual_seed(6)
+    x, a, gate = torch.randn(3, 70, 192, generator=g), torch.randn(3, 70, 192, generator=g), torch.randn(3, 192, generator=g)
+    run_case(gpu, lambda x, a, gt: A.gate_residual(x, a, gt), lambda x, a, gt: x + gt.unsqueeze(1) * a, [x, a, gate], name="gate_residual")

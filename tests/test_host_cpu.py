@@ -66,7 +66,7 @@ def test_error_codes_without_gpu_compute():
     assert cdll.ug_colsum(16, 64, None, 0, 16, 64, 10, 64, 4, 1.0, 16, 1 << 20, None) == lib.UG_ERR_BAD_SHAPE               # rows not a multiple of the group
     assert cdll.ug_colsum(16, 60, None, 0, 16, 60, 8, 60, 4, 1.0, 16, 1 << 20, None) == lib.UG_ERR_BAD_ALIGN                # cols % 8
     assert cdll.ug_colsum(16, 64, None, 0, 16, 64, 8, 64, 4, 1.0, 16, 8, None) == lib.UG_ERR_BAD_SHAPE and b"workspace" in cdll.ug_last_error()
-    assert cdll.ug_colsum_workspace_bytes(4608, 3072, 4608) == 18 * 3072 * 4
+    assert cdll.ug_colsum_workspace_bytes(4608, 3072, 4608) == 36 * 3072 * 4
     assert cdll.ug_qk_rmsnorm_rope_bwd(16, 128, 16, 128, 16, 128, None, 16, None, None, 4, 4, 0, 1, 128, 1e-6, None) == lib.UG_ERR_BAD_SHAPE   # weight without dwx
     assert cdll.ug_attn_prob(16, 64, 16, 16, 64, 4, 64, 65, 1.0, None) == lib.UG_ERR_BAD_SHAPE                               # valid_cols > cols
     args = [16, 128, 1024] * 8

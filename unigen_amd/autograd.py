@@ -135,6 +135,32 @@ def adaln_modulate(x, shift, scale, eps: float = 1e-6):
     return AdaLNModulate.apply(x, shift, scale, eps)
 
 
+class GateResidual(torch.autograd.Function):
+    """x + gate.unsqueeze(1) * a (x, a [B, L, D]; gate [B, D]) as one kernel; backward: d x = d y, d a = gate * d y, d gate = sum_rows(d y * a)."""
+
+    @staticmethod
+    def forward(ctx, x, a, gate):
+        B, Ls, D = a.shape
+        a2, g2 = a.reshape(B * Ls, D).contiguous(), gate.contiguous()
+        y = ops.gate_residual(x.reshape(B * Ls, D).contiguous(), a2, g2, Ls)
+        ctx.save_for_backward(a2, g2)
+        ctx.geom = (B, Ls, D)
+        return y.view(B, Ls, D)
+
+    @staticmethod
+    def backward(ctx, dy):
+        a2, g2 = ctx.saved_tensors
+        B, Ls, D = ctx.geom
+        dy2 = dy.reshape(B * Ls, D).contiguous()
+        da = ops.gate_residual(None, dy2, g2, Ls).view(B, Ls, D) if ctx.needs_input_grad[1] else None
+        dg = ops.colsum(dy2, a2, rows_per_group=Ls) if ctx.needs_input_grad[2] else None
+        return dy, da, dg
+
+
+def gate_residual(x, a, gate):
+    return GateResidual.apply(x, a, gate)
+
+
 class QKNormRope(torch.autograd.Function):
     """RMSNorm over each head (weight w [dh] or None) followed by apply_rotary_emb (cos / sin [positions, dh] fp32 or None) of one of q / k:
     x [B, L, H * dh]; row l of a sample sits at position pos_offset + l."""

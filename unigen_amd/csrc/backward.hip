@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ sr
 // out[g][c] = rnd(alpha * sum_{r in group g} a[r][c] * (b ? b[r][c] : 1)) in two deterministic stages: a block sums COLSUM_ROWS rows of 512 columns
 // (8 per lane, 16-byte loads; its 4 waves take every 4th row, then meet in LDS) into an fp32 partial; the second stage adds the partials of a
 // group in order.
-constexpr int COLSUM_ROWS = 256;
+constexpr int COLSUM_ROWS = 128;
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ a, int64_t lda, const T* __restrict__ b, int64_t ldb, float* __restrict__ part,
                                                              int64_t rows_per_group, int cols, int nchunks) {
@@ -96,6 +96,24 @@ __global__ void colsum_final_kernel(const float* __restrict__ part, T* __restric
         }
         for (; k < nchunks; ++k) s0 += pp[(int64_t)k * cols];
         ElemT<T>::st(out + (int64_t)g * ldo + c, alpha * ((s0 + s1) + (s2 + s3)));
+    }
+}
+
+// y[r][:] = (x ? x[r][:] : 0) + rnd(gate[r / rows_per_sample][:] * a[r][:]): the gated residual `x + gate.unsqueeze(1) * a` of every block (forward of the
+// training path; with x = NULL its backward d a = gate * d y). 8 elements per thread.
+template <typename T>
+__global__ void gate_residual_kernel(const T* __restrict__ x, int64_t ldx, const T* __restrict__ a, int64_t lda, const T* __restrict__ gate, int64_t gate_ld,
+                                     int64_t rows_per_sample, T* __restrict__ y, int64_t ldy, int64_t rows, int D8) {
+    const int64_t total = rows * D8;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / D8; const int c = (int)(i - r * D8) * 8;
+        float av[8], gv[8], xv[8], o[8];
+        ElemT<T>::load8(a + r * lda + c, av);
+        ElemT<T>::load8(gate + (r / rows_per_sample) * gate_ld + c, gv);
+        if (x) ElemT<T>::load8(x + r * ldx + c, xv);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const float p = ElemT<T>::rnd(gv[k] * av[k]); o[k] = x ? xv[k] + p : p; }
+        ElemT<T>::store8(y + r * ldy + c, o);
     }
 }
 
@@ -287,6 +305,19 @@ int gelu_impl(const void* x, const void* dy, void* out, int64_t n, ug_stream_t s
     return UG_OK;
 }
 template <typename T>
+int gate_residual_impl(const void* x, int64_t ldx, const void* a, int64_t lda, const void* gate, int64_t gate_ld, int64_t rows_per_sample, void* y, int64_t ldy,
+                       int64_t rows, int64_t D, ug_stream_t stream) {
+    if (rows == 0) return UG_OK;
+    UG_REQUIRE(a && gate && y && rows > 0 && D > 0 && rows_per_sample > 0 && lda >= D && ldy >= D && gate_ld >= D && (!x || ldx >= D), UG_ERR_BAD_SHAPE,
+               "ug_gate_residual: bad arguments");
+    UG_REQUIRE(D % 8 == 0 && lda % 8 == 0 && ldy % 8 == 0 && gate_ld % 8 == 0 && (!x || ldx % 8 == 0) && ug_aligned(a, 16) && ug_aligned(gate, 16) &&
+               ug_aligned(y, 16) && (!x || ug_aligned(x, 16)), UG_ERR_BAD_ALIGN, "ug_gate_residual: 16-byte alignment / multiples of 8 required");
+    hipLaunchKernelGGL(gate_residual_kernel<T>, dim3(grid1d(rows * (D / 8), 256)), dim3(256), 0, (hipStream_t)stream, (const T*)x, ldx, (const T*)a, lda,
+                       (const T*)gate, gate_ld, rows_per_sample, (T*)y, ldy, rows, (int)(D / 8));
+    UG_CHECK_LAUNCH("ug_gate_residual");
+    return UG_OK;
+}
+template <typename T>
 int adaln_bwd_impl(const void* x, int64_t ldx, const void* dy, int64_t lddy, const void* scale, int64_t mod_ld, int64_t rows_per_sample, void* dx,
                    int64_t lddx, void* dyx, int64_t lddyx, int64_t rows, int64_t D, float eps, ug_stream_t stream) {
     if (rows == 0) return UG_OK;
@@ -358,6 +389,10 @@ extern "C" int64_t ug_colsum_workspace_bytes(int64_t rows, int64_t cols, int64_t
     if (rows <= 0 || cols <= 0 || rows_per_group <= 0) return 0;
     return (rows / rows_per_group) * ((rows_per_group + COLSUM_ROWS - 1) / COLSUM_ROWS) * cols * (int64_t)sizeof(float);
 }
+UG_TWINS(ug_gate_residual, gate_residual_impl,
+         (const void* x, int64_t ldx, const void* a, int64_t lda, const void* gate, int64_t gate_ld, int64_t rows_per_sample, void* y, int64_t ldy, int64_t rows,
+          int64_t D, ug_stream_t stream),
+         (x, ldx, a, lda, gate, gate_ld, rows_per_sample, y, ldy, rows, D, stream))
 UG_TWINS(ug_gelu_tanh, gelu_impl, (const void* x, void* y, int64_t n, ug_stream_t stream), (x, nullptr, y, n, stream))
 UG_TWINS(ug_gelu_tanh_bwd, gelu_impl, (const void* x, const void* dy, void* dx, int64_t n, ug_stream_t stream), (x, dy, dx, n, stream))
 UG_TWINS(ug_adaln_modulate_bwd, adaln_bwd_impl,

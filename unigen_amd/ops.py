@@ -657,3 +657,16 @@ def flash_attn_bwd(q, k, v, o, do, *, heads: int, lse: Optional[torch.Tensor] = 
     if ev is not None:
         _timer.end("attn_bwd", 10.0 * B * heads * Lq * Lkv * dh, ev)
     return dq, dk, dv
+
+
+def gate_residual(x: Optional[torch.Tensor], a: torch.Tensor, gate: torch.Tensor, rows_per_sample: int) -> torch.Tensor:
+    """a (and x) [rows, D]; gate [samples, D] -> x + gate[row // rows_per_sample] * a (x None: the product alone)."""
+    dt = _act(a, "a")
+    _chk(gate, "gate", dt)
+    if x is not None:
+        _chk(x, "x", dt)
+    rows, D = a.shape
+    y = torch.empty(rows, D, device=a.device, dtype=dt)
+    L.check(_fn("ug_gate_residual", dt)(_p(x), x.stride(0) if x is not None else 0, a.data_ptr(), a.stride(0), gate.data_ptr(), gate.stride(0), rows_per_sample,
+                                        y.data_ptr(), D, rows, D, _stream()), "ug_gate_residual")
+    return y
