@@ -673,9 +673,11 @@ int launch(const ug_gemm_desc& d, hipStream_t s) {
     const int groups = d.groups > 0 ? d.groups : 1;
     const int64_t t256 = ((d.M + 255) / 256) * ((d.N + 255) / 256) * groups;
     const int64_t t128 = ((d.M + 127) / 128) * ((d.N + 127) / 128) * groups;
-    // pick the tile by expected chip fill: 256 CUs x 1 workgroup (256^2) vs 256 x 2 (128^2, ~0.82x the 256^2 kernel's rate)
+    // pick the tile by expected chip fill: 256 CUs x 1 workgroup (256^2) vs 256 x 2 (128^2, whose rate relative to the 256^2 kernel is the
+    // weight below: 0.82 on large shapes, but in the cfg2 forward the text-stream projections (M = B x 512) run better on 256^2 tiles:
+    // weight 60 % -> 2.011 images/s, 70 %: 2.004-2.008, 82 % (rounds 1-2): 1.995-2.000, 50 %: 2.010)
     const double e256 = (double)t256 / (double)(((t256 + 255) / 256) * 256);
-    const double e128 = 0.82 * (double)t128 / (double)(((t128 + 511) / 512) * 512);
+    const double e128 = 0.01 * ug_env_int("UG_GEMM_E128_PCT", 60) * (double)t128 / (double)(((t128 + 511) / 512) * 512);
     const bool lora = d.lora_r > 0;
     bool big = (!lora || (d.K >= 2 * BK && EPI != UG_EPI_F32)) && d.M >= 192 && d.N >= 192 && e256 >= e128;
     const int f = forced_tile();
