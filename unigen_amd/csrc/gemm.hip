@@ -718,7 +718,7 @@ int launch(const ug_gemm_desc& d, hipStream_t s) {
         if (split_on < 0) { const char* e = getenv("UG_GEMM_SPLITK_TAIL"); split_on = (e && atoi(e) == 0) ? 0 : 1; }
         // Measured (MI355X): the slab round trip + fences cost ~35 us, so the split only pays when a tile's K loop is long
         // (K = 15360 single-block proj_out: +3.5 %; K = 3072 shapes: -2...-3 %) -> require >= 96 K-tiles.
-        if (split_on && !lora && rem > 0 && rem * 2 <= G && d.workspace && nkt >= 96) {
+        if (split_on && !lora && rem > 0 && rem * 2 <= G && d.workspace && nkt >= ug_env_int("UG_GEMM_SPLITK_MIN_KT", 96)) {
             const int rem8 = (rem + 7) / 8 * 8;
             int cand = G / rem8; if (cand > 8) cand = 8; if (cand > nkt / 4) cand = nkt / 4;
             const size_t need = 4096 + (size_t)rem8 * cand * 65536 * sizeof(float);
