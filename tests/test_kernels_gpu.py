@@ -646,6 +646,20 @@ def test_gemm_fused_qk_rmsnorm_rope_epilogue(gpu):
     frac = float((diff > 0).float().mean())
     print(f"fused qk-rope double: rel_l2 vs two-launch {rel:.3e}, differing elements {frac:.2e}")
     assert rel <= 5e-4 and frac < 2e-2, (rel, frac)
+    # --- rows per sample not a multiple of the tile: 256-row tiles straddle two samples (one position wrap inside a tile) ---------------------
+    B, Ls2 = 4, 320
+    M = B * Ls2
+    x, w, b = _rand(g, M, K), _rand(g, 3 * D, K, scale=K ** -0.5), _rand(g, 3 * D, scale=0.1)
+    cos, sin, cs = tables(Ls2 + 7)
+    xd, wd, bd = x.to(gpu), w.to(gpu), b.to(gpu)
+    two, one = torch.zeros(M, 3 * D, device=gpu, dtype=BF), torch.zeros(M, 3 * D, device=gpu, dtype=BF)
+    ops.gemm(xd, wd, bd, two, M=M)
+    ops.qk_rmsnorm_rope(two, batches=B, rows_per_batch=Ls2, pos_offset=7, ld=3 * D, q_off=0, k_off=D, heads=H, dh=dh, wq_b=wqd, wk_b=wkd, split=0, cos=cos, sin=sin)
+    ops.gemm(xd, wd, bd, one, M=M, qk_rope=ops.QkRope(wqd, wkd, cs, Ls2, 7, 2 * D))
+    torch.cuda.synchronize()
+    diff = (one.float() - two.float()).abs()
+    print(f"fused qk-rope straddling tiles: rel_l2 vs two-launch {float(diff.norm() / two.float().norm()):.3e}, differing {float((diff > 0).float().mean()):.2e}")
+    assert float(diff.norm() / two.float().norm()) <= 5e-4 and float((diff > 0).float().mean()) < 2e-2
     # --- argument checks ----------------------------------------------------------------------------------------------------------------
     with pytest.raises(L.UniGenHipError, match="multiples of 256"):
         ops.gemm(xd[:300], wd, bd, torch.empty(300, 3 * D, device=gpu, dtype=BF), M=300, qk_rope=ops.QkRope(wqd, wkd, cs, 0, 0, 2 * D))
