@@ -87,13 +87,15 @@ typedef struct ug_gemm_desc {
      *   output column n is stored at column n + c_shift when n >= c_shift_from_n > 0 (a gap in the destination row).
      * Both boundaries must be multiples of 256 (a tile never straddles them); c_shift a multiple of 8. */
     int64_t gelu_from_n, c_shift_from_n, c_shift;
-    /* UG_EPI_QKV_ROPE only. Heads are 128 wide; q heads fill columns [0, qk_until_n / 2), k heads [qk_until_n / 2, qk_until_n).
-     *   qk_wq, qk_wk : [128] bf16 RMSNorm weights;  rope_cs : fp32 [positions][64][2] = (cos, sin) of each rotation pair;
+    /* UG_EPI_QKV_ROPE only. Heads are qk_dh wide (128; 0 means 128; or 64: SD3.5); q heads fill columns [0, qk_until_n / 2), k heads
+     * [qk_until_n / 2, qk_until_n).
+     *   qk_wq, qk_wk : [qk_dh] bf16 RMSNorm weights;  rope_cs : fp32 [positions][qk_dh / 2][2] = (cos, sin) of each rotation pair (may be NULL
+     *   at qk_dh = 64: RMSNorm only, JointAttnProcessor2_0 has no RoPE);
      *   row m sits at position rope_pos0 + (m % rope_rpb) (rope_rpb 0: m itself).
      * Needs M, N, qk_until_n multiples of 256, groups 1, no LoRA segment, 16-byte aligned C rows. */
     const void* qk_wq; const void* qk_wk; const float* rope_cs;
     int64_t rope_rpb, rope_pos0, qk_until_n;
-    float qk_eps; int32_t _pad2;
+    float qk_eps; int32_t qk_dh;
 } ug_gemm_desc;
 
 /* bytes of ug_gemm_desc.workspace that are always sufficient (any shape) */

@@ -660,6 +660,27 @@ def test_gemm_fused_qk_rmsnorm_rope_epilogue(gpu):
     diff = (one.float() - two.float()).abs()
     print(f"fused qk-rope straddling tiles: rel_l2 vs two-launch {float(diff.norm() / two.float().norm()):.3e}, differing {float((diff > 0).float().mean()):.2e}")
     assert float(diff.norm() / two.float().norm()) <= 5e-4 and float((diff > 0).float().mean()) < 2e-2
+    # --- head width 64 (SD3.5): four heads per tile, RMSNorm only (no RoPE), and with a table ---------------------------------------------
+    dh4, H4 = 64, D // 64
+    wq4, wk4 = (1 + 0.2 * torch.randn(dh4, generator=g)).to(BF).to(gpu), (1 + 0.2 * torch.randn(dh4, generator=g)).to(BF).to(gpu)
+    B, Ls4 = 2, 512
+    M = B * Ls4
+    x, w, b = _rand(g, M, K), _rand(g, 3 * D, K, scale=K ** -0.5), _rand(g, 3 * D, scale=0.1)
+    xd, wd, bd = x.to(gpu), w.to(gpu), b.to(gpu)
+    ang = torch.rand(Ls4, dh4 // 2, generator=g) * 6.28
+    cos4, sin4 = ang.cos().repeat_interleave(2, 1).contiguous().to(gpu), ang.sin().repeat_interleave(2, 1).contiguous().to(gpu)
+    cs4 = torch.stack([cos4[:, 0::2], sin4[:, 0::2]], -1).contiguous()
+    for tab in (None, (cos4, sin4, cs4)):
+        two, one = torch.zeros(M, 3 * D, device=gpu, dtype=BF), torch.zeros(M, 3 * D, device=gpu, dtype=BF)
+        ops.gemm(xd, wd, bd, two, M=M)
+        ops.qk_rmsnorm_rope(two, batches=B, rows_per_batch=Ls4, ld=3 * D, q_off=0, k_off=D, heads=H4, dh=dh4, wq_b=wq4, wk_b=wk4, split=0,
+                            cos=tab[0] if tab else None, sin=tab[1] if tab else None)
+        ops.gemm(xd, wd, bd, one, M=M, qk_rope=ops.QkRope(wq4, wk4, tab[2] if tab else None, Ls4, 0, 2 * D, dh=dh4))
+        torch.cuda.synchronize()
+        diff = (one.float() - two.float()).abs()
+        rel, frac = float(diff.norm() / two.float().norm()), float((diff > 0).float().mean())
+        print(f"fused qk-norm dh64 rope={tab is not None}: rel_l2 vs two-launch {rel:.3e}, differing {frac:.2e}")
+        assert torch.equal(one[:, 2 * D:], two[:, 2 * D:]) and rel <= 5e-4 and frac < 2e-2, (rel, frac)
     # --- argument checks ----------------------------------------------------------------------------------------------------------------
     with pytest.raises(L.UniGenHipError, match="multiples of 256"):
         ops.gemm(xd[:300], wd, bd, torch.empty(300, 3 * D, device=gpu, dtype=BF), M=300, qk_rope=ops.QkRope(wqd, wkd, cs, 0, 0, 2 * D))

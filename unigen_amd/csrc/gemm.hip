@@ -157,7 +157,7 @@ constexpr int KT_BYTES = 4 * HT_BYTES;
 constexpr int LDS256_BYTES = 2 * KT_BYTES;
 constexpr int SLOT_A0 = 0, SLOT_B0 = HT_BYTES, SLOT_B1 = 2 * HT_BYTES, SLOT_A1 = 3 * HT_BYTES;
 
-template <int EPI, bool LORA>
+template <int EPI, bool LORA, int QKDH = 128>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, const int tiles_per_group, const int total_tiles, const int wide16_gm,
                                                           const int full_tiles, const int nslices, float* __restrict__ slabs,
                                                           unsigned* __restrict__ tickets) {
@@ -425,7 +425,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
                     if constexpr (EPI == UG_EPI_RES_GATE) pg[j][nt] = *(const u32x2*)(gate + n);
                     if constexpr (EPI == UG_EPI_QKV_ROPE) {        // fg[0][nt]: this lane's 4 RMSNorm weights (column within the head)
                         if (qk_tile && j == 0)
-                            pg[0][nt] = *(const u32x2*)((const bf16_t*)(2 * n0 >= p.qk_until_n ? p.qk_wk : p.qk_wq) + wc * 32 + nt * 16 + (lane_e >> 4) * 4);
+                            pg[0][nt] = *(const u32x2*)((const bf16_t*)(2 * n0 >= p.qk_until_n ? p.qk_wk : p.qk_wq) + (QKDH == 64 ? (wc & 1) : wc) * 32 + nt * 16 +
+                                                        (lane_e >> 4) * 4);
                     }
                 }
             if (tile + (int)gridDim.x < n_items) cur = tile_src(tile + gridDim.x, lane_e); else cur.nk = 0;
@@ -495,8 +496,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
         if constexpr (EPI == UG_EPI_QKV_ROPE) {
             if (fast && qk_tile) {
                 // q | k tile: the tile is two heads wide (j = 0, 1); a row of a head is spread over the 4 waves wc = 0..3 (32 columns each)
-                // and, inside a wave, over 4 lane groups of 4 columns x 2 n-tiles.
+                // and, inside a wave, over 4 lane groups of 4 columns x 2 n-tiles. (QKDH = 64, SD3.5: four heads per tile, a head's row over the
+                // wave pair wc & ~1; RoPE optional there - JointAttnProcessor2_0 has none.)
                 const int lg = lane_e >> 4;
+                const int wh = QKDH == 64 ? (wc & 1) : wc;                       // this wave's 32-column slice of its head
+                const bool has_rope = QKDH == 128 || p.rope_cs != nullptr;
                 float* const part = (float*)(smem + LDS256_BYTES + 16) + ((wr * 64 + (lane_e & 15)) * 8);   // [row 256][head 2][wc 4]
                 // (1) the Linear's bf16 output, in place, and the per-row sums of squares: lane groups by permlane swaps, waves through LDS
 #pragma unroll
@@ -519,7 +523,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
                 // (2) normalise, rotate, store. (cos, sin) pairs of row-group rg+1 are loaded before row-group rg is computed and stored.
                 const int colb = (int)n0 + wc * 32 + (lg & 1) * 16 + 8 * (lg >> 1);
                 bf16_t* const Cb = (bf16_t*)p.C + colb;
-                const float* const csb = p.rope_cs + wc * 32 + lg * 4;
+                const float* const csb = p.rope_cs + wh * 32 + lg * 4;
                 const unsigned mrow = (unsigned)m0 + wr * 64 + (lane_e & 15);
                 // position of a row: ONE division per tile (its divisor made opaque, or the reciprocal is hoisted out of the tile loop and
                 // spilled across the K loop); the other 7 rows are < 256 <= rope_rpb further on, so a conditional subtract wraps them.
@@ -534,21 +538,27 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
                     cp[rg & 1] = Cb + (int64_t)rowmap32(m, (unsigned)p.c_rpb, (unsigned)p.c_bstride) * p.ldc;
                     unsigned rr = rr0 + (rg >> 2) * 128 + (rg & 3) * 16;
                     if (rr >= wrap) rr -= wrap;
-                    const float* q = csb + ((int64_t)p.rope_pos0 + rr) * 128;
-                    cbuf[rg & 1][0] = gload16_asm(q);
-                    cbuf[rg & 1][1] = gload16_asm_64(q);
+                    const float* q = csb + ((int64_t)p.rope_pos0 + rr) * QKDH;
+                    if (has_rope) {
+                        cbuf[rg & 1][0] = gload16_asm(q);
+                        cbuf[rg & 1][1] = gload16_asm_64(q);
+                    }
                 };
+                cbuf[0][0] = cbuf[0][1] = cbuf[1][0] = cbuf[1][1] = (u32x4){0u, 0u, 0u, 0u};
                 stores_in_flight = true;
                 open_rows(0);
 #pragma unroll
                 for (int rg = 0; rg < 8; ++rg) {
                     if (rg + 1 < 8) open_rows(rg + 1);
-                    if (rg == 0 || rg == 7) ug_wait_vm<2>(cbuf[rg & 1][0], cbuf[rg & 1][1]);
-                    else ug_wait_vm<4>(cbuf[rg & 1][0], cbuf[rg & 1][1]);
+                    if (has_rope) {
+                        if (rg == 0 || rg == 7) ug_wait_vm<2>(cbuf[rg & 1][0], cbuf[rg & 1][1]);
+                        else ug_wait_vm<4>(cbuf[rg & 1][0], cbuf[rg & 1][1]);
+                    }
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
                         const f32x4 t = *(const f32x4*)(part + ((rg >> 2) * 128 + (rg & 3) * 16) * 8 + j * 4);
-                        const float rs = __builtin_amdgcn_rsqf((t[0] + t[1] + t[2] + t[3]) * (1.0f / 128.0f) + p.qk_eps);
+                        const float tot = QKDH == 128 ? (t[0] + t[1] + t[2] + t[3]) : ((wc & 2) ? t[2] + t[3] : t[0] + t[1]);
+                        const float rs = __builtin_amdgcn_rsqf(tot * (1.0f / (float)QKDH) + p.qk_eps);
                         unsigned pk[2][2];
 #pragma unroll
                         for (int nt = 0; nt < 2; ++nt) {
@@ -558,8 +568,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
                             float x[4];
 #pragma unroll
                             for (int q = 0; q < 4; ++q) x[q] = rbf(rbf(acc[rg >> 2][j][rg & 3][nt][q] * rs) * fg[0][nt][q]);
-                            pk[nt][0] = pack2bf(x[0] * c0 + (-x[1]) * s0, x[1] * c0 + x[0] * s0);
-                            pk[nt][1] = pack2bf(x[2] * c1 + (-x[3]) * s1, x[3] * c1 + x[2] * s1);
+                            if (has_rope) {
+                                pk[nt][0] = pack2bf(x[0] * c0 + (-x[1]) * s0, x[1] * c0 + x[0] * s0);
+                                pk[nt][1] = pack2bf(x[2] * c1 + (-x[3]) * s1, x[3] * c1 + x[2] * s1);
+                            } else {
+                                pk[nt][0] = pack2bf(x[0], x[1]);
+                                pk[nt][1] = pack2bf(x[2], x[3]);
+                            }
                         }
                         swap16(pk[0][0], pk[1][0]); swap16(pk[0][1], pk[1][1]);
                         u32x4 o; o.x = pk[0][0]; o.y = pk[0][1]; o.z = pk[1][0]; o.w = pk[1][1];
@@ -748,7 +763,9 @@ int launch_qkrope(const ug_gemm_desc& d, hipStream_t s) {
                "ug_gemm_bf16: UG_EPI_QKV_ROPE needs M, N, qk_until_n multiples of 256 (M=%lld N=%lld qk_until_n=%lld)", (long long)d.M,
                (long long)d.N, (long long)d.qk_until_n);
     UG_REQUIRE(d.groups == 1 && d.lora_r <= 0, UG_ERR_UNSUPPORTED, "ug_gemm_bf16: UG_EPI_QKV_ROPE is neither grouped nor LoRA-extended");
-    UG_REQUIRE(d.qk_wq && d.qk_wk && d.rope_cs && ug_aligned(d.qk_wq, 8) && ug_aligned(d.qk_wk, 8) && ug_aligned(d.rope_cs, 16) &&
+    const int qdh = d.qk_dh == 0 ? 128 : d.qk_dh;
+    UG_REQUIRE(qdh == 128 || qdh == 64, UG_ERR_UNSUPPORTED, "ug_gemm_bf16: UG_EPI_QKV_ROPE head width %d not in {64, 128}", qdh);
+    UG_REQUIRE(d.qk_wq && d.qk_wk && (d.rope_cs || qdh == 64) && ug_aligned(d.qk_wq, 8) && ug_aligned(d.qk_wk, 8) && ug_aligned(d.rope_cs, 16) &&
                d.ldc % 8 == 0 && ug_aligned(d.C, 16), UG_ERR_BAD_ALIGN, "ug_gemm_bf16: UG_EPI_QKV_ROPE operands missing/misaligned");
     UG_REQUIRE((d.rope_rpb == 0 || d.rope_rpb >= 256) && d.rope_rpb < (1ll << 31) && d.rope_pos0 >= 0 && d.rope_pos0 < (1ll << 31) &&
                (d.gelu_from_n == 0 || d.gelu_from_n >= d.qk_until_n) && (d.c_shift_from_n == 0 || d.c_shift_from_n >= d.qk_until_n),
@@ -756,7 +773,8 @@ int launch_qkrope(const ug_gemm_desc& d, hipStream_t s) {
     constexpr int LDS = LDS256_BYTES + 16 + 256 * 8 * 4;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm256_kernel<UG_EPI_QKV_ROPE, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute((const void*)gemm256_kernel<UG_EPI_QKV_ROPE, false, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute((const void*)gemm256_kernel<UG_EPI_QKV_ROPE, false, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
     }
     static int ncu = 0;
@@ -766,8 +784,12 @@ int launch_qkrope(const ug_gemm_desc& d, hipStream_t s) {
         if (ncu <= 0) ncu = 256;
     }
     const int total = (int)((d.M / 256) * (d.N / 256));
-    hipLaunchKernelGGL((gemm256_kernel<UG_EPI_QKV_ROPE, false>), dim3((unsigned)(total < ncu ? total : ncu)), dim3(512), LDS, s, d, total, total,
-                       1 | ((ug_env_int("UG_GEMM_GROUP_M", 4) & 0xff) << 8), total, 1, (float*)nullptr, (unsigned*)nullptr);
+    const int wgm = 1 | ((ug_env_int("UG_GEMM_GROUP_M", 4) & 0xff) << 8);
+    const dim3 grid((unsigned)(total < ncu ? total : ncu));
+    if (qdh == 128)
+        hipLaunchKernelGGL((gemm256_kernel<UG_EPI_QKV_ROPE, false, 128>), grid, dim3(512), LDS, s, d, total, total, wgm, total, 1, (float*)nullptr, (unsigned*)nullptr);
+    else
+        hipLaunchKernelGGL((gemm256_kernel<UG_EPI_QKV_ROPE, false, 64>), grid, dim3(512), LDS, s, d, total, total, wgm, total, 1, (float*)nullptr, (unsigned*)nullptr);
     UG_CHECK_LAUNCH("ug_gemm_bf16");
     return UG_OK;
 }

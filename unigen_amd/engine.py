@@ -246,9 +246,9 @@ class HipModule(nn.Module):
         w_qkv, b_qkv = self._attn_qkv(a)
         # sample rows: q / k RMSNorm + RoPE in the projection's epilogue when the shapes allow it (whole 256^2 tiles, heads of 128)
         cs = getattr(rope, "cs", None)
-        fused = (cs is not None and wq is not None and ops.qk_rope_fusable(B * Ls, 3 * D, 2 * D, dh, ns.dtype))
+        fused = (wq is not None and (cs is not None or (cos is None and dh == 64)) and ops.qk_rope_fusable(B * Ls, 3 * D, 2 * D, dh, ns.dtype))
         ops.gemm(ns, w_qkv, b_qkv, qkv2[Lc:], M=B * Ls, ldc=3 * D, c_map=RowMap(Ls, Lj),
-                 qk_rope=ops.QkRope(wq, wk, cs, Ls, Lc, 2 * D) if fused else None)
+                 qk_rope=ops.QkRope(wq, wk, cs, Ls, Lc, 2 * D, dh=dh) if fused else None)
         # context stream
         emb_c = None
         if c_out is not None or not ctx_cached:
@@ -298,9 +298,10 @@ class HipModule(nn.Module):
             a2 = p + ".attn2"
             q2 = self._w("qkv2_" + tag, (B * Ls, 3 * D))
             w2, b2 = self._attn_qkv(a2)
-            ops.gemm(n2, w2, b2, q2, M=B * Ls)
             w2q, w2k = opt(a2 + ".norm_q.weight"), opt(a2 + ".norm_k.weight")
-            if w2q is not None:
+            fused2 = w2q is not None and dh == 64 and ops.qk_rope_fusable(B * Ls, 3 * D, 2 * D, dh, n2.dtype)     # attn2 has no RoPE
+            ops.gemm(n2, w2, b2, q2, M=B * Ls, qk_rope=ops.QkRope(w2q, w2k, None, Ls, 0, 2 * D, dh=dh) if fused2 else None)
+            if w2q is not None and not fused2:
                 ops.qk_rmsnorm_rope(q2, batches=B, rows_per_batch=Ls, ld=3 * D, q_off=0, k_off=D, heads=H, dh=dh, wq_b=w2q, wk_b=w2k, split=0)
             att2 = self._w("att2_" + tag, (B * Ls, D))
             st2 = (3 * D, Ls * 3 * D)

@@ -294,7 +294,7 @@ class UniGenFlux(HipModule):
             # q / k RMSNorm + RoPE ride in the same launch's epilogue when the shapes allow (whole 256^2 tiles)
             fused = cs is not None and ops.qk_rope_fusable(B * Lj, 7 * D, 2 * D, dh, n.dtype)
             ops.gemm(n, w7, b7, sb, M=B * Lj, ldc=8 * D, epilogue=L.EPI_BIAS_GELU, gelu_from_n=3 * D, c_shift_from_n=3 * D, c_shift=D,
-                     qk_rope=ops.QkRope(wq, wk, cs, Lj, 0, 2 * D) if fused else None)
+                     qk_rope=ops.QkRope(wq, wk, cs, Lj, 0, 2 * D, dh=dh) if fused else None)
         else:
             w_qkv, b_qkv = self._attn_qkv(a)
             ops.gemm(n, w_qkv, b_qkv, sb, M=B * Lj, ldc=8 * D)

@@ -39,7 +39,7 @@ class GemmDesc(C.Structure):
         ("gelu_from_n", i64), ("c_shift_from_n", i64), ("c_shift", i64),
         ("qk_wq", vp), ("qk_wk", vp), ("rope_cs", vp),
         ("rope_rpb", i64), ("rope_pos0", i64), ("qk_until_n", i64),
-        ("qk_eps", f32), ("_pad2", i32),
+        ("qk_eps", f32), ("qk_dh", i32),
     ]
 
 

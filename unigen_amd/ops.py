@@ -113,10 +113,10 @@ class QkRope:
     """Operands of the UG_EPI_QKV_ROPE epilogue: RMSNorm weights of the q / k heads [128], the (cos, sin) pair table [positions, 64, 2]
     fp32, and the position of output row m = pos0 + m % rows_per_batch. Columns [0, until_n) of the projection are q | k heads."""
 
-    __slots__ = ("wq", "wk", "cs", "rpb", "pos0", "until_n", "eps")
+    __slots__ = ("wq", "wk", "cs", "rpb", "pos0", "until_n", "eps", "dh")
 
-    def __init__(self, wq, wk, cs, rows_per_batch: int, pos0: int, until_n: int, eps: float = 1e-6):
-        self.wq, self.wk, self.cs, self.rpb, self.pos0, self.until_n, self.eps = wq, wk, cs, rows_per_batch, pos0, until_n, eps
+    def __init__(self, wq, wk, cs, rows_per_batch: int, pos0: int, until_n: int, eps: float = 1e-6, dh: int = 128):
+        self.wq, self.wk, self.cs, self.rpb, self.pos0, self.until_n, self.eps, self.dh = wq, wk, cs, rows_per_batch, pos0, until_n, eps, dh
 
 
 def qk_rope_fusable(M: int, N: int, until_n: int, dh: int, dtype: torch.dtype) -> bool:
@@ -125,7 +125,7 @@ def qk_rope_fusable(M: int, N: int, until_n: int, dh: int, dtype: torch.dtype) -
     UG_GEMM_FUSE_QKROPE=0 keeps the stand-alone ug_qk_rmsnorm_rope pass (A/B measurements)."""
     if os.environ.get("UG_GEMM_FUSE_QKROPE", "1") == "0":
         return False
-    return (dtype == torch.bfloat16 and dh == 128 and M % 256 == 0 and N % 256 == 0 and until_n % 256 == 0 and (M // 256) * (N // 256) >= 256)
+    return (dtype == torch.bfloat16 and dh in (64, 128) and M % 256 == 0 and N % 256 == 0 and until_n % 256 == 0 and (M // 256) * (N // 256) >= 256)
 
 
 _gemm_ws: dict = {}
@@ -181,13 +181,19 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: to
     d.gelu_from_n, d.c_shift_from_n, d.c_shift = gelu_from_n, c_shift_from_n, c_shift
     if qk_rope is not None:
         q = qk_rope
-        _chk(q.wq, "qk_rope.wq", dt); _chk(q.wk, "qk_rope.wk", dt); _chk(q.cs, "qk_rope.cs", torch.float32)
-        if q.wq.numel() != 128 or q.wk.numel() != 128 or q.cs.dim() != 3 or tuple(q.cs.shape[1:]) != (64, 2) or not q.cs.is_contiguous():
-            raise ValueError("qk_rope: weights must be [128], the pair table [positions, 64, 2] contiguous")
-        if q.cs.shape[0] < q.pos0 + (q.rpb if q.rpb else M):
-            raise ValueError(f"qk_rope: the pair table has {q.cs.shape[0]} positions, rows reach {q.pos0 + (q.rpb if q.rpb else M)}")
-        d.qk_wq, d.qk_wk, d.rope_cs = q.wq.data_ptr(), q.wk.data_ptr(), q.cs.data_ptr()
-        d.rope_rpb, d.rope_pos0, d.qk_until_n, d.qk_eps = q.rpb, q.pos0, q.until_n, q.eps
+        _chk(q.wq, "qk_rope.wq", dt); _chk(q.wk, "qk_rope.wk", dt)
+        if q.wq.numel() != q.dh or q.wk.numel() != q.dh:
+            raise ValueError(f"qk_rope: weights must be [{q.dh}]")
+        if q.cs is not None:
+            _chk(q.cs, "qk_rope.cs", torch.float32)
+            if q.cs.dim() != 3 or tuple(q.cs.shape[1:]) != (q.dh // 2, 2) or not q.cs.is_contiguous():
+                raise ValueError(f"qk_rope: the pair table must be [positions, {q.dh // 2}, 2] contiguous")
+            if q.cs.shape[0] < q.pos0 + (q.rpb if q.rpb else M):
+                raise ValueError(f"qk_rope: the pair table has {q.cs.shape[0]} positions, rows reach {q.pos0 + (q.rpb if q.rpb else M)}")
+        elif q.dh != 64:
+            raise ValueError("qk_rope: the (cos, sin) table may only be omitted at head width 64")
+        d.qk_wq, d.qk_wk, d.rope_cs = q.wq.data_ptr(), q.wk.data_ptr(), _p(q.cs)
+        d.rope_rpb, d.rope_pos0, d.qk_until_n, d.qk_eps, d.qk_dh = q.rpb, q.pos0, q.until_n, q.eps, q.dh
     stream = _stream()
     ws = _gemm_workspace(a.device, stream)
     d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
