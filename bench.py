@@ -111,6 +111,36 @@ def cpu_baseline(model, mode: str = "auto", max_threads: int = 16):
     torch.set_num_threads(cores)
     if mode == "auto":
         mode = "full" if mem_gb >= 90.0 else "slice"
+    if mode == "cfg1":
+        # BASELINE.json configs[0], the reference's own CPU-runnable case, END TO END on both sides: 512^2 (N = 1024, T = 512), B = 1, the 4-step
+        # denoise loop (4 full-depth forwards + 4 Euler steps) of the oracle on the host and of the HIP path on the GPU, same weights and inputs.
+        from unigen_amd.pipeline import denoise_loop
+        cfg = R.FluxConfig()
+        st = {k: v.detach().to("cpu") for k, v in model.state_dict().items()}
+        inp = R.make_inputs(cfg, B=1, grid=32, T=512)
+        unis = [torch.rand(1024, cfg.expert_nums, generator=torch.Generator().manual_seed(i)) for i in range(4)]
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            ref = R.denoise(st, cfg, latents=inp["hidden_states"], num_steps=4, gate_uniforms=unis,
+                            **{k: v for k, v in inp.items() if k not in ("hidden_states", "gate_uniform")})
+        dt = time.perf_counter() - t0
+        del st
+        dev = next(model.parameters()).device
+        g = {k: v.to(dev) for k, v in inp.items()}
+        def gpu_run():
+            return denoise_loop(model, latents=g["hidden_states"].clone(), control_tokens=g["condition_hidden_states"], prompt_embeds=g["encoder_hidden_states"],
+                                pooled_prompt_embeds=g["pooled_projections"], condition_pooled_prompt_embeds=g["condition_pooled_projections"],
+                                text_ids=g["txt_ids"], latent_image_ids=g["img_ids"], condition_ids=g["condition_ids"], num_inference_steps=4,
+                                gate_uniforms=[u.to(dev) for u in unis])
+        with torch.no_grad():
+            out = gpu_run(); torch.cuda.synchronize()
+            t1 = time.perf_counter(); out = gpu_run(); torch.cuda.synchronize(); dg = time.perf_counter() - t1
+        rel = float((out.float().cpu() - ref.float()).norm() / ref.float().norm())
+        fl = 4 * canonical_flops_per_forward(3072, 1024, 512, 19, 38, 9, 19, 1)
+        return dict(value=1.0 / dt, unit="images/s", cores=cores, kind="port", cpu=cpu_model, mode="cfg1",
+                    sample=f"cfg1 END TO END (512^2, B=1, 4 steps, full depth): oracle {dt:.1f} s per image on {cores} threads ({fl / dt / 1e12:.2f} TFLOP/s); "
+                           f"the HIP path runs the same job in {dg * 1e3:.0f} ms; relL2(final latents, oracle bf16) = {rel:.3e}",
+                    sample_seconds=dt, sample_tflops=fl / 1e12, cpu_tflops_per_s=fl / dt / 1e12, gpu_cfg1_images_per_s=1.0 / dg, cfg1_rel_l2_vs_oracle=rel)
     B, grid, T = 1, 64, 512
     full_flops_per_image = 4 * canonical_flops_per_forward(3072, 4096, 512, 19, 38, 9, 19, 1)
     if mode == "full":
@@ -155,7 +185,8 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="samples per GPU per step; default 4 at N = 1 (cfg2, the metric's configuration) and 8 at "
                     "N > 1 (cfg4: global batch 64 = 8 x 8, reference infer.py:173 shards the samples by rank)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline", choices=["auto", "full", "slice"], default="auto", help="full = one full-depth 1024^2 oracle forward x 4 (needs ~90 GB host RAM)")
+    ap.add_argument("--cpu-baseline", choices=["auto", "full", "slice", "cfg1"], default="auto",
+                    help="full = one full-depth 1024^2 oracle forward x 4 (needs ~90 GB host RAM); cfg1 = BASELINE configs[0] end to end (512^2, B = 1, 4 steps) on CPU and GPU")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--small", action="store_true", help="debug: reduced depth (NOT the headline configuration)")
     ap.add_argument("--graph", action="store_true", help="capture one step (the 4-step denoise loop) in a HIP graph and replay it (SURVEY 8(f) rank 1)")
