@@ -204,3 +204,33 @@ def test_training_variants_fp32(gpu, over):
     e = float((gh - gr).norm() / gr.norm())
     print(f"training variant {list(over)[0]}: loss {loss_h:.6f} vs {loss_r:.6f}, gradients rel_l2 {e:.3e}")
     assert abs(loss_h - loss_r) <= 1e-5 * abs(loss_r) + 1e-7 and e <= 1e-3, (loss_h, loss_r, e)
+
+
+def test_training_gradients_at_flux_width_fp32(gpu):
+    """FLUX WIDTH (D = 3072, 24 heads of 128, pooled 768, text 4096) at reduced depth (2 + 2 base blocks and their control blocks, both shared
+    experts, CoMoE E = 6): loss and control-module gradients of the fp32 verification path against the fp32 oracle's autograd - the 24-head attention
+    backward, K = 15360 proj_out and 3072-wide AdaLN / RMSNorm backward at their real sizes."""
+    import importlib
+    cls = importlib.import_module("src.UniGenTransformer").UniGenFlux
+    cfg = dict(num_layers=2, num_single_layers=2)
+    rcfg = R.FluxConfig(condition_nums=1, **cfg)
+    model = cls.from_config(cfg, device=gpu, dtype=torch.float32)
+    model.init_condition_block(condition_nums=1, condition_types=["canny"], control_params=dict(CONTROL))
+    model.init_synthetic_(seed=6, std=0.02, bias_std=0.01)
+    state = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    model.init_trainable_param()
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
+    inp = R.make_inputs(rcfg, B=1, grid=8, T=64)
+    t = torch.full((1,), 0.5, dtype=BF)
+    target = torch.randn(1, 64, 64, generator=torch.Generator().manual_seed(8))
+    kw = {k: _dev(v, gpu, torch.float32 if k != "gate_uniform" and not k.endswith("_ids") else None) for k, v in inp.items()}
+    _, loss_h, _ = _step(lambda: model(timestep=t.to(gpu), **kw), target, torch.float32)
+    st = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in state.items()}
+    _, loss_r, _ = _step(lambda: R.unigen_flux_forward(st, rcfg, timestep=t, dtype=torch.float32, **inp), target, torch.float32)
+    z = lambda g, k: (g.detach().float().cpu() if g is not None else torch.zeros(state[k].shape))
+    gh = torch.cat([z(model.get_parameter(k).grad, k).flatten() for k in names])
+    gr = torch.cat([z(st[k].grad, k).flatten() for k in names])
+    e = float((gh - gr).norm() / gr.norm())
+    print(f"training FLUX width fp32: loss {loss_h:.6f} vs {loss_r:.6f}, {gh.numel() / 1e9:.2f} B gradient elements, rel_l2 {e:.3e}")
+    report("train_flux_width_f32_grads", gh, gr)
+    assert abs(loss_h - loss_r) <= 1e-5 * abs(loss_r) + 1e-7 and e <= 1e-3, (loss_h, loss_r, e)
