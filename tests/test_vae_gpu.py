@@ -190,3 +190,30 @@ def test_pipeline_pixels_in_pixels_out_with_native_vae(gpu):
     from unigen_amd import pipeline as P
     z = vae.encode_scaled(img.to(gpu), noise=torch.zeros(B, 16, H // 8, W // 8, device=gpu, dtype=BF))
     assert torch.equal(P.pack_latents(z).cpu(), P.pack_latents(z.cpu()))
+
+
+def test_vae_full_geometry_parity_at_512(gpu):
+    """The FLUX VAE at its real widths (128 / 256 / 512 / 512 channels, 83.8 M parameters; the 4 K-token mid-block attention) on a 512 x 512 image:
+    fp32 verification twins against the fp32 oracle (<= 1e-3), bf16 product path as close to that truth as the oracle's bf16."""
+    from unigen_amd.vae import AutoencoderKL
+    cfg = V.VAEConfig()
+    m16 = AutoencoderKL.from_config({}, device=gpu, dtype=BF).init_synthetic_(seed=2)
+    state = {k: v.detach().cpu() for k, v in m16.state_dict().items()}
+    m32 = AutoencoderKL.from_config({}, device=gpu, dtype=F32)
+    m32.load_state_dict({k: v.float() for k, v in m16.state_dict().items()})
+    g = torch.Generator().manual_seed(12)
+    lat = torch.randn(1, 16, 64, 64, generator=g).to(BF)
+    d_t, d_r = V.decode_latents(state, cfg, lat, F32), V.decode_latents(state, cfg, lat, BF)
+    d32, d16 = m32.decode_scaled(lat.to(gpu)), m16.decode_scaled(lat.to(gpu))
+    m = report("vae_full_decode_f32", d32, d_t)
+    e_hip, e_ref = rel_l2(d16, d_t), rel_l2(d_r, d_t)
+    report("vae_full_decode_bf16", d16, d_r, err_hip_vs_fp32=e_hip, err_oraclebf16_vs_fp32=e_ref)
+    assert d32.shape == (1, 3, 512, 512) and m["rel_l2"] <= 1e-3 and e_hip <= 1.25 * e_ref + 1e-4, (m, e_hip, e_ref)
+    img = (torch.rand(1, 3, 512, 512, generator=g) * 2 - 1).to(BF)
+    noise = torch.randn(1, 16, 64, 64, generator=g).to(BF)
+    z_t, z_r = V.encode_condition(state, cfg, img, noise, F32), V.encode_condition(state, cfg, img, noise, BF)
+    z32, z16 = m32.encode_scaled(img.to(gpu), noise=noise.to(gpu)), m16.encode_scaled(img.to(gpu), noise=noise.to(gpu))
+    m = report("vae_full_encode_f32", z32, z_t)
+    e_hip, e_ref = rel_l2(z16, z_t), rel_l2(z_r, z_t)
+    report("vae_full_encode_bf16", z16, z_r, err_hip_vs_fp32=e_hip, err_oraclebf16_vs_fp32=e_ref)
+    assert m["rel_l2"] <= 1e-3 and e_hip <= 1.25 * e_ref + 1e-4, (m, e_hip, e_ref)
