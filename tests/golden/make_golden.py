@@ -105,8 +105,43 @@ def vae_golden():
     print("vae_tiny", {k: tuple(v.shape) for k, v in tensors.items()})
 
 
+TRAIN_CTL = dict(use_rope=True, use_shared_expert=True, use_single_trans_blocks=True, single_control_dev=2, single_block_control_method="overall_add")
+
+
+def train_golden():
+    """One training step (train.py:622-662) of the tiny FLUX configuration on the oracle under autograd, fp32: the loss and, per trainable
+    parameter, the gradient's L2 norm and its first 8 entries - small enough to commit, enough to pin the oracle's backward and the HIP backward."""
+    cfg_d = dict(TINY, num_single_layers=2)
+    cfg = R.FluxConfig(condition_nums=1, **cfg_d)
+    case = dict(B=2, grid=8, T=64, state_seed=21, input_seed=5, timestep=0.75, target_seed=9)
+    st = R.make_state(cfg, seed=case["state_seed"], std=0.05, bias_std=0.02, dtype=torch.float32)
+    trainable = sorted(k for k in st if k.split(".")[0] in ("control_time_text_embed", "control_condition_embed", "control_context_embedder", "control_x_embedder",
+                                                           "control_joint_trans_blocks", "controlnet_add_joint_blocks", "moe", "control_single_trans_blocks",
+                                                           "controlnet_add_single_blocks", "shared_expert"))
+    for k in trainable:
+        st[k] = st[k].clone().requires_grad_(True)
+    inp = R.make_inputs(cfg, B=case["B"], grid=case["grid"], T=case["T"], seed=case["input_seed"])
+    t = torch.full((case["B"],), case["timestep"], dtype=torch.bfloat16)
+    target = torch.randn(case["B"], case["grid"] ** 2, 64, generator=torch.Generator().manual_seed(case["target_seed"]))
+    out, losses, _ = R.unigen_flux_forward(st, cfg, timestep=t, dtype=torch.float32, **inp)
+    loss = ((out - target) ** 2).reshape(case["B"], -1).mean(1).mean() + losses["moe_loss"]
+    loss.backward()
+    tensors = flatten(inp)
+    tensors.update({"timestep": t, "target": target, "out.loss": loss.detach().reshape(1)})
+    names = []
+    for k in trainable:
+        g = st[k].grad if st[k].grad is not None else torch.zeros_like(st[k])
+        names.append(k)
+        tensors["grad." + k] = torch.cat([g.norm().reshape(1), g.flatten()[:8].clone(), torch.zeros(max(0, 8 - g.numel()))])[:9].contiguous()
+    meta = dict(config=json.dumps(cfg_d), case=json.dumps(case), trainable=json.dumps(names), generator="oracle/unigen_ref.py under torch autograd (CPU, fp32)")
+    save_file(tensors, os.path.join(HERE, "train_flux_tiny.safetensors"), metadata=meta)
+    print("train_flux_tiny", len(names), "parameters, loss", float(loss))
+
+
 def main():
     torch.set_num_threads(4)
+    if "--train-only" in sys.argv:
+        return train_golden()
     if "--vae-only" in sys.argv:
         return vae_golden()
     if "--only-new" not in sys.argv:
@@ -114,6 +149,7 @@ def main():
     sd3_goldens()
     block_goldens()
     vae_golden()
+    train_golden()
 
 
 def flux_goldens():

@@ -191,3 +191,25 @@ def test_oracle_reproduces_block_and_sd3_goldens():
         sst = R.make_sd3_state(scfg, seed=case["state_seed"], std=0.05, bias_std=0.02)
         o32, _, cnt = R.unigen_sd3_forward(sst, scfg, timestep=g["timestep"], dtype=torch.float32, **inp)
         assert rel(o32, g["out.fp32"]) <= 1e-4 and torch.equal(cnt["expert_counts"], g["out.expert_counts"])
+
+
+def test_training_golden_pins_the_oracle_backward():
+    """tests/golden/train_flux_tiny.safetensors (tests/golden/make_golden.py --train-only): loss and per-parameter gradient norm + first entries of
+    one training step on the oracle under autograd; recomputed here."""
+    cfg_d, case, inp, g = load_golden("train_flux_tiny")
+    with safe_open(os.path.join(GOLD, "train_flux_tiny.safetensors"), "pt") as f:
+        names = json.loads(f.metadata()["trainable"])
+    cfg = R.FluxConfig(condition_nums=1, **cfg_d)
+    st = R.make_state(cfg, seed=case["state_seed"], std=0.05, bias_std=0.02, dtype=torch.float32)
+    for k in names:
+        st[k] = st[k].clone().requires_grad_(True)
+    out, losses, _ = R.unigen_flux_forward(st, cfg, timestep=g["timestep"], dtype=torch.float32, **inp)
+    loss = ((out - g["target"]) ** 2).reshape(case["B"], -1).mean(1).mean() + losses["moe_loss"]
+    loss.backward()
+    assert abs(float(loss) - float(g["out.loss"])) <= 1e-6 * abs(float(loss))
+    for k in names:
+        gr = st[k].grad if st[k].grad is not None else torch.zeros_like(st[k])
+        ref = g["grad." + k]
+        assert abs(float(gr.norm()) - float(ref[0])) <= 1e-4 * float(ref[0]) + 1e-9, k
+        n = min(8, gr.numel())
+        assert torch.allclose(gr.flatten()[:n], ref[1:1 + n], rtol=1e-3, atol=1e-6 + 1e-4 * float(ref[0]) / max(gr.numel(), 1) ** 0.5), k

@@ -234,3 +234,34 @@ def test_training_gradients_at_flux_width_fp32(gpu):
     print(f"training FLUX width fp32: loss {loss_h:.6f} vs {loss_r:.6f}, {gh.numel() / 1e9:.2f} B gradient elements, rel_l2 {e:.3e}")
     report("train_flux_width_f32_grads", gh, gr)
     assert abs(loss_h - loss_r) <= 1e-5 * abs(loss_r) + 1e-7 and e <= 1e-3, (loss_h, loss_r, e)
+
+
+def test_training_golden_fixture_fp32(gpu):
+    """The committed training fixture (oracle autograd, fp32: loss, per-parameter gradient norms and first entries) against the HIP fp32 path."""
+    import importlib, json, os
+    from safetensors import safe_open
+    from tests.test_oracle_cpu import load_golden, GOLD
+    cfg_d, case, inp, g = load_golden("train_flux_tiny")
+    with safe_open(os.path.join(GOLD, "train_flux_tiny.safetensors"), "pt") as f:
+        names = json.loads(f.metadata()["trainable"])
+    rcfg = R.FluxConfig(condition_nums=1, **cfg_d)
+    state = R.make_state(rcfg, seed=case["state_seed"], std=0.05, bias_std=0.02, dtype=torch.float32)
+    cls = importlib.import_module("src.UniGenTransformer").UniGenFlux
+    model = cls.from_config(cfg_d, device=gpu, dtype=torch.float32)
+    model.init_condition_block(condition_nums=1, condition_types=["canny"], control_params=dict(CONTROL))
+    res = model.load_state_dict({k: v.to(gpu) for k, v in state.items()}, strict=False)
+    assert not res.missing_keys and not res.unexpected_keys
+    model.init_trainable_param()
+    assert sorted(n for n, p in model.named_parameters() if p.requires_grad) == names
+    kw = {k: _dev(v, gpu, torch.float32 if k != "gate_uniform" and not k.endswith("_ids") else None) for k, v in inp.items()}
+    _, loss, _ = _step(lambda: model(timestep=g["timestep"].to(gpu), **kw), g["target"], torch.float32)
+    assert abs(loss - float(g["out.loss"])) <= 1e-5 * abs(loss)
+    worst = 0.0
+    total = sum(float(g["grad." + k][0]) ** 2 for k in names) ** 0.5
+    for k in names:
+        gr = model.get_parameter(k).grad
+        gr = gr.float().cpu() if gr is not None else torch.zeros(state[k].shape)
+        ref = g["grad." + k]
+        worst = max(worst, abs(float(gr.norm()) - float(ref[0])) / max(float(ref[0]), 1e-3 * total / len(names) ** 0.5))
+    print(f"training golden: loss {loss:.6f}, worst per-parameter gradient-norm deviation {worst:.3e}")
+    assert worst <= 1e-3, worst
