@@ -164,3 +164,28 @@ def test_gate_residual_backward(gpu):
     g = torch.Generator().manual_seed(6)
     x, a, gate = torch.randn(3, 70, 192, generator=g), torch.randn(3, 70, 192, generator=g), torch.randn(3, 192, generator=g)
     run_case(gpu, lambda x, a, gt: A.gate_residual(x, a, gt), lambda x, a, gt: x + gt.unsqueeze(1) * a, [x, a, gate], name="gate_residual")
+
+
+@pytest.mark.parametrize("R_,I,J", [(4608, 3072, 3072), (1000, 192, 64), (130, 64, 256), (64, 8, 8), (2500, 320, 1544)])
+def test_gemm_tn_weight_gradient(gpu, R_, I, J):
+    """ug_gemm_tn_bf16 = A^T B (dW = dY^T X) from row-major operands: against fp32 torch on the CPU and against the transposes + ug_gemm_bf16 route."""
+    from unigen_amd import ops
+    g = torch.Generator().manual_seed(R_ + I)
+    a, b = (torch.randn(R_, I, generator=g) * 0.5).to(BF), (torch.randn(R_, J, generator=g) * 0.5).to(BF)
+    ref = a.float().t() @ b.float()
+    out = ops.gemm_tn(a.to(gpu), b.to(gpu))
+    e = rel(out, ref)
+    Rp = (R_ + 63) // 64 * 64
+    alt = torch.empty(I, J, device=gpu, dtype=BF)
+    if J % 4 == 0:
+        ops.gemm(ops.transpose(a.to(gpu), Rp), ops.transpose(b.to(gpu), Rp), None, alt, M=I)
+        e_alt = rel(alt, ref)
+    else:
+        e_alt = e
+    print(f"backward gemm_tn {R_}x{I}x{J}: rel_l2 {e:.3e} (transposes + gemm: {e_alt:.3e})")
+    assert e <= 3e-3 and e <= 1.2 * e_alt + 1e-4, (e, e_alt)
+    # strided operands (column slices of wider buffers)
+    wide_a, wide_b = torch.zeros(R_, I + 16, dtype=BF), torch.zeros(R_, J + 24, dtype=BF)
+    wide_a[:, 8:8 + I], wide_b[:, 16:16 + J] = a, b
+    out2 = ops.gemm_tn(wide_a.to(gpu)[:, 8:8 + I], wide_b.to(gpu)[:, 16:16 + J])
+    assert torch.equal(out2, out)

@@ -77,10 +77,15 @@ class Linear(torch.autograd.Function):
             dx = torch.empty(M, K, device=x.device, dtype=x.dtype)
             ops.gemm(dy, _w_transposed(w), None, dx, M=M)
         if ctx.needs_input_grad[1]:
-            Mp = _pad64(M)
-            dyt, xt = ops.transpose(dy, Mp), _x_transposed(x, Mp)          # [N, Mp], [K, Mp]
-            dw = torch.empty(N, K, device=x.device, dtype=x.dtype)
-            ops.gemm(dyt, xt, None, dw, M=N)
+            if x.dtype == torch.bfloat16 and os.environ.get("UG_WGRAD", "transpose") == "tn":
+                # dY^T X straight from the row-major operands (csrc/gemm_tn.hip: both fragments by transposing LDS reads). Opt-in: its simple 128^2
+                # lock-step structure measured 6 % SLOWER per step than two transposes + the 256^2 kernel (0.884 vs 0.832 s backward at B = 2)
+                dw = ops.gemm_tn(dy, x)
+            else:                                                             # transposed copies + ug_gemm (also what the fp32 verification path runs)
+                Mp = _pad64(M)
+                dyt, xt = ops.transpose(dy, Mp), _x_transposed(x, Mp)          # [N, Mp], [K, Mp]
+                dw = torch.empty(N, K, device=x.device, dtype=x.dtype)
+                ops.gemm(dyt, xt, None, dw, M=N)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = ops.colsum(dy).view(N)
         return dx, dw, db

@@ -9,7 +9,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libunigen_hip.so")
-SOURCES = ["core.hip", "gemm.hip", "gemm_pwg.hip", "attention.hip", "elementwise.hip", "moe.hip", "verify_f32.hip", "probe.hip", "vae.hip", "backward.hip"]
+SOURCES = ["core.hip", "gemm.hip", "gemm_pwg.hip", "attention.hip", "elementwise.hip", "moe.hip", "verify_f32.hip", "probe.hip", "vae.hip", "backward.hip", "gemm_tn.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # attention: scores are finite or -inf, never NaN; without IEEE mode hipcc drops the NaN-quieting v_max x,x it adds per fmaxf operand
 EXTRA = {"attention.hip": ["-fno-honor-nans", "-mno-amdgpu-ieee"]}

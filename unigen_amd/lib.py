@@ -83,6 +83,7 @@ SIGNATURES = {
 }
 # fp32 verification twins: `<name>_f32` has the signature of the function it mirrors (include/unigen_hip.h, last section)
 SIGNATURES.update({
+    "ug_gemm_tn_bf16": (i32, [vp, i64, vp, i64, vp, i64, i64, i64, i64, vp]),
     "ug_transpose": (i32, [vp, i64, i64, vp, i64, i64, i64, i64, i64, i64, vp]),
     "ug_colsum": (i32, [vp, i64, vp, i64, vp, i64, i64, i64, i64, f32, vp, i64, vp]),
     "ug_colsum_workspace_bytes": (i64, [i64, i64, i64]),
