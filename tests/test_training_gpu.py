@@ -265,3 +265,32 @@ def test_training_golden_fixture_fp32(gpu):
         worst = max(worst, abs(float(gr.norm()) - float(ref[0])) / max(float(ref[0]), 1e-3 * total / len(names) ** 0.5))
     print(f"training golden: loss {loss:.6f}, worst per-parameter gradient-norm deviation {worst:.3e}")
     assert worst <= 1e-3, worst
+
+
+def test_sd3_training_gradients_at_sd35_width_fp32(gpu):
+    """SD3.5-medium WIDTH (D = 1536, 24 heads of 64, pooled 2048, text 4096) at reduced depth (2 joint blocks, the first with dual attention, the last
+    context_pre_only; their control blocks; transformer-block experts; both shared experts): fp32 verification path vs the fp32 oracle's autograd."""
+    import importlib
+    cls = importlib.import_module("src.UniGenTransformer").UniGenSD3
+    cfg = dict(sample_size=16, num_layers=2, pos_embed_max_size=12, dual_attention_layers=(0,))
+    ctl = dict(use_shared_expert=True, use_modulate=False)
+    rcfg = R.SD3Config(use_modulate=False, **cfg)
+    model = cls.from_config(cfg, device=gpu, dtype=torch.float32)
+    model.init_condition_block(condition_nums=1, condition_types=["depth"], control_params=dict(ctl))
+    model.init_synthetic_(seed=8, std=0.02, bias_std=0.01)
+    state = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    model.init_trainable_param()
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
+    inp = R.make_sd3_inputs(rcfg, B=1, hw=16, T=24)
+    t = torch.full((1,), 600.0)
+    target = torch.randn(1, 16, 16, 16, generator=torch.Generator().manual_seed(4))
+    kw = {k: _dev(v, gpu, torch.float32 if k != "gate_uniform" else None) for k, v in inp.items()}
+    _, loss_h, _ = _step(lambda: model(timestep=t.to(gpu), **kw), target, torch.float32)
+    st = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in state.items()}
+    _, loss_r, _ = _step(lambda: R.unigen_sd3_forward(st, rcfg, timestep=t, dtype=torch.float32, **inp), target, torch.float32)
+    z = lambda g, k: (g.detach().float().cpu() if g is not None else torch.zeros(state[k].shape))
+    gh = torch.cat([z(model.get_parameter(k).grad, k).flatten() for k in names])
+    gr = torch.cat([z(st[k].grad, k).flatten() for k in names])
+    e = float((gh - gr).norm() / gr.norm())
+    print(f"training SD3.5 width fp32: loss {loss_h:.6f} vs {loss_r:.6f}, {gh.numel() / 1e9:.2f} B gradient elements, rel_l2 {e:.3e}")
+    assert abs(loss_h - loss_r) <= 1e-5 * abs(loss_r) + 1e-7 and e <= 1e-3, (loss_h, loss_r, e)
