@@ -12,7 +12,7 @@ ap.add_argument("--batch", type=int, default=1)
 ap.add_argument("--size", type=int, default=1024)
 ap.add_argument("--ckpt", action="store_true")
 ap.add_argument("--layers", type=int, nargs=2, default=None)
-ap.add_argument("--steps", type=int, default=2)
+ap.add_argument("--steps", type=int, default=3)
 a = ap.parse_args()
 dev, BF = torch.device("cuda:0"), torch.bfloat16
 cfg = {} if a.layers is None else {"num_layers": a.layers[0], "num_single_layers": a.layers[1]}
@@ -36,8 +36,12 @@ t = torch.full((B,), 0.75, device=dev, dtype=BF)
 target = rn(B, N, 64)
 n_train = sum(p.numel() for p in model.parameters() if p.requires_grad)
 n_all = sum(p.numel() for p in model.parameters())
+from unigen_amd import ops
 times = []
+timer = None
 for step in range(a.steps + 1):
+    if step == a.steps:            # HIP events around every GEMM / attention launch of the last step (not part of the timed minimum)
+        timer = ops.KernelTimer(kinds=("gemm", "attn", "attn_bwd")); ops.set_timer(timer)
     for p in model.parameters():
         p.grad = None
     torch.cuda.synchronize(); t0 = time.time()
@@ -46,11 +50,13 @@ for step in range(a.steps + 1):
     loss = ((out.float() - target) ** 2).reshape(B, -1).mean(1).mean() + losses["moe_loss"]
     loss.backward()
     torch.cuda.synchronize(); t2 = time.time()
-    if step:
+    if step and timer is None:
         times.append((t1 - t0, t2 - t1))
     gn = float(torch.sqrt(sum((p.grad.float() ** 2).sum() for p in model.parameters() if p.grad is not None)))
     print(f"step {step}: loss {float(loss):.5f} grad-norm {gn:.4e} forward {t1 - t0:.3f}s backward {t2 - t1:.3f}s", flush=True)
+ops.set_timer(None)
+rates = {k: dict(launches=v["launches"], ms=round(v["ms"], 1), tflops=round(v["flops"] / v["ms"] / 1e9, 1)) for k, v in timer.summary().items()}
 fw, bw = min(x[0] for x in times), min(x[1] for x in times)
 print("TRAIN_BENCH", json.dumps(dict(batch=B, size=a.size, layers=[model.config.num_layers, model.config.num_single_layers], checkpointing=bool(a.ckpt),
       params_total=n_all, params_trainable=n_train, forward_s=round(fw, 3), backward_s=round(bw, 3), samples_per_s=round(B / (fw + bw), 3),
-      peak_mem_gb=round(torch.cuda.max_memory_allocated() / 2 ** 30, 1))))
+      peak_mem_gb=round(torch.cuda.max_memory_allocated() / 2 ** 30, 1), kernel_rates=rates)))
