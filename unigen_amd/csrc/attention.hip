@@ -943,8 +943,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // row index on the LANE) and STREAMS 64-row tiles of the other side through the forward's swizzled LDS image (row reads for the score-like
 // products, transposed reads for the accumulating product):
 //   LSE : owns queries,  streams K       : S^T = K Q^T                         -> lse2[q] = log2 sum_k 2^(c S)          (lane-local statistics)
-//   DQ  : owns queries,  streams K, V    : S^T = K Q^T, dP^T = V dO^T, dS^T = scale P^T (dP^T - delta)  -> dQ^T += K^T dS^T
-//   DK  : owns keys,     streams Q, dO   : S   = Q K^T, dP   = dO V^T, dS   = scale P   (dP   - delta)  -> dK^T += Q^T dS
+//   DQ  : owns queries,  streams K, V    : S^T = K Q^T, dP^T = V dO^T, dS^T = P^T (dP^T - delta)  -> dQ^T += K^T dS^T, x scale at the end
+//   DK  : owns keys,     streams Q, dO   : S   = Q K^T, dP   = dO V^T, dS   = P   (dP   - delta)  -> dK^T += Q^T dS,     x scale at the end
 //   DV  : owns keys,     streams Q, dO   : S   = Q K^T, P                                               -> dV^T += dO^T P
 // with P = 2^(c S - lse2[q]), c = scale log2(e), delta[q] = sum_d dO[q][d] O[q][d]. In every mode the 32x32 accumulator of a score-like product
 // has the streamed index on its rows and the owned index on its lanes, so its registers, packed to bf16, ARE the B operand of the accumulating
@@ -953,7 +953,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // =====================================================================================================================
 enum { BWD_LSE = 0, BWD_DQ = 1, BWD_DK = 2, BWD_DV = 3 };
 
-template <int DH, int MODE>
+template <int DH, int MODE, bool DMA>
 __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(
     const bf16_t* __restrict__ own1, int64_t o1_rs, int64_t o1_bs, const bf16_t* __restrict__ own2, int64_t o2_rs, int64_t o2_bs,
     const bf16_t* __restrict__ st1, int64_t s1_rs, int64_t s1_bs, const bf16_t* __restrict__ st2, int64_t s2_rs, int64_t s2_bs,
@@ -991,20 +991,60 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(
         st_row[u] = cid / NCH; st_ch[u] = cid % NCH;
         st_off[u] = img_off<DH>(st_row[u], st_ch[u]);
     }
-    u32x4 r1[NST], r2[NST];
-    auto stage_load = [&](int row0) {
+    u32x4 r1[DMA ? 1 : NST], r2[DMA ? 1 : NST];
+    // LDS-DMA staging (DMA): a tile image is NI runs of 1 KiB (RPI rows each), wave w owns runs w * NIW .. + NIW - 1 of both streamed tiles; the
+    // DMAs of tile t + 1 are issued at the top of tile t and waited for (vmcnt(0)) ahead of the barrier that ends it - no staging registers,
+    // no ds_write. The swizzle is applied on the source side as in the forward.
+    constexpr int RPI = 1024 / RB, NI = TILE / 1024, NIW = NI / 8;
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    unsigned d1o[NIW], d2o[NIW];
 #pragma unroll
-        for (int u = 0; u < NST; ++u) {
-            int row = row0 + st_row[u]; if (row > Lst - 1) row = Lst - 1;
-            r1[u] = *(const u32x4*)(S1 + (int64_t)row * s1_rs + st_ch[u] * 8);
-            if constexpr (MODE != BWD_LSE) r2[u] = *(const u32x4*)(S2 + (int64_t)row * s2_rs + st_ch[u] * 8);
+    for (int u = 0; u < NIW; ++u) {
+        const int row = (wv * NIW + u) * RPI + lane / NCH;
+        const int ch = (lane % NCH) ^ row_swz<DH>(row);
+        d1o[u] = (unsigned)(row * (int)s1_rs + ch * 8) * 2u;
+        d2o[u] = (unsigned)(row * (int)s2_rs + ch * 8) * 2u;
+    }
+    auto dma_stream = [&](const bf16_t* base, int64_t rs, const unsigned (&off)[NIW], int row0, unsigned dst) {
+        if (row0 + KVB <= Lst) {
+            const void* tb = uniform_ptr(base + (int64_t)row0 * rs);
+#pragma unroll
+            for (int u = 0; u < NIW; ++u) glds16_off(tb, off[u], dst + u * 1024);
+        } else {                                       // ragged last tile: rows past the end re-read the last row (masked below)
+            int lane_r = lane;
+            asm volatile("" : "+v"(lane_r));
+#pragma unroll
+            for (int u = 0; u < NIW; ++u) {
+                const int row = (wv * NIW + u) * RPI + lane_r / NCH;
+                const int ch = (lane_r % NCH) ^ row_swz<DH>(row);
+                int sr = row0 + row; if (sr > Lst - 1) sr = Lst - 1;
+                glds16_ptr(base + (int64_t)sr * rs + ch * 8, dst + u * 1024);
+            }
+        }
+    };
+    auto stage_load = [&](int row0, int buf) {
+        if constexpr (DMA) {
+            const unsigned l0 = __builtin_amdgcn_readfirstlane(lds_addr(smem)) + buf * 2 * TILE + wv * NIW * 1024;
+            dma_stream(S1, s1_rs, d1o, row0, l0);
+            if constexpr (MODE != BWD_LSE) dma_stream(S2, s2_rs, d2o, row0, l0 + TILE);
+        } else {
+#pragma unroll
+            for (int u = 0; u < NST; ++u) {
+                int row = row0 + st_row[u]; if (row > Lst - 1) row = Lst - 1;
+                r1[u] = *(const u32x4*)(S1 + (int64_t)row * s1_rs + st_ch[u] * 8);
+                if constexpr (MODE != BWD_LSE) r2[u] = *(const u32x4*)(S2 + (int64_t)row * s2_rs + st_ch[u] * 8);
+            }
         }
     };
     auto stage_write = [&](int buf) {
+        if constexpr (DMA) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
 #pragma unroll
-        for (int u = 0; u < NST; ++u) {
-            *(u32x4*)(smem + buf * 2 * TILE + st_off[u]) = r1[u];
-            if constexpr (MODE != BWD_LSE) *(u32x4*)(smem + buf * 2 * TILE + TILE + st_off[u]) = r2[u];
+            for (int u = 0; u < NST; ++u) {
+                *(u32x4*)(smem + buf * 2 * TILE + st_off[u]) = r1[u];
+                if constexpr (MODE != BWD_LSE) *(u32x4*)(smem + buf * 2 * TILE + TILE + st_off[u]) = r2[u];
+            }
         }
     };
     const int rowoff = RB * r;
@@ -1027,12 +1067,12 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(
     }
     float m_run = -INFINITY, l_run = 0.f;
     const int ntiles = (Lst + KVB - 1) / KVB;
-    stage_load(0);
+    stage_load(0, 0);
     stage_write(0);
     __syncthreads();
     for (int t = 0; t < ntiles; ++t) {
         const int cur = t & 1;
-        if (t + 1 < ntiles) stage_load((t + 1) * KVB);
+        if (t + 1 < ntiles) stage_load((t + 1) * KVB, cur ^ 1);
         const unsigned char* B1 = smem + cur * 2 * TILE;
         const unsigned char* B2 = B1 + TILE;
         bf16x8 zf[2][2];
@@ -1076,13 +1116,22 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(
                         }
                     }
                 }
+                // z = P (DV) or P (dP - delta) (DQ, DK: the softmax scale is applied once, to the accumulator, in the epilogue); rows past the
+                // end exist only in the ragged last tile
+                if (t * KVB + KVB <= Lst) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const bool valid = srow0 + (i & 3) + 8 * (i >> 2) < Lst;
-                    const float p = __builtin_amdgcn_exp2f(fmaf(x1[i], c, -(OWN_Q ? my_lse : sl[i])));
-                    float v = p;
-                    if constexpr (TWO) v = p * (x2[i] - (OWN_Q ? my_delta : sd[i])) * scale;
-                    z[i] = valid ? v : 0.f;
+                    for (int i = 0; i < 16; ++i) {
+                        const float p = __builtin_amdgcn_exp2f(fmaf(x1[i], c, -(OWN_Q ? my_lse : sl[i])));
+                        z[i] = TWO ? p * (x2[i] - (OWN_Q ? my_delta : sd[i])) : p;
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const bool valid = srow0 + (i & 3) + 8 * (i >> 2) < Lst;
+                        const float p = __builtin_amdgcn_exp2f(fmaf(x1[i], c, -(OWN_Q ? my_lse : sl[i])));
+                        const float v = TWO ? p * (x2[i] - (OWN_Q ? my_delta : sd[i])) : p;
+                        z[i] = valid ? v : 0.f;
+                    }
                 }
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
@@ -1126,9 +1175,10 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(
         for (int db = 0; db < NDB; ++db)
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
+                const float es = TWO ? scale : 1.f;
                 u32x2 w;
-                w.x = pack2bf(acc[db][4 * g4 + 0], acc[db][4 * g4 + 1]);
-                w.y = pack2bf(acc[db][4 * g4 + 2], acc[db][4 * g4 + 3]);
+                w.x = pack2bf(acc[db][4 * g4 + 0] * es, acc[db][4 * g4 + 1] * es);
+                w.y = pack2bf(acc[db][4 * g4 + 2] * es, acc[db][4 * g4 + 3] * es);
                 *(u32x2*)(Orow + 32 * db + 8 * g4 + 4 * h) = w;
             }
     }
@@ -1257,6 +1307,7 @@ extern "C" int ug_flash_attn_bwd(const void* q, int64_t q_rs, int64_t q_bs, cons
     float* delta = (float*)workspace + batches * heads * stat_ld;
     hipStream_t s = (hipStream_t)stream;
     const float c = softmax_scale * 1.4426950408889634f;
+    const int bwd_dma = ug_env_int("UG_ATTN_BWD_DMA", 1);     // LDS-DMA staging of the streamed tiles (0: through registers)
     const int nQ = (int)((Lq + 255) / 256), nK = (int)((Lkv + 255) / 256);
     const int64_t gq = (int64_t)nQ * heads * batches, gk = (int64_t)nK * heads * batches;
     UG_REQUIRE(gq < (1ll << 31) && gk < (1ll << 31), UG_ERR_UNSUPPORTED, "ug_flash_attn_bwd: grid too large");
@@ -1264,11 +1315,13 @@ extern "C" int ug_flash_attn_bwd(const void* q, int64_t q_rs, int64_t q_bs, cons
     const int64_t total = batches * Lq * heads;
     hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, s, (const bf16_t*)o, o_rs, o_bs, (const bf16_t*)dout, do_rs, do_bs, delta,
                        stat_ld, total, (int)heads, (int)Lq, (int)dh);
-#define UG_BWD(DHV, MODEV, GRID, O1, O1R, O1B, O2, O2R, O2B, S1, S1R, S1B, S2, S2R, S2B, OUT, OR, OB, LOWN, LST, NOWN)                                   \
+#define UG_BWD(DHV, MODEV, GRID, ...)                                                                                                                  \
+    do { if (bwd_dma) UG_BWD_(DHV, MODEV, true, GRID, __VA_ARGS__); else UG_BWD_(DHV, MODEV, false, GRID, __VA_ARGS__); } while (0)
+#define UG_BWD_(DHV, MODEV, DMAV, GRID, O1, O1R, O1B, O2, O2R, O2B, S1, S1R, S1B, S2, S2R, S2B, OUT, OR, OB, LOWN, LST, NOWN)                          \
     do {                                                                                                                                                \
         const int lds_ = 2 * 2 * KVB * 2 * DHV;                                                                                                        \
-        (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<DHV, MODEV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_);                       \
-        hipLaunchKernelGGL((attn_bwd_kernel<DHV, MODEV>), dim3((unsigned)(GRID)), dim3(512), lds_, s, (const bf16_t*)(O1), O1R, O1B, (const bf16_t*)(O2), O2R, O2B, \
+        (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<DHV, MODEV, DMAV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_);                       \
+        hipLaunchKernelGGL((attn_bwd_kernel<DHV, MODEV, DMAV>), dim3((unsigned)(GRID)), dim3(512), lds_, s, (const bf16_t*)(O1), O1R, O1B, (const bf16_t*)(O2), O2R, O2B, \
                            (const bf16_t*)(S1), S1R, S1B, (const bf16_t*)(S2), S2R, S2B, lse2, delta, stat_ld, (bf16_t*)(OUT), OR, OB, (int)heads, (int)(LOWN),   \
                            (int)(LST), (int)(NOWN), c, softmax_scale);                                                                                 \
     } while (0)
@@ -1282,6 +1335,7 @@ extern "C" int ug_flash_attn_bwd(const void* q, int64_t q_rs, int64_t q_bs, cons
     if (dh == 128) UG_BWD_ALL(128); else UG_BWD_ALL(64);
 #undef UG_BWD_ALL
 #undef UG_BWD
+#undef UG_BWD_
     UG_CHECK_LAUNCH("ug_flash_attn_bwd");
     return UG_OK;
 }
