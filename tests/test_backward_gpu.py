@@ -159,6 +159,49 @@ def test_flash_attention_backward_kernels(gpu, dh, H, B, Lq, Lkv, monkeypatch):
         assert torch.isfinite(f.float()).all() and e_f <= max(1.5 * e_g, 6e-3), (i, e_f, e_g)
 
 
+_BWD_VARIANT_SNIPPET = r"""
+import os, sys
+os.environ["UG_ENV_DYNAMIC"] = "1"
+sys.path.insert(0, {root!r})
+import torch
+from unigen_amd import ops
+dev = torch.device("cuda:0")
+g = torch.Generator(device=dev).manual_seed(5)
+bad = 0
+for dh, H, B, Lq, Lkv in [(64, 3, 2, 257, 300), (64, 2, 1, 64, 64), (64, 2, 2, 1000, 1003), (128, 2, 2, 300, 333), (128, 2, 1, 640, 512)]:
+    D = H * dh
+    q, do = (torch.randn(B, Lq, D, generator=g, device=dev).to(torch.bfloat16) for _ in range(2))
+    k, v = (torch.randn(B, Lkv, D, generator=g, device=dev).to(torch.bfloat16) for _ in range(2))
+    o = torch.empty(B, Lq, D, device=dev, dtype=torch.bfloat16)
+    lse = torch.zeros(B, H, (Lq + 63) // 64 * 64, device=dev, dtype=torch.float32)
+    ops.flash_attn(q, k, v, o, batches=B, heads=H, dh=dh, Lq=Lq, Lkv=Lkv, lse=lse, q_strides=(D, Lq * D), k_strides=(D, Lkv * D),
+                   v_strides=(D, Lkv * D), o_strides=(D, Lq * D))
+    outs = []
+    for env in ({{"UG_ATTN_BWD_STAGGER": "0", "UG_ATTN_BWD_DMA": "1"}}, {{"UG_ATTN_BWD_STAGGER": "1", "UG_ATTN_BWD_DMA": "1"}}, {{"UG_ATTN_BWD_STAGGER": "0", "UG_ATTN_BWD_DMA": "0"}}):
+        os.environ.update(env)
+        outs.append(ops.flash_attn_bwd(q, k, v, o, do, heads=H, lse=lse))
+        outs.append(ops.flash_attn_bwd(q, k, v, o, do, heads=H, lse=None))          # statistics recomputed by the LSE mode
+    torch.cuda.synchronize()
+    for i, got in enumerate(outs[1:], 1):
+        for a, b, nm in zip(got, outs[0], ("dq", "dk", "dv")):
+            same = torch.equal(a, b) if i % 2 == 0 else bool(((a.float() - b.float()).norm() / b.float().norm()) < 2e-3)
+            if not same:
+                bad += 1
+                print("MISMATCH", dh, Lq, Lkv, "variant", i, nm)
+sys.exit(1 if bad else 0)
+"""
+
+
+def test_flash_attention_backward_selectable_variants(gpu):
+    """The non-default backward kernels return the default's bits: the X|Y staggered kernel (UG_ATTN_BWD_STAGGER=1, dh 64 only; at dh 128 the
+    switch is ignored) and register staging instead of LDS-DMA (UG_ATTN_BWD_DMA=0); with lse=None (statistics recomputed by the LSE mode
+    rather than taken from the forward) the gradients agree to rounding of the statistics. Ragged lengths, one tile, several tiles."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _BWD_VARIANT_SNIPPET.format(root=root)], env=dict(os.environ), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
 def test_gate_residual_backward(gpu):
     from unigen_amd import autograd as A
     g = torch.Generator().manual_seed(6)

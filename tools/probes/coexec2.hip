@@ -1,0 +1,106 @@
+// Probe 2: an X-like wave (MFMAs fed by pipelined LDS reads) beside a Y-like wave (the backward's Z arithmetic) on the same SIMD.
+// Waves 0-3: per iteration 24 MFMAs 32x32x16, optionally each fed by a 1 KiB ds_read_b128 issued 2 steps ahead; waves 4-7: per iteration
+// 32 elements of exp2(fma) * (x - d) -> bf16 pairs (the DQ fast path), or plain fma streams. s_memtime per role, alone and together.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef __attribute__((__vector_size__(8 * sizeof(short)))) short bf16x8;
+typedef __attribute__((__vector_size__(16 * sizeof(float)))) float f32x16;
+
+__device__ __forceinline__ unsigned pack2bf(float a, float b) {
+    unsigned r; asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r;
+}
+
+template <int XK, int YK>
+__global__ __launch_bounds__(512) void coexec2(int roles, int iters, unsigned long long* out, float* sink) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < 32768 / 4; i += 512) ((unsigned*)smem)[i] = 0x3f803f80u;
+    __syncthreads();
+    const bool mf = wave < 4;
+    if (mf && !(roles & 1)) return;
+    if (!mf && !(roles & 2)) return;
+    unsigned long long t0, t1;
+    if (mf) {
+        f32x16 a0 = {}, a1 = {};
+        bf16x8 y = {1, 1, 1, 1, 1, 1, 1, 1};
+        const unsigned char* base = smem + lane * 16;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+        for (int it = 0; it < iters; ++it) {
+            if constexpr (XK == 0) {
+#pragma unroll
+                for (int u = 0; u < 12; ++u) {
+                    a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(y, y, a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(y, y, a1, 0, 0, 0);
+                }
+            } else {
+                bf16x8 f[3][2];
+                f[0][0] = *(const bf16x8*)(base + 0); f[0][1] = *(const bf16x8*)(base + 1024);
+                f[1][0] = *(const bf16x8*)(base + 2048); f[1][1] = *(const bf16x8*)(base + 3072);
+#pragma unroll
+                for (int u = 0; u < 12; ++u) {
+                    if (u + 2 < 12) { f[(u + 2) % 3][0] = *(const bf16x8*)(base + (u + 2) * 2048); f[(u + 2) % 3][1] = *(const bf16x8*)(base + (u + 2) * 2048 + 1024); }
+                    __builtin_amdgcn_sched_barrier(0);
+                    a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[u % 3][0], y, a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[u % 3][1], y, a1, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        asm volatile("s_nop 15\n\ts_nop 15" : "+v"(a0), "+v"(a1));
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+        if (a0[0] + a1[0] == 12345.f) sink[lane] = a0[1];
+    } else {
+        float x1[32], x2[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) { x1[i] = 0.001f * (lane + i); x2[i] = 0.5f + 0.002f * i; }
+        float c = 0.1f, lse = 0.3f, dl = 0.01f;
+        asm volatile("" : "+v"(lse), "+v"(dl), "+s"(c));
+        unsigned acc = 0;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < 32; ++i) { asm volatile("" : "+v"(x1[i])); asm volatile("" : "+v"(x2[i])); }
+            if constexpr (YK == 0) {
+                float z[32];
+#pragma unroll
+                for (int i = 0; i < 32; ++i) { const float p = __builtin_amdgcn_exp2f(fmaf(x1[i], c, -lse)); z[i] = p * (x2[i] - dl); }
+#pragma unroll
+                for (int i = 0; i < 32; i += 2) acc ^= pack2bf(z[i], z[i + 1]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int i = 0; i < 32; ++i) asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(x1[i]) : "v"(x2[i]));
+            }
+        }
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+        float s = 0; for (int i = 0; i < 32; ++i) s += x1[i];
+        if (s == 12345.f || acc == 0x12345u) sink[lane] = s;
+    }
+    if (lane == 0 && blockIdx.x == 17) out[wave] = t1 - t0;
+}
+
+template <int XK, int YK>
+void run(const char* name, unsigned long long* dout, float* sink) {
+    const int iters = 500;
+    double res[3][2];
+    (void)hipFuncSetAttribute((const void*)coexec2<XK, YK>, hipFuncAttributeMaxDynamicSharedMemorySize, 32768);
+    for (int roles = 1; roles <= 3; ++roles) {
+        (void)hipMemset(dout, 0, 64);
+        hipLaunchKernelGGL((coexec2<XK, YK>), dim3(256), dim3(512), 32768, 0, roles, iters, dout, sink);
+        unsigned long long h[8];
+        (void)hipMemcpy(h, dout, 64, hipMemcpyDeviceToHost);
+        res[roles - 1][0] = (double)h[0] / iters; res[roles - 1][1] = (double)h[4] / iters;
+    }
+    printf("COEXEC2 %-34s per iteration: X alone %7.0f | Y alone %7.0f | together: X %7.0f, Y %7.0f\n", name, res[0][0], res[1][1], res[2][0], res[2][1]);
+}
+
+int main() {
+    unsigned long long* dout; float* sink;
+    (void)hipMalloc(&dout, 64); (void)hipMalloc(&sink, 1024);
+    run<0, 0>("X = 24 MFMA            Y = Z math", dout, sink);
+    run<1, 0>("X = 24 MFMA + 24 reads Y = Z math", dout, sink);
+    run<0, 1>("X = 24 MFMA            Y = 128 fma", dout, sink);
+    run<1, 1>("X = 24 MFMA + 24 reads Y = 128 fma", dout, sink);
+    return 0;
+}

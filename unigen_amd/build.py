@@ -13,7 +13,8 @@ SOURCES = ["core.hip", "gemm.hip", "gemm_pwg.hip", "attention.hip", "elementwise
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # attention: scores are finite or -inf, never NaN; without IEEE mode hipcc drops the NaN-quieting v_max x,x it adds per fmaxf operand
 EXTRA = {"attention.hip": ["-fno-honor-nans", "-mno-amdgpu-ieee"]}
-FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-ffp-contract=off"]
+# UG_EXTRA_HIPCC_FLAGS: extra flags for a diagnostic build (e.g. -DUG_DIAG_STAMPS); such a build must be made with force=True both ways
+FLAGS = os.environ.get("UG_EXTRA_HIPCC_FLAGS", "").split() + ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-ffp-contract=off"]
 
 
 def _stale(target: str, deps: list[str]) -> bool:
