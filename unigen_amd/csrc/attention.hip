@@ -466,6 +466,8 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn_kernel(
         };
         const bool groupA = __builtin_amdgcn_readfirstlane(wave) < 4;
         // LDS-DMA staging: a tile image is NI runs of 1 KiB (RPI rows each); wave wb of group B owns runs wb * NIW .. + NIW - 1
+        // (measured and dropped: every wave issuing NI / 8 runs, group A's half at the start of its own softmax segment 2t+1 and waited for
+        // at its end - same bits, -0.5 % at dh 128, -12 % at dh 64: group B's issue cost is not what bounds the segment pairs)
         constexpr int RPI = 1024 / RB, NI = TILE / 1024, NIW = NI / 4;
         const int wb = __builtin_amdgcn_readfirstlane(wave) & 3;
         unsigned dko[NIW], dvo[NIW];
@@ -966,7 +968,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(
     constexpr int RB = 2 * DH, NCH = DH / 8, TILE = KVB * RB, QS = DH / 16, NDB = DH / 32, NT = 512, NST = (KVB * NCH) / NT;
     constexpr bool OWN_Q = MODE == BWD_LSE || MODE == BWD_DQ;          // queries owned (statistics lane-local) or streamed
     constexpr bool TWO = MODE == BWD_DQ || MODE == BWD_DK;             // second score-like product (dP)
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [2][tile of st1 | tile of st2]
+    constexpr int BUFSZ = 2 * TILE + (DMA ? 512 : 0);                      // DMA: + lse2[64] | delta[64] of the streamed rows (queries streamed)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [2][tile of st1 | tile of st2 (| statistics)]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int ot = blockIdx.x % nOwn, bh = blockIdx.x / nOwn;
@@ -1028,9 +1031,13 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(
     };
     auto stage_load = [&](int row0, int buf) {
         if constexpr (DMA) {
-            const unsigned l0 = __builtin_amdgcn_readfirstlane(lds_addr(smem)) + buf * 2 * TILE + wv * NIW * 1024;
+            const unsigned lb = __builtin_amdgcn_readfirstlane(lds_addr(smem)) + buf * BUFSZ, l0 = lb + wv * NIW * 1024;
             dma_stream(S1, s1_rs, d1o, row0, l0);
             if constexpr (MODE != BWD_LSE) dma_stream(S2, s2_rs, d2o, row0, l0 + TILE);
+            if constexpr (!OWN_Q) {                    // the tile's 64 lse2 / delta values ride along (rows padded to a multiple of 64, zeros)
+                if (wv == 0) glds4_ptr(stat_l + row0 + lane, lb + 2 * TILE);
+                if (MODE == BWD_DK && wv == 1) glds4_ptr(stat_d + row0 + lane, lb + 2 * TILE + 256);
+            }
         } else {
 #pragma unroll
             for (int u = 0; u < NST; ++u) {
@@ -1046,8 +1053,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(
         } else {
 #pragma unroll
             for (int u = 0; u < NST; ++u) {
-                *(u32x4*)(smem + buf * 2 * TILE + st_off[u]) = r1[u];
-                if constexpr (MODE != BWD_LSE) *(u32x4*)(smem + buf * 2 * TILE + TILE + st_off[u]) = r2[u];
+                *(u32x4*)(smem + buf * BUFSZ + st_off[u]) = r1[u];
+                if constexpr (MODE != BWD_LSE) *(u32x4*)(smem + buf * BUFSZ + TILE + st_off[u]) = r2[u];
             }
         }
     };
@@ -1077,7 +1084,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(
     for (int t = 0; t < ntiles; ++t) {
         const int cur = t & 1;
         if (t + 1 < ntiles) stage_load((t + 1) * KVB, cur ^ 1);
-        const unsigned char* B1 = smem + cur * 2 * TILE;
+        const unsigned char* B1 = smem + cur * BUFSZ;
         const unsigned char* B2 = B1 + TILE;
         bf16x8 zf[2][2];
         float tmax = -INFINITY;
@@ -1128,7 +1135,19 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(
             } else {
                 float z[16];
                 float sl[16], sd[16];
-                if constexpr (!OWN_Q) {
+                if constexpr (!OWN_Q && DMA) {         // statistics of the streamed rows from the LDS copy (broadcast reads), no global load in the loop
+                    const float* st = (const float*)(B1 + 2 * TILE);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 a = *(const f32x4*)(st + kb * 32 + 4 * h + 8 * g);
+                        sl[4 * g] = a[0]; sl[4 * g + 1] = a[1]; sl[4 * g + 2] = a[2]; sl[4 * g + 3] = a[3];
+                        if constexpr (MODE == BWD_DK) {
+                            const f32x4 d4 = *(const f32x4*)(st + 64 + kb * 32 + 4 * h + 8 * g);
+                            sd[4 * g] = d4[0]; sd[4 * g + 1] = d4[1]; sd[4 * g + 2] = d4[2]; sd[4 * g + 3] = d4[3];
+                        }
+                    }
+                }
+                if constexpr (!OWN_Q && !DMA) {
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         int q0 = srow0 + 8 * g; if (q0 > (int)stat_ld - 4) q0 = (int)stat_ld - 4;       // stat rows are padded to a multiple of 64
@@ -1666,7 +1685,7 @@ extern "C" int ug_flash_attn_bwd(const void* q, int64_t q_rs, int64_t q_bs, cons
     do { if (bwd_dma) UG_BWD_(DHV, MODEV, true, GRID, __VA_ARGS__); else UG_BWD_(DHV, MODEV, false, GRID, __VA_ARGS__); } while (0)
 #define UG_BWD_(DHV, MODEV, DMAV, GRID, O1, O1R, O1B, O2, O2R, O2B, S1, S1R, S1B, S2, S2R, S2B, OUT, OR, OB, LOWN, LST, NOWN)                          \
     do {                                                                                                                                                \
-        const int lds_ = 2 * 2 * KVB * 2 * DHV;                                                                                                        \
+        const int lds_ = 2 * (2 * KVB * 2 * DHV + (DMAV ? 512 : 0));                                                                                   \
         (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<DHV, MODEV, DMAV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_);                       \
         hipLaunchKernelGGL((attn_bwd_kernel<DHV, MODEV, DMAV>), dim3((unsigned)(GRID)), dim3(512), lds_, s, (const bf16_t*)(O1), O1R, O1B, (const bf16_t*)(O2), O2R, O2B, \
                            (const bf16_t*)(S1), S1R, S1B, (const bf16_t*)(S2), S2R, S2B, lse2, delta, stat_ld, (bf16_t*)(OUT), OR, OB, (int)heads, (int)(LOWN),   \
