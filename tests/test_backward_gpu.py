@@ -177,7 +177,7 @@ for dh, H, B, Lq, Lkv in [(64, 3, 2, 257, 300), (64, 2, 1, 64, 64), (64, 2, 2, 1
     ops.flash_attn(q, k, v, o, batches=B, heads=H, dh=dh, Lq=Lq, Lkv=Lkv, lse=lse, q_strides=(D, Lq * D), k_strides=(D, Lkv * D),
                    v_strides=(D, Lkv * D), o_strides=(D, Lq * D))
     outs = []
-    for env in ({{"UG_ATTN_BWD_STAGGER": "0", "UG_ATTN_BWD_DMA": "1"}}, {{"UG_ATTN_BWD_STAGGER": "1", "UG_ATTN_BWD_DMA": "1"}}, {{"UG_ATTN_BWD_STAGGER": "0", "UG_ATTN_BWD_DMA": "0"}}):
+    for env in ({{"UG_ATTN_BWD_DMA": "1"}}, {{"UG_ATTN_BWD_DMA": "0"}}):
         os.environ.update(env)
         outs.append(ops.flash_attn_bwd(q, k, v, o, do, heads=H, lse=lse))
         outs.append(ops.flash_attn_bwd(q, k, v, o, do, heads=H, lse=None))          # statistics recomputed by the LSE mode
@@ -193,9 +193,9 @@ sys.exit(1 if bad else 0)
 
 
 def test_flash_attention_backward_selectable_variants(gpu):
-    """The non-default backward kernels return the default's bits: the X|Y staggered kernel (UG_ATTN_BWD_STAGGER=1, dh 64 only; at dh 128 the
-    switch is ignored) and register staging instead of LDS-DMA (UG_ATTN_BWD_DMA=0); with lse=None (statistics recomputed by the LSE mode
-    rather than taken from the forward) the gradients agree to rounding of the statistics. Ragged lengths, one tile, several tiles."""
+    """Register staging instead of LDS-DMA (UG_ATTN_BWD_DMA=0; statistics of streamed queries by global loads) returns the default's bits; with
+    lse=None (statistics recomputed by the LSE mode rather than taken from the forward) the gradients agree to rounding of the statistics.
+    Ragged lengths, one tile, several tiles, both head widths."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", _BWD_VARIANT_SNIPPET.format(root=root)], env=dict(os.environ), capture_output=True, text=True, timeout=300)

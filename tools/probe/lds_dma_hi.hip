@@ -1,5 +1,5 @@
 // Probe: does global_load_lds_dwordx4 / _dword honour an M0 LDS address above 64 KiB on gfx950 (160 KiB LDS)?
-// Build: hipcc --offload-arch=gfx950 -O2 tools/probes/lds_dma_hi.hip -o tools/probes/bin/lds_dma_hi ; prints one line per destination.
+// Build: hipcc --offload-arch=gfx950 -O2 tools/probe/lds_dma_hi.hip -o tools/probe/bin/lds_dma_hi ; prints one line per destination.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>

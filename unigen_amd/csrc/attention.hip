@@ -956,6 +956,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // has the streamed index on its rows and the owned index on its lanes, so its registers, packed to bf16, ARE the B operand of the accumulating
 // product (the forward's P^T trick); lse / delta are per lane when queries are owned and per accumulator row when they are streamed. S is
 // recomputed per mode (8 product units against the minimum of 5) - still ~4x less time than moving fp32 score matrices through HBM.
+// Streamed tiles (and, when queries are streamed, their 64 lse2 / delta values) reach LDS by LDS-DMA one tile ahead; at dh 128 the LDS reads
+// of every matrix phase are software-pipelined by hand. Measured (tools/attn_bwd_ab.py, profiles/r02f_attn_bwd.log): 501 -> 595 TFLOP/s of the
+// algorithmic 10 B H Lq Lkv dh at dh 128 (4608^2), 395-420 -> 511-551 at dh 64.
+// Tried and removed (commit "Attention backward: hand-pipelined LDS reads ...", same log): an X|Y staggered variant as in the forward (wave
+// groups one segment apart, S of the whole tile and Z crossing the barriers in registers, three LDS-DMA buffers). Same bits, but at dh 128 it
+// needs ~300 registers (hipcc spilled 100: 211 TFLOP/s) and at dh 64 it measured 431-465 against the lock-step kernel's 453-492 of that day:
+// stamps showed each group's segment stretching by 450-900 cycles beside its partner's although a VALU-only and an MFMA-only wave co-execute
+// perfectly in isolation (tools/probe/coexec*.hip) - unexplained, left for a later round. Starting waves 4-7 one matrix phase late per tile
+// inside the lock-step kernel: +3 % / -6 % (dh 128 / 64) before the pipelining, -3 % after it.
 // =====================================================================================================================
 enum { BWD_LSE = 0, BWD_DQ = 1, BWD_DK = 2, BWD_DV = 3 };
 
@@ -1247,299 +1256,6 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(
     }
 }
 
-// =====================================================================================================================
-// Backward, X|Y staggered (modes DQ, DK, DV). The lock-step kernel above spends a tile's matrix time (48 MFMAs per wave), its LDS time (every
-// MFMA's A fragment is a 1 KiB read: 8 waves x 48 KiB = the LDS array's whole bandwidth for as long as the matrix pipe needs) and its VALU time
-// (P, dS: ~1100 cycles per wave) one after the other: ~7600 cycles per tile against ~3100 of each resource. Here the two wave groups run one
-// segment apart, as in the forward:
-//     X(t) = acc += T(t-1)^T Z(t-1)  then  S(t) (and dP(t)): MFMA + LDS reads      Y(t) = Z(t) from S(t): VALU only, no LDS tile reads
-//     segment:   0      1      2      3      4
-//     group A:  S(0)   Y(0)   X(1)   Y(1)   X(2) ...
-//     group B:   -     S(0)   Y(0)   X(1)   Y(1) ...
-// so one group's matrix segment (LDS-fed at half the array's bandwidth) runs beside the other's VALU segment. S(t) crosses the barrier in
-// registers (x1, x2), Z(t) likewise (zf). Streamed tiles are LDS-DMA'd into THREE buffers: tile t is read in segments 2t .. 2t+3 (S by both
-// groups, then the accumulating product of X(t+1)), tile t+2 is issued by every wave at the start of segment 2t+2 (the last reader of its
-// buffer, group B's X(t), ended with segment 2t+1) and waited for at the end of segment 2t+3. When queries are streamed, the 64 lse2 / delta
-// values of the tile ride along (global_load_lds_dword by waves 0 / 1) and are read back with broadcast ds_read_b128 - no global load in the loop.
-// =====================================================================================================================
-// Diagnostic build only (-DUG_DIAG_STAMPS, tools/attn_bwd_stamps.py): per-wave scalar sums of s_memtime differences around the loop's
-// segments, stored once after the loop into a buffer of their own. No stamp executes in the product build.
-#ifdef UG_DIAG_STAMPS
-__device__ unsigned long long ug_attn_stamps[64 * 8 * 8];
-__device__ int ug_diag_mute;        // 1: group B skips its Y / X work, 2: group A does (timing only; results are wrong)
-#define UG_STAMP(v) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
-#define UG_STAMP_ADD(sum, a, b) sum += (b) - (a)
-#else
-#define UG_STAMP(v) do { } while (0)
-#define UG_STAMP_ADD(sum, a, b) do { } while (0)
-#endif
-template <int DH, int MODE>
-__global__ __launch_bounds__(512, 2) void attn_bwd_stg_kernel(
-    const bf16_t* __restrict__ own1, int64_t o1_rs, int64_t o1_bs, const bf16_t* __restrict__ own2, int64_t o2_rs, int64_t o2_bs,
-    const bf16_t* __restrict__ st1, int64_t s1_rs, int64_t s1_bs, const bf16_t* __restrict__ st2, int64_t s2_rs, int64_t s2_bs,
-    const float* __restrict__ lse2, const float* __restrict__ delta, int64_t stat_ld,
-    bf16_t* __restrict__ out, int64_t out_rs, int64_t out_bs, int heads, int Lown, int Lst, int nOwn, float c, float scale) {
-    static_assert(MODE == BWD_DQ || MODE == BWD_DK || MODE == BWD_DV, "statistics come from the forward or the lock-step LSE mode");
-    constexpr int RB = 2 * DH, NCH = DH / 8, TILE = KVB * RB, QS = DH / 16, NDB = DH / 32;
-    constexpr bool OWN_Q = MODE == BWD_DQ, TWO = MODE != BWD_DV;
-    constexpr int BUF = 2 * TILE + 512;                                     // st1 tile | st2 tile | lse2[64] | delta[64]
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [3][BUF]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 31, h = lane >> 5;
-    const int ot = blockIdx.x % nOwn, bh = blockIdx.x / nOwn;
-    const int head = bh % heads, b = bh / heads;
-    const bf16_t* O1 = own1 + (int64_t)b * o1_bs + head * DH;
-    const bf16_t* O2 = TWO ? own2 + (int64_t)b * o2_bs + head * DH : nullptr;
-    const bf16_t* S1 = st1 + (int64_t)b * s1_bs + head * DH;
-    const bf16_t* S2 = st2 + (int64_t)b * s2_bs + head * DH;
-    const int own_row = ot * 256 + wave * 32 + r;
-    const int own_ld = own_row < Lown ? own_row : Lown - 1;
-    bf16x8 f1[QS], f2[TWO ? QS : 1];
-#pragma unroll
-    for (int s = 0; s < QS; ++s) {
-        f1[s] = *(const bf16x8*)(O1 + (int64_t)own_ld * o1_rs + 16 * s + 8 * h);
-        if constexpr (TWO) f2[s] = *(const bf16x8*)(O2 + (int64_t)own_ld * o2_rs + 16 * s + 8 * h);
-    }
-    const float* stat_l = lse2 + (int64_t)bh * stat_ld;
-    const float* stat_d = delta + (int64_t)bh * stat_ld;
-    float my_lse = 0.f, my_delta = 0.f;
-    if constexpr (OWN_Q) { my_lse = stat_l[own_ld]; my_delta = stat_d[own_ld]; }
-    // the owned-operand loads retire here: from now on vmcnt counts LDS-DMAs only
-#pragma unroll
-    for (int s = 0; s < QS; ++s) { asm volatile("" : "+v"(f1[s])); if constexpr (TWO) asm volatile("" : "+v"(f2[s])); }
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(my_lse), "+v"(my_delta)::"memory");
-
-    constexpr int RPI = 1024 / RB, NI = TILE / 1024, NIW = NI / 8;
-    const int wv = __builtin_amdgcn_readfirstlane(wave);
-    const bool groupA = wv < 4;
-    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(smem));
-    const int ntiles = (Lst + KVB - 1) / KVB;
-    unsigned d1o[NIW], d2o[NIW];
-#pragma unroll
-    for (int u = 0; u < NIW; ++u) {
-        const int row = (wv * NIW + u) * RPI + lane / NCH;
-        const int ch = (lane % NCH) ^ row_swz<DH>(row);
-        d1o[u] = (unsigned)(row * (int)s1_rs + ch * 8) * 2u;
-        d2o[u] = (unsigned)(row * (int)s2_rs + ch * 8) * 2u;
-    }
-    auto dma_stream = [&](const bf16_t* base, int64_t rs, const unsigned (&off)[NIW], int row0, unsigned dst) {
-        if (row0 + KVB <= Lst) {
-            const void* tb = uniform_ptr(base + (int64_t)row0 * rs);
-#pragma unroll
-            for (int u = 0; u < NIW; ++u) glds16_off(tb, off[u], dst + u * 1024);
-        } else {                                       // ragged last tile: rows past the end re-read the last row (masked in Z)
-            int lane_r = lane;
-            asm volatile("" : "+v"(lane_r));
-#pragma unroll
-            for (int u = 0; u < NIW; ++u) {
-                const int row = (wv * NIW + u) * RPI + lane_r / NCH;
-                const int ch = (lane_r % NCH) ^ row_swz<DH>(row);
-                int sr = row0 + row; if (sr > Lst - 1) sr = Lst - 1;
-                glds16_ptr(base + (int64_t)sr * rs + ch * 8, dst + u * 1024);
-            }
-        }
-    };
-    auto dma_issue = [&](int t) {                      // tiles past the end are simply not fetched
-        if (t < ntiles) {
-            const unsigned l0 = lds0 + (unsigned)(t % 3) * BUF;
-            dma_stream(S1, s1_rs, d1o, t * KVB, l0 + wv * NIW * 1024);
-            dma_stream(S2, s2_rs, d2o, t * KVB, l0 + TILE + wv * NIW * 1024);
-            if constexpr (!OWN_Q) {                    // statistics rows are padded to a multiple of 64 (zeros)
-                if (wv == 0) glds4_ptr(stat_l + t * KVB + lane, l0 + 2 * TILE);
-                if (TWO && wv == 1) glds4_ptr(stat_d + t * KVB + lane, l0 + 2 * TILE + 256);
-            }
-        }
-    };
-    auto dma_wait = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
-    auto seg_barrier = [&]() {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-    };
-
-    // per-lane LDS read offsets; every swizzled offset is BASE ^ constant (the XOR only touches bits the row and byte terms leave free), so
-    // the segments re-derive their addresses from opaque copies of three bases instead of holding one register per fragment
-    const int k_base = RB * r + 16 * (h ^ row_swz<DH>(r));                 // row fragment s of 32-row block kb: kb * 32 * RB + (k_base ^ 32 s)
-    const int i16 = lane & 15, g16 = lane >> 4;
-    const int t_key = 4 * h + (i16 >> 2), t_lowch = 2 * (g16 & 1) + ((i16 & 3) >> 1), t_b8 = 8 * (i16 & 1);
-    const int tlo_base = RB * t_key + 16 * (t_lowch ^ row_swz<DH>(t_key)) + t_b8;              // d-block db, k-step ks: ks * 16 * RB + (base ^ 64 db)
-    const int thi_base = RB * (t_key + 8) + 16 * (t_lowch ^ row_swz<DH>(t_key + 8)) + t_b8;
-    f32x16 acc[NDB];
-#pragma unroll
-    for (int db = 0; db < NDB; ++db)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[db][i] = 0.f;
-    f32x16 x1[2], x2[TWO ? 2 : 1];
-    bf16x8 zf[2][2];
-
-    // X = [acc^T[d][own] += T(tA)^T[d][streamed] Z(tA)[streamed][own], T = st1 (DQ: K, DK: Q) or st2 (DV: dO)]  then  [x1 = st1(tS) own1^T,
-    // x2 = st2(tS) own2^T], as ONE software pipeline of 4 + 2 QS steps: the LDS reads of step j + PD are issued ahead of the MFMAs of step j
-    // (left to hipcc, each step's reads were issued and waited for right in front of its MFMAs: with only one wave per SIMD in its matrix
-    // segment, the LDS latency was exposed 24 - 48 times per tile and the stagger bought nothing).
-    constexpr int PD = DH == 128 ? 1 : 4;
-    auto do_X = [&](int tA, int tS, auto have_a, auto have_s) {
-        constexpr int NA = decltype(have_a)::value ? 4 : 0, NS = decltype(have_s)::value ? 2 * QS : 0, NSTEP = NA + NS;
-        const unsigned char* Tb = smem + (tA % 3) * BUF + (MODE == BWD_DV ? TILE : 0);
-        const unsigned char* B1 = smem + (tS % 3) * BUF;
-        int lo0 = tlo_base, hi0 = thi_base, kb0 = k_base;
-        asm volatile("" : "+v"(lo0), "+v"(hi0), "+v"(kb0));
-        bf16x8 tfb[PD + 1][NDB], ab[PD + 1][2];
-        auto rd = [&](int j) {
-            const int slot = j % (PD + 1);
-            if (j < NA) {
-#pragma unroll
-                for (int db = 0; db < NDB; ++db) tfb[slot][db] = tr_read_pair(Tb + j * 16 * RB + (lo0 ^ (64 * db)), Tb + j * 16 * RB + (hi0 ^ (64 * db)));
-            } else {
-                const int i = j - NA, kb = i / QS, s5 = i % QS;
-                ab[slot][0] = *(const bf16x8*)(B1 + kb * 32 * RB + (kb0 ^ (32 * s5)));
-                if constexpr (TWO) ab[slot][1] = *(const bf16x8*)(B1 + TILE + kb * 32 * RB + (kb0 ^ (32 * s5)));
-            }
-        };
-        auto mm = [&](int j) {
-            const int slot = j % (PD + 1);
-            if (j < NA) {
-#pragma unroll
-                for (int db = 0; db < NDB; ++db) acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tfb[slot][db], zf[j >> 1][j & 1], acc[db], 0, 0, 0);
-            } else {
-                const int i = j - NA, kb = i / QS, s5 = i % QS;
-                if (s5 == 0) {
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) { x1[kb][e] = 0.f; if constexpr (TWO) x2[kb][e] = 0.f; }
-                }
-                x1[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab[slot][0], f1[s5], x1[kb], 0, 0, 0);
-                if constexpr (TWO) x2[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab[slot][1], f2[s5], x2[kb], 0, 0, 0);
-            }
-        };
-#pragma unroll
-        for (int j = 0; j < PD && j < NSTEP; ++j) rd(j);
-#pragma unroll
-        for (int j = 0; j < NSTEP; ++j) {
-            if (j + PD < NSTEP) rd(j + PD);
-            __builtin_amdgcn_sched_barrier(0);
-            mm(j);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if constexpr (NS > 0) {
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) { asm volatile("" : "+v"(x1[kb])); if constexpr (TWO) asm volatile("" : "+v"(x2[kb])); }
-        }
-    };
-    using yes_t = std::integral_constant<bool, true>;
-    using no_t = std::integral_constant<bool, false>;
-    auto do_Z = [&](int t) {                           // zf = bf16(P) (DV) or bf16(P (dP - delta)) (DQ, DK; x scale in the epilogue)
-        const float* st = (const float*)(smem + (t % 3) * BUF + 2 * TILE);
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            float z[16], sl[16], sd[16];
-            if constexpr (!OWN_Q) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4 a = *(const f32x4*)(st + kb * 32 + 4 * h + 8 * g);
-                    sl[4 * g] = a[0]; sl[4 * g + 1] = a[1]; sl[4 * g + 2] = a[2]; sl[4 * g + 3] = a[3];
-                    if constexpr (TWO) {
-                        const f32x4 d4 = *(const f32x4*)(st + 64 + kb * 32 + 4 * h + 8 * g);
-                        sd[4 * g] = d4[0]; sd[4 * g + 1] = d4[1]; sd[4 * g + 2] = d4[2]; sd[4 * g + 3] = d4[3];
-                    }
-                }
-            }
-            const int srow0 = t * KVB + kb * 32 + 4 * h;
-            if (t * KVB + KVB <= Lst) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const float p = __builtin_amdgcn_exp2f(fmaf(x1[kb][i], c, -(OWN_Q ? my_lse : sl[i])));
-                    z[i] = TWO ? p * (x2[TWO ? kb : 0][i] - (OWN_Q ? my_delta : sd[i])) : p;
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const bool valid = srow0 + (i & 3) + 8 * (i >> 2) < Lst;
-                    const float p = __builtin_amdgcn_exp2f(fmaf(x1[kb][i], c, -(OWN_Q ? my_lse : sl[i])));
-                    const float v = TWO ? p * (x2[TWO ? kb : 0][i] - (OWN_Q ? my_delta : sd[i])) : p;
-                    z[i] = valid ? v : 0.f;
-                }
-            }
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                u32x4 w;
-                w.x = pack2bf(z[8 * s2 + 0], z[8 * s2 + 1]); w.y = pack2bf(z[8 * s2 + 2], z[8 * s2 + 3]);
-                w.z = pack2bf(z[8 * s2 + 4], z[8 * s2 + 5]); w.w = pack2bf(z[8 * s2 + 6], z[8 * s2 + 7]);
-                zf[kb][s2] = __builtin_bit_cast(bf16x8, w);
-            }
-        }
-        // "used" here so that the VALU chain stays inside this segment (see the forward)
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) { asm volatile("" : "+v"(zf[kb][0])); asm volatile("" : "+v"(zf[kb][1])); }
-    };
-#if defined(UG_STG_PRIO) && UG_STG_PRIO == 1
-    if (!groupA) __builtin_amdgcn_s_setprio(1);        // static priority for the younger half
-#endif
-    dma_issue(0);
-    dma_wait();
-    seg_barrier();
-    dma_issue(1);                                      // start of segment 0 (group B issues its share, then idles through the segment)
-    if (!groupA) seg_barrier();
-    do_X(0, 0, no_t{}, yes_t{});                       // S(0). A: segment 0 | B: segment 1
-    if (!groupA) dma_wait();                           // end of segment 1 (B)
-    seg_barrier();
-    [[maybe_unused]] unsigned long long ts[7], sums[6] = {0, 0, 0, 0, 0, 0};
-#ifdef UG_DIAG_STAMPS
-    const int mute_ = __builtin_amdgcn_readfirstlane(ug_diag_mute);
-    const bool muted = (mute_ == 1 && !groupA) || (mute_ == 2 && groupA);
-#else
-    constexpr bool muted = false;
-#endif
-    for (int t = 0; t < ntiles; ++t) {
-        // Y(t): A in odd segment 2t+1 | B in even segment 2t+2
-        UG_STAMP(ts[0]);
-        if (!groupA) dma_issue(t + 2);
-#if defined(UG_STG_PRIO) && UG_STG_PRIO == 2
-        __builtin_amdgcn_s_setprio(1);                 // the VALU segment outranks the partner's matrix segment
-#endif
-        if (!muted) do_Z(t);
-#if defined(UG_STG_PRIO) && UG_STG_PRIO == 2
-        __builtin_amdgcn_s_setprio(0);
-#endif
-        UG_STAMP(ts[1]);
-        if (groupA) dma_wait();                        // end of segment 2t+1: tile t+1 (issued at the start of segment 2t) has landed
-        UG_STAMP(ts[2]);
-        seg_barrier();
-        UG_STAMP(ts[3]);
-        // X(t+1): A in even segment 2t+2 | B in odd segment 2t+3
-        if (groupA) dma_issue(t + 2);
-        if (!muted) { if (t + 1 < ntiles) do_X(t, t + 1, yes_t{}, yes_t{}); else do_X(t, t, yes_t{}, no_t{}); }
-        UG_STAMP(ts[4]);
-        if (!groupA) dma_wait();                       // end of segment 2t+3: tile t+2 has landed
-        UG_STAMP(ts[5]);
-        seg_barrier();
-        UG_STAMP(ts[6]);
-        UG_STAMP_ADD(sums[0], ts[0], ts[1]); UG_STAMP_ADD(sums[1], ts[1], ts[2]); UG_STAMP_ADD(sums[2], ts[2], ts[3]);
-        UG_STAMP_ADD(sums[3], ts[3], ts[4]); UG_STAMP_ADD(sums[4], ts[4], ts[5]); UG_STAMP_ADD(sums[5], ts[5], ts[6]);
-    }
-    if (groupA) seg_barrier();                         // A's trailing (empty) segment pairs with B's last one
-#ifdef UG_DIAG_STAMPS
-    if (blockIdx.x < 64 && lane == 0) {
-#pragma unroll
-        for (int i = 0; i < 6; ++i) ug_attn_stamps[(blockIdx.x * 8 + wv) * 8 + i] = sums[i];
-        ug_attn_stamps[(blockIdx.x * 8 + wv) * 8 + 6] = (unsigned long long)ntiles;
-    }
-#endif
-
-    if (own_row < Lown) {
-        bf16_t* Orow = out + (int64_t)b * out_bs + (int64_t)own_row * out_rs + head * DH;
-        const float es = TWO ? scale : 1.f;
-#pragma unroll
-        for (int db = 0; db < NDB; ++db)
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                u32x2 w;
-                w.x = pack2bf(acc[db][4 * g4 + 0] * es, acc[db][4 * g4 + 1] * es);
-                w.y = pack2bf(acc[db][4 * g4 + 2] * es, acc[db][4 * g4 + 3] * es);
-                *(u32x2*)(Orow + 32 * db + 8 * g4 + 4 * h) = w;
-            }
-    }
-}
-
 // delta[bh][q] = sum_d dO[b][q][h*DH + d] * O[b][q][h*DH + d]; one wave per (b, q, h)
 __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ o, int64_t o_rs, int64_t o_bs, const bf16_t* __restrict__ dout, int64_t d_rs,
                                                          int64_t d_bs, float* __restrict__ delta, int64_t stat_ld, int64_t total, int heads, int Lq, int dh) {
@@ -1663,16 +1379,6 @@ extern "C" int ug_flash_attn_bwd(const void* q, int64_t q_rs, int64_t q_bs, cons
     float* delta = (float*)workspace + batches * heads * stat_ld;
     hipStream_t s = (hipStream_t)stream;
     const float c = softmax_scale * 1.4426950408889634f;
-#ifdef UG_DIAG_STAMPS
-    const int diag_only = ug_env_int("UG_DIAG_BWD_ONLY", 0);      // diagnostic build: launch only mode 1 (DQ) | 2 (DK) | 3 (DV)
-    { const int m = ug_env_int("UG_DIAG_BWD_MUTE", 0); (void)hipMemcpyToSymbol(HIP_SYMBOL(ug_diag_mute), &m, sizeof(int)); }
-#else
-    constexpr int diag_only = 0;
-#endif
-    // UG_ATTN_BWD_STAGGER=1 (dh 64 only; experimental, off): the X|Y staggered kernel. Same bits; measured 431-465 TFLOP/s against 453-492
-    // for the lock-step kernel at dh 64 (B4, 4429^2 / 4096^2). At dh 128 it needs ~300 registers (S of a whole 64-row tile crosses the
-    // barrier beside both operand sets and the accumulators): hipcc spilled 100 of them, 211 vs 548 TFLOP/s - not instantiated.
-    const int bwd_stg = ug_env_int("UG_ATTN_BWD_STAGGER", 0);   // X|Y staggered wave groups (0: the lock-step kernel)
     const int bwd_dma = ug_env_int("UG_ATTN_BWD_DMA", 1);     // LDS-DMA staging of the streamed tiles (0: through registers)
     const int nQ = (int)((Lq + 255) / 256), nK = (int)((Lkv + 255) / 256);
     const int64_t gq = (int64_t)nQ * heads * batches, gk = (int64_t)nK * heads * batches;
@@ -1691,48 +1397,17 @@ extern "C" int ug_flash_attn_bwd(const void* q, int64_t q_rs, int64_t q_bs, cons
                            (const bf16_t*)(S1), S1R, S1B, (const bf16_t*)(S2), S2R, S2B, lse2, delta, stat_ld, (bf16_t*)(OUT), OR, OB, (int)heads, (int)(LOWN),   \
                            (int)(LST), (int)(NOWN), c, softmax_scale);                                                                                 \
     } while (0)
-#define UG_BWD_STG(DHV, MODEV, GRID, O1, O1R, O1B, O2, O2R, O2B, S1, S1R, S1B, S2, S2R, S2B, OUT, OR, OB, LOWN, LST, NOWN)                               \
-    do {                                                                                                                                                \
-        const int lds_ = 3 * (2 * KVB * 2 * DHV + 512);                                                                                                \
-        (void)hipFuncSetAttribute((const void*)attn_bwd_stg_kernel<DHV, MODEV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_);                   \
-        hipLaunchKernelGGL((attn_bwd_stg_kernel<DHV, MODEV>), dim3((unsigned)(GRID)), dim3(512), lds_, s, (const bf16_t*)(O1), O1R, O1B, (const bf16_t*)(O2), O2R, O2B, \
-                           (const bf16_t*)(S1), S1R, S1B, (const bf16_t*)(S2), S2R, S2B, (const float*)lse2, (const float*)delta, stat_ld, (bf16_t*)(OUT), OR, OB, (int)heads, \
-                           (int)(LOWN), (int)(LST), (int)(NOWN), c, softmax_scale);                                                                    \
-    } while (0)
 #define UG_BWD_ALL(DHV)                                                                                                                              \
     do {                                                                                                                                              \
         if (!lse_in) UG_BWD(DHV, BWD_LSE, gq, q, q_rs, q_bs, nullptr, 0, 0, k, k_rs, k_bs, nullptr, 0, 0, nullptr, 0, 0, Lq, Lkv, nQ);             \
-        if (bwd_stg) {                                                                                                                                \
-            if (!diag_only || diag_only == 1) UG_BWD_STG(DHV, BWD_DQ, gq, q, q_rs, q_bs, dout, do_rs, do_bs, k, k_rs, k_bs, v, v_rs, v_bs, dq, dq_rs, dq_bs, Lq, Lkv, nQ);                   \
-            if (!diag_only || diag_only == 2) UG_BWD_STG(DHV, BWD_DK, gk, k, k_rs, k_bs, v, v_rs, v_bs, q, q_rs, q_bs, dout, do_rs, do_bs, dk, dk_rs, dk_bs, Lkv, Lq, nK);                   \
-            if (!diag_only || diag_only == 3) UG_BWD_STG(DHV, BWD_DV, gk, k, k_rs, k_bs, nullptr, 0, 0, q, q_rs, q_bs, dout, do_rs, do_bs, dv, dv_rs, dv_bs, Lkv, Lq, nK);                   \
-        } else {                                                                                                                                      \
-            UG_BWD(DHV, BWD_DQ, gq, q, q_rs, q_bs, dout, do_rs, do_bs, k, k_rs, k_bs, v, v_rs, v_bs, dq, dq_rs, dq_bs, Lq, Lkv, nQ);                   \
-            UG_BWD(DHV, BWD_DK, gk, k, k_rs, k_bs, v, v_rs, v_bs, q, q_rs, q_bs, dout, do_rs, do_bs, dk, dk_rs, dk_bs, Lkv, Lq, nK);                   \
-            UG_BWD(DHV, BWD_DV, gk, k, k_rs, k_bs, nullptr, 0, 0, q, q_rs, q_bs, dout, do_rs, do_bs, dv, dv_rs, dv_bs, Lkv, Lq, nK);                   \
-        }                                                                                                                                             \
+        UG_BWD(DHV, BWD_DQ, gq, q, q_rs, q_bs, dout, do_rs, do_bs, k, k_rs, k_bs, v, v_rs, v_bs, dq, dq_rs, dq_bs, Lq, Lkv, nQ);                   \
+        UG_BWD(DHV, BWD_DK, gk, k, k_rs, k_bs, v, v_rs, v_bs, q, q_rs, q_bs, dout, do_rs, do_bs, dk, dk_rs, dk_bs, Lkv, Lq, nK);                   \
+        UG_BWD(DHV, BWD_DV, gk, k, k_rs, k_bs, nullptr, 0, 0, q, q_rs, q_bs, dout, do_rs, do_bs, dv, dv_rs, dv_bs, Lkv, Lq, nK);                   \
     } while (0)
-#define UG_BWD_ALL_LOCKSTEP(DHV)                                                                                                                              \
-    do {                                                                                                                                              \
-        if (!lse_in) UG_BWD(DHV, BWD_LSE, gq, q, q_rs, q_bs, nullptr, 0, 0, k, k_rs, k_bs, nullptr, 0, 0, nullptr, 0, 0, Lq, Lkv, nQ);             \
-            UG_BWD(DHV, BWD_DQ, gq, q, q_rs, q_bs, dout, do_rs, do_bs, k, k_rs, k_bs, v, v_rs, v_bs, dq, dq_rs, dq_bs, Lq, Lkv, nQ);                   \
-            UG_BWD(DHV, BWD_DK, gk, k, k_rs, k_bs, v, v_rs, v_bs, q, q_rs, q_bs, dout, do_rs, do_bs, dk, dk_rs, dk_bs, Lkv, Lq, nK);                   \
-            UG_BWD(DHV, BWD_DV, gk, k, k_rs, k_bs, nullptr, 0, 0, q, q_rs, q_bs, dout, do_rs, do_bs, dv, dv_rs, dv_bs, Lkv, Lq, nK);                   \
-    } while (0)
-    if (dh == 128) UG_BWD_ALL_LOCKSTEP(128); else UG_BWD_ALL(64);      // the staggered kernel is instantiated for dh 64 only (see bwd_stg)
+    if (dh == 128) UG_BWD_ALL(128); else UG_BWD_ALL(64);
 #undef UG_BWD_ALL
-#undef UG_BWD_ALL_LOCKSTEP
-#undef UG_BWD_STG
 #undef UG_BWD
 #undef UG_BWD_
     UG_CHECK_LAUNCH("ug_flash_attn_bwd");
     return UG_OK;
 }
-
-#ifdef UG_DIAG_STAMPS
-// diagnostic build: [64 blocks][8 waves][8] = cycles in {Y, DMA wait after Y, barrier after Y, X, DMA wait after X, barrier after X}, tiles, -
-extern "C" int ug_diag_attn_stamps(void* host_out, int64_t bytes) {
-    if (!host_out || bytes != (int64_t)sizeof(unsigned long long) * 64 * 8 * 8) return UG_ERR_BAD_SHAPE;
-    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(ug_attn_stamps), (size_t)bytes, 0, hipMemcpyDeviceToHost) == hipSuccess ? UG_OK : UG_ERR_BAD_SHAPE;
-}
-#endif
