@@ -467,7 +467,9 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn_kernel(
         const bool groupA = __builtin_amdgcn_readfirstlane(wave) < 4;
         // LDS-DMA staging: a tile image is NI runs of 1 KiB (RPI rows each); wave wb of group B owns runs wb * NIW .. + NIW - 1
         // (measured and dropped: every wave issuing NI / 8 runs, group A's half at the start of its own softmax segment 2t+1 and waited for
-        // at its end - same bits, -0.5 % at dh 128, -12 % at dh 64: group B's issue cost is not what bounds the segment pairs)
+        // at its end - same bits, -0.5 % at dh 128, -12 % at dh 64: group B's issue cost is not what bounds the segment pairs; and group A
+        // issuing all of them one at a time behind the MFMAs of the first 2 NIW steps of its matrix segment: -11 % / -4 %, ~46 cycles of
+        // matrix-segment time per DMA)
         constexpr int RPI = 1024 / RB, NI = TILE / 1024, NIW = NI / 4;
         const int wb = __builtin_amdgcn_readfirstlane(wave) & 3;
         unsigned dko[NIW], dvo[NIW];
