@@ -290,6 +290,10 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn_kernel(
             m_run = m_new;
         }
         const float mc = m_run * c;
+        // (Measured and dropped, round 2, bit-identical: exponentiating key block 1 - or only its last 8 scores per lane - inside X(t), 3-7 VALU
+        // instructions behind each of its first 8 P.V MFMAs: -8 % / -4 % at dh 128, -10 % / -7 % at dh 64. Ablations of the same day (tools/attn_ab.py
+        // on diagnostic builds): without the K/V DMAs +7-10 %, without this softmax +18 % (+37 % at dh 64), without both +28 % (+53 %): the matrix
+        // segments alone take 78 % of the loop's time at dh 128, and VALU work moved into them costs more than it saves here.)
         // (Measured and dropped, same box: the scale / shift and the row sums two elements per instruction, v_pk_fma_f32 / v_pk_add_f32 -
         // 5 % SLOWER at dh 128 (1086 vs 1146, 1118 vs 1179 TFLOP/s), +1 % at dh 64: the packed forms buy no issue cycles here.)
 #pragma unroll
