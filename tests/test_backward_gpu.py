@@ -202,6 +202,27 @@ def test_flash_attention_backward_selectable_variants(gpu):
     assert r.returncode == 0, r.stdout + r.stderr
 
 
+@pytest.mark.parametrize("dtype", [BF, torch.float32])
+def test_transpose_and_colsum_helpers(gpu, dtype):
+    """ug_transpose (bf16: the 16-byte fast path and the element-wise fallback; fp32 twin) with padded rows, strided sources and a batch dimension -
+    bit-exact - and the two-stage ug_colsum against fp32 torch."""
+    from unigen_amd import ops
+    g = torch.Generator().manual_seed(9)
+    for rows, cols, pad, lead, ld_extra in [(300, 192, 304, (), 0), (64, 64, 64, (), 0), (1000, 72, 1024, (3,), 0), (257, 130, 260, (), 0), (130, 256, 136, (2,), 64),
+                                            (4608, 3072, 4608, (), 0), (77, 8, 80, (), 8)]:
+        full = torch.randn(*lead, rows, cols + ld_extra, generator=g).to(dtype)
+        src = full[..., :cols].to(gpu) if ld_extra == 0 else full.to(gpu)[..., :cols]        # ld_extra: a strided view (row stride > cols)
+        got = ops.transpose(src, pad)
+        want = torch.zeros(*lead, cols, pad, dtype=dtype)
+        want[..., :rows] = full[..., :cols].transpose(-1, -2)
+        assert got.shape == want.shape and torch.equal(got.cpu(), want), (rows, cols, pad, lead, ld_extra)
+    for rows, cols in [(1000, 192), (4608, 3072), (64, 8)]:
+        x = torch.randn(rows, cols, generator=g).to(dtype)
+        got = ops.colsum(x.to(gpu)).float().cpu()
+        want = x.float().sum(0)
+        assert rel(got, want) < (3e-3 if dtype == BF else 1e-5), (rows, cols, rel(got, want))
+
+
 def test_gate_residual_backward(gpu):
     from unigen_amd import autograd as A
     g = torch.Generator().manual_seed(6)

@@ -1398,7 +1398,8 @@ extern "C" int ug_flash_attn_bwd(const void* q, int64_t q_rs, int64_t q_bs, cons
 #define UG_BWD_(DHV, MODEV, DMAV, GRID, O1, O1R, O1B, O2, O2R, O2B, S1, S1R, S1B, S2, S2R, S2B, OUT, OR, OB, LOWN, LST, NOWN)                          \
     do {                                                                                                                                                \
         const int lds_ = 2 * (2 * KVB * 2 * DHV + (DMAV ? 512 : 0));                                                                                   \
-        (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<DHV, MODEV, DMAV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_);                       \
+        static bool attr_ = false;        /* one per expansion site = per instantiation */                                                              \
+        if (!attr_) { (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<DHV, MODEV, DMAV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_); attr_ = true; } \
         hipLaunchKernelGGL((attn_bwd_kernel<DHV, MODEV, DMAV>), dim3((unsigned)(GRID)), dim3(512), lds_, s, (const bf16_t*)(O1), O1R, O1B, (const bf16_t*)(O2), O2R, O2B, \
                            (const bf16_t*)(S1), S1R, S1B, (const bf16_t*)(S2), S2R, S2B, lse2, delta, stat_ld, (bf16_t*)(OUT), OR, OB, (int)heads, (int)(LOWN),   \
                            (int)(LST), (int)(NOWN), c, softmax_scale);                                                                                 \

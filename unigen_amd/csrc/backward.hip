@@ -48,6 +48,39 @@ __global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ sr
     }
 }
 
+// bf16 fast path of the transpose: 16-byte global loads and stores. A 64 x 64 tile goes through LDS transposed ([column][row], pitch 68 elements:
+// 8-byte aligned rows, the 2-byte scatter writes of one instruction fall on 32 distinct banks twice); needs cols, rows_pad, both leading dimensions
+// and batch strides to be multiples of 8 and 16-byte aligned bases. 2.5 -> ~4 TB/s (read + write) on the wgrad operands of a training step.
+__global__ __launch_bounds__(256) void transpose8_kernel(const bf16_t* __restrict__ src, int64_t ld_src, int64_t src_bstride, bf16_t* __restrict__ dst,
+                                                         int64_t ld_dst, int64_t dst_bstride, int rows, int cols, int rows_pad) {
+    constexpr int LD = 68;
+    __shared__ __attribute__((aligned(16))) bf16_t tile[64 * LD];
+    const bf16_t* s = src + (int64_t)blockIdx.z * src_bstride;
+    bf16_t* d = dst + (int64_t)blockIdx.z * dst_bstride;
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int id = threadIdx.x + 256 * u, r = id >> 3, ch = id & 7;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (r0 + r < rows && c0 + 8 * ch < cols) v = *(const u32x4*)(s + (int64_t)(r0 + r) * ld_src + c0 + 8 * ch);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            tile[(8 * ch + 2 * j) * LD + r] = (bf16_t)(v[j] & 0xffffu);
+            tile[(8 * ch + 2 * j + 1) * LD + r] = (bf16_t)(v[j] >> 16);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int id = threadIdx.x + 256 * u, c = id >> 3, rch = id & 7;       // dst row = source column c0 + c, dst columns r0 + 8 rch .. + 7
+        if (c0 + c < cols && r0 + 8 * rch < rows_pad) {
+            const u32x2 lo = *(const u32x2*)(tile + c * LD + 8 * rch), hi = *(const u32x2*)(tile + c * LD + 8 * rch + 4);
+            u32x4 w; w.x = lo.x; w.y = lo.y; w.z = hi.x; w.w = hi.y;
+            *(u32x4*)(d + (int64_t)(c0 + c) * ld_dst + r0 + 8 * rch) = w;
+        }
+    }
+}
+
 // out[g][c] = rnd(alpha * sum_{r in group g} a[r][c] * (b ? b[r][c] : 1)) in two deterministic stages: a block sums COLSUM_ROWS rows of 512 columns
 // (8 per lane, 16-byte loads; its 4 waves take every 4th row, then meet in LDS) into an fp32 partial; the second stage adds the partials of a
 // group in order.
@@ -269,6 +302,15 @@ int transpose_impl(const void* src, int64_t ld_src, int64_t src_bstride, void* d
                "ug_transpose: bad arguments");
     dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((rows_pad + 63) / 64), (unsigned)batch);
     UG_REQUIRE(grid.y < 65536, UG_ERR_UNSUPPORTED, "ug_transpose: too many rows");
+    if constexpr (!ElemT<T>::kF32) {
+        if (cols % 8 == 0 && rows_pad % 8 == 0 && ld_src % 8 == 0 && ld_dst % 8 == 0 && src_bstride % 8 == 0 && dst_bstride % 8 == 0 && ug_aligned(src, 16) &&
+            ug_aligned(dst, 16)) {
+            hipLaunchKernelGGL(transpose8_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, ld_src, src_bstride, (bf16_t*)dst, ld_dst, dst_bstride,
+                               (int)rows, (int)cols, (int)rows_pad);
+            UG_CHECK_LAUNCH("ug_transpose");
+            return UG_OK;
+        }
+    }
     hipLaunchKernelGGL(transpose_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)src, ld_src, src_bstride, (T*)dst, ld_dst, dst_bstride,
                        (int)rows, (int)cols, (int)rows_pad);
     UG_CHECK_LAUNCH("ug_transpose");
