@@ -332,9 +332,12 @@ int ug_gelu_tanh_bwd(const void* x, const void* dy, void* dx, int64_t n, ug_stre
 int ug_adaln_modulate_bwd(const void* x, int64_t ldx, const void* dy, int64_t lddy, const void* scale, int64_t mod_ld, int64_t rows_per_sample,
                           void* dx, int64_t lddx, void* dyx, int64_t lddyx, int64_t rows, int64_t D, float eps, ug_stream_t stream);
 /* backward of ug_qk_rmsnorm_rope for ONE of q / k: x = the projection's output (pre-norm) [rows][heads * dh] at ldx, dy = gradient of the
- * normalised + rotated heads; dx likewise; dwx [rows * heads][dh] = d(un) * xhat whose column sum is d weight (w NULL: no RMSNorm; cos NULL: no RoPE).
+ * normalised + rotated heads; dx likewise; dw_partial: fp32 [ug_qk_rmsnorm_rope_bwd_partials(rows, heads)][dh], partial sums of d(un) * xhat
+ * over disjoint sets of (row, head) vectors - their sum over the first index, taken by the caller, is d weight (deterministic: the assignment of
+ * vectors to partial rows depends only on rows and heads). w NULL: no RMSNorm, dw_partial unused; cos NULL: no RoPE. dh <= 256.
  * Row r sits at position pos_offset + r % rows_per_batch; cos / sin tables [positions][dh] fp32 as in the forward. */
-int ug_qk_rmsnorm_rope_bwd(const void* x, int64_t ldx, const void* dy, int64_t lddy, void* dx, int64_t lddx, void* dwx, const void* w,
+int64_t ug_qk_rmsnorm_rope_bwd_partials(int64_t rows, int32_t heads);
+int ug_qk_rmsnorm_rope_bwd(const void* x, int64_t ldx, const void* dy, int64_t lddy, void* dx, int64_t lddx, void* dw_partial, const void* w,
                            const float* cos_tab, const float* sin_tab, int64_t rows, int64_t rows_per_batch, int64_t pos_offset, int32_t heads,
                            int32_t dh, float eps, ug_stream_t stream);
 /* attention backward between its GEMMs (F.scaled_dot_product_attention, src/UniGenUtils.py:601): lse[r] = logsumexp(scale * S[r][:]);
@@ -372,7 +375,7 @@ int ug_gelu_tanh_f32(const void* x, void* y, int64_t n, ug_stream_t stream);
 int ug_gelu_tanh_bwd_f32(const void* x, const void* dy, void* dx, int64_t n, ug_stream_t stream);
 int ug_adaln_modulate_bwd_f32(const void* x, int64_t ldx, const void* dy, int64_t lddy, const void* scale, int64_t mod_ld, int64_t rows_per_sample,
                               void* dx, int64_t lddx, void* dyx, int64_t lddyx, int64_t rows, int64_t D, float eps, ug_stream_t stream);
-int ug_qk_rmsnorm_rope_bwd_f32(const void* x, int64_t ldx, const void* dy, int64_t lddy, void* dx, int64_t lddx, void* dwx, const void* w,
+int ug_qk_rmsnorm_rope_bwd_f32(const void* x, int64_t ldx, const void* dy, int64_t lddy, void* dx, int64_t lddx, void* dw_partial, const void* w,
                                const float* cos_tab, const float* sin_tab, int64_t rows, int64_t rows_per_batch, int64_t pos_offset, int32_t heads,
                                int32_t dh, float eps, ug_stream_t stream);
 int ug_attn_prob_f32(const float* S, int64_t ld_s, const float* lse, void* P, int64_t ld_p, int64_t rows, int64_t cols, int64_t valid_cols, float scale,

@@ -186,8 +186,9 @@ class QKNormRope(torch.autograd.Function):
         x2, w, cos, sin = ctx.saved_tensors
         B, Ls, heads, dh, pos_offset, eps = ctx.geom
         dy2 = dy.reshape(B * Ls, heads * dh).contiguous()
-        dx, dwx = ops.qk_rmsnorm_rope_bwd(x2.contiguous(), dy2, w, cos, sin, rows_per_batch=Ls, pos_offset=pos_offset, heads=heads, dh=dh, eps=eps)
-        dw = ops.colsum(dwx).view(dh) if (w is not None and ctx.needs_input_grad[1]) else None
+        dx, dw = ops.qk_rmsnorm_rope_bwd(x2.contiguous(), dy2, w, cos, sin, rows_per_batch=Ls, pos_offset=pos_offset, heads=heads, dh=dh, eps=eps)
+        if w is None or not ctx.needs_input_grad[1]:
+            dw = None
         return dx.view(B, Ls, heads * dh), dw, None, None, None, None, None
 
 

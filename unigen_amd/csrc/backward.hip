@@ -193,53 +193,75 @@ __global__ __launch_bounds__(256) void adaln_bwd_kernel(const T* __restrict__ x,
     }
 }
 
-// One wave per (row, head) vector of DH elements (DH / 64 per lane... lanes cover pairs): forward was u = x rs, un = u w, y = rope(un).
-//   dun = rope^T(dy);  du = dun w;  dx = rs (du - u mean(du u));  dwx = dun u  (summed over rows and heads: d weight)
+// One wave per (row, head) vector of DH elements (lane l: pairs l, l + 64 < DH / 2), a grid-stride loop over the vectors: forward was u = x rs,
+// un = u w, y = rope(un).   dun = rope^T(dy);  du = dun w;  dx = rs (du - u mean(du u));  d weight = sum over rows and heads of dun u.
+// Every element is loaded once (a pair per 4- / 8-byte load); the weight gradient is accumulated in registers over the wave's vectors, the four
+// waves of a block meet in LDS in a fixed order and the block writes ONE fp32 partial row [DH] - the caller adds the <= 2048 partial rows
+// (the first version wrote a [vectors][DH] product tensor for ug_colsum: 2/5 of its traffic and a second pair of launches).
+constexpr int QKB_MAXP = 2;        // pairs per lane: head widths up to 256
 template <typename T>
 __global__ __launch_bounds__(256) void qk_bwd_kernel(const T* __restrict__ x, int64_t ldx, const T* __restrict__ dy, int64_t lddy, T* __restrict__ dx,
-                                                     int64_t lddx, T* __restrict__ dwx /* [vectors][DH] */, const T* __restrict__ w,
+                                                     int64_t lddx, float* __restrict__ dw_part /* [gridDim.x][DH] */, const T* __restrict__ w,
                                                      const float* __restrict__ cos_tab, const float* __restrict__ sin_tab, int64_t rows_per_batch,
                                                      int64_t pos_offset, int64_t nvec, int heads, int DH, float eps) {
-    const int lane = threadIdx.x & 63;
-    const int64_t vec = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (vec >= nvec) return;
-    const int64_t row = vec / heads; const int h = (int)(vec - row * heads);
-    const int64_t pos = pos_offset + row % rows_per_batch;
-    const T* xr = x + row * ldx + (int64_t)h * DH; const T* gr = dy + row * lddy + (int64_t)h * DH;
-    // this lane: pairs p = lane, lane + 64, ... < DH / 2
-    float ss = 0.f;
-    for (int p = lane; p < DH / 2; p += 64) { const float a = ElemT<T>::ld(xr + 2 * p), b = ElemT<T>::ld(xr + 2 * p + 1); ss += a * a + b * b; }
-    ss = wave_sum(ss);
-    const float rs = w ? rsqrtf(ss / DH + eps) : 1.0f;
-    float dot = 0.f;
-    for (int p = lane; p < DH / 2; p += 64) {
-        float g0 = ElemT<T>::ld(gr + 2 * p), g1 = ElemT<T>::ld(gr + 2 * p + 1);
-        if (cos_tab) {
-            const float c0 = cos_tab[pos * DH + 2 * p], c1 = cos_tab[pos * DH + 2 * p + 1], s0 = sin_tab[pos * DH + 2 * p], s1 = sin_tab[pos * DH + 2 * p + 1];
-            // y0 = a c0 - b s0, y1 = b c1 + a s1  ->  da = g0 c0 + g1 s1, db = g1 c1 - g0 s0
-            const float t0 = g0 * c0 + g1 * s1, t1 = g1 * c1 - g0 * s0;
-            g0 = t0; g1 = t1;
+    __shared__ float red[4][2 * 64 * QKB_MAXP];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float dwa[QKB_MAXP][2], wq[QKB_MAXP][2];
+#pragma unroll
+    for (int i = 0; i < QKB_MAXP; ++i) {
+        const int p = lane + 64 * i;
+        dwa[i][0] = dwa[i][1] = 0.f; wq[i][0] = wq[i][1] = 0.f;
+        if (w && p < DH / 2) { wq[i][0] = ElemT<T>::ld(w + 2 * p); wq[i][1] = ElemT<T>::ld(w + 2 * p + 1); }
+    }
+    for (int64_t vec = (int64_t)blockIdx.x * 4 + wv; vec < nvec; vec += (int64_t)gridDim.x * 4) {
+        const int64_t row = vec / heads; const int h = (int)(vec - row * heads);
+        const int64_t pos = pos_offset + row % rows_per_batch;
+        const T* xr = x + row * ldx + (int64_t)h * DH; const T* gr = dy + row * lddy + (int64_t)h * DH;
+        float xa[QKB_MAXP][2], g[QKB_MAXP][2];
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < QKB_MAXP; ++i) {
+            const int p = lane + 64 * i;
+            xa[i][0] = xa[i][1] = g[i][0] = g[i][1] = 0.f;
+            if (p < DH / 2) {
+                ElemT<T>::load2(xr + 2 * p, xa[i]);
+                ElemT<T>::load2(gr + 2 * p, g[i]);
+                if (cos_tab) {
+                    const float2 cc = *(const float2*)(cos_tab + pos * DH + 2 * p), sn = *(const float2*)(sin_tab + pos * DH + 2 * p);
+                    // y0 = a c0 - b s0, y1 = b c1 + a s1  ->  da = g0 c0 + g1 s1, db = g1 c1 - g0 s0
+                    const float t0 = g[i][0] * cc.x + g[i][1] * sn.y, t1 = g[i][1] * cc.y - g[i][0] * sn.x;
+                    g[i][0] = t0; g[i][1] = t1;
+                }
+                ss += xa[i][0] * xa[i][0] + xa[i][1] * xa[i][1];
+            }
         }
+        float rs = 1.0f, dot = 0.f;
         if (w) {
-            const float u0 = ElemT<T>::ld(xr + 2 * p) * rs, u1 = ElemT<T>::ld(xr + 2 * p + 1) * rs;
-            dot += g0 * ElemT<T>::ld(w + 2 * p) * u0 + g1 * ElemT<T>::ld(w + 2 * p + 1) * u1;
+            ss = wave_sum(ss);
+            rs = rsqrtf(ss / DH + eps);
+#pragma unroll
+            for (int i = 0; i < QKB_MAXP; ++i) dot += g[i][0] * wq[i][0] * (xa[i][0] * rs) + g[i][1] * wq[i][1] * (xa[i][1] * rs);
+            dot = wave_sum(dot) / DH;
+        }
+#pragma unroll
+        for (int i = 0; i < QKB_MAXP; ++i) {
+            const int p = lane + 64 * i;
+            if (p < DH / 2) {
+                float o[2] = {g[i][0], g[i][1]};
+                if (w) {
+                    const float u0 = xa[i][0] * rs, u1 = xa[i][1] * rs;
+                    dwa[i][0] += g[i][0] * u0; dwa[i][1] += g[i][1] * u1;
+                    o[0] = rs * (g[i][0] * wq[i][0] - u0 * dot); o[1] = rs * (g[i][1] * wq[i][1] - u1 * dot);
+                }
+                ElemT<T>::store2(dx + row * lddx + (int64_t)h * DH + 2 * p, o);
+            }
         }
     }
-    dot = wave_sum(dot) / DH;
-    for (int p = lane; p < DH / 2; p += 64) {
-        float g0 = ElemT<T>::ld(gr + 2 * p), g1 = ElemT<T>::ld(gr + 2 * p + 1);
-        if (cos_tab) {
-            const float c0 = cos_tab[pos * DH + 2 * p], c1 = cos_tab[pos * DH + 2 * p + 1], s0 = sin_tab[pos * DH + 2 * p], s1 = sin_tab[pos * DH + 2 * p + 1];
-            const float t0 = g0 * c0 + g1 * s1, t1 = g1 * c1 - g0 * s0;
-            g0 = t0; g1 = t1;
-        }
-        float o0 = g0, o1 = g1;
-        if (w) {
-            const float u0 = ElemT<T>::ld(xr + 2 * p) * rs, u1 = ElemT<T>::ld(xr + 2 * p + 1) * rs;
-            ElemT<T>::st(dwx + vec * DH + 2 * p, g0 * u0); ElemT<T>::st(dwx + vec * DH + 2 * p + 1, g1 * u1);
-            o0 = rs * (g0 * ElemT<T>::ld(w + 2 * p) - u0 * dot); o1 = rs * (g1 * ElemT<T>::ld(w + 2 * p + 1) - u1 * dot);
-        }
-        ElemT<T>::st(dx + row * lddx + (int64_t)h * DH + 2 * p, o0); ElemT<T>::st(dx + row * lddx + (int64_t)h * DH + 2 * p + 1, o1);
+    if (w) {
+#pragma unroll
+        for (int i = 0; i < QKB_MAXP; ++i) { red[wv][2 * (lane + 64 * i)] = dwa[i][0]; red[wv][2 * (lane + 64 * i) + 1] = dwa[i][1]; }
+        __syncthreads();
+        for (int e = threadIdx.x; e < DH; e += 256) dw_part[(int64_t)blockIdx.x * DH + e] = ((red[0][e] + red[1][e]) + red[2][e]) + red[3][e];
     }
 }
 
@@ -370,15 +392,23 @@ int adaln_bwd_impl(const void* x, int64_t ldx, const void* dy, int64_t lddy, con
     UG_CHECK_LAUNCH("ug_adaln_modulate_bwd");
     return UG_OK;
 }
+}  // namespace
+extern "C" int64_t ug_qk_rmsnorm_rope_bwd_partials(int64_t rows, int32_t heads) {
+    const int64_t blocks = (rows * (int64_t)heads + 3) / 4;
+    return blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+}
+namespace {
 template <typename T>
 int qk_bwd_impl(const void* x, int64_t ldx, const void* dy, int64_t lddy, void* dx, int64_t lddx, void* dwx, const void* w, const float* cos_tab,
                 const float* sin_tab, int64_t rows, int64_t rows_per_batch, int64_t pos_offset, int32_t heads, int32_t dh, float eps, ug_stream_t stream) {
     if (rows == 0) return UG_OK;
     UG_REQUIRE(x && dy && dx && rows > 0 && heads > 0 && dh > 0 && dh % 2 == 0 && rows_per_batch > 0 && (!w || dwx) && (cos_tab == nullptr) == (sin_tab == nullptr),
                UG_ERR_BAD_SHAPE, "ug_qk_rmsnorm_rope_bwd: bad arguments");
+    UG_REQUIRE(dh <= 128 * QKB_MAXP && ldx % 2 == 0 && lddy % 2 == 0 && lddx % 2 == 0 && ug_aligned(x, 2 * sizeof(T)) && ug_aligned(dy, 2 * sizeof(T)) &&
+               ug_aligned(dx, 2 * sizeof(T)), UG_ERR_UNSUPPORTED, "ug_qk_rmsnorm_rope_bwd: head width <= 256, even leading dimensions, pair-aligned bases");
     const int64_t nvec = rows * heads;
-    hipLaunchKernelGGL(qk_bwd_kernel<T>, dim3((unsigned)((nvec + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const T*)x, ldx, (const T*)dy, lddy, (T*)dx,
-                       lddx, (T*)dwx, (const T*)w, cos_tab, sin_tab, rows_per_batch, pos_offset, nvec, (int)heads, (int)dh, eps);
+    hipLaunchKernelGGL(qk_bwd_kernel<T>, dim3((unsigned)ug_qk_rmsnorm_rope_bwd_partials(rows, heads)), dim3(256), 0, (hipStream_t)stream, (const T*)x, ldx,
+                       (const T*)dy, lddy, (T*)dx, lddx, (float*)dwx, (const T*)w, cos_tab, sin_tab, rows_per_batch, pos_offset, nvec, (int)heads, (int)dh, eps);
     UG_CHECK_LAUNCH("ug_qk_rmsnorm_rope_bwd");
     return UG_OK;
 }

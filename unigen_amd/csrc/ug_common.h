@@ -60,6 +60,8 @@ template <> struct ElemT<bf16_t> {
         *(u32x4*)p = v;
     }
     static __device__ __forceinline__ void zero8(bf16_t* p) { *(u32x4*)p = (u32x4){0u, 0u, 0u, 0u}; }
+    static __device__ __forceinline__ void load2(const bf16_t* p, float* f) { const unsigned v = *(const unsigned*)p; f[0] = bflo(v); f[1] = bfhi(v); }
+    static __device__ __forceinline__ void store2(bf16_t* p, const float* f) { *(unsigned*)p = pack2bf(f[0], f[1]); }
     static __device__ __forceinline__ float rnd(float x) { return rbf(x); }          // a bf16 tensor op's output
     static __device__ __forceinline__ float ld(const bf16_t* p) { return bf2f(*p); }
     static __device__ __forceinline__ void st(bf16_t* p, float x) { *p = f2bf(x); }
@@ -75,6 +77,8 @@ template <> struct ElemT<float> {
         *(f32x4*)(p + 4) = (f32x4){f[4], f[5], f[6], f[7]};
     }
     static __device__ __forceinline__ void zero8(float* p) { *(f32x4*)p = (f32x4){0.f, 0.f, 0.f, 0.f}; *(f32x4*)(p + 4) = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    static __device__ __forceinline__ void load2(const float* p, float* f) { const float2 v = *(const float2*)p; f[0] = v.x; f[1] = v.y; }
+    static __device__ __forceinline__ void store2(float* p, const float* f) { *(float2*)p = make_float2(f[0], f[1]); }
     static __device__ __forceinline__ float rnd(float x) { return x; }
     static __device__ __forceinline__ float ld(const float* p) { return *p; }
     static __device__ __forceinline__ void st(float* p, float x) { *p = x; }

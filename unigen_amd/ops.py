@@ -595,18 +595,18 @@ def adaln_modulate_bwd(x: torch.Tensor, dy: torch.Tensor, scale: torch.Tensor, *
 
 def qk_rmsnorm_rope_bwd(x: torch.Tensor, dy: torch.Tensor, w: Optional[torch.Tensor], cos: Optional[torch.Tensor], sin: Optional[torch.Tensor], *,
                         rows_per_batch: int, pos_offset: int, heads: int, dh: int, eps: float = 1e-6):
-    """x, dy [rows, heads * dh] (any row stride) -> (dx [rows, heads * dh], dwx [rows * heads, dh] or None)."""
+    """x, dy [rows, heads * dh] (any row stride) -> (dx [rows, heads * dh], d weight [dh] in x's dtype or None)."""
     dt = _act(x, "x")
     _chk(dy, "dy", dt)
     rows = x.shape[0]
     dx = torch.empty(rows, heads * dh, device=x.device, dtype=dt)
-    dwx = torch.empty(rows * heads, dh, device=x.device, dtype=dt) if w is not None else None
+    dwx = torch.empty(int(L.load().ug_qk_rmsnorm_rope_bwd_partials(rows, heads)), dh, device=x.device, dtype=torch.float32) if w is not None else None
     if cos is not None:
         _chk(cos, "cos", torch.float32); _chk(sin, "sin", torch.float32)
         assert cos.shape[0] >= pos_offset + rows_per_batch and cos.shape[1] == dh and cos.is_contiguous() and sin.is_contiguous()
     L.check(_fn("ug_qk_rmsnorm_rope_bwd", dt)(x.data_ptr(), x.stride(0), dy.data_ptr(), dy.stride(0), dx.data_ptr(), heads * dh, _p(dwx), _p(w), _p(cos),
                                             _p(sin), rows, rows_per_batch, pos_offset, heads, dh, eps, _stream()), "ug_qk_rmsnorm_rope_bwd")
-    return dx, dwx
+    return dx, (dwx.sum(0).to(dt) if dwx is not None else None)       # <= 2048 fp32 partial rows of the kernel, added in a fixed order
 
 
 def row_lse(S: torch.Tensor, scale: float, valid_cols: Optional[int] = None) -> torch.Tensor:
