@@ -327,10 +327,12 @@ int ug_gate_residual_f32(const void* x, int64_t ldx, const void* a, int64_t lda,
 /* y = gelu_tanh(x); dx = dy * gelu_tanh'(x)   (F.gelu(approximate="tanh") of FeedForward net.0 / proj_mlp and its backward) */
 int ug_gelu_tanh(const void* x, void* y, int64_t n, ug_stream_t stream);
 int ug_gelu_tanh_bwd(const void* x, const void* dy, void* dx, int64_t n, ug_stream_t stream);
-/* backward of ug_adaln_modulate (LayerNorm(x) * (1 + scale) + shift): dx, and dyx = dy * xhat whose per-sample column sum is d scale (that of dy
- * is d shift). scale: [samples][mod_ld] as in the forward. */
+/* backward of ug_adaln_modulate (LayerNorm(x) * (1 + scale) + shift): dx, and partials: fp32 [samples][P][2][D], P =
+ * ug_adaln_modulate_bwd_partials(rows, rows_per_sample): partial column sums over disjoint row sets of each sample of dy ([..][0][D], whose sum
+ * over P is d shift) and of dy * xhat ([..][1][D]: d scale); the caller adds them. scale: [samples][mod_ld] as in the forward. D <= 4096, D % 8 == 0. */
+int64_t ug_adaln_modulate_bwd_partials(int64_t rows, int64_t rows_per_sample);
 int ug_adaln_modulate_bwd(const void* x, int64_t ldx, const void* dy, int64_t lddy, const void* scale, int64_t mod_ld, int64_t rows_per_sample,
-                          void* dx, int64_t lddx, void* dyx, int64_t lddyx, int64_t rows, int64_t D, float eps, ug_stream_t stream);
+                          void* dx, int64_t lddx, void* partials, int64_t rows, int64_t D, float eps, ug_stream_t stream);
 /* backward of ug_qk_rmsnorm_rope for ONE of q / k: x = the projection's output (pre-norm) [rows][heads * dh] at ldx, dy = gradient of the
  * normalised + rotated heads; dx likewise; dw_partial: fp32 [ug_qk_rmsnorm_rope_bwd_partials(rows, heads)][dh], partial sums of d(un) * xhat
  * over disjoint sets of (row, head) vectors - their sum over the first index, taken by the caller, is d weight (deterministic: the assignment of
@@ -374,7 +376,7 @@ int ug_colsum_f32(const void* a, int64_t lda, const void* b, int64_t ldb, void* 
 int ug_gelu_tanh_f32(const void* x, void* y, int64_t n, ug_stream_t stream);
 int ug_gelu_tanh_bwd_f32(const void* x, const void* dy, void* dx, int64_t n, ug_stream_t stream);
 int ug_adaln_modulate_bwd_f32(const void* x, int64_t ldx, const void* dy, int64_t lddy, const void* scale, int64_t mod_ld, int64_t rows_per_sample,
-                              void* dx, int64_t lddx, void* dyx, int64_t lddyx, int64_t rows, int64_t D, float eps, ug_stream_t stream);
+                              void* dx, int64_t lddx, void* partials, int64_t rows, int64_t D, float eps, ug_stream_t stream);
 int ug_qk_rmsnorm_rope_bwd_f32(const void* x, int64_t ldx, const void* dy, int64_t lddy, void* dx, int64_t lddx, void* dw_partial, const void* w,
                                const float* cos_tab, const float* sin_tab, int64_t rows, int64_t rows_per_batch, int64_t pos_offset, int32_t heads,
                                int32_t dh, float eps, ug_stream_t stream);

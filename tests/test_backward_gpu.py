@@ -223,6 +223,33 @@ def test_transpose_and_colsum_helpers(gpu, dtype):
         assert rel(got, want) < (3e-3 if dtype == BF else 1e-5), (rows, cols, rel(got, want))
 
 
+@pytest.mark.parametrize("dh,H", [(128, 3), (64, 4), (32, 2)])
+def test_qk_rmsnorm_rope_bwd_paths_agree(gpu, dh, H):
+    """ug_qk_rmsnorm_rope_bwd: the 16-byte kernel (head widths 64 / 128 / 256, aligned operands) and the pair-wise fallback (other widths, or row strides
+    that are not multiples of 8) against fp32 torch autograd of the oracle formula; ragged vector counts (the last wave iteration is partly empty)."""
+    from unigen_amd import ops
+    g = torch.Generator().manual_seed(dh)
+    rows, HD = 101, H * dh
+    x, dy = torch.randn(rows, HD, generator=g), torch.randn(rows, HD, generator=g)
+    w = torch.randn(dh, generator=g) * 0.5 + 1.0
+    ang = torch.randn(rows, dh // 2, generator=g)
+    cos, sin = torch.cos(ang).repeat_interleave(2, 1).contiguous(), torch.sin(ang).repeat_interleave(2, 1).contiguous()
+    xt, wt = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    xh = xt.view(rows, H, dh)
+    un = xh * torch.rsqrt(xh.pow(2).mean(-1, keepdim=True) + 1e-6) * wt
+    rot = torch.stack([-un[..., 1::2], un[..., 0::2]], -1).flatten(-2)
+    y = un * cos[:, None] + rot * sin[:, None]
+    y.reshape(rows, HD).backward(dy)
+    for dt, tol in ((torch.float32, 2e-5), (BF, 1.5e-2)):
+        for pad in (0, 2):                                # pad 2: row stride HD + 2 -> the fallback kernel
+            xs = torch.zeros(rows, HD + pad, dtype=dt); xs[:, :HD] = x.to(dt)
+            ds = torch.zeros(rows, HD + pad, dtype=dt); ds[:, :HD] = dy.to(dt)
+            dx, dw = ops.qk_rmsnorm_rope_bwd(xs.to(gpu)[:, :HD], ds.to(gpu)[:, :HD], w.to(dt).to(gpu), cos.to(gpu), sin.to(gpu), rows_per_batch=rows, pos_offset=0,
+                                             heads=H, dh=dh)
+            # bf16 inputs are the rounded ones: compare against the fp32 gradients of the unrounded problem at bf16 tolerance
+            assert rel(dx, xt.grad) < tol and rel(dw, wt.grad) < tol, (dh, dt, pad, rel(dx, xt.grad), rel(dw, wt.grad))
+
+
 def test_gate_residual_backward(gpu):
     from unigen_amd import autograd as A
     g = torch.Generator().manual_seed(6)

@@ -127,12 +127,7 @@ class AdaLNModulate(torch.autograd.Function):
         x2, scale = ctx.saved_tensors
         B, Ls, D = ctx.geom
         dy2 = dy.reshape(B * Ls, D).contiguous()
-        dx, dyx = ops.adaln_modulate_bwd(x2, dy2, scale, rows_per_sample=Ls, eps=ctx.eps)
-        if Ls == 1:                       # per-token modulation (SD3 transformer-block experts): nothing to sum
-            dshift, dscale = dy2, dyx
-        else:
-            dshift = ops.colsum(dy2, rows_per_group=Ls)
-            dscale = ops.colsum(dyx, rows_per_group=Ls)
+        dx, dshift, dscale = ops.adaln_modulate_bwd(x2, dy2, scale, rows_per_sample=Ls, eps=ctx.eps)
         return dx.view(B, Ls, D), dshift, dscale, None
 
 

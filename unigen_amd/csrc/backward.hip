@@ -150,47 +150,124 @@ __global__ void gate_residual_kernel(const T* __restrict__ x, int64_t ldx, const
     }
 }
 
-template <typename T>
+// 8 elements per lane and access (16-byte loads / stores) when n and the bases allow (VEC); element-wise otherwise
+template <typename T, bool VEC>
 __global__ void gelu_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        ElemT<T>::st(y + i, gelu_f(ElemT<T>::ld(x + i)));
+    if constexpr (VEC) {
+        for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8; i < n; i += (int64_t)gridDim.x * blockDim.x * 8) {
+            float v[8];
+            ElemT<T>::load8(x + i, v);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = gelu_f(v[k]);
+            ElemT<T>::store8(y + i, v);
+        }
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+            ElemT<T>::st(y + i, gelu_f(ElemT<T>::ld(x + i)));
+    }
 }
-template <typename T>
+template <typename T, bool VEC>
 __global__ void gelu_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, int64_t n) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        ElemT<T>::st(dx + i, ElemT<T>::ld(dy + i) * gelu_grad_f(ElemT<T>::ld(x + i)));
+    if constexpr (VEC) {
+        for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8; i < n; i += (int64_t)gridDim.x * blockDim.x * 8) {
+            float v[8], g[8];
+            ElemT<T>::load8(x + i, v); ElemT<T>::load8(dy + i, g);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = g[k] * gelu_grad_f(v[k]);
+            ElemT<T>::store8(dx + i, v);
+        }
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+            ElemT<T>::st(dx + i, ElemT<T>::ld(dy + i) * gelu_grad_f(ElemT<T>::ld(x + i)));
+    }
 }
 
-// One wave per row. y = xhat (1 + s) + sh, xhat = (x - mu) rstd:
-//   g = dy (1 + s);  dx = rstd (g - mean(g) - xhat mean(g xhat));  dyx = dy xhat  (its per-sample column sum is d scale; that of dy is d shift)
-template <typename T>
+// y = xhat (1 + s) + sh, xhat = (x - mu) rstd:   g = dy (1 + s);  dx = rstd (g - mean(g) - xhat mean(g xhat));  d shift[sample] = sum_rows dy,
+// d scale[sample] = sum_rows dy xhat. Block (p, sample) takes the p-th chunk of the sample's rows, one wave per row, NC 16-byte chunks per lane
+// (D <= 512 NC); x and dy are read once and stay in registers, the two column sums are accumulated in registers over the wave's rows, the four waves
+// add theirs in LDS in a fixed order and the block writes ONE fp32 partial [2][D] - the caller adds the partials of a sample. (The first version
+// wrote dy xhat as a tensor and left both column sums to ug_colsum: twice the traffic, four more launches.)
+template <typename T, int NC>
 __global__ __launch_bounds__(256) void adaln_bwd_kernel(const T* __restrict__ x, int64_t ldx, const T* __restrict__ dy, int64_t lddy,
                                                         const T* __restrict__ scale, int64_t mod_ld, int64_t rows_per_sample, T* __restrict__ dx,
-                                                        int64_t lddx, T* __restrict__ dyx, int64_t lddyx, int64_t rows, int D, float eps) {
-    const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    const T* xr = x + row * ldx; const T* gr = dy + row * lddy;
-    const T* sc = scale + (row / rows_per_sample) * mod_ld;
-    float s1 = 0.f, s2 = 0.f;
-    for (int c = lane; c < D; c += 64) { const float v = ElemT<T>::ld(xr + c); s1 += v; s2 += v * v; }
-    s1 = wave_sum(s1); s2 = wave_sum(s2);
-    const float mu = s1 / D;
-    const float rstd = rsqrtf(fmaxf(s2 / D - mu * mu, 0.f) + eps);
-    float a = 0.f, bsum = 0.f;
-    for (int c = lane; c < D; c += 64) {
-        const float xh = (ElemT<T>::ld(xr + c) - mu) * rstd;
-        const float g = ElemT<T>::ld(gr + c) * (1.0f + ElemT<T>::ld(sc + c));
-        a += g; bsum += g * xh;
+                                                        int64_t lddx, float* __restrict__ part /* [samples][gridDim.x][2][D] */, int D, float eps) {
+    extern __shared__ float red[];                                  // [2][D]
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t sample = blockIdx.y;
+    const int64_t chunk = (rows_per_sample + gridDim.x - 1) / gridDim.x;
+    const int64_t r_lo = (int64_t)blockIdx.x * chunk, r_hi = r_lo + chunk < rows_per_sample ? r_lo + chunk : rows_per_sample;
+    const T* sc = scale + sample * mod_ld;
+    float pd[NC][8], px[NC][8];
+#pragma unroll
+    for (int i = 0; i < NC; ++i)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) pd[i][k] = px[i][k] = 0.f;
+    for (int64_t rr = r_lo + wv; rr < r_hi; rr += 4) {
+        const int64_t row = sample * rows_per_sample + rr;
+        const T* xr = x + row * ldx; const T* gr = dy + row * lddy;
+        float xv[NC][8], dv[NC][8];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const int c = 8 * (lane + 64 * i);
+            if (c < D) {
+                ElemT<T>::load8(xr + c, xv[i]); ElemT<T>::load8(gr + c, dv[i]);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { s1 += xv[i][k]; s2 += xv[i][k] * xv[i][k]; }
+            }
+        }
+        s1 = wave_sum(s1); s2 = wave_sum(s2);
+        const float mu = s1 / D;
+        const float rstd = rsqrtf(fmaxf(s2 / D - mu * mu, 0.f) + eps);
+        float a = 0.f, bsum = 0.f;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const int c = 8 * (lane + 64 * i);
+            if (c < D) {
+                float sv[8];
+                ElemT<T>::load8(sc + c, sv);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    xv[i][k] = (xv[i][k] - mu) * rstd;                           // xhat from here on
+                    const float g = dv[i][k] * (1.0f + sv[k]);
+                    a += g; bsum += g * xv[i][k];
+                }
+            }
+        }
+        a = wave_sum(a) / D; bsum = wave_sum(bsum) / D;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const int c = 8 * (lane + 64 * i);
+            if (c < D) {
+                float sv[8], o[8];
+                ElemT<T>::load8(sc + c, sv);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    o[k] = rstd * (dv[i][k] * (1.0f + sv[k]) - a - xv[i][k] * bsum);
+                    pd[i][k] += dv[i][k]; px[i][k] += dv[i][k] * xv[i][k];
+                }
+                ElemT<T>::store8(dx + row * lddx + c, o);
+            }
+        }
     }
-    a = wave_sum(a) / D; bsum = wave_sum(bsum) / D;
-    for (int c = lane; c < D; c += 64) {
-        const float xh = (ElemT<T>::ld(xr + c) - mu) * rstd;
-        const float d = ElemT<T>::ld(gr + c);
-        const float g = d * (1.0f + ElemT<T>::ld(sc + c));
-        ElemT<T>::st(dx + row * lddx + c, rstd * (g - a - xh * bsum));
-        ElemT<T>::st(dyx + row * lddyx + c, d * xh);
+    for (int w4 = 0; w4 < 4; ++w4) {                                // waves 0..3 add their sums in this order
+        if (wv == w4) {
+#pragma unroll
+            for (int i = 0; i < NC; ++i) {
+                const int c = 8 * (lane + 64 * i);
+                if (c < D) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        red[c + k] = (w4 == 0 ? 0.f : red[c + k]) + pd[i][k];
+                        red[D + c + k] = (w4 == 0 ? 0.f : red[D + c + k]) + px[i][k];
+                    }
+                }
+            }
+        }
+        __syncthreads();
     }
+    float* out = part + (sample * gridDim.x + blockIdx.x) * 2 * (int64_t)D;
+    for (int e = threadIdx.x; e < 2 * D; e += 256) out[e] = red[e];
 }
 
 // One wave per (row, head) vector of DH elements (lane l: pairs l, l + 64 < DH / 2), a grid-stride loop over the vectors: forward was u = x rs,
@@ -262,6 +339,79 @@ __global__ __launch_bounds__(256) void qk_bwd_kernel(const T* __restrict__ x, in
         for (int i = 0; i < QKB_MAXP; ++i) { red[wv][2 * (lane + 64 * i)] = dwa[i][0]; red[wv][2 * (lane + 64 * i) + 1] = dwa[i][1]; }
         __syncthreads();
         for (int e = threadIdx.x; e < DH; e += 256) dw_part[(int64_t)blockIdx.x * DH + e] = ((red[0][e] + red[1][e]) + red[2][e]) + red[3][e];
+    }
+}
+
+// The same backward with 16-byte accesses: a (row, head) vector takes LPV = DH / 8 lanes (8 consecutive elements = 4 rotation pairs per lane), a wave
+// handles 64 / LPV vectors per iteration, the two reductions run over the LPV lanes of a vector (xor shuffles). Head widths 64 / 128 / 256.
+template <typename T, int LPV>
+__global__ __launch_bounds__(256) void qk_bwd8_kernel(const T* __restrict__ x, int64_t ldx, const T* __restrict__ dy, int64_t lddy, T* __restrict__ dx,
+                                                      int64_t lddx, float* __restrict__ dw_part /* [gridDim.x][DH] */, const T* __restrict__ w,
+                                                      const float* __restrict__ cos_tab, const float* __restrict__ sin_tab, int64_t rows_per_batch,
+                                                      int64_t pos_offset, int64_t nvec, int heads, float eps) {
+    constexpr int VPW = 64 / LPV, DH = 8 * LPV;
+    __shared__ float red[4][64][8];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int sub = lane % LPV, slot = lane / LPV;
+    float wq[8], dwa[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { dwa[k] = 0.f; wq[k] = w ? ElemT<T>::ld(w + 8 * sub + k) : 0.f; }
+    auto group_sum = [](float v) {
+#pragma unroll
+        for (int m = 1; m < LPV; m <<= 1) v += __shfl_xor(v, m, 64);
+        return v;
+    };
+    for (int64_t vec0 = ((int64_t)blockIdx.x * 4 + wv) * VPW; vec0 < nvec; vec0 += (int64_t)gridDim.x * 4 * VPW) {
+        const int64_t vec = vec0 + slot;
+        const bool valid = vec < nvec;
+        const int64_t vc = valid ? vec : nvec - 1;
+        const int64_t row = vc / heads; const int h = (int)(vc - row * heads);
+        const int64_t pos = pos_offset + row % rows_per_batch;
+        float xa[8], g[8];
+        ElemT<T>::load8(x + row * ldx + (int64_t)h * DH + 8 * sub, xa);
+        ElemT<T>::load8(dy + row * lddy + (int64_t)h * DH + 8 * sub, g);
+        if (cos_tab) {
+            const f32x4 c0 = *(const f32x4*)(cos_tab + pos * DH + 8 * sub), c1 = *(const f32x4*)(cos_tab + pos * DH + 8 * sub + 4);
+            const f32x4 s0 = *(const f32x4*)(sin_tab + pos * DH + 8 * sub), s1 = *(const f32x4*)(sin_tab + pos * DH + 8 * sub + 4);
+            const float cc[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]}, sn[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+#pragma unroll
+            for (int q = 0; q < 8; q += 2) {       // y0 = a c0 - b s0, y1 = b c1 + a s1  ->  da = g0 c0 + g1 s1, db = g1 c1 - g0 s0
+                const float t0 = g[q] * cc[q] + g[q + 1] * sn[q + 1], t1 = g[q + 1] * cc[q + 1] - g[q] * sn[q];
+                g[q] = t0; g[q + 1] = t1;
+            }
+        }
+        float rs = 1.0f, dot = 0.f;
+        if (w) {
+            float ss = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) ss += xa[k] * xa[k];
+            rs = rsqrtf(group_sum(ss) / DH + eps);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) dot += g[k] * wq[k] * (xa[k] * rs);
+            dot = group_sum(dot) / DH;
+        }
+        float o[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            o[k] = g[k];
+            if (w) {
+                const float u = xa[k] * rs;
+                if (valid) dwa[k] += g[k] * u;
+                o[k] = rs * (g[k] * wq[k] - u * dot);
+            }
+        }
+        if (valid) ElemT<T>::store8(dx + row * lddx + (int64_t)h * DH + 8 * sub, o);
+    }
+    if (w) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) red[wv][lane][k] = dwa[k];
+        __syncthreads();
+        for (int e = threadIdx.x; e < DH; e += 256) {
+            float acc = 0.f;
+            for (int w4 = 0; w4 < 4; ++w4)
+                for (int sl = 0; sl < VPW; ++sl) acc += red[w4][sl * LPV + e / 8][e % 8];
+            dw_part[(int64_t)blockIdx.x * DH + e] = acc;
+        }
     }
 }
 
@@ -363,8 +513,15 @@ template <typename T>
 int gelu_impl(const void* x, const void* dy, void* out, int64_t n, ug_stream_t stream) {
     if (n == 0) return UG_OK;
     UG_REQUIRE(x && out && n > 0, UG_ERR_BAD_SHAPE, "ug_gelu_tanh: bad arguments");
-    if (dy) hipLaunchKernelGGL(gelu_bwd_kernel<T>, dim3(grid1d(n, 256 * 8)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)dy, (T*)out, n);
-    else hipLaunchKernelGGL(gelu_kernel<T>, dim3(grid1d(n, 256 * 8)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)out, n);
+    const bool vec = n % 8 == 0 && ug_aligned(x, 16) && ug_aligned(out, 16) && (!dy || ug_aligned(dy, 16));
+    const dim3 grid(grid1d(n, 256 * 8 * (vec ? 2 : 1)));
+    if (dy) {
+        if (vec) hipLaunchKernelGGL((gelu_bwd_kernel<T, true>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)dy, (T*)out, n);
+        else hipLaunchKernelGGL((gelu_bwd_kernel<T, false>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)dy, (T*)out, n);
+    } else {
+        if (vec) hipLaunchKernelGGL((gelu_kernel<T, true>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)out, n);
+        else hipLaunchKernelGGL((gelu_kernel<T, false>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)out, n);
+    }
     UG_CHECK_LAUNCH("ug_gelu_tanh");
     return UG_OK;
 }
@@ -381,14 +538,36 @@ int gate_residual_impl(const void* x, int64_t ldx, const void* a, int64_t lda, c
     UG_CHECK_LAUNCH("ug_gate_residual");
     return UG_OK;
 }
+}  // namespace
+extern "C" int64_t ug_adaln_modulate_bwd_partials(int64_t rows, int64_t rows_per_sample) {
+    if (rows <= 0 || rows_per_sample <= 0) return 0;
+    const int64_t samples = rows / rows_per_sample, by_rows = (rows_per_sample + 3) / 4;
+    int64_t p = 1024 / (samples > 0 ? samples : 1);
+    if (p > by_rows) p = by_rows;
+    return p < 1 ? 1 : p;
+}
+namespace {
 template <typename T>
 int adaln_bwd_impl(const void* x, int64_t ldx, const void* dy, int64_t lddy, const void* scale, int64_t mod_ld, int64_t rows_per_sample, void* dx,
-                   int64_t lddx, void* dyx, int64_t lddyx, int64_t rows, int64_t D, float eps, ug_stream_t stream) {
+                   int64_t lddx, void* part, int64_t rows, int64_t D, float eps, ug_stream_t stream) {
     if (rows == 0) return UG_OK;
-    UG_REQUIRE(x && dy && scale && dx && dyx && rows > 0 && D > 0 && rows_per_sample > 0 && ldx >= D && lddy >= D && lddx >= D && lddyx >= D, UG_ERR_BAD_SHAPE,
-               "ug_adaln_modulate_bwd: bad arguments");
-    hipLaunchKernelGGL(adaln_bwd_kernel<T>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const T*)x, ldx, (const T*)dy, lddy,
-                       (const T*)scale, mod_ld, rows_per_sample, (T*)dx, lddx, (T*)dyx, lddyx, rows, (int)D, eps);
+    UG_REQUIRE(x && dy && scale && dx && part && rows > 0 && D > 0 && rows_per_sample > 0 && rows % rows_per_sample == 0 && ldx >= D && lddy >= D && lddx >= D &&
+               mod_ld >= D && rows / rows_per_sample < 65536, UG_ERR_BAD_SHAPE, "ug_adaln_modulate_bwd: bad arguments");
+    constexpr int EA = ElemT<T>::kF32 ? 16 : 16;
+    UG_REQUIRE(D % 8 == 0 && D <= 4096 && ldx % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0 && mod_ld % 8 == 0 && ug_aligned(x, EA) && ug_aligned(dy, EA) &&
+               ug_aligned(dx, EA) && ug_aligned(scale, EA) && ug_aligned(part, 4), UG_ERR_BAD_ALIGN,
+               "ug_adaln_modulate_bwd: D <= 4096, D and leading dimensions multiples of 8, 16-byte aligned bases");
+    const dim3 grid((unsigned)ug_adaln_modulate_bwd_partials(rows, rows_per_sample), (unsigned)(rows / rows_per_sample));
+    const size_t lds = 2 * (size_t)D * sizeof(float);
+#define UG_ADALN_BWD(NCV)                                                                                                                         \
+    hipLaunchKernelGGL((adaln_bwd_kernel<T, NCV>), grid, dim3(256), lds, (hipStream_t)stream, (const T*)x, ldx, (const T*)dy, lddy, (const T*)scale, mod_ld, \
+                       rows_per_sample, (T*)dx, lddx, (float*)part, (int)D, eps)
+    const int nc = (int)((D + 511) / 512);
+    switch (nc) {
+        case 1: UG_ADALN_BWD(1); break; case 2: UG_ADALN_BWD(2); break; case 3: UG_ADALN_BWD(3); break; case 4: UG_ADALN_BWD(4); break;
+        case 5: case 6: UG_ADALN_BWD(6); break; default: UG_ADALN_BWD(8); break;
+    }
+#undef UG_ADALN_BWD
     UG_CHECK_LAUNCH("ug_adaln_modulate_bwd");
     return UG_OK;
 }
@@ -407,8 +586,19 @@ int qk_bwd_impl(const void* x, int64_t ldx, const void* dy, int64_t lddy, void* 
     UG_REQUIRE(dh <= 128 * QKB_MAXP && ldx % 2 == 0 && lddy % 2 == 0 && lddx % 2 == 0 && ug_aligned(x, 2 * sizeof(T)) && ug_aligned(dy, 2 * sizeof(T)) &&
                ug_aligned(dx, 2 * sizeof(T)), UG_ERR_UNSUPPORTED, "ug_qk_rmsnorm_rope_bwd: head width <= 256, even leading dimensions, pair-aligned bases");
     const int64_t nvec = rows * heads;
-    hipLaunchKernelGGL(qk_bwd_kernel<T>, dim3((unsigned)ug_qk_rmsnorm_rope_bwd_partials(rows, heads)), dim3(256), 0, (hipStream_t)stream, (const T*)x, ldx,
-                       (const T*)dy, lddy, (T*)dx, lddx, (float*)dwx, (const T*)w, cos_tab, sin_tab, rows_per_batch, pos_offset, nvec, (int)heads, (int)dh, eps);
+    const dim3 grid((unsigned)ug_qk_rmsnorm_rope_bwd_partials(rows, heads));
+    const bool vec8 = (dh == 64 || dh == 128 || dh == 256) && ldx % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0 && ug_aligned(x, 16) && ug_aligned(dy, 16) &&
+                      ug_aligned(dx, 16) && (!w || ug_aligned(w, 2)) && (!cos_tab || (ug_aligned(cos_tab, 16) && ug_aligned(sin_tab, 16)));
+#define UG_QKB8(LPVV)                                                                                                                            \
+    hipLaunchKernelGGL((qk_bwd8_kernel<T, LPVV>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)x, ldx, (const T*)dy, lddy, (T*)dx, lddx, (float*)dwx, \
+                       (const T*)w, cos_tab, sin_tab, rows_per_batch, pos_offset, nvec, (int)heads, eps)
+    if (vec8 && dh == 128) UG_QKB8(16);
+    else if (vec8 && dh == 64) UG_QKB8(8);
+    else if (vec8 && dh == 256) UG_QKB8(32);
+    else
+        hipLaunchKernelGGL(qk_bwd_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)x, ldx, (const T*)dy, lddy, (T*)dx, lddx, (float*)dwx, (const T*)w,
+                           cos_tab, sin_tab, rows_per_batch, pos_offset, nvec, (int)heads, (int)dh, eps);
+#undef UG_QKB8
     UG_CHECK_LAUNCH("ug_qk_rmsnorm_rope_bwd");
     return UG_OK;
 }
@@ -469,8 +659,8 @@ UG_TWINS(ug_gelu_tanh, gelu_impl, (const void* x, void* y, int64_t n, ug_stream_
 UG_TWINS(ug_gelu_tanh_bwd, gelu_impl, (const void* x, const void* dy, void* dx, int64_t n, ug_stream_t stream), (x, dy, dx, n, stream))
 UG_TWINS(ug_adaln_modulate_bwd, adaln_bwd_impl,
          (const void* x, int64_t ldx, const void* dy, int64_t lddy, const void* scale, int64_t mod_ld, int64_t rows_per_sample, void* dx, int64_t lddx,
-          void* dyx, int64_t lddyx, int64_t rows, int64_t D, float eps, ug_stream_t stream),
-         (x, ldx, dy, lddy, scale, mod_ld, rows_per_sample, dx, lddx, dyx, lddyx, rows, D, eps, stream))
+          void* partials, int64_t rows, int64_t D, float eps, ug_stream_t stream),
+         (x, ldx, dy, lddy, scale, mod_ld, rows_per_sample, dx, lddx, partials, rows, D, eps, stream))
 UG_TWINS(ug_qk_rmsnorm_rope_bwd, qk_bwd_impl,
          (const void* x, int64_t ldx, const void* dy, int64_t lddy, void* dx, int64_t lddx, void* dwx, const void* w, const float* cos_tab,
           const float* sin_tab, int64_t rows, int64_t rows_per_batch, int64_t pos_offset, int32_t heads, int32_t dh, float eps, ug_stream_t stream),

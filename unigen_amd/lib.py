@@ -90,7 +90,8 @@ SIGNATURES.update({
     "ug_gate_residual": (i32, [vp, i64, vp, i64, vp, i64, i64, vp, i64, i64, i64, vp]),
     "ug_gelu_tanh": (i32, [vp, vp, i64, vp]),
     "ug_gelu_tanh_bwd": (i32, [vp, vp, vp, i64, vp]),
-    "ug_adaln_modulate_bwd": (i32, [vp, i64, vp, i64, vp, i64, i64, vp, i64, vp, i64, i64, i64, f32, vp]),
+    "ug_adaln_modulate_bwd": (i32, [vp, i64, vp, i64, vp, i64, i64, vp, i64, vp, i64, i64, f32, vp]),
+    "ug_adaln_modulate_bwd_partials": (i64, [i64, i64]),
     "ug_qk_rmsnorm_rope_bwd": (i32, [vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, i64, i64, i64, i32, i32, f32, vp]),
     "ug_qk_rmsnorm_rope_bwd_partials": (i64, [i64, i32]),
     "ug_row_lse": (i32, [vp, i64, vp, i64, i64, f32, vp]),

@@ -583,14 +583,17 @@ def gelu_tanh_bwd(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
 
 
 def adaln_modulate_bwd(x: torch.Tensor, dy: torch.Tensor, scale: torch.Tensor, *, rows_per_sample: int, eps: float = 1e-6):
-    """x, dy [rows, D]; scale [samples, D] (row stride = its stride(0)) -> (dx, dy * xhat)."""
+    """x, dy [rows, D]; scale [samples, D] (row stride = its stride(0)) -> (dx [rows, D], d shift [samples, D], d scale [samples, D])."""
     dt = _act(x, "x")
     _chk(dy, "dy", dt); _chk(scale, "scale", dt)
     rows, D = x.shape
-    dx, dyx = torch.empty(rows, D, device=x.device, dtype=dt), torch.empty(rows, D, device=x.device, dtype=dt)
+    samples = rows // rows_per_sample
+    dx = torch.empty(rows, D, device=x.device, dtype=dt)
+    part = torch.empty(samples, int(L.load().ug_adaln_modulate_bwd_partials(rows, rows_per_sample)), 2, D, device=x.device, dtype=torch.float32)
     L.check(_fn("ug_adaln_modulate_bwd", dt)(x.data_ptr(), x.stride(0), dy.data_ptr(), dy.stride(0), scale.data_ptr(), scale.stride(0), rows_per_sample,
-                                           dx.data_ptr(), D, dyx.data_ptr(), D, rows, D, eps, _stream()), "ug_adaln_modulate_bwd")
-    return dx, dyx
+                                           dx.data_ptr(), D, part.data_ptr(), rows, D, eps, _stream()), "ug_adaln_modulate_bwd")
+    sums = part.sum(1).to(dt) if part.shape[1] > 1 else part[:, 0].to(dt)         # the kernel's per-sample partials, added in a fixed order
+    return dx, sums[:, 0], sums[:, 1]
 
 
 def qk_rmsnorm_rope_bwd(x: torch.Tensor, dy: torch.Tensor, w: Optional[torch.Tensor], cos: Optional[torch.Tensor], sin: Optional[torch.Tensor], *,
