@@ -1262,18 +1262,23 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(
     }
 }
 
-// delta[bh][q] = sum_d dO[b][q][h*DH + d] * O[b][q][h*DH + d]; one wave per (b, q, h)
+// delta[bh][q] = sum_d dO[b][q][h*DH + d] * O[b][q][h*DH + d]: DH / 8 lanes per (b, q, h), 16-byte loads, the sum over those lanes by xor shuffles
+template <int DH>
 __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ o, int64_t o_rs, int64_t o_bs, const bf16_t* __restrict__ dout, int64_t d_rs,
-                                                         int64_t d_bs, float* __restrict__ delta, int64_t stat_ld, int64_t total, int heads, int Lq, int dh) {
-    const int lane = threadIdx.x & 63;
-    const int64_t id = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (id >= total) return;
-    const int hd = (int)(id % heads); const int64_t t = id / heads; const int q = (int)(t % Lq); const int64_t b = t / Lq;
+                                                         int64_t d_bs, float* __restrict__ delta, int64_t stat_ld, int64_t total, int heads, int Lq) {
+    constexpr int LPV = DH / 8, VPW = 64 / LPV;
+    const int lane = threadIdx.x & 63, sub = lane % LPV;
+    const int64_t id = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * VPW + lane / LPV;
+    const int64_t idc = id < total ? id : total - 1;
+    const int hd = (int)(idc % heads); const int64_t t = idc / heads; const int q = (int)(t % Lq); const int64_t b = t / Lq;
+    const bf16x8 a = *(const bf16x8*)(o + b * o_bs + (int64_t)q * o_rs + hd * DH + 8 * sub);
+    const bf16x8 g = *(const bf16x8*)(dout + b * d_bs + (int64_t)q * d_rs + hd * DH + 8 * sub);
     float acc = 0.f;
-    for (int d = lane; d < dh; d += 64)
-        acc += bf2f(o[b * o_bs + (int64_t)q * o_rs + hd * dh + d]) * bf2f(dout[b * d_bs + (int64_t)q * d_rs + hd * dh + d]);
-    acc = wave_sum(acc);
-    if (lane == 0) delta[(b * heads + hd) * stat_ld + q] = acc;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc += bf2f((bf16_t)a[k]) * bf2f((bf16_t)g[k]);
+#pragma unroll
+    for (int m = 1; m < LPV; m <<= 1) acc += __shfl_xor(acc, m, 64);
+    if (sub == 0 && id < total) delta[(b * heads + hd) * stat_ld + q] = acc;
 }
 
 }  // namespace
@@ -1391,8 +1396,12 @@ extern "C" int ug_flash_attn_bwd(const void* q, int64_t q_rs, int64_t q_bs, cons
     UG_REQUIRE(gq < (1ll << 31) && gk < (1ll << 31), UG_ERR_UNSUPPORTED, "ug_flash_attn_bwd: grid too large");
     (void)hipMemsetAsync(workspace, 0, (size_t)(2 * batches * heads * stat_ld) * sizeof(float), s);     // padded statistics rows read as 0
     const int64_t total = batches * Lq * heads;
-    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, s, (const bf16_t*)o, o_rs, o_bs, (const bf16_t*)dout, do_rs, do_bs, delta,
-                       stat_ld, total, (int)heads, (int)Lq, (int)dh);
+    if (dh == 128)
+        hipLaunchKernelGGL(attn_delta_kernel<128>, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, s, (const bf16_t*)o, o_rs, o_bs, (const bf16_t*)dout, do_rs, do_bs,
+                           delta, stat_ld, total, (int)heads, (int)Lq);
+    else
+        hipLaunchKernelGGL(attn_delta_kernel<64>, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, s, (const bf16_t*)o, o_rs, o_bs, (const bf16_t*)dout, do_rs, do_bs,
+                           delta, stat_ld, total, (int)heads, (int)Lq);
 #define UG_BWD(DHV, MODEV, GRID, ...)                                                                                                                  \
     do { if (bwd_dma) UG_BWD_(DHV, MODEV, true, GRID, __VA_ARGS__); else UG_BWD_(DHV, MODEV, false, GRID, __VA_ARGS__); } while (0)
 #define UG_BWD_(DHV, MODEV, DMAV, GRID, O1, O1R, O1B, O2, O2R, O2B, S1, S1R, S1B, S2, S2R, S2B, OUT, OR, OB, LOWN, LST, NOWN)                          \
