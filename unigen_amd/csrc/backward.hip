@@ -183,91 +183,76 @@ __global__ void gelu_bwd_kernel(const T* __restrict__ x, const T* __restrict__ d
 }
 
 // y = xhat (1 + s) + sh, xhat = (x - mu) rstd:   g = dy (1 + s);  dx = rstd (g - mean(g) - xhat mean(g xhat));  d shift[sample] = sum_rows dy,
-// d scale[sample] = sum_rows dy xhat. Block (p, sample) takes the p-th chunk of the sample's rows, one wave per row, NC 16-byte chunks per lane
-// (D <= 512 NC); x and dy are read once and stay in registers, the two column sums are accumulated in registers over the wave's rows, the four waves
-// add theirs in LDS in a fixed order and the block writes ONE fp32 partial [2][D] - the caller adds the partials of a sample. (The first version
-// wrote dy xhat as a tensor and left both column sums to ug_colsum: twice the traffic, four more launches.)
-template <typename T, int NC>
-__global__ __launch_bounds__(256) void adaln_bwd_kernel(const T* __restrict__ x, int64_t ldx, const T* __restrict__ dy, int64_t lddy,
+// d scale[sample] = sum_rows dy xhat. Block (p, sample) takes the p-th chunk of the sample's rows; its W = ceil(D / 512) <= 8 waves share every row,
+// each wave one 512-column segment (8 elements per lane, one 16-byte access per operand), the row statistics meet in LDS (two barriers per row,
+// slots alternating by row parity). x and dy are read once; every column belongs to one lane of one wave, so the two column sums are accumulated in
+// registers over the block's rows and stored straight into the block's fp32 partial [2][D] - the caller adds the partials of a sample.
+// (First version: dy xhat written as a tensor, both sums left to ug_colsum - twice the traffic, four more launches. Second: one wave per row with
+// 48 elements per lane - 252 registers, latency-bound at 1.8 TB/s.)
+template <typename T>
+__global__ __launch_bounds__(512) void adaln_bwd_kernel(const T* __restrict__ x, int64_t ldx, const T* __restrict__ dy, int64_t lddy,
                                                         const T* __restrict__ scale, int64_t mod_ld, int64_t rows_per_sample, T* __restrict__ dx,
                                                         int64_t lddx, float* __restrict__ part /* [samples][gridDim.x][2][D] */, int D, float eps) {
-    extern __shared__ float red[];                                  // [2][D]
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __shared__ float slot[2][4][8];                                  // [row parity][s1, s2, a, b][wave]
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, W = blockDim.x >> 6;
     const int64_t sample = blockIdx.y;
     const int64_t chunk = (rows_per_sample + gridDim.x - 1) / gridDim.x;
     const int64_t r_lo = (int64_t)blockIdx.x * chunk, r_hi = r_lo + chunk < rows_per_sample ? r_lo + chunk : rows_per_sample;
-    const T* sc = scale + sample * mod_ld;
-    float pd[NC][8], px[NC][8];
+    const int c = 8 * (lane + 64 * wv);
+    const bool in = c < D;
+    float sv[8], pd[8], px[8];
 #pragma unroll
-    for (int i = 0; i < NC; ++i)
+    for (int k = 0; k < 8; ++k) { pd[k] = px[k] = 0.f; sv[k] = 0.f; }
+    if (in) {
+        ElemT<T>::load8(scale + sample * mod_ld + c, sv);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) pd[i][k] = px[i][k] = 0.f;
-    for (int64_t rr = r_lo + wv; rr < r_hi; rr += 4) {
+        for (int k = 0; k < 8; ++k) sv[k] += 1.0f;
+    }
+    int par = 0;
+    for (int64_t rr = r_lo; rr < r_hi; ++rr, par ^= 1) {
         const int64_t row = sample * rows_per_sample + rr;
-        const T* xr = x + row * ldx; const T* gr = dy + row * lddy;
-        float xv[NC][8], dv[NC][8];
+        float xv[8], dv[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) xv[k] = dv[k] = 0.f;
+        if (in) { ElemT<T>::load8(x + row * ldx + c, xv); ElemT<T>::load8(dy + row * lddy + c, dv); }
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < NC; ++i) {
-            const int c = 8 * (lane + 64 * i);
-            if (c < D) {
-                ElemT<T>::load8(xr + c, xv[i]); ElemT<T>::load8(gr + c, dv[i]);
-#pragma unroll
-                for (int k = 0; k < 8; ++k) { s1 += xv[i][k]; s2 += xv[i][k] * xv[i][k]; }
-            }
-        }
+        for (int k = 0; k < 8; ++k) { s1 += xv[k]; s2 += xv[k] * xv[k]; }
         s1 = wave_sum(s1); s2 = wave_sum(s2);
+        if (lane == 0) { slot[par][0][wv] = s1; slot[par][1][wv] = s2; }
+        __syncthreads();
+        s1 = 0.f; s2 = 0.f;
+        for (int w8 = 0; w8 < W; ++w8) { s1 += slot[par][0][w8]; s2 += slot[par][1][w8]; }
         const float mu = s1 / D;
         const float rstd = rsqrtf(fmaxf(s2 / D - mu * mu, 0.f) + eps);
         float a = 0.f, bsum = 0.f;
 #pragma unroll
-        for (int i = 0; i < NC; ++i) {
-            const int c = 8 * (lane + 64 * i);
-            if (c < D) {
-                float sv[8];
-                ElemT<T>::load8(sc + c, sv);
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    xv[i][k] = (xv[i][k] - mu) * rstd;                           // xhat from here on
-                    const float g = dv[i][k] * (1.0f + sv[k]);
-                    a += g; bsum += g * xv[i][k];
-                }
-            }
+        for (int k = 0; k < 8; ++k) {
+            xv[k] = in ? (xv[k] - mu) * rstd : 0.f;                  // xhat from here on
+            const float g = dv[k] * sv[k];
+            a += g; bsum += g * xv[k];
         }
-        a = wave_sum(a) / D; bsum = wave_sum(bsum) / D;
-#pragma unroll
-        for (int i = 0; i < NC; ++i) {
-            const int c = 8 * (lane + 64 * i);
-            if (c < D) {
-                float sv[8], o[8];
-                ElemT<T>::load8(sc + c, sv);
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    o[k] = rstd * (dv[i][k] * (1.0f + sv[k]) - a - xv[i][k] * bsum);
-                    pd[i][k] += dv[i][k]; px[i][k] += dv[i][k] * xv[i][k];
-                }
-                ElemT<T>::store8(dx + row * lddx + c, o);
-            }
-        }
-    }
-    for (int w4 = 0; w4 < 4; ++w4) {                                // waves 0..3 add their sums in this order
-        if (wv == w4) {
-#pragma unroll
-            for (int i = 0; i < NC; ++i) {
-                const int c = 8 * (lane + 64 * i);
-                if (c < D) {
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        red[c + k] = (w4 == 0 ? 0.f : red[c + k]) + pd[i][k];
-                        red[D + c + k] = (w4 == 0 ? 0.f : red[D + c + k]) + px[i][k];
-                    }
-                }
-            }
-        }
+        a = wave_sum(a); bsum = wave_sum(bsum);
+        if (lane == 0) { slot[par][2][wv] = a; slot[par][3][wv] = bsum; }
         __syncthreads();
+        a = 0.f; bsum = 0.f;
+        for (int w8 = 0; w8 < W; ++w8) { a += slot[par][2][w8]; bsum += slot[par][3][w8]; }
+        a /= D; bsum /= D;
+        if (in) {
+            float o[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                o[k] = rstd * (dv[k] * sv[k] - a - xv[k] * bsum);
+                pd[k] += dv[k]; px[k] += dv[k] * xv[k];
+            }
+            ElemT<T>::store8(dx + row * lddx + c, o);
+        }
     }
-    float* out = part + (sample * gridDim.x + blockIdx.x) * 2 * (int64_t)D;
-    for (int e = threadIdx.x; e < 2 * D; e += 256) out[e] = red[e];
+    if (in) {
+        float* out = part + (sample * gridDim.x + blockIdx.x) * 2 * (int64_t)D;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { out[c + k] = pd[k]; out[D + c + k] = px[k]; }
+    }
 }
 
 // One wave per (row, head) vector of DH elements (lane l: pairs l, l + 64 < DH / 2), a grid-stride loop over the vectors: forward was u = x rs,
@@ -553,21 +538,14 @@ int adaln_bwd_impl(const void* x, int64_t ldx, const void* dy, int64_t lddy, con
     if (rows == 0) return UG_OK;
     UG_REQUIRE(x && dy && scale && dx && part && rows > 0 && D > 0 && rows_per_sample > 0 && rows % rows_per_sample == 0 && ldx >= D && lddy >= D && lddx >= D &&
                mod_ld >= D && rows / rows_per_sample < 65536, UG_ERR_BAD_SHAPE, "ug_adaln_modulate_bwd: bad arguments");
-    constexpr int EA = ElemT<T>::kF32 ? 16 : 16;
+    constexpr int EA = 16;
     UG_REQUIRE(D % 8 == 0 && D <= 4096 && ldx % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0 && mod_ld % 8 == 0 && ug_aligned(x, EA) && ug_aligned(dy, EA) &&
                ug_aligned(dx, EA) && ug_aligned(scale, EA) && ug_aligned(part, 4), UG_ERR_BAD_ALIGN,
                "ug_adaln_modulate_bwd: D <= 4096, D and leading dimensions multiples of 8, 16-byte aligned bases");
     const dim3 grid((unsigned)ug_adaln_modulate_bwd_partials(rows, rows_per_sample), (unsigned)(rows / rows_per_sample));
-    const size_t lds = 2 * (size_t)D * sizeof(float);
-#define UG_ADALN_BWD(NCV)                                                                                                                         \
-    hipLaunchKernelGGL((adaln_bwd_kernel<T, NCV>), grid, dim3(256), lds, (hipStream_t)stream, (const T*)x, ldx, (const T*)dy, lddy, (const T*)scale, mod_ld, \
-                       rows_per_sample, (T*)dx, lddx, (float*)part, (int)D, eps)
-    const int nc = (int)((D + 511) / 512);
-    switch (nc) {
-        case 1: UG_ADALN_BWD(1); break; case 2: UG_ADALN_BWD(2); break; case 3: UG_ADALN_BWD(3); break; case 4: UG_ADALN_BWD(4); break;
-        case 5: case 6: UG_ADALN_BWD(6); break; default: UG_ADALN_BWD(8); break;
-    }
-#undef UG_ADALN_BWD
+    const int waves = (int)((D + 511) / 512);                      // <= 8: D <= 4096
+    hipLaunchKernelGGL(adaln_bwd_kernel<T>, grid, dim3(64 * waves), 0, (hipStream_t)stream, (const T*)x, ldx, (const T*)dy, lddy, (const T*)scale, mod_ld,
+                       rows_per_sample, (T*)dx, lddx, (float*)part, (int)D, eps);
     UG_CHECK_LAUNCH("ug_adaln_modulate_bwd");
     return UG_OK;
 }
