@@ -250,6 +250,22 @@ def test_qk_rmsnorm_rope_bwd_paths_agree(gpu, dh, H):
             assert rel(dx, xt.grad) < tol and rel(dw, wt.grad) < tol, (dh, dt, pad, rel(dx, xt.grad), rel(dw, wt.grad))
 
 
+@pytest.mark.parametrize("rows,rps,D", [(70000, 1, 64), (3 * 333, 333, 1536), (2 * 100, 100, 520)])
+def test_adaln_modulate_bwd_direct(gpu, rows, rps, D):
+    """ug_adaln_modulate_bwd against fp32 torch autograd: per-token modulation with more samples than a grid dimension holds, ragged row chunks,
+    a width that is not a multiple of 512."""
+    from unigen_amd import ops
+    g = torch.Generator().manual_seed(rows + D)
+    x, dy = torch.randn(rows, D, generator=g), torch.randn(rows, D, generator=g)
+    sc = torch.randn(rows // rps, D, generator=g) * 0.3
+    xt, st = x.clone().requires_grad_(True), sc.clone().requires_grad_(True)
+    sh = torch.zeros(rows // rps, D, requires_grad=True)
+    y = F.layer_norm(xt, (D,), eps=1e-6).view(-1, rps, D) * (1 + st[:, None]) + sh[:, None]
+    y.reshape(rows, D).backward(dy)
+    dx, dshift, dscale = ops.adaln_modulate_bwd(x.to(gpu), dy.to(gpu), sc.to(gpu), rows_per_sample=rps)
+    assert rel(dx, xt.grad) < 1e-5 and rel(dshift, sh.grad) < 1e-5 and rel(dscale, st.grad) < 1e-5, (rel(dx, xt.grad), rel(dshift, sh.grad), rel(dscale, st.grad))
+
+
 def test_gate_residual_backward(gpu):
     from unigen_amd import autograd as A
     g = torch.Generator().manual_seed(6)

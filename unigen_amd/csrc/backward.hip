@@ -192,10 +192,11 @@ __global__ void gelu_bwd_kernel(const T* __restrict__ x, const T* __restrict__ d
 template <typename T>
 __global__ __launch_bounds__(512) void adaln_bwd_kernel(const T* __restrict__ x, int64_t ldx, const T* __restrict__ dy, int64_t lddy,
                                                         const T* __restrict__ scale, int64_t mod_ld, int64_t rows_per_sample, T* __restrict__ dx,
-                                                        int64_t lddx, float* __restrict__ part /* [samples][gridDim.x][2][D] */, int D, float eps) {
+                                                        int64_t lddx, float* __restrict__ part /* [samples][gridDim.x][2][D] */, int D, float eps,
+                                                        int64_t samples) {
     __shared__ float slot[2][4][8];                                  // [row parity][s1, s2, a, b][wave]
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, W = blockDim.x >> 6;
-    const int64_t sample = blockIdx.y;
+    for (int64_t sample = blockIdx.y; sample < samples; sample += gridDim.y) {        // gridDim.y = min(samples, 65535)
     const int64_t chunk = (rows_per_sample + gridDim.x - 1) / gridDim.x;
     const int64_t r_lo = (int64_t)blockIdx.x * chunk, r_hi = r_lo + chunk < rows_per_sample ? r_lo + chunk : rows_per_sample;
     const int c = 8 * (lane + 64 * wv);
@@ -252,6 +253,8 @@ __global__ __launch_bounds__(512) void adaln_bwd_kernel(const T* __restrict__ x,
         float* out = part + (sample * gridDim.x + blockIdx.x) * 2 * (int64_t)D;
 #pragma unroll
         for (int k = 0; k < 8; ++k) { out[c + k] = pd[k]; out[D + c + k] = px[k]; }
+    }
+    __syncthreads();                                                  // the slots are reused by the block's next sample
     }
 }
 
@@ -537,15 +540,16 @@ int adaln_bwd_impl(const void* x, int64_t ldx, const void* dy, int64_t lddy, con
                    int64_t lddx, void* part, int64_t rows, int64_t D, float eps, ug_stream_t stream) {
     if (rows == 0) return UG_OK;
     UG_REQUIRE(x && dy && scale && dx && part && rows > 0 && D > 0 && rows_per_sample > 0 && rows % rows_per_sample == 0 && ldx >= D && lddy >= D && lddx >= D &&
-               mod_ld >= D && rows / rows_per_sample < 65536, UG_ERR_BAD_SHAPE, "ug_adaln_modulate_bwd: bad arguments");
+               mod_ld >= D, UG_ERR_BAD_SHAPE, "ug_adaln_modulate_bwd: bad arguments");
     constexpr int EA = 16;
     UG_REQUIRE(D % 8 == 0 && D <= 4096 && ldx % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0 && mod_ld % 8 == 0 && ug_aligned(x, EA) && ug_aligned(dy, EA) &&
                ug_aligned(dx, EA) && ug_aligned(scale, EA) && ug_aligned(part, 4), UG_ERR_BAD_ALIGN,
                "ug_adaln_modulate_bwd: D <= 4096, D and leading dimensions multiples of 8, 16-byte aligned bases");
-    const dim3 grid((unsigned)ug_adaln_modulate_bwd_partials(rows, rows_per_sample), (unsigned)(rows / rows_per_sample));
+    const int64_t samples = rows / rows_per_sample;
+    const dim3 grid((unsigned)ug_adaln_modulate_bwd_partials(rows, rows_per_sample), (unsigned)(samples < 65535 ? samples : 65535));
     const int waves = (int)((D + 511) / 512);                      // <= 8: D <= 4096
     hipLaunchKernelGGL(adaln_bwd_kernel<T>, grid, dim3(64 * waves), 0, (hipStream_t)stream, (const T*)x, ldx, (const T*)dy, lddy, (const T*)scale, mod_ld,
-                       rows_per_sample, (T*)dx, lddx, (float*)part, (int)D, eps);
+                       rows_per_sample, (T*)dx, lddx, (float*)part, (int)D, eps, samples);
     UG_CHECK_LAUNCH("ug_adaln_modulate_bwd");
     return UG_OK;
 }
