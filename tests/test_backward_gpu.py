@@ -266,6 +266,39 @@ def test_adaln_modulate_bwd_direct(gpu, rows, rps, D):
     assert rel(dx, xt.grad) < 1e-5 and rel(dshift, sh.grad) < 1e-5 and rel(dscale, st.grad) < 1e-5, (rel(dx, xt.grad), rel(dshift, sh.grad), rel(dscale, st.grad))
 
 
+def test_backward_kernels_run_to_run_bitwise(gpu):
+    """No atomics anywhere in the backward: the attention backward, the q/k-norm and AdaLN backward (fixed assignment of rows to partial sums), colsum
+    and the weight-gradient route return identical bits on repeated calls with the same inputs."""
+    from unigen_amd import ops
+    from unigen_amd import autograd as A
+    g = torch.Generator().manual_seed(3)
+    B, L, H, dh = 2, 1000, 4, 128
+    D = H * dh
+    q, k, v, do = (torch.randn(B, L, D, generator=g).to(BF).to(gpu) for _ in range(4))
+    o = torch.empty_like(q)
+    lse = torch.zeros(B, H, (L + 63) // 64 * 64, device=gpu, dtype=torch.float32)
+    ops.flash_attn(q, k, v, o, batches=B, heads=H, dh=dh, Lq=L, Lkv=L, lse=lse, q_strides=(D, L * D), k_strides=(D, L * D), v_strides=(D, L * D), o_strides=(D, L * D))
+    x2, dy2 = q.reshape(B * L, D), do.reshape(B * L, D)
+    w = torch.randn(dh, generator=g).to(BF).to(gpu)
+    cos, sin = torch.randn(L, dh, generator=g).to(gpu), torch.randn(L, dh, generator=g).to(gpu)
+    sc = torch.randn(B, D, generator=g).to(BF).to(gpu)
+    wlin = (torch.randn(256, D, generator=g) * 0.05).to(BF).to(gpu)
+
+    def once():
+        out = list(ops.flash_attn_bwd(q, k, v, o, do, heads=H, lse=lse))
+        out += list(ops.qk_rmsnorm_rope_bwd(x2, dy2, w, cos, sin, rows_per_batch=L, pos_offset=0, heads=H, dh=dh))
+        out += list(ops.adaln_modulate_bwd(x2, dy2, sc, rows_per_sample=L))
+        out.append(ops.colsum(dy2))
+        xin = x2.clone().requires_grad_(True); wl = wlin.clone().requires_grad_(True)
+        A.linear(xin, wl, None).backward(dy2[:, :256].contiguous())
+        out += [xin.grad, wl.grad]
+        return out
+
+    first, second = once(), once()
+    for i, (a, b) in enumerate(zip(first, second)):
+        assert torch.equal(a, b), f"output {i} differs between two identical calls"
+
+
 def test_gate_residual_backward(gpu):
     from unigen_amd import autograd as A
     g = torch.Generator().manual_seed(6)
