@@ -6,9 +6,9 @@ from collections import defaultdict
 
 
 def classify(n):
-    for key, c in (("attn_bwd_kernel<128, 0>", "attn_bwd_lse"), ("attn_bwd_kernel<128, 1>", "attn_bwd_dq"), ("attn_bwd_kernel<128, 2>", "attn_bwd_dk"),
-                   ("attn_bwd_kernel<128, 3>", "attn_bwd_dv"), ("flash_attn_kernel", "attn_fwd"), ("gemm256_kernel", "gemm256"), ("gemm128_kernel", "gemm128"),
-                   ("transpose_kernel", "transpose"), ("colsum", "colsum")):
+    for key, c in (("attn_bwd_kernel<128, 0", "attn_bwd_lse"), ("attn_bwd_kernel<128, 1", "attn_bwd_dq"), ("attn_bwd_kernel<128, 2", "attn_bwd_dk"),
+                   ("attn_bwd_kernel<128, 3", "attn_bwd_dv"), ("flash_attn_kernel", "attn_fwd"), ("gemm256_kernel", "gemm256"), ("gemm128_kernel", "gemm128"),
+                   ("transpose", "transpose"), ("colsum", "colsum")):
         if key in n:
             return c
     return None
