@@ -13,6 +13,7 @@ ap.add_argument("--size", type=int, default=1024)
 ap.add_argument("--ckpt", action="store_true")
 ap.add_argument("--layers", type=int, nargs=2, default=None)
 ap.add_argument("--steps", type=int, default=3)
+ap.add_argument("--shapes", action="store_true", help="per-shape table of the last step's GEMM / attention launches (grouped by FLOPs per launch)")
 a = ap.parse_args()
 dev, BF = torch.device("cuda:0"), torch.bfloat16
 cfg = {} if a.layers is None else {"num_layers": a.layers[0], "num_single_layers": a.layers[1]}
@@ -60,3 +61,14 @@ fw, bw = min(x[0] for x in times), min(x[1] for x in times)
 print("TRAIN_BENCH", json.dumps(dict(batch=B, size=a.size, layers=[model.config.num_layers, model.config.num_single_layers], checkpointing=bool(a.ckpt),
       params_total=n_all, params_trainable=n_train, forward_s=round(fw, 3), backward_s=round(bw, 3), samples_per_s=round(B / (fw + bw), 3),
       peak_mem_gb=round(torch.cuda.max_memory_allocated() / 2 ** 30, 1), kernel_rates=rates)))
+
+if a.shapes:
+    import collections
+    groups = collections.defaultdict(list)
+    for kind, flops, e0, e1 in timer.records:
+        groups[(kind, round(flops / 1e9))].append(e0.elapsed_time(e1))
+    tot = sum(sum(v) for v in groups.values())
+    print(f"{'kind':9s} {'GFLOP/launch':>13s} {'launches':>8s} {'avg us':>9s} {'TFLOP/s':>9s} {'share':>7s}")
+    for (kind, gf), v in sorted(groups.items(), key=lambda kv: -sum(kv[1]))[:40]:
+        avg = sum(v) / len(v)
+        print(f"{kind:9s} {gf:13d} {len(v):8d} {avg * 1e3:9.1f} {gf / max(avg, 1e-9):9.1f} {sum(v) / tot:7.1%}")
