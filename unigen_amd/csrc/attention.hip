@@ -526,12 +526,14 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn_kernel(
         auto tile = [&](int t, auto cur_c) {
             // Y(t): A in odd segment 2t+1 (publishes K(t+1), V(t) at its end) | B in even segment 2t+2 (fetches K(t+2), V(t+1) at its start)
             if (!groupA) { if constexpr (DMA) dma_fetch(t + 2, t + 1); else fetch(t + 2, t + 1); }
+            if constexpr (PRIO == 3) __builtin_amdgcn_s_setprio(1);                  // the softmax segment outranks the partner's matrix stream at issue
             do_SM();
             // P^T is "used" here: hipcc otherwise sinks the (pure) scale / exp2 / pack chain across the barrier to its first use, the
             // P.V MFMAs - i.e. out of this VALU-only segment into the matrix-only one, which then ran at ~60 cycles per MFMA
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) { asm volatile("" : "+v"(pf[kb][0])); asm volatile("" : "+v"(pf[kb][1])); }
             asm volatile("" : "+v"(l_run), "+v"(m_run));
+            if constexpr (PRIO == 3) __builtin_amdgcn_s_setprio(0);
             // group A publishes K(t+1), V(t) and at once re-fills the staging registers with K(t+2), V(t+1): its VALU segment has slack
             // (the partner's matrix segment is longer), whereas a fetch at the head of its own X(t) delayed the first MFMA
             if constexpr (!DMA) { if (groupA) { publish(t + 1, t); fetch(t + 2, t + 1); } }
@@ -1326,16 +1328,20 @@ static int flash_attn_fwd_impl(const void* q, int64_t q_row_stride, int64_t q_ba
     // 1068 vs 1044 (8192), 956 vs 933 (B16, 2048); dh = 64 inside the SD3.5 forward: 795 vs 775.
     if (stagger < 0) { const char* e = getenv("UG_ATTN_STAGGER"); stagger = (e && atoi(e) == 0) ? 0 : 1; }
     const bool stg = stagger == 1;
-    // UG_ATTN_PRIO = 0 | 1 | 2, UG_ATTN_WIDE = 0 | 1: A/B switches of the stagger kernel (re-read per call when UG_ENV_DYNAMIC=1)
+    // UG_ATTN_PRIO = 0 | 1 | 2 | 3, UG_ATTN_WIDE = 0 | 1: A/B switches of the stagger kernel (re-read per call when UG_ENV_DYNAMIC=1)
     // Interleaved A/B, round 2 (tools/attn_ab.py, same process): prio 0 + wide stores is the fastest form everywhere - dh 128: 1137 / 1147 / 1178
     // vs 1124 / 1133 / 1172 TFLOP/s for the round-1 default (prio 1, narrow) at 4608^2 / 4096x4608 / 8192x8704; dh 64: 880-885 vs 856-871; the
     // static young-half priority (2) loses 1-2 % at dh 128.
-    const int prio = ug_env_int("UG_ATTN_PRIO", 0), wide = ug_env_int("UG_ATTN_WIDE", 1), dma = ug_env_int("UG_ATTN_DMA", 1);
+    // UG_ATTN_PRIO = 3 (DMA variant): s_setprio 1 around the softmax segment - it is the longer one of each segment pair (loop ablations,
+    // profiles/r02f_attn_bwd.log). Interleaved A/B, 12 of 12 pairs: +0.3-0.5 % at dh 128 (1137 -> 1141, 1153 -> 1158, 1185 -> 1191 TFLOP/s);
+    // dh 64: -0.5 % (within noise) -> default 3 at dh 128, 0 at dh 64.
+    const int prio = ug_env_int("UG_ATTN_PRIO", dh == 128 ? 3 : 0), wide = ug_env_int("UG_ATTN_WIDE", 1), dma = ug_env_int("UG_ATTN_DMA", 1);
 #define UG_ATTN_STG(DHV)                                                                          \
     do {                                                                                          \
+        if (dma && prio == 3) { UG_ATTN_LAUNCH(DHV, 8, true, 3, true, true); break; }             \
         if (dma) { UG_ATTN_LAUNCH(DHV, 8, true, 0, true, true); break; }                          \
-        if (wide) { if (prio == 0) UG_ATTN_LAUNCH(DHV, 8, true, 0, true); else if (prio == 2) UG_ATTN_LAUNCH(DHV, 8, true, 2, true); else UG_ATTN_LAUNCH(DHV, 8, true, 1, true); } \
-        else { if (prio == 0) UG_ATTN_LAUNCH(DHV, 8, true, 0, false); else if (prio == 2) UG_ATTN_LAUNCH(DHV, 8, true, 2, false); else UG_ATTN_LAUNCH(DHV, 8, true, 1, false); } \
+        if (wide) { if (prio == 0 || prio == 3) UG_ATTN_LAUNCH(DHV, 8, true, 0, true); else if (prio == 2) UG_ATTN_LAUNCH(DHV, 8, true, 2, true); else UG_ATTN_LAUNCH(DHV, 8, true, 1, true); } \
+        else { if (prio == 0 || prio == 3) UG_ATTN_LAUNCH(DHV, 8, true, 0, false); else if (prio == 2) UG_ATTN_LAUNCH(DHV, 8, true, 2, false); else UG_ATTN_LAUNCH(DHV, 8, true, 1, false); } \
     } while (0)
     if (dh == 128) { if (nw == 4) UG_ATTN_LAUNCH(128, 4, false); else if (stg) UG_ATTN_STG(128); else UG_ATTN_LAUNCH(128, 8, false); }
     else           { if (nw == 4) UG_ATTN_LAUNCH(64, 4, false); else if (stg) UG_ATTN_STG(64); else UG_ATTN_LAUNCH(64, 8, false); }
