@@ -294,6 +294,9 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn_kernel(
         // instructions behind each of its first 8 P.V MFMAs: -8 % / -4 % at dh 128, -10 % / -7 % at dh 64. Ablations of the same day (tools/attn_ab.py
         // on diagnostic builds): without the K/V DMAs +7-10 %, without this softmax +18 % (+37 % at dh 64), without both +28 % (+53 %): the matrix
         // segments alone take 78 % of the loop's time at dh 128, and VALU work moved into them costs more than it saves here.)
+        // (Measured and dropped: the row sum from the packed bf16 probabilities, two per v_dot2c_f32_bf16: -3.5 % at dh 128. Considered and
+        // rejected on accuracy: Q pre-multiplied by scale * log2(e) in bf16 with the accumulators initialised to -m (no fma per score): the
+        // attention error against fp32 grows from 1.6e-3 to 2.3e-3, 4x on peaked rows.)
         // (Measured and dropped, same box: the scale / shift and the row sums two elements per instruction, v_pk_fma_f32 / v_pk_add_f32 -
         // 5 % SLOWER at dh 128 (1086 vs 1146, 1118 vs 1179 TFLOP/s), +1 % at dh 64: the packed forms buy no issue cycles here.)
 #pragma unroll
