@@ -324,6 +324,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
         // 17 us apart for the whole launch (verified with per-CU stamps) gains nothing; not the line pattern either: 8 rows x 128 B per
         // store instruction instead of 16 x 64 B, or the two half-lines back to back, time the same. What is left is the drain time of the
         // stores on the in-order VM counter beyond the ~1.9 K-tiles of slack below.)
+        // (Measured and dropped, end of round 2 (profiles/r02g_gemm_rim.log): a reads-in-M schedule - every sub-tile's fragments read by the
+        // wave that uses them BETWEEN the MFMAs of the matrix segment one phase earlier (rotating into fragment registers whose last use
+        // was just issued, waits and DMA issues shifted one phase, L segments left with the DMA issue only): bit-identical, all GEMM tests
+        // green, -1...+1 % on every cfg2 shape with or without forced interleaving. Loop ablations of the same day, 8192^3: without the
+        // ds_reads 1518 -> 1732 TFLOP/s, without the MFMAs 2747, without both 3149 (DMA issue + 8 barriers per K-tile alone: 48 % of the
+        // loop's time): the fragment reads cost their ~14 % wherever they are issued - operand delivery, not segment placement.)
         // (Measured and dropped: signalling the hand-off barrier 2-4 MFMAs before the end of a segment, so that the other group is
         // released while this one still has MFMAs queued: -9 % - the two groups' MFMAs then share the pipe, matrix beside matrix.)
         // (Measured and dropped: 2 segments of 32 MFMAs per K-tile and wave group with all DMA issued by waves 4-7 - 4 barriers per
