@@ -75,6 +75,11 @@ def test_error_codes_without_gpu_compute():
     assert cdll.ug_flash_attn_fwd_lse(16, 128, 1024, 16, 128, 1024, 16, 128, 1024, 16, 128, 1024, 1, 1, 8, 8, 128, 1.0, 16, 4, None) == lib.UG_ERR_BAD_SHAPE   # lse_ld < Lq
     assert cdll.ug_flash_attn_bwd_workspace_bytes(2, 24, 4608) == 2 * 2 * 24 * 4608 * 4
     assert cdll.ug_gelu_tanh_bwd_f32(None, 16, 16, 8, None) == lib.UG_ERR_BAD_SHAPE
+    assert cdll.ug_qk_rmsnorm_rope_bwd_partials(9216, 24) == 2048 and cdll.ug_qk_rmsnorm_rope_bwd_partials(3, 2) == 2      # capped / one block per 4 vectors
+    assert cdll.ug_adaln_modulate_bwd_partials(9216, 4608) == 512 and cdll.ug_adaln_modulate_bwd_partials(70000, 1) == 1 and cdll.ug_adaln_modulate_bwd_partials(20, 10) == 3
+    assert cdll.ug_adaln_modulate_bwd(16, 64, 16, 64, 16, 64, 4, 16, 64, None, 8, 64, 1e-6, None) == lib.UG_ERR_BAD_SHAPE                 # no partials buffer
+    assert cdll.ug_adaln_modulate_bwd(16, 8192, 16, 8192, 16, 8192, 4, 16, 8192, 16, 8, 8192, 1e-6, None) == lib.UG_ERR_BAD_ALIGN and b"4096" in cdll.ug_last_error()
+    assert cdll.ug_qk_rmsnorm_rope_bwd(16, 1024, 16, 1024, 16, 1024, 16, 16, None, None, 4, 4, 0, 1, 1024, 1e-6, None) == lib.UG_ERR_UNSUPPORTED   # head width > 256
 
 
 def test_no_cpu_fallback():
