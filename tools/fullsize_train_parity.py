@@ -5,36 +5,53 @@ control modules) on the same weights, inputs, RTS draw and target:
   hip_f32 = the HIP training path (unigen_amd/training.py + autograd.py) through the fp32 verification twins
   hip_bf16 = the HIP product path (bf16 parameters)
 Too heavy for the test suite (75 GB of fp32 parameters on both sides, minutes of CPU time); run it as a tool and keep the line under profiles/.
-usage: python tools/fullsize_train_parity.py [--layers 19 38]"""
+usage: python tools/fullsize_train_parity.py [--layers 19 38] | --sd3 (UniGenSD3 at SD3.5-medium depth and width, N = 1024, T = 333)"""
 import argparse, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from oracle import unigen_ref as R
 from unigen_amd.flux import UniGenFlux
+from unigen_amd.sd3 import UniGenSD3
 
-ap = argparse.ArgumentParser(); ap.add_argument("--layers", type=int, nargs=2, default=None); a = ap.parse_args()
+ap = argparse.ArgumentParser(); ap.add_argument("--layers", type=int, nargs=2, default=None); ap.add_argument("--sd3", action="store_true"); a = ap.parse_args()
 torch.set_num_threads(min(16, os.cpu_count() or 16))
 dev, BF = torch.device("cuda:0"), torch.bfloat16
-CTL = dict(use_rope=True, use_shared_expert=True, use_consis_module=False, use_single_trans_blocks=True, single_control_dev=2,
-           single_block_control_method="overall_add", top_num=1, expert_num_each_condition=3)
-over = dict(num_layers=a.layers[0], num_single_layers=a.layers[1]) if a.layers else {}
-cfg = R.FluxConfig(**over)
-inp = R.make_inputs(cfg, B=1, grid=32, T=512)
-t = torch.full((1,), 0.75, dtype=BF)
-target = torch.randn(1, 1024, 64, generator=torch.Generator().manual_seed(5))
-res = dict(workload=f"one training step, {cfg.num_layers} + {cfg.num_single_layers} base blocks and their control blocks at full width, 512^2 (N=1024, T=512), B=1")
+if a.sd3:
+    Model, oracle_forward, over = UniGenSD3, R.unigen_sd3_forward, {}
+    CTL, COND = dict(use_shared_expert=True, use_modulate=False), ["depth"]
+    cfg = R.SD3Config()
+    inp = R.make_sd3_inputs(cfg, B=1, hw=64, T=333)
+    t = torch.full((1,), 600.0)
+    res = dict(workload="one training step of UniGenSD3 at SD3.5-medium depth and width (24 joint blocks, dual attention 0-12, transformer-block experts), N=1024, T=333, B=1")
+else:
+    Model, oracle_forward = UniGenFlux, R.unigen_flux_forward
+    CTL = dict(use_rope=True, use_shared_expert=True, use_consis_module=False, use_single_trans_blocks=True, single_control_dev=2,
+               single_block_control_method="overall_add", top_num=1, expert_num_each_condition=3)
+    COND = ["canny"]
+    over = dict(num_layers=a.layers[0], num_single_layers=a.layers[1]) if a.layers else {}
+    cfg = R.FluxConfig(**over)
+    inp = R.make_inputs(cfg, B=1, grid=32, T=512)
+    t = torch.full((1,), 0.75, dtype=BF)
+    res = dict(workload=f"one training step, {cfg.num_layers} + {cfg.num_single_layers} base blocks and their control blocks at full width, 512^2 (N=1024, T=512), B=1")
+_target = {}
+
+
+def target_like(out):
+    if "t" not in _target:
+        _target["t"] = torch.randn(tuple(out.shape), generator=torch.Generator().manual_seed(5))
+    return _target["t"]
 
 
 def step(fwd):
     out, losses, _ = fwd()
-    loss = ((out.float() - target.to(out.device).float()) ** 2).reshape(out.shape[0], -1).mean(1).mean() + losses["moe_loss"]
+    loss = ((out.float() - target_like(out).to(out.device).float()) ** 2).reshape(out.shape[0], -1).mean(1).mean() + losses["moe_loss"]
     loss.backward()
     return float(loss)
 
 
 def build(dtype, state=None):
-    m = UniGenFlux.from_config(dict(over), device=dev, dtype=dtype)
-    m.init_condition_block(condition_nums=1, condition_types=["canny"], control_params=dict(CTL))
+    m = Model.from_config(dict(over), device=dev, dtype=dtype)
+    m.init_condition_block(condition_nums=1, condition_types=list(COND), control_params=dict(CTL))
     if state is None:
         m.init_synthetic_(seed=0, std=0.02)
     else:
@@ -75,7 +92,7 @@ del m0
 torch.cuda.empty_cache()
 st = {k: (v.float().clone().requires_grad_(True) if k in names else (v.float() if v.is_floating_point() else v)) for k, v in state.items()}
 t0 = time.perf_counter()
-loss_t = step(lambda: R.unigen_flux_forward(st, cfg, timestep=t, dtype=torch.float32, **inp))
+loss_t = step(lambda: oracle_forward(st, cfg, timestep=t, dtype=torch.float32, **inp))
 res["oracle_f32_s"] = round(time.perf_counter() - t0, 1)
 truth = {k: st[k].grad for k in names}
 truth_shape = {k: tuple(st[k].shape) for k in names}
