@@ -14,6 +14,7 @@ from unigen_amd.sd3 import UniGenSD3
 torch.set_num_threads(min(16, os.cpu_count() or 16))
 dev, BF = torch.device("cuda:0"), torch.bfloat16
 SD3 = len(sys.argv) > 1 and sys.argv[1] == "sd3"        # UniGenSD3 (SD3.5-medium: 24 joint blocks, dual attention 0-12, D = 1536, dh = 64), N = 1024, T = 333
+MULTI = len(sys.argv) > 1 and sys.argv[1] == "multi"    # MultiCondtionUniGenFlux, depth + canny + openpose (cfg3's model: E = 12), N = 1024, T = 512
 if SD3:
     Model, CTL = UniGenSD3, dict(use_shared_expert=True, use_modulate=False)
     cfg = R.SD3Config()
@@ -21,39 +22,42 @@ if SD3:
     t = torch.full((1,), 600.0)
     oracle = R.unigen_sd3_forward
 else:
-    Model = UniGenFlux
+    from unigen_amd.flux import MultiCondtionUniGenFlux
+    Model = MultiCondtionUniGenFlux if MULTI else UniGenFlux
     CTL = dict(use_rope=True, use_shared_expert=True, use_consis_module=False, use_single_trans_blocks=True, single_control_dev=2,
                single_block_control_method="overall_add", top_num=1, expert_num_each_condition=3)
-    cfg = R.FluxConfig()
-    inp = R.make_inputs(cfg, B=1, grid=32, T=512)
+    cfg = R.FluxConfig(condition_nums=3) if MULTI else R.FluxConfig()
+    inp = R.make_inputs(cfg, B=1, grid=32, T=512, n_cond=3 if MULTI else 1)
     t = torch.full((1,), 0.75, dtype=BF)
     oracle = R.unigen_flux_forward
 UniGenFlux = Model
 R_forward = oracle
 m16 = Model.from_config({}, device=dev, dtype=BF)
-m16.init_condition_block(condition_nums=1, condition_types=["canny"], control_params=dict(CTL))
+NC, CT = (3, ["depth", "canny", "openpose"]) if MULTI else (1, ["canny"])
+m16.init_condition_block(condition_nums=NC, condition_types=list(CT), control_params=dict(CTL))
 m16.init_synthetic_(seed=0, std=0.02)
 rel = lambda a, b: float((a.double().cpu() - b.double().cpu()).norm() / b.double().cpu().norm())
 res = {}
 with torch.no_grad():
-    out16 = m16(timestep=t.to(dev), **{k: v.to(dev) for k, v in inp.items()})[0].float().cpu()
+    mv = lambda v, f=None: [mv(x, f) for x in v] if isinstance(v, (list, tuple)) else (v.to(dev) if f is None or not v.is_floating_point() else v.to(dev).to(f))
+    out16 = m16(timestep=t.to(dev), **{k: mv(v) for k, v in inp.items()})[0].float().cpu()
     st16 = {k: v.detach().cpu() for k, v in m16.state_dict().items()}
     sd16 = dict(m16.state_dict())
     t0 = time.perf_counter(); ref16 = R_forward(st16, cfg, timestep=t, dtype=BF, **inp)[0].float(); res["oracle_bf16_s"] = round(time.perf_counter() - t0, 1)
     print("bf16 done", res, flush=True)
     m32 = UniGenFlux.from_config({}, device=dev, dtype=torch.float32)
-    m32.init_condition_block(condition_nums=1, condition_types=["canny"], control_params=dict(CTL))
+    m32.init_condition_block(condition_nums=NC, condition_types=list(CT), control_params=dict(CTL))
     m32.load_state_dict({k: (v.float() if v.is_floating_point() else v) for k, v in sd16.items()})
     del m16, sd16
     torch.cuda.empty_cache()
     t0 = time.perf_counter()
-    out32 = m32(timestep=t.to(dev), **{k: (v.to(dev).float() if (v.is_floating_point() and k != "gate_uniform") else v.to(dev)) for k, v in inp.items()})[0].cpu()
+    out32 = m32(timestep=t.to(dev), **{k: (mv(v) if k == "gate_uniform" else mv(v, torch.float32)) for k, v in inp.items()})[0].cpu()
     torch.cuda.synchronize(); res["hip_f32_s"] = round(time.perf_counter() - t0, 1)
     del m32
     st32 = {k: (v.float() if v.is_floating_point() else v) for k, v in st16.items()}
     del st16
     print("hip f32 done", res, flush=True)
     t0 = time.perf_counter(); truth = R_forward(st32, cfg, timestep=t, dtype=torch.float32, **inp)[0]; res["oracle_f32_s"] = round(time.perf_counter() - t0, 1)
-res.update(workload=("UniGenSD3, SD3.5-medium depth and width, N=1024, T=333, B=1" if SD3 else "one forward at full depth and width, 512^2 (N=1024, T=512), B=1"), rel_l2_hip_f32_vs_oracle_f32=rel(out32, truth),
+res.update(workload=("UniGenSD3, SD3.5-medium depth and width, N=1024, T=333, B=1" if SD3 else ("MultiCondtionUniGenFlux (3 conditions, E = 12), " if MULTI else "") + "one forward at full depth and width, 512^2 (N=1024, T=512), B=1"), rel_l2_hip_f32_vs_oracle_f32=rel(out32, truth),
            rel_l2_hip_bf16_vs_oracle_f32=rel(out16, truth), rel_l2_oracle_bf16_vs_oracle_f32=rel(ref16, truth), rel_l2_hip_bf16_vs_oracle_bf16=rel(out16, ref16))
 print("FULLSIZE_PARITY", json.dumps(res))
