@@ -27,7 +27,8 @@ else:
     CTL = dict(use_rope=True, use_shared_expert=True, use_consis_module=False, use_single_trans_blocks=True, single_control_dev=2,
                single_block_control_method="overall_add", top_num=1, expert_num_each_condition=3)
     cfg = R.FluxConfig(condition_nums=3) if MULTI else R.FluxConfig()
-    inp = R.make_inputs(cfg, B=1, grid=32, T=512, n_cond=3 if MULTI else 1)
+    GRID = int(sys.argv[2]) if len(sys.argv) > 2 else 32            # 64: the metric's own size, 1024^2 (N = 4096)
+    inp = R.make_inputs(cfg, B=1, grid=GRID, T=512, n_cond=3 if MULTI else 1)
     t = torch.full((1,), 0.75, dtype=BF)
     oracle = R.unigen_flux_forward
 UniGenFlux = Model
@@ -58,6 +59,6 @@ with torch.no_grad():
     del st16
     print("hip f32 done", res, flush=True)
     t0 = time.perf_counter(); truth = R_forward(st32, cfg, timestep=t, dtype=torch.float32, **inp)[0]; res["oracle_f32_s"] = round(time.perf_counter() - t0, 1)
-res.update(workload=("UniGenSD3, SD3.5-medium depth and width, N=1024, T=333, B=1" if SD3 else ("MultiCondtionUniGenFlux (3 conditions, E = 12), " if MULTI else "") + "one forward at full depth and width, 512^2 (N=1024, T=512), B=1"), rel_l2_hip_f32_vs_oracle_f32=rel(out32, truth),
+res.update(workload=("UniGenSD3, SD3.5-medium depth and width, N=1024, T=333, B=1" if SD3 else ("MultiCondtionUniGenFlux (3 conditions, E = 12), " if MULTI else "") + f"one forward at full depth and width, {16 * GRID}^2 (N={GRID * GRID}, T=512), B=1"), rel_l2_hip_f32_vs_oracle_f32=rel(out32, truth),
            rel_l2_hip_bf16_vs_oracle_f32=rel(out16, truth), rel_l2_oracle_bf16_vs_oracle_f32=rel(ref16, truth), rel_l2_hip_bf16_vs_oracle_bf16=rel(out16, ref16))
 print("FULLSIZE_PARITY", json.dumps(res))
