@@ -13,28 +13,47 @@ ap.add_argument("--size", type=int, default=1024)
 ap.add_argument("--ckpt", action="store_true")
 ap.add_argument("--layers", type=int, nargs=2, default=None)
 ap.add_argument("--steps", type=int, default=3)
+ap.add_argument("--sd3", action="store_true", help="UniGenSD3 (SD3.5-medium geometry, depth control, transformer-block experts) instead of UniGenFlux")
 ap.add_argument("--shapes", action="store_true", help="per-shape table of the last step's GEMM / attention launches (grouped by FLOPs per launch)")
 a = ap.parse_args()
 dev, BF = torch.device("cuda:0"), torch.bfloat16
-cfg = {} if a.layers is None else {"num_layers": a.layers[0], "num_single_layers": a.layers[1]}
-model = UniGenFlux.from_config(cfg, device=dev, dtype=BF)
-model.init_condition_block(condition_nums=1, condition_types=["canny"], control_params=dict(
-    use_rope=True, use_shared_expert=True, use_consis_module=False, use_single_trans_blocks=True, single_control_dev=2,
-    single_block_control_method="overall_add", top_num=1, expert_num_each_condition=3))
-model.init_synthetic_(seed=0, std=0.02)
-model.init_trainable_param()
-if a.ckpt:
-    model.enable_gradient_checkpointing()
-B, grid, T = a.batch, a.size // 16, 512
-N = grid * grid
+B = a.batch
 g = torch.Generator(device=dev).manual_seed(5)
 rn = lambda *s: torch.randn(*s, generator=g, device=dev)
-inp = dict(hidden_states=rn(B, N, 64).to(BF), condition_hidden_states=rn(B, N, 64).to(BF), encoder_hidden_states=(0.1 * rn(B, T, 4096)).to(BF),
-           pooled_projections=rn(B, 768).to(BF), condition_pooled_projections=rn(B, 768).to(BF))
-ids = prepare_latent_image_ids(grid, grid, dev, BF)
-txt = torch.zeros(T, 3, device=dev, dtype=BF)
-t = torch.full((B,), 0.75, device=dev, dtype=BF)
-target = rn(B, N, 64)
+if a.sd3:
+    from oracle import unigen_ref as R          # input shapes only (make_sd3_inputs); the model under test is the HIP one
+    from unigen_amd.sd3 import UniGenSD3
+    model = UniGenSD3.from_config({}, device=dev, dtype=BF)
+    model.init_condition_block(condition_nums=1, condition_types=["depth"], control_params=dict(use_shared_expert=True, use_modulate=False))
+    model.init_synthetic_(seed=0, std=0.02)
+    model.init_trainable_param()
+    if a.ckpt:
+        model.enable_gradient_checkpointing()
+    hw = a.size // 8
+    raw = R.make_sd3_inputs(R.SD3Config(), B=B, hw=hw, T=333)
+    inp = {k: (v.to(dev).to(BF) if (v.is_floating_point() and k != "gate_uniform") else v.to(dev)) for k, v in raw.items()}
+    t = torch.full((B,), 600.0, device=dev)
+    fwd = lambda: model(timestep=t, **inp)
+    target = rn(B, 16, hw, hw)
+else:
+    cfg = {} if a.layers is None else {"num_layers": a.layers[0], "num_single_layers": a.layers[1]}
+    model = UniGenFlux.from_config(cfg, device=dev, dtype=BF)
+    model.init_condition_block(condition_nums=1, condition_types=["canny"], control_params=dict(
+        use_rope=True, use_shared_expert=True, use_consis_module=False, use_single_trans_blocks=True, single_control_dev=2,
+        single_block_control_method="overall_add", top_num=1, expert_num_each_condition=3))
+    model.init_synthetic_(seed=0, std=0.02)
+    model.init_trainable_param()
+    if a.ckpt:
+        model.enable_gradient_checkpointing()
+    grid, T = a.size // 16, 512
+    N = grid * grid
+    inp = dict(hidden_states=rn(B, N, 64).to(BF), condition_hidden_states=rn(B, N, 64).to(BF), encoder_hidden_states=(0.1 * rn(B, T, 4096)).to(BF),
+               pooled_projections=rn(B, 768).to(BF), condition_pooled_projections=rn(B, 768).to(BF))
+    ids = prepare_latent_image_ids(grid, grid, dev, BF)
+    txt = torch.zeros(T, 3, device=dev, dtype=BF)
+    t = torch.full((B,), 0.75, device=dev, dtype=BF)
+    fwd = lambda: model(timestep=t, img_ids=ids, txt_ids=txt, condition_ids=ids, **inp)
+    target = rn(B, N, 64)
 n_train = sum(p.numel() for p in model.parameters() if p.requires_grad)
 n_all = sum(p.numel() for p in model.parameters())
 from unigen_amd import ops
@@ -46,7 +65,7 @@ for step in range(a.steps + 1):
     for p in model.parameters():
         p.grad = None
     torch.cuda.synchronize(); t0 = time.time()
-    out, losses, _ = model(timestep=t, img_ids=ids, txt_ids=txt, condition_ids=ids, **inp)
+    out, losses, _ = fwd()
     torch.cuda.synchronize(); t1 = time.time()
     loss = ((out.float() - target) ** 2).reshape(B, -1).mean(1).mean() + losses["moe_loss"]
     loss.backward()
@@ -58,7 +77,7 @@ for step in range(a.steps + 1):
 ops.set_timer(None)
 rates = {k: dict(launches=v["launches"], ms=round(v["ms"], 1), tflops=round(v["flops"] / v["ms"] / 1e9, 1)) for k, v in timer.summary().items()}
 fw, bw = min(x[0] for x in times), min(x[1] for x in times)
-print("TRAIN_BENCH", json.dumps(dict(batch=B, size=a.size, layers=[model.config.num_layers, model.config.num_single_layers], checkpointing=bool(a.ckpt),
+print("TRAIN_BENCH", json.dumps(dict(model="UniGenSD3" if a.sd3 else "UniGenFlux", batch=B, size=a.size, layers=[model.config.num_layers, getattr(model.config, "num_single_layers", 0)], checkpointing=bool(a.ckpt),
       params_total=n_all, params_trainable=n_train, forward_s=round(fw, 3), backward_s=round(bw, 3), samples_per_s=round(B / (fw + bw), 3),
       peak_mem_gb=round(torch.cuda.max_memory_allocated() / 2 ** 30, 1), kernel_rates=rates)))
 
