@@ -21,7 +21,6 @@ B = a.batch
 g = torch.Generator(device=dev).manual_seed(5)
 rn = lambda *s: torch.randn(*s, generator=g, device=dev)
 if a.sd3:
-    from oracle import unigen_ref as R          # input shapes only (make_sd3_inputs); the model under test is the HIP one
     from unigen_amd.sd3 import UniGenSD3
     model = UniGenSD3.from_config({}, device=dev, dtype=BF)
     model.init_condition_block(condition_nums=1, condition_types=["depth"], control_params=dict(use_shared_expert=True, use_modulate=False))
@@ -30,8 +29,10 @@ if a.sd3:
     if a.ckpt:
         model.enable_gradient_checkpointing()
     hw = a.size // 8
-    raw = R.make_sd3_inputs(R.SD3Config(), B=B, hw=hw, T=333)
-    inp = {k: (v.to(dev).to(BF) if (v.is_floating_point() and k != "gate_uniform") else v.to(dev)) for k, v in raw.items()}
+    c = model.config
+    inp = dict(hidden_states=rn(B, c.in_channels, hw, hw).to(BF), condition_hidden_states=rn(B, c.in_channels, hw, hw).to(BF),
+               encoder_hidden_states=(0.1 * rn(B, 333, c.joint_attention_dim)).to(BF), pooled_projections=rn(B, c.pooled_projection_dim).to(BF),
+               condition_pooled_projections=rn(B, c.pooled_projection_dim).to(BF))
     t = torch.full((B,), 600.0, device=dev)
     fwd = lambda: model(timestep=t, **inp)
     target = rn(B, 16, hw, hw)
