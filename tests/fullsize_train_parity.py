@@ -5,7 +5,7 @@ control modules) on the same weights, inputs, RTS draw and target:
   hip_f32 = the HIP training path (unigen_amd/training.py + autograd.py) through the fp32 verification twins
   hip_bf16 = the HIP product path (bf16 parameters)
 Too heavy for the test suite (75 GB of fp32 parameters on both sides, minutes of CPU time); run it as a tool and keep the line under profiles/.
-usage: python tools/fullsize_train_parity.py [--layers 19 38] | --sd3 (UniGenSD3 at SD3.5-medium depth and width, N = 1024, T = 333)"""
+usage: python tests/fullsize_train_parity.py [--layers 19 38] | --sd3 (UniGenSD3 at SD3.5-medium depth and width, N = 1024, T = 333)"""
 import argparse, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

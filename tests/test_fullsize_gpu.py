@@ -250,13 +250,13 @@ def test_fused_qk_rope_forward_vs_fp32_verification(gpu, monkeypatch):
 @pytest.mark.parametrize("which", ["flux", "sd3"])
 def test_full_model_forward_parity(gpu, which):
     """ONE forward of the FULL model (19 + 38 base blocks, 9 + 19 control blocks, D = 3072, H = 24, CoMoE E = 6; cfg1's token counts N = 1024,
-    T = 512, B = 1) against the CPU oracle on the same 18.8 B synthetic parameters (tools/fullsize_f32_parity.py, run in a child process so that its
+    T = 512, B = 1) against the CPU oracle on the same 18.8 B synthetic parameters (tests/fullsize_f32_parity.py, run in a child process so that its
     ~120 GB of host copies are returned at once): the fp32 verification path must meet the north star's 1e-3 against the fp32 oracle (measured
     9.2e-5), and the bf16 product path must be as close to that truth as the oracle's own bf16 evaluation (measured 1.86e-2 vs 1.84e-2).
     "sd3": the same for UniGenSD3 at SD3.5-medium size (24 joint blocks with dual attention in 0-12, D = 1536, 24 heads of 64; N = 1024, T = 333)."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    p = subprocess.run([sys.executable, os.path.join(root, "tools", "fullsize_f32_parity.py"), which], capture_output=True, text=True, timeout=1100, cwd=root)
+    p = subprocess.run([sys.executable, os.path.join(root, "tests", "fullsize_f32_parity.py"), which], capture_output=True, text=True, timeout=1100, cwd=root)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     line = [l for l in p.stdout.splitlines() if l.startswith("FULLSIZE_PARITY")][-1]
     r = json.loads(line[len("FULLSIZE_PARITY "):])
