@@ -503,3 +503,38 @@ def test_zero_shard_merge(tmp_path, stage, world):
     assert set(res.unexpected_keys) == {"odd.weight", "frozen.odd", "some.buffer", "alias.weight"}
     g2 = m2.state_dict()
     assert all(torch.equal(g2[k], ctrl[k].to(g2[k].dtype)) for k in ctrl if k in g2)
+
+
+class _EvalPayload:
+    """A shard entry whose __reduce__ names builtins.eval / os.system: what an attacker-written `*_optim_states.pt` would carry."""
+    def __init__(self, fn, arg):
+        self.fn, self.arg = fn, arg
+
+    def __reduce__(self):
+        return (self.fn, (self.arg,))
+
+
+@pytest.mark.parametrize("protocol", [2, 4])
+def test_zero_unpickler_runs_no_payload(tmp_path, protocol):
+    """the ZeRO shard reader resolves an exact allowlist of globals; `builtins.eval`, `os.system`, `torch.hub.load` and
+    the like become inert stubs, so a crafted shard executes nothing - while real tensors, containers and dtypes still load."""
+    import builtins, os as _os
+    from unigen_amd.checkpoint import _zero_load, merge_zero_checkpoint, _Stub
+    marker = tmp_path / "pwned"
+    code = f"open({str(marker)!r}, 'w').write('x')"
+    shard = dict(optimizer_state_dict=dict(zero_stage=2, partition_count=1, single_partition_of_fp32_groups=[torch.arange(6.0)],
+                                           evil1=_EvalPayload(builtins.eval, code), evil2=_EvalPayload(_os.system, f"touch {marker}"),
+                                           evil3=_EvalPayload(builtins.exec, code), evil4=_EvalPayload(getattr(builtins, "__import__"), "antigravity"),
+                                           scaler=_FakeLossScaler(), dt=torch.bfloat16, sz=torch.Size([2, 3]), half=torch.ones(3, dtype=torch.bfloat16)))
+    f = tmp_path / "mp_rank_00_optim_states.pt"
+    torch.save(shard, str(f), pickle_protocol=protocol)
+    got = _zero_load(str(f))["optimizer_state_dict"]
+    assert not marker.exists()
+    assert all(isinstance(got[k], _Stub) for k in ("evil1", "evil2", "evil3", "evil4", "scaler"))
+    assert got["dt"] is torch.bfloat16 and got["sz"] == torch.Size([2, 3]) and torch.equal(got["half"], torch.ones(3, dtype=torch.bfloat16))
+    assert torch.equal(got["single_partition_of_fp32_groups"][0], torch.arange(6.0))
+    # a directory whose shards lack the ZeRO entries is a clear error, not a KeyError
+    d = tmp_path / "ck"; (d / "t").mkdir(parents=True); (d / "latest").write_text("t")
+    torch.save(dict(optimizer_state_dict=dict(partition_count=1)), str(d / "t" / "mp_rank_00_optim_states.pt"))
+    with pytest.raises(ValueError, match="zero_stage"):
+        merge_zero_checkpoint(str(d))

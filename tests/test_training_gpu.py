@@ -294,3 +294,42 @@ def test_sd3_training_gradients_at_sd35_width_fp32(gpu):
     e = float((gh - gr).norm() / gr.norm())
     print(f"training SD3.5 width fp32: loss {loss_h:.6f} vs {loss_r:.6f}, {gh.numel() / 1e9:.2f} B gradient elements, rel_l2 {e:.3e}")
     assert abs(loss_h - loss_r) <= 1e-5 * abs(loss_r) + 1e-7 and e <= 1e-3, (loss_h, loss_r, e)
+
+
+def test_train_validate_train_keeps_weight_transposes_fresh(gpu):
+    """train step -> no-grad validation forward (the inference engine packs QKV / AdaLN / expert weights into new
+    buffers and re-points the parameters, freeing the old storages) -> train step, the sequence of the reference's train.py with
+    log_validation. The backward's cache of frozen-weight transposes is keyed by address: it must be dropped when storage moves, or the
+    second step reads the transposed copy of a different weight. Same weights and inputs: both steps must give the same gradients."""
+    import importlib
+    from unigen_amd import autograd as AG
+    cls = importlib.import_module("src.UniGenTransformer").UniGenFlux
+    B, grid, T = 1, 8, 64
+    rcfg = R.FluxConfig(condition_nums=1, **TINY)
+    model = cls.from_config(dict(TINY), device=gpu, dtype=BF)
+    model.init_condition_block(condition_nums=1, condition_types=["canny"], control_params=dict(CONTROL))
+    model.init_synthetic_(seed=11, std=0.05, bias_std=0.02)
+    model.init_trainable_param()
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
+    inp = R.make_inputs(rcfg, B=B, grid=grid, T=T)
+    kw = {k: _dev(v, gpu, BF if k != "gate_uniform" and not k.endswith("_ids") else None) for k, v in inp.items()}
+    t = torch.full((B,), 0.5, dtype=BF, device=gpu)
+    target = torch.randn(B, grid * grid, 64, generator=torch.Generator().manual_seed(2))
+
+    def grads():
+        model.zero_grad(set_to_none=True)
+        _step(lambda: model(timestep=t, **kw), target, BF)
+        return torch.cat([(model.get_parameter(k).grad if model.get_parameter(k).grad is not None else torch.zeros_like(model.get_parameter(k))).float().flatten()
+                          for k in names])
+
+    g1 = grads()
+    assert len(AG._wt_cache) > 0                      # frozen base weights were transposed for dX and cached
+    ptr_before = model.get_parameter("transformer_blocks.0.attn.to_q.weight").data_ptr()
+    with torch.no_grad():
+        model(timestep=t, **kw)                       # inference engine: packs, re-points p.data
+    assert model.get_parameter("transformer_blocks.0.attn.to_q.weight").data_ptr() != ptr_before
+    assert len(AG._wt_cache) == 0 and len(AG._xt_cache) == 0
+    g2 = grads()
+    e = float((g2 - g1).norm() / g1.norm())
+    assert e <= 1e-4, e                               # a stale transposed weight is an O(1) error
+    AG.clear_caches()

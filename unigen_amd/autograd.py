@@ -24,15 +24,24 @@ def _w_transposed(w: torch.Tensor) -> torch.Tensor:
     """[N, K] -> [K, N] (N must be a multiple of 64: it becomes the contraction length). Frozen weights are transposed once."""
     if w.requires_grad:
         return ops.transpose(w.detach())
-    # the entry keeps the weight alive, so its address cannot be recycled for another tensor of the same shape while the entry exists;
-    # `_version` catches in-place updates (load_state_dict, optimizer steps on a weight that was frozen before)
-    key = (w.data_ptr(), tuple(w.shape), w.dtype, w._version)
+    # the entry pins the STORAGE (a detached alias, not the Parameter object: `p.data = new_buffer` - engine._pack, nn.Module._apply - would
+    # free the old storage under a pinned Parameter and let another weight of the same shape land on its address), so the address cannot be
+    # recycled while the entry exists; `_version` catches in-place updates (load_state_dict, optimizer steps on a formerly frozen weight).
+    # Re-pointing also calls clear_caches() (engine._pack / _pack_stack), which drops the dead transposed copies.
+    key = (w.data_ptr(), tuple(w.shape), tuple(w.stride()), w.dtype, w._version)
     hit = _wt_cache.get(key)
     if hit is None:
         if len(_wt_cache) > 4096:
             _wt_cache.clear()
-        hit = _wt_cache[key] = (ops.transpose(w.detach()), w)
+        hit = _wt_cache[key] = (ops.transpose(w.detach()), w.detach())
     return hit[0]
+
+
+def clear_caches() -> None:
+    """Drop the cached transposes (frozen weights, recent activations). Called when parameters are re-pointed to packed buffers and by the
+    training loop at the end of a step (the activation entries otherwise outlive the backward: a few hundred MB at full size)."""
+    _wt_cache.clear()
+    _xt_cache.clear()
 
 
 _xt_cache: list = []        # the last few activation transposes of this backward pass: (source tensor, padded length, transposed copy)
@@ -71,9 +80,9 @@ class Linear(torch.autograd.Function):
         M, K = x.shape
         N = w.shape[0]
         dx = dw = db = None
-        if N % 64 != 0:
-            raise L.UniGenHipError(f"Linear backward: out_features={N} must be a multiple of 64 (it is the contraction length of dX = dY W)")
         if ctx.needs_input_grad[0]:
+            if N % 64 != 0:
+                raise L.UniGenHipError(f"Linear backward: out_features={N} must be a multiple of 64 (it is the contraction length of dX = dY W)")
             dx = torch.empty(M, K, device=x.device, dtype=x.dtype)
             ops.gemm(dy, _w_transposed(w), None, dx, M=M)
         if ctx.needs_input_grad[1]:

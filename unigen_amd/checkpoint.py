@@ -13,8 +13,9 @@ The reference resolves `--transformer` three ways (infer.py:124-140) and `train.
 
 Tensors are returned on the CPU in their stored dtype; the model's `load_state_dict` casts to bf16 and writes through its packed
 (fused QKV / stacked expert) views. No network access. Plain state-dict files load with `weights_only=True`; ZeRO shard files pickle
-DeepSpeed objects (loss scaler, config) beside the tensors, so they are read with an unpickler that replaces every non-torch,
-non-builtin class by an inert stub (nothing from the checkpoint is imported or executed).
+DeepSpeed objects (loss scaler, config) beside the tensors, so they are read with an unpickler that resolves an exact allowlist of
+(module, name) pairs - tensor rebuild functions, storages, dtypes, plain containers - and replaces every other global by an inert stub:
+nothing from the checkpoint is imported or executed (tests/test_host_cpu.py::test_zero_unpickler_runs_no_payload).
 
 Parity note: no DeepSpeed checkpoint exists in this container (no deepspeed, no weights), so the merge is pinned only by a writer that
 restates the SAVE side of the same release (tests/test_host_cpu.py::test_zero_shard_merge) - format parity unpinned.
@@ -88,8 +89,37 @@ class _Stub:
         return self
 
 
+# Exact (module, name) pairs a ZeRO shard may resolve. Everything else - the rest of `builtins` (eval, exec, getattr, __import__ ...), of
+# `torch` (torch.hub, torch.load ...) and of `numpy` included - becomes an inert _Stub: a `__reduce__` that names it calls _Stub(...), which
+# does nothing. (allowlisting whole module roots let `builtins.eval` through.)
+_SAFE_BUILTINS = ("dict", "list", "tuple", "set", "frozenset", "int", "float", "bool", "bytes", "bytearray", "str", "slice", "complex", "range")
+_SAFE_TORCH_STORAGES = ("FloatStorage", "DoubleStorage", "HalfStorage", "BFloat16Storage", "LongStorage", "IntStorage", "ShortStorage",
+                        "CharStorage", "ByteStorage", "BoolStorage", "UntypedStorage", "ComplexFloatStorage", "ComplexDoubleStorage")
+_SAFE_TORCH_DTYPES = ("float32", "float64", "float16", "bfloat16", "int64", "int32", "int16", "int8", "uint8", "bool", "complex64", "complex128",
+                      "float", "double", "half", "long", "int", "short")
+
+
+def _safe_globals():
+    import collections
+    ok = {("collections", "OrderedDict"): collections.OrderedDict, ("torch", "Size"): torch.Size, ("torch", "device"): torch.device,
+          ("torch._utils", "_rebuild_tensor_v2"): torch._utils._rebuild_tensor_v2, ("torch._utils", "_rebuild_parameter"): torch._utils._rebuild_parameter,
+          ("torch._utils", "_rebuild_tensor"): torch._utils._rebuild_tensor, ("torch.serialization", "_get_layout"): torch.serialization._get_layout,
+          ("_codecs", "encode"): __import__("_codecs").encode}           # bytes objects of protocol-2 pickles
+    import builtins
+    for n in _SAFE_BUILTINS:
+        ok[("builtins", n)] = ok[("__builtin__", n)] = getattr(builtins, n)
+    for n in _SAFE_TORCH_STORAGES:
+        if hasattr(torch, n):
+            ok[("torch", n)] = getattr(torch, n)
+    ok[("torch.storage", "UntypedStorage")] = torch.UntypedStorage
+    ok[("torch.storage", "_load_from_bytes")] = _Stub                    # carries a nested pickle: never evaluated
+    for n in _SAFE_TORCH_DTYPES:
+        ok[("torch", n)] = getattr(torch, n)
+    return ok
+
+
 class _SafePickle:
-    """pickle_module for torch.load: torch / collections / builtins resolve normally, everything else becomes _Stub."""
+    """pickle_module for torch.load of a ZeRO shard: only the exact globals of `_safe_globals()` resolve, everything else becomes _Stub."""
     import pickle as _p
     __name__ = "unigen_amd.checkpoint._SafePickle"
     load, loads, dump, dumps = _p.load, _p.loads, _p.dump, _p.dumps
@@ -97,16 +127,26 @@ class _SafePickle:
     Pickler = _p.Pickler
 
     class Unpickler(_p.Unpickler):
-        _OK = ("torch", "collections", "builtins", "numpy", "_codecs", "copyreg")
+        _OK = None
 
         def find_class(self, module, name):
-            if module.split(".")[0] in self._OK:
-                return super().find_class(module, name)
-            return type(name, (_Stub,), {"__module__": module})
+            cls = type(self)
+            if cls._OK is None:
+                cls._OK = _safe_globals()
+            hit = cls._OK.get((module, name))
+            if hit is not None:
+                return hit
+            return type(str(name).split(".")[-1] or "Stub", (_Stub,), {"__module__": module})
 
 
 def _zero_load(path: str):
     return torch.load(path, map_location="cpu", weights_only=False, pickle_module=_SafePickle)
+
+
+def _need(d, key, where):
+    if not isinstance(d, dict) or key not in d:
+        raise ValueError(f"{where}: not a DeepSpeed ZeRO shard this reader understands (no '{key}' entry; written by deepspeed 0.14-0.16?)")
+    return d[key]
 
 
 def _natural(files):
@@ -126,9 +166,9 @@ def merge_zero_checkpoint(checkpoint_dir: str, tag: str = None) -> Dict[str, tor
     optim_files = _natural(glob.glob(os.path.join(ds_dir, "*_optim_states.pt")))
     if not optim_files:
         raise OSError(f"{ds_dir}: no *_optim_states.pt shards")
-    optim = [_zero_load(f)["optimizer_state_dict"] for f in optim_files]
-    stage = int(optim[0]["zero_stage"])
-    world = optim[0]["partition_count"]
+    optim = [_need(_zero_load(f), "optimizer_state_dict", f) for f in optim_files]
+    stage = int(_need(optim[0], "zero_stage", optim_files[0]))
+    world = _need(optim[0], "partition_count", optim_files[0])
     world = int(max(world)) if isinstance(world, (list, tuple)) else int(world)
     if world != len(optim_files):
         raise ValueError(f"{ds_dir}: {len(optim_files)} optimizer shards but partition_count = {world}")
@@ -138,7 +178,7 @@ def merge_zero_checkpoint(checkpoint_dir: str, tag: str = None) -> Dict[str, tor
         raise OSError(f"{ds_dir}: no *_model_states.pt for ZeRO stage {stage}")
     models = [_zero_load(f) for f in model_files]
     m0 = models[0]
-    param_shapes = m0["param_shapes"]                      # list (one dict name -> shape per optimizer param group)
+    param_shapes = _need(m0, "param_shapes", model_files[0])   # list (one dict name -> shape per optimizer param group)
     if isinstance(param_shapes, dict):
         param_shapes = [param_shapes]
     numel = lambda shp: int(torch.Size(shp).numel())
@@ -157,7 +197,7 @@ def merge_zero_checkpoint(checkpoint_dir: str, tag: str = None) -> Dict[str, tor
         else:
             sd[name] = m0["frozen_param_fragments"][name].float()
     if stage == 3:
-        flats = [torch.cat([g.reshape(-1) for g in o["fp32_flat_groups"]], 0) for o in optim]      # per rank: its partitions of every param, in order
+        flats = [torch.cat([g.reshape(-1) for g in _need(o, "fp32_flat_groups", f)], 0) for o, f in zip(optim, optim_files)]      # per rank: its partitions of every param, in order
         offset = 0
         for shapes in param_shapes:
             for name, shp in shapes.items():
@@ -170,7 +210,7 @@ def merge_zero_checkpoint(checkpoint_dir: str, tag: str = None) -> Dict[str, tor
     elif stage in (1, 2):
         align = 2 * world
         up = lambda x: align * -(-x // align)
-        ngroups = len(optim[0]["single_partition_of_fp32_groups"])
+        ngroups = len(_need(optim[0], "single_partition_of_fp32_groups", optim_files[0]))
         if ngroups != len(param_shapes):
             raise ValueError(f"{ds_dir}: {ngroups} flat groups but {len(param_shapes)} parameter groups")
         for gi, shapes in enumerate(param_shapes):

@@ -126,6 +126,17 @@ class HipModule(nn.Module):
         return self
 
     # ------------------------------------------------------------------ weight packing --------------------------------
+    @staticmethod
+    def _storage_moved():
+        """Parameters were re-pointed at new storage: the backward's cached weight transposes (autograd._wt_cache, keyed by address) are stale."""
+        from . import autograd
+        autograd.clear_caches()
+
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)          # .to() / .cuda() / .float(): every parameter gets new storage
+        self._storage_moved()
+        return r
+
     def _P(self, name: str) -> torch.Tensor:
         return self.get_parameter(name).data
 
@@ -142,6 +153,7 @@ class HipModule(nn.Module):
             p.data = t[off:off + n]
             off += n
         self._packed[key] = t
+        self._storage_moved()
         return t
 
     def _pack_stack(self, key: str, names: Sequence[str]) -> torch.Tensor:
@@ -153,6 +165,7 @@ class HipModule(nn.Module):
         for i, p in enumerate(params):
             p.data = t[i]
         self._packed[key] = t
+        self._storage_moved()
         return t
 
     def _attn_qkv(self, p: str) -> Tuple[torch.Tensor, torch.Tensor]:
