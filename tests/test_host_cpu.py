@@ -538,3 +538,45 @@ def test_zero_unpickler_runs_no_payload(tmp_path, protocol):
     torch.save(dict(optimizer_state_dict=dict(partition_count=1)), str(d / "t" / "mp_rank_00_optim_states.pt"))
     with pytest.raises(ValueError, match="zero_stage"):
         merge_zero_checkpoint(str(d))
+
+
+@pytest.mark.parametrize("cls", ["UniGenFlux", "UniGenSD3"])
+def test_control_modules_start_from_the_reference_initial_values(cls):
+    """src/UniGenTransformer.py:727-773, 833-842 (Flux) / :26-128 (SD3): deep copies of the base embedders, torch default nn.Linear init for the
+    control blocks / gate / experts (every expert a copy of ONE module), RMSNorm weights = 1, zeros ONLY for the zero-res projections."""
+    torch.manual_seed(0)
+    if cls == "UniGenFlux":
+        m = _model()
+        sd = m.state_dict()
+        for dst, src in (("control_time_text_embed.", "time_text_embed."), ("control_condition_embed.", "time_text_embed."), ("control_x_embedder.", "x_embedder.")):
+            keys = [k for k in sd if k.startswith(dst)]
+            assert keys and all(torch.equal(sd[k], sd[src + k[len(dst):]]) for k in keys), dst
+        zero = ("controlnet_add_joint_blocks.", "controlnet_add_single_blocks.")
+        fresh = ("control_context_embedder.", "control_joint_trans_blocks.", "control_single_trans_blocks.", "shared_expert.", "moe.")
+    else:
+        m = importlib.import_module("src.UniGenTransformer").UniGenSD3.from_config(dict(sample_size=16, num_layers=2, attention_head_dim=64, num_attention_heads=2,
+                joint_attention_dim=64, caption_projection_dim=128, pooled_projection_dim=64, pos_embed_max_size=12, dual_attention_layers=(0,)))
+        m.init_condition_block(condition_nums=1, condition_types=["depth"], control_params=dict(use_shared_expert=True))
+        sd = m.state_dict()
+        zero = ("controlnet_add_blocks.",)
+        fresh = ("control_pos_embed_input.proj", "control_time_text_embed.", "control_condition_embed.", "control_context_embedder.",
+                 "control_transformer_blocks.", "shared_expert.", "moe.")
+    assert all(torch.isfinite(v.float()).all() for v in sd.values())
+    for k, v in sd.items():
+        if k.startswith(zero):
+            assert float(v.abs().max()) == 0.0, k
+        elif k.startswith(fresh):
+            if k.endswith(".weight") and v.dim() == 1:
+                assert torch.equal(v, torch.ones_like(v)), k                       # RMSNorm
+            elif k.endswith(".weight"):
+                bound = 1.0 / v[0].numel() ** 0.5                                   # kaiming_uniform_(a = sqrt(5)) = U(-1/sqrt(fan_in), 1/sqrt(fan_in))
+                vf = v.float()
+                assert float(vf.abs().max()) <= bound * 1.01 and float(vf.std()) > 0.4 * bound, (k, bound, float(vf.std()))
+    # deepspeed Experts: num_experts deep copies of one module -> identical experts, but a non-degenerate (untied) gate
+    pe = "moe.moe_layer.experts.deepspeed_experts."
+    e0 = {k[len(pe) + 2:]: v for k, v in sd.items() if k.startswith(pe + "0.")}
+    n_e = sd["moe.moe_layer.gate.wg.weight"].shape[0]
+    assert n_e == 6 and all(torch.equal(sd[f"{pe}{e}.{r}"], v) for e in range(1, n_e) for r, v in e0.items())
+    wg = sd["moe.moe_layer.gate.wg.weight"].float()
+    assert float((wg[0] - wg[1]).abs().max()) > 0
+    assert all(p.requires_grad is False for p in m.parameters())

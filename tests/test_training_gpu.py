@@ -333,3 +333,44 @@ def test_train_validate_train_keeps_weight_transposes_fresh(gpu):
     e = float((g2 - g1).norm() / g1.norm())
     assert e <= 1e-4, e                               # a stale transposed weight is an O(1) error
     AG.clear_caches()
+
+
+def test_training_from_the_reference_initial_values_is_alive(gpu):
+    """from `init_condition_block`'s own initial values (no synthetic re-init) a train.py run must not start from a dead
+    network. Step 1 behaves like any zero-initialised ControlNet: the zero-res projections (and the gate, through l_aux) receive gradients,
+    everything upstream of a zero projection gets exactly zero. After ONE update of the zero-res projections every trainable parameter that
+    feeds a kept output has a non-zero gradient (round 2 zeroed all control parameters: q = k = 0, tied gate, most gradients stayed zero)."""
+    import importlib
+    torch.manual_seed(7)
+    cls = importlib.import_module("src.UniGenTransformer").UniGenFlux
+    B, grid, T = 2, 8, 64
+    rcfg = R.FluxConfig(condition_nums=1, **TINY)
+    model = cls.from_config(dict(TINY), device=gpu, dtype=BF)              # base: torch default init (a stand-in for from_pretrained)
+    model.init_condition_block(condition_nums=1, condition_types=["canny"], control_params=dict(CONTROL))
+    model.init_trainable_param()
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
+    inp = R.make_inputs(rcfg, B=B, grid=grid, T=T)
+    kw = {k: _dev(v, gpu, BF if k != "gate_uniform" and not k.endswith("_ids") else None) for k, v in inp.items()}
+    t = torch.full((B,), 0.5, dtype=BF, device=gpu)
+    target = torch.randn(B, grid * grid, 64, generator=torch.Generator().manual_seed(2))
+    gmax = lambda k: 0.0 if model.get_parameter(k).grad is None else float(model.get_parameter(k).grad.float().abs().max())
+
+    _step(lambda: model(timestep=t, **kw), target, BF)
+    zero_res = [k for k in names if k.startswith("controlnet_add_")]
+    assert zero_res and all(gmax(k) > 0 for k in zero_res if k.endswith(".weight")), "zero-res projections must learn at step 1"
+    assert gmax("moe.moe_layer.gate.wg.weight") > 0                        # l_aux
+    assert all(gmax(k) == 0.0 for k in names if k.startswith(("control_joint_trans_blocks.", "control_single_trans_blocks.", "shared_expert.")))
+    with torch.no_grad():
+        for k in zero_res:
+            p = model.get_parameter(k)
+            p.add_(p.grad.to(p.dtype), alpha=-50.0)      # one plain SGD step on the zero-res projections
+    model.zero_grad(set_to_none=True)
+    _step(lambda: model(timestep=t, **kw), target, BF)
+    # parameters that only feed a DISCARDED context output (src/UniGenTransformer.py:1097,1022) get zero in the reference too
+    dead_pat = (".attn.to_add_out.", ".ff_context.", ".attn.add_q_proj.", ".attn.norm_added_q.")
+    dead = [k for k in names if k.startswith(("control_joint_trans_blocks.", "shared_expert.1.")) and any(d in k for d in dead_pat)]
+    live = [k for k in names if k not in dead]
+    still_zero = [k for k in live if gmax(k) == 0.0]
+    assert not still_zero, f"{len(still_zero)} of {len(live)} live parameters have zero gradient, e.g. {still_zero[:6]}"
+    assert all(gmax(k) == 0.0 for k in dead)
+    assert all(torch.isfinite(model.get_parameter(k).grad.float()).all() for k in live)

@@ -37,6 +37,45 @@ def _register(root: nn.Module, name: str, shape: Tuple[int, ...], device, dtype)
     return p
 
 
+def reference_init_(root: nn.Module, names: Sequence[str], copies: Dict[str, str], zero_prefixes: Sequence[str], expert_prefix: str) -> None:
+    """Initial values of the control modules as the reference's constructors leave them (src/UniGenTransformer.py:727-773, 833-842, 26-128):
+      * `copies` {dst prefix: src prefix}: `copy.deepcopy` of a base module (Flux: control_time_text_embed, control_condition_embed <-
+        time_text_embed; control_x_embedder <- x_embedder, :731-742);
+      * `zero_prefixes`: `zero_module(nn.Linear)` - the zero-res projections controlnet_add_* only (:757,771; :119-123 for SD3);
+      * RMSNorm weights (1-D `*.weight`) = 1; every other `nn.Linear` / `nn.Conv2d` = torch's default reset_parameters():
+        weight ~ U(-1/sqrt(fan_in), 1/sqrt(fan_in)) (kaiming_uniform_, a = sqrt(5)), bias ~ U(-1/sqrt(fan_in), 1/sqrt(fan_in));
+      * deepspeed `Experts` deep-copies ONE expert module num_experts times: every expert starts from expert 0's values.
+    Draws come from torch's global generator on the parameters' device, as the reference's do. (Round 2 zeroed all of it: a from-scratch
+    train.py run then starts from a dead network - tied gate, q = k = 0, most gradients exactly zero.)"""
+    params = dict(root.named_parameters())
+    e0 = expert_prefix + "0."
+    with torch.no_grad():
+        for name in names:
+            p = params[name]
+            src = next((s + name[len(d):] for d, s in copies.items() if name.startswith(d)), None)
+            if src is not None:
+                p.copy_(params[src])
+            elif any(name.startswith(z) for z in zero_prefixes):
+                p.zero_()
+            elif name.startswith(expert_prefix) and not name.startswith(e0):
+                continue                                                    # filled from expert 0 below
+            elif name.endswith(".weight") and p.dim() == 1:
+                p.fill_(1.0)
+            elif name.endswith(".weight"):
+                bound = 1.0 / math.sqrt(p[0].numel())
+                p.copy_(torch.empty(p.shape, device=p.device, dtype=torch.float32).uniform_(-bound, bound))
+            elif name.endswith(".bias"):
+                w = params.get(name[:-len("bias")] + "weight")
+                bound = 1.0 / math.sqrt(w[0].numel()) if w is not None and w.dim() > 1 else 0.0
+                p.copy_(torch.empty(p.shape, device=p.device, dtype=torch.float32).uniform_(-bound, bound))
+            else:
+                raise L.UniGenHipError(f"reference_init_: no rule for parameter {name}")
+        for name in names:
+            if name.startswith(expert_prefix) and not name.startswith(e0):
+                rest = name[len(expert_prefix):].split(".", 1)[1]
+                params[name].copy_(params[e0 + rest])
+
+
 class _Workspace:
     def __init__(self):
         self._bufs: Dict[Tuple, torch.Tensor] = {}

@@ -24,7 +24,7 @@ from torch import nn
 
 from . import lib as L
 from . import ops
-from .engine import BF, HipModule, _Holder, _register, _Stream, _Workspace
+from .engine import BF, HipModule, _Holder, _register, _Stream, _Workspace, reference_init_
 from .ops import RowMap
 
 
@@ -128,7 +128,7 @@ class UniGenFlux(HipModule):
     multi_condition = False
 
     # ------------------------------------------------------------------ construction ---------------------------------
-    def __init__(self, config: Optional[dict] = None, device=None, dtype=BF, **kwargs):
+    def __init__(self, config: Optional[dict] = None, device=None, dtype=BF, _init: bool = True, **kwargs):
         super().__init__()
         c = dict(FLUX_SCHNELL_CONFIG)
         c.update(config or {})
@@ -144,6 +144,8 @@ class UniGenFlux(HipModule):
         self._rope_cache: Dict[Tuple, Tuple[torch.Tensor, torch.Tensor]] = {}
         for name, shape in base_param_shapes(self.config).items():
             _register(self, name, shape, device, dtype)
+        if _init:      # from_config = a fresh model: torch's default initial values (from_pretrained overwrites, so it skips this)
+            reference_init_(self, list(base_param_shapes(self.config)), copies={}, zero_prefixes=(), expert_prefix="\0")
 
     @classmethod
     def from_config(cls, config: dict, **kw) -> "UniGenFlux":
@@ -161,7 +163,7 @@ class UniGenFlux(HipModule):
         with open(os.path.join(path, "config.json")) as f:
             raw = json.load(f)
         cfg = {k: raw[k] for k in FLUX_SCHNELL_CONFIG if k in raw}
-        model = cls(cfg, device=device, dtype=torch_dtype)
+        model = cls(cfg, device=device, dtype=torch_dtype, _init=False)
         from safetensors.torch import load_file
         files = sorted(f for f in os.listdir(path) if f.endswith(".safetensors"))
         if not files:
@@ -209,10 +211,12 @@ class UniGenFlux(HipModule):
             raise ValueError("at most 16 experts are supported")
         self._ctl = ctl
         dev_, dt_ = self.device, self.dtype
-        for name, shape in control_param_shapes(self.config, ctl).items():
-            p = _register(self, name, shape, dev_, dt_)
-            with torch.no_grad():
-                p.zero_()
+        shapes = control_param_shapes(self.config, ctl)
+        for name, shape in shapes.items():
+            _register(self, name, shape, dev_, dt_)
+        reference_init_(self, list(shapes), copies={"control_time_text_embed.": "time_text_embed.", "control_condition_embed.": "time_text_embed.",
+                                                    "control_x_embedder.": "x_embedder."},
+                        zero_prefixes=("controlnet_add_joint_blocks.", "controlnet_add_single_blocks."), expert_prefix="moe.moe_layer.experts.deepspeed_experts.")
         names = ["control_time_text_embed", "control_condition_embed", "control_context_embedder", "control_x_embedder",
                  "control_joint_trans_blocks", "controlnet_add_joint_blocks", "moe"]
         if ctl.use_single_trans_blocks:

@@ -19,7 +19,7 @@ import torch
 
 from . import lib as L
 from . import ops
-from .engine import BF, HipModule, _register, _Stream
+from .engine import BF, HipModule, _register, _Stream, reference_init_
 from .flux import _lin, _time_text_embed_shapes
 from .ops import RowMap
 
@@ -114,7 +114,7 @@ def sincos_pos_embed_2d(embed_dim: int, grid_size: int, base_size: int) -> torch
 class UniGenSD3(HipModule):
     """Drop-in for the reference `UniGenSD3`."""
 
-    def __init__(self, config: Optional[dict] = None, device=None, dtype=BF, **kwargs):
+    def __init__(self, config: Optional[dict] = None, device=None, dtype=BF, _init: bool = True, **kwargs):
         super().__init__()
         c = dict(SD35_MEDIUM_CONFIG)
         c.update(config or {})
@@ -132,6 +132,8 @@ class UniGenSD3(HipModule):
         self._pos_crop: Dict[Tuple, torch.Tensor] = {}
         for name, shape in sd3_base_param_shapes(self.config).items():
             _register(self, name, shape, device, dtype)
+        if _init:      # from_config = a fresh model: torch's default initial values (from_pretrained overwrites, so it skips this)
+            reference_init_(self, list(sd3_base_param_shapes(self.config)), copies={}, zero_prefixes=(), expert_prefix="\0")
         mx = self.config.pos_embed_max_size
         base = self.config.sample_size // self.config.patch_size
         table = sincos_pos_embed_2d(self.inner_dim, mx, base).unsqueeze(0)
@@ -151,7 +153,7 @@ class UniGenSD3(HipModule):
             raise OSError(f"{path} is not a local directory (unigen_amd loads checkpoints from disk only)")
         with open(os.path.join(path, "config.json")) as f:
             raw = json.load(f)
-        model = cls({k: raw[k] for k in SD35_MEDIUM_CONFIG if k in raw}, device=device, dtype=torch_dtype)
+        model = cls({k: raw[k] for k in SD35_MEDIUM_CONFIG if k in raw}, device=device, dtype=torch_dtype, _init=False)
         from safetensors.torch import load_file
         sd = {}
         for fn in sorted(f for f in os.listdir(path) if f.endswith(".safetensors")):
@@ -191,10 +193,11 @@ class UniGenSD3(HipModule):
             raise ValueError("top-1 gating with at most 16 experts is implemented")
         self._ctl = ctl
         dev_, dt_ = self.device, self.dtype
-        for name, shape in sd3_control_param_shapes(self.config, ctl).items():
-            prm = _register(self, name, shape, dev_, dt_)
-            with torch.no_grad():
-                prm.zero_()
+        shapes = sd3_control_param_shapes(self.config, ctl)
+        for name, shape in shapes.items():
+            _register(self, name, shape, dev_, dt_)
+        # UniGenBase.init_control_block builds every control module fresh (no deepcopy of the base), zero only for controlnet_add_blocks (:119-123)
+        reference_init_(self, list(shapes), copies={}, zero_prefixes=("controlnet_add_blocks.",), expert_prefix="moe.moe_layer.experts.deepspeed_experts.")
         self.control_pos_embed_input.register_buffer("pos_embed", self.pos_embed.pos_embed.clone(), persistent=True)
         names = ["control_pos_embed_input", "control_time_text_embed", "control_condition_embed", "control_context_embedder",
                  "control_transformer_blocks", "controlnet_add_blocks", "moe"] + (["shared_expert"] if ctl.use_shared_expert else [])

@@ -294,7 +294,9 @@ class AutoencoderKL(nn.Module):
 
     def encode(self, x: torch.Tensor, return_dict: bool = True):
         m, B, H, W = self._encode_moments(x)
-        dist = DiagonalGaussianDistribution(m, B, self.config.latent_channels, H, W)
+        # the moments live in a reused workspace: the distribution owns a copy (2 * latent channels at latent resolution - tiny), so a second
+        # encode() before .sample() / .mode() cannot overwrite it (diffusers semantics)
+        dist = DiagonalGaussianDistribution(m.clone(), B, self.config.latent_channels, H, W)
         return SimpleNamespace(latent_dist=dist) if return_dict else (dist,)
 
     @torch.no_grad()
