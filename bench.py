@@ -1,8 +1,10 @@
 #!/usr/bin/env python
 """Headline benchmark: images/sec at 1024^2, FLUX-schnell geometry + canny condition, 4 denoise steps (BASELINE.json).
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W [--config cfg2|cfg3|cfg4|cfg5] [--batch B]
   N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+          or plain `python bench.py --gpus N`: with no torchrun environment the script launches its own N ranks (one fresh child
+          process per GPU, started BEFORE anything touches the GPU; reference script/infer.sh:49-67 `accelerate launch`)
 
 A "step" is one pass of the hot path over one batch: the full 4-step denoise loop (4 UniGenFlux forwards + 4 Euler steps) of a
 batch of B = 4 synthetic 1024x1024 samples (cfg2: N = 4096 image tokens, T = 512 text tokens, 19 double + 38 single base blocks,
@@ -97,6 +99,37 @@ def _host_info(max_threads: int):
     return cores, cpu_model, mem_gb
 
 
+def cpu_baseline_other(model, config: str, max_threads: int = 16):
+    """cfg3 / cfg5: the CPU oracle on ONE full-depth forward of the stated workload at B = 1 image, on the GPU run's own weights.
+    cfg3: MultiCondtionUniGenFlux (3 conditions, E = 12), 1024^2, an image = 4 forwards. cfg5: UniGenSD3 with CFG (an image-step = one
+    2-sample forward), 1024^2, T = 333, an image = 28 such forwards."""
+    from oracle import unigen_ref as R
+    cores, cpu_model, mem_gb = _host_info(max_threads)
+    torch.set_num_threads(cores)
+    st = {k: v.detach().to("cpu") for k, v in model.state_dict().items()}
+    if config == "cfg3":
+        cfg = R.FluxConfig(condition_nums=3)
+        inp = R.make_inputs(cfg, B=1, grid=64, T=512, n_cond=3)
+        t = torch.full((1,), 1.0, dtype=torch.bfloat16)
+        run = lambda: R.unigen_flux_forward(st, cfg, timestep=t, dtype=torch.bfloat16, **inp)[0]
+        per_image, what = 4, "MultiCondtionUniGenFlux depth+canny+openpose (E=12), 1024^2 (N=4096, T=512), full depth, B=1"
+    else:
+        cfg = R.SD3Config()
+        inp = R.make_sd3_inputs(cfg, B=2, hw=128, T=333)
+        t = torch.full((2,), 500.0)
+        run = lambda: R.unigen_sd3_forward(st, cfg, timestep=t, dtype=torch.bfloat16, **inp)[0]
+        per_image, what = 28, "UniGenSD3 (SD3.5-medium, 24 blocks, D=1536), 1024^2 (N=4096, T=333), one CFG forward = 2 samples"
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        out = run()
+    dt = time.perf_counter() - t0
+    assert torch.isfinite(out.float()).all()
+    return dict(value=1.0 / (per_image * dt), unit="images/s", cores=cores, kind="port", cpu=cpu_model, mode="full",
+                sample=f"oracle (bf16 torch CPU restatement of the reference) timed on ONE full-depth forward of {what}, the GPU run's own random-init "
+                       f"weights: {dt:.1f} s on {cores} threads; an image = {per_image} such forwards -> images/s = 1 / ({per_image} x {dt:.1f} s)",
+                sample_seconds=dt)
+
+
 def cpu_baseline(model, mode: str = "auto", max_threads: int = 16):
     """The CPU oracle (port of the reference) timed on this box's host cores, rank 0, N = 1 only.
 
@@ -177,121 +210,269 @@ def cpu_baseline(model, mode: str = "auto", max_threads: int = 16):
                 sample_tflops=sample_flops / 1e12, cpu_tflops_per_s=sample_flops / dt / 1e12)
 
 
+# ----------------------------------------------------------------------------------------------------------------------
+# workloads: BASELINE.json configs[1..4]. Each builder returns (model, one_step, info); one_step() = one pass of the hot path over the
+# per-GPU batch (the whole denoise loop of B images), inputs and weights resident in HBM.
+# ----------------------------------------------------------------------------------------------------------------------
+
+def _flux_workload(config, B, rank, dev, small):
+    from unigen_amd.flux import MultiCondtionUniGenFlux, UniGenFlux
+    from unigen_amd.pipeline import denoise_loop, prepare_latent_image_ids
+    from unigen_amd import dist_utils as DU
+    K = 3 if config == "cfg3" else 1
+    cfg = dict(num_layers=2, num_single_layers=4) if small else {}
+    cls = MultiCondtionUniGenFlux if K > 1 else UniGenFlux
+    model = cls.from_config(cfg, device=dev, dtype=torch.bfloat16)
+    model.init_condition_block(condition_nums=K, condition_types=["depth", "canny", "openpose"][:K] if K > 1 else ["canny"],
+                               control_params=dict(CONTROL_PARAMS))
+    model.init_synthetic_(seed=0, std=0.02)
+    grid, T, steps_per_image = 64, 512, 4
+    N, E = grid * grid, model._ctl.expert_nums
+    g = torch.Generator(device=dev).manual_seed(DU.rank_seed(12443, rank))   # reference default seed (infer.py:61) + rank
+    rn = lambda *s: torch.randn(*s, generator=g, device=dev, dtype=torch.float32)
+    latents0 = rn(B, N, 64).to(torch.bfloat16)
+    conds = [rn(B, N, 64).to(torch.bfloat16) for _ in range(K)]
+    prompt = (0.1 * rn(B, T, 4096)).to(torch.bfloat16)
+    pooled = rn(B, 768).to(torch.bfloat16)
+    cpools = [rn(B, 768).to(torch.bfloat16) for _ in range(K)]
+    ids = prepare_latent_image_ids(grid, grid, dev, torch.bfloat16)
+    txt_ids = torch.zeros(T, 3, device=dev, dtype=torch.bfloat16)
+    unis = [[torch.rand(B * N, E, generator=g, device=dev) for _ in range(K)] for _ in range(steps_per_image)]
+    if K == 1:
+        conds, cpools, cids, unis = conds[0], cpools[0], ids, [u[0] for u in unis]
+    else:
+        cids = [ids] * K
+
+    def one_step():
+        return denoise_loop(model, latents=latents0.clone(), control_tokens=conds, prompt_embeds=prompt, pooled_prompt_embeds=pooled,
+                            condition_pooled_prompt_embeds=cpools, text_ids=txt_ids, latent_image_ids=ids, condition_ids=cids,
+                            num_inference_steps=steps_per_image, gate_uniforms=unis)
+
+    n_d, n_s = model.config.num_layers, model.config.num_single_layers
+    fl = steps_per_image * canonical_flops_per_forward(model.inner_dim, N, T, n_d, n_s, model._ctl.cn_joint_layers, model._ctl.cn_single_layers, K)
+    geom = ("N=4096 image + T=512 text tokens, FLUX-schnell geometry 19 double + 38 single blocks D=3072 H=24, 9+19 control blocks, "
+            f"CoMoE E={E}, 4 denoise steps, bf16, random-init weights" + (" [--small DEBUG depth]" if small else ""))
+    return model, one_step, dict(flops_per_image=fl, flops_kind="canonical (SURVEY 8(d))", geom=geom, step="one 4-step denoise loop of the per-GPU batch",
+                                 attn_kernel="flash_attn_kernel<128> (ug_flash_attn_fwd)")
+
+
+def _sd3_workload(B, rank, dev, small):
+    from unigen_amd.sd3 import UniGenSD3
+    from unigen_amd.pipeline import sd3_denoise_loop
+    from unigen_amd import dist_utils as DU
+    model = UniGenSD3.from_config(dict(num_layers=4, dual_attention_layers=(0, 1)) if small else {}, device=dev, dtype=torch.bfloat16)
+    model.init_condition_block(condition_nums=1, condition_types=["depth"], control_params=dict(use_shared_expert=True))   # config/unigen.yaml
+    model.init_synthetic_(seed=0, std=0.02)
+    steps_per_image, T = 28, 333
+    g = torch.Generator(device=dev).manual_seed(DU.rank_seed(12443, rank))
+    rn = lambda *s: torch.randn(*s, generator=g, device=dev, dtype=torch.float32)
+    lat0, cond = rn(B, 16, 128, 128).to(torch.bfloat16), rn(B, 16, 128, 128).to(torch.bfloat16)
+    enc = (0.1 * rn(2 * B, T, 4096)).to(torch.bfloat16)                       # [negative | positive] (src/UniGenPipeline.py:286-290)
+    pooled, cpooled = rn(2 * B, 2048).to(torch.bfloat16), rn(2 * B, 2048).to(torch.bfloat16)
+    unis = [torch.rand(2 * B * 4096, model._ctl.expert_nums, generator=g, device=dev) for _ in range(steps_per_image)]
+
+    def one_step():
+        return sd3_denoise_loop(model, latents=lat0.clone(), control_latents=cond, prompt_embeds=enc, pooled_prompt_embeds=pooled,
+                                condition_pooled_prompt_embeds=cpooled, num_inference_steps=steps_per_image, guidance_scale=7.0, gate_uniforms=unis)
+
+    geom = ("SD3.5-medium geometry 24 joint blocks (13 dual-attention) D=1536 H=24 dh=64 + 24 control blocks, transformer-block experts E=6, "
+            "N=4096 image + T=333 text tokens, classifier-free guidance (2 samples per image-step), 28 denoise steps, bf16, random-init weights"
+            + (" [--small DEBUG depth]" if small else ""))
+    return model, one_step, dict(flops_per_image=None, flops_kind="executed by the GEMM + attention launches (no canonical count for SD3 in SURVEY 8(d))",
+                                 geom=geom, step="one 28-step CFG denoise loop of the per-GPU batch", attn_kernel="flash_attn_kernel<64> (ug_flash_attn_fwd)")
+
+
+def _self_launch(args, argv):
+    """`python bench.py --gpus N` with no torchrun environment: start N ranks ourselves. This parent has not touched the GPU
+    (torch.cuda.device_count() does not initialise it) and never will; every rank is a FRESH child process, no exec of a GPU process."""
+    import socket
+    import subprocess
+    n = args.gpus
+    ndev = torch.cuda.device_count()
+    print(f"[bench] self-launch: {n} ranks; torch.cuda.device_count() = {ndev}", file=sys.stderr, flush=True)
+    sharing = os.environ.get("UG_DIST_BACKEND", "") == "gloo"          # rehearsal: ranks may share a GPU (no RCCL communicator)
+    if not args.dry_run and ndev < n and not sharing:
+        raise SystemExit(f"bench.py --gpus {n}: this node shows only {ndev} GPU(s) (torch.cuda.device_count()); nothing was measured")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                c = p.poll()
+                if c is not None:
+                    pending.remove(p)
+                    if c != 0 and rc == 0:
+                        rc = c
+                        for q in pending:            # one rank failed: the others would wait in a barrier forever
+                            q.terminate()
+            time.sleep(0.2)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    raise SystemExit(rc)
+
+
+def _dry_run(args, world, rank):
+    """Harness rehearsal without a GPU (tests/test_host_cpu.py): rendezvous, barriers, max over ranks and the JSON line, with a sleep as the step."""
+    from unigen_amd import dist_utils as DU
+    dev = torch.device("cpu")
+    rank, world = DU.init_distributed(dev)
+    for _ in range(args.warmup):
+        time.sleep(0.01)
+    DU.barrier(dev, world)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.01 * (1 + rank))
+    DU.barrier(dev, world)
+    elapsed = DU.max_over_ranks(time.perf_counter() - t0, dev, world)
+    if rank == 0:
+        print(json.dumps(dict(metric="DRY RUN (no GPU work): harness rehearsal only", dry_run=True, value=None, unit="images/s", n_gpus=world,
+                              steps=args.steps, warmup=args.warmup, ms_per_step=1000.0 * elapsed / args.steps, higher_is_better=True, scaling="weak",
+                              vs_baseline=None, data="none", config=dict(workload="none"))), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _timed(one_step, steps, warmup, dev, world, timer, ops):
+    from unigen_amd import dist_utils as DU
+    for _ in range(warmup):
+        out = one_step()
+    DU.barrier(dev, world)
+    ops.set_timer(timer)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = one_step()
+    DU.barrier(dev, world)
+    elapsed = time.perf_counter() - t0
+    ops.set_timer(None)
+    if not torch.isfinite(out.float()).all():
+        raise SystemExit("non-finite latents after denoising")
+    return DU.max_over_ranks(elapsed, dev, world), out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=0, help="samples per GPU per step; default 4 at N = 1 (cfg2, the metric's configuration) and 8 at "
-                    "N > 1 (cfg4: global batch 64 = 8 x 8, reference infer.py:173 shards the samples by rank)")
+    ap.add_argument("--config", choices=["cfg2", "cfg3", "cfg4", "cfg5"], default=None,
+                    help="BASELINE.json configs: cfg2 = UniGenFlux canny B=4 (the metric's configuration, default at N = 1); cfg4 = the same model at B=8 per "
+                         "GPU (global 64 on 8 GPUs; default at N > 1); cfg3 = MultiCondtionUniGenFlux depth+canny+openpose B=8; cfg5 = UniGenSD3 depth B=8 (CFG, 28 steps)")
+    ap.add_argument("--batch", type=int, default=0, help="samples per GPU per step; default 4 for cfg2, 8 for cfg3 / cfg4 / cfg5 (reference infer.py:173 shards samples by rank)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline", choices=["auto", "full", "slice", "cfg1"], default="auto",
                     help="full = one full-depth 1024^2 oracle forward x 4 (needs ~90 GB host RAM); cfg1 = BASELINE configs[0] end to end (512^2, B = 1, 4 steps) on CPU and GPU")
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--no-scaling-base", action="store_true", help="N = 1, cfg2 only: skip the extra B = 8 measurement (cfg4's per-GPU shape, the like-for-like base of the 1 -> 8 curve)")
     ap.add_argument("--small", action="store_true", help="debug: reduced depth (NOT the headline configuration)")
-    ap.add_argument("--graph", action="store_true", help="capture one step (the 4-step denoise loop) in a HIP graph and replay it (SURVEY 8(f) rank 1)")
+    ap.add_argument("--graph", action="store_true", help="capture one step (the whole denoise loop) in a HIP graph and replay it (SURVEY 8(f) rank 1)")
+    ap.add_argument("--dry-run", action="store_true", help="no GPU work: rehearse the multi-process harness (spawn, rendezvous, barriers, JSON) on the CPU with gloo")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        _self_launch(args, sys.argv[1:])                                  # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE = {world}: launch with --nproc-per-node {args.gpus}, or without a launcher")
+    if args.dry_run:
+        return _dry_run(args, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: unigen_amd has no CPU path")
-    local_rank = local_rank % max(torch.cuda.device_count(), 1)      # rehearsal: more ranks than GPUs share devices
+    ndev = torch.cuda.device_count()
+    if rank == 0:
+        print(f"[bench] world = {world}; torch.cuda.device_count() = {ndev}", file=sys.stderr, flush=True)
+    if ndev < world and os.environ.get("UG_DIST_BACKEND", "") != "gloo":
+        raise SystemExit(f"bench.py --gpus {world}: this node shows only {ndev} GPU(s); nothing was measured")
+    local_rank = local_rank % max(ndev, 1)                               # rehearsal (UG_DIST_BACKEND=gloo): more ranks than GPUs share devices
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     from unigen_amd import dist_utils as DU
     rank, world = DU.init_distributed(dev)
-    if world > 1:
-        import torch.distributed as dist
-
     from unigen_amd import ops
-    from unigen_amd.flux import UniGenFlux
-    from unigen_amd.pipeline import denoise_loop, prepare_latent_image_ids
 
-    cfg = dict(num_layers=2, num_single_layers=4) if args.small else {}
-    model = UniGenFlux.from_config(cfg, device=dev, dtype=torch.bfloat16)
-    model.init_condition_block(condition_nums=1, condition_types=["canny"], control_params=dict(CONTROL_PARAMS))
-    model.init_synthetic_(seed=0, std=0.02)
-
+    config = args.config or ("cfg2" if world == 1 else "cfg4")
     if args.batch <= 0:
-        args.batch = 4 if world == 1 else 8
-    B, grid, T, steps_per_image = args.batch, 64, 512, 4
-    N = grid * grid
-    g = torch.Generator(device=dev).manual_seed(DU.rank_seed(12443, rank))   # reference default seed (infer.py:61) + rank
-    rn = lambda *s: torch.randn(*s, generator=g, device=dev, dtype=torch.float32)
-    latents0 = rn(B, N, 64).to(torch.bfloat16)
-    control = rn(B, N, 64).to(torch.bfloat16)
-    prompt = (0.1 * rn(B, T, 4096)).to(torch.bfloat16)
-    pooled, cond_pooled = rn(B, 768).to(torch.bfloat16), rn(B, 768).to(torch.bfloat16)
-    ids = prepare_latent_image_ids(grid, grid, dev, torch.bfloat16)
-    txt_ids = torch.zeros(T, 3, device=dev, dtype=torch.bfloat16)
-    uniforms = [torch.rand(B * N, model._ctl.expert_nums, generator=g, device=dev) for _ in range(steps_per_image)]
+        args.batch = 4 if config == "cfg2" else 8
+    B = args.batch
+    if config == "cfg5":
+        model, one_step, info = _sd3_workload(B, rank, dev, args.small)
+    else:
+        model, one_step, info = _flux_workload(config, B, rank, dev, args.small)
 
-    def one_step():
-        lat = latents0.clone()
-        return denoise_loop(model, latents=lat, control_tokens=control, prompt_embeds=prompt, pooled_prompt_embeds=pooled,
-                            condition_pooled_prompt_embeds=cond_pooled, text_ids=txt_ids, latent_image_ids=ids, condition_ids=ids,
-                            num_inference_steps=steps_per_image, gate_uniforms=uniforms)
-
-    def barrier():
-        DU.barrier(dev, world)
-
-    for _ in range(args.warmup):
-        out = one_step()
-    graph = None
     if args.graph:
         # every workspace exists after the warm-up; capture on a side stream as torch requires, then replay on it
         if args.warmup < 1:
             raise SystemExit("--graph needs at least one warm-up step (lazy workspace allocation)")
+        for _ in range(args.warmup):
+            one_step()
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             graph_out = one_step()
-        eager_step = one_step
 
         def one_step():                     # noqa: F811
             graph.replay()
             return graph_out
     timer = None if (args.no_kernel_timer or args.graph) else ops.KernelTimer()
-    barrier()
-    ops.set_timer(timer)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = one_step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    ops.set_timer(None)
-    if not torch.isfinite(out.float()).all():
-        raise SystemExit("non-finite latents after denoising")
-    elapsed = DU.max_over_ranks(elapsed, dev, world)
+    elapsed, out = _timed(one_step, args.steps, args.warmup, dev, world, timer, ops)
+
+    scaling_base = None
+    if world == 1 and config == "cfg2" and B == 4 and not args.no_scaling_base and not args.small and not args.graph:
+        # cfg4's per-GPU share (B = 8) on ONE GPU: the like-for-like base of the 1 -> 8 scaling curve (N > 1 lines run B = 8 per GPU);
+        # measured after the timed region, same model
+        del one_step
+        _, step8, _ = _flux_workload_inputs_only(model, 8, rank, dev)
+        e8, _ = _timed(step8, 2, 1, dev, 1, None, ops)
+        scaling_base = dict(workload="cfg4's per-GPU shape on one GPU: B=8, same model", per_gpu_batch=8, steps=2, warmup=1, value=8 * 2 / e8, unit="images/s",
+                            ms_per_step=1000.0 * e8 / 2, note="divide the N > 1 lines (B = 8 per GPU) by N x THIS value for a like-for-like efficiency")
 
     if rank == 0:
         images = B * args.steps * world
         value = images / elapsed
-        n_d, n_s = model.config.num_layers, model.config.num_single_layers
-        fl_img = steps_per_image * canonical_flops_per_forward(model.inner_dim, N, T, n_d, n_s, model._ctl.cn_joint_layers, model._ctl.cn_single_layers, 1)
-        line = dict(metric="images/sec at 1024^2, FLUX-schnell+canny, 4-step", value=value, unit="images/s", n_gpus=world, steps=args.steps,
+        names = dict(cfg2=f"cfg2: UniGenFlux canny single-condition, 1024x1024, batch={B}, ",
+                     cfg4=f"cfg4: UniGenFlux canny, 1024x1024, global batch {B * world} sharded over {world} x MI355X (B={B} per GPU; 64 = 8 x 8 at N=8), ",
+                     cfg3=f"cfg3: MultiCondtionUniGenFlux depth+canny+openpose multi-condition (per-condition CoMoE, summed), 1024x1024, batch={B}" + (f" per GPU x {world}" if world > 1 else "") + ", ",
+                     cfg5=f"cfg5: UniGenSD3 (SD3.5-medium backbone) depth single-condition, 1024x1024, batch={B}" + (f" per GPU x {world}" if world > 1 else "") + ", ")
+        metric = ("images/sec at 1024^2, FLUX-schnell+canny, 4-step" if config in ("cfg2", "cfg4") else
+                  "images/sec at 1024^2, FLUX-schnell + depth+canny+openpose, 4-step" if config == "cfg3" else "images/sec at 1024^2, SD3.5-medium + depth, 28-step CFG")
+        line = dict(metric=metric, value=value, unit="images/s", n_gpus=world, steps=args.steps,
                     warmup=args.warmup, ms_per_step=1000.0 * elapsed / args.steps, higher_is_better=True, scaling="weak", vs_baseline=None,
                     dtype="bf16", data="synthetic",
-                    config=dict(workload=((f"cfg4: UniGenFlux canny, 1024x1024, global batch {B * world} sharded over {world} x MI355X (B={B} per GPU; 64 = 8 x 8 at N=8), "
-                                           if world > 1 else f"cfg2: UniGenFlux canny single-condition, 1024x1024, batch={B}, ") +
-                                          "N=4096 image + T=512 text tokens, FLUX-schnell geometry 19 double + 38 single blocks D=3072 H=24, 9+19 control blocks, "
-                                          "CoMoE E=6, 4 denoise steps, bf16, random-init weights" + (" [--small DEBUG depth]" if args.small else "")),
-                                per_gpu_batch=B, global_batch=B * world, parallelism=f"dp{world} (independent samples, RCCL barrier only)",
-                                step="one 4-step denoise loop of the per-GPU batch"),
-                    hip_graph=bool(args.graph), flops_per_image_canonical=fl_img, e2e_mfma_frac=value / world * fl_img / (MFMA_BF16_PEAK_TFLOPS * 1e12))
-        if timer is not None:
-            s = timer.summary()
+                    config=dict(workload=names[config] + info["geom"], baseline_config=config, per_gpu_batch=B, global_batch=B * world,
+                                parallelism=f"dp{world} (independent samples, RCCL barrier only)", step=info["step"]),
+                    hip_graph=bool(args.graph), device_count=ndev)
+        s = timer.summary() if timer is not None else {}
+        fl_img = info["flops_per_image"]
+        if fl_img is None and s:
+            fl_img = sum(d["flops"] for d in s.values()) / (B * args.steps)
+        if fl_img is not None:
+            line["flops_per_image"] = fl_img
+            line["flops_per_image_kind"] = info["flops_kind"]
+            if config in ("cfg2", "cfg4"):
+                line["flops_per_image_canonical"] = fl_img
+            line["e2e_mfma_frac"] = value / world * fl_img / (MFMA_BF16_PEAK_TFLOPS * 1e12)
+        if scaling_base is not None:
+            line["scaling_base"] = scaling_base
+        if s:
             gm, at = s.get("gemm"), s.get("attn")
             ach = gm["flops"] / (gm["ms"] * 1e-3) / 1e12
             traffic, traffic_note, pmc = None, None, {}
             cands = sorted(p for p in os.listdir(os.path.join(ROOT, "profiles")) if p.endswith("_pmc.json"))      # newest round's PMC summary
             tf = os.path.join(ROOT, "profiles", cands[-1] if cands else "r01_hbm_traffic.json")
-            if os.path.exists(tf) and not args.small and B == 4:      # PMC passes of this same command (see the file's `source`, tools/pmc_summary.py)
+            if os.path.exists(tf) and not args.small and config == "cfg2" and B == 4:      # PMC passes of this same command (see the file's `source`, tools/pmc_summary.py)
                 with open(tf) as f:
                     tj = json.load(f)
                 traffic = tj["kernels"]["gemm_all"]["hbm_bytes_per_launch"]
@@ -313,18 +494,44 @@ def main():
                                     share_of_step_time=gm["ms"] * 1e-3 / elapsed)
             if at:
                 a2 = at["flops"] / (at["ms"] * 1e-3) / 1e12
-                line["roofline_attention"] = dict(bound="mfma", kernel="flash_attn128_kernel (ug_flash_attn_fwd)", achieved=a2, peak=MFMA_BF16_PEAK_TFLOPS,
+                line["roofline_attention"] = dict(bound="mfma", kernel=info["attn_kernel"], achieved=a2, peak=MFMA_BF16_PEAK_TFLOPS,
                                                   unit="TFLOP/s", frac=a2 / MFMA_BF16_PEAK_TFLOPS, peak_measured=pk32, frac_of_measured=a2 / pk32,
                                                   launches=at["launches"],
                                                   avg_launch_us=1000.0 * at["ms"] / at["launches"], share_of_step_time=at["ms"] * 1e-3 / elapsed)
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(model, args.cpu_baseline)
+            if config in ("cfg3", "cfg5"):
+                line["cpu_baseline"] = cpu_baseline_other(model, config)
+            else:
+                line["cpu_baseline"] = cpu_baseline(model, args.cpu_baseline)
+                if line["cpu_baseline"]["mode"] == "slice":           # never silently: the estimate is named in the workload too
+                    line["config"]["workload"] += " [cpu_baseline: FLOP-scaled SLICE estimate, host RAM below 90 GB]"
             line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
-            line["parity"] = fixture_parity(dev)
+            if config != "cfg5":
+                line["parity"] = fixture_parity(dev)
         print(json.dumps(line), flush=True)
     if world > 1:
+        import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _flux_workload_inputs_only(model, B, rank, dev):
+    """A second batch size on an existing UniGenFlux (the B = 8 scaling base): same input recipe as _flux_workload."""
+    from unigen_amd.pipeline import denoise_loop, prepare_latent_image_ids
+    from unigen_amd import dist_utils as DU
+    grid, T = 64, 512
+    N, E = grid * grid, model._ctl.expert_nums
+    g = torch.Generator(device=dev).manual_seed(DU.rank_seed(12443, rank) + 1000)
+    rn = lambda *s: torch.randn(*s, generator=g, device=dev, dtype=torch.float32)
+    lat, cond = rn(B, N, 64).to(torch.bfloat16), rn(B, N, 64).to(torch.bfloat16)
+    prompt, pooled, cpool = (0.1 * rn(B, T, 4096)).to(torch.bfloat16), rn(B, 768).to(torch.bfloat16), rn(B, 768).to(torch.bfloat16)
+    ids = prepare_latent_image_ids(grid, grid, dev, torch.bfloat16)
+    txt = torch.zeros(T, 3, device=dev, dtype=torch.bfloat16)
+    unis = [torch.rand(B * N, E, generator=g, device=dev) for _ in range(4)]
+    step = lambda: denoise_loop(model, latents=lat.clone(), control_tokens=cond, prompt_embeds=prompt, pooled_prompt_embeds=pooled,
+                                condition_pooled_prompt_embeds=cpool, text_ids=txt, latent_image_ids=ids, condition_ids=ids, num_inference_steps=4,
+                                gate_uniforms=unis)
+    return model, step, None
 
 
 if __name__ == "__main__":

@@ -580,3 +580,36 @@ def test_control_modules_start_from_the_reference_initial_values(cls):
     wg = sd["moe.moe_layer.gate.wg.weight"].float()
     assert float((wg[0] - wg[1]).abs().max()) > 0
     assert all(p.requires_grad is False for p in m.parameters())
+
+
+def _run_bench(args, env_extra=None, timeout=180):
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py"), *args], capture_output=True, text=True, timeout=timeout, env=env, cwd=root)
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus N` with NO launcher must work (the driver's N = 1 form; reference script/infer.sh:49-67 starts
+    one process per GPU). The parent spawns one fresh child per rank before anything touches a GPU; here the harness is rehearsed on the
+    CPU (gloo, --dry-run: no GPU work, value null): rendezvous, barriers, max over ranks, exactly one JSON line from rank 0."""
+    import json
+    r = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--dry-run"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["dry_run"] is True and d["value"] is None and d["steps"] == 2 and d["scaling"] == "weak"
+    assert d["ms_per_step"] >= 19.0                       # MAX over ranks: rank 1 sleeps 20 ms per step, rank 0 only 10
+    assert "torch.cuda.device_count() = 0" in r.stderr
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """Without --dry-run the launcher prints the device count and fails clearly when the node has fewer GPUs than ranks (never fabricates)."""
+    r = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0"])
+    assert r.returncode != 0 and "shows only 0 GPU(s)" in (r.stderr + r.stdout)
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    # a torchrun-style environment whose world size disagrees with --gpus is an error too
+    r = _run_bench(["--gpus", "2", "--dry-run"], env_extra=dict(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
