@@ -44,7 +44,11 @@ with torch.no_grad():
     out16 = m16(timestep=t.to(dev), **{k: mv(v) for k, v in inp.items()})[0].float().cpu()
     st16 = {k: v.detach().cpu() for k, v in m16.state_dict().items()}
     sd16 = dict(m16.state_dict())
-    t0 = time.perf_counter(); ref16 = R_forward(st16, cfg, timestep=t, dtype=BF, **inp)[0].float(); res["oracle_bf16_s"] = round(time.perf_counter() - t0, 1)
+    NO_REF16 = "--no-ref16" in sys.argv          # the test suite's 1024^2 case: skip the oracle's own bf16 evaluation (65 s of host time; its ratio to the HIP bf16 error is pinned at N = 1024)
+    if NO_REF16:
+        ref16 = None
+    else:
+        t0 = time.perf_counter(); ref16 = R_forward(st16, cfg, timestep=t, dtype=BF, **inp)[0].float(); res["oracle_bf16_s"] = round(time.perf_counter() - t0, 1)
     print("bf16 done", res, flush=True)
     m32 = UniGenFlux.from_config({}, device=dev, dtype=torch.float32)
     m32.init_condition_block(condition_nums=NC, condition_types=list(CT), control_params=dict(CTL))
@@ -60,5 +64,6 @@ with torch.no_grad():
     print("hip f32 done", res, flush=True)
     t0 = time.perf_counter(); truth = R_forward(st32, cfg, timestep=t, dtype=torch.float32, **inp)[0]; res["oracle_f32_s"] = round(time.perf_counter() - t0, 1)
 res.update(workload=("UniGenSD3, SD3.5-medium depth and width, N=1024, T=333, B=1" if SD3 else ("MultiCondtionUniGenFlux (3 conditions, E = 12), " if MULTI else "") + f"one forward at full depth and width, {16 * GRID}^2 (N={GRID * GRID}, T=512), B=1"), rel_l2_hip_f32_vs_oracle_f32=rel(out32, truth),
-           rel_l2_hip_bf16_vs_oracle_f32=rel(out16, truth), rel_l2_oracle_bf16_vs_oracle_f32=rel(ref16, truth), rel_l2_hip_bf16_vs_oracle_bf16=rel(out16, ref16))
+           rel_l2_hip_bf16_vs_oracle_f32=rel(out16, truth), rel_l2_oracle_bf16_vs_oracle_f32=(rel(ref16, truth) if ref16 is not None else None),
+           rel_l2_hip_bf16_vs_oracle_bf16=(rel(out16, ref16) if ref16 is not None else None))
 print("FULLSIZE_PARITY", json.dumps(res))

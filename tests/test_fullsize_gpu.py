@@ -270,14 +270,17 @@ def test_full_model_forward_parity(gpu, which):
     "sd3":    UniGenSD3 at SD3.5-medium size (24 joint blocks with dual attention in 0-12, D = 1536, 24 heads of 64; N = 1024, T = 333)."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    argv = {"flux64": ["flux", "64"], "multi": ["multi"], "sd3": ["sd3"]}[which]
+    argv = {"flux64": ["flux", "64", "--no-ref16"], "multi": ["multi"], "sd3": ["sd3"]}[which]
     p = subprocess.run([sys.executable, os.path.join(root, "tests", "fullsize_f32_parity.py"), *argv], capture_output=True, text=True, timeout=1100, cwd=root)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     line = [l for l in p.stdout.splitlines() if l.startswith("FULLSIZE_PARITY")][-1]
     r = json.loads(line[len("FULLSIZE_PARITY "):])
     print(line)
     assert r["rel_l2_hip_f32_vs_oracle_f32"] <= 1e-3, r
-    assert r["rel_l2_hip_bf16_vs_oracle_f32"] <= 1.25 * r["rel_l2_oracle_bf16_vs_oracle_f32"] + 1e-3, r
+    if r["rel_l2_oracle_bf16_vs_oracle_f32"] is not None:
+        assert r["rel_l2_hip_bf16_vs_oracle_f32"] <= 1.25 * r["rel_l2_oracle_bf16_vs_oracle_f32"] + 1e-3, r
+    else:       # flux64: the oracle's own bf16 evaluation (2.11e-2 at this size, round 2) is not re-run inside the suite's time budget
+        assert r["rel_l2_hip_bf16_vs_oracle_f32"] <= 2.8e-2, r
 
 
 def test_full_depth_gradient_parity(gpu):

@@ -79,6 +79,84 @@ __global__ __launch_bounds__(256) void adaln_modulate_kernel(
     }
 }
 
+// Fast path of the same op for the model widths (bf16, D = NCH * 512 exactly: 3072 FLUX, 1536 SD3.5, 4096): round 3.
+// The generic kernel above puts every `if (c < nchunk)` load in its own basic block, and hipcc waits vmcnt(0) behind each one: six
+// dependent HBM round trips per row (~4 TB/s, and only by occupancy). Here a wave issues its whole row (NCH x 16 B per lane) and the
+// sample's shift / scale chunks back to back with no branch in between, keeps the row PACKED (NCH x 4 registers instead of NCH x 8 floats),
+// and reduces with DPP row operations + 4 v_readlane instead of 12 dependent ds_bpermute (each an LDS crossbar round trip with its own
+// lgkmcnt(0)). Same formula and rounding points; only the association of the two fp32 row sums differs from the generic kernel.
+#define UG_DPP_ADD(V, CTRL) ((V) + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (V)), (CTRL), 0xf, 0xf, true)))
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    v = UG_DPP_ADD(v, 0xB1);      // quad_perm [1,0,3,2]: lane ^ 1
+    v = UG_DPP_ADD(v, 0x4E);      // quad_perm [2,3,0,1]: lane ^ 2
+    v = UG_DPP_ADD(v, 0x141);     // row_half_mirror: the other quad of the 8-lane half row
+    v = UG_DPP_ADD(v, 0x140);     // row_mirror: the other half of the 16-lane row -> every lane holds its row's sum
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+    return (r0 + r1) + (r2 + r3);
+}
+
+template <int NCH>
+__global__ __launch_bounds__(256) void adaln_modulate_fast_kernel(
+    const bf16_t* __restrict__ x, int64_t ldx, unsigned x_rpb, unsigned x_bstride,
+    const bf16_t* __restrict__ shift, const bf16_t* __restrict__ scale, int64_t mod_ld, unsigned rows_per_sample,
+    bf16_t* __restrict__ out, int64_t ldo, unsigned rows, float eps) {
+    constexpr int D = NCH * 512;
+    const int lane = threadIdx.x & 63;
+    const unsigned row = blockIdx.x * 4u + (unsigned)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // scalar: the row maps below are SALU
+    if (row >= rows) return;
+    unsigned prow = row;
+    if (x_rpb) { const unsigned b = row / x_rpb; prow = b * x_bstride + (row - b * x_rpb); }
+    const bf16_t* xr = x + (int64_t)prow * ldx + lane * 8;
+    u32x4 xv[NCH];
+#pragma unroll
+    for (int t = 0; t < NCH; ++t) xv[t] = __builtin_nontemporal_load((const u32x4*)(xr + t * 512));      // read once: do not displace the GEMM operands in L2
+    const unsigned b = row / rows_per_sample;
+    const bf16_t* sh = shift + (int64_t)b * mod_ld + lane * 8;
+    const bf16_t* sc = scale + (int64_t)b * mod_ld + lane * 8;
+    u32x4 shv[NCH], scv[NCH];
+#pragma unroll
+    for (int t = 0; t < NCH; ++t) { shv[t] = *(const u32x4*)(sh + t * 512); scv[t] = *(const u32x4*)(sc + t * 512); }
+    __builtin_amdgcn_sched_barrier(0);                     // every load is in flight before the first use
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < NCH; ++t) {
+        float f[8]; unpack8(xv[t], f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += f[e];
+    }
+    const float mean = wave_sum_dpp(s) / (float)D;
+    // the row stays packed between the passes: an opaque use stops hipcc from keeping all NCH x 8 unpacked floats alive (133 registers, 3 waves
+    // per SIMD) - the unpack is two VALU ops per pair and this kernel waits on memory
+#pragma unroll
+    for (int t = 0; t < NCH; ++t) asm volatile("" : "+v"(xv[t]));
+    float q = 0.f;
+#pragma unroll
+    for (int t = 0; t < NCH; ++t) {
+        float f[8]; unpack8(xv[t], f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = f[e] - mean; q += d * d; }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum_dpp(q) / (float)D + eps);
+#pragma unroll
+    for (int t = 0; t < NCH; ++t) asm volatile("" : "+v"(xv[t]), "+v"(shv[t]), "+v"(scv[t]));
+    bf16_t* orow = out + (int64_t)row * ldo + lane * 8;
+#pragma unroll
+    for (int t = 0; t < NCH; ++t) {
+        float f[8], fs[8], fc[8], o[8];
+        unpack8(xv[t], f); unpack8(shv[t], fs); unpack8(scv[t], fc);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float n = rbf((f[e] - mean) * rstd);     // LayerNorm output (bf16 tensor in the reference)
+            const float s1 = rbf(1.0f + fc[e]);            // (1 + scale)
+            o[e] = rbf(n * s1) + fs[e];                    // * then +, each a bf16 op in the reference (the + is rounded by the pack)
+        }
+        *(u32x4*)(orow + t * 512) = pack8(o);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // q/k RMSNorm + RoPE, in place on the fused projection buffer. DH/8 lanes per head vector.
 // reference: diffusers RMSNorm (Attention.norm_q/k, norm_added_q/k) + apply_rotary_emb; src/UniGenUtils.py:561-599
@@ -424,6 +502,18 @@ int adaln_modulate_impl(const void* x, int64_t ldx, int64_t x_rpb, int64_t x_bst
     UG_REQUIRE(ldx % 8 == 0 && ldo % 8 == 0 && mod_ld % 8 == 0 && ug_aligned(x, 16) && ug_aligned(out, 16) &&
                ug_aligned(shift, 16) && ug_aligned(scale, 16), UG_ERR_BAD_ALIGN, "ug_adaln_modulate: 16-byte alignment required");
     const unsigned grid = (unsigned)((rows + 3) / 4);
+    if constexpr (!ElemT<T>::kF32) {
+        // model widths: the branch-free kernel (UG_ADALN_FAST=0 keeps the generic one, for A/B and as the reference of the bit-equality test)
+        const bool fits32 = rows < (1ll << 31) && x_rpb < (1ll << 31) && x_bstride < (1ll << 31) && rows_per_sample < (1ll << 31) && x_rpb >= 0;
+        if (fits32 && (D == 1536 || D == 3072 || D == 4096) && ug_env_int("UG_ADALN_FAST", 1)) {
+#define UG_ADALN_GO(NCH) hipLaunchKernelGGL(adaln_modulate_fast_kernel<NCH>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, (unsigned)x_rpb, \
+            (unsigned)x_bstride, (const bf16_t*)shift, (const bf16_t*)scale, mod_ld, (unsigned)rows_per_sample, (bf16_t*)out, ldo, (unsigned)rows, eps)
+            if (D == 1536) UG_ADALN_GO(3); else if (D == 3072) UG_ADALN_GO(6); else UG_ADALN_GO(8);
+#undef UG_ADALN_GO
+            UG_CHECK_LAUNCH("ug_adaln_modulate");
+            return UG_OK;
+        }
+    }
     hipLaunchKernelGGL(adaln_modulate_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)x, ldx, x_rpb,
                        x_bstride, (const T*)shift, (const T*)scale, mod_ld, rows_per_sample, (T*)out, ldo, rows, (int)D, eps);
     UG_CHECK_LAUNCH("ug_adaln_modulate");
