@@ -555,6 +555,53 @@ sys.exit(1 if bad else 0)
     assert r.returncode == 0, r.stdout + r.stderr
 
 
+def test_gemm_whole_line_one_wave_per_simd_kernel_matches_default(gpu):
+    """Round 3: gemm_pwg64_kernel (UG_GEMM_PWG=3) - one wave per SIMD, 4 x (128 x 128), 64-deep ring units of whole 128-byte
+    lines, one barrier per K-tile. A measurement build of that main loop (whole 256^2 tiles only): same MFMA shape and K order as the 8-phase
+    kernel -> bit-identical, on every epilogue it carries, K = 192 (shorter than the ring) .. 3072, a row-mapped A, several tiles per workgroup."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import os, sys
+os.environ["UG_ENV_DYNAMIC"] = "1"
+sys.path.insert(0, %r)
+import torch
+from unigen_amd import ops, lib as L
+from unigen_amd.ops import RowMap
+dev = torch.device("cuda:0")
+g = torch.Generator(device=dev).manual_seed(0)
+rn = lambda *s: torch.randn(*s, generator=g, device=dev).to(torch.bfloat16)
+bad = 0
+for (M, N, K, epi, mapped) in [(512, 512, 192, L.EPI_BIAS, False), (1024, 768, 3072, L.EPI_BIAS_GELU, False), (768, 256, 320, L.EPI_RES_GATE, False),
+                               (512, 512, 256, L.EPI_RES_SCALE, True), (8192, 3072, 1024, L.EPI_BIAS, False), (256, 256, 576, L.EPI_BIAS, False)]:
+    rows = M // 2 if mapped else 0
+    a = rn(M + (128 if mapped else 0), K)                 # mapped: two batches of M / 2 rows at a stride of M / 2 + 64 rows
+    w, b = rn(N, K) * 0.1, rn(N)
+    r, gate = rn(M, N), rn(M // 256, N)
+    outs = []
+    for mode in ("0", "3"):
+        os.environ["UG_GEMM_PWG"] = mode
+        out = torch.zeros(M, N, device=dev, dtype=torch.bfloat16)
+        kw = dict(M=M, epilogue=epi)
+        if mapped:
+            kw.update(a_map=RowMap(rows, rows + 64))
+        if epi in (L.EPI_RES_GATE, L.EPI_RES_SCALE):
+            kw.update(residual=r, alpha=0.7)
+        if epi == L.EPI_RES_GATE:
+            kw.update(gate=gate, gate_ld=N, rows_per_sample=256)
+        ops.gemm(a, w, b, out, **kw)
+        outs.append(out)
+    torch.cuda.synchronize()
+    ref = (a.float()[:M] if not mapped else torch.cat([a.float()[:rows], a.float()[rows + 64:2 * rows + 64]])) @ w.float().t()
+    if not torch.equal(outs[0], outs[1]) or not torch.isfinite(outs[1].float()).all() or (epi == L.EPI_BIAS and float(((outs[1].float() - b.float()) - ref).norm() / ref.norm()) > 1e-2):
+        bad += 1
+        print("MISMATCH", M, N, K, epi, mapped, float((outs[1].float() - outs[0].float()).abs().max()))
+sys.exit(1 if bad else 0)
+""" % root
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
 def test_gemm_lora_segment_in_256_kernel_matches_128(gpu):
     """The LoRA K-segment (T . B^T appended to the K loop, src/lora_switching_module.py:11-38) runs in BOTH tile kernels; same MFMA shape and
     K order -> bit-identical. Shapes where the dispatcher picks the 256^2 kernel, ragged M, 1-2 LoRA K-tiles, K = 128 (shortest) .. 320."""

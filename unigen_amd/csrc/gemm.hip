@@ -178,6 +178,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
     const int nM = (int)((M + 255) / 256), nN = (int)((N + 255) / 256);
     const int st_off = wave * 16 * 128;
     const int wide16 = wide16_gm & 1;            // bits 8.. of the argument: GROUP_M of the tile walk (0 = 8)
+    const bool rows_contig = (wide16_gm & 2) != 0;   // the C (and R) row maps never split a 256-row tile (rows per batch % 256 == 0): one scalar map per tile
     int a_off, b_off, ch0, ch1;          // fragment read offsets; set per tile (see the tile loop)
     // LORA: the K loop runs on through a second segment, T[m][0..r) . B[n][0..r) (the same K-segment the 128^2 kernel appends), with
     // the staging pointers of a half-tile pair swapped to the LoRA operands (pre-biased by -K) just before their first LoRA K-tile.
@@ -409,7 +410,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
         constexpr int EPI_A = EPI == UG_EPI_QKV_ROPE ? UG_EPI_BIAS_GELU : EPI;      // what a tile outside the q | k columns runs
         bool qk_tile = false;
         if constexpr (EPI == UG_EPI_QKV_ROPE) qk_tile = n0 < p.qk_until_n;
-        bool fast = EPI != UG_EPI_F32 && wide16 && m0 + 256 <= M && n0 + 256 <= N && rem < 0;
+        bool fast = EPI != UG_EPI_F32 && wide16 && rows_contig && m0 + 256 <= M && n0 + 256 <= N && rem < 0;
         unsigned sample = 0;
         if constexpr (EPI == UG_EPI_RES_GATE) {
             sample = (unsigned)m0 / (unsigned)p.rows_per_sample;
@@ -539,9 +540,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
                 const unsigned rr0 = rpb ? mrow % rpb : mrow;
                 u32x4 cbuf[2][2];
                 bf16_t* cp[2];
+                bf16_t* const c_lane = Cb + (int64_t)(rowmap32((unsigned)m0, (unsigned)p.c_rpb, (unsigned)p.c_bstride) + (unsigned)(wr * 64 + (lane_e & 15))) * p.ldc;
                 auto open_rows = [&](int rg) {
-                    const unsigned m = mrow + (rg >> 2) * 128 + (rg & 3) * 16;
-                    cp[rg & 1] = Cb + (int64_t)rowmap32(m, (unsigned)p.c_rpb, (unsigned)p.c_bstride) * p.ldc;
+                    cp[rg & 1] = c_lane + (int64_t)((rg >> 2) * 128 + (rg & 3) * 16) * p.ldc;      // rows_contig: one scalar row map per tile
                     unsigned rr = rr0 + (rg >> 2) * 128 + (rg & 3) * 16;
                     if (rr >= wrap) rr -= wrap;
                     const float* q = csb + ((int64_t)p.rope_pos0 + rr) * QKDH;
@@ -598,14 +599,20 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
             const TileSplit ts = tile_split<EPI>(p, n0);
             bf16_t* const Cb = (bf16_t*)p.C + (int64_t)g * p.c_gstride + colb + ts.cshift;
             const bf16_t* const Rb = RES ? (const bf16_t*)p.R + (int64_t)g * p.r_gstride + colb : nullptr;
-            const unsigned mrow = (unsigned)m0 + wr * 64 + (lane_e & 15);
+            // Row maps: ONE scalar map per tile (rows_contig: a tile's 256 rows are consecutive in C and in R), this lane's row pointer
+            // once, then a wave-uniform offset per row-group. (Round 2 mapped every row-group's row with a 32-bit division per map and a
+            // 64-bit multiply: ~45 of the ~190 VALU instructions per row-group of this VALU-bound epilogue.)
+            const int rl = wr * 64 + (lane_e & 15);
+            bf16_t* const c_lane = Cb + (int64_t)(rowmap32((unsigned)m0, (unsigned)p.c_rpb, (unsigned)p.c_bstride) + (unsigned)rl) * p.ldc;
+            const bf16_t* r_lane = nullptr;
+            if constexpr (RES) r_lane = Rb + (int64_t)(rowmap32((unsigned)m0, (unsigned)p.r_rpb, (unsigned)p.r_bstride) + (unsigned)rl) * p.ldr;
             u32x4 rbuf[2][2];
             bf16_t* cp[2];
             auto open_rows = [&](int rg) {
-                const unsigned m = mrow + (rg >> 2) * 128 + (rg & 3) * 16;
-                cp[rg & 1] = Cb + (int64_t)rowmap32(m, (unsigned)p.c_rpb, (unsigned)p.c_bstride) * p.ldc;
+                const int off = (rg >> 2) * 128 + (rg & 3) * 16;
+                cp[rg & 1] = c_lane + (int64_t)off * p.ldc;
                 if constexpr (RES) {
-                    const bf16_t* rp = Rb + (int64_t)rowmap32(m, (unsigned)p.r_rpb, (unsigned)p.r_bstride) * p.ldr;
+                    const bf16_t* rp = r_lane + (int64_t)off * p.ldr;
                     rbuf[rg & 1][0] = gload16_asm(rp);
                     rbuf[rg & 1][1] = gload16_asm_256(rp);
                 } else {
@@ -723,10 +730,11 @@ int launch(const ug_gemm_desc& d, hipStream_t s) {
         dim3 grid((unsigned)(total < ncu ? total : ncu), 1, 1);
         // 16-byte epilogue accesses need 8-column granularity everywhere the epilogue touches
         const bool res = d.epilogue == UG_EPI_RES_GATE || d.epilogue == UG_EPI_RES_SCALE;
-        const int wide16 = d.N % 8 == 0 && d.ldc % 8 == 0 && d.c_gstride % 8 == 0 && ug_aligned(d.C, 16) &&
-                           (!res || (d.ldr % 8 == 0 && d.r_gstride % 8 == 0 && ug_aligned(d.R, 16)));
+        const int wide16 = (d.N % 8 == 0 && d.ldc % 8 == 0 && d.c_gstride % 8 == 0 && ug_aligned(d.C, 16) &&
+                            (!res || (d.ldr % 8 == 0 && d.r_gstride % 8 == 0 && ug_aligned(d.R, 16)))) |
+                           ((d.c_rpb % 256 == 0 && (!res || d.r_rpb % 256 == 0) && ug_env_int("UG_GEMM_EPI_ROWS_CONTIG", 1)) ? 2 : 0);
         // UG_GEMM_PWG=1: the one-wave-per-SIMD kernel (gemm_pwg.hip) takes every shape it supports
-        if (EPI != UG_EPI_F32 && wide16 && !lora && ug_env_int("UG_GEMM_PWG", 0)) return ug_gemm_launch_pwg(d, s);
+        if (EPI != UG_EPI_F32 && (wide16 & 1) && !lora && ug_env_int("UG_GEMM_PWG", 0)) return ug_gemm_launch_pwg(d, s);
         // split-K tail (see the kernel header): needs the caller's workspace for the slabs and tickets
         int full = total, nsl = 1;
         // M-tiles per group of the tile walk. In the cfg2 forward (same box, bench.py x 2 each): 4 -> 2.014 images/s / GEMM 1337 TFLOP/s,
@@ -790,7 +798,9 @@ int launch_qkrope(const ug_gemm_desc& d, hipStream_t s) {
         if (ncu <= 0) ncu = 256;
     }
     const int total = (int)((d.M / 256) * (d.N / 256));
-    const int wgm = 1 | ((ug_env_int("UG_GEMM_GROUP_M", 4) & 0xff) << 8);
+    UG_REQUIRE(d.c_rpb % 256 == 0, UG_ERR_UNSUPPORTED, "ug_gemm_bf16: UG_EPI_QKV_ROPE needs the C row map's rows per batch (%lld) to be a multiple of 256",
+               (long long)d.c_rpb);
+    const int wgm = 3 | ((ug_env_int("UG_GEMM_GROUP_M", 4) & 0xff) << 8);
     const dim3 grid((unsigned)(total < ncu ? total : ncu));
     if (qdh == 128)
         hipLaunchKernelGGL((gemm256_kernel<UG_EPI_QKV_ROPE, false, 128>), grid, dim3(512), LDS, s, d, total, total, wgm, total, 1, (float*)nullptr, (unsigned*)nullptr);

@@ -210,6 +210,13 @@ __device__ __forceinline__ void ug_wait_vm(u32x4& a, u32x4& b) {
     asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory");
 }
 
+// bf16 rounding of a PAIR: one v_cvt_pk_bf16_f32 + two unpacks (1.5 instructions per value; rounding value by value hipcc emitted a
+// cvt_pk with a zero second operand per value: 2 per value - the full-tile epilogue is VALU-bound, both waves of a SIMD run it at once)
+__device__ __forceinline__ void rbf2(float& a, float& b) {
+    const unsigned u = pack2bf(a, b);
+    a = bflo(u); b = bfhi(u);
+}
+
 template <int EPI>
 __device__ __forceinline__ u32x4 epi_chunk_full(const float alpha, const f32x4 ax, const f32x4 ay, const float* bx, const float* by,
                                                 const float* gx, const float* gy, const u32x4 r) {
@@ -217,8 +224,7 @@ __device__ __forceinline__ u32x4 epi_chunk_full(const float alpha, const f32x4 a
 #pragma unroll
     for (int q = 0; q < 4; ++q) { vx[q] = ax[q] + bx[q]; vy[q] = ay[q] + by[q]; }
     if constexpr (EPI != UG_EPI_BIAS) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { vx[q] = rbf(vx[q]); vy[q] = rbf(vy[q]); }      // the Linear's bf16 output
+        rbf2(vx[0], vx[1]); rbf2(vx[2], vx[3]); rbf2(vy[0], vy[1]); rbf2(vy[2], vy[3]);      // the Linear's bf16 output
     }
     if constexpr (EPI == UG_EPI_BIAS_GELU) {
 #pragma unroll
@@ -231,8 +237,11 @@ __device__ __forceinline__ u32x4 epi_chunk_full(const float alpha, const f32x4 a
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float sx = EPI == UG_EPI_RES_GATE ? gx[q] : alpha, sy = EPI == UG_EPI_RES_GATE ? gy[q] : alpha;
-            vx[q] = rx[q] + rbf(sx * vx[q]); vy[q] = ry[q] + rbf(sy * vy[q]);
+            vx[q] = sx * vx[q]; vy[q] = sy * vy[q];
         }
+        rbf2(vx[0], vx[1]); rbf2(vx[2], vx[3]); rbf2(vy[0], vy[1]); rbf2(vy[2], vy[3]);      // gate * v / alpha * v as a bf16 tensor
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { vx[q] = rx[q] + vx[q]; vy[q] = ry[q] + vy[q]; }
     }
     unsigned x0 = pack2bf(vx[0], vx[1]), x1 = pack2bf(vx[2], vx[3]);
     unsigned y0 = pack2bf(vy[0], vy[1]), y1 = pack2bf(vy[2], vy[3]);

@@ -191,6 +191,180 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gemm_pwg_kernel(const ug_gemm
     }
 }
 
+// =====================================================================================================================
+// Round 3: the WHOLE-LINE variant of the one-wave-per-SIMD structure ("build, do not estimate").
+// The kernel above moves its operands in 64-byte row pieces (32-deep K-steps: two requests per 128-byte L2 line), which caps its
+// intake at ~46 GB/s per CU. Here the ring unit is ONE OPERAND of a 64-deep K-tile: 256 rows x 128 bytes = 32 KiB, whole lines, the same
+// swizzled image as gemm256_kernel (16-byte chunk c of row r at position c ^ (r & 7)); a 1-KiB LDS-DMA piece is 8 rows x 128 B.
+// Five units fill the 160 KiB of LDS; unit index u = 2 T (A of K-tile T) or 2 T + 1 (W of K-tile T) lives in slot u % 5.
+// Compute steps stay 32 deep (64 MFMAs of 16x16x32 per wave against 16 ds_read_b128 for the NEXT step's fragments, accumulators in
+// AGPRs); K-tile T = steps 2 T (chunks 0-3 of a row) and 2 T + 1 (chunks 4-7). A(T) and W(T) are free once the fragments of step
+// 2 T + 1 are in registers, i.e. at the barrier on top of step 2 T + 1 - the ONLY barrier per K-tile (2048 MFMA cycles). Refill:
+//   step 2 T + 1 issues W(T + 2) into A(T)'s slot, step 2 T + 2 issues A(T + 3) into W(T)'s slot (8 pieces per wave and step);
+//   the top of step 2 T + 1 waits vmcnt(8): everything but A(T + 2) - in particular A(T + 1), W(T + 1), read during this step - landed.
+// W units have 1-2 steps of lead, A units 3-4. Epilogue: the generic one of the kernel above (this is a measurement build of the
+// main loop, reachable through UG_GEMM_PWG=3; the fused epilogues / split-K tail / LoRA segment live in gemm256_kernel).
+// =====================================================================================================================
+constexpr int QU = 256 * 64 * 2;               // bytes of one ring unit (32 KiB)
+constexpr int QRING = 5;
+
+template <int EPI, int VAR>
+__global__ __launch_bounds__(256, 1) void gemm_pwg64_kernel(const ug_gemm_desc p, const int tiles_per_group, const int total_tiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int64_t M = p.M, N = p.N;
+    const int nM = (int)((M + 255) / 256), nN = (int)((N + 255) / 256);
+    const int nkt = (int)(p.K / 64);
+    const int nsteps = 2 * nkt;
+
+    for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+        // lane-derived constants of the K loop, re-derived per tile from an opaque copy of the lane id: kept live across the tile loop they were
+        // spilled around the epilogue (which moves 256 accumulators through the VGPRs) and reloaded - with a vmcnt(0) - inside the step loop
+        int lane_m = lane;
+        asm volatile("" : "+v"(lane_m));
+        const int frow = lane_m & 15, fch = lane_m >> 4;
+        // fragment byte offsets inside a unit for k-half 0 / 1 (chunks fch / 4 + fch), before the 16-row tile offset t * 2048
+        const int a_row = (wr * 128 + frow) * 128, b_row = (wc * 128 + frow) * 128;
+        const int ch_h0 = ((fch ^ (frow & 7)) << 4), ch_h1 = (((4 + fch) ^ (frow & 7)) << 4);
+        const int g = tile / tiles_per_group;
+        const TileCoord tc = tile_of_block(tile - g * tiles_per_group, nM, nN, 4);
+        const int64_t m0 = (int64_t)tc.tm * 256, n0 = (int64_t)tc.tn * 256;
+        // staging sources: wave w stages rows [64 w, 64 w + 64) of every unit, 8 rows (1 KiB) per piece. Whole tiles only (the launcher checks
+        // M, N, the A row map's rows-per-batch are multiples of 256): piece i is piece 0 plus i * 8 rows, so two 64-bit lane pointers and
+        // wave-uniform byte offsets replace sixteen lane pointers (32 registers: the first build spilled 80)
+        const bf16_t* a0; const bf16_t* b0;
+        {
+            const bf16_t* Ab = (const bf16_t*)p.A + (int64_t)g * p.a_gstride;
+            const bf16_t* Wb = (const bf16_t*)p.W + (int64_t)g * p.w_gstride;
+            const int row = wave * 64 + (lane_m >> 3);
+            const int c = (lane_m & 7) ^ (row & 7);        // rows i * 8 further on have the same (row & 7)
+            a0 = Ab + (int64_t)rowmap32((unsigned)(m0 + row), (unsigned)p.a_rpb, (unsigned)p.a_bstride) * p.lda + c * 8;
+            b0 = Wb + (n0 + row) * p.ldw + c * 8;
+        }
+        const int64_t a_pc = 8 * p.lda, b_pc = 8 * p.ldw;      // elements between consecutive pieces
+        auto stage_unit = [&](int u, int pc0, int pc1) __attribute__((always_inline)) {     // pieces [pc0, pc1) of unit u (K-tile u >> 1, past the end: clamped re-reads)
+            int T = u >> 1; if (T > nkt - 1) T = nkt - 1;
+            unsigned char* dst = smem + (u % QRING) * QU + wave * 64 * 128;
+            const int64_t ko = (int64_t)T * 64;
+            // the piece address is formed where it is used (one 64-bit add of a wave-uniform offset): hoisted out of the step loop, hipcc kept all
+            // sixteen piece pointers live and spilled fragment addresses around them (scratch reloads + vmcnt(0) inside the loop)
+            const bf16_t* base = (u & 1) ? b0 : a0;
+            asm volatile("" : "+v"(base));
+            const int64_t pc = (u & 1) ? b_pc : a_pc;
+            for (int i = pc0; i < pc1; ++i) glds16(base + (ko + i * pc), dst + i * 1024);
+        };
+        f32x4 acc[8][8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; asm volatile("" : "+a"(acc[i][j])); }
+        bf16x8 af[2][8], bf[2][8];
+        __builtin_amdgcn_s_barrier();                       // the previous tile's last reads retired (its MFMAs consumed them)
+        if constexpr (!(VAR & 1)) {
+#pragma unroll
+            for (int u = 0; u < QRING; ++u) stage_unit(u, 0, 8);
+        }
+        asm volatile("s_waitcnt vmcnt(24)" ::: "memory");   // A(0), W(0) landed
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int t = 0; t < 8; ++t) af[0][t] = *(const bf16x8*)(smem + 0 * QU + a_row + t * 2048 + ch_h0);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) bf[0][t] = *(const bf16x8*)(smem + 1 * QU + b_row + t * 2048 + ch_h0);
+
+        auto step = [&](auto set_c, int s) __attribute__((always_inline)) {
+            constexpr int SET = decltype(set_c)::value;      // SET = s & 1: even steps compute k-half 0 and read k-half 1 of the same K-tile
+            const int T = s >> 1;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if constexpr (SET == 1) {
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();                // A(T), W(T) free; A(T + 1), W(T + 1) visible
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // fragments of step s + 1: SET == 0 -> K-tile T, k-half 1; SET == 1 -> K-tile T + 1, k-half 0 (past the end: stale, never used)
+            const int Tn = SET == 0 ? T : T + 1;
+            const unsigned char* ua = smem + ((2 * Tn) % QRING) * QU + a_row + (SET == 0 ? ch_h1 : ch_h0);
+            const unsigned char* ub = smem + ((2 * Tn + 1) % QRING) * QU + b_row + (SET == 0 ? ch_h1 : ch_h0);
+            const int urefill = SET == 1 ? 2 * (T + 2) + 1 : 2 * (T + 2);        // odd step 2 T + 1: W(T + 2); even step 2 T' (T' = T): A(T' + 2) ... see header (step 2 T + 2 issues A(T + 3))
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+#pragma unroll
+                for (int q = 4 * i; q < 4 * i + 4; ++q) {
+                    const int mt = q / 8, nt = q % 8;
+                    if constexpr (VAR & 16) asm volatile("" :: "v"(bf[SET][nt]), "v"(af[SET][mt]));
+                    else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[mt][nt]) : "v"(bf[SET][nt]), "v"(af[SET][mt]));
+                }
+                if (i < 8) af[SET ^ 1][i] = *(const bf16x8*)(ua + i * 2048);
+                else bf[SET ^ 1][i - 8] = *(const bf16x8*)(ub + (i - 8) * 2048);
+                if constexpr (!(VAR & 1)) {
+                    // 8 pieces per step, one every other MFMA group; step 0 of a tile issues nothing (A(2) went out with the prologue)
+                    if ((i & 1) == 1 && s > 0) stage_unit(urefill, i >> 1, (i >> 1) + 1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        for (int s = 0; s < nsteps; s += 2) {
+            step(std::integral_constant<int, 0>{}, s);
+            step(std::integral_constant<int, 1>{}, s + 1);
+        }
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15" ::: "memory");
+
+        // ---- epilogue (generic): lane holds, for row m = .. + mt * 16 + (lane & 15), columns nt * 16 + 4 (lane >> 4) .. + 3 ----
+        int lane = lane_m;
+        asm volatile("" : "+v"(lane));
+        const bf16_t* bias = p.bias ? (const bf16_t*)p.bias + (int64_t)g * p.bias_gstride : nullptr;
+        const TileSplit ts = tile_split<EPI>(p, n0);
+        float bv[8][4];
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt) {
+            const int64_t n = n0 + wc * 128 + nt * 16 + (lane >> 4) * 4;
+            load_bias4(n < N ? bias : nullptr, n, bv[nt]);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+            const int64_t m = m0 + wr * 128 + mt * 16 + (lane & 15);
+            const bool row_ok = m < M;
+            RowCtx rc = row_ctx<EPI>(p, g, (unsigned)(row_ok ? m : M - 1));
+            rc.coff += ts.cshift;
+#pragma unroll
+            for (int np = 0; np < 4; ++np) {
+                if (EPI == UG_EPI_BIAS_GELU && !ts.gelu)
+                    epi_store_pair16<UG_EPI_BIAS>(p, rc, row_ok, n0 + wc * 128 + np * 32, N, lane, acc[mt][2 * np], acc[mt][2 * np + 1], bv[2 * np], bv[2 * np + 1]);
+                else
+                    epi_store_pair16<EPI>(p, rc, row_ok, n0 + wc * 128 + np * 32, N, lane, acc[mt][2 * np], acc[mt][2 * np + 1], bv[2 * np], bv[2 * np + 1]);
+            }
+        }
+    }
+}
+
+template <int EPI, int VAR>
+int launch_pwg64_t(const ug_gemm_desc& d, hipStream_t s) {
+    constexpr int PLDS = QRING * QU;
+    const int groups = d.groups > 0 ? d.groups : 1;
+    const int64_t t256 = ((d.M + 255) / 256) * ((d.N + 255) / 256) * groups;
+    UG_REQUIRE(d.K % 64 == 0 && d.K >= 192 && d.M % 256 == 0 && d.N % 256 == 0 && d.a_rpb % 256 == 0, UG_ERR_UNSUPPORTED,
+               "ug_gemm_bf16(pwg64): whole 256^2 tiles only, K a multiple of 64 and >= 192 (M=%lld N=%lld K=%lld)", (long long)d.M, (long long)d.N, (long long)d.K);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_pwg64_kernel<EPI, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
+        attr_set = true;
+    }
+    static int ncu = 0;
+    if (ncu == 0) {
+        int dev = 0; hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
+        if (ncu <= 0) ncu = 256;
+    }
+    const int total = (int)t256;
+    dim3 grid((unsigned)(total < ncu ? total : ncu), 1, 1);
+    hipLaunchKernelGGL((gemm_pwg64_kernel<EPI, VAR>), grid, dim3(256), PLDS, s, d, (int)(t256 / groups), total);
+    UG_CHECK_LAUNCH("ug_gemm_bf16(pwg64)");
+    return UG_OK;
+}
+
 template <int EPI, int NW, int VAR, int PRING = 4>
 int launch_pwg_t(const ug_gemm_desc& d, hipStream_t s) {
     constexpr int PLDS = PRING * PSLOT;
@@ -221,6 +395,15 @@ int launch_pwg_t(const ug_gemm_desc& d, hipStream_t s) {
 int ug_gemm_launch_pwg(const ug_gemm_desc& d, hipStream_t s) {
     const int mode = ug_env_int("UG_GEMM_PWG", 0);
     const int var = ug_env_int("UG_PWG_VAR", 0);
+    if (mode == 3) {                  // round 3: whole-line (64-deep ring units) one-wave-per-SIMD kernel; var 1 = no DMA, 16 = no MFMA (timing only)
+        switch (d.epilogue) {
+            case UG_EPI_BIAS: return var == 1 ? launch_pwg64_t<UG_EPI_BIAS, 1>(d, s) : var == 16 ? launch_pwg64_t<UG_EPI_BIAS, 16>(d, s) : launch_pwg64_t<UG_EPI_BIAS, 0>(d, s);
+            case UG_EPI_BIAS_GELU: return launch_pwg64_t<UG_EPI_BIAS_GELU, 0>(d, s);
+            case UG_EPI_RES_GATE: return launch_pwg64_t<UG_EPI_RES_GATE, 0>(d, s);
+            case UG_EPI_RES_SCALE: return launch_pwg64_t<UG_EPI_RES_SCALE, 0>(d, s);
+            default: UG_FAIL(UG_ERR_UNSUPPORTED, "ug_gemm_bf16(pwg64): epilogue %d", d.epilogue);
+        }
+    }
 #define UG_PWG_CASE(E)                                                                            \
     case E:                                                                                       \
         if (mode == 2) return var == 2 ? launch_pwg_t<E, 8, 2>(d, s) : launch_pwg_t<E, 8, 0>(d, s);   \
