@@ -1,0 +1,70 @@
+"""Interleaved A/B of TWO BUILDS of libunigen_hip.so in one process (rule: never rank builds by timings taken on different devices):
+the in-tree library vs UG_LIB_B (default tools/probe/bin/libunigen_base.so, a build of an earlier commit's gemm.hip), on the cfg2 GEMM launches
+as the forward issues them (row-mapped C / R, gates per sample, the fused q/k RMSNorm + RoPE + GELU launch of the single blocks). Outputs are
+compared bit for bit. usage: python tools/gemm_lib_ab.py [label substrings]"""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from unigen_amd import ops, lib as L
+from unigen_amd.ops import QkRope, RowMap
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+lib_a = L.load()
+path_b = os.environ.get("UG_LIB_B", os.path.join(ROOT, "tools", "probe", "bin", "libunigen_base.so"))
+lib_b = C.CDLL(path_b)
+for name, (res, args) in L.SIGNATURES.items():
+    fn = getattr(lib_b, name); fn.restype = res; fn.argtypes = args
+LIBS = [("base", lib_b), ("new", lib_a)]
+dev, BF = torch.device("cuda:0"), torch.bfloat16
+g = torch.Generator(device=dev).manual_seed(0)
+rn = lambda *s, sc=1.0: (torch.randn(*s, generator=g, device=dev) * sc).to(BF)
+B, NI, T, D = 4, 4096, 512, 3072
+SHAPES = [
+    ("single qkv+mlp (q/k rope | v | gelu)", B * (NI + T), 7 * D, D, "qkrope"),
+    ("single out K=15360 res_gate", B * (NI + T), D, 5 * D, L.EPI_RES_GATE),
+    ("ff up gelu", B * NI, 4 * D, D, L.EPI_BIAS_GELU),
+    ("ff down K=12288 res_gate", B * NI, D, 4 * D, L.EPI_RES_GATE),
+    ("qkv image (q/k rope | v)", B * NI, 3 * D, D, "qkrope3"),
+    ("attn out res_gate", B * NI, D, D, L.EPI_RES_GATE),
+    ("zero-res res_scale", B * (NI + T), D, D, L.EPI_RES_SCALE),
+]
+if len(sys.argv) > 1:
+    SHAPES = [s for s in SHAPES if any(a in s[0] for a in sys.argv[1:])]
+for label, M, N, K, epi in SHAPES:
+    rows = M // B
+    a, w, b = rn(M, K), rn(N, K, sc=0.03), rn(N, sc=0.1)
+    res, gate = rn(M, N), rn(B, N)
+    kw = dict(M=M)
+    if epi in ("qkrope", "qkrope3"):
+        cs = torch.rand(rows, 64, 2, generator=g, device=dev) * 2 - 1
+        kw.update(qk_rope=QkRope(rn(128) + 1, rn(128) + 1, cs.contiguous(), rows, 0, 2 * D, 1e-6, 128))
+        if epi == "qkrope":
+            kw.update(gelu_from_n=3 * D)
+    else:
+        kw.update(epilogue=epi)
+        if epi in (L.EPI_RES_GATE, L.EPI_RES_SCALE):
+            kw.update(residual=res, alpha=0.5)
+        if epi == L.EPI_RES_GATE:
+            kw.update(gate=gate, gate_ld=N, rows_per_sample=rows)
+    outs = [torch.empty(M, N, device=dev, dtype=BF) for _ in LIBS]
+
+    def run(i):
+        L._lib = LIBS[i][1]
+        ops.gemm(a, w, b, outs[i], **kw)
+    for i in range(2):
+        run(i); run(i)
+    torch.cuda.synchronize()
+    mism = float((outs[0] != outs[1]).float().mean())
+    times = [[], []]
+    for rnd in range(7):
+        for i in range(2):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                run(i)
+            e1.record(); e1.synchronize()
+            times[i].append(e0.elapsed_time(e1) / 3)
+    L._lib = lib_a
+    fl = 2.0 * M * N * K
+    med = [sorted(t)[len(t) // 2] for t in times]
+    print(f"{label:40s} {M}x{N}x{K}  base {fl / med[0] / 1e9:7.1f}  new {fl / med[1] / 1e9:7.1f} TFLOP/s ({(med[0] / med[1] - 1) * 100:+.1f} %)   mismatching elements {mism:.2e}", flush=True)

@@ -518,10 +518,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
 #pragma unroll
                         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                const float v = rbf(acc[rg >> 2][j][rg & 3][nt][q] + fb[j][nt][q]);
-                                acc[rg >> 2][j][rg & 3][nt][q] = v;
-                                ss += v * v;
+                            for (int q = 0; q < 4; q += 2) {
+                                float v0 = acc[rg >> 2][j][rg & 3][nt][q] + fb[j][nt][q], v1 = acc[rg >> 2][j][rg & 3][nt][q + 1] + fb[j][nt][q + 1];
+                                rbf2(v0, v1);                                     // rounded in pairs (gemm_epilogue.h)
+                                acc[rg >> 2][j][rg & 3][nt][q] = v0; acc[rg >> 2][j][rg & 3][nt][q + 1] = v1;
+                                ss += v0 * v0; ss += v1 * v1;
                             }
                         part[((rg >> 2) * 128 + (rg & 3) * 16) * 8 + j * 4 + wc] = sum_row_groups(ss);
                     }
@@ -574,7 +575,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
                             const float c1 = __builtin_bit_cast(float, (unsigned)cs.z), s1 = __builtin_bit_cast(float, (unsigned)cs.w);
                             float x[4];
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) x[q] = rbf(rbf(acc[rg >> 2][j][rg & 3][nt][q] * rs) * fg[0][nt][q]);
+                            for (int q = 0; q < 4; ++q) x[q] = acc[rg >> 2][j][rg & 3][nt][q] * rs;
+                            rbf2(x[0], x[1]); rbf2(x[2], x[3]);                  // x * rsqrt as a bf16 tensor ...
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) x[q] = x[q] * fg[0][nt][q];
+                            rbf2(x[0], x[1]); rbf2(x[2], x[3]);                  // ... then * weight
                             if (has_rope) {
                                 pk[nt][0] = pack2bf(x[0] * c0 + (-x[1]) * s0, x[1] * c0 + x[0] * s0);
                                 pk[nt][1] = pack2bf(x[2] * c1 + (-x[3]) * s1, x[3] * c1 + x[2] * s1);
