@@ -15,6 +15,9 @@ VARIANTS = [dict(UG_ATTN_PRIO="1", UG_ATTN_WIDE="0", UG_ATTN_DMA="0"), dict(UG_A
             dict(UG_ATTN_PRIO="0", UG_ATTN_WIDE="1", UG_ATTN_DMA="0"), dict(UG_ATTN_PRIO="0", UG_ATTN_WIDE="1", UG_ATTN_DMA="1")]
 if os.environ.get("ATTN_AB_VARIANTS"):        # e.g. "0,1,0;0,1,1" = prio,wide,dma per variant
     VARIANTS = [dict(zip(("UG_ATTN_PRIO", "UG_ATTN_WIDE", "UG_ATTN_DMA"), v.split(","))) for v in os.environ["ATTN_AB_VARIANTS"].split(";")]
+if os.environ.get("ATTN_AB_ENVS"):            # generic: "K=V,K=V;K=V" = one environment per variant (switches not named keep their defaults)
+    VARIANTS = [dict(kv.split("=") for kv in v.split(",") if kv) for v in os.environ["ATTN_AB_ENVS"].split(";")]
+    ALLKEYS = sorted({k for v in VARIANTS for k in v})
 SHAPES = [(4, 4608, 4608), (4, 4096, 4608), (4, 8192, 8704), (2, 1000, 1003)] if dh == 128 else [(16, 4096, 4429), (16, 4096, 4096)]
 g = torch.Generator(device=dev).manual_seed(0)
 for B, Lq, Lkv in SHAPES:
@@ -23,6 +26,9 @@ for B, Lq, Lkv in SHAPES:
     outs = [torch.empty(B, Lq, D, device=dev, dtype=torch.bfloat16) for _ in VARIANTS]
 
     def run(i):
+        if os.environ.get("ATTN_AB_ENVS"):
+            for k in ALLKEYS:
+                os.environ.pop(k, None)
         os.environ.update(VARIANTS[i])
         ops.flash_attn(qkv[0, Lkv - Lq:], qkv[0, 0, D:], qkv[0, 0, 2 * D:], outs[i], batches=B, heads=H, dh=dh, Lq=Lq, Lkv=Lkv,
                        q_strides=st, k_strides=st, v_strides=st, o_strides=(D, Lq * D))
@@ -30,7 +36,12 @@ for B, Lq, Lkv in SHAPES:
         run(i); run(i)
     torch.cuda.synchronize()
     for i in range(1, len(VARIANTS)):
-        assert torch.equal(outs[i], outs[0]), f"variant {VARIANTS[i]} differs from the default"
+        if os.environ.get("ATTN_AB_ENVS"):       # different tile sizes associate the online softmax differently: report, do not assert bit equality
+            d = float((outs[i].float() - outs[0].float()).norm() / outs[0].float().norm())
+            print(f"  variant {VARIANTS[i]} vs variant 0: rel_l2 {d:.2e}, identical bits: {torch.equal(outs[i], outs[0])}")
+            assert d <= 5e-3
+        else:
+            assert torch.equal(outs[i], outs[0]), f"variant {VARIANTS[i]} differs from the default"
     times = [[] for _ in VARIANTS]
     for rnd in range(7):
         for i in range(len(VARIANTS)):
@@ -43,4 +54,4 @@ for B, Lq, Lkv in SHAPES:
     fl = 4.0 * B * H * Lq * Lkv * dh
     for i, v in enumerate(VARIANTS):
         t = sorted(times[i])
-        print(f"dh{dh} B{B} {Lq}x{Lkv} prio={v['UG_ATTN_PRIO']} wide={v['UG_ATTN_WIDE']} dma={v['UG_ATTN_DMA']}: median {fl / t[len(t) // 2] / 1e9:7.1f}  best {fl / t[0] / 1e9:7.1f} TFLOP/s", flush=True)
+        print(f"dh{dh} B{B} {Lq}x{Lkv} {v}: median {fl / t[len(t) // 2] / 1e9:7.1f}  best {fl / t[0] / 1e9:7.1f} TFLOP/s", flush=True)

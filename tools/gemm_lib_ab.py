@@ -15,6 +15,10 @@ lib_b = C.CDLL(path_b)
 for name, (res, args) in L.SIGNATURES.items():
     fn = getattr(lib_b, name); fn.restype = res; fn.argtypes = args
 LIBS = [("base", lib_b), ("new", lib_a)]
+AB_ENV = os.environ.get("UG_AB_ENV")          # e.g. UG_AB_ENV=UG_GEMM_C_PLAIN: the in-tree library with NAME=0 ("base") vs NAME=1 ("new") instead of two builds
+if AB_ENV:
+    os.environ["UG_ENV_DYNAMIC"] = "1"
+    LIBS = [("0", lib_a), ("1", lib_a)]
 dev, BF = torch.device("cuda:0"), torch.bfloat16
 g = torch.Generator(device=dev).manual_seed(0)
 rn = lambda *s, sc=1.0: (torch.randn(*s, generator=g, device=dev) * sc).to(BF)
@@ -49,6 +53,8 @@ for label, M, N, K, epi in SHAPES:
     outs = [torch.empty(M, N, device=dev, dtype=BF) for _ in LIBS]
 
     def run(i):
+        if AB_ENV:
+            os.environ[AB_ENV] = LIBS[i][0]
         L._lib = LIBS[i][1]
         ops.gemm(a, w, b, outs[i], **kw)
     for i in range(2):

@@ -88,16 +88,27 @@ __device__ __forceinline__ float ug_max_halves(float x) {
 // the VALU, together (the lock-step loop, STAGGER = false, kept for A/B: both phases then serialise and a tile costs the sum).
 // Two barriers per tile; every thread fetches its share of K(t+2), V(t+1) at the start of an even segment and publishes it to LDS at
 // the end of the following odd one, into buffers nobody reads in those two segments.
-template <int DH, int NW, bool STAGGER, int PRIO = 1, bool WIDE = false, bool DMA = false>   // head dim 128 | 64; waves per workgroup: 8 (256 query rows, 1 / CU) or 4 (128 rows, 2 / CU)
+template <int DH, int NW, bool STAGGER, int PRIO = 1, bool WIDE = false, bool DMA = false, int KV = 64, int OCC = 2>   // head dim 128 | 64; waves per workgroup: 8 (256 query rows, 1 / CU) or 4 (128 rows, 2 / CU)
+// KV: keys per tile. 64 everywhere in rounds 1-2; round 3 adds KV = 128 for head dim 64 (UniGenSD3): a 128-key tile of 128-byte rows is the
+// same 16 KiB image, the same register budget (S^T 64 + P 32 + O 32 + Q 16 against 32 + 16 + 64 + 32 at dh 128 / 64 keys) and the same 32
+// MFMAs per matrix segment as the dh 128 kernel, so the per-segment costs (two barriers, the max exchange, the lazy-rescale test, fences,
+// the first-read latency) are paid once per 128 keys instead of once per 64 (at dh 64 the kernel ran at 55-60 %
+// of its VALU-issue bound).
 // PRIO (stagger only): 0 = no priority games; 1 = s_setprio 1 around the matrix stream of every X segment; 2 = ONE static s_setprio 1 for
 // the younger wave group (waves 4-7) before the loop (cdna guide T5, static form). WIDE: 16-byte epilogue stores (T21).
 // DMA (stagger only): K / V tiles go HBM -> LDS with global_load_lds_dwordx4 (no staging registers, no ds_write): the swizzled image is
 // produced on the SOURCE side (lane l of an instruction lands at byte 16 l of a 1 KiB run = 4 rows at dh 128, so it fetches chunk
 // (l % 16) ^ f(row) of its row), and group B (waves 4-7) issues all of it at the start of its softmax segment, two segments ahead of use.
-__global__ __launch_bounds__(64 * NW, 2) void flash_attn_kernel(
+// OCC: waves per SIMD the register allocation must allow. 2 = one 8-wave workgroup per CU (all shipped forms). OCC = 4 (round 3, head dim 64
+// only, A/B): <= 128 registers so that TWO workgroups share a CU (64 KiB of LDS each) - four waves per SIMD fill each other's barrier and
+// latency bubbles in the VALU-bound dh 64 loop; Q fragments then come from LDS (16 registers fewer).
+__global__ __launch_bounds__(64 * NW, OCC) void flash_attn_kernel(
     const bf16_t* __restrict__ q, int64_t q_rs, int64_t q_bs, const bf16_t* __restrict__ k, int64_t k_rs, int64_t k_bs,
     const bf16_t* __restrict__ v, int64_t v_rs, int64_t v_bs, bf16_t* __restrict__ o, int64_t o_rs, int64_t o_bs,
     int heads, int Lq, int Lkv, int nQ, float c /* softmax_scale * log2(e) */, float* __restrict__ lse_out /* nullable */, int64_t lse_ld) {
+    constexpr int KVB = KV;                          // shadows the file-level constant (the other kernels keep 64)
+    constexpr int NKB = KVB / 32;                    // 32-key blocks of S^T per tile
+    constexpr int NKS = KVB / 16;                    // k-steps of O^T += V^T P^T per tile
     constexpr int RB = 2 * DH;                       // row bytes
     constexpr int NCH = DH / 8;                      // 16-byte chunks per row
     constexpr int TILE = KVB * RB;                   // bytes of one K (or V) tile image
@@ -128,7 +139,7 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn_kernel(
     // Lock-step variant: Q fragments stay in registers. X/Y stagger: they live in LDS (same swizzled row image as K, one
     // ds_read_b128 per k-step) because S^T must survive a barrier next to the P.V operands and 32 fewer VGPRs avoid spills.
     constexpr int QBASE = 2 * 2 * KVB * RB;            // byte offset of the Q image behind the two K|V buffers
-    constexpr bool QLDS = STAGGER && UG_STAGGER_Q_IN_LDS;
+    constexpr bool QLDS = STAGGER && (UG_STAGGER_Q_IN_LDS || OCC == 4);
     bf16x8 qf[QLDS ? 1 : QS];
     const int q_lds = QBASE + RB * (wave * 32 + r);
     const int qx = h ^ row_swz<DH>(r);                  // wave * 32 keeps row_swz unchanged (multiple of 16)
@@ -204,62 +215,65 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn_kernel(
     float m_run = -INFINITY, l_run = 0.f;
 
     const int ntiles = (Lkv + KVB - 1) / KVB;
-    bf16x8 pf[2][2];                                   // P^T fragments of the tile between its S and P stages
+    bf16x8 pf[NKB][2];                                 // P^T fragments of the tile between its S and P stages
     // CUR = buffer parity as a compile-time constant: every LDS address below is then a loop-invariant VGPR + an immediate offset
     // (with a runtime parity hipcc re-materialised ~50 address adds per tile, a quarter of the VALU work of the loop).
-    f32x16 sacc[2];                                    // S^T of the tile between its QK^T and its softmax
+    f32x16 sacc[NKB];                                  // S^T of the tile between its QK^T and its softmax
     auto do_QK = [&](int t, auto cur_c) {
         constexpr int CUR = decltype(cur_c)::value;
         const int kv0 = t * KVB;
         const unsigned char* Kbuf = smem + CUR * 2 * TILE;
         // ---- S^T[key][q]: all 8 K fragments of key block 0 first, then block-0 MFMAs with the block-1 reads between them ----
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+        for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
             for (int i = 0; i < 16; ++i) sacc[kb][i] = 0.f;
         if constexpr (!STAGGER) {
-            bf16x8 kf0[QS], kf1[QS];
+            bf16x8 kf[NKB][QS];
 #pragma unroll
-            for (int s = 0; s < QS; ++s) kf0[s] = *(const bf16x8*)(Kbuf + k_rowoff + 16 * ((2 * s) ^ kx));
+            for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
-            for (int s = 0; s < QS; ++s) kf1[s] = *(const bf16x8*)(Kbuf + 32 * RB + k_rowoff + 16 * ((2 * s) ^ kx));
+                for (int s = 0; s < QS; ++s) kf[kb][s] = *(const bf16x8*)(Kbuf + kb * 32 * RB + k_rowoff + 16 * ((2 * s) ^ kx));
 #pragma unroll
-            for (int s = 0; s < QS; ++s) sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0[s], qf[s], sacc[0], 0, 0, 0);
+            for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
-            for (int s = 0; s < QS; ++s) sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1[s], qf[s], sacc[1], 0, 0, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, QS, 0);       // ds_reads of key block 0
+                for (int s = 0; s < QS; ++s) sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kb][s], qf[s], sacc[kb], 0, 0, 0);
+            if constexpr (NKB == 2) {
+                __builtin_amdgcn_sched_group_barrier(0x100, QS, 0);       // ds_reads of key block 0
 #pragma unroll
-            for (int s = 0; s < QS; ++s) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // 1 MFMA (block 0)
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    // 1 ds_read (block 1)
+                for (int s = 0; s < QS; ++s) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // 1 MFMA (block 0)
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    // 1 ds_read (block 1)
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, QS, 0);       // MFMAs of block 1
             }
-            __builtin_amdgcn_sched_group_barrier(0x008, QS, 0);       // MFMAs of block 1
         } else {
             // Q comes from LDS too: per k-step one Q fragment and the two key blocks' K fragments, read two steps ahead of their
             // MFMAs (9 fragments = 36 VGPRs live instead of 24 fragments if hipcc hoisted every read).
-            bf16x8 ql[QS], kf0[QS], kf1[QS];
+            bf16x8 ql[QS], kf[NKB][QS];
 #pragma unroll
             for (int s = 0; s < QS; ++s) {
                 if constexpr (QLDS) ql[s] = *(const bf16x8*)(smem + q_lds + 16 * ((2 * s) ^ qx)); else ql[s] = qf[s];
-                kf0[s] = *(const bf16x8*)(Kbuf + k_rowoff + 16 * ((2 * s) ^ kx));
-                kf1[s] = *(const bf16x8*)(Kbuf + 32 * RB + k_rowoff + 16 * ((2 * s) ^ kx));
+#pragma unroll
+                for (int kb = 0; kb < NKB; ++kb) kf[kb][s] = *(const bf16x8*)(Kbuf + kb * 32 * RB + k_rowoff + 16 * ((2 * s) ^ kx));
             }
 #pragma unroll
-            for (int s = 0; s < QS; ++s) {
-                sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0[s], ql[s], sacc[0], 0, 0, 0);
-                sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1[s], ql[s], sacc[1], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);        // fragments of k-steps 0, 1
+            for (int s = 0; s < QS; ++s)
 #pragma unroll
-            for (int s = 0; s < QS - 2; ++s) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);    // MFMAs of step s
-                __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);    // fragments of step s + 2
+                for (int kb = 0; kb < NKB; ++kb) sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kb][s], ql[s], sacc[kb], 0, 0, 0);
+            if constexpr (NKB == 2) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);        // fragments of k-steps 0, 1
+#pragma unroll
+                for (int s = 0; s < QS - 2; ++s) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);    // MFMAs of step s
+                    __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);    // fragments of step s + 2
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
             }
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
         }
         if (kv0 + KVB > Lkv) {   // ragged last tile: keys >= Lkv do not exist
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int key = kv0 + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
@@ -271,7 +285,7 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn_kernel(
         // ---- online softmax, all lane-local (this lane: query r, 32 of the tile's 64 keys; lane^32 has the rest) ----
         float tmax = sacc[0][0];
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+        for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
             for (int i = 0; i < 16; ++i) tmax = fmaxf(tmax, sacc[kb][i]);
         tmax = ug_max_halves(tmax);
@@ -300,7 +314,7 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn_kernel(
         // (Measured and dropped, same box: the scale / shift and the row sums two elements per instruction, v_pk_fma_f32 / v_pk_add_f32 -
         // 5 % SLOWER at dh 128 (1086 vs 1146, 1118 vs 1179 TFLOP/s), +1 % at dh 64: the packed forms buy no issue cycles here.)
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+        for (int kb = 0; kb < NKB; ++kb) {
             float p[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
@@ -321,24 +335,26 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn_kernel(
         const unsigned char* Vbuf = smem + CUR * 2 * TILE + TILE;
         // ---- O^T[d][q] += V^T[d][key] P^T[key][q]: the V fragments of d-block db+1 are read between the MFMAs of block db ----
         {
-            bf16x8 vf[NDB][4];
+            bf16x8 vf[NDB][NKS];
 #pragma unroll
             for (int db = 0; db < NDB; ++db)
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks)
+                for (int ks = 0; ks < NKS; ++ks)
                     vf[db][ks] = tr_read_pair(Vbuf + ks * 16 * RB + voff_lo[db], Vbuf + ks * 16 * RB + voff_hi[db]);
 #pragma unroll
             for (int db = 0; db < NDB; ++db)
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks)
+                for (int ks = 0; ks < NKS; ++ks)
                     oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[db][ks], pf[ks >> 1][ks & 1], oacc[db], 0, 0, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 8, 1);            // 8 tr reads (d-block 0)
+            if constexpr (NKS == 4) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 8, 1);            // 8 tr reads (d-block 0)
 #pragma unroll
-            for (int i = 0; i < 4 * (NDB - 1); ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);        // 1 MFMA
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 1);        // 2 tr reads of the next d-block
+                for (int i = 0; i < 4 * (NDB - 1); ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);        // 1 MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 1);        // 2 tr reads of the next d-block
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 1);            // last d-block
             }
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 1);            // last d-block
         }
     };
     // X(t) of the stagger variant as an explicit stream (sched_barrier after every piece): P.V(t) - 16 MFMAs, k-step outer so the 4
@@ -346,51 +362,55 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn_kernel(
     // of its MFMA and the first K / Q fragments of the second half are requested under the last P.V MFMAs: this wave is alone on the
     // matrix pipe in this segment (its SIMD partner is in the VALU-only Y), so an exposed ds_read latency is an idle pipe. hipcc's
     // own order (sched_group_barrier hints included) ran the segment at 70-90 cycles per MFMA.
-    auto qx_frag = [&](int s) -> bf16x8 { if constexpr (STAGGER && UG_STAGGER_Q_IN_LDS) return *(const bf16x8*)(smem + q_lds + 16 * ((2 * s) ^ qx)); else return qf[s]; };
+    auto qx_frag = [&](int s) -> bf16x8 { if constexpr (QLDS) return *(const bf16x8*)(smem + q_lds + 16 * ((2 * s) ^ qx)); else return qf[s]; };
     auto do_X = [&](int t, auto cur_c, bool have_qk) __attribute__((always_inline)) {
         constexpr int CUR = decltype(cur_c)::value;
         const unsigned char* Vbuf = smem + CUR * 2 * TILE + TILE;
         const unsigned char* Kbuf = smem + (CUR ^ 1) * 2 * TILE;
-        bf16x8 vf[4][NDB];
+        bf16x8 vf[NKS][NDB];
         auto rdv = [&](int ks) {
 #pragma unroll
             for (int db = 0; db < NDB; ++db) vf[ks][db] = tr_read_pair(Vbuf + ks * 16 * RB + voff_lo[db], Vbuf + ks * 16 * RB + voff_hi[db]);
         };
-        bf16x8 kf0[QS], kf1[QS];
+        bf16x8 kf[NKB][QS];
         auto rdk = [&](int s) {
-            kf0[s] = *(const bf16x8*)(Kbuf + k_rowoff + 16 * ((2 * s) ^ kx));
-            kf1[s] = *(const bf16x8*)(Kbuf + 32 * RB + k_rowoff + 16 * ((2 * s) ^ kx));
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) kf[kb][s] = *(const bf16x8*)(Kbuf + kb * 32 * RB + k_rowoff + 16 * ((2 * s) ^ kx));
         };
+        constexpr int QPRE = QS / 4;                   // k-steps of K.Q^T whose fragments are requested under each of the last two P.V steps
         rdv(0); rdv(1);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(1);                   // the matrix stream outranks the partner wave's softmax VALU at issue
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
+        for (int ks = 0; ks < NKS; ++ks) {
 #pragma unroll
             for (int db = 0; db < NDB; ++db)
                 oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[ks][db], pf[ks >> 1][ks & 1], oacc[db], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if (ks + 2 < 4) rdv(ks + 2);
-            else if (have_qk) { rdk(2 * (ks - 2)); rdk(2 * (ks - 2) + 1); }      // k-steps 0-3 of the second half
+            if (ks + 2 < NKS) rdv(ks + 2);
+            else if (have_qk) {                                                    // the first 2 QPRE k-steps of the second half
+#pragma unroll
+                for (int j = 0; j < QPRE; ++j) rdk(QPRE * (ks - (NKS - 2)) + j);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         if (!have_qk) { if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(0); return; }
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+        for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
             for (int i = 0; i < 16; ++i) sacc[kb][i] = 0.f;
 #pragma unroll
         for (int s = 0; s < QS; ++s) {
-            sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0[s], qx_frag(s), sacc[0], 0, 0, 0);
-            sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1[s], qx_frag(s), sacc[1], 0, 0, 0);
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kb][s], qx_frag(s), sacc[kb], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if (s + 4 < QS) { rdk(s + 4); __builtin_amdgcn_sched_barrier(0); }
+            if (s + 2 * QPRE < QS) { rdk(s + 2 * QPRE); __builtin_amdgcn_sched_barrier(0); }
         }
         if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(0);
         const int kv0 = (t + 1) * KVB;
         if (kv0 + KVB > Lkv) {   // ragged last tile: keys >= Lkv do not exist
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int key = kv0 + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
@@ -490,8 +510,13 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn_kernel(
         auto dma_tile = [&](const bf16_t* base, int64_t rs, const unsigned (&off)[NIW], int tile, unsigned dst) {
             if (tile * KVB + KVB <= Lkv) {             // whole tile: wave-uniform base (SGPR pair) + per-lane 32-bit byte offset
                 const void* tb = uniform_ptr(base + (int64_t)tile * KVB * rs);
+                if constexpr (OCC == 4) {          // one lane offset per operand, the run's rows folded into the scalar base (registers are what this form is short of)
 #pragma unroll
-                for (int u = 0; u < NIW; ++u) glds16_off(tb, off[u], dst + u * 1024);
+                    for (int u = 0; u < NIW; ++u) glds16_off((const char*)tb + (int64_t)u * RPI * rs * 2, off[0], dst + u * 1024);
+                } else {
+#pragma unroll
+                    for (int u = 0; u < NIW; ++u) glds16_off(tb, off[u], dst + u * 1024);
+                }
             } else {                                   // ragged last tile: rows past the end re-read the last key (masked in S^T)
                 int lane_r = lane;
                 asm volatile("" : "+v"(lane_r));      // row / chunk re-derived here, not kept live through the loop
@@ -534,7 +559,7 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn_kernel(
             // P^T is "used" here: hipcc otherwise sinks the (pure) scale / exp2 / pack chain across the barrier to its first use, the
             // P.V MFMAs - i.e. out of this VALU-only segment into the matrix-only one, which then ran at ~60 cycles per MFMA
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb) { asm volatile("" : "+v"(pf[kb][0])); asm volatile("" : "+v"(pf[kb][1])); }
+            for (int kb = 0; kb < NKB; ++kb) { asm volatile("" : "+v"(pf[kb][0])); asm volatile("" : "+v"(pf[kb][1])); }
             asm volatile("" : "+v"(l_run), "+v"(m_run));
             if constexpr (PRIO == 3) __builtin_amdgcn_s_setprio(0);
             // group A publishes K(t+1), V(t) and at once re-fills the staging registers with K(t+2), V(t+1): its VALU segment has slack
@@ -1308,6 +1333,10 @@ static int flash_attn_fwd_impl(const void* q, int64_t q_row_stride, int64_t q_ba
     const int64_t nwg = (int64_t)nQ * heads * batches;
     UG_REQUIRE(nwg < (1ll << 31), UG_ERR_UNSUPPORTED, "ug_flash_attn_fwd: grid too large");
     const float c = softmax_scale * 1.4426950408889634f;
+#define UG_ATTN_LAUNCH_KV(KVV, OCCV, DHV, NWV, STG, ...)                                                                                  \
+    hipLaunchKernelGGL((flash_attn_kernel<DHV, NWV, STG, __VA_ARGS__, KVV, OCCV>), dim3((unsigned)nwg), dim3(64 * NWV), 2 * 2 * KVV * 2 * DHV + (STG ? 32 * NWV * 2 * DHV : 0), (hipStream_t)stream, \
+                       (const bf16_t*)q, q_row_stride, q_batch_stride, (const bf16_t*)k, k_row_stride, k_batch_stride, (const bf16_t*)v, \
+                       v_row_stride, v_batch_stride, (bf16_t*)o, o_row_stride, o_batch_stride, (int)heads, (int)Lq, (int)Lkv, nQ, c, lse_out, lse_ld)
 #define UG_ATTN_LAUNCH(DHV, NWV, STG, ...)                                                                                           \
     hipLaunchKernelGGL((flash_attn_kernel<DHV, NWV, STG, ##__VA_ARGS__>), dim3((unsigned)nwg), dim3(64 * NWV), 2 * 2 * KVB * 2 * DHV + (STG ? 32 * NWV * 2 * DHV : 0), (hipStream_t)stream, \
                        (const bf16_t*)q, q_row_stride, q_batch_stride, (const bf16_t*)k, k_row_stride, k_batch_stride, (const bf16_t*)v, \
@@ -1346,8 +1375,19 @@ static int flash_attn_fwd_impl(const void* q, int64_t q_row_stride, int64_t q_ba
         if (wide) { if (prio == 0 || prio == 3) UG_ATTN_LAUNCH(DHV, 8, true, 0, true); else if (prio == 2) UG_ATTN_LAUNCH(DHV, 8, true, 2, true); else UG_ATTN_LAUNCH(DHV, 8, true, 1, true); } \
         else { if (prio == 0 || prio == 3) UG_ATTN_LAUNCH(DHV, 8, true, 0, false); else if (prio == 2) UG_ATTN_LAUNCH(DHV, 8, true, 2, false); else UG_ATTN_LAUNCH(DHV, 8, true, 1, false); } \
     } while (0)
+    // Head dim 64 (round 3): 128-key tiles in the default stagger + LDS-DMA form; UG_ATTN_KV64=64 restores the 64-key tiles (A/B, tests)
+    const int kv64 = ug_env_int("UG_ATTN_KV64", 128);
     if (dh == 128) { if (nw == 4) UG_ATTN_LAUNCH(128, 4, false); else if (stg) UG_ATTN_STG(128); else UG_ATTN_LAUNCH(128, 8, false); }
+    else if (nw == 8 && stg && dma && kv64 == 128) {
+        static bool attr = false;
+        if (!attr) { (void)hipFuncSetAttribute((const void*)flash_attn_kernel<64, 8, true, 0, true, true, 128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * 128 * 2 * 64 + 32 * 8 * 2 * 64); attr = true; }
+        UG_ATTN_LAUNCH_KV(128, 2, 64, 8, true, 0, true, true);
+    }
+    else if (nw == 8 && stg && dma && kv64 == 464) {        // UG_ATTN_KV64=464: 64-key tiles, <= 128 registers, two workgroups per CU
+        UG_ATTN_LAUNCH_KV(64, 4, 64, 8, true, 0, true, true);
+    }
     else           { if (nw == 4) UG_ATTN_LAUNCH(64, 4, false); else if (stg) UG_ATTN_STG(64); else UG_ATTN_LAUNCH(64, 8, false); }
+#undef UG_ATTN_LAUNCH_KV
 #undef UG_ATTN_STG
 #undef UG_ATTN_LAUNCH
     UG_CHECK_LAUNCH("ug_flash_attn_fwd");
