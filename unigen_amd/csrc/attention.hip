@@ -171,7 +171,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void flash_attn_kernel(
         st_off[u] = img_off<DH>(st_row[u], st_ch[u]);
     }
     u32x4 kreg[NST], vreg[NST];
-    auto stage_load = [&](int kv0) {
+    auto stage_load = [&](int kv0) __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < NST; ++u) {
             int key = kv0 + st_row[u]; if (key > Lkv - 1) key = Lkv - 1;
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void flash_attn_kernel(
             vreg[u] = *(const u32x4*)(Vb + (int64_t)key * v_rs + st_ch[u] * 8);
         }
     };
-    auto stage_write = [&](int buf) {
+    auto stage_write = [&](int buf) __attribute__((always_inline)) {
         unsigned char* Kbuf = smem + buf * 2 * TILE;
         unsigned char* Vbuf = Kbuf + TILE;
 #pragma unroll
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void flash_attn_kernel(
     // CUR = buffer parity as a compile-time constant: every LDS address below is then a loop-invariant VGPR + an immediate offset
     // (with a runtime parity hipcc re-materialised ~50 address adds per tile, a quarter of the VALU work of the loop).
     f32x16 sacc[NKB];                                  // S^T of the tile between its QK^T and its softmax
-    auto do_QK = [&](int t, auto cur_c) {
+    auto do_QK = [&](int t, auto cur_c) __attribute__((always_inline)) {
         constexpr int CUR = decltype(cur_c)::value;
         const int kv0 = t * KVB;
         const unsigned char* Kbuf = smem + CUR * 2 * TILE;
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void flash_attn_kernel(
                 }
         }
     };
-    auto do_SM = [&]() {
+    auto do_SM = [&]() __attribute__((always_inline)) {
         // ---- online softmax, all lane-local (this lane: query r, 32 of the tile's 64 keys; lane^32 has the rest) ----
         float tmax = sacc[0][0];
 #pragma unroll
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void flash_attn_kernel(
             }
         }
     };
-    auto do_P = [&](int t, auto cur_c) {
+    auto do_P = [&](int t, auto cur_c) __attribute__((always_inline)) {
         constexpr int CUR = decltype(cur_c)::value;
         const unsigned char* Vbuf = smem + CUR * 2 * TILE + TILE;
         // ---- O^T[d][q] += V^T[d][key] P^T[key][q]: the V fragments of d-block db+1 are read between the MFMAs of block db ----
@@ -362,18 +362,18 @@ __global__ __launch_bounds__(64 * NW, OCC) void flash_attn_kernel(
     // of its MFMA and the first K / Q fragments of the second half are requested under the last P.V MFMAs: this wave is alone on the
     // matrix pipe in this segment (its SIMD partner is in the VALU-only Y), so an exposed ds_read latency is an idle pipe. hipcc's
     // own order (sched_group_barrier hints included) ran the segment at 70-90 cycles per MFMA.
-    auto qx_frag = [&](int s) -> bf16x8 { if constexpr (QLDS) return *(const bf16x8*)(smem + q_lds + 16 * ((2 * s) ^ qx)); else return qf[s]; };
+    auto qx_frag = [&](int s) __attribute__((always_inline)) -> bf16x8 { if constexpr (QLDS) return *(const bf16x8*)(smem + q_lds + 16 * ((2 * s) ^ qx)); else return qf[s]; };
     auto do_X = [&](int t, auto cur_c, bool have_qk) __attribute__((always_inline)) {
         constexpr int CUR = decltype(cur_c)::value;
         const unsigned char* Vbuf = smem + CUR * 2 * TILE + TILE;
         const unsigned char* Kbuf = smem + (CUR ^ 1) * 2 * TILE;
         bf16x8 vf[NKS][NDB];
-        auto rdv = [&](int ks) {
+        auto rdv = [&](int ks) __attribute__((always_inline)) {
 #pragma unroll
             for (int db = 0; db < NDB; ++db) vf[ks][db] = tr_read_pair(Vbuf + ks * 16 * RB + voff_lo[db], Vbuf + ks * 16 * RB + voff_hi[db]);
         };
         bf16x8 kf[NKB][QS];
-        auto rdk = [&](int s) {
+        auto rdk = [&](int s) __attribute__((always_inline)) {
 #pragma unroll
             for (int kb = 0; kb < NKB; ++kb) kf[kb][s] = *(const bf16x8*)(Kbuf + kb * 32 * RB + k_rowoff + 16 * ((2 * s) ^ kx));
         };
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void flash_attn_kernel(
         stage_load(0);
         stage_write(0);
         __syncthreads();
-        auto tile = [&](int t, auto cur_c) {
+        auto tile = [&](int t, auto cur_c) __attribute__((always_inline)) {
             constexpr int CUR = decltype(cur_c)::value;
             if (t + 1 < ntiles) stage_load((t + 1) * KVB);
             do_QK(t, cur_c);
@@ -446,7 +446,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void flash_attn_kernel(
         //   group B:          -     QK(0)    Y(0)    X(0)    Y(1) ...
         // K(t+1) and V(t) are first needed in segment 2t+2: every thread fetches its share at the START of even segment 2t and
         // publishes it at the END of odd segment 2t+1 (into buffers nobody reads in 2t / 2t+1). Loads cross barriers: raw s_barrier.
-        auto seg_barrier = [&]() {
+        auto seg_barrier = [&]() __attribute__((always_inline)) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
@@ -465,7 +465,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void flash_attn_kernel(
             koff[u] = (unsigned)(st_row[u] * (int)k_rs + st_ch[u] * 8);
             voff[u] = (unsigned)(st_row[u] * (int)v_rs + st_ch[u] * 8);
         }
-        auto fetch = [&](int kt, int vt) {
+        auto fetch = [&](int kt, int vt) __attribute__((always_inline)) {
             if (kt * KVB + KVB <= Lkv && vt * KVB + KVB <= Lkv) {       // wave-uniform: both tiles whole
                 const bf16_t* kbase = Kb + (int64_t)kt * KVB * k_rs;
                 const bf16_t* vbase = Vb + (int64_t)vt * KVB * v_rs;
@@ -484,7 +484,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void flash_attn_kernel(
                 }
             }
         };
-        auto publish = [&](int kt, int vt) {
+        auto publish = [&](int kt, int vt) __attribute__((always_inline)) {
 #pragma unroll
             for (int u = 0; u < NST; ++u) {
                 *(u32x4*)(smem + (kt & 1) * 2 * TILE + st_off[u]) = kreg[u];
@@ -510,9 +510,15 @@ __global__ __launch_bounds__(64 * NW, OCC) void flash_attn_kernel(
         auto dma_tile = [&](const bf16_t* base, int64_t rs, const unsigned (&off)[NIW], int tile, unsigned dst) {
             if (tile * KVB + KVB <= Lkv) {             // whole tile: wave-uniform base (SGPR pair) + per-lane 32-bit byte offset
                 const void* tb = uniform_ptr(base + (int64_t)tile * KVB * rs);
-                if constexpr (OCC == 4) {          // one lane offset per operand, the run's rows folded into the scalar base (registers are what this form is short of)
+                if constexpr (OCC == 4) {          // lane offsets re-derived at the issue (not kept live through the loop: registers are what this form is short of)
+                    int lane_r = lane;
+                    asm volatile("" : "+v"(lane_r));
 #pragma unroll
-                    for (int u = 0; u < NIW; ++u) glds16_off((const char*)tb + (int64_t)u * RPI * rs * 2, off[0], dst + u * 1024);
+                    for (int u = 0; u < NIW; ++u) {
+                        const int row = (wb * NIW + u) * RPI + lane_r / NCH;
+                        const int ch = (lane_r % NCH) ^ row_swz<DH>(row);
+                        glds16_off(tb, (unsigned)(row * (int)rs + ch * 8) * 2u, dst + u * 1024);
+                    }
                 } else {
 #pragma unroll
                     for (int u = 0; u < NIW; ++u) glds16_off(tb, off[u], dst + u * 1024);
@@ -529,12 +535,12 @@ __global__ __launch_bounds__(64 * NW, OCC) void flash_attn_kernel(
                 }
             }
         };
-        auto dma_fetch = [&](int kt, int vt) {         // tiles past the end are simply not fetched
+        auto dma_fetch = [&](int kt, int vt) __attribute__((always_inline)) {         // tiles past the end are simply not fetched
             const unsigned l0 = __builtin_amdgcn_readfirstlane(lds_addr(smem)) + wb * NIW * 1024;
             if (kt < ntiles) dma_tile(Kb, k_rs, dko, kt, l0 + (kt & 1) * 2 * TILE);
             if (vt < ntiles) dma_tile(Vb, v_rs, dvo, vt, l0 + (vt & 1) * 2 * TILE + TILE);
         };
-        auto dma_wait = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+        auto dma_wait = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
         if constexpr (PRIO == 2) { if (!groupA) __builtin_amdgcn_s_setprio(1); }
         if constexpr (DMA) {
             if (!groupA) { dma_fetch(0, ntiles); dma_wait(); }     // K(0) only
@@ -551,7 +557,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void flash_attn_kernel(
         if (!groupA) { if constexpr (DMA) dma_wait(); else publish(1, 0); }    // end of segment 1 (B)
         seg_barrier();
         // one tile = Y(t) | X(t); buffer parity is a compile-time constant (two tiles per trip)
-        auto tile = [&](int t, auto cur_c) {
+        auto tile = [&](int t, auto cur_c) __attribute__((always_inline)) {
             // Y(t): A in odd segment 2t+1 (publishes K(t+1), V(t) at its end) | B in even segment 2t+2 (fetches K(t+2), V(t+1) at its start)
             if (!groupA) { if constexpr (DMA) dma_fetch(t + 2, t + 1); else fetch(t + 2, t + 1); }
             if constexpr (PRIO == 3) __builtin_amdgcn_s_setprio(1);                  // the softmax segment outranks the partner's matrix stream at issue

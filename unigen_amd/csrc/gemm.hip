@@ -178,7 +178,6 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
     const int nM = (int)((M + 255) / 256), nN = (int)((N + 255) / 256);
     const int st_off = wave * 16 * 128;
     const int wide16 = wide16_gm & 1;            // bits 8.. of the argument: GROUP_M of the tile walk (0 = 8)
-    const bool plain_st = (wide16_gm & 4) != 0;      // A/B (UG_GEMM_C_STORES=plain): full-tile C stores without the non-temporal hint
     const bool rows_contig = (wide16_gm & 2) != 0;   // the C (and R) row maps never split a 256-row tile (rows per batch % 256 == 0): one scalar map per tile
     int a_off, b_off, ch0, ch1;          // fragment read offsets; set per tile (see the tile loop)
     // LORA: the K loop runs on through a second segment, T[m][0..r) . B[n][0..r) (the same K-segment the 128^2 kernel appends), with
@@ -591,7 +590,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
                         }
                         swap16(pk[0][0], pk[1][0]); swap16(pk[0][1], pk[1][1]);
                         u32x4 o; o.x = pk[0][0]; o.y = pk[0][1]; o.z = pk[1][0]; o.w = pk[1][1];
-                        if (plain_st) *(u32x4*)(cp[rg & 1] + j * 128) = o; else __builtin_nontemporal_store(o, (u32x4*)(cp[rg & 1] + j * 128));
+                        __builtin_nontemporal_store(o, (u32x4*)(cp[rg & 1] + j * 128));
                     }
                 }
                 continue;
@@ -642,7 +641,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
                                                       fg[j][0], fg[j][1], rbuf[rg & 1][j])
                         : epi_chunk_full<EPI_A>(p.alpha, acc[rg >> 2][j][rg & 3][0], acc[rg >> 2][j][rg & 3][1], fb[j][0], fb[j][1],
                                               fg[j][0], fg[j][1], rbuf[rg & 1][j]);
-                    if (plain_st) *(u32x4*)(cp[rg & 1] + j * 128) = o; else __builtin_nontemporal_store(o, (u32x4*)(cp[rg & 1] + j * 128));
+                    __builtin_nontemporal_store(o, (u32x4*)(cp[rg & 1] + j * 128));
                 }
             }
             continue;
@@ -738,8 +737,9 @@ int launch(const ug_gemm_desc& d, hipStream_t s) {
         const bool res = d.epilogue == UG_EPI_RES_GATE || d.epilogue == UG_EPI_RES_SCALE;
         const int wide16 = (d.N % 8 == 0 && d.ldc % 8 == 0 && d.c_gstride % 8 == 0 && ug_aligned(d.C, 16) &&
                             (!res || (d.ldr % 8 == 0 && d.r_gstride % 8 == 0 && ug_aligned(d.R, 16)))) |
-                           ((d.c_rpb % 256 == 0 && (!res || d.r_rpb % 256 == 0) && ug_env_int("UG_GEMM_EPI_ROWS_CONTIG", 1)) ? 2 : 0) |
-                           (ug_env_int("UG_GEMM_C_PLAIN", 0) ? 4 : 0);
+                           ((d.c_rpb % 256 == 0 && (!res || d.r_rpb % 256 == 0) && ug_env_int("UG_GEMM_EPI_ROWS_CONTIG", 1)) ? 2 : 0);
+        // (Measured and dropped, round 3: plain instead of non-temporal C stores in the full-tile epilogue - +-0.5 % on every cfg2 shape,
+        // profiles/r03d_gemm_cplain.log: the per-tile store cost is not the cache policy.)
         // UG_GEMM_PWG=1: the one-wave-per-SIMD kernel (gemm_pwg.hip) takes every shape it supports
         if (EPI != UG_EPI_F32 && (wide16 & 1) && !lora && ug_env_int("UG_GEMM_PWG", 0)) return ug_gemm_launch_pwg(d, s);
         // split-K tail (see the kernel header): needs the caller's workspace for the slabs and tickets
@@ -807,7 +807,7 @@ int launch_qkrope(const ug_gemm_desc& d, hipStream_t s) {
     const int total = (int)((d.M / 256) * (d.N / 256));
     UG_REQUIRE(d.c_rpb % 256 == 0, UG_ERR_UNSUPPORTED, "ug_gemm_bf16: UG_EPI_QKV_ROPE needs the C row map's rows per batch (%lld) to be a multiple of 256",
                (long long)d.c_rpb);
-    const int wgm = 3 | (ug_env_int("UG_GEMM_C_PLAIN", 0) ? 4 : 0) | ((ug_env_int("UG_GEMM_GROUP_M", 4) & 0xff) << 8);
+    const int wgm = 3 | ((ug_env_int("UG_GEMM_GROUP_M", 4) & 0xff) << 8);
     const dim3 grid((unsigned)(total < ncu ? total : ncu));
     if (qdh == 128)
         hipLaunchKernelGGL((gemm256_kernel<UG_EPI_QKV_ROPE, false, 128>), grid, dim3(512), LDS, s, d, total, total, wgm, total, 1, (float*)nullptr, (unsigned*)nullptr);
