@@ -1381,8 +1381,11 @@ static int flash_attn_fwd_impl(const void* q, int64_t q_row_stride, int64_t q_ba
         if (wide) { if (prio == 0 || prio == 3) UG_ATTN_LAUNCH(DHV, 8, true, 0, true); else if (prio == 2) UG_ATTN_LAUNCH(DHV, 8, true, 2, true); else UG_ATTN_LAUNCH(DHV, 8, true, 1, true); } \
         else { if (prio == 0 || prio == 3) UG_ATTN_LAUNCH(DHV, 8, true, 0, false); else if (prio == 2) UG_ATTN_LAUNCH(DHV, 8, true, 2, false); else UG_ATTN_LAUNCH(DHV, 8, true, 1, false); } \
     } while (0)
-    // Head dim 64 (round 3): 128-key tiles in the default stagger + LDS-DMA form; UG_ATTN_KV64=64 restores the 64-key tiles (A/B, tests)
-    const int kv64 = ug_env_int("UG_ATTN_KV64", 128);
+    // Head dim 64 (round 3, UG_ATTN_KV64): 464 (default) = 64-key tiles at <= 128 registers so that TWO workgroups share a CU; 128 = 128-key
+    // tiles, one workgroup per CU; 64 = the round-2 kernel. Interleaved A/B (tools/attn_ab.py, profiles/r03e_attn_ab64.log): alone
+    // 872 / 906 / 902 TFLOP/s (64 / 128 / 464) at 4096 x 4429, 886 / 920 / 912 at 4096^2; inside the SD3.5 forward, where other kernels'
+    // tails and launches leave more bubbles to fill, 834 / 868 / 918 (0.4214 / 0.4144 / 0.4043 s per forward). 464 is bit-identical to 64.
+    const int kv64 = ug_env_int("UG_ATTN_KV64", 464);
     if (dh == 128) { if (nw == 4) UG_ATTN_LAUNCH(128, 4, false); else if (stg) UG_ATTN_STG(128); else UG_ATTN_LAUNCH(128, 8, false); }
     else if (nw == 8 && stg && dma && kv64 == 128) {
         static bool attr = false;
