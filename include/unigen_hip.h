@@ -324,6 +324,14 @@ int ug_gate_residual(const void* x, int64_t ldx, const void* a, int64_t lda, con
                      int64_t ldy, int64_t rows, int64_t D, ug_stream_t stream);
 int ug_gate_residual_f32(const void* x, int64_t ldx, const void* a, int64_t lda, const void* gate, int64_t gate_ld, int64_t rows_per_sample, void* y,
                          int64_t ldy, int64_t rows, int64_t D, ug_stream_t stream);
+/* backward of ug_moe_gate_top1 (deepspeed TopKGate / top1gating gate softmax, src/UniGenUtils.py:99; reference: torch autograd through
+ * F.linear(x.float(), wg.float()) + softmax, train.py:654): d gates [S, E] fp32 -> dx [S, D] = d(x + c) (the gradient of BOTH x and c) and
+ * dwg_partials fp32 [ug_moe_gate_bwd_slices(S)][E][D], whose sum over the first axis (fixed order: reproducible) is d wg. E <= 16. */
+int ug_moe_gate_bwd(const float* gates, const float* dgates, const void* x, const void* c, int64_t ld, const void* wg, int64_t S, int64_t D, int32_t E,
+                    void* dx, int64_t lddx, float* dwg_partials, ug_stream_t stream);
+int ug_moe_gate_bwd_f32(const float* gates, const float* dgates, const void* x, const void* c, int64_t ld, const void* wg, int64_t S, int64_t D, int32_t E,
+                        void* dx, int64_t lddx, float* dwg_partials, ug_stream_t stream);
+int64_t ug_moe_gate_bwd_slices(int64_t S);
 /* y = gelu_tanh(x); dx = dy * gelu_tanh'(x)   (F.gelu(approximate="tanh") of FeedForward net.0 / proj_mlp and its backward) */
 int ug_gelu_tanh(const void* x, void* y, int64_t n, ug_stream_t stream);
 int ug_gelu_tanh_bwd(const void* x, const void* dy, void* dx, int64_t n, ug_stream_t stream);

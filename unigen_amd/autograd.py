@@ -74,18 +74,17 @@ class Linear(torch.autograd.Function):
         return out
 
     @staticmethod
-    def backward(ctx, dy):
-        x, w = ctx.saved_tensors
-        dy = dy.contiguous()
+    def _grads(need_dx, need_dw, need_db, x, w, dy):
+        """(dX = dY W, dW = dY^T X, db = colsum(dY)) of y = x w^T + b for the requested ones; dy contiguous [M, N]."""
         M, K = x.shape
         N = w.shape[0]
         dx = dw = db = None
-        if ctx.needs_input_grad[0]:
+        if need_dx:
             if N % 64 != 0:
                 raise L.UniGenHipError(f"Linear backward: out_features={N} must be a multiple of 64 (it is the contraction length of dX = dY W)")
             dx = torch.empty(M, K, device=x.device, dtype=x.dtype)
             ops.gemm(dy, _w_transposed(w), None, dx, M=M)
-        if ctx.needs_input_grad[1]:
+        if need_dw:
             if x.dtype == torch.bfloat16 and os.environ.get("UG_WGRAD", "transpose") == "tn":
                 # dY^T X straight from the row-major operands (csrc/gemm_tn.hip: both fragments by transposing LDS reads). Opt-in: its simple 128^2
                 # lock-step structure measured 6 % SLOWER per step than two transposes + the 256^2 kernel (0.884 vs 0.832 s backward at B = 2)
@@ -95,9 +94,116 @@ class Linear(torch.autograd.Function):
                 dyt, xt = ops.transpose(dy, Mp), _x_transposed(x, Mp)          # [N, Mp], [K, Mp]
                 dw = torch.empty(N, K, device=x.device, dtype=x.dtype)
                 ops.gemm(dyt, xt, None, dw, M=N)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+        if need_db:
             db = ops.colsum(dy).view(N)
         return dx, dw, db
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        return Linear._grads(ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2], x, w, dy.contiguous())
+
+
+class LinearResScale(torch.autograd.Function):
+    """r + alpha * F.linear(x, w, b) on [M, K] rows - the zero-res projections `x + controlnet_add_*(z) * conditioning_scale`
+    (src/UniGenTransformer.py:1104,1141,1166) - as ONE ug_gemm_bf16 with the UG_EPI_RES_SCALE epilogue (the rounding points of the three torch
+    ops: Linear output, * alpha, + r each a bf16 tensor). Backward: d r = d y; d(lin) = alpha * d y, then Linear's two GEMMs and a column sum."""
+
+    @staticmethod
+    def forward(ctx, r, x, w, b, alpha):
+        M, K = x.shape
+        N = w.shape[0]
+        out = torch.empty(M, N, device=x.device, dtype=x.dtype)
+        ops.gemm(x, w, b, out, M=M, epilogue=L.EPI_RES_SCALE, residual=r, alpha=float(alpha))
+        ctx.save_for_backward(x, w)
+        ctx.has_bias, ctx.alpha = b is not None, float(alpha)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        du = dy if ctx.alpha == 1.0 else (dy * ctx.alpha)
+        dx, dw, db = Linear._grads(ctx.needs_input_grad[1], ctx.needs_input_grad[2], ctx.has_bias and ctx.needs_input_grad[3], x, w, du)
+        return (dy if ctx.needs_input_grad[0] else None), dx, dw, db, None
+
+
+def linear_res_scale(r: torch.Tensor, x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], alpha: float) -> torch.Tensor:
+    """r + alpha * linear(x): r [..., N], x [..., K] with equal leading dims."""
+    lead = x.shape[:-1]
+    return LinearResScale.apply(r.reshape(-1, r.shape[-1]).contiguous(), x.reshape(-1, x.shape[-1]).contiguous(), w, b, alpha).view(*lead, w.shape[0])
+
+
+class LinearCat2(torch.autograd.Function):
+    """F.linear(torch.cat([a, m], -1), w, b) WITHOUT the concatenation - the single block's proj_out over [attention | gelu(mlp)]
+    (diffusers FluxSingleTransformerBlock, called at src/UniGenTransformer.py:1151): the m columns run as the K-segment extension of ug_gemm_bf16
+    (the LoRA segment: T = m, B = w[:, Ka:]), one kernel, one fp32 accumulation in the concatenated K order -> the same bits as the GEMM over the
+    materialised [M, Ka + Km] tensor. Backward: d a and d m as two GEMMs into their own buffers, d w column block by column block."""
+
+    @staticmethod
+    def forward(ctx, a, m, w, b):
+        M, Ka = a.shape
+        N = w.shape[0]
+        out = torch.empty(M, N, device=a.device, dtype=a.dtype)
+        ops.gemm(a, w[:, :Ka], b, out, M=M, lora_t=m, lora_b=w[:, Ka:])
+        ctx.save_for_backward(a, m, w)
+        ctx.has_bias = b is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        a, m, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        M, Ka = a.shape
+        Km, N = m.shape[1], w.shape[0]
+        da = dm = dw = db = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            if N % 64 != 0:
+                raise L.UniGenHipError(f"LinearCat2 backward: out_features={N} must be a multiple of 64")
+            wt = _w_transposed(w)                                             # [Ka + Km, N]: row blocks are the transposed column blocks of w
+            if ctx.needs_input_grad[0]:
+                da = torch.empty(M, Ka, device=a.device, dtype=a.dtype)
+                ops.gemm(dy, wt[:Ka], None, da, M=M)
+            if ctx.needs_input_grad[1]:
+                dm = torch.empty(M, Km, device=a.device, dtype=a.dtype)
+                ops.gemm(dy, wt[Ka:], None, dm, M=M)
+        if ctx.needs_input_grad[2]:
+            Mp = _pad64(M)
+            dyt = ops.transpose(dy, Mp)
+            dw = torch.empty(N, Ka + Km, device=a.device, dtype=a.dtype)
+            ops.gemm(dyt, _x_transposed(a, Mp), None, dw[:, :Ka], M=N)
+            ops.gemm(dyt, _x_transposed(m, Mp), None, dw[:, Ka:], M=N)
+        if ctx.has_bias and ctx.needs_input_grad[3]:
+            db = ops.colsum(dy).view(N)
+        return da, dm, dw, db
+
+
+def linear_cat2(a: torch.Tensor, m: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor]) -> torch.Tensor:
+    lead = a.shape[:-1]
+    return LinearCat2.apply(a.reshape(-1, a.shape[-1]).contiguous(), m.reshape(-1, m.shape[-1]).contiguous(), w, b).view(*lead, w.shape[0])
+
+
+class MoeGate(torch.autograd.Function):
+    """gates = softmax(F.linear((x + c).float(), wg.float())) [S, E] fp32 and the arg-max expert per token: ug_moe_gate_top1 forward,
+    ug_moe_gate_bwd backward (deepspeed TopKGate, src/UniGenUtils.py:99). idx is not differentiable."""
+
+    @staticmethod
+    def forward(ctx, x, c, wg):
+        S, D = x.shape
+        E = wg.shape[0]
+        gates = torch.empty(S, E, device=x.device, dtype=torch.float32)
+        idx = torch.empty(S, device=x.device, dtype=torch.int32)
+        wgc = wg.contiguous()
+        ops.moe_gate_top1(x, c, wgc, gates, idx)
+        ctx.save_for_backward(gates, x, c, wgc)
+        ctx.mark_non_differentiable(idx)
+        return gates, idx
+
+    @staticmethod
+    def backward(ctx, dgates, _didx):
+        gates, x, c, wg = ctx.saved_tensors
+        dxc, dwg = ops.moe_gate_bwd(gates, dgates.float().contiguous(), x, c, wg)
+        return (dxc if ctx.needs_input_grad[0] else None), (dxc if ctx.needs_input_grad[1] else None), (dwg if ctx.needs_input_grad[2] else None)
 
 
 def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor]) -> torch.Tensor:

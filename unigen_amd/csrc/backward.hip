@@ -497,6 +497,95 @@ int colsum_impl(const void* a, int64_t lda, const void* b, int64_t ldb, void* ou
     UG_CHECK_LAUNCH("ug_colsum");
     return UG_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Backward of the top-1 gate (deepspeed TopKGate, src/UniGenUtils.py:99): gates = softmax(F.linear((x + c).float(), wg.float())).
+// Given d gates [S, E] (fp32, from l_aux and the combine weights):  d logits = gates * (d gates - sum_e d gates * gates);
+//   d(x + c)[s] = sum_e d logits[s, e] * wg[e]        (one wave per token; the same tensor is d x and d c)
+//   d wg[e]     = sum_s d logits[s, e] * bf16(x + c)[s]  (column blocks x token slices -> fp32 partials, added in a fixed order by the caller)
+// Round 2 ran this through F.linear / autograd (vendor BLAS on a product path); these two kernels read x and c once each.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int GBW_MAXE = 16;
+__device__ __forceinline__ void gate_dlogits(const float* __restrict__ g, const float* __restrict__ dg, int E, float* dl) {
+    float dot = 0.f;
+#pragma unroll
+    for (int e = 0; e < GBW_MAXE; ++e) if (e < E) dot += dg[e] * g[e];
+#pragma unroll
+    for (int e = 0; e < GBW_MAXE; ++e) dl[e] = e < E ? g[e] * (dg[e] - dot) : 0.f;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void moe_gate_bwd_dx_kernel(const float* __restrict__ gates, const float* __restrict__ dgates, const T* __restrict__ wg,
+                                                              int64_t S, int D, int E, T* __restrict__ dx, int64_t lddx) {
+    using EL = ElemT<T>;
+    const int lane = threadIdx.x & 63;
+    const int64_t s = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (s >= S) return;
+    float dl[GBW_MAXE];
+    gate_dlogits(gates + s * E, dgates + s * E, E, dl);
+    for (int ch = lane; ch < (D >> 3); ch += 64) {
+        float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < GBW_MAXE; ++e) {
+            if (e < E) {
+                float w[8];
+                EL::load8(wg + (int64_t)e * D + ch * 8, w);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) o[i] += dl[e] * w[i];
+            }
+        }
+        EL::store8(dx + s * lddx + ch * 8, o);
+    }
+}
+constexpr int GBW_TOK = 128;          // tokens per slice of the d wg partial sums
+template <typename T>
+__global__ __launch_bounds__(256) void moe_gate_bwd_dw_kernel(const float* __restrict__ gates, const float* __restrict__ dgates, const T* __restrict__ x,
+                                                              const T* __restrict__ c, int64_t ld, int64_t S, int D, int E, float* __restrict__ part) {
+    // block = 4 waves; blockIdx.x = column block of 512 (8 per lane), blockIdx.y = token slice; each wave takes every 4th token of the slice,
+    // the four waves' sums meet in LDS. part[slice][e][D].
+    using EL = ElemT<T>;
+    __shared__ float red[4][64 * 8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = blockIdx.x * 512 + lane * 8;
+    const int64_t s0 = (int64_t)blockIdx.y * GBW_TOK;
+    float acc[GBW_MAXE][8];
+#pragma unroll
+    for (int e = 0; e < GBW_MAXE; ++e)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[e][i] = 0.f;
+    if (col < D) {
+        for (int t = wave; t < GBW_TOK; t += 4) {
+            const int64_t s = s0 + t;
+            if (s >= S) break;
+            float dl[GBW_MAXE], a[8], b[8];
+            gate_dlogits(gates + s * E, dgates + s * E, E, dl);
+            EL::load8(x + s * ld + col, a);
+            EL::load8(c + s * ld + col, b);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a[i] = EL::rnd(a[i] + b[i]);
+#pragma unroll
+            for (int e = 0; e < GBW_MAXE; ++e)
+                if (e < E) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) acc[e][i] += dl[e] * a[i];
+                }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < GBW_MAXE; ++e) {
+        if (e < E) {                                   // E is uniform: every thread reaches the barriers
+#pragma unroll
+            for (int i = 0; i < 8; ++i) red[wave][lane * 8 + i] = acc[e][i];
+            __syncthreads();
+            if (wave == 0 && col < D) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    part[((int64_t)blockIdx.y * E + e) * D + col + i] = (red[0][lane * 8 + i] + red[1][lane * 8 + i]) + (red[2][lane * 8 + i] + red[3][lane * 8 + i]);
+            }
+            __syncthreads();
+        }
+    }
+}
+
 template <typename T>
 int gelu_impl(const void* x, const void* dy, void* out, int64_t n, ug_stream_t stream) {
     if (n == 0) return UG_OK;
@@ -511,6 +600,21 @@ int gelu_impl(const void* x, const void* dy, void* out, int64_t n, ug_stream_t s
         else hipLaunchKernelGGL((gelu_kernel<T, false>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)out, n);
     }
     UG_CHECK_LAUNCH("ug_gelu_tanh");
+    return UG_OK;
+}
+template <typename T>
+int moe_gate_bwd_impl(const float* gates, const float* dgates, const void* x, const void* c, int64_t ld, const void* wg, int64_t S, int64_t D, int32_t E,
+                      void* dx, int64_t lddx, float* dwg_partials, ug_stream_t stream) {
+    if (S == 0) return UG_OK;
+    UG_REQUIRE(gates && dgates && x && c && wg && dx && dwg_partials && S > 0 && D > 0 && E >= 1 && E <= GBW_MAXE && ld >= D && lddx >= D, UG_ERR_BAD_SHAPE,
+               "ug_moe_gate_bwd: bad arguments (E <= %d)", GBW_MAXE);
+    UG_REQUIRE(D % 8 == 0 && ld % 8 == 0 && lddx % 8 == 0 && ug_aligned(x, 16) && ug_aligned(c, 16) && ug_aligned(wg, 16) && ug_aligned(dx, 16), UG_ERR_BAD_ALIGN,
+               "ug_moe_gate_bwd: 16-byte alignment required");
+    hipLaunchKernelGGL(moe_gate_bwd_dx_kernel<T>, dim3((unsigned)((S + 3) / 4)), dim3(256), 0, (hipStream_t)stream, gates, dgates, (const T*)wg, S, (int)D, (int)E,
+                       (T*)dx, lddx);
+    hipLaunchKernelGGL(moe_gate_bwd_dw_kernel<T>, dim3((unsigned)((D + 511) / 512), (unsigned)((S + GBW_TOK - 1) / GBW_TOK)), dim3(256), 0, (hipStream_t)stream, gates,
+                       dgates, (const T*)x, (const T*)c, ld, S, (int)D, (int)E, dwg_partials);
+    UG_CHECK_LAUNCH("ug_moe_gate_bwd");
     return UG_OK;
 }
 template <typename T>
@@ -637,6 +741,11 @@ UG_TWINS(ug_gate_residual, gate_residual_impl,
          (const void* x, int64_t ldx, const void* a, int64_t lda, const void* gate, int64_t gate_ld, int64_t rows_per_sample, void* y, int64_t ldy, int64_t rows,
           int64_t D, ug_stream_t stream),
          (x, ldx, a, lda, gate, gate_ld, rows_per_sample, y, ldy, rows, D, stream))
+UG_TWINS(ug_moe_gate_bwd, moe_gate_bwd_impl,
+         (const float* gates, const float* dgates, const void* x, const void* c, int64_t ld, const void* wg, int64_t S, int64_t D, int32_t E, void* dx,
+          int64_t lddx, float* dwg_partials, ug_stream_t stream),
+         (gates, dgates, x, c, ld, wg, S, D, E, dx, lddx, dwg_partials, stream))
+extern "C" int64_t ug_moe_gate_bwd_slices(int64_t S) { return S <= 0 ? 0 : (S + GBW_TOK - 1) / GBW_TOK; }
 UG_TWINS(ug_gelu_tanh, gelu_impl, (const void* x, void* y, int64_t n, ug_stream_t stream), (x, nullptr, y, n, stream))
 UG_TWINS(ug_gelu_tanh_bwd, gelu_impl, (const void* x, const void* dy, void* dx, int64_t n, ug_stream_t stream), (x, dy, dx, n, stream))
 UG_TWINS(ug_adaln_modulate_bwd, adaln_bwd_impl,

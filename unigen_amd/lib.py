@@ -88,6 +88,8 @@ SIGNATURES.update({
     "ug_colsum": (i32, [vp, i64, vp, i64, vp, i64, i64, i64, i64, f32, vp, i64, vp]),
     "ug_colsum_workspace_bytes": (i64, [i64, i64, i64]),
     "ug_gate_residual": (i32, [vp, i64, vp, i64, vp, i64, i64, vp, i64, i64, i64, vp]),
+    "ug_moe_gate_bwd": (i32, [vp, vp, vp, vp, i64, vp, i64, i64, i32, vp, i64, vp, vp]),
+    "ug_moe_gate_bwd_slices": (i64, [i64]),
     "ug_gelu_tanh": (i32, [vp, vp, i64, vp]),
     "ug_gelu_tanh_bwd": (i32, [vp, vp, vp, i64, vp]),
     "ug_adaln_modulate_bwd": (i32, [vp, i64, vp, i64, vp, i64, i64, vp, i64, vp, i64, i64, f32, vp]),
@@ -102,7 +104,7 @@ SIGNATURES.update({
     "ug_flash_attn_bwd": (i32, [vp, i64, i64] * 8 + [i64, i32, i64, i64, i32, f32, vp, vp, i64, vp]),
     "ug_flash_attn_fwd_lse": (i32, [vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, i64, i64, i64, i32, i64, i64, i32, f32, vp, i64, vp]),
 })
-_F32_TWINS = {"ug_gate_residual_f32": "ug_gate_residual", "ug_transpose_f32": "ug_transpose", "ug_colsum_f32": "ug_colsum", "ug_gelu_tanh_f32": "ug_gelu_tanh", "ug_gelu_tanh_bwd_f32": "ug_gelu_tanh_bwd",
+_F32_TWINS = {"ug_gate_residual_f32": "ug_gate_residual", "ug_moe_gate_bwd_f32": "ug_moe_gate_bwd", "ug_transpose_f32": "ug_transpose", "ug_colsum_f32": "ug_colsum", "ug_gelu_tanh_f32": "ug_gelu_tanh", "ug_gelu_tanh_bwd_f32": "ug_gelu_tanh_bwd",
               "ug_adaln_modulate_bwd_f32": "ug_adaln_modulate_bwd", "ug_qk_rmsnorm_rope_bwd_f32": "ug_qk_rmsnorm_rope_bwd",
               "ug_attn_prob_f32": "ug_attn_prob", "ug_attn_dscore_f32": "ug_attn_dscore", "ug_rowdot_f32": "ug_rowdot",
               "ug_gemm_f32": "ug_gemm_bf16", "ug_small_linear_f32": "ug_small_linear_bf16", "ug_adaln_modulate_f32": "ug_adaln_modulate",

@@ -346,6 +346,20 @@ def moe_gate_top1(x: torch.Tensor, c: torch.Tensor, wg: torch.Tensor, gates: tor
             "ug_moe_gate_top1")
 
 
+def moe_gate_bwd(gates: torch.Tensor, dgates: torch.Tensor, x: torch.Tensor, c: torch.Tensor, wg: torch.Tensor):
+    """Backward of moe_gate_top1: gates, d gates [S, E] fp32; x, c [S, D]; wg [E, D] -> (d(x + c) [S, D], d wg [E, D] in wg's dtype)."""
+    dt = _act(x, "x")
+    _chk(c, "c", dt); _chk(wg, "wg", dt); _chk(gates, "gates", torch.float32); _chk(dgates, "dgates", torch.float32)
+    S, D = x.shape
+    E = wg.shape[0]
+    assert x.stride(0) == c.stride(0) and wg.is_contiguous() and gates.is_contiguous() and dgates.is_contiguous() and gates.shape == dgates.shape == (S, E)
+    dx = torch.empty(S, D, device=x.device, dtype=dt)
+    part = torch.empty(int(L.load().ug_moe_gate_bwd_slices(S)), E, D, device=x.device, dtype=torch.float32)
+    L.check(_fn("ug_moe_gate_bwd", dt)(gates.data_ptr(), dgates.data_ptr(), x.data_ptr(), c.data_ptr(), x.stride(0), wg.data_ptr(), S, D, E, dx.data_ptr(), D,
+                                     part.data_ptr(), _stream()), "ug_moe_gate_bwd")
+    return dx, part.sum(0).to(dt)          # the kernel's per-slice fp32 partials, added in a fixed order
+
+
 def moe_capacity_rts(gates, idx, uniform, capacity: int, slot, token_of_slot, exp_counts, l_aux) -> None:
     _chk(gates, "gates", torch.float32); _chk(idx, "idx", torch.int32); _chk(uniform, "uniform", torch.float32)
     _chk(slot, "slot", torch.int32); _chk(token_of_slot, "token_of_slot", torch.int32)

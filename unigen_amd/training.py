@@ -29,6 +29,11 @@ def _lin(model, prefix: str, x: torch.Tensor) -> torch.Tensor:
     return A.linear(x, _p(model, prefix + ".weight"), _p(model, prefix + ".bias"))
 
 
+def _zero_res(model, prefix: str, x, z, scale: float):
+    """x + Linear(z) * conditioning_scale (src/UniGenTransformer.py:1104 + :1141 / :1166-1172): one GEMM with the residual epilogue."""
+    return A.linear_res_scale(x, z, _p(model, prefix + ".weight"), _p(model, prefix + ".bias"), scale)
+
+
 def _time_text_embed(model, prefix: str, t_f32, pooled, g_f32):
     """CombinedTimestep(Guidance)TextProjEmbeddings (diffusers embeddings.py)."""
     B, dt = pooled.shape[0], pooled.dtype
@@ -94,11 +99,12 @@ def _double_block_body(model, prefix: str, x, enc, temb, rope, text_first: bool 
     n, g, sh, sc, gm = _adaln(model, prefix + ".norm1", x, temb, 6)
     nc, cg, csh, csc, cgm = _adaln(model, prefix + ".norm1_context", enc, temb, 6)
     a, ca = _attention(model, prefix + ".attn", n, nc, rope, text_first)
-    # (A.gate_residual - the gated residual and its backward as HIP kernels - measured the same step time within box noise and 2 GB more per sample)
-    x = x + g.unsqueeze(1) * a
-    x = x + gm.unsqueeze(1) * _feed_forward(model, prefix + ".ff", A.adaln_modulate(x, sh, sc))
-    enc = enc + cg.unsqueeze(1) * ca
-    enc = enc + cgm.unsqueeze(1) * _feed_forward(model, prefix + ".ff_context", A.adaln_modulate(enc, csh, csc))
+    # x + gate * a: ONE HIP kernel forward (ug_gate_residual), two backward (gate * dy, per-sample column sums of dy * a) - round 2 left these to
+    # torch's mul + add kernels (at::native: 14 % of a training step with the cats and copies below)
+    x = A.gate_residual(x, a, g)
+    x = A.gate_residual(x, _feed_forward(model, prefix + ".ff", A.adaln_modulate(x, sh, sc)), gm)
+    enc = A.gate_residual(enc, ca, cg)
+    enc = A.gate_residual(enc, _feed_forward(model, prefix + ".ff_context", A.adaln_modulate(enc, csh, csc)), cgm)
     return enc, x
 
 
@@ -107,7 +113,8 @@ def _single_block_body(model, prefix: str, h, temb, rope):
     n, gate = _adaln(model, prefix + ".norm", h, temb, 3)
     mlp = A.GeluTanh.apply(_lin(model, prefix + ".proj_mlp", n))
     a, _ = _attention(model, prefix + ".attn", n, None, rope, True)
-    return h + gate.unsqueeze(1) * _lin(model, prefix + ".proj_out", torch.cat([a, mlp], dim=2))
+    # proj_out(cat[a, mlp]) without the [B, L, 5 D] concatenation: the mlp columns ride as the GEMM's K-segment extension (same bits)
+    return A.gate_residual(h, A.linear_cat2(a, mlp, _p(model, prefix + ".proj_out.weight"), _p(model, prefix + ".proj_out.bias")), gate)
 
 
 class _GatherRows(torch.autograd.Function):
@@ -151,9 +158,8 @@ def _route(model, x, c, uniform):
     B, N, D = x.shape
     E, S = model._ctl.expert_nums, B * N
     C = max(int(math.ceil(S / E)), 4)
-    logits = F.linear((x + c).reshape(S, D).float(), model.get_parameter("moe.moe_layer.gate.wg.weight").float())
-    gates = F.softmax(logits, dim=1)
-    idx = torch.argmax(gates, dim=1).to(torch.int32)
+    # gate logits / softmax / arg-max and their backward: HIP kernels (round 2 ran F.linear + F.softmax here: vendor BLAS on a product path)
+    gates, idx = A.MoeGate.apply(x.reshape(S, D).contiguous(), c.reshape(S, D).contiguous(), model.get_parameter("moe.moe_layer.gate.wg.weight"))
     if uniform is None:
         uniform = torch.rand(S, E, device=x.device, dtype=torch.float32)
     slot, tos = torch.empty(S, device=x.device, dtype=torch.int32), torch.empty(E, C, device=x.device, dtype=torch.int32)
@@ -252,15 +258,18 @@ def flux_forward(model, hidden_states, condition_hidden_states=None, conditionin
         else:
             z_in = x
         _, z = _double_block(model, f"control_joint_trans_blocks.{m}", z_in, moe["ctrl_enc"], moe["condition_temb"], rope_ctl_j, text_first=False)
-        x = x + _lin(model, f"controlnet_add_joint_blocks.{m}", z) * conditioning_scale
+        x = _zero_res(model, f"controlnet_add_joint_blocks.{m}", x, z, conditioning_scale)
     h = torch.cat([enc, x], dim=1)
     for j in range(n_s):
         h = _single_block(model, f"single_transformer_blocks.{j}", h, temb, rope_base)
         if ctl.use_single_trans_blocks:
             m = int(j / (n_s / n_cs))
             z = _single_block(model, f"control_single_trans_blocks.{m}", h, moe["condition_temb"], rope_ctl_s)
-            y = _lin(model, f"controlnet_add_single_blocks.{m}", z) * conditioning_scale
-            h = h + y if ctl.single_block_control_method == "overall_add" else torch.cat([h[:, :T], h[:, T:] + y[:, T:]], dim=1)
+            if ctl.single_block_control_method == "overall_add":
+                h = _zero_res(model, f"controlnet_add_single_blocks.{m}", h, z, conditioning_scale)
+            else:
+                y = _lin(model, f"controlnet_add_single_blocks.{m}", z) * conditioning_scale
+                h = torch.cat([h[:, :T], h[:, T:] + y[:, T:]], dim=1)
     x = h[:, T:]
     e = _lin(model, "norm_out.linear", F.silu(temb).to(dt))                     # AdaLayerNormContinuous: (scale, shift)
     scale, shift = e.chunk(2, dim=1)
@@ -273,6 +282,11 @@ def flux_forward(model, hidden_states, condition_hidden_states=None, conditionin
 # ---------------------------------------------------------------------------------------------------------------------
 def _gate(g, y):
     return g * y if g.dim() == y.dim() else g.unsqueeze(1) * y
+
+
+def _gres(x, g, y):
+    """x + gate * y: per-sample gates [B, D] through ug_gate_residual, per-token gates (the experts' [B, L, D] tembs) stay elementwise."""
+    return x + g * y if g.dim() == y.dim() else A.gate_residual(x, y, g.contiguous())
 
 
 def _mod(x, shift, scale):
@@ -311,14 +325,14 @@ def _sd3_joint_block(model, prefix: str, x, enc, temb, context_pre_only: bool = 
     a, ca = _sd3_attention(model, prefix + ".attn", n, nc, context_pre_only)
     if dual:                                                    # SD35AdaLayerNormZeroX: norm_hidden_states2 from the block's INPUT
         a2, _ = _sd3_attention(model, prefix + ".attn2", _mod(x, ch[6], ch[7]), None)
-    x = x + _gate(g, a)
+    x = _gres(x, g, a)
     if dual:
-        x = x + _gate(ch[8], a2)
-    x = x + _gate(gm, _feed_forward(model, prefix + ".ff", _mod(x, shm, scm)))
+        x = _gres(x, ch[8], a2)
+    x = _gres(x, gm, _feed_forward(model, prefix + ".ff", _mod(x, shm, scm)))
     if context_pre_only:
         return None, x
-    enc = enc + _gate(cc[2], ca)
-    enc = enc + _gate(cc[5], _feed_forward(model, prefix + ".ff_context", _mod(enc, cc[3], cc[4])))
+    enc = _gres(enc, cc[2], ca)
+    enc = _gres(enc, cc[5], _feed_forward(model, prefix + ".ff_context", _mod(enc, cc[3], cc[4])))
     return enc, x
 
 
@@ -326,8 +340,8 @@ def _sd3_single_block(model, prefix: str, x, temb):
     """SD3SingleTransformerBlock.forward (src/UniGenUtils.py:386-414); temb per sample [B, D] or per token [B, L, D]."""
     ch = _lin(model, prefix + ".norm1.linear", F.silu(temb)).chunk(6, dim=-1)
     a, _ = _sd3_attention(model, prefix + ".attn", _mod(x, ch[0], ch[1]), None)
-    x = x + _gate(ch[2], a)
-    return x + _gate(ch[5], _feed_forward(model, prefix + ".ff", _mod(x, ch[3], ch[4])))
+    x = _gres(x, ch[2], a)
+    return _gres(x, ch[5], _feed_forward(model, prefix + ".ff", _mod(x, ch[3], ch[4])))
 
 
 def _sd3_patch_embed(model, prefix: str, latents):
@@ -396,7 +410,7 @@ def sd3_forward(model, hidden_states, condition_hidden_states=None, conditioning
             z_in = x
         enc = enc_new
         _, z = _sd3_joint_block(model, f"control_transformer_blocks.{i}", z_in, moe["ctrl_enc"], moe["condition_temb"], dual=dual)
-        x = x + _lin(model, f"controlnet_add_blocks.{i}", z) * conditioning_scale
+        x = _zero_res(model, f"controlnet_add_blocks.{i}", x, z, conditioning_scale)
     e = _lin(model, "norm_out.linear", F.silu(temb).to(dt)).chunk(2, dim=1)
     out = _lin(model, "proj_out", A.adaln_modulate(x.contiguous(), e[1], e[0]))
     out = out.view(B, h, w, p, p, model.out_channels).permute(0, 5, 1, 3, 2, 4).reshape(B, model.out_channels, h * p, w * p)
