@@ -14,6 +14,7 @@ ap.add_argument("--ckpt", action="store_true")
 ap.add_argument("--layers", type=int, nargs=2, default=None)
 ap.add_argument("--steps", type=int, default=3)
 ap.add_argument("--sd3", action="store_true", help="UniGenSD3 (SD3.5-medium geometry, depth control, transformer-block experts) instead of UniGenFlux")
+ap.add_argument("--no-gradnorm", action="store_true", help="skip the per-step gradient-norm diagnostic (hundreds of small torch kernels: keep it out of rocprofv3 kernel statistics)")
 ap.add_argument("--shapes", action="store_true", help="per-shape table of the last step's GEMM / attention launches (grouped by FLOPs per launch)")
 a = ap.parse_args()
 dev, BF = torch.device("cuda:0"), torch.bfloat16
@@ -73,7 +74,7 @@ for step in range(a.steps + 1):
     torch.cuda.synchronize(); t2 = time.time()
     if step and timer is None:
         times.append((t1 - t0, t2 - t1))
-    gn = float(torch.sqrt(sum((p.grad.float() ** 2).sum() for p in model.parameters() if p.grad is not None)))
+    gn = float("nan") if a.no_gradnorm else float(torch.sqrt(sum((p.grad.float() ** 2).sum() for p in model.parameters() if p.grad is not None)))
     print(f"step {step}: loss {float(loss):.5f} grad-norm {gn:.4e} forward {t1 - t0:.3f}s backward {t2 - t1:.3f}s", flush=True)
 ops.set_timer(None)
 rates = {k: dict(launches=v["launches"], ms=round(v["ms"], 1), tflops=round(v["flops"] / v["ms"] / 1e9, 1)) for k, v in timer.summary().items()}

@@ -183,6 +183,81 @@ def linear_cat2(a: torch.Tensor, m: torch.Tensor, w: torch.Tensor, b: Optional[t
     return LinearCat2.apply(a.reshape(-1, a.shape[-1]).contiguous(), m.reshape(-1, m.shape[-1]).contiguous(), w, b).view(*lead, w.shape[0])
 
 
+def _adjacent(ts) -> bool:
+    """The tensors are consecutive row blocks of one contiguous buffer (the packed QKV / QKV+MLP weights of engine._pack)."""
+    for a, b in zip(ts[:-1], ts[1:]):
+        if a is None or b is None or not a.is_contiguous() or not b.is_contiguous() or a.dtype != b.dtype:
+            return False
+        if b.data_ptr() != a.data_ptr() + a.numel() * a.element_size() or a.shape[1:] != b.shape[1:]:
+            return False
+    return ts[0] is not None and ts[0].is_contiguous()
+
+
+class LinearN(torch.autograd.Function):
+    """n Linear layers that read the SAME rows x (to_q | to_k | to_v [| proj_mlp] of an attention block): ONE ug_gemm_bf16 over their packed
+    weights when the parameters sit back to back in memory (engine._pack re-points them so), n GEMMs into the column blocks of one buffer
+    otherwise. Returns the n column blocks as views. Backward: d x accumulates through the GEMM's residual epilogue (dy_1 W_1, then
+    R + dy_2 W_2, ...: the same bf16 sums autograd would form with separate add kernels), d w_i = dy_i^T x with ONE transposed copy of x."""
+
+    @staticmethod
+    def forward(ctx, x, n, *wb):
+        ws, bs = wb[:n], wb[n:]
+        M, K = x.shape
+        Ns = [w.shape[0] for w in ws]
+        out = torch.empty(M, sum(Ns), device=x.device, dtype=x.dtype)
+        has_b = all(b is not None for b in bs)
+        if _adjacent(list(ws)) and (has_b and _adjacent([b.view(-1, 1) for b in bs]) or all(b is None for b in bs)):
+            wp = torch.as_strided(ws[0], (sum(Ns), K), (K, 1))
+            bp = torch.as_strided(bs[0], (sum(Ns),), (1,)) if has_b else None
+            ops.gemm(x, wp, bp, out, M=M)
+        else:
+            c0 = 0
+            for w, b, N in zip(ws, bs, Ns):
+                ops.gemm(x, w, b, out[:, c0:], M=M)          # ldc = the buffer's row stride, N columns from column c0
+                c0 += N
+        ctx.save_for_backward(x, *ws)
+        ctx.n, ctx.Ns, ctx.has_b = n, Ns, [b is not None for b in bs]
+        outs, c0 = [], 0
+        for N in Ns:
+            outs.append(out[:, c0:c0 + N]); c0 += N
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        x, ws = ctx.saved_tensors[0], ctx.saved_tensors[1:]
+        n, M, K = ctx.n, x.shape[0], x.shape[1]
+        dx = None
+        dws, dbs = [None] * n, [None] * n
+        Mp = _pad64(M)
+        for i, (dy, w) in enumerate(zip(dys, ws)):
+            if dy is None:
+                continue
+            dy = dy.contiguous()
+            N = w.shape[0]
+            if ctx.needs_input_grad[0]:
+                if N % 64 != 0:
+                    raise L.UniGenHipError(f"LinearN backward: out_features={N} must be a multiple of 64")
+                if dx is None:
+                    dx = torch.empty(M, K, device=x.device, dtype=x.dtype)
+                    ops.gemm(dy, _w_transposed(w), None, dx, M=M)
+                else:                                             # dx += dy W (in place: every element is read and written by one lane)
+                    ops.gemm(dy, _w_transposed(w), None, dx, M=M, epilogue=L.EPI_RES_SCALE, residual=dx, alpha=1.0)
+            if ctx.needs_input_grad[2 + i]:
+                dw = torch.empty(N, K, device=x.device, dtype=x.dtype)
+                ops.gemm(ops.transpose(dy, Mp), _x_transposed(x, Mp), None, dw, M=N)
+                dws[i] = dw
+            if ctx.has_b[i] and ctx.needs_input_grad[2 + n + i]:
+                dbs[i] = ops.colsum(dy).view(N)
+        return (dx, None, *dws, *dbs)
+
+
+def linear_n(x: torch.Tensor, ws, bs):
+    """[F.linear(x, w_i, b_i) for i]: x [..., K] -> views [..., N_i] of one buffer."""
+    lead = x.shape[:-1]
+    outs = LinearN.apply(x.reshape(-1, x.shape[-1]).contiguous(), len(ws), *ws, *bs)
+    return [o.unflatten(0, lead) if len(lead) != 1 else o for o in outs]
+
+
 class MoeGate(torch.autograd.Function):
     """gates = softmax(F.linear((x + c).float(), wg.float())) [S, E] fp32 and the arg-max expert per token: ug_moe_gate_top1 forward,
     ug_moe_gate_bwd backward (deepspeed TopKGate, src/UniGenUtils.py:99). idx is not differentiable."""

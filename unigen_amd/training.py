@@ -29,6 +29,10 @@ def _lin(model, prefix: str, x: torch.Tensor) -> torch.Tensor:
     return A.linear(x, _p(model, prefix + ".weight"), _p(model, prefix + ".bias"))
 
 
+def _lin_n(model, x: torch.Tensor, prefixes):
+    return A.linear_n(x, [_p(model, p + ".weight") for p in prefixes], [_p(model, p + ".bias") for p in prefixes])
+
+
 def _zero_res(model, prefix: str, x, z, scale: float):
     """x + Linear(z) * conditioning_scale (src/UniGenTransformer.py:1104 + :1141 / :1166-1172): one GEMM with the residual epilogue."""
     return A.linear_res_scale(x, z, _p(model, prefix + ".weight"), _p(model, prefix + ".bias"), scale)
@@ -57,21 +61,30 @@ def _feed_forward(model, prefix: str, x):
     return _lin(model, prefix + ".net.2", A.GeluTanh.apply(_lin(model, prefix + ".net.0.proj", x)))
 
 
-def _attention(model, prefix: str, x, enc, rope, text_first: bool):
+def _attention(model, prefix: str, x, enc, rope, text_first: bool, mlp_prefix: Optional[str] = None):
     """Attention of a Flux block (FluxAttnProcessor2_0: [context | sample]; JointAttnRopeProcessor src/UniGenUtils.py:532-622: [sample | context]).
     RoPE rows follow the joint order, so each stream is rotated at its offset before the concatenation."""
     H = model.config.num_attention_heads
     N = x.shape[1]
     T = enc.shape[1] if enc is not None else 0
     x_off, e_off = (T, 0) if text_first else (0, N)
-    q = A.qk_norm_rope(_lin(model, prefix + ".to_q", x), _p(model, prefix + ".norm_q.weight"), rope, H, x_off)
-    k = A.qk_norm_rope(_lin(model, prefix + ".to_k", x), _p(model, prefix + ".norm_k.weight"), rope, H, x_off)
-    v = _lin(model, prefix + ".to_v", x)
+    # to_q | to_k | to_v read the same rows: one GEMM over the packed weights (engine._attn_qkv makes the three parameters views of one
+    # buffer), one accumulated d x in the backward instead of three GEMM outputs summed by autograd's add kernels
+    if mlp_prefix is not None:           # single block: keep flux._single_block's four-way pack [q | k | v | proj_mlp] (q, k, v are its first three row blocks)
+        names = [prefix + ".to_q", prefix + ".to_k", prefix + ".to_v", mlp_prefix]
+        model._pack(mlp_prefix.rsplit(".", 1)[0] + ".qkv_mlp.w", [n + ".weight" for n in names])
+        model._pack(mlp_prefix.rsplit(".", 1)[0] + ".qkv_mlp.b", [n + ".bias" for n in names])
+    else:
+        model._attn_qkv(prefix)
+    q, k, v = _lin_n(model, x, [prefix + ".to_q", prefix + ".to_k", prefix + ".to_v"])
+    q = A.qk_norm_rope(q, _p(model, prefix + ".norm_q.weight"), rope, H, x_off)
+    k = A.qk_norm_rope(k, _p(model, prefix + ".norm_k.weight"), rope, H, x_off)
     if enc is None:
         return A.attention(q, k, v, H), None
-    eq = A.qk_norm_rope(_lin(model, prefix + ".add_q_proj", enc), _p(model, prefix + ".norm_added_q.weight"), rope, H, e_off)
-    ek = A.qk_norm_rope(_lin(model, prefix + ".add_k_proj", enc), _p(model, prefix + ".norm_added_k.weight"), rope, H, e_off)
-    ev = _lin(model, prefix + ".add_v_proj", enc)
+    model._attn_add_qkv(prefix)
+    eq, ek, ev = _lin_n(model, enc, [prefix + ".add_q_proj", prefix + ".add_k_proj", prefix + ".add_v_proj"])
+    eq = A.qk_norm_rope(eq, _p(model, prefix + ".norm_added_q.weight"), rope, H, e_off)
+    ek = A.qk_norm_rope(ek, _p(model, prefix + ".norm_added_k.weight"), rope, H, e_off)
     order = (lambda a, b: torch.cat([a, b], 1)) if text_first else (lambda a, b: torch.cat([b, a], 1))
     o = A.attention(order(eq, q), order(ek, k), order(ev, v), H)
     eo, xo = (o[:, :T], o[:, T:]) if text_first else (o[:, N:], o[:, :N])
@@ -111,8 +124,8 @@ def _double_block_body(model, prefix: str, x, enc, temb, rope, text_first: bool 
 def _single_block_body(model, prefix: str, h, temb, rope):
     """diffusers FluxSingleTransformerBlock.forward."""
     n, gate = _adaln(model, prefix + ".norm", h, temb, 3)
-    mlp = A.GeluTanh.apply(_lin(model, prefix + ".proj_mlp", n))
-    a, _ = _attention(model, prefix + ".attn", n, None, rope, True)
+    a, _ = _attention(model, prefix + ".attn", n, None, rope, True, mlp_prefix=prefix + ".proj_mlp")
+    mlp = A.GeluTanh.apply(_lin(model, prefix + ".proj_mlp", n))      # its own GEMM: GELU wants a contiguous [M, 4 D] (a view of the fused output would be copied)
     # proj_out(cat[a, mlp]) without the [B, L, 5 D] concatenation: the mlp columns ride as the GEMM's K-segment extension (same bits)
     return A.gate_residual(h, A.linear_cat2(a, mlp, _p(model, prefix + ".proj_out.weight"), _p(model, prefix + ".proj_out.bias")), gate)
 
