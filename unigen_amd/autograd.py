@@ -224,7 +224,8 @@ class LinearN(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *dys):
-        x, ws = ctx.saved_tensors[0], ctx.saved_tensors[1:]
+        saved = ctx.saved_tensors            # ONE access: under torch.utils.checkpoint a second unpack of the same tensors is an error
+        x, ws = saved[0], saved[1:]
         n, M, K = ctx.n, x.shape[0], x.shape[1]
         dx = None
         dws, dbs = [None] * n, [None] * n
@@ -371,7 +372,9 @@ class QKNormRope(torch.autograd.Function):
         x2, w, cos, sin = ctx.saved_tensors
         B, Ls, heads, dh, pos_offset, eps = ctx.geom
         dy2 = dy.reshape(B * Ls, heads * dh).contiguous()
-        dx, dw = ops.qk_rmsnorm_rope_bwd(x2.contiguous(), dy2, w, cos, sin, rows_per_batch=Ls, pos_offset=pos_offset, heads=heads, dh=dh, eps=eps)
+        if x2.stride(-1) != 1:
+            x2 = x2.contiguous()                 # (a column block of a fused QKV output keeps its row stride: the kernel takes any)
+        dx, dw = ops.qk_rmsnorm_rope_bwd(x2, dy2, w, cos, sin, rows_per_batch=Ls, pos_offset=pos_offset, heads=heads, dh=dh, eps=eps)
         if w is None or not ctx.needs_input_grad[1]:
             dw = None
         return dx.view(B, Ls, heads * dh), dw, None, None, None, None, None
