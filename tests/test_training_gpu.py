@@ -324,10 +324,11 @@ def test_train_validate_train_keeps_weight_transposes_fresh(gpu):
 
     g1 = grads()
     assert len(AG._wt_cache) > 0                      # frozen base weights were transposed for dX and cached
-    ptr_before = model.get_parameter("transformer_blocks.0.attn.to_q.weight").data_ptr()
+    # (the training forward packs to_q | to_k | to_v itself since round 3; the AdaLN linears are packed by the inference engine only)
+    ptr_before = model.get_parameter("transformer_blocks.0.norm1.linear.weight").data_ptr()
     with torch.no_grad():
         model(timestep=t, **kw)                       # inference engine: packs, re-points p.data
-    assert model.get_parameter("transformer_blocks.0.attn.to_q.weight").data_ptr() != ptr_before
+    assert model.get_parameter("transformer_blocks.0.norm1.linear.weight").data_ptr() != ptr_before
     assert len(AG._wt_cache) == 0 and len(AG._xt_cache) == 0
     g2 = grads()
     e = float((g2 - g1).norm() / g1.norm())
