@@ -47,6 +47,7 @@ class FluxConfig:
     use_rope: bool = True
     use_pooled_prompt_embeds: bool = True
     use_shared_expert: bool = True
+    use_consis_module: bool = False
     use_single_trans_blocks: bool = True
     single_control_dev: int = 2
     single_block_control_method: str = "overall_add"
@@ -357,6 +358,17 @@ def comoe(state: State, cfg: FluxConfig, x, cond_tokens, ctrl_enc, control_temb,
     Returns (expert_hidden_states, expert_condition_hidden_states, l_aux, exp_counts, routing)."""
     c = linear(state, "control_x_embedder", cond_tokens)
     eh, ec, l_aux, exp_counts, routing = comoe_experts(state, cfg, x, c, pooled, cond_pooled, None, uniform)
+    if cfg.use_consis_module:
+        # "V2" consistency module (src/UniGenTransformer.py:984-1004): consis_module[0] is called TWICE, consis_module[1] is built (:909-920,
+        # so it is in the state dict and in trainable_control_modules) but never called. Both calls keep only the sample-stream output.
+        #   1. sample = expert condition states, context = condition tokens c, temb = condition_temb, ids (condition_ids | condition_ids)
+        #   2. sample = [expert hidden | result of 1], context = hidden states x, temb = kwargs['temb'] = control_temb (:1055), ids (img | cond | img)
+        N0 = x.shape[1]
+        rope_a = control_rope(cfg, torch.cat([ids["condition_ids"], ids["condition_ids"]], 0)) if cfg.use_rope else None
+        _, cech = flux_double_block(state, "consis_module.0", cfg, ec, c, condition_temb, rope_a, text_first=False)
+        rope_b = control_rope(cfg, torch.cat([ids["img_ids"], ids["condition_ids"], ids["img_ids"]], 0)) if cfg.use_rope else None
+        _, y = flux_double_block(state, "consis_module.0", cfg, torch.cat([eh, cech], 1), x, control_temb, rope_b, text_first=False)
+        eh, ec = eh + y[:, :N0], ec + y[:, N0:]
     if not cfg.use_shared_expert:
         return eh, ec, l_aux, exp_counts, routing
     # shared_expert[0](hidden=x, encoder=c, temb=condition_temb): sample-first [img | cond]   (:1013-1015)
@@ -567,6 +579,9 @@ def state_shapes(cfg: FluxConfig) -> Dict[str, Tuple[int, ...]]:
     if cfg.use_shared_expert:
         for k in (0, 1):
             s.update(_double_block_shapes(f"shared_expert.{k}", D, dh))
+    if cfg.use_consis_module:
+        for k in (0, 1):
+            s.update(_double_block_shapes(f"consis_module.{k}", D, dh))
     return s
 
 

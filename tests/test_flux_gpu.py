@@ -187,3 +187,45 @@ def test_full_depth_block_schedule_fp32(gpu):
     e_hip, e_ref = rel_l2(out16, truth16), rel_l2(ref16, truth16)
     report("flux_full_depth_bf16", out16, ref16, err_hip_vs_fp32=e_hip, err_oraclebf16_vs_fp32=e_ref)
     assert e_hip <= 1.25 * e_ref + 1e-3, (e_hip, e_ref)
+
+
+@pytest.mark.parametrize("cls_name,n_cond,shared", [("UniGenFlux", 1, True), ("UniGenFlux", 1, False), ("MultiCondtionUniGenFlux", 2, True)])
+def test_consistency_module_forward_matches_oracle(gpu, cls_name, n_cond, shared):
+    """`use_consis_module` (src/UniGenTransformer.py:893-923, 982-1004; off in every shipped configuration, rejected until round 3): the "V2" path -
+    consis_module[0] over (expert condition states | condition tokens), then over ([expert hidden | that] | hidden states), residuals onto
+    the experts' outputs, before the shared experts. fp32 verification twins <= 1e-3 vs the fp32 oracle (the orchestration), bf16 path as
+    close to that truth as the oracle's own bf16; consis_module.1 exists in the state dict and is never used (as in the reference)."""
+    import importlib
+    cls = getattr(importlib.import_module("src.UniGenTransformer"), cls_name)
+    cp = dict(CONTROL); cp.update(use_consis_module=True, use_shared_expert=shared)
+    B, grid, T = 2, 8, 32
+    rcfg = R.FluxConfig(condition_nums=n_cond, use_consis_module=True, use_shared_expert=shared, **TINY)
+    model = cls.from_config(dict(TINY), device=gpu, dtype=BF)
+    model.init_condition_block(condition_nums=n_cond, condition_types=["canny", "depth"][:n_cond], control_params=cp)
+    model.init_synthetic_(seed=21, std=0.05, bias_std=0.02)
+    state = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    assert set(state) == set(R.state_shapes(rcfg)) and any(k.startswith("consis_module.1.") for k in state)
+    assert "consis_module" in model.trainable_control_modules
+    inp = R.make_inputs(rcfg, B=B, grid=grid, T=T, n_cond=n_cond)
+    t = torch.full((B,), 0.75, dtype=BF)
+    truth, _, _ = R.unigen_flux_forward(state, rcfg, timestep=t, dtype=torch.float32, **inp)
+    ref16, _, cnt16 = R.unigen_flux_forward(state, rcfg, timestep=t, dtype=BF, **inp)
+    out, _, outs = model(timestep=t.to(gpu), **{k: _to_dev(v, gpu) for k, v in inp.items()})
+    err_hip, err_ref = rel_l2(out, truth), rel_l2(ref16, truth)
+    m = report(f"forward_consis_{cls_name}_{int(shared)}", out, ref16, err_hip_vs_fp32=err_hip, err_oraclebf16_vs_fp32=err_ref)
+    assert err_hip <= 1.25 * err_ref + 1e-3 and m["rel_l2"] <= 2e-2, m
+    assert torch.equal(outs["expert_counts"].cpu(), cnt16["expert_counts"])
+    # the module matters: the same weights without it give a different output
+    rcfg0 = R.FluxConfig(condition_nums=n_cond, use_consis_module=False, use_shared_expert=shared, **TINY)
+    without = R.unigen_flux_forward(state, rcfg0, timestep=t, dtype=BF, **inp)[0]
+    assert rel_l2(without, ref16) > 1e-3
+    # fp32 verification twins: the orchestration to the north star's tolerance
+    m32 = cls.from_config(dict(TINY), device=gpu, dtype=torch.float32)
+    m32.init_condition_block(condition_nums=n_cond, condition_types=["canny", "depth"][:n_cond], control_params=cp)
+    m32.load_state_dict({k: v.float() for k, v in state.items()})
+    cast = lambda k, v: ([x.to(gpu) if (k == "gate_uniform" or not x.is_floating_point()) else x.to(gpu).float() for x in v] if isinstance(v, (list, tuple))
+                         else (v.to(gpu) if (k == "gate_uniform" or not v.is_floating_point()) else v.to(gpu).float()))
+    out32 = m32(timestep=t.to(gpu).float(), **{k: cast(k, v) for k, v in inp.items()})[0]
+    e32 = rel_l2(out32, truth)
+    print(f"consis fp32 verification: {e32:.3e}")
+    assert e32 <= 1e-3, e32

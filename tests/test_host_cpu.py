@@ -613,3 +613,18 @@ def test_bench_refuses_more_ranks_than_gpus():
     # a torchrun-style environment whose world size disagrees with --gpus is an error too
     r = _run_bench(["--gpus", "2", "--dry-run"], env_extra=dict(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
     assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
+
+
+def test_consis_module_parameters_follow_the_reference():
+    """use_consis_module (src/UniGenTransformer.py:893-923): two joint blocks `consis_module.{0,1}` under the reference's key names, trainable,
+    default-initialised; the oracle's state shapes agree; with the flag off (every shipped configuration) nothing is registered."""
+    from oracle import unigen_ref as R
+    on, off = _model(use_consis_module=True), _model()
+    ks_on, ks_off = set(on.state_dict()), set(off.state_dict())
+    extra = ks_on - ks_off
+    assert extra and all(k.startswith("consis_module.") for k in extra) and not any(k.startswith("consis_module.") for k in ks_off)
+    assert {k.split(".")[1] for k in extra} == {"0", "1"} and "consis_module.0.attn.to_add_out.weight" in extra
+    assert ks_on == set(R.state_shapes(R.FluxConfig(condition_nums=1, use_consis_module=True, **TINY)))
+    assert "consis_module" in on.trainable_control_modules and "consis_module" not in off.trainable_control_modules
+    w = on.state_dict()["consis_module.0.attn.to_q.weight"].float()
+    assert float(w.std()) > 0 and torch.equal(on.state_dict()["consis_module.1.attn.norm_q.weight"], torch.ones(TINY["attention_head_dim"], dtype=w.dtype if False else on.state_dict()["consis_module.1.attn.norm_q.weight"].dtype))

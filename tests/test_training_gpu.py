@@ -375,3 +375,39 @@ def test_training_from_the_reference_initial_values_is_alive(gpu):
     assert not still_zero, f"{len(still_zero)} of {len(live)} live parameters have zero gradient, e.g. {still_zero[:6]}"
     assert all(gmax(k) == 0.0 for k in dead)
     assert all(torch.isfinite(model.get_parameter(k).grad.float()).all() for k in live)
+
+
+def test_consistency_module_gradients_match_oracle_autograd(gpu):
+    """`use_consis_module` under autograd (round 3): gradients of the control modules - consis_module.0 included, consis_module.1 exactly zero / None as
+    in the reference, where it is built but never called - through the fp32 twins against torch autograd of the fp32 oracle."""
+    import importlib
+    cls = importlib.import_module("src.UniGenTransformer").UniGenFlux
+    B, grid, T = 1, 8, 64
+    cp = dict(CONTROL); cp.update(use_consis_module=True)
+    rcfg = R.FluxConfig(condition_nums=1, use_consis_module=True, **TINY)
+    base = cls.from_config(dict(TINY), device=gpu, dtype=torch.float32)
+    base.init_condition_block(condition_nums=1, condition_types=["canny"], control_params=cp)
+    base.init_synthetic_(seed=13, std=0.05, bias_std=0.02)
+    base.init_trainable_param()
+    state = {k: v.detach().cpu() for k, v in base.state_dict().items()}
+    names = [n for n, p in base.named_parameters() if p.requires_grad]
+    assert any(n.startswith("consis_module.0.") for n in names) and any(n.startswith("consis_module.1.") for n in names)
+    inp = R.make_inputs(rcfg, B=B, grid=grid, T=T)
+    t = torch.full((B,), 0.75, dtype=BF)
+    target = torch.randn(B, grid * grid, 64, generator=torch.Generator().manual_seed(5))
+    st = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in state.items()}
+    _, loss_t, _ = _step(lambda: R.unigen_flux_forward(st, rcfg, timestep=t, dtype=torch.float32, **inp), target, torch.float32)
+    kw = {k: _dev(v, gpu, torch.float32 if k != "gate_uniform" and not k.endswith("_ids") else None) for k, v in inp.items()}
+    _, loss_h, _ = _step(lambda: base(timestep=t.to(gpu), **kw), target, torch.float32)
+    z = lambda g, k: g.detach().float().cpu() if g is not None else torch.zeros(state[k].shape)
+    gt = torch.cat([z(st[k].grad, k).flatten() for k in names])
+    gh = torch.cat([z(base.get_parameter(k).grad, k).flatten() for k in names])
+    e = float((gh - gt).norm() / gt.norm())
+    print(f"consis training fp32: loss {loss_h:.6f} vs {loss_t:.6f}; gradients rel_l2 {e:.3e}")
+    assert abs(loss_h - loss_t) <= 1e-5 * abs(loss_t) + 1e-7 and e <= 1e-3, (loss_h, loss_t, e)
+    c0 = torch.cat([z(st[k].grad, k).flatten() for k in names if k.startswith("consis_module.0.attn.to_q")])
+    assert float(c0.abs().max()) > 0, "consis_module.0 must receive a gradient"
+    for k in names:
+        if k.startswith("consis_module.1."):
+            g = base.get_parameter(k).grad
+            assert g is None or float(g.abs().max()) == 0.0, k

@@ -119,6 +119,9 @@ def control_param_shapes(cfg, ctl) -> Dict[str, Tuple[int, ...]]:
     if ctl.use_shared_expert:
         for k in (0, 1):
             _double_block_shapes(s, f"shared_expert.{k}", D, dh)
+    if getattr(ctl, "use_consis_module", False):
+        for k in (0, 1):          # both are built (:909-920); only consis_module[0] is ever called (:992,996)
+            _double_block_shapes(s, f"consis_module.{k}", D, dh)
     return s
 
 
@@ -188,8 +191,6 @@ class UniGenFlux(HipModule):
             # the shipped yaml yields stock single blocks fed per-token temb, which cannot run.
             raise ValueError("UniGenFlux needs control_params.use_rope or control_params.use_modulate (modulated experts); "
                              "the transformer-block expert variant of config/unigen.yaml is not executable in the reference either")
-        if get("use_consis_module", False):
-            raise ValueError("use_consis_module is not supported (off in every shipped configuration)")
         if get("cn2base_method", "add") != "add":
             raise ValueError("only cn2base_method='add' is supported (the CrossAttn variant is dead code in the reference)")
         dev = int(get("single_control_dev", 2))
@@ -199,6 +200,7 @@ class UniGenFlux(HipModule):
             use_pooled_prompt_embeds=bool(get("use_pooled_prompt_embeds", True)),
             use_encoder_hidden_states=bool(get("use_encoder_hidden_states", True)),
             use_shared_expert=bool(get("use_shared_expert", False)),
+            use_consis_module=bool(get("use_consis_module", False)),
             use_single_trans_blocks=bool(get("use_single_trans_blocks", True)),
             single_block_control_method=get("single_block_control_method", "overall_add"),
             cn_joint_layers=self.config.num_layers // dev, cn_single_layers=self.config.num_single_layers // dev,
@@ -223,6 +225,8 @@ class UniGenFlux(HipModule):
             names += ["control_single_trans_blocks", "controlnet_add_single_blocks"]
         if ctl.use_shared_expert:
             names.append("shared_expert")
+        if ctl.use_consis_module:
+            names.append("consis_module")
         self.trainable_control_modules = {n: getattr(self, n) for n in names}
         if get("use_transformer_params", False):
             self.init_control_param()
@@ -354,6 +358,30 @@ class UniGenFlux(HipModule):
         ops.gemm(xd, w_c, b_c, yc, M=C, groups=E, a_gstride=C * D, w_gstride=D * D, bias_gstride=D, c_gstride=C * D)
         ops.moe_dispatch_modulate(x, yc, mod_h, tos, xd, **mk)
         ops.gemm(xd, w_h, b_h, yh, M=C, groups=E, a_gstride=C * D, w_gstride=D * D, bias_gstride=D, c_gstride=C * D)
+        consis = None
+        if ctl.use_consis_module:
+            # "V2" consistency module (src/UniGenTransformer.py:984-1004; off in every shipped configuration, round 3): needs the experts' outputs in
+            # TOKEN order and separately - ug_moe_combine with the other operand zero gives exactly bf16(p * y). consis_module[0] runs twice
+            # (consis_module[1] only holds parameters), both times keeping the sample stream only (context = K / V).
+            zero = self._w("moe_zero", (E, C, D)); zero.zero_()
+            ehc = self._w("moe_ehc", (B, 2 * N, D))            # per sample [expert hidden | consistency condition states]
+            ehc2 = ehc.view(B * 2 * N, D)
+            ect = self._w("moe_ect", (S, D))                   # expert condition states, token order
+            ops.moe_combine(zero, yc, gates, idx, slot, ect, E=E, capacity=C)
+            for b in range(B):                                 # token rows of one sample are contiguous in ehc[b, :N]
+                sl = slice(b * N, (b + 1) * N)
+                ops.moe_combine(yh, zero, gates[sl], idx[sl], slot[sl], ehc[b, :N], E=E, capacity=C)
+            round_to = img_ids.dtype if ctl.use_rope else None
+            rope_a = self._rope([cond_ids, cond_ids], round_to) if ctl.use_rope else None
+            self._double_block("consis_module.0", B, _Stream(ect, N), _Stream(ehc2[N:], N, 2 * N), _Stream(c, N), None, condition_temb, rope_a, "cs0")
+            rope_b = self._rope([img_ids, img_ids, cond_ids], round_to) if ctl.use_rope else None
+            ycons = self._w("moe_consis", (B, 2 * N, D))
+            self._double_block("consis_module.0", B, _Stream(ehc2, 2 * N), _Stream(ycons.view(B * 2 * N, D), 2 * N), _Stream(x, N), None, control_temb, rope_b, "cs1")
+            eh2, ec2 = self._w("moe_eh2", (B, N, D)), self._w("moe_ec2", (B, N, D))
+            for b in range(B):
+                ops.add(ehc[b, :N], ycons[b, :N], eh2[b])                       # expert_hidden_states + consis_expert_hidden
+                ops.add(ect.view(B, N, D)[b], ycons[b, N:], ec2[b])             # expert_condition_states + consis_expert_condition_hidden
+            consis = (eh2, ec2)
         xs = cs = None
         s_map = ops.IDENT
         if ctl.use_shared_expert:
@@ -369,6 +397,23 @@ class UniGenFlux(HipModule):
             xcs = _Stream(xc2, 2 * N)
             self._double_block("shared_expert.1", B, xcs, xcs, _Stream(ctrl_enc, T), None, control_temb, rope1, "se1")
             xs, cs, s_map = xc2, xc2[N:], RowMap(N, 2 * N)      # token (b, n): image half at row b*2N + n, condition half N rows further
+        if consis is not None:
+            # (x_s + expert_h') + (cond_s + expert_c'), each sum a bf16 tensor (:1024, 1089): token-order operands, per sample
+            eh2, ec2 = consis
+            t1, t2 = self._w("moe_t1", (N, D)), self._w("moe_t2", (N, D))
+            z3 = z0.view(B, N, D)
+            for b in range(B):
+                if xs is not None:
+                    xsb, csb = xs.view(B, 2 * N, D)[b, :N], xs.view(B, 2 * N, D)[b, N:]
+                    ops.add(xsb, eh2[b], t1); ops.add(csb, ec2[b], t2)
+                    a_, b_ = t1, t2
+                else:
+                    a_, b_ = eh2[b], ec2[b]
+                if accumulate:
+                    ops.add(a_, b_, t1); ops.add(z3[b], t1, z3[b])
+                else:
+                    ops.add(a_, b_, z3[b])
+            return l_aux, exp_counts
         # combine + CoMoE residual sums for all B samples in one launch (:1024, 1089)
         ops.moe_combine(yh, yc, gates, idx, slot, z0, E=E, capacity=C, xs=xs, cs=cs, s_map=s_map, accumulate=accumulate)
         return l_aux, exp_counts

@@ -212,9 +212,15 @@ def _comoe(model, x, cond_tokens, ctrl_enc, control_temb, condition_temb, pooled
     N = x.shape[1]
     c = _lin(model, "control_x_embedder", cond_tokens)
     eh, ec, l_aux, exp_counts = _experts_modulated(model, x, c, pooled, cond_pooled, uniform)
+    round_to = img_ids.dtype if ctl.use_rope else None
+    if ctl.use_consis_module:            # "V2" consistency module (:984-1004): consis_module[0] twice, sample-stream outputs only
+        rope_a = model._rope([cond_ids, cond_ids], round_to) if ctl.use_rope else None
+        _, cech = _double_block(model, "consis_module.0", ec, c, condition_temb, rope_a, text_first=False)
+        rope_b = model._rope([img_ids, cond_ids, img_ids], round_to) if ctl.use_rope else None
+        _, y = _double_block(model, "consis_module.0", torch.cat([eh, cech], 1), x, control_temb, rope_b, text_first=False)
+        eh, ec = eh + y[:, :N], ec + y[:, N:]
     if not ctl.use_shared_expert:
         return eh, ec, l_aux, exp_counts
-    round_to = img_ids.dtype if ctl.use_rope else None
     rope0 = model._rope([img_ids, cond_ids], round_to) if ctl.use_rope else None
     cond_s, x_s = _double_block(model, "shared_expert.0", x, c, condition_temb, rope0, text_first=False)
     rope1 = model._rope([img_ids, cond_ids, txt_ids], round_to) if ctl.use_rope else None
