@@ -156,6 +156,11 @@ constexpr int HT_BYTES = 128 * 64 * 2;
 constexpr int KT_BYTES = 4 * HT_BYTES;
 constexpr int LDS256_BYTES = 2 * KT_BYTES;
 constexpr int SLOT_A0 = 0, SLOT_B0 = HT_BYTES, SLOT_B1 = 2 * HT_BYTES, SLOT_A1 = 3 * HT_BYTES;
+#ifdef UG_DIAG_STAMPS
+constexpr int UG_STAMP_LDS = 2048;
+#else
+constexpr int UG_STAMP_LDS = 0;
+#endif
 
 template <int EPI, bool LORA, int QKDH = 128>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, const int tiles_per_group, const int total_tiles, const int wide16_gm,
@@ -177,6 +182,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
     const int64_t M = p.M, N = p.N;
     const int nM = (int)((M + 255) / 256), nN = (int)((N + 255) / 256);
     const int st_off = wave * 16 * 128;
+#ifdef UG_DIAG_STAMPS
+    constexpr int stamp_off = LDS256_BYTES + 16 + (EPI == UG_EPI_QKV_ROPE ? 256 * 8 * 4 : 0);
+#endif
     const int wide16 = wide16_gm & 1;            // bits 8.. of the argument: GROUP_M of the tile walk (0 = 8)
     const bool rows_contig = (wide16_gm & 2) != 0;   // the C (and R) row maps never split a 256-row tile (rows per batch % 256 == 0): one scalar map per tile
     int a_off, b_off, ch0, ch1;          // fragment read offsets; set per tile (see the tile loop)
@@ -288,6 +296,17 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
     } while (0)
 #endif
 #define UG_BARRIER() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
+/* -DUG_DIAG_STAMPS (tools/gemm_stamps.py, a separate library build): s_memtime at five points of every tile of a workgroup, kept in 2 KiB of LDS
+ * behind the kernel's own (no global store inside the loop: stores count on the VM counter the ring's waits are counted against) and flushed to
+ * the split-K slab area after the last tile. Points: 0 tile top, 1 first K-tile's operands landed, 2 K loop done, 3 next tile's ring requested
+ * (epilogue starts), 4 epilogue issued. */
+#ifdef UG_DIAG_STAMPS
+    unsigned long long* const stamp_lds = (unsigned long long*)(smem + stamp_off);
+    int tile_seq = 0;
+#define UG_STAMP(I) do { if (threadIdx.x == 0 && tile_seq < 50) stamp_lds[tile_seq * 5 + (I)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define UG_STAMP(I) do { } while (0)
+#endif
 
     int tile = blockIdx.x;
     if (tile >= n_items) return;
@@ -315,6 +334,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
                 for (int a = 0; a < 4; ++a)
 #pragma unroll
                     for (int b = 0; b < 2; ++b) acc[i][j][a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        UG_STAMP(0);
         // In flight from before (issued ahead of the previous tile's epilogue, or below for the first tile):
         // A0(0) B0(0) B1(0) A1(0) [A0(1) B0(1)]. The 8 half-tile slots form a ring: a slot is re-staged two K-tiles ahead as soon as
         // its last ds_read is >= 3 segments old (B0's fragments stay in registers for phase 3, so its slot frees after phase 0):
@@ -351,6 +371,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
         const bool pre = nk >= 3, sif = stores_in_flight;
         if (pre) UG_WAIT_VM(12, sif); else if (nk > 1) UG_WAIT_VM(8, sif); else UG_WAIT_VM(4, sif);      // A0(0), B0(0) landed
         UG_BARRIER();
+        UG_STAMP(1);
         if (wr == 1) UG_BARRIER();          // waves 4-7 run one barrier behind
         for (int kt = 0; kt < nk; ++kt) {
             unsigned char* cb = smem + (kt & 1) * KT_BYTES;
@@ -392,6 +413,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
         }
 #undef UG_WAIT_VM
         if (wr == 0) UG_BARRIER();          // both groups level again; every LDS read of this tile has retired
+        UG_STAMP(2);
 
         // next tile: addresses + first K-tile DMA, then this tile's epilogue runs under it
         const int64_t m0 = cur.m0, n0 = cur.n0;
@@ -449,6 +471,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
             if (tile + (int)gridDim.x < n_items) cur = tile_src(tile + gridDim.x, lane_e); else cur.nk = 0;
         }
         if (cur.nk > 0) stage_first(cur);
+        UG_STAMP(3);
         if (rem >= 0) {
             // ---- split-K tail: slab out, ticket, last arriver reduces (cdna guide section 5, "in-launch split-K reduction") ----
             float* my = slabs + ((size_t)rem * nslices + slice) * 65536;
@@ -593,6 +616,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
                         __builtin_nontemporal_store(o, (u32x4*)(cp[rg & 1] + j * 128));
                     }
                 }
+                UG_STAMP(4);
+#ifdef UG_DIAG_STAMPS
+                ++tile_seq;
+#endif
                 continue;
             }
         }
@@ -644,6 +671,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
                     __builtin_nontemporal_store(o, (u32x4*)(cp[rg & 1] + j * 128));
                 }
             }
+            UG_STAMP(4);
+#ifdef UG_DIAG_STAMPS
+            ++tile_seq;
+#endif
             continue;
         }
         const bf16_t* bias = p.bias ? (const bf16_t*)p.bias + (int64_t)g * p.bias_gstride : nullptr;
@@ -694,6 +725,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
                 }
         }
     }
+#ifdef UG_DIAG_STAMPS
+    // flush: workgroup b's stamps at slabs[(b * 50 + seq) * 5 + point] as 64-bit ticks (slabs points at the caller's workspace + 4096)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0 && slabs != nullptr) {
+        unsigned long long* out = (unsigned long long*)slabs + (size_t)blockIdx.x * 250;
+        for (int i = 0; i < 250; ++i) out[i] = i < tile_seq * 5 ? stamp_lds[i] : 0ull;
+    }
+#endif
+#undef UG_STAMP
 #undef UG_MMA_QUADRANT
 #undef UG_BARRIER
 }
@@ -719,9 +759,9 @@ int launch(const ug_gemm_desc& d, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)gemm128_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)gemm256_kernel<EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256_BYTES + 16);
+        (void)hipFuncSetAttribute((const void*)gemm256_kernel<EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256_BYTES + 16 + UG_STAMP_LDS);
         if (EPI != UG_EPI_F32)
-            (void)hipFuncSetAttribute((const void*)gemm256_kernel<EPI, EPI != UG_EPI_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256_BYTES + 16);
+            (void)hipFuncSetAttribute((const void*)gemm256_kernel<EPI, EPI != UG_EPI_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256_BYTES + 16 + UG_STAMP_LDS);
         attr_set = true;
     }
     if (big) {
@@ -766,9 +806,12 @@ int launch(const ug_gemm_desc& d, hipStream_t s) {
             }
         }
         if (lora)       // (EPI_F32 never gets here with LoRA; its second instantiation is the plain kernel again)
-            hipLaunchKernelGGL((gemm256_kernel<EPI, EPI != UG_EPI_F32>), grid, dim3(512), LDS256_BYTES + 16, s, d, (int)(t256 / groups), total, wide16 | gm, full, nsl, slabs, tickets);
+            hipLaunchKernelGGL((gemm256_kernel<EPI, EPI != UG_EPI_F32>), grid, dim3(512), LDS256_BYTES + 16 + UG_STAMP_LDS, s, d, (int)(t256 / groups), total, wide16 | gm, full, nsl, slabs, tickets);
         else
-            hipLaunchKernelGGL((gemm256_kernel<EPI, false>), grid, dim3(512), LDS256_BYTES + 16, s, d, (int)(t256 / groups), total, wide16 | gm, full, nsl, slabs, tickets);
+#ifdef UG_DIAG_STAMPS
+            if (nsl == 1 && d.workspace && (size_t)d.workspace_bytes >= 4096 + (size_t)256 * 250 * 8) slabs = (float*)((char*)d.workspace + 4096);
+#endif
+            hipLaunchKernelGGL((gemm256_kernel<EPI, false>), grid, dim3(512), LDS256_BYTES + 16 + UG_STAMP_LDS, s, d, (int)(t256 / groups), total, wide16 | gm, full, nsl, slabs, tickets);
     } else {
         const int nM = (int)((d.M + BM - 1) / BM), nN = (int)((d.N + BN - 1) / BN);
         dim3 grid((unsigned)(nM * nN), 1, (unsigned)groups);
@@ -791,7 +834,7 @@ int launch_qkrope(const ug_gemm_desc& d, hipStream_t s) {
     UG_REQUIRE((d.rope_rpb == 0 || d.rope_rpb >= 256) && d.rope_rpb < (1ll << 31) && d.rope_pos0 >= 0 && d.rope_pos0 < (1ll << 31) &&
                (d.gelu_from_n == 0 || d.gelu_from_n >= d.qk_until_n) && (d.c_shift_from_n == 0 || d.c_shift_from_n >= d.qk_until_n),
                UG_ERR_BAD_SHAPE, "ug_gemm_bf16: UG_EPI_QKV_ROPE bad positions / column split");
-    constexpr int LDS = LDS256_BYTES + 16 + 256 * 8 * 4;
+    constexpr int LDS = LDS256_BYTES + 16 + 256 * 8 * 4 + UG_STAMP_LDS;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)gemm256_kernel<UG_EPI_QKV_ROPE, false, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -809,10 +852,14 @@ int launch_qkrope(const ug_gemm_desc& d, hipStream_t s) {
                (long long)d.c_rpb);
     const int wgm = 3 | ((ug_env_int("UG_GEMM_GROUP_M", 4) & 0xff) << 8);
     const dim3 grid((unsigned)(total < ncu ? total : ncu));
+    float* stamps = nullptr;
+#ifdef UG_DIAG_STAMPS
+    if (d.workspace && (size_t)d.workspace_bytes >= 4096 + (size_t)256 * 250 * 8) stamps = (float*)((char*)d.workspace + 4096);
+#endif
     if (qdh == 128)
-        hipLaunchKernelGGL((gemm256_kernel<UG_EPI_QKV_ROPE, false, 128>), grid, dim3(512), LDS, s, d, total, total, wgm, total, 1, (float*)nullptr, (unsigned*)nullptr);
+        hipLaunchKernelGGL((gemm256_kernel<UG_EPI_QKV_ROPE, false, 128>), grid, dim3(512), LDS, s, d, total, total, wgm, total, 1, stamps, (unsigned*)nullptr);
     else
-        hipLaunchKernelGGL((gemm256_kernel<UG_EPI_QKV_ROPE, false, 64>), grid, dim3(512), LDS, s, d, total, total, wgm, total, 1, (float*)nullptr, (unsigned*)nullptr);
+        hipLaunchKernelGGL((gemm256_kernel<UG_EPI_QKV_ROPE, false, 64>), grid, dim3(512), LDS, s, d, total, total, wgm, total, 1, stamps, (unsigned*)nullptr);
     UG_CHECK_LAUNCH("ug_gemm_bf16");
     return UG_OK;
 }
