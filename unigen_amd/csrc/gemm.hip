@@ -156,6 +156,9 @@ constexpr int HT_BYTES = 128 * 64 * 2;
 constexpr int KT_BYTES = 4 * HT_BYTES;
 constexpr int LDS256_BYTES = 2 * KT_BYTES;
 constexpr int SLOT_A0 = 0, SLOT_B0 = HT_BYTES, SLOT_B1 = 2 * HT_BYTES, SLOT_A1 = 3 * HT_BYTES;
+#ifndef UG_EPI_RES_PREFETCH
+#define UG_EPI_RES_PREFETCH 4          /* row-groups of residual chunks in flight in the full-tile epilogue (2 = rounds 1-2) */
+#endif
 #ifdef UG_DIAG_STAMPS
 constexpr int UG_STAMP_LDS = 2048;
 #else
@@ -638,37 +641,50 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
             bf16_t* const c_lane = Cb + (int64_t)(rowmap32((unsigned)m0, (unsigned)p.c_rpb, (unsigned)p.c_bstride) + (unsigned)rl) * p.ldc;
             const bf16_t* r_lane = nullptr;
             if constexpr (RES) r_lane = Rb + (int64_t)(rowmap32((unsigned)m0, (unsigned)p.r_rpb, (unsigned)p.r_bstride) + (unsigned)rl) * p.ldr;
-            u32x4 rbuf[2][2];
-            bf16_t* cp[2];
+            // Residual chunks are requested PF row-groups ahead (round 3: PF = 4, was 2). In-kernel stamps (tools/gemm_stamps.py) showed the R + gate * v
+            // epilogue at 8.3 us per tile against 3.7 us for bias only at equal stores: with one row-group of lead every row-group waited out a
+            // full memory latency behind the next tile's 16 ring DMAs. The fragment registers of the K loop are dead here, so 4 x 8 registers are free.
+            constexpr int PF = UG_EPI_RES_PREFETCH;
+            u32x4 rbuf[PF][2];
             auto open_rows = [&](int rg) {
-                const int off = (rg >> 2) * 128 + (rg & 3) * 16;
-                cp[rg & 1] = c_lane + (int64_t)off * p.ldc;
                 if constexpr (RES) {
-                    const bf16_t* rp = r_lane + (int64_t)off * p.ldr;
-                    rbuf[rg & 1][0] = gload16_asm(rp);
-                    rbuf[rg & 1][1] = gload16_asm_256(rp);
+                    const bf16_t* rp = r_lane + (int64_t)((rg >> 2) * 128 + (rg & 3) * 16) * p.ldr;
+                    rbuf[rg % PF][0] = gload16_asm(rp);
+                    rbuf[rg % PF][1] = gload16_asm_256(rp);
                 } else {
-                    rbuf[rg & 1][0] = rbuf[rg & 1][1] = (u32x4){0u, 0u, 0u, 0u};
+                    rbuf[rg % PF][0] = rbuf[rg % PF][1] = (u32x4){0u, 0u, 0u, 0u};
                 }
             };
             stores_in_flight = true;
-            open_rows(0);
+#pragma unroll
+            for (int rg = 0; rg < PF - 1; ++rg) open_rows(rg);
 #pragma unroll
             for (int rg = 0; rg < 8; ++rg) {
-                if (rg + 1 < 8) open_rows(rg + 1);
+                if (rg + PF - 1 < 8) open_rows(rg + PF - 1);
                 if constexpr (RES) {
-                    // younger than this row-group's two loads: the next row-group's two loads and the previous one's two stores
-                    if (rg == 0 || rg == 7) ug_wait_vm<2>(rbuf[rg & 1][0], rbuf[rg & 1][1]);
-                    else ug_wait_vm<4>(rbuf[rg & 1][0], rbuf[rg & 1][1]);
+                    // younger than this row-group's two loads on the in-order VM counter: the loads of the next min(PF - 1, 7 - rg) row-groups
+                    // and the stores of the previous min(PF - 1, rg) ones
+                    constexpr int LA = PF - 1;
+                    const int younger = 2 * ((7 - rg) < LA ? (7 - rg) : LA) + 2 * (rg < LA ? rg : LA);
+                    switch (younger) {
+                        case 2: ug_wait_vm<2>(rbuf[rg % PF][0], rbuf[rg % PF][1]); break;
+                        case 4: ug_wait_vm<4>(rbuf[rg % PF][0], rbuf[rg % PF][1]); break;
+                        case 6: ug_wait_vm<6>(rbuf[rg % PF][0], rbuf[rg % PF][1]); break;
+                        case 8: ug_wait_vm<8>(rbuf[rg % PF][0], rbuf[rg % PF][1]); break;
+                        case 10: ug_wait_vm<10>(rbuf[rg % PF][0], rbuf[rg % PF][1]); break;
+                        case 12: ug_wait_vm<12>(rbuf[rg % PF][0], rbuf[rg % PF][1]); break;
+                        default: ug_wait_vm<14>(rbuf[rg % PF][0], rbuf[rg % PF][1]); break;
+                    }
                 }
+                bf16_t* const cpr = c_lane + (int64_t)((rg >> 2) * 128 + (rg & 3) * 16) * p.ldc;
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const u32x4 o = (EPI_A == UG_EPI_BIAS_GELU && !ts.gelu)
                         ? epi_chunk_full<UG_EPI_BIAS>(p.alpha, acc[rg >> 2][j][rg & 3][0], acc[rg >> 2][j][rg & 3][1], fb[j][0], fb[j][1],
-                                                      fg[j][0], fg[j][1], rbuf[rg & 1][j])
+                                                      fg[j][0], fg[j][1], rbuf[rg % PF][j])
                         : epi_chunk_full<EPI_A>(p.alpha, acc[rg >> 2][j][rg & 3][0], acc[rg >> 2][j][rg & 3][1], fb[j][0], fb[j][1],
-                                              fg[j][0], fg[j][1], rbuf[rg & 1][j]);
-                    __builtin_nontemporal_store(o, (u32x4*)(cp[rg & 1] + j * 128));
+                                              fg[j][0], fg[j][1], rbuf[rg % PF][j]);
+                    __builtin_nontemporal_store(o, (u32x4*)(cpr + j * 128));
                 }
             }
             UG_STAMP(4);
