@@ -157,7 +157,7 @@ constexpr int KT_BYTES = 4 * HT_BYTES;
 constexpr int LDS256_BYTES = 2 * KT_BYTES;
 constexpr int SLOT_A0 = 0, SLOT_B0 = HT_BYTES, SLOT_B1 = 2 * HT_BYTES, SLOT_A1 = 3 * HT_BYTES;
 #ifndef UG_EPI_RES_PREFETCH
-#define UG_EPI_RES_PREFETCH 4          /* row-groups of residual chunks in flight in the full-tile epilogue (2 = rounds 1-2) */
+#define UG_EPI_RES_PREFETCH 8          /* row-groups of residual chunks in flight in the full-tile epilogue: all 8 (2 = rounds 1-2). Two-library A/B: 4: +-0.5 %, 8: +0.5...+1.1 % on the R + gate * v shapes; no spills (252 registers) */
 #endif
 #ifdef UG_DIAG_STAMPS
 constexpr int UG_STAMP_LDS = 2048;
@@ -641,9 +641,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
             bf16_t* const c_lane = Cb + (int64_t)(rowmap32((unsigned)m0, (unsigned)p.c_rpb, (unsigned)p.c_bstride) + (unsigned)rl) * p.ldc;
             const bf16_t* r_lane = nullptr;
             if constexpr (RES) r_lane = Rb + (int64_t)(rowmap32((unsigned)m0, (unsigned)p.r_rpb, (unsigned)p.r_bstride) + (unsigned)rl) * p.ldr;
-            // Residual chunks are requested PF row-groups ahead (round 3: PF = 4, was 2). In-kernel stamps (tools/gemm_stamps.py) showed the R + gate * v
+            // Residual chunks are requested PF row-groups ahead (round 3: all 8, was 2). In-kernel stamps (tools/gemm_stamps.py) showed the R + gate * v
             // epilogue at 8.3 us per tile against 3.7 us for bias only at equal stores: with one row-group of lead every row-group waited out a
-            // full memory latency behind the next tile's 16 ring DMAs. The fragment registers of the K loop are dead here, so 4 x 8 registers are free.
+            // full memory latency behind the next tile's 16 ring DMAs. The fragment registers of the K loop are dead here, so 8 x 8 registers are free; what the stamps also show: wave 0 finishes earlier (8.3 -> 7.0 us) but then waits longer at the next tile's first barrier - the workgroup's epilogue is bound by the CU's memory path (ring prefetch + R + C = 384 KB), not by one wave's latency chain.
             constexpr int PF = UG_EPI_RES_PREFETCH;
             u32x4 rbuf[PF][2];
             auto open_rows = [&](int rg) {
