@@ -604,6 +604,56 @@ sys.exit(1 if bad else 0)
     assert r.returncode == 0, r.stdout + r.stderr
 
 
+def test_gemm_cross_tile_stream_matches_default(gpu):
+    """Round 3: UG_GEMM_XTILE=1 - the last two K-tiles of a full tile stage the NEXT tile's first two K-tiles into the ring slots that would idle
+    (gemm.hip next_src), so the ring never drains at a tile boundary. Same MFMAs in the same order -> bit-identical. Shapes with 2-6 tiles per
+    workgroup, K-tile counts 4 .. 48 (even: streamed) and 5 (odd: falls back per tile), ragged M / N rims, a row-mapped A, every epilogue."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import os, sys
+os.environ["UG_ENV_DYNAMIC"] = "1"
+sys.path.insert(0, %r)
+import torch
+from unigen_amd import ops, lib as L
+from unigen_amd.ops import RowMap
+dev = torch.device("cuda:0")
+g = torch.Generator(device=dev).manual_seed(0)
+rn = lambda *s: torch.randn(*s, generator=g, device=dev).to(torch.bfloat16)
+bad = 0
+for (M, N, K, epi, mapped) in [(8192, 4096, 256, L.EPI_BIAS, False), (8192, 6144, 512, L.EPI_BIAS_GELU, False), (8192, 6144, 1024, L.EPI_RES_GATE, False),
+                               (8192, 4096, 256, L.EPI_RES_SCALE, True), (16384, 3072, 3072, L.EPI_RES_GATE, False), (8000, 4100 - 4, 384, L.EPI_BIAS, False),
+                               (8192, 4096, 320, L.EPI_BIAS, False), (8192, 8192, 640, L.EPI_F32, False)]:
+    rows = M // 2 if mapped else 0
+    a = rn(M + (128 if mapped else 0), K)
+    w, b = rn(N, K) * 0.1, rn(N)
+    r, gate = rn(M, N), rn((M + 255) // 256, N)
+    outs = []
+    for mode in ("0", "1"):
+        os.environ["UG_GEMM_XTILE"] = mode
+        out = torch.zeros(M, N, device=dev, dtype=torch.float32 if epi == L.EPI_F32 else torch.bfloat16)
+        kw = dict(M=M, epilogue=epi)
+        if mapped:
+            kw.update(a_map=RowMap(rows, rows + 64))
+        if epi in (L.EPI_RES_GATE, L.EPI_RES_SCALE):
+            kw.update(residual=r, alpha=0.7)
+        if epi == L.EPI_RES_GATE:
+            kw.update(gate=gate, gate_ld=N, rows_per_sample=256)
+        ops.gemm(a, w, None if epi == L.EPI_F32 else b, out, **kw)
+        outs.append(out)
+    torch.cuda.synchronize()
+    ref = (a.float()[:M] if not mapped else torch.cat([a.float()[:rows], a.float()[rows + 64:2 * rows + 64]])) @ w.float().t()
+    plain = epi in (L.EPI_BIAS, L.EPI_F32)
+    if not torch.equal(outs[0], outs[1]) or not torch.isfinite(outs[1].float()).all() or \
+            (plain and float(((outs[1].float() - (0 if epi == L.EPI_F32 else b.float())) - ref).norm() / ref.norm()) > 1e-2):
+        bad += 1
+        print("MISMATCH", M, N, K, epi, mapped, float((outs[1].float() - outs[0].float()).abs().max()))
+sys.exit(1 if bad else 0)
+""" % root
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
 def test_gemm_lora_segment_in_256_kernel_matches_128(gpu):
     """The LoRA K-segment (T . B^T appended to the K loop, src/lora_switching_module.py:11-38) runs in BOTH tile kernels; same MFMA shape and
     K order -> bit-identical. Shapes where the dispatcher picks the 256^2 kernel, ragged M, 1-2 LoRA K-tiles, K = 128 (shortest) .. 320."""

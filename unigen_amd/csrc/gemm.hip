@@ -247,6 +247,31 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
             t.b[h][i] = (const bf16_t*)p.lora_B + wn * p.ldb + c * 8 - p.K;
         }
     };
+    // Cross-tile stream (bit 2 of wide16_gm): the ring does not drain at a tile boundary. In the last two K-tiles of a full tile the staging
+    // slots that would idle (K-tiles nk, nk + 1 do not exist) take the NEXT tile's K-tiles 0 and 1 instead - same slots, same phases, same
+    // waits as the steady state - so the next tile's operands arrive under this tile's MFMAs and the epilogue's stores (and residual loads)
+    // have the CU's memory path to themselves. Like the LoRA segment switch, a half-tile pair's pointers are replaced right before its first
+    // use for the next tile, pre-biased by -nk * BK so the running K offsets stay valid; needs an even K-tile count (ring parity).
+    // MEASURED (round 3, profiles/r03o_*): bit-identical; the stamp profile shows the "next" share of a tile falling 2.5 -> 1.1 us and the first
+    // barrier's wait 4.0 -> 3.4 us, but the two K-tiles that now carry DMAs run at the steady-state 1.9 us instead of the DMA-free 1.3 us:
+    // -0.7 ... +0.9 % per cfg2 shape, 2.006 vs 2.012 images/s end to end -> OFF by default (UG_GEMM_XTILE=1 enables). What it establishes: the
+    // bytes a tile has to move are conserved, and the loop already runs at the pace of the CU's LDS / L1 path, not at the pace of its issue.
+    int64_t nx_m0 = 0, nx_n0 = 0; int nx_g = 0;
+    auto next_src = [&](TileSrc& t, int h, int nk_cur) __attribute__((always_inline)) {
+        int lane_l = lane;
+        asm volatile("" : "+v"(lane_l));
+        const bf16_t* Ab = (const bf16_t*)p.A + (int64_t)nx_g * p.a_gstride - (int64_t)nk_cur * BK;
+        const bf16_t* Wb = (const bf16_t*)p.W + (int64_t)nx_g * p.w_gstride - (int64_t)nk_cur * BK;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = wave * 16 + i * 8 + (lane_l >> 3);
+            const int c = (lane_l & 7) ^ (row & 7);
+            int64_t am = nx_m0 + h * 128 + row; if (am > M - 1) am = M - 1;
+            int64_t wn = nx_n0 + h * 128 + row; if (wn > N - 1) wn = N - 1;
+            t.a[h][i] = Ab + (int64_t)rowmap32((unsigned)am, (unsigned)p.a_rpb, (unsigned)p.a_bstride) * p.lda + c * 8;
+            t.b[h][i] = Wb + wn * p.ldw + c * 8;
+        }
+    };
     auto stage = [&](unsigned char* slot, const bf16_t* const (&src)[2], int64_t ko) {
         glds16(src[0] + ko, slot + st_off);
         glds16(src[1] + ko, slot + st_off + 8 * 128);
@@ -319,6 +344,16 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
     for (; tile < n_items; tile += gridDim.x) {
         const int nk = cur.nk;             // K-tiles of THIS work item (shadows the full count)
         if (nk == 0) break;                // padding item (only ever the last one of a workgroup)
+        bool xt = false;                   // this tile's last two K-tiles stage the next tile's first two (see next_src)
+        if constexpr (!LORA) {
+            const int nxt = tile + (int)gridDim.x;
+            if ((wide16_gm & 4) && nxt < full_tiles && nk >= 4 && !(nk & 1)) {
+                xt = true;
+                nx_g = nxt / tiles_per_group;
+                const TileCoord tc = tile_of_block(nxt - nx_g * tiles_per_group, nM, nN, (wide16_gm >> 8) ? (wide16_gm >> 8) : 8);
+                nx_m0 = (int64_t)tc.tm * 256; nx_n0 = (int64_t)tc.tn * 256;
+            }
+        }
         {   // Lane-derived constants of the K loop, re-derived per tile from an opaque copy of the lane id so that they are not live
             // through the epilogue (kept live across the whole tile loop, hipcc spilled a_off / b_off and reloaded them - with a
             // vmcnt(0) that drains the DMA ring - in every K-tile).
@@ -379,11 +414,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
         for (int kt = 0; kt < nk; ++kt) {
             unsigned char* cb = smem + (kt & 1) * KT_BYTES;
             unsigned char* nb = smem + ((kt & 1) ^ 1) * KT_BYTES;
-            const bool n1 = kt + 1 < nk, n2 = kt + 2 < nk;
+            const bool n1 = kt + 1 < nk || xt, n2 = kt + 2 < nk || xt;
             const bool pre0 = pre && kt == 0;
             const bool x01 = sif && (kt == 0 || (pre && kt == 1)), x3 = sif && kt == 0;
             const int64_t k1 = (int64_t)(kt + 1) * BK, k2 = (int64_t)(kt + 2) * BK;
             if (LORA && kt + 1 == nkA) lora_src(cur, 1);
+            if (!LORA && xt && kt + 1 == nk) next_src(cur, 1, nk);
             // phase 0: quadrant (0,0)
             read_A(cb + SLOT_A0); read_B(breg0, cb + SLOT_B0);
             if (pre0) UG_WAIT_VM(10, x01);
@@ -403,6 +439,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
             // phase 2: quadrant (1,1)
             read_A(cb + SLOT_A1);
             if (LORA && kt + 2 == nkA) lora_src(cur, 0);
+            if (!LORA && xt && kt + 2 == nk) next_src(cur, 0, nk);
             if (n2) stage(cb + SLOT_A0, cur.a[0], k2);
             UG_BARRIER();
             UG_MMA_QUADRANT(1, 1, breg);
@@ -461,7 +498,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
                                                         (lane_e >> 4) * 4);
                     }
                 }
-            if (tile + (int)gridDim.x < n_items) cur = tile_src(tile + gridDim.x, lane_e); else cur.nk = 0;
+            if (!xt) { if (tile + (int)gridDim.x < n_items) cur = tile_src(tile + gridDim.x, lane_e); else cur.nk = 0; }
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -470,10 +507,20 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
                     fg[j][nt][0] = bflo(pg[j][nt].x); fg[j][nt][1] = bfhi(pg[j][nt].x); fg[j][nt][2] = bflo(pg[j][nt].y); fg[j][nt][3] = bfhi(pg[j][nt].y);
                 }
             __builtin_amdgcn_sched_barrier(0);
-        } else {
+        } else if (!xt) {
             if (tile + (int)gridDim.x < n_items) cur = tile_src(tile + gridDim.x, lane_e); else cur.nk = 0;
         }
-        if (cur.nk > 0) stage_first(cur);
+        if (xt) {
+            // K-tiles 0 and 1 (A0 B0 B1 A1 | A0 B0) of the next tile were requested inside the K loop; the ring's last two half-tiles follow
+            // here (their slots were read in this tile's last K-tile), so the next tile starts exactly as after stage_first.
+            const int64_t unbias = (int64_t)nk * BK;
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) { cur.a[h][i] += unbias; cur.b[h][i] += unbias; }
+            stage(smem + KT_BYTES + SLOT_B1, cur.b[1], BK); stage(smem + KT_BYTES + SLOT_A1, cur.a[1], BK);
+            cur.m0 = nx_m0; cur.n0 = nx_n0; cur.g = nx_g;
+        } else if (cur.nk > 0) stage_first(cur);
         UG_STAMP(3);
         if (rem >= 0) {
             // ---- split-K tail: slab out, ticket, last arriver reduces (cdna guide section 5, "in-launch split-K reduction") ----
@@ -793,7 +840,8 @@ int launch(const ug_gemm_desc& d, hipStream_t s) {
         const bool res = d.epilogue == UG_EPI_RES_GATE || d.epilogue == UG_EPI_RES_SCALE;
         const int wide16 = (d.N % 8 == 0 && d.ldc % 8 == 0 && d.c_gstride % 8 == 0 && ug_aligned(d.C, 16) &&
                             (!res || (d.ldr % 8 == 0 && d.r_gstride % 8 == 0 && ug_aligned(d.R, 16)))) |
-                           ((d.c_rpb % 256 == 0 && (!res || d.r_rpb % 256 == 0) && ug_env_int("UG_GEMM_EPI_ROWS_CONTIG", 1)) ? 2 : 0);
+                           ((d.c_rpb % 256 == 0 && (!res || d.r_rpb % 256 == 0) && ug_env_int("UG_GEMM_EPI_ROWS_CONTIG", 1)) ? 2 : 0) |
+                           (ug_env_int("UG_GEMM_XTILE", 0) ? 4 : 0);
         // (Measured and dropped, round 3: plain instead of non-temporal C stores in the full-tile epilogue - +-0.5 % on every cfg2 shape,
         // profiles/r03d_gemm_cplain.log: the per-tile store cost is not the cache policy.)
         // UG_GEMM_PWG=1: the one-wave-per-SIMD kernel (gemm_pwg.hip) takes every shape it supports
@@ -866,7 +914,7 @@ int launch_qkrope(const ug_gemm_desc& d, hipStream_t s) {
     const int total = (int)((d.M / 256) * (d.N / 256));
     UG_REQUIRE(d.c_rpb % 256 == 0, UG_ERR_UNSUPPORTED, "ug_gemm_bf16: UG_EPI_QKV_ROPE needs the C row map's rows per batch (%lld) to be a multiple of 256",
                (long long)d.c_rpb);
-    const int wgm = 3 | ((ug_env_int("UG_GEMM_GROUP_M", 4) & 0xff) << 8);
+    const int wgm = 3 | (ug_env_int("UG_GEMM_XTILE", 0) ? 4 : 0) | ((ug_env_int("UG_GEMM_GROUP_M", 4) & 0xff) << 8);
     const dim3 grid((unsigned)(total < ncu ? total : ncu));
     float* stamps = nullptr;
 #ifdef UG_DIAG_STAMPS
