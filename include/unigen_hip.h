@@ -221,6 +221,8 @@ typedef struct ug_conv_desc {
     void* out; int64_t Ho, Wo, Cout;            /* Cout a multiple of 4 */
     int32_t KH, KW, stride, pad_t, pad_l, up;
     const void* zero_page;                      /* >= 128 bytes of zeros, 16-byte aligned (device): what padding taps read */
+    int64_t zero_page_bytes;                    /* size of zero_page (0 is read as 128). With >= 2 * (Cin + 64) bytes, Cin / 64 a power of two >= 2 and Cout,
+                                                 * B Ho Wo multiples of 256, the convolution runs on the 256^2 GEMM kernel (its A operand gathered per tap) */
 } ug_conv_desc;
 
 /* torch F.conv2d (called by diffusers Conv2d layers of the VAE) as an implicit GEMM on MFMA. */

@@ -98,6 +98,103 @@ def test_groupnorm_softmax_layout_sample(gpu, dt):
     assert rel_l2(zz, exp) <= (1e-6 if dt == F32 else 4e-3)
 
 
+def test_conv2d_on_the_256_gemm_kernel_matches_the_conv_kernel(gpu):
+    """Round 3: convolutions with Cout and B Ho Wo multiples of 256 and Cin / 64 a power of two >= 2 run on the 256^2
+    8-phase GEMM kernel, its A operand gathered per filter tap (gemm.hip CONV; UG_CONV256=0 keeps conv2d_nhwc_kernel). Same MFMA shape and the
+    same (tap, channel) accumulation order -> bit-identical, on 'same' / Downsample2D / Upsample2D geometry, with and without the residual,
+    one tile and several tiles per workgroup, batch > 1; and <= 1e-3 against torch's fp32 convolution rounded once."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import os, sys
+os.environ["UG_ENV_DYNAMIC"] = "1"
+os.environ["UG_CONV256_MIN_TILES"] = "1"
+sys.path.insert(0, %r)
+import torch
+import torch.nn.functional as F
+from unigen_amd import ops
+dev, BF = torch.device("cuda:0"), torch.bfloat16
+g = torch.Generator().manual_seed(7)
+rn = lambda *s, sc=1.0: (sc * torch.randn(*s, generator=g)).to(BF)
+bad = 0
+for (B, H, W, Cin, Cout, mode, res) in [(1, 32, 32, 128, 256, "same", False), (2, 16, 16, 256, 256, "up", True), (1, 64, 64, 128, 256, "down", False),
+                                        (2, 32, 32, 512, 512, "same", True), (1, 128, 128, 256, 512, "same", True), (3, 64, 64, 128, 1024, "same", False)]:
+    x, w, b = rn(B, Cin, H, W), rn(Cout, Cin, 3, 3, sc=(9 * Cin) ** -0.5), rn(Cout, sc=0.1)
+    if mode == "same":
+        ref = F.conv2d(x.float(), w.float(), b.float(), padding=1); kw = dict(stride=1, pad_t=1, pad_l=1, up=0)
+    elif mode == "down":
+        ref = F.conv2d(F.pad(x.float(), (0, 1, 0, 1)), w.float(), b.float(), stride=2); kw = dict(stride=2, pad_t=0, pad_l=0, up=0)
+    else:
+        ref = F.conv2d(F.interpolate(x.float(), scale_factor=2.0, mode="nearest"), w.float(), b.float(), padding=1); kw = dict(stride=1, pad_t=1, pad_l=1, up=1)
+    Ho, Wo = ref.shape[-2:]
+    ref = ref.to(BF).float()
+    r = rn(B, Cout, Ho, Wo) if res else None
+    if res:
+        ref = (ref + r.float()).to(BF).float()
+    xh = x.permute(0, 2, 3, 1).reshape(B * H * W, Cin).contiguous().to(dev)
+    wh = w.permute(0, 2, 3, 1).contiguous().to(dev)
+    rh = r.permute(0, 2, 3, 1).reshape(B * Ho * Wo, Cout).contiguous().to(dev) if res else None
+    outs = []
+    for mode2 in ("0", "1"):
+        os.environ["UG_CONV256"] = mode2
+        out = torch.zeros(B * Ho * Wo, Cout, device=dev, dtype=BF)
+        ops.conv2d_nhwc(xh, wh, b.to(dev), out, B=B, H=H, W=W, Ho=Ho, Wo=Wo, KH=3, KW=3, residual=rh, **kw)
+        outs.append(out)
+    torch.cuda.synchronize()
+    got = outs[1].float().cpu().view(B, Ho, Wo, Cout).permute(0, 3, 1, 2)
+    rel = float((got - ref).norm() / ref.norm())
+    if not torch.equal(outs[0], outs[1]) or rel > 1e-3:
+        bad += 1
+        print("MISMATCH", B, H, W, Cin, Cout, mode, res, rel, float((outs[0].float() - outs[1].float()).abs().max()))
+sys.exit(1 if bad else 0)
+""" % root
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_groupnorm_fast_kernels_match_generic(gpu):
+    """Round 3: the 16-byte GroupNorm kernels of the AutoencoderKL widths (C = 128 / 256 / 512; UG_GN_FAST=0 restores the
+    generic pair) - same statistics layout and fp64 combine; SiLU through v_exp_f32 / v_rcp_f32. Against the generic kernels: without SiLU at
+    most one bf16 ulp on isolated elements (the statistics' partial sums associate differently), with SiLU the same; against torch's fp32
+    group_norm (+ silu) <= 1e-3 relative L2 like the generic test. Ragged pixel counts (not a multiple of the 256-row slab or of 256 / (C / 8))."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import os, sys
+os.environ["UG_ENV_DYNAMIC"] = "1"
+sys.path.insert(0, %r)
+import torch
+import torch.nn.functional as F
+from unigen_amd import ops
+dev, BF = torch.device("cuda:0"), torch.bfloat16
+g = torch.Generator().manual_seed(5)
+bad = 0
+for (B, HW, C) in [(2, 1000, 128), (1, 4099, 256), (2, 777, 512), (1, 64 * 64, 512), (1, 3, 128)]:
+    x = (torch.randn(B, HW, C, generator=g) * 2 + 0.5).to(BF)
+    ga, be = (1 + 0.1 * torch.randn(C, generator=g)).to(BF), (0.1 * torch.randn(C, generator=g)).to(BF)
+    for silu in (False, True):
+        outs = []
+        for mode in ("0", "1"):
+            os.environ["UG_GN_FAST"] = mode
+            out = torch.empty(B * HW, C, device=dev, dtype=BF)
+            ops.groupnorm_nhwc(x.reshape(B * HW, C).to(dev), ga.to(dev), be.to(dev), out, B=B, HW=HW, groups=32, silu=silu)
+            outs.append(out.float().cpu().view(B, HW, C))
+        ref = F.group_norm(x.float().transpose(1, 2), 32, ga.float(), be.float(), eps=1e-6).transpose(1, 2).to(BF).float()
+        if silu:
+            ref = F.silu(ref)
+        rel = float((outs[1] - ref).norm() / ref.norm())
+        d = (outs[1] - outs[0]).abs()
+        ulp = outs[0].abs().clamp_min(1e-30) * 2.0 ** -7          # one bf16 step is at most 2^-7 of the value
+        frac = float((d > 0).float().mean())
+        if rel > 1e-3 or bool((d > ulp * 1.001).any()) or frac > 2e-3:
+            bad += 1
+            print("MISMATCH", B, HW, C, silu, rel, frac, float((d / ulp).max()))
+sys.exit(1 if bad else 0)
+""" % root
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
 def _models(gpu, seed=3):
     cls = importlib.import_module("unigen_amd.vae").AutoencoderKL
     m16 = cls.from_config(dict(TINY), device=gpu, dtype=BF).init_synthetic_(seed)

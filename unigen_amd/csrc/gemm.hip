@@ -165,10 +165,10 @@ constexpr int UG_STAMP_LDS = 2048;
 constexpr int UG_STAMP_LDS = 0;
 #endif
 
-template <int EPI, bool LORA, int QKDH = 128>
+template <int EPI, bool LORA, int QKDH = 128, bool CONV = false>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, const int tiles_per_group, const int total_tiles, const int wide16_gm,
                                                           const int full_tiles, const int nslices, float* __restrict__ slabs,
-                                                          unsigned* __restrict__ tickets) {
+                                                          unsigned* __restrict__ tickets, const UgConvGeom cv) {
     // PERSISTENT: the grid is one workgroup per CU; each walks tiles blockIdx.x, +gridDim.x, ... (same XCD-aware order as a plain
     // launch would see round by round). The first K-tile of the NEXT tile is put in flight before the epilogue of the current one,
     // so workgroup relaunch, address set-up and the first DMA latency overlap the C stores instead of preceding the main loop.
@@ -196,7 +196,18 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
     const int nkA = (int)(p.K / BK);
     const int nk = nkA + (LORA ? p.lora_r / BK : 0);
 
-    struct TileSrc { const bf16_t* a[2][2]; const bf16_t* b[2][2]; int64_t m0, n0; int g; int nk; int rem; int slice; };
+    struct TileSrc { const bf16_t* a[2][2]; const bf16_t* b[2][2]; int64_t m0, n0; int g; int nk; int rem; int slice; unsigned pk[2][2]; };
+    // CONV (AutoencoderKL 3x3 convolutions, vae.hip): A row m is output pixel (b, oy, ox), kept packed per staging row (b << 24 | oy << 12 | ox);
+    // the K axis runs tap by tap (ktp K-tiles each), and a half-tile pair's A pointers are re-derived for the next tap right before that tap's
+    // first K-tile is staged (the LoRA segment's switch, once per tap): source pixel of the tap (stride, one-sided padding and nearest-2x
+    // upsampling folded in exactly as conv2d_nhwc_kernel does), or the zero page for padding; pre-biased by -tap * Cin so the running K offset applies.
+    auto conv_ptr = [&](unsigned pk, int tap, int c) __attribute__((always_inline)) {
+        const int ky = tap / cv.KW, kx = tap - ky * cv.KW;
+        const int yv = (int)((pk >> 12) & 0xfffu) * cv.stride + ky - cv.pad_t, xv = (int)(pk & 0xfffu) * cv.stride + kx - cv.pad_l;
+        const bool ok = (unsigned)yv < (unsigned)(cv.H << cv.up) && (unsigned)xv < (unsigned)(cv.W << cv.up);
+        const int64_t pix = ((int64_t)(pk >> 24) * cv.H + (yv >> cv.up)) * cv.W + (xv >> cv.up);
+        return (ok ? (const bf16_t*)p.A + pix * cv.Cin : cv.zero) + c * 8 - (int64_t)tap * cv.Cin;
+    };
     // work item w -> tile and K range. Items >= full_tiles are K-slices of remainder tile `rem`; a tile's slices share blockIdx & 7
     // (= one XCD under round-robin placement; speed only).
     const int n_items = full_tiles + (((total_tiles - full_tiles) + 7) / 8) * 8 * nslices;
@@ -229,10 +240,25 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
                 const int c = (lane & 7) ^ (row & 7);
                 int64_t am = t.m0 + h * 128 + row; if (am > M - 1) am = M - 1;
                 int64_t wn = t.n0 + h * 128 + row; if (wn > N - 1) wn = N - 1;
-                t.a[h][i] = Ab + (int64_t)rowmap32((unsigned)am, (unsigned)p.a_rpb, (unsigned)p.a_bstride) * p.lda + c * 8 + (int64_t)kb * BK;
+                if constexpr (CONV) {
+                    const unsigned hw = (unsigned)(cv.Ho * cv.Wo), bb = (unsigned)am / hw, rr = (unsigned)am - bb * hw, oy = rr / (unsigned)cv.Wo;
+                    t.pk[h][i] = bb << 24 | oy << 12 | (rr - oy * (unsigned)cv.Wo);
+                    t.a[h][i] = conv_ptr(t.pk[h][i], 0, c);
+                } else {
+                    t.a[h][i] = Ab + (int64_t)rowmap32((unsigned)am, (unsigned)p.a_rpb, (unsigned)p.a_bstride) * p.lda + c * 8 + (int64_t)kb * BK;
+                }
                 t.b[h][i] = Wb + wn * p.ldw + c * 8 + (int64_t)kb * BK;
             }
         return t;
+    };
+    auto conv_src = [&](TileSrc& t, int h, int tap) __attribute__((always_inline)) {
+        int lane_l = lane;
+        asm volatile("" : "+v"(lane_l));
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = wave * 16 + i * 8 + (lane_l >> 3);
+            t.a[h][i] = conv_ptr(t.pk[h][i], tap, (lane_l & 7) ^ (row & 7));
+        }
     };
     auto lora_src = [&](TileSrc& t, int h) {
         int lane_l = lane;
@@ -345,7 +371,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
         const int nk = cur.nk;             // K-tiles of THIS work item (shadows the full count)
         if (nk == 0) break;                // padding item (only ever the last one of a workgroup)
         bool xt = false;                   // this tile's last two K-tiles stage the next tile's first two (see next_src)
-        if constexpr (!LORA) {
+        if constexpr (!LORA && !CONV) {
             const int nxt = tile + (int)gridDim.x;
             if ((wide16_gm & 4) && nxt < full_tiles && nk >= 4 && !(nk & 1)) {
                 xt = true;
@@ -420,6 +446,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
             const int64_t k1 = (int64_t)(kt + 1) * BK, k2 = (int64_t)(kt + 2) * BK;
             if (LORA && kt + 1 == nkA) lora_src(cur, 1);
             if (!LORA && xt && kt + 1 == nk) next_src(cur, 1, nk);
+            if (CONV && n1 && ((kt + 1) & (cv.ktp - 1)) == 0) conv_src(cur, 1, (kt + 1) / cv.ktp);
             // phase 0: quadrant (0,0)
             read_A(cb + SLOT_A0); read_B(breg0, cb + SLOT_B0);
             if (pre0) UG_WAIT_VM(10, x01);
@@ -440,6 +467,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
             read_A(cb + SLOT_A1);
             if (LORA && kt + 2 == nkA) lora_src(cur, 0);
             if (!LORA && xt && kt + 2 == nk) next_src(cur, 0, nk);
+            if (CONV && n2 && ((kt + 2) & (cv.ktp - 1)) == 0) conv_src(cur, 0, (kt + 2) / cv.ktp);
             if (n2) stage(cb + SLOT_A0, cur.a[0], k2);
             UG_BARRIER();
             UG_MMA_QUADRANT(1, 1, breg);
@@ -870,12 +898,12 @@ int launch(const ug_gemm_desc& d, hipStream_t s) {
             }
         }
         if (lora)       // (EPI_F32 never gets here with LoRA; its second instantiation is the plain kernel again)
-            hipLaunchKernelGGL((gemm256_kernel<EPI, EPI != UG_EPI_F32>), grid, dim3(512), LDS256_BYTES + 16 + UG_STAMP_LDS, s, d, (int)(t256 / groups), total, wide16 | gm, full, nsl, slabs, tickets);
+            hipLaunchKernelGGL((gemm256_kernel<EPI, EPI != UG_EPI_F32>), grid, dim3(512), LDS256_BYTES + 16 + UG_STAMP_LDS, s, d, (int)(t256 / groups), total, wide16 | gm, full, nsl, slabs, tickets, UgConvGeom{});
         else
 #ifdef UG_DIAG_STAMPS
             if (nsl == 1 && d.workspace && (size_t)d.workspace_bytes >= 4096 + (size_t)256 * 250 * 8) slabs = (float*)((char*)d.workspace + 4096);
 #endif
-            hipLaunchKernelGGL((gemm256_kernel<EPI, false>), grid, dim3(512), LDS256_BYTES + 16 + UG_STAMP_LDS, s, d, (int)(t256 / groups), total, wide16 | gm, full, nsl, slabs, tickets);
+            hipLaunchKernelGGL((gemm256_kernel<EPI, false>), grid, dim3(512), LDS256_BYTES + 16 + UG_STAMP_LDS, s, d, (int)(t256 / groups), total, wide16 | gm, full, nsl, slabs, tickets, UgConvGeom{});
     } else {
         const int nM = (int)((d.M + BM - 1) / BM), nN = (int)((d.N + BN - 1) / BN);
         dim3 grid((unsigned)(nM * nN), 1, (unsigned)groups);
@@ -921,14 +949,41 @@ int launch_qkrope(const ug_gemm_desc& d, hipStream_t s) {
     if (d.workspace && (size_t)d.workspace_bytes >= 4096 + (size_t)256 * 250 * 8) stamps = (float*)((char*)d.workspace + 4096);
 #endif
     if (qdh == 128)
-        hipLaunchKernelGGL((gemm256_kernel<UG_EPI_QKV_ROPE, false, 128>), grid, dim3(512), LDS, s, d, total, total, wgm, total, 1, stamps, (unsigned*)nullptr);
+        hipLaunchKernelGGL((gemm256_kernel<UG_EPI_QKV_ROPE, false, 128>), grid, dim3(512), LDS, s, d, total, total, wgm, total, 1, stamps, (unsigned*)nullptr, UgConvGeom{});
     else
-        hipLaunchKernelGGL((gemm256_kernel<UG_EPI_QKV_ROPE, false, 64>), grid, dim3(512), LDS, s, d, total, total, wgm, total, 1, stamps, (unsigned*)nullptr);
+        hipLaunchKernelGGL((gemm256_kernel<UG_EPI_QKV_ROPE, false, 64>), grid, dim3(512), LDS, s, d, total, total, wgm, total, 1, stamps, (unsigned*)nullptr, UgConvGeom{});
     UG_CHECK_LAUNCH("ug_gemm_bf16");
     return UG_OK;
 }
 
 }  // namespace
+
+// ug_conv2d_nhwc on the 256^2 kernel (see UgConvGeom): whole 256^2 tiles, bias or residual epilogue, no split-K tail (no workspace at this boundary).
+int ug_gemm_launch_conv256(const ug_gemm_desc& d, const UgConvGeom& cv, hipStream_t s) {
+    if (d.M % 256 || d.N % 256 || d.K % BK || cv.ktp < 2 || (cv.ktp & (cv.ktp - 1)) || d.K / BK < 3) return UG_ERR_UNSUPPORTED;
+    static int ncu = 0;
+    if (ncu == 0) {
+        int dev = 0; hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
+        if (ncu <= 0) ncu = 256;
+    }
+    constexpr int LDS = LDS256_BYTES + 16 + UG_STAMP_LDS;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm256_kernel<UG_EPI_BIAS, false, 128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute((const void*)gemm256_kernel<UG_EPI_RES_SCALE, false, 128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+    }
+    const int total = (int)((d.M / 256) * (d.N / 256));
+    const int wgm = 3 | ((ug_env_int("UG_GEMM_GROUP_M", 4) & 0xff) << 8);       // 16-byte epilogue accesses, one row map per tile (C and R are plain [M][N])
+    const dim3 grid((unsigned)(total < ncu ? total : ncu));
+    if (d.epilogue == UG_EPI_RES_SCALE)
+        hipLaunchKernelGGL((gemm256_kernel<UG_EPI_RES_SCALE, false, 128, true>), grid, dim3(512), LDS, s, d, total, total, wgm, total, 1, (float*)nullptr, (unsigned*)nullptr, cv);
+    else
+        hipLaunchKernelGGL((gemm256_kernel<UG_EPI_BIAS, false, 128, true>), grid, dim3(512), LDS, s, d, total, total, wgm, total, 1, (float*)nullptr, (unsigned*)nullptr, cv);
+    UG_CHECK_LAUNCH("ug_conv2d_nhwc(256)");
+    return UG_OK;
+}
 
 extern "C" int64_t ug_gemm_workspace_bytes(void) { return 4096 + (int64_t)256 * 65536 * (int64_t)sizeof(float); }
 

@@ -6,6 +6,11 @@
 // one-wave-per-SIMD 256^2 kernel (gemm_pwg.hip); the dispatcher in gemm.hip decides when it runs
 int ug_gemm_launch_pwg(const ug_gemm_desc& d, hipStream_t s);
 
+// Implicit-GEMM convolution on the 256^2 kernel (vae.hip -> gemm.hip): the A operand of ug_gemm_desc is the NHWC activation, gathered per filter tap.
+// M = B Ho Wo output pixels, N = Cout, K = KH KW Cin with Cin / 64 = ktp K-tiles per tap (a power of two >= 2); `zero` = at least Cin + 64 zero elements.
+struct UgConvGeom { const bf16_t* zero; int H, W, Cin, Ho, Wo, KW, stride, pad_t, pad_l, up, ktp; };
+int ug_gemm_launch_conv256(const ug_gemm_desc& d, const UgConvGeom& cv, hipStream_t s);      // UG_ERR_UNSUPPORTED: the caller keeps its own kernel
+
 namespace {
 
 typedef const __attribute__((address_space(1))) void* gptr_t;

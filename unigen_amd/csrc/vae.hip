@@ -239,6 +239,91 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
     }
 }
 
+// bf16 product kernels for C = 8 * CCH, CCH in {16, 32, 64} (the AutoencoderKL widths 128 / 256 / 512): thread -> one 16-byte channel chunk
+// (constant per thread: gamma / beta / statistics are loaded once) x every (256 / CCH)-th pixel row of a GN_FAST_ROWS-row slab, four loads in
+// flight. Same partial layout and fp64 fixed-order combine as the generic kernels. SiLU as y * rcp(1 + 2^(-y log2 e)) (v_exp_f32 / v_rcp_f32,
+// 1 ulp each, against expf + IEEE division: the bf16 result differs in the last place on a few elements per million).
+// Round 3: the generic pair ran at ~40 % of the HBM roofline (2-byte loads of one channel column per thread in the
+// statistics pass, expf + a division + two 64-bit div / mod per 8 elements in the apply pass).
+constexpr int GN_FAST_ROWS = 256;
+
+template <int CCH>
+__global__ __launch_bounds__(256) void gn_partial_fast_kernel(const bf16_t* __restrict__ x, int64_t HW, int G, int nchunks, double* __restrict__ part) {
+    constexpr int C = CCH * 8, RPP = 256 / CCH;
+    __shared__ float red[256][16];
+    const int t = threadIdx.x, cc = t % CCH, ro = t / CCH, b = blockIdx.y;
+    const int64_t r0 = (int64_t)blockIdx.x * GN_FAST_ROWS, r1 = (r0 + GN_FAST_ROWS < HW) ? r0 + GN_FAST_ROWS : HW;
+    const bf16_t* xp = x + ((int64_t)b * HW) * C + cc * 8;
+    float sm[8], sq[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sm[e] = 0.f; sq[e] = 0.f; }
+    auto add = [&](const u32x4& v) __attribute__((always_inline)) {
+        const float f[8] = {bflo(v.x), bfhi(v.x), bflo(v.y), bfhi(v.y), bflo(v.z), bfhi(v.z), bflo(v.w), bfhi(v.w)};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { sm[e] += f[e]; sq[e] += f[e] * f[e]; }
+    };
+    int64_t r = r0 + ro;
+    for (; r + 3 * RPP < r1; r += 4 * RPP) {
+        u32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *(const u32x4*)(xp + (r + u * RPP) * C);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) add(v[u]);
+    }
+    for (; r < r1; r += RPP) add(*(const u32x4*)(xp + r * C));
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { red[t][e] = sm[e]; red[t][8 + e] = sq[e]; }
+    __syncthreads();
+    if (t < G) {                                     // fixed order: row offsets outer, the group's channels inner
+        const int cg = C / G;
+        double ss = 0.0, qq = 0.0;
+        for (int o = 0; o < RPP; ++o)
+            for (int k = 0; k < cg; ++k) {
+                const int c = t * cg + k;
+                ss += (double)red[o * CCH + (c >> 3)][c & 7]; qq += (double)red[o * CCH + (c >> 3)][8 + (c & 7)];
+            }
+        double* o2 = part + (((int64_t)b * nchunks + blockIdx.x) * G + t) * 2;
+        o2[0] = ss; o2[1] = qq;
+    }
+}
+
+template <int CCH>
+__global__ __launch_bounds__(256) void gn_apply_fast_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ gamma, const bf16_t* __restrict__ beta,
+                                                            const float* __restrict__ stats, int64_t HW, int G, int silu, bf16_t* __restrict__ out) {
+    constexpr int C = CCH * 8, RPP = 256 / CCH;
+    const int t = threadIdx.x, cc = t % CCH, ro = t / CCH, b = blockIdx.y;
+    const int cg = C / G;
+    const int64_t r0 = (int64_t)blockIdx.x * GN_FAST_ROWS, r1 = (r0 + GN_FAST_ROWS < HW) ? r0 + GN_FAST_ROWS : HW;
+    float ga[8], be[8], mu[8], rs[8];
+    ElemT<bf16_t>::load8(gamma + cc * 8, ga); ElemT<bf16_t>::load8(beta + cc * 8, be);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int g = (cc * 8 + e) / cg;
+        mu[e] = stats[((int64_t)b * G + g) * 2]; rs[e] = stats[((int64_t)b * G + g) * 2 + 1];
+    }
+    const bf16_t* xp = x + ((int64_t)b * HW) * C + cc * 8;
+    bf16_t* op = out + ((int64_t)b * HW) * C + cc * 8;
+    auto one = [&](const u32x4& v, bf16_t* dst) __attribute__((always_inline)) {
+        float f[8] = {bflo(v.x), bfhi(v.x), bflo(v.y), bfhi(v.y), bflo(v.z), bfhi(v.z), bflo(v.w), bfhi(v.w)};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float y = rbf((f[e] - mu[e]) * rs[e] * ga[e] + be[e]);                                     // F.group_norm output (one rounding)
+            if (silu) y = y * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(y * -1.44269504088896341f));   // F.silu, rounded by the store
+            f[e] = y;
+        }
+        ElemT<bf16_t>::store8(dst, f);
+    };
+    int64_t r = r0 + ro;
+    for (; r + 3 * RPP < r1; r += 4 * RPP) {
+        u32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *(const u32x4*)(xp + (r + u * RPP) * C);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) one(v[u], op + (r + u * RPP) * C);
+    }
+    for (; r < r1; r += RPP) one(*(const u32x4*)(xp + r * C), op + r * C);
+}
+
 // P[r][:] = softmax(scale * S[r][:]) : S fp32 [rows][ld_s], P element type T [rows][ld_p]; one block per row
 template <typename T>
 __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ S, int64_t ld_s, T* __restrict__ P, int64_t ld_p, int cols, float scale) {
@@ -309,13 +394,33 @@ int groupnorm_impl(const void* x, const void* gamma, const void* beta, void* out
     UG_REQUIRE(C % 8 == 0 && cg <= 256 && 256 % cg == 0, UG_ERR_UNSUPPORTED, "ug_groupnorm_nhwc: C %% 8 == 0 and channels per group (%d) must divide 256", cg);
     UG_REQUIRE(ug_aligned(x, 16) && ug_aligned(out, 16) && ug_aligned(gamma, 16) && ug_aligned(beta, 16) && ug_aligned(workspace, 8), UG_ERR_BAD_ALIGN,
                "ug_groupnorm_nhwc: 16-byte alignment required");
-    const int64_t nchunks = (HW + GN_ROWS - 1) / GN_ROWS;
+    int64_t nchunks = (HW + GN_ROWS - 1) / GN_ROWS;
     const int64_t part_bytes = B * nchunks * G * 2 * (int64_t)sizeof(double);
     UG_REQUIRE(workspace_bytes >= part_bytes + B * G * 2 * (int64_t)sizeof(float), UG_ERR_BAD_SHAPE, "ug_groupnorm_nhwc: workspace too small (ug_groupnorm_workspace_bytes)");
     UG_REQUIRE(nchunks < (1 << 30) && B < 65536, UG_ERR_UNSUPPORTED, "ug_groupnorm_nhwc: too large");
     hipStream_t s = (hipStream_t)stream;
     double* part = (double*)workspace;
     float* stats = (float*)((char*)workspace + part_bytes);
+    if constexpr (!ElemT<T>::kF32) {
+        // the AutoencoderKL widths: 16-byte kernels over 256-row slabs (fewer, larger partials in the same workspace); UG_GN_FAST=0 keeps the generic pair
+        if ((C == 128 || C == 256 || C == 512) && G <= 256 && (cg == 4 || cg == 8 || cg == 16) && ug_env_int("UG_GN_FAST", 1)) {
+            nchunks = (HW + GN_FAST_ROWS - 1) / GN_FAST_ROWS;
+            const dim3 grid((unsigned)nchunks, (unsigned)B);
+#define UG_GN_FAST_LAUNCH(CCH)                                                                                                                                     \
+    do {                                                                                                                                                           \
+        hipLaunchKernelGGL(gn_partial_fast_kernel<CCH>, grid, dim3(256), 0, s, (const bf16_t*)x, HW, (int)G, (int)nchunks, part);                                  \
+        UG_CHECK_LAUNCH("ug_groupnorm_nhwc(partial)");                                                                                                             \
+        hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)G, (unsigned)B), dim3(256), 0, s, (const double*)part, HW, cg, (int)G, (int)nchunks, eps, stats);    \
+        UG_CHECK_LAUNCH("ug_groupnorm_nhwc(finalize)");                                                                                                            \
+        hipLaunchKernelGGL(gn_apply_fast_kernel<CCH>, grid, dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)gamma, (const bf16_t*)beta, (const float*)stats, HW, \
+                           (int)G, (int)silu, (bf16_t*)out);                                                                                                       \
+        UG_CHECK_LAUNCH("ug_groupnorm_nhwc(apply)");                                                                                                               \
+    } while (0)
+            if (C == 128) UG_GN_FAST_LAUNCH(16); else if (C == 256) UG_GN_FAST_LAUNCH(32); else UG_GN_FAST_LAUNCH(64);
+#undef UG_GN_FAST_LAUNCH
+            return UG_OK;
+        }
+    }
     hipLaunchKernelGGL(gn_partial_kernel<T>, dim3((unsigned)nchunks, (unsigned)B), dim3(256), 0, s, (const T*)x, HW, (int)C, (int)G, (int)nchunks, part);
     UG_CHECK_LAUNCH("ug_groupnorm_nhwc(partial)");
     hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)G, (unsigned)B), dim3(256), 0, s, (const double*)part, HW, cg, (int)G, (int)nchunks, eps, stats);
@@ -400,9 +505,23 @@ extern "C" int ug_conv2d_nhwc(const ug_conv_desc* dp, ug_stream_t stream) {
     p.x = (const bf16_t*)d.x; p.w = (const bf16_t*)d.w; p.bias = (const bf16_t*)d.bias; p.R = (const bf16_t*)d.R; p.out = (bf16_t*)d.out; p.zero = (const bf16_t*)d.zero_page;
     p.B = (int)d.B; p.H = (int)d.H; p.W = (int)d.W; p.Cin = (int)d.Cin; p.Ho = (int)d.Ho; p.Wo = (int)d.Wo; p.Cout = (int)d.Cout;
     p.KH = d.KH; p.KW = d.KW; p.stride = d.stride; p.pad_t = d.pad_t; p.pad_l = d.pad_l; p.up = d.up;
+    const int64_t M = d.B * d.Ho * d.Wo;
+    {   // the 256^2 GEMM kernel with a per-tap A gather (gemm.hip, CONV): whole tiles, Cin / 64 a power of two >= 2, at least UG_CONV256_MIN_TILES tiles
+        const int64_t ktp = d.Cin / 64, tiles = (M / 256) * (d.Cout / 256);
+        if (M % 256 == 0 && d.Cout % 256 == 0 && ktp >= 2 && (ktp & (ktp - 1)) == 0 && d.zero_page_bytes >= 2 * (d.Cin + 64) && d.B < 256 && d.H < 2048 && d.W < 2048 &&
+            d.Ho < 4096 && d.Wo < 4096 && ug_aligned(d.out, 16) && (!d.R || ug_aligned(d.R, 16)) && tiles >= ug_env_int("UG_CONV256_MIN_TILES", 128) && ug_env_int("UG_CONV256", 1)) {
+            ug_gemm_desc g = {};
+            g.A = d.x; g.lda = d.Cin; g.W = d.w; g.ldw = (int64_t)d.KH * d.KW * d.Cin; g.bias = d.bias; g.C = d.out; g.ldc = d.Cout; g.R = d.R; g.ldr = d.Cout;
+            g.M = M; g.N = d.Cout; g.K = g.ldw; g.groups = 1; g.alpha = 1.0f; g.epilogue = d.R ? UG_EPI_RES_SCALE : UG_EPI_BIAS;
+            UgConvGeom cv;
+            cv.zero = (const bf16_t*)d.zero_page; cv.H = (int)d.H; cv.W = (int)d.W; cv.Cin = (int)d.Cin; cv.Ho = (int)d.Ho; cv.Wo = (int)d.Wo; cv.KW = d.KW;
+            cv.stride = d.stride; cv.pad_t = d.pad_t; cv.pad_l = d.pad_l; cv.up = d.up; cv.ktp = (int)ktp;
+            const int rc2 = ug_gemm_launch_conv256(g, cv, (hipStream_t)stream);
+            if (rc2 != UG_ERR_UNSUPPORTED) return rc2;
+        }
+    }
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)conv2d_nhwc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CLDS); attr = true; }
-    const int64_t M = d.B * d.Ho * d.Wo;
     const int64_t grid = ((M + CBM - 1) / CBM) * ((d.Cout + CBN - 1) / CBN);
     UG_REQUIRE(grid < (1ll << 31), UG_ERR_UNSUPPORTED, "ug_conv2d_nhwc: grid too large");
     hipLaunchKernelGGL(conv2d_nhwc_kernel, dim3((unsigned)grid), dim3(256), CLDS, (hipStream_t)stream, p);

@@ -47,7 +47,7 @@ class ConvDesc(C.Structure):
     """Mirror of struct ug_conv_desc (include/unigen_hip.h)."""
 
     _fields_ = [("x", vp), ("B", i64), ("H", i64), ("W", i64), ("Cin", i64), ("w", vp), ("bias", vp), ("R", vp), ("out", vp), ("Ho", i64), ("Wo", i64),
-                ("Cout", i64), ("KH", i32), ("KW", i32), ("stride", i32), ("pad_t", i32), ("pad_l", i32), ("up", i32), ("zero_page", vp)]
+                ("Cout", i64), ("KH", i32), ("KW", i32), ("stride", i32), ("pad_t", i32), ("pad_l", i32), ("up", i32), ("zero_page", vp), ("zero_page_bytes", i64)]
 
 
 # name -> (restype, argtypes); must list every symbol declared in include/unigen_hip.h

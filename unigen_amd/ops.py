@@ -458,7 +458,7 @@ _zero_pages: dict = {}
 def _zero_page(device) -> torch.Tensor:
     z = _zero_pages.get(device)
     if z is None:
-        z = torch.zeros(256, dtype=torch.uint8, device=device)
+        z = torch.zeros(4096, dtype=torch.uint8, device=device)      # >= 2 * (Cin + 64) bytes for Cin <= 1984: the 256^2 convolution path
         _zero_pages[device] = z
     return z
 
@@ -481,7 +481,8 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], 
         d.R = residual.data_ptr()
     d.out, d.Ho, d.Wo, d.Cout = out.data_ptr(), Ho, Wo, Cout
     d.KH, d.KW, d.stride, d.pad_t, d.pad_l, d.up = KH, KW, stride, pad_t, pad_l, up
-    d.zero_page = _zero_page(x.device).data_ptr()
+    zp = _zero_page(x.device)
+    d.zero_page, d.zero_page_bytes = zp.data_ptr(), zp.numel()
     L.check(_fn("ug_conv2d_nhwc", dt)(C.byref(d), _stream()), "ug_conv2d_nhwc")
     return out
 
