@@ -100,15 +100,18 @@ def test_groupnorm_softmax_layout_sample(gpu, dt):
 
 def test_conv2d_on_the_256_gemm_kernel_matches_the_conv_kernel(gpu):
     """Round 3: convolutions with Cout and B Ho Wo multiples of 256 and Cin / 64 a power of two >= 2 run on the 256^2
-    8-phase GEMM kernel, its A operand gathered per filter tap (gemm.hip CONV; UG_CONV256=0 keeps conv2d_nhwc_kernel). Same MFMA shape and the
-    same (tap, channel) accumulation order -> bit-identical, on 'same' / Downsample2D / Upsample2D geometry, with and without the residual,
-    one tile and several tiles per workgroup, batch > 1; and <= 1e-3 against torch's fp32 convolution rounded once."""
+    8-phase GEMM kernel, its A operand gathered per filter tap (gemm.hip CONV; UG_CONV256=0 keeps the convolution kernels); the others with
+    B Ho Wo a multiple of 256 on the 256 x 128 three-stage form of conv2d_nhwc_kernel (UG_CONV_BIG=0: the 128 x 128 two-stage form of rounds
+    1-2). Same MFMA shape and the same (tap, channel) accumulation order -> all three bit-identical, on 'same' / Downsample2D / Upsample2D
+    geometry, with and without the residual, one tile and several tiles per workgroup, batch > 1, Cout = 128 / 192, one K-tile per tap; and
+    <= 1e-3 against torch's fp32 convolution rounded once."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = r"""
 import os, sys
 os.environ["UG_ENV_DYNAMIC"] = "1"
 os.environ["UG_CONV256_MIN_TILES"] = "1"
+os.environ["UG_CONV_BIG_MIN_TILES"] = "1"
 sys.path.insert(0, %r)
 import torch
 import torch.nn.functional as F
@@ -118,7 +121,9 @@ g = torch.Generator().manual_seed(7)
 rn = lambda *s, sc=1.0: (sc * torch.randn(*s, generator=g)).to(BF)
 bad = 0
 for (B, H, W, Cin, Cout, mode, res) in [(1, 32, 32, 128, 256, "same", False), (2, 16, 16, 256, 256, "up", True), (1, 64, 64, 128, 256, "down", False),
-                                        (2, 32, 32, 512, 512, "same", True), (1, 128, 128, 256, 512, "same", True), (3, 64, 64, 128, 1024, "same", False)]:
+                                        (2, 32, 32, 512, 512, "same", True), (1, 128, 128, 256, 512, "same", True), (3, 64, 64, 128, 1024, "same", False),
+                                        (1, 64, 64, 128, 128, "same", True), (1, 32, 32, 64, 192, "same", False), (2, 32, 32, 128, 128, "up", False),
+                                        (1, 64, 64, 64, 128, "down", True)]:
     x, w, b = rn(B, Cin, H, W), rn(Cout, Cin, 3, 3, sc=(9 * Cin) ** -0.5), rn(Cout, sc=0.1)
     if mode == "same":
         ref = F.conv2d(x.float(), w.float(), b.float(), padding=1); kw = dict(stride=1, pad_t=1, pad_l=1, up=0)
@@ -135,15 +140,15 @@ for (B, H, W, Cin, Cout, mode, res) in [(1, 32, 32, 128, 256, "same", False), (2
     wh = w.permute(0, 2, 3, 1).contiguous().to(dev)
     rh = r.permute(0, 2, 3, 1).reshape(B * Ho * Wo, Cout).contiguous().to(dev) if res else None
     outs = []
-    for mode2 in ("0", "1"):
-        os.environ["UG_CONV256"] = mode2
+    for c256, big in (("0", "0"), ("0", "1"), ("1", "1")):       # 128 x 128 two-stage kernel | 256 x 128 three-stage kernel | 256^2 GEMM kernel where eligible
+        os.environ["UG_CONV256"], os.environ["UG_CONV_BIG"] = c256, big
         out = torch.zeros(B * Ho * Wo, Cout, device=dev, dtype=BF)
         ops.conv2d_nhwc(xh, wh, b.to(dev), out, B=B, H=H, W=W, Ho=Ho, Wo=Wo, KH=3, KW=3, residual=rh, **kw)
         outs.append(out)
     torch.cuda.synchronize()
-    got = outs[1].float().cpu().view(B, Ho, Wo, Cout).permute(0, 3, 1, 2)
+    got = outs[2].float().cpu().view(B, Ho, Wo, Cout).permute(0, 3, 1, 2)
     rel = float((got - ref).norm() / ref.norm())
-    if not torch.equal(outs[0], outs[1]) or rel > 1e-3:
+    if not torch.equal(outs[0], outs[1]) or not torch.equal(outs[0], outs[2]) or rel > 1e-3:
         bad += 1
         print("MISMATCH", B, H, W, Cin, Cout, mode, res, rel, float((outs[0].float() - outs[1].float()).abs().max()))
 sys.exit(1 if bad else 0)
@@ -181,7 +186,7 @@ for (B, HW, C) in [(2, 1000, 128), (1, 4099, 256), (2, 777, 512), (1, 64 * 64, 5
             outs.append(out.float().cpu().view(B, HW, C))
         ref = F.group_norm(x.float().transpose(1, 2), 32, ga.float(), be.float(), eps=1e-6).transpose(1, 2).to(BF).float()
         if silu:
-            ref = F.silu(ref)
+            ref = F.silu(ref).to(BF).float()
         rel = float((outs[1] - ref).norm() / ref.norm())
         d = (outs[1] - outs[0]).abs()
         ulp = outs[0].abs().clamp_min(1e-30) * 2.0 ** -7          # one bf16 step is at most 2^-7 of the value

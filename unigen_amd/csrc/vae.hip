@@ -20,16 +20,24 @@
 
 namespace {
 
-constexpr int CBM = 128, CBN = 128, CBK = 64;
-constexpr int CTILE = CBM * CBK * 2;
-constexpr int CLDS = 4 * CTILE;               // 2 buffers x (A + W): 64 KiB
+constexpr int CBN = 128, CBK = 64;
 
 struct ConvP {
     const bf16_t* x; const bf16_t* w; const bf16_t* bias; const bf16_t* R; bf16_t* out; const bf16_t* zero;
     int B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad_t, pad_l, up;
 };
 
-__global__ __launch_bounds__(256, 2) void conv2d_nhwc_kernel(const ConvP p) {
+// Tile (64 NWM) x 128 x 64, 2 NWM waves (NWM x 2, each 64 x 64), a ring of NST K-tile stages in LDS, ONE barrier per K-tile: a stage is
+// waited for with a counted vmcnt (the NST - 2 younger stages stay in flight), the barrier that follows both publishes it and retires
+// every read of the stage re-filled right after. <2, 2>: 128 x 128, 64 KiB, two workgroups per CU (rounds 1-2; ragged and small shapes);
+// <4, 3>: 256 x 128, 144 KiB, one workgroup per CU, two K-tiles ahead - 0.75x the L2 -> LDS bytes per FLOP of the 128^2 tile (UG_CONV_BIG=1).
+// MEASURED (round 3, profiles/r03q_vae_bench.log): bit-identical and NOT faster - decode 14.05-14.09 ms with it against 13.89 ms without: the
+// convolutions left on this kernel (Cout = 128: K = 9 x 128 = 18 K-tiles) are short tiles whose first-DMA latency and C stores only hide
+// under ANOTHER workgroup of the same CU, which the 64 KiB form has and the 144 KiB form does not. Off by default.
+template <int NWM, int NST>
+__global__ __launch_bounds__(128 * NWM, 2) void conv2d_nhwc_kernel(const ConvP p) {
+    constexpr int NW = 2 * NWM, CBM = 64 * NWM, APER = 4, WPER = CBN / (NW * 8), PER = APER + WPER;
+    constexpr int ATILE = CBM * CBK * 2, WTILE = CBN * CBK * 2, STAGE = ATILE + WTILE;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -41,45 +49,49 @@ __global__ __launch_bounds__(256, 2) void conv2d_nhwc_kernel(const ConvP p) {
     const int ldw = p.KH * p.KW * p.Cin;
     const int Hv = p.H << p.up, Wv = p.W << p.up;
 
-    // staging rows of this lane: output pixel (b, oy, ox) of A rows wave*32 + i*8 + (lane >> 3); W rows likewise
-    int pb[4], py[4], px[4];
-    const bf16_t* wsrc[4];
-    int chunk[4];
+    // staging rows of this lane: output pixel (b, oy, ox) of A rows wave*32 + i*8 + (lane >> 3); W rows wave*(8 WPER) + i*8 + (lane >> 3)
+    int pb[APER], py[APER], px[APER];
+    const bf16_t* wsrc[WPER];
+    int chunk[APER], wchunk[WPER];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < APER; ++i) {
         const int row = wave * 32 + i * 8 + (lane >> 3);
         chunk[i] = ((lane & 7) ^ (row & 7)) * 8;
         int m = m0 + row; if (m > M - 1) m = M - 1;
         const int b = m / (p.Ho * p.Wo), r = m - b * (p.Ho * p.Wo);
         pb[i] = b; py[i] = r / p.Wo; px[i] = r - py[i] * p.Wo;
+    }
+#pragma unroll
+    for (int i = 0; i < WPER; ++i) {
+        const int row = wave * (8 * WPER) + i * 8 + (lane >> 3);
+        wchunk[i] = ((lane & 7) ^ (row & 7)) * 8;
         int n = n0 + row; if (n > N - 1) n = N - 1;
-        wsrc[i] = p.w + (int64_t)n * ldw + chunk[i];
+        wsrc[i] = p.w + (int64_t)n * ldw + wchunk[i];
     }
     const int kt_per_tap = p.Cin / CBK;
     const int nk = p.KH * p.KW * kt_per_tap;
-    const bf16_t* asrc[4];
-    bool aok[4];
-    auto tap_sources = [&](int tap) {        // the pixel each staging row reads for this tap (virtual, i.e. upsampled, coordinates -> stored ones)
+    const bf16_t* asrc[APER];
+    bool aok[APER];
+    auto tap_sources = [&](int tap) __attribute__((always_inline)) {        // the pixel each staging row reads for this tap (virtual, i.e. upsampled, coordinates -> stored ones)
         const int ky = tap / p.KW, kx = tap - ky * p.KW;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < APER; ++i) {
             const int yv = py[i] * p.stride + ky - p.pad_t, xv = px[i] * p.stride + kx - p.pad_l;
             aok[i] = yv >= 0 && yv < Hv && xv >= 0 && xv < Wv;
             const int sy = aok[i] ? yv >> p.up : 0, sx = aok[i] ? xv >> p.up : 0;
             asrc[i] = p.x + (((int64_t)pb[i] * p.H + sy) * p.W + sx) * p.Cin + chunk[i];
         }
     };
-    auto stage = [&](int buf, int kt) {
+    auto stage = [&](int buf, int kt) __attribute__((always_inline)) {
         const int tap = kt / kt_per_tap, ci = (kt - tap * kt_per_tap) * CBK;
         if (ci == 0) tap_sources(tap);                       // wave-uniform
-        unsigned char* Abuf = smem + buf * 2 * CTILE;
-        unsigned char* Wbuf = Abuf + CTILE;
+        unsigned char* Abuf = smem + buf * STAGE;
+        unsigned char* Wbuf = Abuf + ATILE;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int off = (wave * 32 + i * 8) * 128;
-            glds16(aok[i] ? asrc[i] + ci : p.zero + chunk[i], Abuf + off);     // padding lanes read the 128-byte zero page
-            glds16(wsrc[i] + (int64_t)kt * CBK, Wbuf + off);
-        }
+        for (int i = 0; i < APER; ++i)
+            glds16(aok[i] ? asrc[i] + ci : p.zero + chunk[i], Abuf + (wave * 32 + i * 8) * 128);     // padding lanes read the 128-byte zero page
+#pragma unroll
+        for (int i = 0; i < WPER; ++i) glds16(wsrc[i] + (int64_t)kt * CBK, Wbuf + (wave * (8 * WPER) + i * 8) * 128);
     };
     f32x4 acc[4][4];
 #pragma unroll
@@ -87,14 +99,18 @@ __global__ __launch_bounds__(256, 2) void conv2d_nhwc_kernel(const ConvP p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int frow = lane & 15, fch = lane >> 4, fsw = lane & 7;
-    stage(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+#pragma unroll
+    for (int st = 0; st < NST - 1; ++st)
+        if (st < nk) stage(st, st);
+    int cur = 0;
     for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
-        const unsigned char* Abuf = smem + cur * 2 * CTILE;
-        const unsigned char* Wbuf = Abuf + CTILE;
+        // stage kt landed (this wave's share): at most NST - 2 younger stages stay in flight
+        if (NST >= 3 && kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * PER) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0);
+        if (kt + NST - 1 < nk) stage(cur == 0 ? NST - 1 : cur - 1, kt + NST - 1);     // the stage read in the previous iteration
+        const unsigned char* Abuf = smem + cur * STAGE;
+        const unsigned char* Wbuf = Abuf + ATILE;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             bf16x8 af[4], wf[4];
@@ -108,8 +124,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_nhwc_kernel(const ConvP p) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        cur = cur + 1 == NST ? 0 : cur + 1;
     }
     // epilogue: lane holds D[n = 4 consecutive][m]: out = R + bf16(acc + bias)
 #pragma unroll
@@ -509,7 +524,7 @@ extern "C" int ug_conv2d_nhwc(const ug_conv_desc* dp, ug_stream_t stream) {
     {   // the 256^2 GEMM kernel with a per-tap A gather (gemm.hip, CONV): whole tiles, Cin / 64 a power of two >= 2, at least UG_CONV256_MIN_TILES tiles
         const int64_t ktp = d.Cin / 64, tiles = (M / 256) * (d.Cout / 256);
         if (M % 256 == 0 && d.Cout % 256 == 0 && ktp >= 2 && (ktp & (ktp - 1)) == 0 && d.zero_page_bytes >= 2 * (d.Cin + 64) && d.B < 256 && d.H < 2048 && d.W < 2048 &&
-            d.Ho < 4096 && d.Wo < 4096 && ug_aligned(d.out, 16) && (!d.R || ug_aligned(d.R, 16)) && tiles >= ug_env_int("UG_CONV256_MIN_TILES", 128) && ug_env_int("UG_CONV256", 1)) {
+            d.Ho < 4096 && d.Wo < 4096 && ug_aligned(d.out, 16) && (!d.R || ug_aligned(d.R, 16)) && tiles >= ug_env_int("UG_CONV256_MIN_TILES", 192) && ug_env_int("UG_CONV256", 1)) {
             ug_gemm_desc g = {};
             g.A = d.x; g.lda = d.Cin; g.W = d.w; g.ldw = (int64_t)d.KH * d.KW * d.Cin; g.bias = d.bias; g.C = d.out; g.ldc = d.Cout; g.R = d.R; g.ldr = d.Cout;
             g.M = M; g.N = d.Cout; g.K = g.ldw; g.groups = 1; g.alpha = 1.0f; g.epilogue = d.R ? UG_EPI_RES_SCALE : UG_EPI_BIAS;
@@ -520,11 +535,25 @@ extern "C" int ug_conv2d_nhwc(const ug_conv_desc* dp, ug_stream_t stream) {
             if (rc2 != UG_ERR_UNSUPPORTED) return rc2;
         }
     }
+    // 256 x 128 tiles, three stages (Cout = 128 layers; convolutions with too few 256^2 tiles): whole tiles in M, at least one tile per CU pair
+    constexpr int LDS_BIG = 3 * (256 + CBN) * CBK * 2, LDS_SMALL = 2 * (128 + CBN) * CBK * 2;
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)conv2d_nhwc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CLDS); attr = true; }
-    const int64_t grid = ((M + CBM - 1) / CBM) * ((d.Cout + CBN - 1) / CBN);
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)conv2d_nhwc_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_SMALL);
+        (void)hipFuncSetAttribute((const void*)conv2d_nhwc_kernel<4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BIG);
+        attr = true;
+    }
+    const int64_t nN = (d.Cout + CBN - 1) / CBN;
+    if (M % 256 == 0 && (M / 256) * nN >= ug_env_int("UG_CONV_BIG_MIN_TILES", 128) && ug_env_int("UG_CONV_BIG", 0)) {
+        const int64_t grid = (M / 256) * nN;
+        UG_REQUIRE(grid < (1ll << 31), UG_ERR_UNSUPPORTED, "ug_conv2d_nhwc: grid too large");
+        hipLaunchKernelGGL((conv2d_nhwc_kernel<4, 3>), dim3((unsigned)grid), dim3(512), LDS_BIG, (hipStream_t)stream, p);
+        UG_CHECK_LAUNCH("ug_conv2d_nhwc");
+        return UG_OK;
+    }
+    const int64_t grid = ((M + 127) / 128) * nN;
     UG_REQUIRE(grid < (1ll << 31), UG_ERR_UNSUPPORTED, "ug_conv2d_nhwc: grid too large");
-    hipLaunchKernelGGL(conv2d_nhwc_kernel, dim3((unsigned)grid), dim3(256), CLDS, (hipStream_t)stream, p);
+    hipLaunchKernelGGL((conv2d_nhwc_kernel<2, 2>), dim3((unsigned)grid), dim3(256), LDS_SMALL, (hipStream_t)stream, p);
     UG_CHECK_LAUNCH("ug_conv2d_nhwc");
     return UG_OK;
 }
