@@ -1,12 +1,12 @@
 #!/bin/bash
 # rocprofv3 evidence for one round, summarised ON the GPU box (the raw counter CSVs are tens of MB each): kernel stats + the PMC passes
-# MI355X_MICROARCH.md prescribes (separate --pmc passes, --kernel-trace only). usage: bash tools/pmc_r02.sh TAG
+# MI355X_MICROARCH.md prescribes (separate --pmc passes, --kernel-trace only). usage: [BENCH_ARGS="--config cfg5"] bash tools/pmc_r02.sh TAG
 set -o pipefail
 TAG=${1:-r02}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 S=/tmp/ug_prof_$TAG; rm -rf $S; mkdir -p $S gpurun_out profiles
-B="python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-kernel-timer --no-scaling-base"
-rocprofv3 --kernel-trace --stats --output-format csv -d $S/stats -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timer --no-scaling-base > $S/stats.log 2>&1 || { tail -5 $S/stats.log; exit 1; }
+B="python3 bench.py ${BENCH_ARGS:-} --steps 1 --warmup 0 --no-cpu-baseline --no-kernel-timer --no-scaling-base"
+rocprofv3 --kernel-trace --stats --output-format csv -d $S/stats -- python3 bench.py ${BENCH_ARGS:-} --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timer --no-scaling-base > $S/stats.log 2>&1 || { tail -5 $S/stats.log; exit 1; }
 cp $S/stats/*/*kernel_stats.csv profiles/${TAG}_bench_kernel_stats.csv
 for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum"; do
   n=$(echo $c | cut -d" " -f1)
