@@ -509,8 +509,20 @@ __global__ __launch_bounds__(64 * NW, OCC) void flash_attn_kernel(
         }
         auto dma_tile = [&](const bf16_t* base, int64_t rs, const unsigned (&off)[NIW], int tile, unsigned dst) {
             if (tile * KVB + KVB <= Lkv) {             // whole tile: wave-uniform base (SGPR pair) + per-lane 32-bit byte offset
-                const void* tb = uniform_ptr(base + (int64_t)tile * KVB * rs);
-                if constexpr (OCC == 4) {          // lane offsets re-derived at the issue (not kept live through the loop: registers are what this form is short of)
+                if constexpr (OCC == 4 && DH == 64 && NIW == 2) {
+                    // Lane offsets re-derived at the issue (not kept live through the loop: registers are what this form is short of), cheaply:
+                    // run u of wave wb covers rows (2 wb + u) * 8 + lane / 8, so the wave / run part of the row goes into the scalar base and
+                    // row_swz<64> reduces to a lane term with bit 0 = u: the second run's chunk is the first one's ^ 1. ~10 VALU per tile
+                    // instead of ~48 (round 3: the generic re-derivation was ~12 % of the issuing waves' VALU instructions).
+                    int lane_r = lane;
+                    asm volatile("" : "+v"(lane_r));
+                    const int sw = (((lane_r >> 4) & 1) << 2) | ((lane_r >> 4) & 2);
+                    const unsigned c0 = (unsigned)(((lane_r & 7) ^ sw) << 4), rp = (unsigned)((lane_r >> 3) * (int)rs) * 2u;
+                    const char* tw = (const char*)uniform_ptr(base + ((int64_t)tile * KVB + wb * NIW * RPI) * rs);
+                    glds16_off(tw, rp + c0, dst);
+                    glds16_off(tw + (int64_t)RPI * rs * 2, rp + (c0 ^ 16u), dst + 1024);
+                } else if constexpr (OCC == 4) {
+                    const void* tb = uniform_ptr(base + (int64_t)tile * KVB * rs);
                     int lane_r = lane;
                     asm volatile("" : "+v"(lane_r));
 #pragma unroll
@@ -520,6 +532,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void flash_attn_kernel(
                         glds16_off(tb, (unsigned)(row * (int)rs + ch * 8) * 2u, dst + u * 1024);
                     }
                 } else {
+                    const void* tb = uniform_ptr(base + (int64_t)tile * KVB * rs);
 #pragma unroll
                     for (int u = 0; u < NIW; ++u) glds16_off(tb, off[u], dst + u * 1024);
                 }
