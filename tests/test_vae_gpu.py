@@ -98,6 +98,21 @@ def test_groupnorm_softmax_layout_sample(gpu, dt):
     assert rel_l2(zz, exp) <= (1e-6 if dt == F32 else 4e-3)
 
 
+@pytest.mark.parametrize("cols", [1024, 3072, 4096, 16384])
+def test_softmax_rows_single_read_kernel(gpu, cols):
+    """Round 3: rows whose length is a multiple of 1024 (<= 16384: the VAE mid-block attention's 4096 / 16384 tokens) take the kernel that reads
+    the fp32 scores once and keeps the row in registers; <= 4e-3 against torch's fp32 softmax like the generic kernel (bf16 output), rows sum to 1."""
+    from unigen_amd import ops
+    g = torch.Generator().manual_seed(11)
+    s = torch.randn(37, cols, generator=g) * 4
+    s[3, 5] = 60.0                                      # one dominant score
+    p = torch.empty(37, cols, device=gpu, dtype=BF)
+    ops.softmax_rows(s.to(gpu), p, 0.31)
+    ref = F.softmax(0.31 * s, dim=1)
+    assert report(f"softmax_rows_fast_{cols}", p, ref)["rel_l2"] <= 4e-3
+    assert float((p.float().sum(1).cpu() - 1).abs().max()) <= 2e-2
+
+
 def test_conv2d_on_the_256_gemm_kernel_matches_the_conv_kernel(gpu):
     """Round 3: convolutions with Cout and B Ho Wo multiples of 256 and Cin / 64 a power of two >= 2 run on the 256^2
     8-phase GEMM kernel, its A operand gathered per filter tap (gemm.hip CONV; UG_CONV256=0 keeps the convolution kernels); the others with

@@ -358,6 +358,44 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
     for (int c = threadIdx.x; c < cols; c += 256) ElemT<T>::st(p + c, expf(s[c] * scale - mx) * inv);
 }
 
+// bf16 product form for cols == 1024 NV (NV <= 16: the VAE's 4096 / 16384 tokens): the row is read ONCE (16-byte loads, 4 NV values per thread in
+// registers), exponentials are taken once (v_exp_f32 on log2(e)-scaled scores), probabilities leave as 8-byte stores. The generic kernel above
+// read the row three times and took two expf per element: 1 GB of fp32 scores at 1024^2 in 0.66 ms (2.3 TB/s). UG_SOFTMAX_FAST=0 keeps it.
+template <int NV>
+__global__ __launch_bounds__(256) void softmax_rows_fast_kernel(const float* __restrict__ S, int64_t ld_s, bf16_t* __restrict__ P, int64_t ld_p, float scale) {
+    __shared__ float red[2][4];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const f32x4* s = (const f32x4*)(S + (int64_t)blockIdx.x * ld_s) + t;
+    bf16_t* p = P + (int64_t)blockIdx.x * ld_p + 4 * t;
+    const float c = scale * 1.44269504088896341f;
+    f32x4 v[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) v[j] = __builtin_nontemporal_load(s + 256 * j);
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) mx = fmaxf(fmaxf(mx, fmaxf(v[j][0], v[j][1])), fmaxf(v[j][2], v[j][3]));
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) mx = fmaxf(mx, __shfl_xor(mx, m, 64));
+    if (lane == 0) red[0][wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3])) * c;        // scale > 0 (host check): the max commutes with it
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[j][e] = __builtin_amdgcn_exp2f(v[j][e] * c - mx); sum += v[j][e]; }
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) sum += __shfl_xor(sum, m, 64);
+    if (lane == 0) red[1][wave] = sum;
+    __syncthreads();
+    const float inv = 1.0f / (((red[1][0] + red[1][1]) + red[1][2]) + red[1][3]);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        u32x2 o; o.x = pack2bf(v[j][0] * inv, v[j][1] * inv); o.y = pack2bf(v[j][2] * inv, v[j][3] * inv);
+        *(u32x2*)(p + 1024 * j) = o;
+    }
+}
+
 // out[b][y][x][c] = c < C ? f(in[b][c][y][x]) : 0, f(v) = rnd(rnd(v / div) + add) when div != 0 (the latent un-scaling of the decode side)
 template <typename T>
 __global__ void nchw_to_nhwc_kernel(const T* __restrict__ in, T* __restrict__ out, int B, int C, int HW, int Cp, float div, float add) {
@@ -450,6 +488,20 @@ template <typename T>
 int softmax_impl(const float* S, int64_t ld_s, void* P, int64_t ld_p, int64_t rows, int64_t cols, float scale, ug_stream_t stream) {
     if (rows == 0) return UG_OK;
     UG_REQUIRE(S && P && rows > 0 && cols > 0 && ld_s >= cols && ld_p >= cols && rows < (1ll << 31) && cols < (1ll << 31), UG_ERR_BAD_SHAPE, "ug_softmax_rows: bad arguments");
+    if constexpr (!ElemT<T>::kF32) {
+        if (cols % 1024 == 0 && cols <= 16384 && scale > 0.f && ld_s % 4 == 0 && ld_p % 4 == 0 && ug_aligned(S, 16) && ug_aligned(P, 8) && ug_env_int("UG_SOFTMAX_FAST", 1)) {
+            const dim3 grid((unsigned)rows);
+            const hipStream_t st = (hipStream_t)stream;
+            switch (cols / 1024) {
+#define UG_SM_CASE(NV) case NV: hipLaunchKernelGGL(softmax_rows_fast_kernel<NV>, grid, dim3(256), 0, st, S, ld_s, (bf16_t*)P, ld_p, scale); break
+                UG_SM_CASE(1); UG_SM_CASE(2); UG_SM_CASE(3); UG_SM_CASE(4); UG_SM_CASE(5); UG_SM_CASE(6); UG_SM_CASE(7); UG_SM_CASE(8);
+                UG_SM_CASE(9); UG_SM_CASE(10); UG_SM_CASE(11); UG_SM_CASE(12); UG_SM_CASE(13); UG_SM_CASE(14); UG_SM_CASE(15); UG_SM_CASE(16);
+#undef UG_SM_CASE
+            }
+            UG_CHECK_LAUNCH("ug_softmax_rows");
+            return UG_OK;
+        }
+    }
     hipLaunchKernelGGL(softmax_rows_kernel<T>, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, S, ld_s, (T*)P, ld_p, (int)cols, scale);
     UG_CHECK_LAUNCH("ug_softmax_rows");
     return UG_OK;
