@@ -478,15 +478,27 @@ def euler_step(latents: torch.Tensor, model_output: torch.Tensor, sigma: float, 
     return prev.to(model_output.dtype)
 
 
-def denoise(state: State, cfg: FluxConfig, *, latents, num_steps: int, dtype=torch.bfloat16, gate_uniforms=None, **fwd_kwargs):
-    """UniGenFLUXPipeline.__call__ loop: timestep = t.expand(B).to(latents.dtype); forward(timestep / 1000); Euler step."""
+def denoise(state: State, cfg: FluxConfig, *, latents, num_steps: int, dtype=torch.bfloat16, gate_uniforms=None, true_cfg_scale: float = 1.0,
+            negative_encoder_hidden_states=None, negative_pooled_projections=None, negative_gate_uniforms=None, negative_txt_ids=None, **fwd_kwargs):
+    """UniGenFLUXPipeline.__call__ loop (src/UniGenPipeline.py:721-789): timestep = t.expand(B).to(latents.dtype); forward(timestep / 1000);
+    with true CFG (:748-763) a second forward on the negative prompt - without conditioning_scale, i.e. the forward's default - and
+    neg + true_cfg_scale * (pred - neg) in the working dtype; Euler step."""
     sig = schnell_sigmas(num_steps)
     latents = latents.to(dtype)
     B = latents.shape[0]
+    do_true_cfg = true_cfg_scale > 1 and negative_encoder_hidden_states is not None and negative_pooled_projections is not None
     for i in range(num_steps):
         t = (sig[i] * 1000).expand(B).to(latents.dtype)
         uni = None if gate_uniforms is None else gate_uniforms[i]
         pred = unigen_flux_forward(state, cfg, hidden_states=latents, timestep=t / 1000, gate_uniform=uni, dtype=dtype, **fwd_kwargs)[0]
+        if do_true_cfg:
+            kw = {k: v for k, v in fwd_kwargs.items() if k not in ("encoder_hidden_states", "pooled_projections", "conditioning_scale")}
+            nuni = None if negative_gate_uniforms is None else negative_gate_uniforms[i]
+            if negative_txt_ids is not None:
+                kw["txt_ids"] = negative_txt_ids
+            neg = unigen_flux_forward(state, cfg, hidden_states=latents, timestep=t / 1000, gate_uniform=nuni, dtype=dtype,
+                                      encoder_hidden_states=negative_encoder_hidden_states, pooled_projections=negative_pooled_projections, **kw)[0]
+            pred = neg + true_cfg_scale * (pred - neg)
         latents = euler_step(latents, pred, float(sig[i]), float(sig[i + 1]))
     return latents
 

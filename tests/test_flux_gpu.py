@@ -130,6 +130,48 @@ def test_denoise_loop_matches_oracle_and_golden(gpu):
     assert m["rel_l2"] <= 2e-2, m
 
 
+def test_true_cfg_and_step_callback_follow_the_reference_loop(gpu):
+    """src/UniGenPipeline.py:748-763, 774-781: with `true_cfg_scale > 1` and negative embeds every step runs a second forward on the negative
+    prompt - called WITHOUT conditioning_scale, as the reference does - and combines `neg + s * (pred - neg)` in bf16; `callback_on_step_end`
+    sees (pipeline, step, timestep, {latents}) and may replace the latents. Against the oracle's loop (negative prompt of a different length)."""
+    import importlib
+    model, state, rcfg = _build(gpu, "UniGenFlux", 1)
+    inp = R.make_inputs(rcfg, B=2, grid=8, T=32)
+    g = torch.Generator().manual_seed(21)
+    neg_e = (0.5 * torch.randn(2, 24, rcfg.joint_attention_dim, generator=g)).to(BF)
+    neg_p = torch.randn(2, rcfg.pooled_projection_dim, generator=g).to(BF)
+    uni = [inp["gate_uniform"]] * 2
+    fw = {k: v for k, v in inp.items() if k not in ("hidden_states", "gate_uniform")}
+    ref = R.denoise(state, rcfg, latents=inp["hidden_states"], num_steps=2, dtype=BF, gate_uniforms=uni, negative_gate_uniforms=uni, true_cfg_scale=2.5,
+                    negative_encoder_hidden_states=neg_e, negative_pooled_projections=neg_p, negative_txt_ids=torch.zeros(24, 3, dtype=BF),
+                    conditioning_scale=0.7, **fw)
+    plain = R.denoise(state, rcfg, latents=inp["hidden_states"], num_steps=2, dtype=BF, gate_uniforms=uni, conditioning_scale=0.7, **fw)
+    pipe = importlib.import_module("src.UniGenPipeline").UniGenFLUXPipeline.from_pretrained(None, transformer=None)
+    pipe.transformer = model
+    seen = []
+
+    def cb(p, i, t, kw):
+        seen.append((p is pipe, i, float(t), tuple(kw)))
+        return {}
+    dev_uni = [inp["gate_uniform"].to(gpu)] * 2
+    call = dict(prompt_embeds=inp["encoder_hidden_states"], pooled_prompt_embeds=inp["pooled_projections"],
+                condition_pooled_prompt_embeds=inp["condition_pooled_projections"], control_image=inp["condition_hidden_states"],
+                latents=inp["hidden_states"], height=128, width=128, num_inference_steps=2, output_type="latent", dtype=BF, conditioning_scale=0.7,
+                gate_uniforms=dev_uni)
+    res = pipe(true_cfg_scale=2.5, negative_prompt_embeds=neg_e, negative_pooled_prompt_embeds=neg_p, negative_gate_uniforms=dev_uni,
+               callback_on_step_end=cb, **call)
+    m = report("denoise2_true_cfg", res.images, ref, vs_plain=rel_l2(ref, plain))
+    assert m["vs_plain"] > 5e-2, m                      # the guidance term is not a no-op in this case
+    assert m["rel_l2"] <= 3e-2, m
+    assert seen == [(True, 0, 1000.0, ("latents",)), (True, 1, 500.0, ("latents",))], seen
+    # true_cfg_scale <= 1 or no negative embeds: the plain loop
+    res1 = pipe(true_cfg_scale=1.0, negative_prompt_embeds=neg_e, negative_pooled_prompt_embeds=neg_p, **call)
+    assert rel_l2(res1.images, plain) <= 2e-2
+    # a callback that replaces the latents after step 0 changes the result exactly as restarting from the replaced latents does
+    half = pipe(callback_on_step_end=lambda p, i, t, kw: {"latents": kw["latents"] * 0.5} if i == 0 else {}, **call).images
+    assert rel_l2(half, res1.images) > 1e-2
+
+
 def test_denoise_step_is_hip_graph_capturable(gpu):
     """the whole denoise loop (C-ABI launches on torch's stream, no host copies, no allocation after warm-up)
     captures into one HIP graph; the replay is bitwise identical to the eager run."""

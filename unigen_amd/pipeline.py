@@ -89,9 +89,17 @@ def unpack_latents(latents: torch.Tensor, height: int, width: int, vae_scale_fac
 def denoise_loop(transformer, *, latents: torch.Tensor, control_tokens, prompt_embeds: torch.Tensor, pooled_prompt_embeds: torch.Tensor,
                  condition_pooled_prompt_embeds, text_ids: torch.Tensor, latent_image_ids: torch.Tensor, condition_ids,
                  num_inference_steps: int = 4, sigmas: Optional[Sequence[float]] = None, guidance_scale: float = 3.5,
-                 conditioning_scale: float = 1.0, shift: float = 1.0, use_dynamic_shifting: bool = False, gate_uniforms=None) -> torch.Tensor:
+                 conditioning_scale: float = 1.0, shift: float = 1.0, use_dynamic_shifting: bool = False, gate_uniforms=None,
+                 true_cfg_scale: float = 1.0, negative_prompt_embeds: Optional[torch.Tensor] = None,
+                 negative_pooled_prompt_embeds: Optional[torch.Tensor] = None, negative_text_ids: Optional[torch.Tensor] = None,
+                 negative_gate_uniforms=None, callback_on_step_end=None, callback_on_step_end_tensor_inputs: Sequence[str] = ("latents",),
+                 pipeline=None) -> torch.Tensor:
     """The hot loop (src/UniGenPipeline.py:721-789): per step `timestep = t.expand(B).to(latents.dtype)`, transformer(timestep / 1000)[0],
-    latents = latents + (sigma_next - sigma) * noise_pred evaluated in fp32 and cast back. Updates and returns `latents` in place."""
+    latents = latents + (sigma_next - sigma) * noise_pred evaluated in fp32 and cast back. Updates and returns `latents` in place.
+    True classifier-free guidance (`:748-763`: `true_cfg_scale > 1` with negative embeds): a second forward on the negative prompt - called, as
+    the reference does, WITHOUT `conditioning_scale` (the forward's default) - and `neg + true_cfg_scale * (pred - neg)` in the latents' dtype
+    (ug_cfg_combine: the three bf16 tensor ops' roundings). `callback_on_step_end(pipeline, i, t, {name: tensor})` (`:774-781`) may return
+    replacements for `latents` and `prompt_embeds`."""
     mu = calculate_shift(latents.shape[1]) if use_dynamic_shifting else None
     sig = flow_match_sigmas(num_inference_steps, sigmas=sigmas, shift=shift, use_dynamic_shifting=use_dynamic_shifting, mu=mu)
     B = latents.shape[0]
@@ -99,6 +107,9 @@ def denoise_loop(transformer, *, latents: torch.Tensor, control_tokens, prompt_e
     if transformer.config.guidance_embeds:
         guidance = torch.full([B], guidance_scale, device=latents.device, dtype=torch.float32)
     latents = latents.contiguous()
+    do_true_cfg = true_cfg_scale > 1 and negative_prompt_embeds is not None and negative_pooled_prompt_embeds is not None
+    if do_true_cfg and negative_text_ids is None:
+        negative_text_ids = torch.zeros(negative_prompt_embeds.shape[1], 3, device=latents.device, dtype=text_ids.dtype)
     for i in range(num_inference_steps):
         # `t.expand(B).to(latents.dtype)`: built on the device (a fill kernel, no host copy -> the loop is HIP-graph capturable)
         timestep = torch.full((B,), sig[i] * 1000.0, dtype=torch.float32, device=latents.device).to(latents.dtype)
@@ -107,7 +118,22 @@ def denoise_loop(transformer, *, latents: torch.Tensor, control_tokens, prompt_e
                                  encoder_hidden_states=prompt_embeds, pooled_projections=pooled_prompt_embeds,
                                  condition_pooled_projections=condition_pooled_prompt_embeds, timestep=timestep / 1000, txt_ids=text_ids,
                                  img_ids=latent_image_ids, guidance=guidance, condition_ids=condition_ids, gate_uniform=uni)[0]
+        if do_true_cfg:
+            nuni = None if negative_gate_uniforms is None else negative_gate_uniforms[i]
+            neg = transformer(hidden_states=latents, condition_hidden_states=control_tokens, encoder_hidden_states=negative_prompt_embeds,
+                              pooled_projections=negative_pooled_prompt_embeds, condition_pooled_projections=condition_pooled_prompt_embeds,
+                              timestep=timestep / 1000, txt_ids=negative_text_ids, img_ids=latent_image_ids, guidance=guidance,
+                              condition_ids=condition_ids, gate_uniform=nuni)[0]
+            noise_pred = ops.cfg_combine(neg.contiguous(), noise_pred.contiguous(), float(true_cfg_scale), torch.empty_like(neg, memory_format=torch.contiguous_format))
         ops.euler_step(latents, noise_pred, sig[i + 1] - sig[i])
+        if callback_on_step_end is not None:
+            t = torch.tensor(sig[i] * 1000.0, dtype=torch.float32, device=latents.device)
+            have = dict(latents=latents, prompt_embeds=prompt_embeds, noise_pred=noise_pred, timestep=timestep)
+            outs = callback_on_step_end(pipeline, i, t, {k: have[k] for k in callback_on_step_end_tensor_inputs})
+            new_latents = outs.pop("latents", latents)
+            if new_latents is not latents:
+                latents = new_latents.to(latents.dtype).contiguous()
+            prompt_embeds = outs.pop("prompt_embeds", prompt_embeds)
     return latents
 
 
@@ -209,9 +235,15 @@ class UniGenFLUXPipeline:
                  guidance_scale: float = 3.5, num_images_per_prompt: int = 1, generator=None, latents: Optional[torch.Tensor] = None,
                  prompt_embeds: Optional[torch.Tensor] = None, pooled_prompt_embeds: Optional[torch.Tensor] = None,
                  condition_prompt_embeds=None, condition_pooled_prompt_embeds=None, condition_ids=None, output_type: str = "latent",
-                 return_dict: bool = True, max_sequence_length: int = 512, dtype: torch.dtype = BF, gate_uniforms=None, **kwargs):
+                 return_dict: bool = True, max_sequence_length: int = 512, dtype: torch.dtype = BF, gate_uniforms=None,
+                 true_cfg_scale: float = 1.0, negative_prompt=None, negative_prompt_2=None, negative_prompt_embeds: Optional[torch.Tensor] = None,
+                 negative_pooled_prompt_embeds: Optional[torch.Tensor] = None, negative_gate_uniforms=None, callback_on_step_end=None,
+                 callback_on_step_end_tensor_inputs: Sequence[str] = ("latents",), **kwargs):
         tr = self.transformer
         dev = tr.device
+        for unsupported in ("ip_adapter_image", "ip_adapter_image_embeds", "negative_ip_adapter_image", "negative_ip_adapter_image_embeds"):
+            if kwargs.get(unsupported) is not None:
+                raise NotImplementedError(f"{unsupported}: IP-Adapter image embeds are outside this package's scope (SURVEY section 8)")
         if control_image is None:
             raise ValueError("control_image is required (pixels [B, 3, H, W] with a VAE attached, or packed condition latents [B, N, 4*C])")
         multi = isinstance(control_image, (list, tuple))
@@ -228,6 +260,12 @@ class UniGenFLUXPipeline:
         if prompt_embeds is None or pooled_prompt_embeds is None or condition_pooled_prompt_embeds is None or \
                 (multi and any(c is None for c in condition_pooled_prompt_embeds)):
             raise ValueError("prompt (or prompt_embeds + pooled_prompt_embeds) and condition_prompt (or condition_pooled_prompt_embeds) are required")
+        # true classifier-free guidance (src/UniGenPipeline.py:567-570, 594-607): a negative prompt (or its embeds) and true_cfg_scale > 1
+        has_neg = negative_prompt is not None or (negative_prompt_embeds is not None and negative_pooled_prompt_embeds is not None)
+        do_true_cfg = true_cfg_scale > 1 and has_neg
+        if do_true_cfg:
+            negative_prompt_embeds, negative_pooled_prompt_embeds = self._encode("negative_prompt", negative_prompt, negative_prompt_2, negative_prompt_embeds,
+                                                                                 negative_pooled_prompt_embeds, dev, num_images_per_prompt, max_sequence_length)
         height = height or self.default_sample_size * self.vae_scale_factor
         width = width or self.default_sample_size * self.vae_scale_factor
         hl, wl = height // (self.vae_scale_factor * 2), width // (self.vae_scale_factor * 2)
@@ -249,7 +287,11 @@ class UniGenFLUXPipeline:
                            text_ids=text_ids, latent_image_ids=ids, condition_ids=condition_ids, num_inference_steps=num_inference_steps,
                            sigmas=sigmas, guidance_scale=guidance_scale, conditioning_scale=conditioning_scale,
                            shift=self.scheduler.config["shift"], use_dynamic_shifting=self.scheduler.config["use_dynamic_shifting"],
-                           gate_uniforms=gate_uniforms)
+                           gate_uniforms=gate_uniforms, true_cfg_scale=true_cfg_scale if do_true_cfg else 1.0,
+                           negative_prompt_embeds=cast(negative_prompt_embeds) if do_true_cfg else None,
+                           negative_pooled_prompt_embeds=cast(negative_pooled_prompt_embeds) if do_true_cfg else None,
+                           negative_gate_uniforms=negative_gate_uniforms, callback_on_step_end=callback_on_step_end,
+                           callback_on_step_end_tensor_inputs=callback_on_step_end_tensor_inputs, pipeline=self)
         if output_type != "latent":
             out = self._decode(out, height, width, output_type)
         if not return_dict:
