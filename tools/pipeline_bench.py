@@ -1,0 +1,42 @@
+"""User-visible latency of one image batch through UniGenFLUXPipeline on one GPU: control pixels -> VAE encode -> pack -> 4-step denoise loop -> unpack ->
+VAE decode (text embeds given: CLIP / T5 are the caller's). cfg2 geometry (1024^2, canny, FLUX-schnell depth, B = 4), random weights and inputs.
+Reports the three stages and the rate with the VAE inside the timed region (bench.py's metric times the loop alone, as BASELINE.json defines it).
+usage: python tools/pipeline_bench.py [--batch 4] [--reps 3]"""
+import argparse, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from unigen_amd.flux import UniGenFlux
+from unigen_amd.vae import AutoencoderKL
+from unigen_amd.pipeline import UniGenFLUXPipeline
+
+ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=4); ap.add_argument("--reps", type=int, default=3); a = ap.parse_args()
+dev, BF = torch.device("cuda:0"), torch.bfloat16
+B = a.batch
+model = UniGenFlux.from_config({}, device=dev, dtype=BF)
+model.init_condition_block(condition_nums=1, condition_types=["canny"],
+                           control_params=dict(use_rope=True, use_shared_expert=True, use_single_trans_blocks=True, single_control_dev=2))
+model.init_synthetic_(seed=0, std=0.02)
+vae = AutoencoderKL(device=dev, dtype=BF); vae.init_synthetic_(seed=0)
+pipe = UniGenFLUXPipeline(transformer=model, vae=vae)
+g = torch.Generator(device=dev).manual_seed(0)
+rn = lambda *s: torch.randn(*s, generator=g, device=dev)
+image = rn(B, 3, 1024, 1024).clamp(-1, 1).to(BF)
+prompt, pooled, cpool = (0.1 * rn(B, 512, 4096)).to(BF), rn(B, 768).to(BF), rn(B, 768).to(BF)
+call = dict(prompt_embeds=prompt, pooled_prompt_embeds=pooled, condition_pooled_prompt_embeds=cpool, height=1024, width=1024, num_inference_steps=4, dtype=BF)
+
+
+def timed(f):
+    f(); torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(a.reps): out = f()
+    torch.cuda.synchronize(); return (time.perf_counter() - t0) / a.reps, out
+
+
+t_all, img = timed(lambda: pipe(control_image=image, output_type="pt", **call).images)
+packed = pipe._encode_control(image, 1024, 1024, BF, None)
+t_enc, _ = timed(lambda: pipe._encode_control(image, 1024, 1024, BF, None))
+t_loop, lat = timed(lambda: pipe(control_image=packed, output_type="latent", **call).images)
+t_dec, _ = timed(lambda: pipe._decode(lat, 1024, 1024, "pt"))
+assert img.shape == (B, 3, 1024, 1024) and bool(torch.isfinite(img.float()).all())
+print("PIPELINE_BENCH", json.dumps(dict(batch=B, steps=4, size=1024, total_s=round(t_all, 4), images_per_s_with_vae=round(B / t_all, 4), vae_encode_s=round(t_enc, 4),
+                                       denoise_loop_s=round(t_loop, 4), vae_decode_s=round(t_dec, 4), images_per_s_loop_only=round(B / t_loop, 4),
+                                       vae_share=round((t_enc + t_dec) / t_all, 4))))
