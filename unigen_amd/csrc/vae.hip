@@ -7,10 +7,14 @@
 //                       operand is gathered by the LDS-DMA itself: each lane's source address is its pixel's row of the tap being staged
 //                       (or a zero page for padding), so no im2col buffer exists; nearest-2x upsampling (Upsample2D) is folded into the
 //                       gather (source pixel = (y >> 1, x >> 1)), the asymmetric (0, 1, 0, 1) padding of Downsample2D is just pad_t = pad_l = 0.
-//                       128 x 128 x 64 tiles, 4 waves, v_mfma_f32_16x16x32_bf16, double-buffered LDS; bias and residual add fused.
-//   ug_groupnorm_nhwc   GroupNorm(eps) [+ SiLU] in two deterministic passes (per-chunk partial moments, fixed-order combine in fp64).
+//                       128 x 128 x 64 tiles, 4 waves, v_mfma_f32_16x16x32_bf16, double-buffered LDS; bias and residual add fused. Round 3: with
+//                       Cout and B Ho Wo multiples of 256 and Cin / 64 a power of two the SAME convolution runs on the 256^2 8-phase GEMM
+//                       kernel (gemm.hip, CONV: per-tap A gather; bit-identical); a 256 x 128 three-stage form of this kernel is kept as a switch.
+//   ug_groupnorm_nhwc   GroupNorm(eps) [+ SiLU] in two deterministic passes (per-chunk partial moments, fixed-order combine in fp64); 16-byte
+//                       kernels for the AutoencoderKL widths (C = 128 / 256 / 512) at the HBM roofline.
 //   ug_softmax_rows     row softmax of fp32 scores -> probabilities (the mid-block attention has ONE head of dim C = 512: it runs as
-//                       scores = q k^T (ug_gemm, fp32 out), this kernel, then P v (ug_gemm) - flash tiling buys nothing at 16 K tokens once).
+//                       scores = q k^T (ug_gemm, fp32 out), this kernel, then P v (ug_gemm): a 512-wide head does not fit the flash kernel's
+//                       registers); rows of 1024 n <= 16384 scores are read once and kept in registers.
 //   ug_nchw_to_nhwc / ug_nhwc_to_nchw   boundary layout changes (+ channel zero-padding to the conv's K granularity, + the latent scale / shift).
 //   ug_vae_sample       DiagonalGaussianDistribution.sample() + (z - shift) * scale.
 // Every kernel is a template over the element type: bf16 = product, fp32 = verification twin (the fp32 convolution is a direct loop).
