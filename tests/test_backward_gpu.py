@@ -177,7 +177,7 @@ for dh, H, B, Lq, Lkv in [(64, 3, 2, 257, 300), (64, 2, 1, 64, 64), (64, 2, 2, 1
     ops.flash_attn(q, k, v, o, batches=B, heads=H, dh=dh, Lq=Lq, Lkv=Lkv, lse=lse, q_strides=(D, Lq * D), k_strides=(D, Lkv * D),
                    v_strides=(D, Lkv * D), o_strides=(D, Lq * D))
     outs = []
-    for env in ({{"UG_ATTN_BWD_DMA": "1"}}, {{"UG_ATTN_BWD_DMA": "0"}}):
+    for env in ({{"UG_ATTN_BWD_DMA": "1", "UG_ATTN_BWD_FUSE_DKV": "1"}}, {{"UG_ATTN_BWD_DMA": "1", "UG_ATTN_BWD_FUSE_DKV": "0"}}, {{"UG_ATTN_BWD_DMA": "0"}}):
         os.environ.update(env)
         outs.append(ops.flash_attn_bwd(q, k, v, o, do, heads=H, lse=lse))
         outs.append(ops.flash_attn_bwd(q, k, v, o, do, heads=H, lse=None))          # statistics recomputed by the LSE mode
@@ -193,7 +193,9 @@ sys.exit(1 if bad else 0)
 
 
 def test_flash_attention_backward_selectable_variants(gpu):
-    """Register staging instead of LDS-DMA (UG_ATTN_BWD_DMA=0; statistics of streamed queries by global loads) returns the default's bits; with
+    """The fused dK / dV kernel (default; round 3: a 32-key block shared by the two waves of a pair, 5 product units instead of 8) against the separate DK and
+    DV modes (UG_ATTN_BWD_FUSE_DKV=0): same products in the same order -> the same bits. Register staging instead of LDS-DMA (UG_ATTN_BWD_DMA=0; statistics
+    of streamed queries by global loads; never fused) returns the default's bits; with
     lse=None (statistics recomputed by the LSE mode rather than taken from the forward) the gradients agree to rounding of the statistics.
     Ragged lengths, one tile, several tiles, both head widths."""
     import os, subprocess, sys

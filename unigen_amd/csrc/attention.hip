@@ -1311,6 +1311,219 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Fused dK / dV (round 3): the DK and DV modes above both recompute S = Q K^T over the same (keys, queries) - 8 product units per attention
+// against the minimum of 5. Fusing them on the 256-key ownership needs 128 accumulator + 64 owned-operand registers beside the score tiles:
+// over the 256 a two-wave-per-SIMD kernel has. This kernel splits the work of a 32-key block between the TWO waves of a pair instead:
+//   a workgroup owns 128 keys; waves p and p + 4 (p = 0..3) own the same 32 keys (K and V fragments in registers, key on the lane);
+//   score phase : wave half h = wave >> 2 takes the 32 streamed queries kb = h of the 64-row tile: S, dP -> P (for dV) and dS = P (dP - delta)
+//                 (for dK), packed to bf16 - the B operands of the accumulating products - and published lane-linear in LDS (4 KiB per wave);
+//   accumulation: after a barrier every wave has both halves' operands and accumulates the head dims [h DH/2, (h+1) DH/2) of BOTH gradients over
+//                 all 64 queries: dK^T += Q^T dS, dV^T += dO^T P (transposed reads of the streamed tiles, as in the modes above).
+// Per 32 keys x 64 queries: 16 + 16 (scores) + 16 + 16 (accumulation) MFMAs = the five product units, no duplicated product, 64 accumulator
+// registers per wave. Streamed tiles, statistics and the LDS image are those of the DK mode; two barriers per tile (operand exchange, buffer swap).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int DH>
+__global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(
+    const bf16_t* __restrict__ kk, int64_t k_rs, int64_t k_bs, const bf16_t* __restrict__ vv, int64_t v_rs, int64_t v_bs,
+    const bf16_t* __restrict__ qq, int64_t q_rs, int64_t q_bs, const bf16_t* __restrict__ dd, int64_t d_rs, int64_t d_bs,
+    const float* __restrict__ lse2, const float* __restrict__ delta, int64_t stat_ld, bf16_t* __restrict__ dk, int64_t dk_rs, int64_t dk_bs,
+    bf16_t* __restrict__ dv, int64_t dv_rs, int64_t dv_bs, int heads, int Lkv, int Lq, int nOwn, float c, float scale) {
+    constexpr int RB = 2 * DH, NCH = DH / 8, TILE = KVB * RB, QS = DH / 16, NDBH = DH / 64;
+    constexpr int BUFSZ = 2 * TILE + 512, ZOFF = 2 * BUFSZ;                // [2][Q tile | dO tile | lse2[64] | delta[64]] then 8 x 4 KiB of exchanged operands
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pair = wave & 3, half = wave >> 2;
+    const int r = lane & 31, h = lane >> 5;
+    const int ot = blockIdx.x % nOwn, bh = blockIdx.x / nOwn;
+    const int head = bh % heads, b = bh / heads;
+    const bf16_t* Kb = kk + (int64_t)b * k_bs + head * DH;
+    const bf16_t* Vb = vv + (int64_t)b * v_bs + head * DH;
+    const bf16_t* Qb = qq + (int64_t)b * q_bs + head * DH;
+    const bf16_t* Db = dd + (int64_t)b * d_bs + head * DH;
+    const int own_row = ot * 128 + pair * 32 + r;
+    const int own_ld = own_row < Lkv ? own_row : Lkv - 1;
+    bf16x8 fk[QS], fv[QS];
+#pragma unroll
+    for (int s = 0; s < QS; ++s) {
+        fk[s] = *(const bf16x8*)(Kb + (int64_t)own_ld * k_rs + 16 * s + 8 * h);
+        fv[s] = *(const bf16x8*)(Vb + (int64_t)own_ld * v_rs + 16 * s + 8 * h);
+    }
+    const float* stat_l = lse2 + (int64_t)bh * stat_ld;
+    const float* stat_d = delta + (int64_t)bh * stat_ld;
+    // LDS-DMA staging as in attn_bwd_kernel: wave w owns runs w * NIW .. + NIW - 1 of both streamed tiles, one tile ahead
+    constexpr int RPI = 1024 / RB, NI = TILE / 1024, NIW = NI / 8;
+    unsigned d1o[NIW], d2o[NIW];
+#pragma unroll
+    for (int u = 0; u < NIW; ++u) {
+        const int row = (wave * NIW + u) * RPI + lane / NCH;
+        const int ch = (lane % NCH) ^ row_swz<DH>(row);
+        d1o[u] = (unsigned)(row * (int)q_rs + ch * 8) * 2u;
+        d2o[u] = (unsigned)(row * (int)d_rs + ch * 8) * 2u;
+    }
+    auto dma_stream = [&](const bf16_t* base, int64_t rs, const unsigned (&off)[NIW], int row0, unsigned dst) __attribute__((always_inline)) {
+        if (row0 + KVB <= Lq) {
+            const void* tb = uniform_ptr(base + (int64_t)row0 * rs);
+#pragma unroll
+            for (int u = 0; u < NIW; ++u) glds16_off(tb, off[u], dst + u * 1024);
+        } else {                                       // ragged last tile: rows past the end re-read the last row (masked below)
+            int lane_r = lane;
+            asm volatile("" : "+v"(lane_r));
+#pragma unroll
+            for (int u = 0; u < NIW; ++u) {
+                const int row = (wave * NIW + u) * RPI + lane_r / NCH;
+                const int ch = (lane_r % NCH) ^ row_swz<DH>(row);
+                int sr = row0 + row; if (sr > Lq - 1) sr = Lq - 1;
+                glds16_ptr(base + (int64_t)sr * rs + ch * 8, dst + u * 1024);
+            }
+        }
+    };
+    auto stage_load = [&](int row0, int buf) __attribute__((always_inline)) {
+        const unsigned lb = __builtin_amdgcn_readfirstlane(lds_addr(smem)) + buf * BUFSZ, l0 = lb + wave * NIW * 1024;
+        dma_stream(Qb, q_rs, d1o, row0, l0);
+        dma_stream(Db, d_rs, d2o, row0, l0 + TILE);
+        if (wave == 0) glds4_ptr(stat_l + row0 + lane, lb + 2 * TILE);          // the tile's 64 lse2 / delta values (rows padded to a multiple of 64, zeros)
+        if (wave == 1) glds4_ptr(stat_d + row0 + lane, lb + 2 * TILE + 256);
+    };
+    const int k_base = RB * r + 16 * (h ^ row_swz<DH>(r));                 // row fragment s of 32-row block kb: kb * 32 * RB + (k_base ^ 32 s)
+    const int i16 = lane & 15, g16 = lane >> 4;
+    const int t_key = 4 * h + (i16 >> 2), t_lowch = 2 * (g16 & 1) + ((i16 & 3) >> 1), t_b8 = 8 * (i16 & 1);
+    const int tlo_base = RB * t_key + 16 * (t_lowch ^ row_swz<DH>(t_key)) + t_b8;              // d-block db, k-step ks: ks * 16 * RB + (base ^ 64 db)
+    const int thi_base = RB * (t_key + 8) + 16 * (t_lowch ^ row_swz<DH>(t_key + 8)) + t_b8;
+    f32x16 accK[NDBH], accV[NDBH];
+#pragma unroll
+    for (int db = 0; db < NDBH; ++db)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { accK[db][i] = 0.f; accV[db][i] = 0.f; }
+    unsigned char* const zmine = smem + ZOFF + wave * 4096 + lane * 16;
+    const unsigned char* const zpart = smem + ZOFF + (wave ^ 4) * 4096 + lane * 16;
+    const int ntiles = (Lq + KVB - 1) / KVB;
+    stage_load(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < ntiles) stage_load((t + 1) * KVB, cur ^ 1);
+        const unsigned char* B1 = smem + cur * BUFSZ;
+        const unsigned char* B2 = B1 + TILE;
+        // ---- score phase: the 32 streamed queries kb = half ----
+        bf16x8 zk[2], zv[2];
+        {
+            f32x16 x1, x2;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { x1[i] = 0.f; x2[i] = 0.f; }
+            int kb0 = k_base;
+            asm volatile("" : "+v"(kb0));
+            constexpr int PDS = 2;
+            bf16x8 ab[PDS + 1][2];
+            auto rd = [&](int s5) __attribute__((always_inline)) {
+                ab[s5 % (PDS + 1)][0] = *(const bf16x8*)(B1 + half * 32 * RB + (kb0 ^ (32 * s5)));
+                ab[s5 % (PDS + 1)][1] = *(const bf16x8*)(B2 + half * 32 * RB + (kb0 ^ (32 * s5)));
+            };
+#pragma unroll
+            for (int j = 0; j < PDS && j < QS; ++j) rd(j);
+#pragma unroll
+            for (int s5 = 0; s5 < QS; ++s5) {
+                if (s5 + PDS < QS) rd(s5 + PDS);
+                __builtin_amdgcn_sched_barrier(0);
+                x1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab[s5 % (PDS + 1)][0], fk[s5], x1, 0, 0, 0);
+                x2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab[s5 % (PDS + 1)][1], fv[s5], x2, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const float* st = (const float*)(B1 + 2 * TILE);
+            float sl[16], sd[16];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 a = *(const f32x4*)(st + half * 32 + 4 * h + 8 * g);
+                const f32x4 d4 = *(const f32x4*)(st + 64 + half * 32 + 4 * h + 8 * g);
+                sl[4 * g] = a[0]; sl[4 * g + 1] = a[1]; sl[4 * g + 2] = a[2]; sl[4 * g + 3] = a[3];
+                sd[4 * g] = d4[0]; sd[4 * g + 1] = d4[1]; sd[4 * g + 2] = d4[2]; sd[4 * g + 3] = d4[3];
+            }
+            float pk[16], pv[16];
+            const int srow0 = t * KVB + half * 32 + 4 * h;
+            if (t * KVB + KVB <= Lq) {                 // rows past the end exist only in the ragged last tile
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    pv[i] = __builtin_amdgcn_exp2f(fmaf(x1[i], c, -sl[i]));
+                    pk[i] = pv[i] * (x2[i] - sd[i]);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float p = __builtin_amdgcn_exp2f(fmaf(x1[i], c, -sl[i]));
+                    const bool valid = srow0 + (i & 3) + 8 * (i >> 2) < Lq;
+                    pv[i] = valid ? p : 0.f;
+                    pk[i] = valid ? p * (x2[i] - sd[i]) : 0.f;
+                }
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                u32x4 w;
+                w.x = pack2bf(pk[8 * s2 + 0], pk[8 * s2 + 1]); w.y = pack2bf(pk[8 * s2 + 2], pk[8 * s2 + 3]);
+                w.z = pack2bf(pk[8 * s2 + 4], pk[8 * s2 + 5]); w.w = pack2bf(pk[8 * s2 + 6], pk[8 * s2 + 7]);
+                zk[s2] = __builtin_bit_cast(bf16x8, w);
+                w.x = pack2bf(pv[8 * s2 + 0], pv[8 * s2 + 1]); w.y = pack2bf(pv[8 * s2 + 2], pv[8 * s2 + 3]);
+                w.z = pack2bf(pv[8 * s2 + 4], pv[8 * s2 + 5]); w.w = pack2bf(pv[8 * s2 + 6], pv[8 * s2 + 7]);
+                zv[s2] = __builtin_bit_cast(bf16x8, w);
+            }
+            *(bf16x8*)(zmine) = zk[0]; *(bf16x8*)(zmine + 1024) = zk[1]; *(bf16x8*)(zmine + 2048) = zv[0]; *(bf16x8*)(zmine + 3072) = zv[1];
+        }
+        // ---- accumulation: dims [half DH/2, +DH/2) of dK^T and dV^T over all 64 queries; the transposed fragments of k-step ks + 1 are requested
+        //      before the MFMAs of step ks, those of step 0 ahead of the barrier (they do not depend on the partner) ----
+        {
+            int lo0 = tlo_base, hi0 = thi_base;
+            asm volatile("" : "+v"(lo0), "+v"(hi0));
+            bf16x8 tq[2][NDBH], td[2][NDBH];
+            auto rdT = [&](int ks) __attribute__((always_inline)) {
+#pragma unroll
+                for (int db = 0; db < NDBH; ++db) {
+                    const int dg = half * NDBH + db;
+                    tq[ks & 1][db] = tr_read_pair(B1 + ks * 16 * RB + (lo0 ^ (64 * dg)), B1 + ks * 16 * RB + (hi0 ^ (64 * dg)));
+                    td[ks & 1][db] = tr_read_pair(B2 + ks * 16 * RB + (lo0 ^ (64 * dg)), B2 + ks * 16 * RB + (hi0 ^ (64 * dg)));
+                }
+            };
+            rdT(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();                           // both halves' operands are in LDS
+            const bf16x8 pk0 = *(const bf16x8*)(zpart), pk1 = *(const bf16x8*)(zpart + 1024), pv0 = *(const bf16x8*)(zpart + 2048), pv1 = *(const bf16x8*)(zpart + 3072);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bool mine = (ks >> 1) == half;               // wave-uniform
+                const bf16x8 bK = mine ? zk[ks & 1] : ((ks & 1) ? pk1 : pk0);
+                const bf16x8 bV = mine ? zv[ks & 1] : ((ks & 1) ? pv1 : pv0);
+                if (ks + 1 < 4) rdT(ks + 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int db = 0; db < NDBH; ++db) {
+                    accK[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tq[ks & 1][db], bK, accK[db], 0, 0, 0);
+                    accV[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(td[ks & 1][db], bV, accV[db], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (t + 1 < ntiles) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    if (own_row < Lkv) {
+        bf16_t* Krow = dk + (int64_t)b * dk_bs + (int64_t)own_row * dk_rs + head * DH;
+        bf16_t* Vrow = dv + (int64_t)b * dv_bs + (int64_t)own_row * dv_rs + head * DH;
+#pragma unroll
+        for (int db = 0; db < NDBH; ++db)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int d0 = 32 * (half * NDBH + db) + 8 * g4 + 4 * h;
+                u32x2 w;
+                w.x = pack2bf(accK[db][4 * g4 + 0] * scale, accK[db][4 * g4 + 1] * scale);
+                w.y = pack2bf(accK[db][4 * g4 + 2] * scale, accK[db][4 * g4 + 3] * scale);
+                *(u32x2*)(Krow + d0) = w;
+                w.x = pack2bf(accV[db][4 * g4 + 0], accV[db][4 * g4 + 1]);
+                w.y = pack2bf(accV[db][4 * g4 + 2], accV[db][4 * g4 + 3]);
+                *(u32x2*)(Vrow + d0) = w;
+            }
+    }
+}
+
 // delta[bh][q] = sum_d dO[b][q][h*DH + d] * O[b][q][h*DH + d]: DH / 8 lanes per (b, q, h), 16-byte loads, the sum over those lanes by xor shuffles
 template <int DH>
 __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ o, int64_t o_rs, int64_t o_bs, const bf16_t* __restrict__ dout, int64_t d_rs,
@@ -1465,6 +1678,10 @@ extern "C" int ug_flash_attn_bwd(const void* q, int64_t q_rs, int64_t q_bs, cons
     const int nQ = (int)((Lq + 255) / 256), nK = (int)((Lkv + 255) / 256);
     const int64_t gq = (int64_t)nQ * heads * batches, gk = (int64_t)nK * heads * batches;
     UG_REQUIRE(gq < (1ll << 31) && gk < (1ll << 31), UG_ERR_UNSUPPORTED, "ug_flash_attn_bwd: grid too large");
+    // fused dK / dV kernel (128 keys per workgroup; needs the LDS-DMA staging and equal row strides are NOT required); UG_ATTN_BWD_FUSE_DKV=0: the two modes
+    const int nK2 = (int)((Lkv + 127) / 128);
+    const int64_t gk2 = (int64_t)nK2 * heads * batches;
+    const bool fuse_dkv = bwd_dma && gk2 < (1ll << 31) && ug_env_int("UG_ATTN_BWD_FUSE_DKV", 1);
     (void)hipMemsetAsync(workspace, 0, (size_t)(2 * batches * heads * stat_ld) * sizeof(float), s);     // padded statistics rows read as 0
     const int64_t total = batches * Lq * heads;
     if (dh == 128)
@@ -1488,8 +1705,17 @@ extern "C" int ug_flash_attn_bwd(const void* q, int64_t q_rs, int64_t q_bs, cons
     do {                                                                                                                                              \
         if (!lse_in) UG_BWD(DHV, BWD_LSE, gq, q, q_rs, q_bs, nullptr, 0, 0, k, k_rs, k_bs, nullptr, 0, 0, nullptr, 0, 0, Lq, Lkv, nQ);             \
         UG_BWD(DHV, BWD_DQ, gq, q, q_rs, q_bs, dout, do_rs, do_bs, k, k_rs, k_bs, v, v_rs, v_bs, dq, dq_rs, dq_bs, Lq, Lkv, nQ);                   \
-        UG_BWD(DHV, BWD_DK, gk, k, k_rs, k_bs, v, v_rs, v_bs, q, q_rs, q_bs, dout, do_rs, do_bs, dk, dk_rs, dk_bs, Lkv, Lq, nK);                   \
-        UG_BWD(DHV, BWD_DV, gk, k, k_rs, k_bs, nullptr, 0, 0, q, q_rs, q_bs, dout, do_rs, do_bs, dv, dv_rs, dv_bs, Lkv, Lq, nK);                   \
+        if (fuse_dkv) {                                                                                                                            \
+            constexpr int lds_ = 2 * (2 * KVB * 2 * DHV + 512) + 8 * 4096;                                                                          \
+            static bool attr_ = false;                                                                                                              \
+            if (!attr_) { (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<DHV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_); attr_ = true; } \
+            hipLaunchKernelGGL((attn_bwd_dkv_kernel<DHV>), dim3((unsigned)gk2), dim3(512), lds_, s, (const bf16_t*)k, k_rs, k_bs, (const bf16_t*)v, v_rs, v_bs,  \
+                               (const bf16_t*)q, q_rs, q_bs, (const bf16_t*)dout, do_rs, do_bs, lse2, delta, stat_ld, (bf16_t*)dk, dk_rs, dk_bs, (bf16_t*)dv,   \
+                               dv_rs, dv_bs, (int)heads, (int)Lkv, (int)Lq, nK2, c, softmax_scale);                                                  \
+        } else {                                                                                                                                    \
+            UG_BWD(DHV, BWD_DK, gk, k, k_rs, k_bs, v, v_rs, v_bs, q, q_rs, q_bs, dout, do_rs, do_bs, dk, dk_rs, dk_bs, Lkv, Lq, nK);               \
+            UG_BWD(DHV, BWD_DV, gk, k, k_rs, k_bs, nullptr, 0, 0, q, q_rs, q_bs, dout, do_rs, do_bs, dv, dv_rs, dv_bs, Lkv, Lq, nK);               \
+        }                                                                                                                                           \
     } while (0)
     if (dh == 128) UG_BWD_ALL(128); else UG_BWD_ALL(64);
 #undef UG_BWD_ALL
