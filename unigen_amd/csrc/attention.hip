@@ -1329,12 +1329,12 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(
     const bf16_t* __restrict__ qq, int64_t q_rs, int64_t q_bs, const bf16_t* __restrict__ dd, int64_t d_rs, int64_t d_bs,
     const float* __restrict__ lse2, const float* __restrict__ delta, int64_t stat_ld, bf16_t* __restrict__ dk, int64_t dk_rs, int64_t dk_bs,
     bf16_t* __restrict__ dv, int64_t dv_rs, int64_t dv_bs, int heads, int Lkv, int Lq, int nOwn, float c, float scale) {
-    constexpr int RB = 2 * DH, NCH = DH / 8, TILE = KVB * RB, QS = DH / 16, NDBH = DH / 64;
-    constexpr int BUFSZ = 2 * TILE + 512, ZOFF = 2 * BUFSZ;                // [2][Q tile | dO tile | lse2[64] | delta[64]] then 8 x 4 KiB of exchanged operands
+    constexpr int RB = 2 * DH, NCH = DH / 8, TILE = KVB * RB, QS = DH / 16, NDB = DH / 32;
+    constexpr int BUFSZ = 2 * TILE + 512, NSTG = 3, ZOFF = NSTG * BUFSZ;   // [3][Q tile | dO tile | lse2[64] | delta[64]] then [2][8 waves] x 2 KiB of exchanged operands
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int pair = wave & 3, half = wave >> 2;
+    const int pair = wave & 3, half = wave >> 2;           // half 0: queries kb = 0 of a tile, accumulates dK; half 1: queries kb = 1, accumulates dV
     const int r = lane & 31, h = lane >> 5;
     const int ot = blockIdx.x % nOwn, bh = blockIdx.x / nOwn;
     const int head = bh % heads, b = bh / heads;
@@ -1352,7 +1352,9 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(
     }
     const float* stat_l = lse2 + (int64_t)bh * stat_ld;
     const float* stat_d = delta + (int64_t)bh * stat_ld;
-    // LDS-DMA staging as in attn_bwd_kernel: wave w owns runs w * NIW .. + NIW - 1 of both streamed tiles, one tile ahead
+    // LDS-DMA staging as in attn_bwd_kernel (wave w owns runs w * NIW .. + NIW - 1 of both streamed tiles), but a ring of three stages: tile t + 2 is
+    // requested right after the barrier of tile t (its stage was last read by the accumulation of tile t - 1, which every wave has left by then) and is
+    // waited for ahead of the barrier of tile t + 1 - one barrier per tile certifies both the exchange and the landing.
     constexpr int RPI = 1024 / RB, NI = TILE / 1024, NIW = NI / 8;
     unsigned d1o[NIW], d2o[NIW];
 #pragma unroll
@@ -1379,8 +1381,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(
             }
         }
     };
-    auto stage_load = [&](int row0, int buf) __attribute__((always_inline)) {
-        const unsigned lb = __builtin_amdgcn_readfirstlane(lds_addr(smem)) + buf * BUFSZ, l0 = lb + wave * NIW * 1024;
+    auto stage_load = [&](int row0, int stg) __attribute__((always_inline)) {
+        const unsigned lb = __builtin_amdgcn_readfirstlane(lds_addr(smem)) + stg * BUFSZ, l0 = lb + wave * NIW * 1024;
         dma_stream(Qb, q_rs, d1o, row0, l0);
         dma_stream(Db, d_rs, d2o, row0, l0 + TILE);
         if (wave == 0) glds4_ptr(stat_l + row0 + lane, lb + 2 * TILE);          // the tile's 64 lse2 / delta values (rows padded to a multiple of 64, zeros)
@@ -1391,24 +1393,24 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(
     const int t_key = 4 * h + (i16 >> 2), t_lowch = 2 * (g16 & 1) + ((i16 & 3) >> 1), t_b8 = 8 * (i16 & 1);
     const int tlo_base = RB * t_key + 16 * (t_lowch ^ row_swz<DH>(t_key)) + t_b8;              // d-block db, k-step ks: ks * 16 * RB + (base ^ 64 db)
     const int thi_base = RB * (t_key + 8) + 16 * (t_lowch ^ row_swz<DH>(t_key + 8)) + t_b8;
-    f32x16 accK[NDBH], accV[NDBH];
+    f32x16 acc[NDB];                                   // dK^T (half 0) or dV^T (half 1): [d][own key]
 #pragma unroll
-    for (int db = 0; db < NDBH; ++db)
+    for (int db = 0; db < NDB; ++db)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { accK[db][i] = 0.f; accV[db][i] = 0.f; }
-    unsigned char* const zmine = smem + ZOFF + wave * 4096 + lane * 16;
-    const unsigned char* const zpart = smem + ZOFF + (wave ^ 4) * 4096 + lane * 16;
+        for (int i = 0; i < 16; ++i) acc[db][i] = 0.f;
     const int ntiles = (Lq + KVB - 1) / KVB;
     stage_load(0, 0);
+    if (ntiles > 1) stage_load(KVB, 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    int stg = 0;                                       // stage of tile t
     for (int t = 0; t < ntiles; ++t) {
-        const int cur = t & 1;
-        if (t + 1 < ntiles) stage_load((t + 1) * KVB, cur ^ 1);
-        const unsigned char* B1 = smem + cur * BUFSZ;
+        const unsigned char* B1 = smem + stg * BUFSZ;
         const unsigned char* B2 = B1 + TILE;
-        // ---- score phase: the 32 streamed queries kb = half ----
-        bf16x8 zk[2], zv[2];
+        unsigned char* const zmine = smem + ZOFF + (t & 1) * 16384 + wave * 2048 + lane * 16;
+        const unsigned char* const zpart = smem + ZOFF + (t & 1) * 16384 + (wave ^ 4) * 2048 + lane * 16;
+        // ---- score phase: the 32 streamed queries kb = half; this wave keeps the operand of ITS gradient and publishes the other one ----
+        bf16x8 zown[2];
         {
             f32x16 x1, x2;
 #pragma unroll
@@ -1441,7 +1443,6 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(
                 sd[4 * g] = d4[0]; sd[4 * g + 1] = d4[1]; sd[4 * g + 2] = d4[2]; sd[4 * g + 3] = d4[3];
             }
             float pk[16], pv[16];
-            const int srow0 = t * KVB + half * 32 + 4 * h;
             if (t * KVB + KVB <= Lq) {                 // rows past the end exist only in the ragged last tile
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
@@ -1449,6 +1450,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(
                     pk[i] = pv[i] * (x2[i] - sd[i]);
                 }
             } else {
+                const int srow0 = t * KVB + half * 32 + 4 * h;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const float p = __builtin_amdgcn_exp2f(fmaf(x1[i], c, -sl[i]));
@@ -1457,6 +1459,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(
                     pk[i] = valid ? p * (x2[i] - sd[i]) : 0.f;
                 }
             }
+            bf16x8 zk[2], zv[2];
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 u32x4 w;
@@ -1467,59 +1470,51 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(
                 w.z = pack2bf(pv[8 * s2 + 4], pv[8 * s2 + 5]); w.w = pack2bf(pv[8 * s2 + 6], pv[8 * s2 + 7]);
                 zv[s2] = __builtin_bit_cast(bf16x8, w);
             }
-            *(bf16x8*)(zmine) = zk[0]; *(bf16x8*)(zmine + 1024) = zk[1]; *(bf16x8*)(zmine + 2048) = zv[0]; *(bf16x8*)(zmine + 3072) = zv[1];
+            zown[0] = half ? zv[0] : zk[0]; zown[1] = half ? zv[1] : zk[1];        // wave-uniform selects
+            *(bf16x8*)(zmine) = half ? zk[0] : zv[0];
+            *(bf16x8*)(zmine + 1024) = half ? zk[1] : zv[1];
         }
-        // ---- accumulation: dims [half DH/2, +DH/2) of dK^T and dV^T over all 64 queries; the transposed fragments of k-step ks + 1 are requested
-        //      before the MFMAs of step ks, those of step 0 ahead of the barrier (they do not depend on the partner) ----
+        // ---- accumulation over all 64 queries: dK^T += Q^T dS (half 0) or dV^T += dO^T P (half 1); the transposed fragments of k-step ks + 1 are
+        //      requested before the MFMAs of step ks, those of step 0 ahead of the barrier (they do not depend on the partner) ----
         {
+            const unsigned char* Tb = half ? B2 : B1;
             int lo0 = tlo_base, hi0 = thi_base;
             asm volatile("" : "+v"(lo0), "+v"(hi0));
-            bf16x8 tq[2][NDBH], td[2][NDBH];
+            bf16x8 tf[2][NDB];
             auto rdT = [&](int ks) __attribute__((always_inline)) {
 #pragma unroll
-                for (int db = 0; db < NDBH; ++db) {
-                    const int dg = half * NDBH + db;
-                    tq[ks & 1][db] = tr_read_pair(B1 + ks * 16 * RB + (lo0 ^ (64 * dg)), B1 + ks * 16 * RB + (hi0 ^ (64 * dg)));
-                    td[ks & 1][db] = tr_read_pair(B2 + ks * 16 * RB + (lo0 ^ (64 * dg)), B2 + ks * 16 * RB + (hi0 ^ (64 * dg)));
-                }
+                for (int db = 0; db < NDB; ++db) tf[ks & 1][db] = tr_read_pair(Tb + ks * 16 * RB + (lo0 ^ (64 * db)), Tb + ks * 16 * RB + (hi0 ^ (64 * db)));
             };
             rdT(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's share of tile t + 1 has landed (requested a whole tile ago)
             __builtin_amdgcn_sched_barrier(0);
-            __syncthreads();                           // both halves' operands are in LDS
-            const bf16x8 pk0 = *(const bf16x8*)(zpart), pk1 = *(const bf16x8*)(zpart + 1024), pv0 = *(const bf16x8*)(zpart + 2048), pv1 = *(const bf16x8*)(zpart + 3072);
+            __syncthreads();                           // the partner's operand is in LDS; tile t + 1 is complete; nobody reads the stage of tile t - 1 any more
+            if (t + 2 < ntiles) stage_load((t + 2) * KVB, stg == 0 ? 2 : stg - 1);
+            const bf16x8 zp0 = *(const bf16x8*)(zpart), zp1 = *(const bf16x8*)(zpart + 1024);
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const bool mine = (ks >> 1) == half;               // wave-uniform
-                const bf16x8 bK = mine ? zk[ks & 1] : ((ks & 1) ? pk1 : pk0);
-                const bf16x8 bV = mine ? zv[ks & 1] : ((ks & 1) ? pv1 : pv0);
+                const bf16x8 bz = mine ? zown[ks & 1] : ((ks & 1) ? zp1 : zp0);
                 if (ks + 1 < 4) rdT(ks + 1);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int db = 0; db < NDBH; ++db) {
-                    accK[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tq[ks & 1][db], bK, accK[db], 0, 0, 0);
-                    accV[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(td[ks & 1][db], bV, accV[db], 0, 0, 0);
-                }
+                for (int db = 0; db < NDB; ++db) acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf[ks & 1][db], bz, acc[db], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (t + 1 < ntiles) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        stg = stg == 2 ? 0 : stg + 1;
     }
     if (own_row < Lkv) {
-        bf16_t* Krow = dk + (int64_t)b * dk_bs + (int64_t)own_row * dk_rs + head * DH;
-        bf16_t* Vrow = dv + (int64_t)b * dv_bs + (int64_t)own_row * dv_rs + head * DH;
+        bf16_t* Orow = (half ? dv + (int64_t)b * dv_bs + (int64_t)own_row * dv_rs : dk + (int64_t)b * dk_bs + (int64_t)own_row * dk_rs) + head * DH;
+        const float es = half ? 1.f : scale;
 #pragma unroll
-        for (int db = 0; db < NDBH; ++db)
+        for (int db = 0; db < NDB; ++db)
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
-                const int d0 = 32 * (half * NDBH + db) + 8 * g4 + 4 * h;
                 u32x2 w;
-                w.x = pack2bf(accK[db][4 * g4 + 0] * scale, accK[db][4 * g4 + 1] * scale);
-                w.y = pack2bf(accK[db][4 * g4 + 2] * scale, accK[db][4 * g4 + 3] * scale);
-                *(u32x2*)(Krow + d0) = w;
-                w.x = pack2bf(accV[db][4 * g4 + 0], accV[db][4 * g4 + 1]);
-                w.y = pack2bf(accV[db][4 * g4 + 2], accV[db][4 * g4 + 3]);
-                *(u32x2*)(Vrow + d0) = w;
+                w.x = pack2bf(acc[db][4 * g4 + 0] * es, acc[db][4 * g4 + 1] * es);
+                w.y = pack2bf(acc[db][4 * g4 + 2] * es, acc[db][4 * g4 + 3] * es);
+                *(u32x2*)(Orow + 32 * db + 8 * g4 + 4 * h) = w;
             }
     }
 }
@@ -1706,7 +1701,7 @@ extern "C" int ug_flash_attn_bwd(const void* q, int64_t q_rs, int64_t q_bs, cons
         if (!lse_in) UG_BWD(DHV, BWD_LSE, gq, q, q_rs, q_bs, nullptr, 0, 0, k, k_rs, k_bs, nullptr, 0, 0, nullptr, 0, 0, Lq, Lkv, nQ);             \
         UG_BWD(DHV, BWD_DQ, gq, q, q_rs, q_bs, dout, do_rs, do_bs, k, k_rs, k_bs, v, v_rs, v_bs, dq, dq_rs, dq_bs, Lq, Lkv, nQ);                   \
         if (fuse_dkv) {                                                                                                                            \
-            constexpr int lds_ = 2 * (2 * KVB * 2 * DHV + 512) + 8 * 4096;                                                                          \
+            constexpr int lds_ = 3 * (2 * KVB * 2 * DHV + 512) + 2 * 8 * 2048;                                                                          \
             static bool attr_ = false;                                                                                                              \
             if (!attr_) { (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<DHV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_); attr_ = true; } \
             hipLaunchKernelGGL((attn_bwd_dkv_kernel<DHV>), dim3((unsigned)gk2), dim3(512), lds_, s, (const bf16_t*)k, k_rs, k_bs, (const bf16_t*)v, v_rs, v_bs,  \
