@@ -1316,12 +1316,20 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(
 // against the minimum of 5. Fusing them on the 256-key ownership needs 128 accumulator + 64 owned-operand registers beside the score tiles:
 // over the 256 a two-wave-per-SIMD kernel has. This kernel splits the work of a 32-key block between the TWO waves of a pair instead:
 //   a workgroup owns 128 keys; waves p and p + 4 (p = 0..3) own the same 32 keys (K and V fragments in registers, key on the lane);
-//   score phase : wave half h = wave >> 2 takes the 32 streamed queries kb = h of the 64-row tile: S, dP -> P (for dV) and dS = P (dP - delta)
-//                 (for dK), packed to bf16 - the B operands of the accumulating products - and published lane-linear in LDS (4 KiB per wave);
-//   accumulation: after a barrier every wave has both halves' operands and accumulates the head dims [h DH/2, (h+1) DH/2) of BOTH gradients over
-//                 all 64 queries: dK^T += Q^T dS, dV^T += dO^T P (transposed reads of the streamed tiles, as in the modes above).
+//   score phase : wave half h = wave >> 2 takes the 32 streamed queries kb = h of the 64-row tile: S, dP -> P and dS = P (dP - delta), packed to bf16 -
+//                 the B operands of the accumulating products. Half 0 accumulates dK, half 1 accumulates dV: a wave keeps the operand of ITS gradient
+//                 and publishes the other one lane-linear in LDS (2 KiB per wave, double-buffered);
+//   accumulation: after ONE barrier per tile a wave has its partner's operand too and accumulates its gradient over all 64 queries, all head dims:
+//                 dK^T += Q^T dS (half 0) or dV^T += dO^T P (half 1) (transposed reads of the streamed tile, fragments one k-step ahead).
 // Per 32 keys x 64 queries: 16 + 16 (scores) + 16 + 16 (accumulation) MFMAs = the five product units, no duplicated product, 64 accumulator
-// registers per wave. Streamed tiles, statistics and the LDS image are those of the DK mode; two barriers per tile (operand exchange, buffer swap).
+// registers per wave. The streamed tiles (image and statistics of the DK mode) sit in a ring of THREE stages: tile t + 2 is requested right after the
+// barrier of tile t and waited for ahead of the barrier of tile t + 1, so that single barrier certifies the exchange, the landing and the free stage.
+// Measured (tools/attn_bwd_ab.py, profiles/r03y_attn_bwd_fuse_*.log; whole backward incl. the DQ mode): dh 128 605 -> 711 TFLOP/s of the algorithmic
+// 10 B H Lq Lkv dh at 4608^2 (+17.6 %; 8704^2 +17 %, 1000^2 +8 %), dh 64 531 -> 578 / 574 -> 612; same bits as the two modes (same products, same order).
+// Steps on the way: the first form (both gradients per wave on half the head dims, 4 KiB exchange, two barriers) +0.8 %; its transposed reads one step
+// ahead +2 %; the per-element row masks out of the whole-tile path (32 v_cndmask per tile: the score phase is VALU-bound) +13.6 %; this form +17.6 %.
+// Tried and dropped: the dV waves scoring tile t + 1 BEFORE accumulating tile t while the dK waves do the opposite (the two waves of a SIMD then
+// alternate VALU-heavy and MFMA-only phases): 37 spilled registers at dh 128 (421 TFLOP/s), and 522 vs 578 at dh 64 without a single spill.
 // ---------------------------------------------------------------------------------------------------------------------
 template <int DH>
 __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(
