@@ -116,7 +116,8 @@ def test_attention_backward(gpu):
         run_case(gpu, hip, ref, [qkv], name=f"attention_dh{dh}_{Lq}x{Lkv}")
 
 
-@pytest.mark.parametrize("dh,H,B,Lq,Lkv", [(128, 3, 2, 300, 333), (64, 2, 1, 64, 64), (128, 2, 2, 600, 520), (64, 4, 2, 257, 129)])
+@pytest.mark.parametrize("dh,H,B,Lq,Lkv", [(128, 3, 2, 300, 333), (64, 2, 1, 64, 64), (128, 2, 2, 600, 520), (64, 4, 2, 257, 129),
+                                           (128, 2, 1, 2100, 2200)])      # the last one: >= 2048 queries at dh 128 -> the pair-scheme dQ kernel by default
 def test_flash_attention_backward_kernels(gpu, dh, H, B, Lq, Lkv, monkeypatch):
     """ug_flash_attn_bwd (lse / dQ / dK / dV kernels on the forward's tiling) against torch autograd of SDPA in fp32 on the CPU, ragged lengths,
     strided q / k / v inside one [B, L, 3 H dh] buffer; and against the GEMM formulation of the same backward (UG_ATTN_BWD=gemm)."""
@@ -177,17 +178,26 @@ for dh, H, B, Lq, Lkv in [(64, 3, 2, 257, 300), (64, 2, 1, 64, 64), (64, 2, 2, 1
     ops.flash_attn(q, k, v, o, batches=B, heads=H, dh=dh, Lq=Lq, Lkv=Lkv, lse=lse, q_strides=(D, Lq * D), k_strides=(D, Lkv * D),
                    v_strides=(D, Lkv * D), o_strides=(D, Lq * D))
     outs = []
-    for env in ({{"UG_ATTN_BWD_DMA": "1", "UG_ATTN_BWD_FUSE_DKV": "1"}}, {{"UG_ATTN_BWD_DMA": "1", "UG_ATTN_BWD_FUSE_DKV": "0"}}, {{"UG_ATTN_BWD_DMA": "0"}}):
+    # variant 0: pair-scheme dQ kernel (forced: by default it takes head width 128 from 2048 queries) + fused dK / dV kernel; 1: separate DK / DV modes; 2: the 256-query DQ mode; 3: register staging (all modes)
+    for env in ({{"UG_ATTN_BWD_DMA": "1", "UG_ATTN_BWD_FUSE_DKV": "1", "UG_ATTN_BWD_PAIR_DQ": "2"}}, {{"UG_ATTN_BWD_FUSE_DKV": "0"}},
+                {{"UG_ATTN_BWD_FUSE_DKV": "1", "UG_ATTN_BWD_PAIR_DQ": "0"}}, {{"UG_ATTN_BWD_DMA": "0"}}):
         os.environ.update(env)
         outs.append(ops.flash_attn_bwd(q, k, v, o, do, heads=H, lse=lse))
         outs.append(ops.flash_attn_bwd(q, k, v, o, do, heads=H, lse=None))          # statistics recomputed by the LSE mode
     torch.cuda.synchronize()
+    close = lambda a, b: bool(((a.float() - b.float()).norm() / b.float().norm()) < 2e-3)
     for i, got in enumerate(outs[1:], 1):
         for a, b, nm in zip(got, outs[0], ("dq", "dk", "dv")):
-            same = torch.equal(a, b) if i % 2 == 0 else bool(((a.float() - b.float()).norm() / b.float().norm()) < 2e-3)
+            # given statistics: dk / dv bitwise everywhere; dq bitwise among the pair-scheme runs (variants 0, 1), to fp32 rounding against the DQ mode
+            # (two partial sums over the keys instead of one); recomputed statistics: to rounding
+            exact = i % 2 == 0 and (nm != "dq" or i // 2 == 1)
+            same = torch.equal(a, b) if exact else close(a, b)
             if not same:
                 bad += 1
                 print("MISMATCH", dh, Lq, Lkv, "variant", i, nm)
+    if not (torch.equal(outs[4][0], outs[6][0])):                                  # the DQ mode itself: LDS-DMA and register staging agree bitwise
+        bad += 1
+        print("MISMATCH", dh, Lq, Lkv, "dq of the DQ mode, DMA vs registers")
 sys.exit(1 if bad else 0)
 """
 
@@ -195,7 +205,8 @@ sys.exit(1 if bad else 0)
 def test_flash_attention_backward_selectable_variants(gpu):
     """The fused dK / dV kernel (default; round 3: a 32-key block shared by the two waves of a pair, 5 product units instead of 8) against the separate DK and
     DV modes (UG_ATTN_BWD_FUSE_DKV=0): same products in the same order -> the same bits. Register staging instead of LDS-DMA (UG_ATTN_BWD_DMA=0; statistics
-    of streamed queries by global loads; never fused) returns the default's bits; with
+    of streamed queries by global loads; never fused) returns the default's bits; the pair-scheme dQ kernel (default; 128 queries per workgroup, each wave of a pair
+    sums over half of the keys) agrees with the 256-query DQ mode (UG_ATTN_BWD_PAIR_DQ=0) to fp32 rounding of the sum over keys; with
     lse=None (statistics recomputed by the LSE mode rather than taken from the forward) the gradients agree to rounding of the statistics.
     Ragged lengths, one tile, several tiles, both head widths."""
     import os, subprocess, sys

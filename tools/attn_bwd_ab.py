@@ -33,7 +33,11 @@ for B, Lq, Lkv in SHAPES:
     torch.cuda.synchronize()
     for i in range(1, len(VARIANTS)):
         for a, b, nm in zip(outs[i], outs[0], ("dq", "dk", "dv")):
-            assert torch.equal(a, b), f"variant {VARIANTS[i]}: {nm} differs from the reference variant"
+            if os.environ.get("ATTN_BWD_AB_TOL"):     # variants that sum in another order (the pair-scheme dQ kernel vs the DQ mode): relative L2 instead of bits
+                e = float((a.float() - b.float()).norm() / b.float().norm())
+                assert e <= float(os.environ["ATTN_BWD_AB_TOL"]), f"variant {VARIANTS[i]}: {nm} differs from the reference variant by {e:.3e}"
+            else:
+                assert torch.equal(a, b), f"variant {VARIANTS[i]}: {nm} differs from the reference variant"
     times = [[] for _ in VARIANTS]
     for rnd in range(7):
         for i in range(len(VARIANTS)):

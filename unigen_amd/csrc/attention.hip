@@ -1527,6 +1527,183 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// dQ on the pair scheme (round 3): the DQ mode above owns 256 queries per workgroup - 18 x 24 x B = 864 workgroups at L = 4608, B = 2: 3.4 rounds of
+// the 256 CUs, the last one 37 % full. Here a workgroup owns 128 queries; waves p and p + 4 own the same 32 (Q and dO fragments in registers, query on
+// the lane), wave half h takes the 32 streamed KEYS kb = h of each 64-key tile: S^T, dP^T -> dS^T -> dQ^T += K^T dS^T over its own keys only - no
+// exchange per tile, 24 MFMAs per wave and tile - and the two partial sums of a pair meet once, in LDS, after the last tile. Twice the workgroups
+// (6.75 rounds: 4 % idle in the last instead of 16 %), half the accumulator-side registers, the three-stage stream ring and one barrier per tile of
+// the fused dK / dV kernel. The sum over keys associates differently from the DQ mode (two partial sums): same value to fp32 rounding, not the same bits.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int DH>
+__global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(
+    const bf16_t* __restrict__ qq, int64_t q_rs, int64_t q_bs, const bf16_t* __restrict__ dd, int64_t d_rs, int64_t d_bs,
+    const bf16_t* __restrict__ kk, int64_t k_rs, int64_t k_bs, const bf16_t* __restrict__ vv, int64_t v_rs, int64_t v_bs,
+    const float* __restrict__ lse2, const float* __restrict__ delta, int64_t stat_ld, bf16_t* __restrict__ dq, int64_t dq_rs, int64_t dq_bs,
+    int heads, int Lq, int Lkv, int nOwn, float c, float scale) {
+    constexpr int RB = 2 * DH, NCH = DH / 8, TILE = KVB * RB, QS = DH / 16, NDB = DH / 32;
+    constexpr int BUFSZ = 2 * TILE;                    // [3][K tile | V tile]
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pair = wave & 3, half = wave >> 2;
+    const int r = lane & 31, h = lane >> 5;
+    const int ot = blockIdx.x % nOwn, bh = blockIdx.x / nOwn;
+    const int head = bh % heads, b = bh / heads;
+    const bf16_t* Qb = qq + (int64_t)b * q_bs + head * DH;
+    const bf16_t* Db = dd + (int64_t)b * d_bs + head * DH;
+    const bf16_t* Kb = kk + (int64_t)b * k_bs + head * DH;
+    const bf16_t* Vb = vv + (int64_t)b * v_bs + head * DH;
+    const int own_row = ot * 128 + pair * 32 + r;
+    const int own_ld = own_row < Lq ? own_row : Lq - 1;
+    bf16x8 fq[QS], fo[QS];
+#pragma unroll
+    for (int s = 0; s < QS; ++s) {
+        fq[s] = *(const bf16x8*)(Qb + (int64_t)own_ld * q_rs + 16 * s + 8 * h);
+        fo[s] = *(const bf16x8*)(Db + (int64_t)own_ld * d_rs + 16 * s + 8 * h);
+    }
+    const float my_lse = lse2[(int64_t)bh * stat_ld + own_ld], my_delta = delta[(int64_t)bh * stat_ld + own_ld];
+    constexpr int RPI = 1024 / RB, NI = TILE / 1024, NIW = NI / 8;
+    unsigned d1o[NIW], d2o[NIW];
+#pragma unroll
+    for (int u = 0; u < NIW; ++u) {
+        const int row = (wave * NIW + u) * RPI + lane / NCH;
+        const int ch = (lane % NCH) ^ row_swz<DH>(row);
+        d1o[u] = (unsigned)(row * (int)k_rs + ch * 8) * 2u;
+        d2o[u] = (unsigned)(row * (int)v_rs + ch * 8) * 2u;
+    }
+    auto dma_stream = [&](const bf16_t* base, int64_t rs, const unsigned (&off)[NIW], int row0, unsigned dst) __attribute__((always_inline)) {
+        if (row0 + KVB <= Lkv) {
+            const void* tb = uniform_ptr(base + (int64_t)row0 * rs);
+#pragma unroll
+            for (int u = 0; u < NIW; ++u) glds16_off(tb, off[u], dst + u * 1024);
+        } else {                                       // ragged last tile: rows past the end re-read the last key (masked below)
+            int lane_r = lane;
+            asm volatile("" : "+v"(lane_r));
+#pragma unroll
+            for (int u = 0; u < NIW; ++u) {
+                const int row = (wave * NIW + u) * RPI + lane_r / NCH;
+                const int ch = (lane_r % NCH) ^ row_swz<DH>(row);
+                int sr = row0 + row; if (sr > Lkv - 1) sr = Lkv - 1;
+                glds16_ptr(base + (int64_t)sr * rs + ch * 8, dst + u * 1024);
+            }
+        }
+    };
+    auto stage_load = [&](int row0, int stg) __attribute__((always_inline)) {
+        const unsigned l0 = __builtin_amdgcn_readfirstlane(lds_addr(smem)) + stg * BUFSZ + wave * NIW * 1024;
+        dma_stream(Kb, k_rs, d1o, row0, l0);
+        dma_stream(Vb, v_rs, d2o, row0, l0 + TILE);
+    };
+    const int k_base = RB * r + 16 * (h ^ row_swz<DH>(r));
+    const int i16 = lane & 15, g16 = lane >> 4;
+    const int t_key = 4 * h + (i16 >> 2), t_lowch = 2 * (g16 & 1) + ((i16 & 3) >> 1), t_b8 = 8 * (i16 & 1);
+    const int tlo_base = RB * t_key + 16 * (t_lowch ^ row_swz<DH>(t_key)) + t_b8;
+    const int thi_base = RB * (t_key + 8) + 16 * (t_lowch ^ row_swz<DH>(t_key + 8)) + t_b8;
+    f32x16 acc[NDB];                                   // partial dQ^T [d][own query] over this wave's key blocks
+#pragma unroll
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[db][i] = 0.f;
+    const int ntiles = (Lkv + KVB - 1) / KVB;
+    stage_load(0, 0);
+    if (ntiles > 1) stage_load(KVB, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int stg = 0;
+    for (int t = 0; t < ntiles; ++t) {
+        const unsigned char* B1 = smem + stg * BUFSZ;
+        const unsigned char* B2 = B1 + TILE;
+        if (t + 2 < ntiles) stage_load((t + 2) * KVB, stg == 0 ? 2 : stg - 1);      // the stage of tile t - 1: every wave left it before the barrier behind us
+        f32x16 x1, x2;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { x1[i] = 0.f; x2[i] = 0.f; }
+        {
+            int kb0 = k_base;
+            asm volatile("" : "+v"(kb0));
+            constexpr int PDS = 3;
+            bf16x8 ab[PDS + 1][2];
+            auto rd = [&](int s5) __attribute__((always_inline)) {
+                ab[s5 % (PDS + 1)][0] = *(const bf16x8*)(B1 + half * 32 * RB + (kb0 ^ (32 * s5)));
+                ab[s5 % (PDS + 1)][1] = *(const bf16x8*)(B2 + half * 32 * RB + (kb0 ^ (32 * s5)));
+            };
+#pragma unroll
+            for (int j = 0; j < PDS && j < QS; ++j) rd(j);
+#pragma unroll
+            for (int s5 = 0; s5 < QS; ++s5) {
+                if (s5 + PDS < QS) rd(s5 + PDS);
+                __builtin_amdgcn_sched_barrier(0);
+                x1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab[s5 % (PDS + 1)][0], fq[s5], x1, 0, 0, 0);
+                x2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab[s5 % (PDS + 1)][1], fo[s5], x2, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // the transposed K fragments of this wave's two k-steps (keys 32 half + 16 ks ..): requested now, used after the softmax arithmetic
+        bf16x8 tf[2][NDB];
+        {
+            int lo0 = tlo_base, hi0 = thi_base;
+            asm volatile("" : "+v"(lo0), "+v"(hi0));
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int db = 0; db < NDB; ++db)
+                    tf[ks][db] = tr_read_pair(B1 + (2 * half + ks) * 16 * RB + (lo0 ^ (64 * db)), B1 + (2 * half + ks) * 16 * RB + (hi0 ^ (64 * db)));
+        }
+        float z[16];
+        if (t * KVB + KVB <= Lkv) {                    // keys past the end exist only in the ragged last tile
+#pragma unroll
+            for (int i = 0; i < 16; ++i) z[i] = __builtin_amdgcn_exp2f(fmaf(x1[i], c, -my_lse)) * (x2[i] - my_delta);
+        } else {
+            const int srow0 = t * KVB + half * 32 + 4 * h;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float v = __builtin_amdgcn_exp2f(fmaf(x1[i], c, -my_lse)) * (x2[i] - my_delta);
+                z[i] = srow0 + (i & 3) + 8 * (i >> 2) < Lkv ? v : 0.f;
+            }
+        }
+        bf16x8 zf[2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            u32x4 w;
+            w.x = pack2bf(z[8 * s2 + 0], z[8 * s2 + 1]); w.y = pack2bf(z[8 * s2 + 2], z[8 * s2 + 3]);
+            w.z = pack2bf(z[8 * s2 + 4], z[8 * s2 + 5]); w.w = pack2bf(z[8 * s2 + 6], z[8 * s2 + 7]);
+            zf[s2] = __builtin_bit_cast(bf16x8, w);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int db = 0; db < NDB; ++db) acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf[ks][db], zf[ks], acc[db], 0, 0, 0);
+        // this wave's share of tile t + 1 (requested two tiles ago) has landed; the requests of tile t + 2, issued above, stay in flight
+        if (t + 2 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NIW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        stg = stg == 2 ? 0 : stg + 1;
+    }
+    // the pair's two partial sums: half 1 parks its accumulators in LDS (lane-linear, NDB x 4 KiB per wave; the stream stages are free now), half 0 adds them
+    float* park = (float*)smem + pair * (NDB * 4 * 256) + lane * 4;     // 4 x NDB x 4 KiB <= the three stream stages at either head width
+    if (half == 1) {
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4)
+                *(f32x4*)(park + (db * 4 + g4) * 256) = (f32x4){acc[db][4 * g4 + 0], acc[db][4 * g4 + 1], acc[db][4 * g4 + 2], acc[db][4 * g4 + 3]};
+    }
+    __syncthreads();
+    if (half == 0 && own_row < Lq) {
+        bf16_t* Orow = dq + (int64_t)b * dq_bs + (int64_t)own_row * dq_rs + head * DH;
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const f32x4 o = *(const f32x4*)(park + (db * 4 + g4) * 256);
+                u32x2 w;
+                w.x = pack2bf((acc[db][4 * g4 + 0] + o[0]) * scale, (acc[db][4 * g4 + 1] + o[1]) * scale);
+                w.y = pack2bf((acc[db][4 * g4 + 2] + o[2]) * scale, (acc[db][4 * g4 + 3] + o[3]) * scale);
+                *(u32x2*)(Orow + 32 * db + 8 * g4 + 4 * h) = w;
+            }
+    }
+}
+
 // delta[bh][q] = sum_d dO[b][q][h*DH + d] * O[b][q][h*DH + d]: DH / 8 lanes per (b, q, h), 16-byte loads, the sum over those lanes by xor shuffles
 template <int DH>
 __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ o, int64_t o_rs, int64_t o_bs, const bf16_t* __restrict__ dout, int64_t d_rs,
@@ -1685,6 +1862,13 @@ extern "C" int ug_flash_attn_bwd(const void* q, int64_t q_rs, int64_t q_bs, cons
     const int nK2 = (int)((Lkv + 127) / 128);
     const int64_t gk2 = (int64_t)nK2 * heads * batches;
     const bool fuse_dkv = bwd_dma && gk2 < (1ll << 31) && ug_env_int("UG_ATTN_BWD_FUSE_DKV", 1);
+    // dQ on 128-query workgroups (attn_bwd_dq_kernel); UG_ATTN_BWD_PAIR_DQ=0: the 256-query DQ mode
+    const int nQ2 = (int)((Lq + 127) / 128);
+    const int64_t gq2 = (int64_t)nQ2 * heads * batches;
+    // Measured (tools/attn_bwd_ab.py, profiles/r03y_attn_bwd_pair_dq.log): dh 128 at 4608^2 / 8704^2 +2.6 % / +2.5 % of the whole backward; dh 128 at
+    // 1000^2 -7 %, dh 64 -3 % (half the MFMAs per wave and barrier) -> on by default only for head width 128 and >= 2048 queries (2 forces it everywhere)
+    const int pdq = ug_env_int("UG_ATTN_BWD_PAIR_DQ", 1);
+    const bool pair_dq = bwd_dma && gq2 < (1ll << 31) && (pdq == 2 || (pdq == 1 && dh == 128 && Lq >= 2048));
     (void)hipMemsetAsync(workspace, 0, (size_t)(2 * batches * heads * stat_ld) * sizeof(float), s);     // padded statistics rows read as 0
     const int64_t total = batches * Lq * heads;
     if (dh == 128)
@@ -1707,7 +1891,16 @@ extern "C" int ug_flash_attn_bwd(const void* q, int64_t q_rs, int64_t q_bs, cons
 #define UG_BWD_ALL(DHV)                                                                                                                              \
     do {                                                                                                                                              \
         if (!lse_in) UG_BWD(DHV, BWD_LSE, gq, q, q_rs, q_bs, nullptr, 0, 0, k, k_rs, k_bs, nullptr, 0, 0, nullptr, 0, 0, Lq, Lkv, nQ);             \
-        UG_BWD(DHV, BWD_DQ, gq, q, q_rs, q_bs, dout, do_rs, do_bs, k, k_rs, k_bs, v, v_rs, v_bs, dq, dq_rs, dq_bs, Lq, Lkv, nQ);                   \
+        if (pair_dq) {                                                                                                                             \
+            constexpr int ldsq_ = 3 * (2 * KVB * 2 * DHV);                                                                                          \
+            static bool attrq_ = false;                                                                                                             \
+            if (!attrq_) { (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<DHV>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsq_); attrq_ = true; } \
+            hipLaunchKernelGGL((attn_bwd_dq_kernel<DHV>), dim3((unsigned)gq2), dim3(512), ldsq_, s, (const bf16_t*)q, q_rs, q_bs, (const bf16_t*)dout, do_rs, do_bs, \
+                               (const bf16_t*)k, k_rs, k_bs, (const bf16_t*)v, v_rs, v_bs, lse2, delta, stat_ld, (bf16_t*)dq, dq_rs, dq_bs, (int)heads,    \
+                               (int)Lq, (int)Lkv, nQ2, c, softmax_scale);                                                                           \
+        } else {                                                                                                                                    \
+            UG_BWD(DHV, BWD_DQ, gq, q, q_rs, q_bs, dout, do_rs, do_bs, k, k_rs, k_bs, v, v_rs, v_bs, dq, dq_rs, dq_bs, Lq, Lkv, nQ);               \
+        }                                                                                                                                           \
         if (fuse_dkv) {                                                                                                                            \
             constexpr int lds_ = 3 * (2 * KVB * 2 * DHV + 512) + 2 * 8 * 2048;                                                                          \
             static bool attr_ = false;                                                                                                              \
