@@ -1330,6 +1330,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kernel(
 // ahead +2 %; the per-element row masks out of the whole-tile path (32 v_cndmask per tile: the score phase is VALU-bound) +13.6 %; this form +17.6 %.
 // Tried and dropped: the dV waves scoring tile t + 1 BEFORE accumulating tile t while the dK waves do the opposite (the two waves of a SIMD then
 // alternate VALU-heavy and MFMA-only phases): 37 spilled registers at dh 128 (421 TFLOP/s), and 522 vs 578 at dh 64 without a single spill.
+// Also dropped: scalar branches instead of the wave-uniform `half ? a : b` selects of the operands (24 v_cndmask per tile): the duplicated
+// accumulation block costs 46 spilled registers at dh 128 (476 TFLOP/s).
 // ---------------------------------------------------------------------------------------------------------------------
 template <int DH>
 __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(
