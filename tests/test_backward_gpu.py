@@ -310,6 +310,15 @@ def test_backward_kernels_run_to_run_bitwise(gpu):
     first, second = once(), once()
     for i, (a, b) in enumerate(zip(first, second)):
         assert torch.equal(a, b), f"output {i} differs between two identical calls"
+    # the round-3 kernels at a length where both are the default (dh 128, >= 2048 queries: pair-scheme dQ + fused dK / dV; partial sums meet in LDS, no atomics)
+    L2 = 2304
+    q2, k2, v2, do2 = (torch.randn(1, L2, D, generator=g).to(BF).to(gpu) for _ in range(4))
+    o2 = torch.empty_like(q2)
+    lse2 = torch.zeros(1, H, L2, device=gpu, dtype=torch.float32)
+    ops.flash_attn(q2, k2, v2, o2, batches=1, heads=H, dh=dh, Lq=L2, Lkv=L2, lse=lse2, q_strides=(D, L2 * D), k_strides=(D, L2 * D), v_strides=(D, L2 * D), o_strides=(D, L2 * D))
+    a3, b3 = ops.flash_attn_bwd(q2, k2, v2, o2, do2, heads=H, lse=lse2), ops.flash_attn_bwd(q2, k2, v2, o2, do2, heads=H, lse=lse2)
+    for x, y, nm in zip(a3, b3, ("dq", "dk", "dv")):
+        assert torch.equal(x, y) and bool(torch.isfinite(x.float()).all()), nm
 
 
 def test_gate_residual_backward(gpu):
