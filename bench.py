@@ -332,12 +332,14 @@ def _dry_run(args, world, rank):
     t0 = time.perf_counter()
     for _ in range(args.steps):
         time.sleep(0.01 * (1 + rank))
+    own = time.perf_counter() - t0                 # this rank's own loop, before the closing barrier: what the per-rank record carries
     DU.barrier(dev, world)
     elapsed = DU.max_over_ranks(time.perf_counter() - t0, dev, world)
+    per_rank = [dict(rank=i, images=int(r[0]), seconds=r[1], device_index=int(r[2])) for i, r in enumerate(DU.all_gather_floats([args.steps, own, rank], dev, world))]
     if rank == 0:
         print(json.dumps(dict(metric="DRY RUN (no GPU work): harness rehearsal only", dry_run=True, value=None, unit="images/s", n_gpus=world,
                               steps=args.steps, warmup=args.warmup, ms_per_step=1000.0 * elapsed / args.steps, higher_is_better=True, scaling="weak",
-                              vs_baseline=None, data="none", config=dict(workload="none"))), flush=True)
+                              vs_baseline=None, data="none", config=dict(workload="none"), per_rank=per_rank)), flush=True)
     if world > 1:
         import torch.distributed as dist
         dist.barrier()
@@ -353,12 +355,15 @@ def _timed(one_step, steps, warmup, dev, world, timer, ops):
     t0 = time.perf_counter()
     for _ in range(steps):
         out = one_step()
+    if dev.type == "cuda":
+        torch.cuda.synchronize(dev)
+    own = time.perf_counter() - t0                 # this rank's own K steps; the job's time is the MAX over ranks of the barrier-bracketed region
     DU.barrier(dev, world)
     elapsed = time.perf_counter() - t0
     ops.set_timer(None)
     if not torch.isfinite(out.float()).all():
         raise SystemExit("non-finite latents after denoising")
-    return DU.max_over_ranks(elapsed, dev, world), out
+    return DU.max_over_ranks(elapsed, dev, world), out, own
 
 
 def main():
@@ -396,7 +401,11 @@ def main():
         print(f"[bench] world = {world}; torch.cuda.device_count() = {ndev}", file=sys.stderr, flush=True)
     if ndev < world and os.environ.get("UG_DIST_BACKEND", "") != "gloo":
         raise SystemExit(f"bench.py --gpus {world}: this node shows only {ndev} GPU(s); nothing was measured")
-    local_rank = local_rank % max(ndev, 1)                               # rehearsal (UG_DIST_BACKEND=gloo): more ranks than GPUs share devices
+    if os.environ.get("UG_DIST_BACKEND", "") == "gloo":
+        local_rank = local_rank % max(ndev, 1)                           # rehearsal only: more ranks than GPUs share devices
+    if not (0 <= local_rank < ndev):
+        raise SystemExit(f"bench.py: LOCAL_RANK {local_rank} has no device (torch.cuda.device_count() = {ndev})")
+    print(f"[bench] rank {rank} of {world} -> cuda:{local_rank} ({torch.cuda.get_device_name(local_rank)})", file=sys.stderr, flush=True)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     from unigen_amd import dist_utils as DU
@@ -427,7 +436,14 @@ def main():
             graph.replay()
             return graph_out
     timer = None if (args.no_kernel_timer or args.graph) else ops.KernelTimer()
-    elapsed, out = _timed(one_step, args.steps, args.warmup, dev, world, timer, ops)
+    elapsed, out, own_elapsed = _timed(one_step, args.steps, args.warmup, dev, world, timer, ops)
+    # one all_gather of every rank's own record, so that a straggler (or a rank on the wrong device) shows in the one JSON line.
+    # The measured MFMA-only rate of each rank's chip rides along: boxes differ by 8-12 % (DVFS), and cross-box comparisons need it.
+    pk16 = ops.probe_mfma_peak(dev, shape=1)
+    pk32 = ops.probe_mfma_peak(dev, shape=0)
+    per_rank = [dict(rank=i, images=int(r[0]), seconds=r[1], images_per_s=r[0] / r[1], device_index=int(r[2]), mfma_probe_16x16x32_tflops=r[3],
+                     mfma_probe_32x32x16_tflops=r[4])
+                for i, r in enumerate(DU.all_gather_floats([B * args.steps, own_elapsed, local_rank, pk16, pk32], dev, world))]
 
     scaling_base = None
     if world == 1 and config == "cfg2" and B == 4 and not args.no_scaling_base and not args.small and not args.graph:
@@ -435,7 +451,7 @@ def main():
         # measured after the timed region, same model
         del one_step
         _, step8, _ = _flux_workload_inputs_only(model, 8, rank, dev)
-        e8, _ = _timed(step8, 2, 1, dev, 1, None, ops)
+        e8, _, _ = _timed(step8, 2, 1, dev, 1, None, ops)
         scaling_base = dict(workload="cfg4's per-GPU shape on one GPU: B=8, same model", per_gpu_batch=8, steps=2, warmup=1, value=8 * 2 / e8, unit="images/s",
                             ms_per_step=1000.0 * e8 / 2, note="divide the N > 1 lines (B = 8 per GPU) by N x THIS value for a like-for-like efficiency")
 
@@ -453,7 +469,7 @@ def main():
                     dtype="bf16", data="synthetic",
                     config=dict(workload=names[config] + info["geom"], baseline_config=config, per_gpu_batch=B, global_batch=B * world,
                                 parallelism=f"dp{world} (independent samples, RCCL barrier only)", step=info["step"]),
-                    hip_graph=bool(args.graph), device_count=ndev)
+                    hip_graph=bool(args.graph), device_count=ndev, per_rank=per_rank)
         s = timer.summary() if timer is not None else {}
         fl_img = info["flops_per_image"]
         if fl_img is None and s:
@@ -464,32 +480,35 @@ def main():
             if config in ("cfg2", "cfg4"):
                 line["flops_per_image_canonical"] = fl_img
             line["e2e_mfma_frac"] = value / world * fl_img / (MFMA_BF16_PEAK_TFLOPS * 1e12)
+            # the same against the bare-MFMA rate this chip held in THIS run (16x16x32 probe, rank 0's device): the number to compare across boxes
+            line["e2e_frac_of_measured"] = value / world * fl_img / (pk16 * 1e12)
+            line["mfma_probe_tflops"] = dict(shape_16x16x32=pk16, shape_32x32x16=pk32, note="ug_probe_mfma_bf16, same run, rank 0's device")
         if scaling_base is not None:
             line["scaling_base"] = scaling_base
         if s:
             gm, at = s.get("gemm"), s.get("attn")
             ach = gm["flops"] / (gm["ms"] * 1e-3) / 1e12
-            traffic, traffic_note, pmc = None, None, {}
+            traffic, traffic_note, traffic_src, pmc = None, None, None, {}
             cands = sorted(p for p in os.listdir(os.path.join(ROOT, "profiles")) if p.endswith("_pmc.json"))      # newest round's PMC summary
             tf = os.path.join(ROOT, "profiles", cands[-1] if cands else "r01_hbm_traffic.json")
             if os.path.exists(tf) and not args.small and config == "cfg2" and B == 4:      # PMC passes of this same command (see the file's `source`, tools/pmc_summary.py)
                 with open(tf) as f:
                     tj = json.load(f)
                 traffic = tj["kernels"]["gemm_all"]["hbm_bytes_per_launch"]
-                traffic_note = (f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, profiles/{os.path.basename(tf)}): (2*FETCH_SIZE + WRITE_SIZE)*1024 per "
+                traffic_src = dict(measured_in_this_run=False, file=f"profiles/{os.path.basename(tf)}",
+                                   file_mtime_utc=time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime(os.path.getmtime(tf))), collected=tj.get("source"))
+                traffic_note = (f"NOT measured in this run - counters need their own rocprofv3 passes - read from an earlier profile of the same command on another box: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, profiles/{os.path.basename(tf)}): (2*FETCH_SIZE + WRITE_SIZE)*1024 per "
                                 "launch; the L2-fabric counters include Infinity-Cache hits, so this is traffic beyond the XCD L2, an upper bound on HBM bytes")
                 g256 = tj["kernels"].get("gemm256", {})
                 if "mfma_busy_frac" in g256:
-                    pmc = dict(mfma_busy=g256["mfma_busy_frac"], effective_clock_ghz=g256["effective_clock_ghz"],
+                    pmc = dict(measured_in_this_run=False, file=f"profiles/{os.path.basename(tf)}", mfma_busy=g256["mfma_busy_frac"], effective_clock_ghz=g256["effective_clock_ghz"],
                                hbm_side_gbps=g256["hbm_bytes_per_launch"] / (g256["avg_launch_us_profiled"] * 1e-6) / 1e9)
-            # second denominator: the measured MFMA-only rate of this chip, at the clock it holds under matrix load
-            pk16 = ops.probe_mfma_peak(dev, shape=1)
-            pk32 = ops.probe_mfma_peak(dev, shape=0)
+            # second denominator: the measured MFMA-only rate of this chip, at the clock it holds under matrix load (pk16 / pk32 above)
             line["roofline"] = dict(bound="mfma", kernel="gemm256_kernel / gemm128_kernel (ug_gemm_bf16)", achieved=ach, peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s",
                                     frac=ach / MFMA_BF16_PEAK_TFLOPS, peak_measured=pk16, frac_of_measured=ach / pk16,
                                     peak_measured_note=("ug_probe_mfma_bf16: bare v_mfma_f32_16x16x32_bf16 loop (the GEMM's shape), register operands with random values, "
                                                         f"one wave per SIMD on every CU, HIP events; the 32x32x16 shape (attention) measures {pk32:.0f}"),
-                                    traffic=traffic, traffic_note=traffic_note, pmc_gemm256=pmc or None, launches=gm["launches"],
+                                    traffic=traffic, traffic_note=traffic_note, traffic_source=traffic_src, pmc_gemm256=pmc or None, launches=gm["launches"],
                                     avg_launch_us=1000.0 * gm["ms"] / gm["launches"], avg_launch_gflop=gm["flops"] / gm["launches"] / 1e9,
                                     share_of_step_time=gm["ms"] * 1e-3 / elapsed)
             if at:

@@ -301,6 +301,27 @@ def modulated_linear(x: torch.Tensor, w: torch.Tensor, s: torch.Tensor) -> torch
     return F.linear(s * x, w)
 
 
+def expert_forward(state: State, xd: torch.Tensor, cd: torch.Tensor, pd: torch.Tensor, cpd: torch.Tensor, literal: bool = False,
+                   prefix: str = "moe.moe_layer.experts.deepspeed_experts."):
+    """UniGenFlux.expert_forward (src/UniGenTransformer.py:925-967; UniGenBase.expert_forward :225-267 is the same text), modulated experts:
+    per expert e on its dispatched slots  c' = mf(c, W_c, Lin_c(cond_pooled)) + b_c ;  h' = mf(h + c', W_h, Lin_h(pooled)) + b_h.
+    xd, cd [E, C, D]; pd, cpd [E, C, P] -> (h' [E, C, D], c' [E, C, D]). REFERENCE-PINNED: tests/test_ref_leaf_cpu.py holds it to the
+    outputs of the reference's own function (tests/golden/ref_leaf.safetensors)."""
+    dt = xd.dtype
+    mf = modulated_flatten_literal if literal else modulated_linear
+    yh, yc = [], []
+    for e in range(xd.shape[0]):
+        p = f"{prefix}{e}"
+        wc, bc = state[p + ".0.0.weight"].to(dt), state[p + ".0.0.bias"].to(dt)
+        wh, bh = state[p + ".1.0.weight"].to(dt), state[p + ".1.0.bias"].to(dt)
+        s_c = linear(state, p + ".0.1", cpd[e][None])
+        s_h = linear(state, p + ".1.1", pd[e][None])
+        c_e = mf(cd[e][None], wc, s_c) + bc.unsqueeze(0)
+        h_e = mf(xd[e][None] + c_e, wh, s_h) + bh.unsqueeze(0)
+        yh.append(h_e[0]); yc.append(c_e[0])
+    return torch.stack(yh), torch.stack(yc)
+
+
 def comoe_experts(state: State, cfg: FluxConfig, x, c, pooled, cond_pooled, gates_in: Optional[torch.Tensor],
                   uniform: torch.Tensor, literal: bool = False):
     """MOELayer.forward + UniGenFlux.expert_forward with modulated experts. x, c: [B, N, D]. Returns
@@ -333,18 +354,7 @@ def comoe_experts(state: State, cfg: FluxConfig, x, c, pooled, cond_pooled, gate
         xd, cd = dispatch(x.reshape(S, D)), dispatch(c.reshape(S, D))
         pd = dispatch(pooled.unsqueeze(1).expand(-1, N, -1).reshape(S, -1))
         cpd = dispatch(cond_pooled.unsqueeze(1).expand(-1, N, -1).reshape(S, -1))
-    mf = modulated_flatten_literal if literal else modulated_linear
-    yh, yc = [], []
-    for e in range(E):
-        p = f"moe.moe_layer.experts.deepspeed_experts.{e}"
-        wc, bc = state[p + ".0.0.weight"].to(dt), state[p + ".0.0.bias"].to(dt)
-        wh, bh = state[p + ".1.0.weight"].to(dt), state[p + ".1.0.bias"].to(dt)
-        s_c = linear(state, p + ".0.1", cpd[e][None])
-        s_h = linear(state, p + ".1.1", pd[e][None])
-        c_e = mf(cd[e][None], wc, s_c) + bc.unsqueeze(0)
-        h_e = mf(xd[e][None] + c_e, wh, s_h) + bh.unsqueeze(0)
-        yh.append(h_e[0]); yc.append(c_e[0])
-    yh, yc = torch.stack(yh), torch.stack(yc)               # [E, C, D]
+    yh, yc = expert_forward(state, xd, cd, pd, cpd, literal=literal)    # [E, C, D]
     cw = combine_weights.to(dt)
     eh = torch.einsum("sec,ecm->sm", cw, yh).reshape(B, N, D)
     ec = torch.einsum("sec,ecm->sm", cw, yc).reshape(B, N, D)

@@ -42,6 +42,95 @@ def test_gemm_full_size_sampled_rows(gpu, M, N, K, epi):
     assert m["rel_l2"] <= 1e-3, m
 
 
+def test_gemm_full_size_single_block_fused_qkv_mlp_launch(gpu):
+    """The DOMINANT launch of the cfg2 step at its real size (32.9 % of the GPU time, profiles/r03_bench_kernel_stats.csv): a single block's
+    to_q | to_k | to_v | proj_mlp projection, 18432 x 21504 x 3072, with q / k RMSNorm + RoPE in the epilogue (`gemm256_kernel<UG_EPI_QKV_ROPE>`,
+    Attention.norm_q / norm_k + apply_rotary_emb, src/UniGenUtils.py:561-599), GELU-tanh from column 3D on and the column shift that leaves the
+    attention slot free - launched exactly as flux._single_block does. Sampled rows (tile edges, sample boundaries, interior) against the fp32
+    formula with the reference's rounding points: v / mlp <= 1e-3, q / k <= 3e-3 (the bound of the kernel-level test at D = 512)."""
+    from unigen_amd import lib as L, ops
+    D, dh, B, Lj = 3072, 128, 4, 4608
+    H, M, K = D // dh, B * Lj, D
+    g = torch.Generator(device=gpu).manual_seed(77)
+    a, w, b = _randn(gpu, g, M, K), _randn(gpu, g, 7 * D, K, scale=K ** -0.5), _randn(gpu, g, 7 * D, scale=0.1)
+    wq, wk = (1 + 0.2 * torch.randn(dh, generator=g, device=gpu)).to(BF), (1 + 0.2 * torch.randn(dh, generator=g, device=gpu)).to(BF)
+    ang = torch.rand(Lj, dh // 2, generator=g, device=gpu) * 6.28
+    cs = torch.stack([ang.cos(), ang.sin()], -1).contiguous()                     # [positions, 64, 2] fp32 pair table
+    assert ops.qk_rope_fusable(M, 7 * D, 2 * D, dh, BF)
+    sb = torch.zeros(M, 8 * D, device=gpu, dtype=BF)
+    run = lambda o: ops.gemm(a, w, b, o, M=M, ldc=8 * D, epilogue=L.EPI_BIAS_GELU, gelu_from_n=3 * D, c_shift_from_n=3 * D, c_shift=D,
+                             qk_rope=ops.QkRope(wq, wk, cs, Lj, 0, 2 * D, dh=dh))
+    run(sb)
+    sb2 = torch.zeros_like(sb); run(sb2)
+    assert torch.equal(sb, sb2), "not bitwise repeatable"
+    assert not sb[:, 3 * D:4 * D].any(), "the attention slot must stay untouched"
+    rows = torch.tensor([0, 1, 255, 256, 4607, 4608, 4609, 9215, 9216, 12345, M - 257, M - 1])
+    acc = a[rows].cpu().float() @ w.cpu().float().t()
+    v = (acc + b.cpu().float()).to(BF)                                            # Linear output, rounded (the reference's rounding point)
+    got = sb[rows].cpu()
+    pos = rows % Lj
+    cosr, sinr = ang.cpu()[pos].cos().repeat_interleave(2, 1), ang.cpu()[pos].sin().repeat_interleave(2, 1)
+    for name, c0, wn in (("q", 0, wq), ("k", D, wk)):
+        x = v[:, c0:c0 + D].float().view(len(rows), H, dh)
+        rs = torch.rsqrt((x * x).mean(-1, keepdim=True) + 1e-6)
+        x = ((x * rs).to(BF).float() * wn.cpu().float()).to(BF).float()
+        xr = torch.stack([-x[..., 1::2], x[..., 0::2]], -1).flatten(-2)
+        ref = (x * cosr[:, None] + xr * sinr[:, None]).reshape(len(rows), D)
+        m = report(f"full_gemm_qkvrope_{name}_{M}x{7 * D}x{K}", got[:, c0:c0 + D], ref)
+        assert m["rel_l2"] <= 3e-3, m
+    m = report(f"full_gemm_qkvrope_v_{M}x{7 * D}x{K}", got[:, 2 * D:3 * D], v[:, 2 * D:3 * D])
+    assert m["rel_l2"] <= 1e-3, m
+    m = report(f"full_gemm_qkvrope_mlp_{M}x{7 * D}x{K}", got[:, 4 * D:], F.gelu(v[:, 3 * D:], approximate="tanh"))
+    assert m["rel_l2"] <= 1e-3, m
+
+
+def test_gemm_full_size_zero_res_projection_in_place(gpu):
+    """`hidden = hidden + controlnet_add_*(z) * conditioning_scale` (src/UniGenTransformer.py:1104, 1141, 1166-1167) at its real size, launched as
+    flux does: 18432 x 3072 x 3072 with the `R + alpha * v` epilogue (`gemm256_kernel<UG_EPI_RES_SCALE>`) and the residual ALIASED to the output."""
+    from unigen_amd import lib as L, ops
+    M, N, K, alpha = 18432, 3072, 3072, 0.75
+    g = torch.Generator(device=gpu).manual_seed(78)
+    a, w, b = _randn(gpu, g, M, K), _randn(gpu, g, N, K, scale=K ** -0.5), _randn(gpu, g, N, scale=0.1)
+    h0 = _randn(gpu, g, M, N)
+    h = h0.clone()
+    ops.gemm(a, w, b, h, M=M, epilogue=L.EPI_RES_SCALE, residual=h, alpha=alpha)
+    out = torch.empty_like(h0)
+    ops.gemm(a, w, b, out, M=M, epilogue=L.EPI_RES_SCALE, residual=h0, alpha=alpha)
+    assert torch.equal(h, out), "in-place (R aliased to C) differs from out-of-place"
+    rows = torch.tensor([0, 1, 255, 256, 4607, 4608, 9999, M - 257, M - 1])
+    v = (a[rows].cpu().float() @ w.cpu().float().t() + b.cpu().float()).to(BF)
+    ref = h0[rows].cpu() + v * alpha
+    m = report(f"full_gemm_res_scale_{M}x{N}x{K}", h[rows], ref)
+    assert m["rel_l2"] <= 1e-3, m
+
+
+@pytest.mark.parametrize("Lq,Lkv,qoff", [(4096, 4608, 512), (8192, 8704, 512)])
+def test_attention_full_size_rectangular(gpu, Lq, Lkv, qoff):
+    """The rectangular launches of the cfg2 step at their real sizes: a control joint block (queries = the 4096 sample rows of the joint sequence,
+    keys = all 4608 rows: text K/V only, src/UniGenTransformer.py:1097) and CoMoE's shared_expert[1] (8192 image + condition queries against
+    8704 keys incl. the control text, :1015-1020). Queries start `qoff` rows into the joint buffer, as the engine launches them."""
+    from unigen_amd import ops
+    B, H, dh = 4, 24, 128
+    D = H * dh
+    g = torch.Generator(device=gpu).manual_seed(Lq)
+    qkv = _randn(gpu, g, B, Lkv, 3 * D)
+    out = torch.empty(B, Lq, D, device=gpu, dtype=BF)
+    st = (3 * D, Lkv * 3 * D)
+    run = lambda o: ops.flash_attn(qkv[0, qoff:], qkv[0, 0, D:], qkv[0, 0, 2 * D:], o, batches=B, heads=H, dh=dh, Lq=Lq, Lkv=Lkv, q_strides=st, k_strides=st,
+                                   v_strides=st, o_strides=(D, Lq * D))
+    run(out)
+    out2 = torch.empty_like(out); run(out2)
+    assert torch.equal(out, out2), "not bitwise repeatable"
+    for (b, h) in ((0, 0), (3, 23), (2, 11)):
+        rows = torch.tensor([0, 31, 32, 255, 256, Lq // 2 + 1, Lq - 257, Lq - 1])
+        q = qkv[b, qoff + rows, h * dh:(h + 1) * dh].cpu().float()
+        k = qkv[b, :, D + h * dh:D + (h + 1) * dh].cpu().float()
+        v = qkv[b, :, 2 * D + h * dh:2 * D + (h + 1) * dh].cpu().float()
+        ref = torch.softmax(q @ k.t() * dh ** -0.5, dim=-1) @ v
+        m = report(f"full_attn_{Lq}x{Lkv}_b{b}h{h}", out[b, rows, h * dh:(h + 1) * dh], ref)
+        assert m["rel_l2"] <= 4e-3, m
+
+
 def test_attention_full_size_properties(gpu):
     from unigen_amd import ops
     B, H, L, dh = 4, 24, 4608, 128
@@ -220,6 +309,75 @@ def test_cfg4_b8_and_cfg2_b4_whole_forward_properties(gpu, monkeypatch):
     again4 = model(timestep=t[:B4], img_ids=ids, txt_ids=txt, condition_ids=ids, gate_uniform=uni4, **in4)[0]
     assert torch.equal(again4, out4), "B = 4 forward is not bitwise repeatable"
     report("cfg2_b4_forward", again4, out4)
+
+
+def test_cfg3_three_conditions_b8_whole_forward_properties(gpu):
+    """BASELINE cfg3 AT ITS STATED BATCH: MultiCondtionUniGenFlux depth + canny + openpose (E = 12 experts, per-condition CoMoE summed,
+    src/UniGenTransformer.py:1275-1357), 1024^2, B = 8 - S = 32768 tokens through the gate, capacity ceil(S / 12) = 2731 and the Random Token
+    Selection, per condition. No oracle evaluates this size (the full 3-condition model is oracle-checked at N = 1024, B = 1:
+    test_full_model_forward_parity[multi]); here: finite, every token counted for the last condition, bitwise repeatable, and the routing
+    tensors the engine leaves behind form a partial permutation within capacity."""
+    from unigen_amd.flux import MultiCondtionUniGenFlux
+    from unigen_amd.pipeline import prepare_latent_image_ids
+    model = MultiCondtionUniGenFlux.from_config({}, device=gpu, dtype=BF)
+    model.init_condition_block(condition_nums=3, condition_types=["depth", "canny", "openpose"], control_params=dict(
+        use_rope=True, use_shared_expert=True, use_consis_module=False, use_single_trans_blocks=True, single_control_dev=2,
+        single_block_control_method="overall_add", top_num=1, expert_num_each_condition=3))
+    model.init_synthetic_(seed=0, std=0.02)
+    B, grid, T, K = 8, 64, 512, 3
+    N, E = grid * grid, model._ctl.expert_nums
+    assert E == 12
+    g = torch.Generator(device=gpu).manual_seed(6)
+    rn = lambda *s: torch.randn(*s, generator=g, device=gpu)
+    ids = prepare_latent_image_ids(grid, grid, gpu, BF)
+    inp = dict(hidden_states=rn(B, N, 64).to(BF), condition_hidden_states=[rn(B, N, 64).to(BF) for _ in range(K)],
+               encoder_hidden_states=(0.1 * rn(B, T, 4096)).to(BF), pooled_projections=rn(B, 768).to(BF),
+               condition_pooled_projections=[rn(B, 768).to(BF) for _ in range(K)], condition_ids=[ids] * K)
+    txt = torch.zeros(T, 3, device=gpu, dtype=BF)
+    t = torch.full((B,), 0.5, device=gpu, dtype=BF)
+    unis = [torch.rand(B * N, E, generator=g, device=gpu) for _ in range(K)]
+    full = model(timestep=t, img_ids=ids, txt_ids=txt, gate_uniform=unis, **inp)
+    out, cnt = full[0].clone(), full[2]["expert_counts"].clone()
+    S, C = B * N, -(-B * N // E)
+    assert out.shape == (B, N, 64) and torch.isfinite(out.float()).all() and int(cnt.sum()) == S and torch.isfinite(full[1]["moe_loss"])
+    # the last condition's routing, as the engine left it in its workspaces: slots are a partial permutation within capacity, counts match
+    idx = model._w("moe_idx", (S,), torch.int32).cpu().long()
+    slot = model._w("moe_slot", (S,), torch.int32).cpu().long()
+    tos = model._w("moe_tos", (E, C), torch.int32).cpu().long()
+    assert torch.equal(torch.bincount(idx, minlength=E), cnt.cpu())
+    kept = slot >= 0
+    for e in range(E):
+        n_keep = int((kept & (idx == e)).sum())
+        assert n_keep == min(int(cnt[e]), C)
+        assert torch.equal(tos[e, :n_keep], torch.nonzero(kept & (idx == e)).flatten()) and torch.all(tos[e, n_keep:] == -1)
+    again = model(timestep=t, img_ids=ids, txt_ids=txt, gate_uniform=unis, **inp)[0]
+    assert torch.equal(again, out), "cfg3 B = 8 forward is not bitwise repeatable"
+    report("cfg3_b8_forward", again, out)
+
+
+def test_cfg5_sd3_b8_cfg_whole_forward_properties(gpu):
+    """BASELINE cfg5 AT ITS STATED BATCH: UniGenSD3 at SD3.5-medium size, 1024^2 (128 x 128 latents -> N = 4096, T = 333), B = 8 images = 16 samples
+    with classifier-free guidance (src/UniGenPipeline.py:286-290), the shipped yaml's transformer-block experts (self-attention over each expert's
+    C = ceil(65536 / 6) = 10923 capacity slots, src/UniGenTransformer.py:225-267). Finite, every token counted, bitwise repeatable (the full model is
+    oracle-checked at N = 1024: test_full_model_forward_parity[sd3])."""
+    from unigen_amd.sd3 import UniGenSD3
+    model = UniGenSD3.from_config({}, device=gpu, dtype=BF)
+    model.init_condition_block(condition_nums=1, condition_types=["depth"], control_params=dict(use_shared_expert=True))
+    model.init_synthetic_(seed=0, std=0.02)
+    B, T = 16, 333
+    E = model._ctl.expert_nums
+    g = torch.Generator(device=gpu).manual_seed(8)
+    rn = lambda *s: torch.randn(*s, generator=g, device=gpu)
+    inp = dict(hidden_states=rn(B, 16, 128, 128).to(BF), condition_hidden_states=rn(B, 16, 128, 128).to(BF), encoder_hidden_states=(0.1 * rn(B, T, 4096)).to(BF),
+               pooled_projections=rn(B, 2048).to(BF), condition_pooled_projections=rn(B, 2048).to(BF))
+    t = torch.full((B,), 500.0, device=gpu)
+    uni = torch.rand(B * 4096, E, generator=g, device=gpu)
+    full = model(timestep=t, gate_uniform=uni, **inp)
+    out, cnt = full[0].clone(), full[2]["expert_counts"].clone()
+    assert out.shape == (B, 16, 128, 128) and torch.isfinite(out.float()).all() and int(cnt.sum()) == B * 4096 and torch.isfinite(full[1]["moe_loss"])
+    again = model(timestep=t, gate_uniform=uni, **inp)[0]
+    assert torch.equal(again, out), "cfg5 B = 16 forward is not bitwise repeatable"
+    report("cfg5_b16_forward", again, out)
 
 
 def test_fused_qk_rope_forward_vs_fp32_verification(gpu, monkeypatch):

@@ -344,6 +344,8 @@ elapsed = 0.5 + rank            # pretend rank 1 is slower
 mx = DU.max_over_ranks(elapsed, dev, world)
 tot = DU.sum_over_ranks(b - a, dev, world)
 assert mx == 1.5 and tot == 10 and DU.rank_seed(12443, rank) == 12443 + rank, (mx, tot)
+rec = DU.all_gather_floats([b - a, elapsed, rank], dev, world)
+assert rec == [[5.0, 0.5, 0.0], [5.0, 1.5, 1.0]], rec
 DU.barrier(dev, world)
 if rank == 0:
     print("GLOO_OK", world, mx, tot)
@@ -602,6 +604,10 @@ def test_bench_launches_its_own_ranks():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["dry_run"] is True and d["value"] is None and d["steps"] == 2 and d["scaling"] == "weak"
     assert d["ms_per_step"] >= 19.0                       # MAX over ranks: rank 1 sleeps 20 ms per step, rank 0 only 10
+    # the all_gather of per-rank (images, seconds, device) makes the straggler visible in the one line
+    pr = d["per_rank"]
+    assert [x["rank"] for x in pr] == [0, 1] and all(x["images"] == 2 for x in pr)
+    assert pr[1]["seconds"] > 1.5 * pr[0]["seconds"] and pr[0]["seconds"] >= 0.019
     assert "torch.cuda.device_count() = 0" in r.stderr
 
 

@@ -22,8 +22,19 @@ void ug_set_error(const char* fmt, ...);
 #define UG_CHECK_LAUNCH(name) do { hipError_t e_ = hipGetLastError(); \
     if (e_ != hipSuccess) UG_FAIL(UG_ERR_HIP, "%s: launch failed: %s", name, hipGetErrorString(e_)); } while (0)
 
-// integer tuning switch from the environment: cached per call site name, re-read on every call when UG_ENV_DYNAMIC=1 (A/B tools)
+// integer switch from the environment: cached per call site name, re-read on every call when UG_ENV_DYNAMIC=1 (A/B tools). The PRODUCT library
+// uses it only where a switch selects between two SHIPPED kernels that the dispatcher otherwise picks by shape (tests pin each of them):
+// UG_GEMM_FORCE_TILE, UG_ADALN_FAST, UG_GN_FAST, UG_SOFTMAX_FAST, UG_CONV256 / UG_CONV256_MIN_TILES.
 int ug_env_int(const char* name, int dflt);
+// Tuning constants and measured-and-dropped kernel variants: compile-time constants in the product library (one kernel per dispatch decision);
+// `python -m unigen_amd.build --probe` builds tools/probe/libunigen_hip_probe.so with -DUG_PROBE_BUILD, where they are environment switches
+// again and the dropped variants (one-wave-per-SIMD GEMMs, cross-tile stream, lock-step / 4-wave / one-wave-per-SIMD attention, register-staged
+// backward, ...) are compiled in for A/B measurements (tools/probe/README.md).
+#ifdef UG_PROBE_BUILD
+#define UG_TUNE(name, dflt) ug_env_int(name, dflt)
+#else
+#define UG_TUNE(name, dflt) (dflt)
+#endif
 
 static inline bool ug_aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 

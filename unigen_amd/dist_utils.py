@@ -1,6 +1,7 @@
 """Batch-parallel multi-GPU plumbing: one process per GPU, independent samples per rank, no data-path collective.
 The reference shards its DataLoader by rank and has zero collectives in the denoise loop (infer.py:173); here the only
-collectives are the barriers around a timed region and one MAX all-reduce of the elapsed time (RCCL on GPUs, gloo in CPU tests)."""
+collectives are the barriers around a timed region, one MAX all-reduce of the elapsed time and one all_gather of the per-rank
+(images, seconds, device, probe) record for the report - RCCL on GPUs, gloo in CPU tests."""
 from __future__ import annotations
 
 import os
@@ -21,13 +22,16 @@ def rank_seed(base_seed: int, rank: int) -> int:
     return base_seed + rank
 
 
-def init_distributed(device: torch.device):
-    """Initialise torch.distributed from the torchrun environment. Returns (rank, world). Backend nccl (= RCCL) on GPUs, gloo on CPU."""
+def init_distributed(device: torch.device, force: bool = False):
+    """Initialise torch.distributed from the torchrun environment. Returns (rank, world). Backend nccl (= RCCL) on GPUs, gloo on CPU.
+    `force`: form the process group even at world size 1 (tests/test_dist_gpu.py proves RCCL initialisation on a one-GPU box that way)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    if world > 1:
+    if world > 1 or force:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", str(rank)); os.environ.setdefault("WORLD_SIZE", str(world))
         if not dist.is_initialized():
             backend = os.environ.get("UG_DIST_BACKEND", "nccl" if device.type == "cuda" else "gloo")   # nccl = RCCL over xGMI
             if backend == "nccl":
@@ -37,8 +41,15 @@ def init_distributed(device: torch.device):
     return rank, world
 
 
-def barrier(device: torch.device, world: int) -> None:
+def _group_up(world: int) -> bool:
     if world > 1:
+        return True
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized()          # a forced 1-rank group (init_distributed(force=True))
+
+
+def barrier(device: torch.device, world: int) -> None:
+    if _group_up(world):
         import torch.distributed as dist
         dist.barrier()
     if device.type == "cuda":
@@ -51,7 +62,7 @@ def _reduce_device(device: torch.device) -> torch.device:
 
 
 def max_over_ranks(value: float, device: torch.device, world: int) -> float:
-    if world == 1:
+    if not _group_up(world):
         return float(value)
     import torch.distributed as dist
     t = torch.tensor([value], device=_reduce_device(device), dtype=torch.float64)
@@ -60,9 +71,22 @@ def max_over_ranks(value: float, device: torch.device, world: int) -> float:
 
 
 def sum_over_ranks(value: float, device: torch.device, world: int) -> float:
-    if world == 1:
+    if not _group_up(world):
         return float(value)
     import torch.distributed as dist
     t = torch.tensor([value], device=_reduce_device(device), dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
+
+
+def all_gather_floats(values, device: torch.device, world: int):
+    """Every rank contributes the same number of floats; returns [world][len(values)] on every rank (the per-rank
+    (n_images, seconds, ...) record behind the one JSON line, so that a straggler rank is visible in it)."""
+    vals = [float(v) for v in values]
+    if not _group_up(world):
+        return [vals]
+    import torch.distributed as dist
+    t = torch.tensor(vals, device=_reduce_device(device), dtype=torch.float64)
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [o.cpu().tolist() for o in out]
