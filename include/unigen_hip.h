@@ -62,7 +62,7 @@ typedef struct ug_gemm_desc {
     const void* W; int64_t ldw;
     const void* bias;                 /* [N] bf16 or NULL */
     void* C; int64_t ldc; int64_t c_rpb; int64_t c_bstride;
-    const void* R; int64_t ldr; int64_t r_rpb; int64_t r_bstride; /* residual (may alias C) */
+    const void* R; int64_t ldr; int64_t r_rpb; int64_t r_bstride; /* residual; MAY ALIAS C (same base, ld and row map): every kernel path reads a residual element before the store that overwrites it (tests/test_kernels_gpu.py::test_gemm_residual_aliased_to_output_every_dispatch_path) */
     const void* gate; int64_t gate_ld; int64_t rows_per_sample;   /* gate[(m / rows_per_sample) * gate_ld + n] bf16 */
     float alpha;
     int32_t epilogue;
@@ -306,10 +306,6 @@ int ug_probe_mfma_bf16(int32_t shape, int64_t blocks, int64_t iters, void* scrat
  * forward). The matrix work of the backward is ug_gemm_bf16 again (dX = dY W through a transposed copy of W, dW = dY^T X through transposed copies
  * of dY and X, the attention backward as grouped GEMMs per sample); these entry points are what sits between those GEMMs. Each replaces the
  * autograd formula of the torch op named; each has an `_f32` twin like the forward entry points. ---- */
-/* C[I][J] = sum_r A[r][I] * B[r][J], bf16 in / out, fp32 accumulation: dW = dY^T X of a Linear layer (A = dY [rows][out_features],
- * B = X [rows][in_features]) straight from the row-major operands - both MFMA fragments come from transposing LDS reads, no transposed copies.
- * I, J, lda, ldb multiples of 8. (The fp32 verification path uses ug_transpose + ug_gemm_f32.) */
-int ug_gemm_tn_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t R, int64_t I, int64_t J, ug_stream_t stream);
 /* dst[b][c][r] = src[b][r][c] for r < rows, c < cols; dst[b][c][rows .. rows_pad) = 0. (Tensor.t().contiguous() of an operand) */
 int ug_transpose(const void* src, int64_t ld_src, int64_t src_bstride, void* dst, int64_t ld_dst, int64_t dst_bstride, int64_t batch, int64_t rows,
                  int64_t cols, int64_t rows_pad, ug_stream_t stream);

@@ -46,6 +46,8 @@ def step(fwd):
     out, losses, _ = fwd()
     loss = ((out.float() - target_like(out).to(out.device).float()) ** 2).reshape(out.shape[0], -1).mean(1).mean() + losses["moe_loss"]
     loss.backward()
+    from unigen_amd import autograd as A_
+    A_.clear_activation_cache()      # the last activation transposes (and the tensors they pin) must not outlive the step
     return float(loss)
 
 

@@ -540,6 +540,13 @@ def test_zero_unpickler_runs_no_payload(tmp_path, protocol):
     torch.save(dict(optimizer_state_dict=dict(partition_count=1)), str(d / "t" / "mp_rank_00_optim_states.pt"))
     with pytest.raises(ValueError, match="zero_stage"):
         merge_zero_checkpoint(str(d))
+    # a field the merge arithmetic needs that resolved to a stub (here partition_count stored as a numpy scalar: numpy's reconstructor is
+    # not allow-listed) fails with the blocked global's name, not with a later `int(_Stub)` TypeError
+    import numpy as np
+    torch.save(dict(optimizer_state_dict=dict(zero_stage=2, partition_count=np.int64(1), single_partition_of_fp32_groups=[torch.arange(6.0)])),
+               str(d / "t" / "mp_rank_00_optim_states.pt"))
+    with pytest.raises(ValueError, match=r"partition_count.*numpy"):
+        merge_zero_checkpoint(str(d))
 
 
 @pytest.mark.parametrize("cls", ["UniGenFlux", "UniGenSD3"])

@@ -12,7 +12,7 @@ import torch
 import torch.nn.functional as F
 
 from oracle import unigen_ref as R
-from tests.util import bf, report
+from tests.util import bf, rel_l2, report
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-3
@@ -418,28 +418,41 @@ def test_grouped_residual_gate_gather_rowbcast_plain_dispatch(gpu):
 
 
 def test_lora_linear_switch(gpu):
-    """LoRALinear forward = one fused GEMM (base + adapter K-segment); enable_lora switches adapters per condition."""
+    """LoRALinear forward = one fused GEMM (base + adapter K-segment); enable_lora switches adapters per condition (src/lora_switching_module.py:4-38,
+    PEFT 0.15 `y = base(x) + sum_a B_a(A_a(x)) * alpha_a / r_a`). Tolerance as everywhere: the fp32 verification twin <= 1e-3 against the fp32 formula
+    (measured ~1e-6); the bf16 product kernel <= 4e-3 against the formula evaluated with PEFT's own bf16 rounding points and NO further from the
+    fp32 result than that evaluation (it rounds once, after accumulating base and adapters in fp32, where PEFT rounds every op)."""
     import importlib
     mod = importlib.import_module("src.lora_switching_module")
     g = torch.Generator().manual_seed(4)
     K, N, M = 128, 192, 100
-    lin = mod.LoRALinear(K, N, device=gpu)
     w, b = _rand(g, N, K, scale=K ** -0.5), _rand(g, N, scale=0.1)
-    lin.weight.data.copy_(w); lin.bias.data.copy_(b)
     ads = {"canny": (_rand(g, 8, K, scale=K ** -0.5), _rand(g, N, 8, scale=0.3), 8, 16.0), "depth": (_rand(g, 4, K, scale=K ** -0.5), _rand(g, N, 4, scale=0.3), 4, 4.0)}
-    for name, (A, Bm, r, alpha) in ads.items():
-        lin.add_adapter(name, r=r, lora_alpha=alpha, A=A, B=Bm)
     x = _rand(g, 2, M // 2, K)
-    both = lin(x.to(gpu))
-    ref = R.lora_linear(x.float(), w.float(), b.float(), [(A.float(), Bm.float(), alpha / r) for (A, Bm, r, alpha) in ads.values()])
-    m = report("lora_linear_both", both, ref)
-    assert m["rel_l2"] <= 3e-3, m
-    with mod.enable_lora([lin], ["depth"]):
-        only = lin(x.to(gpu))
-    A, Bm, r, alpha = ads["depth"]
-    ref = R.lora_linear(x.float(), w.float(), b.float(), [(A.float(), Bm.float(), alpha / r)])
-    m = report("lora_linear_depth_only", only, ref)
-    assert m["rel_l2"] <= 3e-3, m
+    for dt in (torch.float32, BF):
+        lin = mod.LoRALinear(K, N, device=gpu, dtype=dt)
+        lin.weight.data.copy_(w); lin.bias.data.copy_(b)
+        for name, (A, Bm, r, alpha) in ads.items():
+            lin.add_adapter(name, r=r, lora_alpha=alpha, A=A, B=Bm)
+        for active in (["canny", "depth"], ["depth"]):
+            spec = [(ads[n][0], ads[n][1], ads[n][3] / ads[n][2]) for n in active]
+            truth = R.lora_linear(x.float(), w.float(), b.float(), [(A.float(), Bm.float(), sc) for A, Bm, sc in spec])
+            if len(active) == 2:
+                got = lin(x.to(gpu, dt))
+            else:
+                with mod.enable_lora([lin], active):
+                    got = lin(x.to(gpu, dt))
+                # the reference restores through set_scale (src/lora_switching_module.py:36-38), i.e. multiplies the saved scaling by alpha / r AGAIN:
+                # idempotent only when alpha == r ("depth" here); mirrored, not fixed (SURVEY A12)
+                assert lin.scaling["canny"] == (16.0 / 8) ** 2 and lin.scaling["depth"] == 1.0
+            tag = "f32" if dt == torch.float32 else "bf16"
+            if dt == torch.float32:
+                m = report(f"lora_linear_{'+'.join(active)}_{tag}", got, truth)
+                assert m["rel_l2"] <= 1e-5, m
+            else:
+                ref16 = R.lora_linear(x, w, b, spec)                # PEFT's bf16 eager rounding points
+                m = report(f"lora_linear_{'+'.join(active)}_{tag}", got, ref16, err_hip_vs_fp32=rel_l2(got, truth), err_ref16_vs_fp32=rel_l2(ref16, truth))
+                assert m["rel_l2"] <= 4e-3 and m["err_hip_vs_fp32"] <= 1.05 * m["err_ref16_vs_fp32"], m
 
 
 @pytest.mark.parametrize("M,N,K,epi", [(2304, 3072, 6144, "res_gate"), (4608, 4096, 8192, "gelu"), (2000, 2900 // 4 * 4, 6208, "bias")])
@@ -464,194 +477,30 @@ def test_gemm_splitk_tail(gpu, M, N, K, epi):
     assert m["rel_l2"] <= TOL, m
 
 
-_PWG_SNIPPET = r"""
-import sys, torch, torch.nn.functional as F
-sys.path.insert(0, {root!r})
-from unigen_amd import ops
-gpu, BF = torch.device("cuda:0"), torch.bfloat16
-import os
-def run(B, H, Lq, Lkv, spike):
-    dh = int(os.environ.get("UG_TEST_DH", "128")); D = H * dh
-    g = torch.Generator().manual_seed(Lq + 7 * Lkv)
-    qkv = (torch.randn(B, Lkv, 3 * D, generator=g) * (0.5 if spike else 1.0)).to(BF)
-    if spike:
-        qkv[0, 200, D:D + dh] = qkv[0, Lkv - Lq + 17, :dh] * 8.0     # tile 3: far past the lazy-rescale threshold
-        qkv[0, Lkv - 5, D:D + dh] = qkv[0, Lkv - Lq + min(99, Lq - 1), :dh] * 12.0
-    d = qkv.to(gpu)
-    out = torch.zeros(B, Lq, D, device=gpu, dtype=BF)
-    st = (3 * D, Lkv * 3 * D)
-    ops.flash_attn(d[0, Lkv - Lq:], d[0, 0, D:], d[0, 0, 2 * D:], out, batches=B, heads=H, dh=dh, Lq=Lq, Lkv=Lkv, q_strides=st, k_strides=st, v_strides=st, o_strides=(D, Lq * D))
-    q = qkv[:, Lkv - Lq:, :D].view(B, Lq, H, dh).transpose(1, 2).float()
-    k = qkv[:, :, D:2 * D].view(B, Lkv, H, dh).transpose(1, 2).float()
-    v = qkv[:, :, 2 * D:].view(B, Lkv, H, dh).transpose(1, 2).float()
-    ref = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B, Lq, D)
-    rel = ((out.float().cpu() - ref).norm() / ref.norm()).item()
-    print("pwg", B, H, Lq, Lkv, spike, rel)
-    return rel
-worst = max(run(1, 2, 256, 256, False), run(2, 3, 300, 333, False), run(1, 2, 512, 1024, True), run(1, 1, 64, 64, False), run(1, 2, 70, 700, True))
-sys.exit(0 if worst <= 4e-3 else 1)
-"""
-
-
-@pytest.mark.parametrize("env", [{"UG_ATTN_PWG": "1"}, {"UG_ATTN_STAGGER": "0"}, {"UG_ATTN_STAGGER": "0", "UG_TEST_DH": "64"},
-                                 {"UG_ATTN_WAVES": "4"}, {"UG_ATTN_PRIO": "1", "UG_ATTN_WIDE": "0"}, {"UG_ATTN_PRIO": "2", "UG_ATTN_WIDE": "1", "UG_TEST_DH": "64"},
-                                 {"UG_ATTN_DMA": "1"}, {"UG_ATTN_DMA": "1", "UG_TEST_DH": "64"}, {"UG_ATTN_DMA": "0"}, {"UG_ATTN_DMA": "0", "UG_TEST_DH": "64"},
-                                 {"UG_ATTN_PRIO": "0"}, {"UG_ATTN_PRIO": "3", "UG_TEST_DH": "64"},
-                                 {"UG_ATTN_KV64": "64", "UG_TEST_DH": "64"}, {"UG_ATTN_KV64": "464", "UG_TEST_DH": "64"}, {"UG_ATTN_KV64": "128", "UG_TEST_DH": "64"}],
-                         ids=["one-wave-per-simd", "lock-step-dh128", "lock-step-dh64", "four-wave-workgroups", "r1-default-prio1-narrow", "static-prio-wide-dh64",
-                              "lds-dma-dh128", "lds-dma-dh64", "register-staged-dh128", "register-staged-dh64", "no-priority-dh128", "softmax-priority-dh64",
-                              "dh64-64-key-tiles", "dh64-two-workgroups-per-cu", "dh64-128-key-tiles"])
-def test_flash_attn_selectable_variants(gpu, env):
-    """The non-default attention kernels: UG_ATTN_PWG=1 (4 waves x 64 rows, 512 registers, software-pipelined in the wave), the lock-step
-    loop at both head dims and the 4-wave workgroups (the default is the X|Y stagger). The switches are read once per process, so each variant runs
-    in a child: ragged Lq / Lkv, one tile, and keys that force the lazy rescale in a late tile."""
-    import os, subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-c", _PWG_SNIPPET.format(root=root)], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0, r.stdout + r.stderr
-
-
-def test_gemm_one_wave_per_simd_variants_match_default(gpu):
-    """gemm_pwg.hip (UG_GEMM_PWG=1: 4 waves x 128x128, 512 registers; =2: 8 waves x 128x64): selectable alternatives to the 8-phase 256^2
-    kernel, kept because they are the measurement that located the GEMM's bound (the L2 -> LDS intake). Same MFMA
-    shape and K order -> bit-identical results, all epilogues, ragged edges, row maps, grouped, column split. UG_ENV_DYNAMIC re-reads the switch."""
-    import os, subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = r"""
-import os, sys
-os.environ["UG_ENV_DYNAMIC"] = "1"
-sys.path.insert(0, %r)
-import torch
-from unigen_amd import ops, lib as L
-dev = torch.device("cuda:0")
-g = torch.Generator(device=dev).manual_seed(0)
-rn = lambda *s: torch.randn(*s, generator=g, device=dev).to(torch.bfloat16)
-bad = 0
-for (M, N, K, epi, grp) in [(600, 520, 192, L.EPI_BIAS, 1), (512, 768, 3072, L.EPI_BIAS_GELU, 1), (1000, 256, 320, L.EPI_RES_GATE, 1), (300, 512, 64, L.EPI_RES_SCALE, 1),
-                            (260, 256, 128, L.EPI_BIAS, 3), (512, 1024, 256, "split", 1)]:
-    a, w, b = rn(grp, M, K), rn(grp, N, K) * 0.1, rn(grp, N)
-    r, gate = rn(grp, M, N), rn(grp, (M + 99) // 100, N)
-    outs = []
-    for mode in ("0", "1", "2"):
-        os.environ["UG_GEMM_PWG"] = mode
-        out = torch.zeros(grp, M, N + 64, device=dev, dtype=torch.bfloat16)
-        kw = dict(M=M, groups=grp, a_gstride=M * K, w_gstride=N * K, bias_gstride=N, c_gstride=M * (N + 64), ldc=N + 64)
-        if epi == "split":
-            kw.update(epilogue=L.EPI_BIAS_GELU, gelu_from_n=512, c_shift_from_n=512, c_shift=64)
-        else:
-            kw.update(epilogue=epi)
-        if epi in (L.EPI_RES_GATE, L.EPI_RES_SCALE):
-            kw.update(residual=r, r_gstride=M * N, alpha=0.7)
-        if epi == L.EPI_RES_GATE:
-            kw.update(gate=gate, gate_ld=N, rows_per_sample=100, gate_gstride=gate.shape[1] * N)
-        ops.gemm(a, w, b, out, **kw)
-        outs.append(out)
-    torch.cuda.synchronize()
-    for o in outs[1:]:
-        if not torch.equal(o, outs[0]):
-            bad += 1
-            print("MISMATCH", M, N, K, epi, grp, float((o.float() - outs[0].float()).abs().max()))
-sys.exit(1 if bad else 0)
-""" % root
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0, r.stdout + r.stderr
-
-
-def test_gemm_whole_line_one_wave_per_simd_kernel_matches_default(gpu):
-    """Round 3: gemm_pwg64_kernel (UG_GEMM_PWG=3) - one wave per SIMD, 4 x (128 x 128), 64-deep ring units of whole 128-byte
-    lines, one barrier per K-tile. A measurement build of that main loop (whole 256^2 tiles only): same MFMA shape and K order as the 8-phase
-    kernel -> bit-identical, on every epilogue it carries, K = 192 (shorter than the ring) .. 3072, a row-mapped A, several tiles per workgroup."""
-    import os, subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = r"""
-import os, sys
-os.environ["UG_ENV_DYNAMIC"] = "1"
-sys.path.insert(0, %r)
-import torch
-from unigen_amd import ops, lib as L
-from unigen_amd.ops import RowMap
-dev = torch.device("cuda:0")
-g = torch.Generator(device=dev).manual_seed(0)
-rn = lambda *s: torch.randn(*s, generator=g, device=dev).to(torch.bfloat16)
-bad = 0
-for (M, N, K, epi, mapped) in [(512, 512, 192, L.EPI_BIAS, False), (1024, 768, 3072, L.EPI_BIAS_GELU, False), (768, 256, 320, L.EPI_RES_GATE, False),
-                               (512, 512, 256, L.EPI_RES_SCALE, True), (8192, 3072, 1024, L.EPI_BIAS, False), (256, 256, 576, L.EPI_BIAS, False)]:
-    rows = M // 2 if mapped else 0
-    a = rn(M + (128 if mapped else 0), K)                 # mapped: two batches of M / 2 rows at a stride of M / 2 + 64 rows
-    w, b = rn(N, K) * 0.1, rn(N)
-    r, gate = rn(M, N), rn(M // 256, N)
-    outs = []
-    for mode in ("0", "3"):
-        os.environ["UG_GEMM_PWG"] = mode
-        out = torch.zeros(M, N, device=dev, dtype=torch.bfloat16)
-        kw = dict(M=M, epilogue=epi)
-        if mapped:
-            kw.update(a_map=RowMap(rows, rows + 64))
-        if epi in (L.EPI_RES_GATE, L.EPI_RES_SCALE):
-            kw.update(residual=r, alpha=0.7)
-        if epi == L.EPI_RES_GATE:
-            kw.update(gate=gate, gate_ld=N, rows_per_sample=256)
-        ops.gemm(a, w, b, out, **kw)
-        outs.append(out)
-    torch.cuda.synchronize()
-    ref = (a.float()[:M] if not mapped else torch.cat([a.float()[:rows], a.float()[rows + 64:2 * rows + 64]])) @ w.float().t()
-    if not torch.equal(outs[0], outs[1]) or not torch.isfinite(outs[1].float()).all() or (epi == L.EPI_BIAS and float(((outs[1].float() - b.float()) - ref).norm() / ref.norm()) > 1e-2):
-        bad += 1
-        print("MISMATCH", M, N, K, epi, mapped, float((outs[1].float() - outs[0].float()).abs().max()))
-sys.exit(1 if bad else 0)
-""" % root
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0, r.stdout + r.stderr
-
-
-def test_gemm_cross_tile_stream_matches_default(gpu):
-    """Round 3: UG_GEMM_XTILE=1 - the last two K-tiles of a full tile stage the NEXT tile's first two K-tiles into the ring slots that would idle
-    (gemm.hip next_src), so the ring never drains at a tile boundary. Same MFMAs in the same order -> bit-identical. Shapes with 2-6 tiles per
-    workgroup, K-tile counts 4 .. 48 (even: streamed) and 5 (odd: falls back per tile), ragged M / N rims, a row-mapped A, every epilogue."""
-    import os, subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = r"""
-import os, sys
-os.environ["UG_ENV_DYNAMIC"] = "1"
-sys.path.insert(0, %r)
-import torch
-from unigen_amd import ops, lib as L
-from unigen_amd.ops import RowMap
-dev = torch.device("cuda:0")
-g = torch.Generator(device=dev).manual_seed(0)
-rn = lambda *s: torch.randn(*s, generator=g, device=dev).to(torch.bfloat16)
-bad = 0
-for (M, N, K, epi, mapped) in [(8192, 4096, 256, L.EPI_BIAS, False), (8192, 6144, 512, L.EPI_BIAS_GELU, False), (8192, 6144, 1024, L.EPI_RES_GATE, False),
-                               (8192, 4096, 256, L.EPI_RES_SCALE, True), (16384, 3072, 3072, L.EPI_RES_GATE, False), (8000, 4100 - 4, 384, L.EPI_BIAS, False),
-                               (8192, 4096, 320, L.EPI_BIAS, False), (8192, 8192, 640, L.EPI_F32, False)]:
-    rows = M // 2 if mapped else 0
-    a = rn(M + (128 if mapped else 0), K)
-    w, b = rn(N, K) * 0.1, rn(N)
-    r, gate = rn(M, N), rn((M + 255) // 256, N)
-    outs = []
-    for mode in ("0", "1"):
-        os.environ["UG_GEMM_XTILE"] = mode
-        out = torch.zeros(M, N, device=dev, dtype=torch.float32 if epi == L.EPI_F32 else torch.bfloat16)
-        kw = dict(M=M, epilogue=epi)
-        if mapped:
-            kw.update(a_map=RowMap(rows, rows + 64))
-        if epi in (L.EPI_RES_GATE, L.EPI_RES_SCALE):
-            kw.update(residual=r, alpha=0.7)
-        if epi == L.EPI_RES_GATE:
-            kw.update(gate=gate, gate_ld=N, rows_per_sample=256)
-        ops.gemm(a, w, None if epi == L.EPI_F32 else b, out, **kw)
-        outs.append(out)
-    torch.cuda.synchronize()
-    ref = (a.float()[:M] if not mapped else torch.cat([a.float()[:rows], a.float()[rows + 64:2 * rows + 64]])) @ w.float().t()
-    plain = epi in (L.EPI_BIAS, L.EPI_F32)
-    if not torch.equal(outs[0], outs[1]) or not torch.isfinite(outs[1].float()).all() or \
-            (plain and float(((outs[1].float() - (0 if epi == L.EPI_F32 else b.float())) - ref).norm() / ref.norm()) > 1e-2):
-        bad += 1
-        print("MISMATCH", M, N, K, epi, mapped, float((outs[1].float() - outs[0].float()).abs().max()))
-sys.exit(1 if bad else 0)
-""" % root
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0, r.stdout + r.stderr
+@pytest.mark.parametrize("M,N,K,path", [(100, 192, 128, "128^2 kernel, ragged M"), (130, 64, 64, "128^2 kernel, N below one tile"),
+                                        (8192, 4096, 256, "256^2 kernel, whole tiles: fast epilogue, 8 row-groups of residual prefetched"),
+                                        (8000, 4100, 192, "256^2 kernel, ragged M / N rims: slow edge epilogue"),
+                                        (2304, 3072, 6144, "256^2 kernel, split-K tail: the last arriver's epilogue")])
+@pytest.mark.parametrize("epi", ["res_gate", "res_scale"])
+def test_gemm_residual_aliased_to_output_every_dispatch_path(gpu, M, N, K, path, epi):
+    """include/unigen_hip.h: `R` may alias `C` (the engine's in-place `x = x + gate * f(x)` / zero-res launches, and LinearN.backward's dX
+    accumulation). Every dispatch path must read a residual element before the store that overwrites it - pinned here per path: aliased == the
+    out-of-place result, bitwise."""
+    from unigen_amd import lib as L, ops
+    g = torch.Generator().manual_seed(M + N + K)
+    a, w, b = _rand(g, M, K).to(gpu), _rand(g, N, K, scale=K ** -0.5).to(gpu), _rand(g, N, scale=0.1).to(gpu)
+    res, gate = _rand(g, M, N).to(gpu), _rand(g, (M + 255) // 256, N).to(gpu)
+    code = L.EPI_RES_GATE if epi == "res_gate" else L.EPI_RES_SCALE
+    kw = dict(M=M, epilogue=code, alpha=0.7)
+    if epi == "res_gate":
+        kw.update(gate=gate, gate_ld=N, rows_per_sample=256)
+    out = torch.empty(M, N, device=gpu, dtype=BF)
+    ops.gemm(a, w, b, out, residual=res, **kw)
+    inplace = res.clone()
+    ops.gemm(a, w, b, inplace, residual=inplace, **kw)
+    assert torch.equal(inplace, out), path
+    ref = _epi_ref(a.cpu().float() @ w.cpu().float().t(), b.cpu(), epi, res.cpu(), gate.cpu(), 256, 0.7)
+    assert report(f"gemm_alias_{epi}_{M}x{N}x{K}", inplace, ref)["rel_l2"] <= TOL
 
 
 def test_gemm_lora_segment_in_256_kernel_matches_128(gpu):

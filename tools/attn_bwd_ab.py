@@ -3,6 +3,8 @@ Usage: python tools/attn_bwd_ab.py [dh]; env ATTN_BWD_AB="UG_ATTN_BWD_DMA=0;UG_A
 Prints median / best TFLOP/s of the ALGORITHMIC backward FLOPs (10 B H Lq Lkv dh) and checks every variant returns the reference's bits."""
 import os, sys
 os.environ["UG_ENV_DYNAMIC"] = "1"
+# the variants exist only in the probe library: python -m unigen_amd.build --probe (tools/probe/README.md)
+os.environ.setdefault("UG_LIB_PATH", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "probe", "libunigen_hip_probe.so"))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from unigen_amd import ops

@@ -2,6 +2,8 @@
 kernel (gemm_pwg.hip, UG_GEMM_PWG=1) on the cfg2 projection shapes, random data; checks bitwise/near equality of the results first."""
 import os, sys
 os.environ["UG_ENV_DYNAMIC"] = "1"
+# the variants exist only in the probe library: python -m unigen_amd.build --probe (tools/probe/README.md)
+os.environ.setdefault("UG_LIB_PATH", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "probe", "libunigen_hip_probe.so"))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from unigen_amd import ops, lib as L

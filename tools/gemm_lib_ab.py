@@ -5,20 +5,25 @@ compared bit for bit. usage: python tools/gemm_lib_ab.py [label substrings]"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from unigen_amd import ops, lib as L
-from unigen_amd.ops import QkRope, RowMap
-
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-lib_a = L.load()
-path_b = os.environ.get("UG_LIB_B", os.path.join(ROOT, "tools", "probe", "bin", "libunigen_base.so"))
-lib_b = C.CDLL(path_b)
-for name, (res, args) in L.SIGNATURES.items():
-    fn = getattr(lib_b, name); fn.restype = res; fn.argtypes = args
-LIBS = [("base", lib_b), ("new", lib_a)]
-AB_ENV = os.environ.get("UG_AB_ENV")          # e.g. UG_AB_ENV=UG_GEMM_C_PLAIN: the in-tree library with NAME=0 ("base") vs NAME=1 ("new") instead of two builds
+from unigen_amd import lib as L
+AB_ENV = os.environ.get("UG_AB_ENV")          # e.g. UG_AB_ENV=UG_GEMM_WALK:0,1,2 - ONE library (the probe build: UG_LIB_PATH) with NAME set to each value in turn, instead of two builds
 if AB_ENV:
     os.environ["UG_ENV_DYNAMIC"] = "1"
-    LIBS = [("0", lib_a), ("1", lib_a)]
+    os.environ.setdefault("UG_LIB_PATH", os.path.join(ROOT, "tools", "probe", "libunigen_hip_probe.so"))
+    import importlib; importlib.reload(L)
+lib_a = L.load()
+if AB_ENV:
+    AB_ENV, _, vals = AB_ENV.partition(":")
+    LIBS = [(v, lib_a) for v in (vals.split(",") if vals else ["0", "1"])]
+else:
+    path_b = os.environ.get("UG_LIB_B", os.path.join(ROOT, "tools", "probe", "bin", "libunigen_base.so"))
+    lib_b = C.CDLL(path_b)
+    for name, (res, args) in L.SIGNATURES.items():
+        fn = getattr(lib_b, name); fn.restype = res; fn.argtypes = args
+    LIBS = [("base", lib_b), ("new", lib_a)]
+from unigen_amd import ops
+from unigen_amd.ops import QkRope, RowMap
 dev, BF = torch.device("cuda:0"), torch.bfloat16
 g = torch.Generator(device=dev).manual_seed(0)
 rn = lambda *s, sc=1.0: (torch.randn(*s, generator=g, device=dev) * sc).to(BF)
@@ -57,13 +62,13 @@ for label, M, N, K, epi in SHAPES:
             os.environ[AB_ENV] = LIBS[i][0]
         L._lib = LIBS[i][1]
         ops.gemm(a, w, b, outs[i], **kw)
-    for i in range(2):
+    for i in range(len(LIBS)):
         run(i); run(i)
     torch.cuda.synchronize()
-    mism = float((outs[0] != outs[1]).float().mean())
-    times = [[], []]
+    mism = max(float((outs[0] != o).float().mean()) for o in outs[1:])
+    times = [[] for _ in LIBS]
     for rnd in range(7):
-        for i in range(2):
+        for i in range(len(LIBS)):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(3):
@@ -73,4 +78,4 @@ for label, M, N, K, epi in SHAPES:
     L._lib = lib_a
     fl = 2.0 * M * N * K
     med = [sorted(t)[len(t) // 2] for t in times]
-    print(f"{label:40s} {M}x{N}x{K}  base {fl / med[0] / 1e9:7.1f}  new {fl / med[1] / 1e9:7.1f} TFLOP/s ({(med[0] / med[1] - 1) * 100:+.1f} %)   mismatching elements {mism:.2e}", flush=True)
+    print(f"{label:40s} {M}x{N}x{K}  " + "  ".join(f"{nm} {fl / m / 1e9:7.1f} ({(med[0] / m - 1) * 100:+.1f} %)" for (nm, _), m in zip(LIBS, med)) + f" TFLOP/s   mismatching elements {mism:.2e}", flush=True)

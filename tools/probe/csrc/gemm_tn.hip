@@ -4,6 +4,7 @@
 // attention kernel uses for V^T - out of 64-row x 128-column tiles in the attention kernel's swizzled 256-byte-row image. 128 x 128 output tile,
 // 4 waves (2 x 2, each 64 x 64 = four 32x32x16 accumulators), two tile pairs in LDS (64 KiB, 2 workgroups / CU), register staging one tile ahead.
 #include "ug_common.h"
+#include "../unigen_hip_probe.h"   // probe library only: not part of the product C ABI
 
 namespace {
 

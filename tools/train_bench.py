@@ -71,6 +71,8 @@ for step in range(a.steps + 1):
     torch.cuda.synchronize(); t1 = time.time()
     loss = ((out.float() - target) ** 2).reshape(B, -1).mean(1).mean() + losses["moe_loss"]
     loss.backward()
+    from unigen_amd import autograd as A_
+    A_.clear_activation_cache()      # the last activation transposes (and the tensors they pin) must not outlive the step
     torch.cuda.synchronize(); t2 = time.time()
     if step and timer is None:
         times.append((t1 - t0, t2 - t1))

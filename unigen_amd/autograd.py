@@ -38,9 +38,17 @@ def _w_transposed(w: torch.Tensor) -> torch.Tensor:
 
 
 def clear_caches() -> None:
-    """Drop the cached transposes (frozen weights, recent activations). Called when parameters are re-pointed to packed buffers and by the
-    training loop at the end of a step (the activation entries otherwise outlive the backward: a few hundred MB at full size)."""
+    """Drop EVERY cached transpose (frozen weights and recent activations). Only for when parameters are re-pointed at new storage
+    (engine._pack / _pack_stack / _apply call it); a training loop must NOT call this per step - every frozen weight would be re-transposed
+    each step - it calls clear_activation_cache()."""
     _wt_cache.clear()
+    _xt_cache.clear()
+
+
+def clear_activation_cache() -> None:
+    """Drop the (up to 4) activation transposes of the last backward and the source tensors they pin - hundreds of MB at full size that would
+    otherwise outlive the step. Call after `loss.backward()` (tools/train_bench.py, tests/fullsize_train_parity.py do); the frozen-weight
+    transposes stay."""
     _xt_cache.clear()
 
 
@@ -85,15 +93,12 @@ class Linear(torch.autograd.Function):
             dx = torch.empty(M, K, device=x.device, dtype=x.dtype)
             ops.gemm(dy, _w_transposed(w), None, dx, M=M)
         if need_dw:
-            if x.dtype == torch.bfloat16 and os.environ.get("UG_WGRAD", "transpose") == "tn":
-                # dY^T X straight from the row-major operands (csrc/gemm_tn.hip: both fragments by transposing LDS reads). Opt-in: its simple 128^2
-                # lock-step structure measured 6 % SLOWER per step than two transposes + the 256^2 kernel (0.884 vs 0.832 s backward at B = 2)
-                dw = ops.gemm_tn(dy, x)
-            else:                                                             # transposed copies + ug_gemm (also what the fp32 verification path runs)
-                Mp = _pad64(M)
-                dyt, xt = ops.transpose(dy, Mp), _x_transposed(x, Mp)          # [N, Mp], [K, Mp]
-                dw = torch.empty(N, K, device=x.device, dtype=x.dtype)
-                ops.gemm(dyt, xt, None, dw, M=N)
+            # transposed copies + ug_gemm (also what the fp32 verification path runs). A transposed-operand kernel (dY^T X straight from the row-major
+            # operands, tools/probe: csrc/gemm_tn.hip) measured 6 % SLOWER per step than this (0.884 vs 0.832 s backward at B = 2): probe library only.
+            Mp = _pad64(M)
+            dyt, xt = ops.transpose(dy, Mp), _x_transposed(x, Mp)          # [N, Mp], [K, Mp]
+            dw = torch.empty(N, K, device=x.device, dtype=x.dtype)
+            ops.gemm(dyt, xt, None, dw, M=N)
         if need_db:
             db = ops.colsum(dy).view(N)
         return dx, dw, db

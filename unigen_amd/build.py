@@ -1,4 +1,13 @@
-"""Build libunigen_hip.so (gfx950) in-tree with hipcc. No torch C++ extension: the library is a plain C ABI."""
+"""Build libunigen_hip.so (gfx950) in-tree with hipcc. No torch C++ extension: the library is a plain C ABI.
+
+    python -m unigen_amd.build [--force]     the PRODUCT library unigen_amd/libunigen_hip.so: one kernel per dispatch decision, tuning constants fixed
+    python -m unigen_amd.build --probe       tools/probe/libunigen_hip_probe.so: the same sources with -DUG_PROBE_BUILD, i.e. every measured-and-dropped
+                                             kernel variant compiled in and the UG_* tuning switches read from the environment again (A/B tools only;
+                                             select it with UG_LIB_PATH). Objects go to tools/probe/obj/, never next to the product's.
+
+A clean clone has no binaries (*.o / *.so are git-ignored): `unigen_amd.lib.load()` calls build() when the library is missing, and
+`__graft_entry__.build()` forces a full recompile (about 30 s) so that "does it build" is really exercised.
+"""
 from __future__ import annotations
 
 import os
@@ -7,9 +16,13 @@ import sys
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libunigen_hip.so")
-SOURCES = ["core.hip", "gemm.hip", "gemm_pwg.hip", "attention.hip", "elementwise.hip", "moe.hip", "verify_f32.hip", "probe.hip", "vae.hip", "backward.hip", "gemm_tn.hip"]
+PROBE_DIR = os.path.join(ROOT, "tools", "probe")
+PROBE_LIB = os.path.join(PROBE_DIR, "libunigen_hip_probe.so")
+SOURCES = ["core.hip", "gemm.hip", "attention.hip", "elementwise.hip", "moe.hip", "verify_f32.hip", "probe.hip", "vae.hip", "backward.hip"]
+PROBE_ONLY_SOURCES = ["gemm_pwg.hip", "gemm_tn.hip"]      # tools/probe/csrc/: kernels that lost their A/B, not in the product library
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # attention: scores are finite or -inf, never NaN; without IEEE mode hipcc drops the NaN-quieting v_max x,x it adds per fmaxf operand
 EXTRA = {"attention.hip": ["-fno-honor-nans", "-mno-amdgpu-ieee"]}
@@ -24,16 +37,23 @@ def _stale(target: str, deps: list[str]) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, probe: bool = False) -> str:
     """Compile every .hip source to an object and link the shared library. Returns the library path."""
-    hdrs = [os.path.join(CSRC, "ug_common.h"), os.path.join(CSRC, "gemm_epilogue.h"), os.path.join(HERE, "..", "include", "unigen_hip.h")]
+    hdrs = [os.path.join(CSRC, "ug_common.h"), os.path.join(CSRC, "gemm_epilogue.h"), os.path.join(ROOT, "include", "unigen_hip.h")]
+    sources = SOURCES + (PROBE_ONLY_SOURCES if probe else [])
+    objdir = os.path.join(PROBE_DIR, "obj") if probe else CSRC
+    lib = PROBE_LIB if probe else LIB
+    flags = (["-DUG_PROBE_BUILD", "-I", CSRC] if probe else []) + FLAGS
+    if probe:
+        os.makedirs(objdir, exist_ok=True)
+        hdrs.append(os.path.join(PROBE_DIR, "unigen_hip_probe.h"))
     objs, jobs = [], []
-    for src in SOURCES:
-        s = os.path.join(CSRC, src)
-        o = os.path.join(CSRC, src.replace(".hip", ".o"))
+    for src in sources:
+        s = os.path.join(PROBE_DIR, "csrc", src) if src in PROBE_ONLY_SOURCES else os.path.join(CSRC, src)
+        o = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            jobs.append([HIPCC, *FLAGS, *EXTRA.get(src, []), "-c", s, "-o", o])
+            jobs.append([HIPCC, *flags, *EXTRA.get(src, []), "-c", s, "-o", o])
 
     def run(cmd):
         if verbose:
@@ -47,10 +67,10 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if jobs:
         with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
             list(ex.map(run, jobs))
-    if force or jobs or _stale(LIB, objs):
-        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs])
-    return LIB
+    if force or jobs or _stale(lib, objs):
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs])
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, probe="--probe" in sys.argv))

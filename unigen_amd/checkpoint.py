@@ -143,9 +143,34 @@ def _zero_load(path: str):
     return torch.load(path, map_location="cpu", weights_only=False, pickle_module=_SafePickle)
 
 
-def _need(d, key, where):
+def _has_stub(v, depth: int = 0):
+    """The first blocked global inside a value the merge needs (a _Stub instance or class), or None."""
+    if isinstance(v, _Stub) or (isinstance(v, type) and issubclass(v, _Stub)):
+        return v if isinstance(v, type) else type(v)
+    if depth < 3:
+        if isinstance(v, dict):
+            for x in list(v.keys())[:64] + list(v.values())[:64]:
+                hit = _has_stub(x, depth + 1)
+                if hit is not None:
+                    return hit
+        elif isinstance(v, (list, tuple)):
+            for x in v[:64]:
+                hit = _has_stub(x, depth + 1)
+                if hit is not None:
+                    return hit
+    return None
+
+
+def _need(d, key, where, leaf: bool = True):
+    """A field the merge arithmetic depends on: present, and not replaced by the unpickler's inert stub (a shard that stores e.g. its
+    partition_count as a numpy scalar or its tensors as a subclass resolves globals outside the allowlist; failing HERE names the blocked
+    (module, name) instead of a later `int(_Stub)` TypeError)."""
     if not isinstance(d, dict) or key not in d:
         raise ValueError(f"{where}: not a DeepSpeed ZeRO shard this reader understands (no '{key}' entry; written by deepspeed 0.14-0.16?)")
+    hit = _has_stub(d[key]) if leaf else None          # containers such as optimizer_state_dict legitimately hold stubbed objects (loss scaler, config)
+    if hit is not None:
+        raise ValueError(f"{where}: field '{key}' needs the global {hit.__module__}.{hit.__name__}, which the shard reader does not resolve "
+                         "(only tensors, storages, dtypes and plain containers are allow-listed); convert the checkpoint with zero_to_fp32.py instead")
     return d[key]
 
 
@@ -166,7 +191,7 @@ def merge_zero_checkpoint(checkpoint_dir: str, tag: str = None) -> Dict[str, tor
     optim_files = _natural(glob.glob(os.path.join(ds_dir, "*_optim_states.pt")))
     if not optim_files:
         raise OSError(f"{ds_dir}: no *_optim_states.pt shards")
-    optim = [_need(_zero_load(f), "optimizer_state_dict", f) for f in optim_files]
+    optim = [_need(_zero_load(f), "optimizer_state_dict", f, leaf=False) for f in optim_files]
     stage = int(_need(optim[0], "zero_stage", optim_files[0]))
     world = _need(optim[0], "partition_count", optim_files[0])
     world = int(max(world)) if isinstance(world, (list, tuple)) else int(world)
@@ -189,7 +214,10 @@ def merge_zero_checkpoint(checkpoint_dir: str, tag: str = None) -> Dict[str, tor
         if k in buffer_names:
             sd[k] = v.float()
     # frozen parameters
-    frozen_shapes = m0.get("frozen_param_shapes") or {}
+    frozen_shapes = (_need(m0, "frozen_param_shapes", model_files[0]) if m0.get("frozen_param_shapes") is not None else None) or {}
+    if frozen_shapes:
+        for m, f in zip(models, model_files):
+            _need(m, "frozen_param_fragments", f)
     for name, shp in frozen_shapes.items():
         if stage == 3:
             frag = torch.cat([m["frozen_param_fragments"][name].reshape(-1) for m in models], 0)

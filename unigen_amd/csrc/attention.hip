@@ -635,6 +635,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void flash_attn_kernel(
 }
 
 
+#ifdef UG_PROBE_BUILD   // measured 4 % behind the 8-wave stagger: kept for A/B in the probe library only
 // =====================================================================================================================
 // One wave per SIMD ("pwg"): 4 waves x 64 query rows, up to 512 registers per lane, software-pipelined inside the wave.
 //
@@ -998,6 +999,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 }
 
 
+#endif   // UG_PROBE_BUILD
+
 // =====================================================================================================================
 // Attention BACKWARD (the autograd of F.scaled_dot_product_attention, src/UniGenUtils.py:601) on the forward kernel's
 // tiling. One kernel, four modes; a workgroup OWNS 256 rows of one side (each wave 32, their fragments in registers as the B operand, the owned
@@ -1020,6 +1023,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // stamps showed each group's segment stretching by 450-900 cycles beside its partner's although a VALU-only and an MFMA-only wave co-execute
 // perfectly in isolation (tools/probe/coexec*.hip) - unexplained, left for a later round. Starting waves 4-7 one matrix phase late per tile
 // inside the lock-step kernel: +3 % / -6 % (dh 128 / 64) before the pipelining, -3 % after it.
+
 // =====================================================================================================================
 enum { BWD_LSE = 0, BWD_DQ = 1, BWD_DK = 2, BWD_DV = 3 };
 
@@ -1740,6 +1744,25 @@ static int flash_attn_fwd_impl(const void* q, int64_t q_row_stride, int64_t q_ba
                q_batch_stride % 8 == 0 && k_batch_stride % 8 == 0 && v_batch_stride % 8 == 0 && o_batch_stride % 4 == 0 &&
                ug_aligned(q, 16) && ug_aligned(k, 16) && ug_aligned(v, 16) && ug_aligned(o, 8),
                UG_ERR_BAD_ALIGN, "ug_flash_attn_fwd: strides must be multiples of 8 elements and bases 16-byte aligned");
+#ifndef UG_PROBE_BUILD
+    // PRODUCT BUILD: one kernel per head width - the X|Y stagger with LDS-DMA staging and 16-byte stores; at head width 128 with s_setprio around the
+    // softmax segment (PRIO 3), at head width 64 the <= 128-register form so that two workgroups share a CU (KV 64, OCC 4). Every other form that was
+    // built and measured (lock-step loop, 4-wave workgroups, one wave per SIMD, register staging, 128-key tiles, priority variants) is compiled only
+    // into the probe library (python -m unigen_amd.build --probe; tools/probe/README.md), where UG_ATTN_* select it.
+    constexpr int nw = 8;
+    const int qrows = 32 * nw;
+    const int nQ = (int)((Lq + qrows - 1) / qrows);
+    const int64_t nwg = (int64_t)nQ * heads * batches;
+    UG_REQUIRE(nwg < (1ll << 31), UG_ERR_UNSUPPORTED, "ug_flash_attn_fwd: grid too large");
+    const float c = softmax_scale * 1.4426950408889634f;
+#define UG_ATTN_LAUNCH_KV(KVV, OCCV, DHV, NWV, STG, ...)                                                                                  \
+    hipLaunchKernelGGL((flash_attn_kernel<DHV, NWV, STG, __VA_ARGS__, KVV, OCCV>), dim3((unsigned)nwg), dim3(64 * NWV), 2 * 2 * KVV * 2 * DHV + (STG ? 32 * NWV * 2 * DHV : 0), (hipStream_t)stream, \
+                       (const bf16_t*)q, q_row_stride, q_batch_stride, (const bf16_t*)k, k_row_stride, k_batch_stride, (const bf16_t*)v, \
+                       v_row_stride, v_batch_stride, (bf16_t*)o, o_row_stride, o_batch_stride, (int)heads, (int)Lq, (int)Lkv, nQ, c, lse_out, lse_ld)
+    if (dh == 128) UG_ATTN_LAUNCH_KV(64, 2, 128, 8, true, 3, true, true);
+    else UG_ATTN_LAUNCH_KV(64, 4, 64, 8, true, 0, true, true);
+#undef UG_ATTN_LAUNCH_KV
+#else
     static int nw = -1;
     if (nw < 0) { const char* e = getenv("UG_ATTN_WAVES"); nw = (e && atoi(e) == 4) ? 4 : 8; }   // 8 measured faster (841 vs 800 TFLOP/s at L = 4608)
     const int qrows = 32 * nw;
@@ -1807,6 +1830,7 @@ static int flash_attn_fwd_impl(const void* q, int64_t q_row_stride, int64_t q_ba
 #undef UG_ATTN_LAUNCH_KV
 #undef UG_ATTN_STG
 #undef UG_ATTN_LAUNCH
+#endif   // UG_PROBE_BUILD
     UG_CHECK_LAUNCH("ug_flash_attn_fwd");
     return UG_OK;
 }
@@ -1856,20 +1880,21 @@ extern "C" int ug_flash_attn_bwd(const void* q, int64_t q_rs, int64_t q_bs, cons
     float* delta = (float*)workspace + batches * heads * stat_ld;
     hipStream_t s = (hipStream_t)stream;
     const float c = softmax_scale * 1.4426950408889634f;
-    const int bwd_dma = ug_env_int("UG_ATTN_BWD_DMA", 1);     // LDS-DMA staging of the streamed tiles (0: through registers)
+    const int bwd_dma = UG_TUNE("UG_ATTN_BWD_DMA", 1);     // LDS-DMA staging of the streamed tiles (0: through registers)
     const int nQ = (int)((Lq + 255) / 256), nK = (int)((Lkv + 255) / 256);
     const int64_t gq = (int64_t)nQ * heads * batches, gk = (int64_t)nK * heads * batches;
     UG_REQUIRE(gq < (1ll << 31) && gk < (1ll << 31), UG_ERR_UNSUPPORTED, "ug_flash_attn_bwd: grid too large");
     // fused dK / dV kernel (128 keys per workgroup; needs the LDS-DMA staging and equal row strides are NOT required); UG_ATTN_BWD_FUSE_DKV=0: the two modes
     const int nK2 = (int)((Lkv + 127) / 128);
     const int64_t gk2 = (int64_t)nK2 * heads * batches;
-    const bool fuse_dkv = bwd_dma && gk2 < (1ll << 31) && ug_env_int("UG_ATTN_BWD_FUSE_DKV", 1);
+    UG_REQUIRE(gk2 < (1ll << 31) && (int64_t)((Lq + 127) / 128) * heads * batches < (1ll << 31), UG_ERR_UNSUPPORTED, "ug_flash_attn_bwd: grid too large");
+    const bool fuse_dkv = bwd_dma && UG_TUNE("UG_ATTN_BWD_FUSE_DKV", 1);
     // dQ on 128-query workgroups (attn_bwd_dq_kernel); UG_ATTN_BWD_PAIR_DQ=0: the 256-query DQ mode
     const int nQ2 = (int)((Lq + 127) / 128);
     const int64_t gq2 = (int64_t)nQ2 * heads * batches;
     // Measured (tools/attn_bwd_ab.py, profiles/r03y_attn_bwd_pair_dq.log): dh 128 at 4608^2 / 8704^2 +2.6 % / +2.5 % of the whole backward; dh 128 at
     // 1000^2 -7 %, dh 64 -3 % (half the MFMAs per wave and barrier) -> on by default only for head width 128 and >= 2048 queries (2 forces it everywhere)
-    const int pdq = ug_env_int("UG_ATTN_BWD_PAIR_DQ", 1);
+    const int pdq = UG_TUNE("UG_ATTN_BWD_PAIR_DQ", 1);
     const bool pair_dq = bwd_dma && gq2 < (1ll << 31) && (pdq == 2 || (pdq == 1 && dh == 128 && Lq >= 2048));
     (void)hipMemsetAsync(workspace, 0, (size_t)(2 * batches * heads * stat_ld) * sizeof(float), s);     // padded statistics rows read as 0
     const int64_t total = batches * Lq * heads;
@@ -1879,8 +1904,18 @@ extern "C" int ug_flash_attn_bwd(const void* q, int64_t q_rs, int64_t q_bs, cons
     else
         hipLaunchKernelGGL(attn_delta_kernel<64>, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, s, (const bf16_t*)o, o_rs, o_bs, (const bf16_t*)dout, do_rs, do_bs,
                            delta, stat_ld, total, (int)heads, (int)Lq);
+#ifdef UG_PROBE_BUILD
 #define UG_BWD(DHV, MODEV, GRID, ...)                                                                                                                  \
     do { if (bwd_dma) UG_BWD_(DHV, MODEV, true, GRID, __VA_ARGS__); else UG_BWD_(DHV, MODEV, false, GRID, __VA_ARGS__); } while (0)
+#define UG_BWD_SPLIT_DKV(DHV)                                                                                                                       \
+    do {                                                                                                                                            \
+        UG_BWD(DHV, BWD_DK, gk, k, k_rs, k_bs, v, v_rs, v_bs, q, q_rs, q_bs, dout, do_rs, do_bs, dk, dk_rs, dk_bs, Lkv, Lq, nK);                   \
+        UG_BWD(DHV, BWD_DV, gk, k, k_rs, k_bs, nullptr, 0, 0, q, q_rs, q_bs, dout, do_rs, do_bs, dv, dv_rs, dv_bs, Lkv, Lq, nK);                   \
+    } while (0)
+#else      /* product: LDS-DMA staging only; dK and dV always by the fused kernel (the two separate modes are probe-build variants) */
+#define UG_BWD(DHV, MODEV, GRID, ...) UG_BWD_(DHV, MODEV, true, GRID, __VA_ARGS__)
+#define UG_BWD_SPLIT_DKV(DHV) do { } while (0)
+#endif
 #define UG_BWD_(DHV, MODEV, DMAV, GRID, O1, O1R, O1B, O2, O2R, O2B, S1, S1R, S1B, S2, S2R, S2B, OUT, OR, OB, LOWN, LST, NOWN)                          \
     do {                                                                                                                                                \
         const int lds_ = 2 * (2 * KVB * 2 * DHV + (DMAV ? 512 : 0));                                                                                   \
@@ -1890,16 +1925,26 @@ extern "C" int ug_flash_attn_bwd(const void* q, int64_t q_rs, int64_t q_bs, cons
                            (const bf16_t*)(S1), S1R, S1B, (const bf16_t*)(S2), S2R, S2B, lse2, delta, stat_ld, (bf16_t*)(OUT), OR, OB, (int)heads, (int)(LOWN),   \
                            (int)(LST), (int)(NOWN), c, softmax_scale);                                                                                 \
     } while (0)
+#define UG_BWD_PAIR_DQ(DHV)                                                                                                                         \
+    do {                                                                                                                                            \
+        constexpr int ldsq_ = 3 * (2 * KVB * 2 * DHV);                                                                                              \
+        static bool attrq_ = false;                                                                                                                 \
+        if (!attrq_) { (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<DHV>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsq_); attrq_ = true; } \
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<DHV>), dim3((unsigned)gq2), dim3(512), ldsq_, s, (const bf16_t*)q, q_rs, q_bs, (const bf16_t*)dout, do_rs, do_bs, \
+                           (const bf16_t*)k, k_rs, k_bs, (const bf16_t*)v, v_rs, v_bs, lse2, delta, stat_ld, (bf16_t*)dq, dq_rs, dq_bs, (int)heads,        \
+                           (int)Lq, (int)Lkv, nQ2, c, softmax_scale);                                                                               \
+    } while (0)
+#define UG_BWD_PAIR_DQ_128() UG_BWD_PAIR_DQ(128)
+#ifdef UG_PROBE_BUILD
+#define UG_BWD_PAIR_DQ_64() UG_BWD_PAIR_DQ(64)
+#else      /* product: the pair-scheme dQ kernel only runs at head width 128 (pair_dq above); no head-width-64 instantiation */
+#define UG_BWD_PAIR_DQ_64() do { } while (0)
+#endif
 #define UG_BWD_ALL(DHV)                                                                                                                              \
     do {                                                                                                                                              \
         if (!lse_in) UG_BWD(DHV, BWD_LSE, gq, q, q_rs, q_bs, nullptr, 0, 0, k, k_rs, k_bs, nullptr, 0, 0, nullptr, 0, 0, Lq, Lkv, nQ);             \
         if (pair_dq) {                                                                                                                             \
-            constexpr int ldsq_ = 3 * (2 * KVB * 2 * DHV);                                                                                          \
-            static bool attrq_ = false;                                                                                                             \
-            if (!attrq_) { (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<DHV>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsq_); attrq_ = true; } \
-            hipLaunchKernelGGL((attn_bwd_dq_kernel<DHV>), dim3((unsigned)gq2), dim3(512), ldsq_, s, (const bf16_t*)q, q_rs, q_bs, (const bf16_t*)dout, do_rs, do_bs, \
-                               (const bf16_t*)k, k_rs, k_bs, (const bf16_t*)v, v_rs, v_bs, lse2, delta, stat_ld, (bf16_t*)dq, dq_rs, dq_bs, (int)heads,    \
-                               (int)Lq, (int)Lkv, nQ2, c, softmax_scale);                                                                           \
+            UG_BWD_PAIR_DQ_##DHV();                                                                                                                 \
         } else {                                                                                                                                    \
             UG_BWD(DHV, BWD_DQ, gq, q, q_rs, q_bs, dout, do_rs, do_bs, k, k_rs, k_bs, v, v_rs, v_bs, dq, dq_rs, dq_bs, Lq, Lkv, nQ);               \
         }                                                                                                                                           \
@@ -1911,12 +1956,15 @@ extern "C" int ug_flash_attn_bwd(const void* q, int64_t q_rs, int64_t q_bs, cons
                                (const bf16_t*)q, q_rs, q_bs, (const bf16_t*)dout, do_rs, do_bs, lse2, delta, stat_ld, (bf16_t*)dk, dk_rs, dk_bs, (bf16_t*)dv,   \
                                dv_rs, dv_bs, (int)heads, (int)Lkv, (int)Lq, nK2, c, softmax_scale);                                                  \
         } else {                                                                                                                                    \
-            UG_BWD(DHV, BWD_DK, gk, k, k_rs, k_bs, v, v_rs, v_bs, q, q_rs, q_bs, dout, do_rs, do_bs, dk, dk_rs, dk_bs, Lkv, Lq, nK);               \
-            UG_BWD(DHV, BWD_DV, gk, k, k_rs, k_bs, nullptr, 0, 0, q, q_rs, q_bs, dout, do_rs, do_bs, dv, dv_rs, dv_bs, Lkv, Lq, nK);               \
+            UG_BWD_SPLIT_DKV(DHV);                                                                                                                  \
         }                                                                                                                                           \
     } while (0)
     if (dh == 128) UG_BWD_ALL(128); else UG_BWD_ALL(64);
 #undef UG_BWD_ALL
+#undef UG_BWD_PAIR_DQ
+#undef UG_BWD_PAIR_DQ_128
+#undef UG_BWD_PAIR_DQ_64
+#undef UG_BWD_SPLIT_DKV
 #undef UG_BWD
 #undef UG_BWD_
     UG_CHECK_LAUNCH("ug_flash_attn_bwd");

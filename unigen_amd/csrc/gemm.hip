@@ -228,7 +228,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
             }
         }
         t.g = tile / tiles_per_group;
-        const TileCoord tc = tile_of_block(tile - t.g * tiles_per_group, nM, nN, (wide16_gm >> 8) ? (wide16_gm >> 8) : 8);
+        const TileCoord tc = tile_of_block(tile - t.g * tiles_per_group, nM, nN, ((wide16_gm >> 8) & 0xff) ? ((wide16_gm >> 8) & 0xff) : 8, (wide16_gm >> 16) & 3);
         t.m0 = (int64_t)tc.tm * 256; t.n0 = (int64_t)tc.tn * 256;
         const bf16_t* Ab = (const bf16_t*)p.A + (int64_t)t.g * p.a_gstride;
         const bf16_t* Wb = (const bf16_t*)p.W + (int64_t)t.g * p.w_gstride;
@@ -282,6 +282,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
     // barrier's wait 4.0 -> 3.4 us, but the two K-tiles that now carry DMAs run at the steady-state 1.9 us instead of the DMA-free 1.3 us:
     // -0.7 ... +0.9 % per cfg2 shape, 2.006 vs 2.012 images/s end to end -> OFF by default (UG_GEMM_XTILE=1 enables). What it establishes: the
     // bytes a tile has to move are conserved, and the loop already runs at the pace of the CU's LDS / L1 path, not at the pace of its issue.
+#ifdef UG_PROBE_BUILD
+#define UG_XTILE_ON(FLAGS) (((FLAGS) & 4) != 0)
+#else      /* product: the cross-tile stream measured neutral (round 3) and is compiled out - `xt` below is a constant false */
+#define UG_XTILE_ON(FLAGS) false
+#endif
     int64_t nx_m0 = 0, nx_n0 = 0; int nx_g = 0;
     auto next_src = [&](TileSrc& t, int h, int nk_cur) __attribute__((always_inline)) {
         int lane_l = lane;
@@ -373,10 +378,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
         bool xt = false;                   // this tile's last two K-tiles stage the next tile's first two (see next_src)
         if constexpr (!LORA && !CONV) {
             const int nxt = tile + (int)gridDim.x;
-            if ((wide16_gm & 4) && nxt < full_tiles && nk >= 4 && !(nk & 1)) {
+            if (UG_XTILE_ON(wide16_gm) && nxt < full_tiles && nk >= 4 && !(nk & 1)) {
                 xt = true;
                 nx_g = nxt / tiles_per_group;
-                const TileCoord tc = tile_of_block(nxt - nx_g * tiles_per_group, nM, nN, (wide16_gm >> 8) ? (wide16_gm >> 8) : 8);
+                const TileCoord tc = tile_of_block(nxt - nx_g * tiles_per_group, nM, nN, ((wide16_gm >> 8) & 0xff) ? ((wide16_gm >> 8) & 0xff) : 8, (wide16_gm >> 16) & 3);
                 nx_m0 = (int64_t)tc.tm * 256; nx_n0 = (int64_t)tc.tn * 256;
             }
         }
@@ -826,6 +831,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
 #endif
 #undef UG_STAMP
 #undef UG_MMA_QUADRANT
+#undef UG_XTILE_ON
 #undef UG_BARRIER
 }
 
@@ -841,7 +847,7 @@ int launch(const ug_gemm_desc& d, hipStream_t s) {
     // weight below: 0.82 on large shapes, but in the cfg2 forward the text-stream projections (M = B x 512) run better on 256^2 tiles:
     // weight 60 % -> 2.011 images/s, 70 %: 2.004-2.008, 82 % (rounds 1-2): 1.995-2.000, 50 %: 2.010)
     const double e256 = (double)t256 / (double)(((t256 + 255) / 256) * 256);
-    const double e128 = 0.01 * ug_env_int("UG_GEMM_E128_PCT", 60) * (double)t128 / (double)(((t128 + 511) / 512) * 512);
+    const double e128 = 0.01 * UG_TUNE("UG_GEMM_E128_PCT", 60) * (double)t128 / (double)(((t128 + 511) / 512) * 512);
     const bool lora = d.lora_r > 0;
     bool big = (!lora || (d.K >= 2 * BK && EPI != UG_EPI_F32)) && d.M >= 192 && d.N >= 192 && e256 >= e128;
     const int f = forced_tile();
@@ -868,25 +874,26 @@ int launch(const ug_gemm_desc& d, hipStream_t s) {
         const bool res = d.epilogue == UG_EPI_RES_GATE || d.epilogue == UG_EPI_RES_SCALE;
         const int wide16 = (d.N % 8 == 0 && d.ldc % 8 == 0 && d.c_gstride % 8 == 0 && ug_aligned(d.C, 16) &&
                             (!res || (d.ldr % 8 == 0 && d.r_gstride % 8 == 0 && ug_aligned(d.R, 16)))) |
-                           ((d.c_rpb % 256 == 0 && (!res || d.r_rpb % 256 == 0) && ug_env_int("UG_GEMM_EPI_ROWS_CONTIG", 1)) ? 2 : 0) |
-                           (ug_env_int("UG_GEMM_XTILE", 0) ? 4 : 0);
+                           ((d.c_rpb % 256 == 0 && (!res || d.r_rpb % 256 == 0) && UG_TUNE("UG_GEMM_EPI_ROWS_CONTIG", 1)) ? 2 : 0) |
+                           (UG_TUNE("UG_GEMM_XTILE", 0) ? 4 : 0);
         // (Measured and dropped, round 3: plain instead of non-temporal C stores in the full-tile epilogue - +-0.5 % on every cfg2 shape,
         // profiles/r03d_gemm_cplain.log: the per-tile store cost is not the cache policy.)
         // UG_GEMM_PWG=1: the one-wave-per-SIMD kernel (gemm_pwg.hip) takes every shape it supports
+#ifdef UG_PROBE_BUILD
         if (EPI != UG_EPI_F32 && (wide16 & 1) && !lora && ug_env_int("UG_GEMM_PWG", 0)) return ug_gemm_launch_pwg(d, s);
+#endif
         // split-K tail (see the kernel header): needs the caller's workspace for the slabs and tickets
         int full = total, nsl = 1;
         // M-tiles per group of the tile walk. In the cfg2 forward (same box, bench.py x 2 each): 4 -> 2.014 images/s / GEMM 1337 TFLOP/s,
         // 8 (rounds 1-2) 1.991-2.004 / 1322-1330, 6: 2.006, 3 / 5 / 2: 2.002-2.004, 16: 1.965, 32: 1.905 (profiles/r02c_group_m.log)
-        const int gm = (ug_env_int("UG_GEMM_GROUP_M", 4) & 0xff) << 8;
+        const int gm = ((UG_TUNE("UG_GEMM_GROUP_M", 4) & 0xff) << 8) | ((UG_TUNE("UG_GEMM_WALK", 0) & 3) << 16);
         float* slabs = nullptr; unsigned* tickets = nullptr;
         const int G = ncu, rem = total % G;            // total < ncu: every tile is a remainder tile
         const int nkt = (int)(d.K / BK);
-        static int split_on = -1;
-        if (split_on < 0) { const char* e = getenv("UG_GEMM_SPLITK_TAIL"); split_on = (e && atoi(e) == 0) ? 0 : 1; }
+        const int split_on = UG_TUNE("UG_GEMM_SPLITK_TAIL", 1);
         // Measured (MI355X): the slab round trip + fences cost ~35 us, so the split only pays when a tile's K loop is long
         // (K = 15360 single-block proj_out: +3.5 %; K = 3072 shapes: -2...-3 %) -> require >= 96 K-tiles.
-        if (split_on && !lora && rem > 0 && rem * 2 <= G && d.workspace && nkt >= ug_env_int("UG_GEMM_SPLITK_MIN_KT", 96)) {
+        if (split_on && !lora && rem > 0 && rem * 2 <= G && d.workspace && nkt >= UG_TUNE("UG_GEMM_SPLITK_MIN_KT", 96)) {
             const int rem8 = (rem + 7) / 8 * 8;
             int cand = G / rem8; if (cand > 8) cand = 8; if (cand > nkt / 4) cand = nkt / 4;
             const size_t need = 4096 + (size_t)rem8 * cand * 65536 * sizeof(float);
@@ -897,13 +904,14 @@ int launch(const ug_gemm_desc& d, hipStream_t s) {
                 slabs = (float*)((char*)d.workspace + 4096);
             }
         }
-        if (lora)       // (EPI_F32 never gets here with LoRA; its second instantiation is the plain kernel again)
+        if (lora) {     // (EPI_F32 never gets here with LoRA; its second instantiation is the plain kernel again)
             hipLaunchKernelGGL((gemm256_kernel<EPI, EPI != UG_EPI_F32>), grid, dim3(512), LDS256_BYTES + 16 + UG_STAMP_LDS, s, d, (int)(t256 / groups), total, wide16 | gm, full, nsl, slabs, tickets, UgConvGeom{});
-        else
+        } else {
 #ifdef UG_DIAG_STAMPS
             if (nsl == 1 && d.workspace && (size_t)d.workspace_bytes >= 4096 + (size_t)256 * 250 * 8) slabs = (float*)((char*)d.workspace + 4096);
 #endif
             hipLaunchKernelGGL((gemm256_kernel<EPI, false>), grid, dim3(512), LDS256_BYTES + 16 + UG_STAMP_LDS, s, d, (int)(t256 / groups), total, wide16 | gm, full, nsl, slabs, tickets, UgConvGeom{});
+        }
     } else {
         const int nM = (int)((d.M + BM - 1) / BM), nN = (int)((d.N + BN - 1) / BN);
         dim3 grid((unsigned)(nM * nN), 1, (unsigned)groups);
@@ -942,7 +950,7 @@ int launch_qkrope(const ug_gemm_desc& d, hipStream_t s) {
     const int total = (int)((d.M / 256) * (d.N / 256));
     UG_REQUIRE(d.c_rpb % 256 == 0, UG_ERR_UNSUPPORTED, "ug_gemm_bf16: UG_EPI_QKV_ROPE needs the C row map's rows per batch (%lld) to be a multiple of 256",
                (long long)d.c_rpb);
-    const int wgm = 3 | (ug_env_int("UG_GEMM_XTILE", 0) ? 4 : 0) | ((ug_env_int("UG_GEMM_GROUP_M", 4) & 0xff) << 8);
+    const int wgm = 3 | (UG_TUNE("UG_GEMM_XTILE", 0) ? 4 : 0) | ((UG_TUNE("UG_GEMM_GROUP_M", 4) & 0xff) << 8) | ((UG_TUNE("UG_GEMM_WALK", 0) & 3) << 16);
     const dim3 grid((unsigned)(total < ncu ? total : ncu));
     float* stamps = nullptr;
 #ifdef UG_DIAG_STAMPS
@@ -975,7 +983,7 @@ int ug_gemm_launch_conv256(const ug_gemm_desc& d, const UgConvGeom& cv, hipStrea
         attr_set = true;
     }
     const int total = (int)((d.M / 256) * (d.N / 256));
-    const int wgm = 3 | ((ug_env_int("UG_GEMM_GROUP_M", 4) & 0xff) << 8);       // 16-byte epilogue accesses, one row map per tile (C and R are plain [M][N])
+    const int wgm = 3 | ((UG_TUNE("UG_GEMM_GROUP_M", 4) & 0xff) << 8);       // 16-byte epilogue accesses, one row map per tile (C and R are plain [M][N])
     const dim3 grid((unsigned)(total < ncu ? total : ncu));
     if (d.epilogue == UG_EPI_RES_SCALE)
         hipLaunchKernelGGL((gemm256_kernel<UG_EPI_RES_SCALE, false, 128, true>), grid, dim3(512), LDS, s, d, total, total, wgm, total, 1, (float*)nullptr, (unsigned*)nullptr, cv);

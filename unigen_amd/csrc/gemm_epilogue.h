@@ -3,8 +3,10 @@
 #pragma once
 #include "ug_common.h"
 
-// one-wave-per-SIMD 256^2 kernel (gemm_pwg.hip); the dispatcher in gemm.hip decides when it runs
+#ifdef UG_PROBE_BUILD
+// one-wave-per-SIMD 256^2 kernels (gemm_pwg.hip, probe library only: measured 8-11 % behind the 8-phase kernel); UG_GEMM_PWG selects them
 int ug_gemm_launch_pwg(const ug_gemm_desc& d, hipStream_t s);
+#endif
 
 // Implicit-GEMM convolution on the 256^2 kernel (vae.hip -> gemm.hip): the A operand of ug_gemm_desc is the NHWC activation, gathered per filter tap.
 // M = B Ho Wo output pixels, N = Cout, K = KH KW Cin with Cin / 64 = ktp K-tiles per tap (a power of two >= 2); `zero` = at least Cin + 64 zero elements.
@@ -25,11 +27,26 @@ struct TileCoord { int tm, tn; };
 // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch), so give each XCD a contiguous chunk of
 // the tile sequence, and walk that sequence in groups of 8 M-tiles x all N-tiles so co-resident tiles share A/W panels
 // in the XCD's L2. Only affects speed.
-__device__ __forceinline__ TileCoord tile_of_block(int bid, int nM, int nN, int GROUP_M = 8) {
+// WALK (bits 16.. of the 256^2 kernel's flag word; round 4 experiment, VERDICT r3 item 6 ii): 0 = the grouped walk below; 1 / 2 = compact blocks of
+// 8 M-tiles x 4 N-tiles - the 32 tiles one XCD runs per round of the persistent grid then always share exactly 8 A-panels and 4 W-panels (12
+// panel streams for 64 panel uses: the 0.81 L2-hit bound in EVERY round, where the grouped walk's rounds straddle two groups whenever nN is not
+// a multiple of 8) - blocks ordered N-fastest (1: consecutive rounds keep the A panels) or M-fastest (2: keep the W panels). Needs 8 | nM, 4 | nN.
+__device__ __forceinline__ TileCoord tile_of_block(int bid, int nM, int nN, int GROUP_M = 8, int WALK = 0) {
     const int nwg = nM * nN;
     const int q = nwg >> 3, r = nwg & 7;
     const int xcd = bid & 7, k = bid >> 3;
     const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;  // bijective for any nwg
+    if (WALK != 0 && (nM & 7) == 0 && (nN & 3) == 0) {
+        const int blk = id >> 5, w = id & 31;
+        const int nbn = nN >> 2, nbm = nM >> 3;
+        int bmi, bni;
+        if (WALK == 1) { bmi = blk / nbn; bni = blk - bmi * nbn; }
+        else { bni = blk / nbm; bmi = blk - bni * nbm; }
+        TileCoord t;
+        t.tm = bmi * 8 + (w & 7);
+        t.tn = bni * 4 + (w >> 3);
+        return t;
+    }
     const int per_group = GROUP_M * nN;
     const int gid = id / per_group;
     const int first_m = gid * GROUP_M;

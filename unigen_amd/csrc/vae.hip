@@ -596,10 +596,13 @@ extern "C" int ug_conv2d_nhwc(const ug_conv_desc* dp, ug_stream_t stream) {
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)conv2d_nhwc_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_SMALL);
+#ifdef UG_PROBE_BUILD
         (void)hipFuncSetAttribute((const void*)conv2d_nhwc_kernel<4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BIG);
+#endif
         attr = true;
     }
     const int64_t nN = (d.Cout + CBN - 1) / CBN;
+#ifdef UG_PROBE_BUILD      /* the 256 x 128 three-stage form: bit-identical and no faster (round 3) - probe library only */
     if (M % 256 == 0 && (M / 256) * nN >= ug_env_int("UG_CONV_BIG_MIN_TILES", 128) && ug_env_int("UG_CONV_BIG", 0)) {
         const int64_t grid = (M / 256) * nN;
         UG_REQUIRE(grid < (1ll << 31), UG_ERR_UNSUPPORTED, "ug_conv2d_nhwc: grid too large");
@@ -607,6 +610,7 @@ extern "C" int ug_conv2d_nhwc(const ug_conv_desc* dp, ug_stream_t stream) {
         UG_CHECK_LAUNCH("ug_conv2d_nhwc");
         return UG_OK;
     }
+#endif
     const int64_t grid = ((M + 127) / 128) * nN;
     UG_REQUIRE(grid < (1ll << 31), UG_ERR_UNSUPPORTED, "ug_conv2d_nhwc: grid too large");
     hipLaunchKernelGGL((conv2d_nhwc_kernel<2, 2>), dim3((unsigned)grid), dim3(256), LDS_SMALL, (hipStream_t)stream, p);

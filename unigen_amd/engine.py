@@ -179,12 +179,33 @@ class HipModule(nn.Module):
     def _P(self, name: str) -> torch.Tensor:
         return self.get_parameter(name).data
 
+    def _is_packed(self, t: Optional[torch.Tensor], params, stacked: bool) -> bool:
+        """EVERY member still a view of `t` at its own offset (another grouping that re-pointed a later member must not pass as packed)."""
+        if t is None or params[0].device != t.device:
+            return False
+        off = 0
+        esz = t.element_size()
+        for i, p in enumerate(params):
+            want = t.data_ptr() + (i * t.stride(0) if stacked else off * t.stride(0)) * esz
+            if p.data.data_ptr() != want or not p.data.is_contiguous():
+                return False
+            off += p.data.shape[0]
+        return True
+
+    def _drop_superseded(self, key: str, params) -> None:
+        """A new pack of these parameters replaces every older pack that still holds one of them (a second grouping of the same weights would
+        otherwise keep a stale duplicate of their storage alive in self._packed)."""
+        ptrs = {p.data.untyped_storage().data_ptr() for p in params}
+        for k in [k for k, t in self._packed.items() if k != key and t.untyped_storage().data_ptr() in ptrs]:
+            del self._packed[k]
+
     def _pack(self, key: str, names: Sequence[str]) -> torch.Tensor:
         """Concatenate parameters along dim 0 into one buffer and re-point them at views of it (no duplicate storage)."""
         params = [self.get_parameter(n) for n in names]
         t = self._packed.get(key)
-        if t is not None and params[0].data.data_ptr() == t.data_ptr() and params[0].device == t.device:
+        if self._is_packed(t, params, stacked=False):
             return t
+        self._drop_superseded(key, params)
         t = torch.cat([p.data for p in params], dim=0).contiguous()
         off = 0
         for p in params:
@@ -198,8 +219,9 @@ class HipModule(nn.Module):
     def _pack_stack(self, key: str, names: Sequence[str]) -> torch.Tensor:
         params = [self.get_parameter(n) for n in names]
         t = self._packed.get(key)
-        if t is not None and params[0].data.data_ptr() == t.data_ptr() and params[0].device == t.device:
+        if self._is_packed(t, params, stacked=True):
             return t
+        self._drop_superseded(key, params)
         t = torch.stack([p.data for p in params], dim=0).contiguous()
         for i, p in enumerate(params):
             p.data = t[i]
@@ -210,6 +232,17 @@ class HipModule(nn.Module):
     def _attn_qkv(self, p: str) -> Tuple[torch.Tensor, torch.Tensor]:
         return (self._pack(p + ".qkv.w", [f"{p}.to_q.weight", f"{p}.to_k.weight", f"{p}.to_v.weight"]),
                 self._pack(p + ".qkv.b", [f"{p}.to_q.bias", f"{p}.to_k.bias", f"{p}.to_v.bias"]))
+
+    def _single_qkv_mlp(self, p: str) -> Optional[Tuple[torch.Tensor, torch.Tensor]]:
+        """ONE grouping of a single block's projections for the inference engine and the training forward alike: the four-way pack
+        [to_q | to_k | to_v | proj_mlp] when the q|k|v / mlp split falls on a 256-column tile boundary (3 D % 256 == 0: the fused launch of
+        flux._single_block), otherwise None and the caller uses the three-way _attn_qkv pack. (Two groupings of the same weights made
+        alternating train / eval forwards re-pack on every call.)"""
+        if (3 * self.inner_dim) % 256 != 0:
+            return None
+        a = p + ".attn"
+        names = [f"{a}.to_q", f"{a}.to_k", f"{a}.to_v", f"{p}.proj_mlp"]
+        return (self._pack(p + ".qkv_mlp.w", [x + ".weight" for x in names]), self._pack(p + ".qkv_mlp.b", [x + ".bias" for x in names]))
 
     def _attn_add_qkv(self, p: str) -> Tuple[torch.Tensor, torch.Tensor]:
         return (self._pack(p + ".aqkv.w", [f"{p}.add_q_proj.weight", f"{p}.add_k_proj.weight", f"{p}.add_v_proj.weight"]),

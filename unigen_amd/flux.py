@@ -295,10 +295,9 @@ class UniGenFlux(HipModule):
         wq, wk = self._P(a + ".norm_q.weight"), self._P(a + ".norm_k.weight")
         cs = getattr(rope, "cs", None)
         fused = False
-        if (3 * D) % 256 == 0:                         # the split must fall on a tile boundary
-            names = [f"{a}.to_q", f"{a}.to_k", f"{a}.to_v", f"{p}.proj_mlp"]
-            w7 = self._pack(p + ".qkv_mlp.w", [x + ".weight" for x in names])
-            b7 = self._pack(p + ".qkv_mlp.b", [x + ".bias" for x in names])
+        packed = self._single_qkv_mlp(p)               # None unless the split falls on a tile boundary (3 D % 256 == 0)
+        if packed is not None:
+            w7, b7 = packed
             # q / k RMSNorm + RoPE ride in the same launch's epilogue when the shapes allow (whole 256^2 tiles)
             fused = cs is not None and ops.qk_rope_fusable(B * Lj, 7 * D, 2 * D, dh, n.dtype)
             ops.gemm(n, w7, b7, sb, M=B * Lj, ldc=8 * D, epilogue=L.EPI_BIAS_GELU, gelu_from_n=3 * D, c_shift_from_n=3 * D, c_shift=D,

@@ -83,7 +83,6 @@ SIGNATURES = {
 }
 # fp32 verification twins: `<name>_f32` has the signature of the function it mirrors (include/unigen_hip.h, last section)
 SIGNATURES.update({
-    "ug_gemm_tn_bf16": (i32, [vp, i64, vp, i64, vp, i64, i64, i64, i64, vp]),
     "ug_transpose": (i32, [vp, i64, i64, vp, i64, i64, i64, i64, i64, i64, vp]),
     "ug_colsum": (i32, [vp, i64, vp, i64, vp, i64, i64, i64, i64, f32, vp, i64, vp]),
     "ug_colsum_workspace_bytes": (i64, [i64, i64, i64]),
@@ -131,10 +130,15 @@ def load() -> C.CDLL:
     if _lib is not None:
         return _lib
     if not os.path.exists(LIB_PATH):
-        raise UniGenHipError(
-            f"{LIB_PATH} not found: build it with `python -m unigen_amd.build` (hipcc --offload-arch=gfx950). "
-            "unigen_amd has no CPU fallback for the hot path."
-        )
+        # a clean clone carries no binaries: build the product library once, in-tree (about 30 s); there is no CPU fallback for the hot path
+        if os.environ.get("UG_LIB_PATH"):
+            raise UniGenHipError(f"UG_LIB_PATH={LIB_PATH} not found (probe library: `python -m unigen_amd.build --probe`)")
+        try:
+            from . import build as _build
+            _build.build()
+        except Exception as e:      # no hipcc, compile error: fail loudly, never fall back
+            raise UniGenHipError(f"{LIB_PATH} not found and `python -m unigen_amd.build` (hipcc --offload-arch=gfx950) failed: {e}. "
+                                 "unigen_amd has no CPU fallback for the hot path.") from e
     # The library links libamdhip64 by SONAME. PyTorch-ROCm ships its own copy of the HIP runtime: it has to be in the process first so
     # that both resolve to ONE runtime (loaded the other way round, the system runtime and torch's each keep their own device state and
     # launches fail with "no ROCm-capable device is detected").

@@ -70,12 +70,13 @@ class LoRALinear(nn.Module):
         shp = x.shape
         x2 = x.reshape(-1, shp[-1])
         M = x2.shape[0]
-        out = torch.empty(M, self.out_features, device=x.device, dtype=BF)
+        dt = self.weight.dtype                                            # bf16 (product) or fp32 (verification twins, ug_gemm_f32)
+        out = torch.empty(M, self.out_features, device=x.device, dtype=dt)
         A, Bm = self._fused_adapters()
         if A is None:
             ops.gemm(x2, self.weight, self.bias, out, M=M)
         else:
-            t = torch.empty(M, A.shape[0], device=x.device, dtype=BF)
+            t = torch.empty(M, A.shape[0], device=x.device, dtype=dt)
             ops.gemm(x2, A, None, t, M=M)                              # T = x A^T
             ops.gemm(x2, self.weight, self.bias, out, M=M, lora_t=t, lora_b=Bm)   # base GEMM + LoRA K-segment in one accumulator
         return out.view(*shp[:-1], self.out_features)

@@ -694,16 +694,3 @@ def gate_residual(x: Optional[torch.Tensor], a: torch.Tensor, gate: torch.Tensor
     L.check(_fn("ug_gate_residual", dt)(_p(x), x.stride(0) if x is not None else 0, a.data_ptr(), a.stride(0), gate.data_ptr(), gate.stride(0), rows_per_sample,
                                         y.data_ptr(), D, rows, D, _stream()), "ug_gate_residual")
     return y
-
-
-def gemm_tn(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
-    """a [R, I], b [R, J] (bf16, row-major, any row stride) -> a^T b [I, J]: the weight gradient dY^T X without transposed copies."""
-    _chk(a, "a"); _chk(b, "b")
-    R, I = a.shape
-    J = b.shape[1]
-    out = torch.empty(I, J, device=a.device, dtype=bf16)
-    ev = _timer.begin("gemm") if _timer is not None else None
-    L.check(L.load().ug_gemm_tn_bf16(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(), J, R, I, J, _stream()), "ug_gemm_tn_bf16")
-    if ev is not None:
-        _timer.end("gemm", 2.0 * R * I * J, ev)
-    return out

@@ -70,11 +70,9 @@ def _attention(model, prefix: str, x, enc, rope, text_first: bool, mlp_prefix: O
     x_off, e_off = (T, 0) if text_first else (0, N)
     # to_q | to_k | to_v read the same rows: one GEMM over the packed weights (engine._attn_qkv makes the three parameters views of one
     # buffer), one accumulated d x in the backward instead of three GEMM outputs summed by autograd's add kernels
-    if mlp_prefix is not None:           # single block: keep flux._single_block's four-way pack [q | k | v | proj_mlp] (q, k, v are its first three row blocks)
-        names = [prefix + ".to_q", prefix + ".to_k", prefix + ".to_v", mlp_prefix]
-        model._pack(mlp_prefix.rsplit(".", 1)[0] + ".qkv_mlp.w", [n + ".weight" for n in names])
-        model._pack(mlp_prefix.rsplit(".", 1)[0] + ".qkv_mlp.b", [n + ".bias" for n in names])
-    else:
+    # single block: the SAME grouping as flux._single_block (engine._single_qkv_mlp: four-way [q | k | v | proj_mlp] when the split is tile-aligned,
+    # else the three-way pack) - q, k, v are the first three row blocks either way
+    if mlp_prefix is None or model._single_qkv_mlp(mlp_prefix.rsplit(".", 1)[0]) is None:
         model._attn_qkv(prefix)
     q, k, v = _lin_n(model, x, [prefix + ".to_q", prefix + ".to_k", prefix + ".to_v"])
     q = A.qk_norm_rope(q, _p(model, prefix + ".norm_q.weight"), rope, H, x_off)
