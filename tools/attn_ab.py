@@ -20,11 +20,12 @@ if os.environ.get("ATTN_AB_VARIANTS"):        # e.g. "0,1,0;0,1,1" = prio,wide,d
 if os.environ.get("ATTN_AB_ENVS"):            # generic: "K=V,K=V;K=V" = one environment per variant (switches not named keep their defaults)
     VARIANTS = [dict(kv.split("=") for kv in v.split(",") if kv) for v in os.environ["ATTN_AB_ENVS"].split(";")]
     ALLKEYS = sorted({k for v in VARIANTS for k in v})
-SHAPES = [(4, 4608, 4608), (4, 4096, 4608), (4, 8192, 8704), (2, 1000, 1003)] if dh == 128 else [(16, 4096, 4429), (16, 4096, 4096)]
+SHAPES = ([(4, 4608, 4608), (4, 4096, 4608)] if os.environ.get("ATTN_AB_SHORT") else [(4, 4608, 4608), (4, 4096, 4608), (4, 8192, 8704), (4, 1536, 1536), (2, 1000, 1003)]) if dh == 128 else [(16, 4096, 4429), (16, 4096, 4096)]
 g = torch.Generator(device=dev).manual_seed(0)
 for B, Lq, Lkv in SHAPES:
-    qkv = torch.randn(B, Lkv, 3 * D, generator=g, device=dev).to(torch.bfloat16)
-    st = (3 * D, Lkv * 3 * D)
+    W8 = 8 * D if os.environ.get("ATTN_AB_WIDE_ROWS") else 3 * D       # the single block's [q | k | v | attn | mlp] rows
+    qkv = torch.randn(B, Lkv, W8, generator=g, device=dev).to(torch.bfloat16)
+    st = (W8, Lkv * W8)
     outs = [torch.empty(B, Lq, D, device=dev, dtype=torch.bfloat16) for _ in VARIANTS]
 
     def run(i):
@@ -45,8 +46,21 @@ for B, Lq, Lkv in SHAPES:
         else:
             assert torch.equal(outs[i], outs[0]), f"variant {VARIANTS[i]} differs from the default"
     times = [[] for _ in VARIANTS]
+    heat = os.environ.get("ATTN_AB_HEAT")          # in-application conditions: every timed attention launch directly follows a large GEMM (hot chip, L2 turned over)
+    if heat:
+        ga, gw, gc = (torch.randn(16384, 3072, generator=g, device=dev).to(torch.bfloat16), torch.randn(12288, 3072, generator=g, device=dev).to(torch.bfloat16) * 0.02,
+                      torch.empty(16384, 12288, device=dev, dtype=torch.bfloat16))
     for rnd in range(7):
         for i in range(len(VARIANTS)):
+            if heat:
+                tot = 0.0
+                for _ in range(4):
+                    ops.gemm(ga, gw, None, gc, M=16384)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(); run(i); e1.record(); e1.synchronize()
+                    tot += e0.elapsed_time(e1)
+                times[i].append(tot / 4)
+                continue
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(4):
@@ -56,4 +70,5 @@ for B, Lq, Lkv in SHAPES:
     fl = 4.0 * B * H * Lq * Lkv * dh
     for i, v in enumerate(VARIANTS):
         t = sorted(times[i])
-        print(f"dh{dh} B{B} {Lq}x{Lkv} {v}: median {fl / t[len(t) // 2] / 1e9:7.1f}  best {fl / t[0] / 1e9:7.1f} TFLOP/s", flush=True)
+        print(f"dh{dh} B{B} {Lq}x{Lkv} {v}: median {fl / t[len(t) // 2] / 1e9:7.1f}  best {fl / t[0] / 1e9:7.1f} TFLOP/s" +
+              ("   rounds: " + " ".join(f"{fl / x / 1e9:.0f}" for x in times[i]) if os.environ.get("ATTN_AB_ROUNDS") else ""), flush=True)

@@ -62,12 +62,12 @@ sys.exit(0 if worst <= 4e-3 else 1)
 """
 
 
-@pytest.mark.parametrize("env", [{"UG_ATTN_PWG": "1"}, {"UG_ATTN_STAGGER": "0"}, {"UG_ATTN_STAGGER": "0", "UG_TEST_DH": "64"},
+@pytest.mark.parametrize("env", [{"UG_ATTN_M16": "1"}, {"UG_ATTN_M16": "1", "UG_ATTN_PRIO": "0"}, {"UG_ATTN_M16": "1", "UG_TEST_DH": "64"}, {"UG_ATTN_PWG": "1"}, {"UG_ATTN_STAGGER": "0"}, {"UG_ATTN_STAGGER": "0", "UG_TEST_DH": "64"},
                                  {"UG_ATTN_WAVES": "4"}, {"UG_ATTN_PRIO": "1", "UG_ATTN_WIDE": "0"}, {"UG_ATTN_PRIO": "2", "UG_ATTN_WIDE": "1", "UG_TEST_DH": "64"},
                                  {"UG_ATTN_DMA": "1"}, {"UG_ATTN_DMA": "1", "UG_TEST_DH": "64"}, {"UG_ATTN_DMA": "0"}, {"UG_ATTN_DMA": "0", "UG_TEST_DH": "64"},
                                  {"UG_ATTN_PRIO": "0"}, {"UG_ATTN_PRIO": "3", "UG_TEST_DH": "64"},
                                  {"UG_ATTN_KV64": "64", "UG_TEST_DH": "64"}, {"UG_ATTN_KV64": "464", "UG_TEST_DH": "64"}, {"UG_ATTN_KV64": "128", "UG_TEST_DH": "64"}],
-                         ids=["one-wave-per-simd", "lock-step-dh128", "lock-step-dh64", "four-wave-workgroups", "r1-default-prio1-narrow", "static-prio-wide-dh64",
+                         ids=["mfma-16x16x32-stagger", "mfma-16x16x32-stagger-no-prio", "mfma-16x16x32-stagger-dh64", "one-wave-per-simd", "lock-step-dh128", "lock-step-dh64", "four-wave-workgroups", "r1-default-prio1-narrow", "static-prio-wide-dh64",
                               "lds-dma-dh128", "lds-dma-dh64", "register-staged-dh128", "register-staged-dh64", "no-priority-dh128", "softmax-priority-dh64",
                               "dh64-64-key-tiles", "dh64-two-workgroups-per-cu", "dh64-128-key-tiles"])
 def test_flash_attn_selectable_variants(gpu, env):
