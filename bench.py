@@ -439,8 +439,9 @@ def main():
     elapsed, out, own_elapsed = _timed(one_step, args.steps, args.warmup, dev, world, timer, ops)
     # one all_gather of every rank's own record, so that a straggler (or a rank on the wrong device) shows in the one JSON line.
     # The measured MFMA-only rate of each rank's chip rides along: boxes differ by 8-12 % (DVFS), and cross-box comparisons need it.
-    pk16 = ops.probe_mfma_peak(dev, shape=1)
-    pk32 = ops.probe_mfma_peak(dev, shape=0)
+    probe = not (args.no_kernel_timer or args.graph)          # profiling runs (--no-kernel-timer) keep the probe's launches out of the kernel statistics
+    pk16 = ops.probe_mfma_peak(dev, shape=1) if probe else 0.0
+    pk32 = ops.probe_mfma_peak(dev, shape=0) if probe else 0.0
     per_rank = [dict(rank=i, images=int(r[0]), seconds=r[1], images_per_s=r[0] / r[1], device_index=int(r[2]), mfma_probe_16x16x32_tflops=r[3],
                      mfma_probe_32x32x16_tflops=r[4])
                 for i, r in enumerate(DU.all_gather_floats([B * args.steps, own_elapsed, local_rank, pk16, pk32], dev, world))]
@@ -481,8 +482,9 @@ def main():
                 line["flops_per_image_canonical"] = fl_img
             line["e2e_mfma_frac"] = value / world * fl_img / (MFMA_BF16_PEAK_TFLOPS * 1e12)
             # the same against the bare-MFMA rate this chip held in THIS run (16x16x32 probe, rank 0's device): the number to compare across boxes
-            line["e2e_frac_of_measured"] = value / world * fl_img / (pk16 * 1e12)
-            line["mfma_probe_tflops"] = dict(shape_16x16x32=pk16, shape_32x32x16=pk32, note="ug_probe_mfma_bf16, same run, rank 0's device")
+            if probe:
+                line["e2e_frac_of_measured"] = value / world * fl_img / (pk16 * 1e12)
+                line["mfma_probe_tflops"] = dict(shape_16x16x32=pk16, shape_32x32x16=pk32, note="ug_probe_mfma_bf16, same run, rank 0's device")
         if scaling_base is not None:
             line["scaling_base"] = scaling_base
         if s:
@@ -496,7 +498,7 @@ def main():
                     tj = json.load(f)
                 traffic = tj["kernels"]["gemm_all"]["hbm_bytes_per_launch"]
                 traffic_src = dict(measured_in_this_run=False, file=f"profiles/{os.path.basename(tf)}",
-                                   file_mtime_utc=time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime(os.path.getmtime(tf))), collected=tj.get("source"))
+                                   collected_utc=tj.get("collected_utc", "not recorded (profile of an earlier round)"), collected=tj.get("source"))
                 traffic_note = (f"NOT measured in this run - counters need their own rocprofv3 passes - read from an earlier profile of the same command on another box: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, profiles/{os.path.basename(tf)}): (2*FETCH_SIZE + WRITE_SIZE)*1024 per "
                                 "launch; the L2-fabric counters include Infinity-Cache hits, so this is traffic beyond the XCD L2, an upper bound on HBM bytes")
                 g256 = tj["kernels"].get("gemm256", {})

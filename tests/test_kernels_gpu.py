@@ -227,9 +227,8 @@ def test_qk_rmsnorm_rope(gpu, dh, H):
 @pytest.mark.parametrize("B,H,Lq,Lkv,qoff", [(1, 2, 256, 256, 0), (2, 3, 300, 333, 0), (1, 2, 64, 200, 136), (1, 1, 512, 1024, 0),
                                              (1, 2, 300, 2100, 1700), (2, 1, 2049, 2049, 0), (1, 3, 70, 2048, 0)])
 def test_flash_attn(gpu, B, H, Lq, Lkv, qoff):
-    """qoff > 0: queries are rows [qoff, qoff+Lq) of the joint sequence (image-only queries of a control joint block). Head width 128 runs the
-    32x32x16 stagger kernel below 2048 keys and its 16x16x32 form from 2048 keys on (round 4): the last three cases reach the latter on ragged
-    query / key counts (a one-key last tile, fewer queries than one workgroup owns)."""
+    """qoff > 0: queries are rows [qoff, qoff+Lq) of the joint sequence (image-only queries of a control joint block). The last three cases: long
+    key sequences with ragged query / key counts (a one-key last tile, fewer queries than one workgroup owns, queries starting deep in the buffer)."""
     from unigen_amd import ops
     dh = 128
     D = H * dh
@@ -249,9 +248,8 @@ def test_flash_attn(gpu, B, H, Lq, Lkv, qoff):
 
 @pytest.mark.parametrize("Lkv", [320, 2304])
 def test_flash_attn_rescale_branch(gpu, Lkv):
-    """Force the online-softmax rescale: one key row far larger than the rest in a LATE tile (cdna guide rule 26). Lkv = 320: the 32x32x16
-    kernel; 2304: the 16x16x32 kernel (two query blocks per wave, each with its own lazy reference point: queries 17 and 99 sit in different
-    blocks of different waves, query 40 shares a wave with 99... every combination of one / both blocks of a wave moving)."""
+    """Force the online-softmax rescale: one key row far larger than the rest in a LATE tile (cdna guide rule 26); Lkv = 2304 adds spikes in tiles
+    14 and 23 for queries of one wave (40), and for two queries of ANOTHER wave in the same tile (100, 120: rows of both 16-row halves)."""
     from unigen_amd import ops
     B, H, Lq, dh = 1, 1, 256, 128
     g = torch.Generator().manual_seed(3)
@@ -259,7 +257,7 @@ def test_flash_attn_rescale_branch(gpu, Lkv):
     k[0, 200] = q[0, 17] * 4.0     # spikes the score of query 17 (and correlates with others) in tile 3
     k[0, Lkv - 20] = q[0, 99] * 6.0     # and again in the last tile
     if Lkv > 1000:
-        k[0, 900] = q[0, 40] * 5.0; k[0, 1500] = (q[0, 100] + q[0, 120]) * 4.0      # query 100 / 120: both 16-query blocks of wave 3 move in one tile
+        k[0, 900] = q[0, 40] * 5.0; k[0, 1500] = (q[0, 100] + q[0, 120]) * 4.0
     out = torch.zeros(B, Lq, dh, device=gpu, dtype=BF)
     ops.flash_attn(q.to(gpu), k.to(gpu), v.to(gpu), out, batches=B, heads=H, dh=dh, Lq=Lq, Lkv=Lkv, q_strides=(dh, Lq * dh),
                    k_strides=(dh, Lkv * dh), v_strides=(dh, Lkv * dh), o_strides=(dh, Lq * dh))

@@ -33,7 +33,9 @@ def main():
     tag, fcsv, wcsv, bcsv = sys.argv[1:5]
     F, W, Bz = load(fcsv), load(wcsv), load(bcsv)
     T = load(sys.argv[5]) if len(sys.argv) > 5 else {}
-    out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE (separate passes) -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-kernel-timer",
+    import time
+    out = {"collected_utc": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime()), "tag": tag,
+           "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE (separate passes) -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-kernel-timer",
            "correction": "bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 FETCH_SIZE correction; KiB units); counters beyond the XCD L2 include Infinity-Cache hits",
            "kernels": {}}
     tot_b, tot_n = 0.0, 0
