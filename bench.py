@@ -394,6 +394,9 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE = {world}: launch with --nproc-per-node {args.gpus}, or without a launcher")
     if args.dry_run:
         return _dry_run(args, world, rank)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC only on these hosts: RCCL needs it (already exported on the GPU boxes)
+    if world > 1:                                                      # N ranks on one host: do not let every rank's torch CPU pool take all cores
+        torch.set_num_threads(max(1, (os.cpu_count() or world) // world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: unigen_amd has no CPU path")
     ndev = torch.cuda.device_count()

@@ -3,16 +3,25 @@
 TEST INFRASTRUCTURE ONLY. Nothing in the product path (unigen_amd/, src/) imports this module; only tests/,
 __graft_entry__.smoke() and bench.py's cpu_baseline leg do, as the checker / the timed CPU baseline.
 
-PARITY UNPINNED: the reference (gavin-gqzhang/UniGen @ /root/reference) ships no tests, golden vectors or fixtures, it
-cannot be imported here (deepspeed / diffusers / peft / ipdb are absent: ordinary ModuleNotFoundError) and `UniGenFlux`
-uses classes that are defined nowhere (FluxJointRoPETransformerBlock, FluxSingleRoPETransformerBlock). This file restates
+PARITY: PARTLY REFERENCE-PINNED (round 4), OTHERWISE UNPINNED. The reference (gavin-gqzhang/UniGen @ /root/reference) ships no tests, golden
+vectors or fixtures, it cannot be imported here (deepspeed / diffusers / peft / ipdb are absent: ordinary ModuleNotFoundError) and `UniGenFlux`
+uses classes that are defined nowhere (FluxJointRoPETransformerBlock, FluxSingleRoPETransformerBlock). Its self-contained torch-only functions
+CAN be run: tests/golden/make_ref_leaf_golden.py compiles them from the reference's files at run time (build container only) and
+tests/test_ref_leaf_cpu.py holds these rows of this file to their outputs (tests/golden/ref_leaf.safetensors):
+  modulated_flatten_literal / modulated_linear  <- modulated_flatten          src/UniGenUtils.py:204-228
+  adaln_zero / adaln_zero_any                   <- adanorm_forward            src/UniGenUtils.py:354-363
+  adaln_zero_x                                  <- sd35adanormX_forward       src/UniGenUtils.py:340-352
+  adaln_continuous                              <- adanormContinuous_forward  src/UniGenUtils.py:365-373
+  expert_forward                                <- UniGenFlux.expert_forward  src/UniGenTransformer.py:925-967 (== UniGenBase :225-267)
+Everything else is UNPINNED: it restates
   * src/UniGenTransformer.py:712-1450   (UniGenFlux, MultiCondtionUniGenFlux)
   * src/UniGenUtils.py:17-228,340-622   (MoE glue, modulated_flatten, JointAttnRopeProcessor)
   * src/UniGenPipeline.py:662-677,721-789 (timesteps, denoise loop)
 and the published algorithms of its un-vendored dependencies, pinned in /root/reference/environment.yaml:
   diffusers==0.32.2 (FluxTransformerBlock, FluxSingleTransformerBlock, FluxAttnProcessor2_0, AdaLayerNormZero*,
   FluxPosEmbed, apply_rotary_emb, CombinedTimestepTextProjEmbeddings, FlowMatchEulerDiscreteScheduler),
-  deepspeed==0.16.5 (sharded_moe.top1gating / TopKGate), peft==0.15.0 (LoRA Linear).
+  deepspeed==0.16.5 (sharded_moe.top1gating / TopKGate), peft==0.15.0 (LoRA Linear)
+and is pinned against drift only by fixtures this file generated itself (tests/golden/make_golden.py).
 
 Everything runs on a flat `state` dict {reference state-dict key: tensor}. `dtype` chooses the arithmetic:
   torch.bfloat16 -> the reference's own eager rounding points (every torch op rounds to bf16),
