@@ -764,7 +764,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
                                                       fg[j][0], fg[j][1], rbuf[rg % PF][j])
                         : epi_chunk_full<EPI_A>(p.alpha, acc[rg >> 2][j][rg & 3][0], acc[rg >> 2][j][rg & 3][1], fb[j][0], fb[j][1],
                                               fg[j][0], fg[j][1], rbuf[rg % PF][j]);
+#ifdef UG_DIAG_FULLLINE     /* TIMING ONLY (wrong layout): the same 16 bytes per lane, but one instruction = 8 rows x 128 B (whole lines) instead of 16 rows x 64 B */
+                    {
+                        bf16_t* const dg = Cb - colb + (int)n0 + (int64_t)(rowmap32((unsigned)m0, (unsigned)p.c_rpb, (unsigned)p.c_bstride) + (unsigned)(wr * 64 + (rg >> 2) * 128 + (rg & 3) * 16 + 8 * j + ((lane_e & 15) >> 1))) * p.ldc
+                                           + wc * 64 + (lane_e & 1) * 32 + (lane_e >> 4) * 8;
+                        __builtin_nontemporal_store(o, (u32x4*)dg);
+                    }
+#else
                     __builtin_nontemporal_store(o, (u32x4*)(cpr + j * 128));
+#endif
                 }
             }
             UG_STAMP(4);
