@@ -185,6 +185,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
     const int64_t M = p.M, N = p.N;
     const int nM = (int)((M + 255) / 256), nN = (int)((N + 255) / 256);
     const int st_off = wave * 16 * 128;
+    // Which tile column a wave's quadrant (., j) covers. Rounds 1-3: j * 128 + wc * 32 (B half-tile j holds tile columns j * 128 ..). Round 4 (NPERM,
+    // every epilogue except the q/k RMSNorm + RoPE one, whose head arithmetic is written for the old map): wc * 64 + j * 32, i.e. row rho of B half-tile h
+    // is tile column (rho >> 5) * 64 + h * 32 + (rho & 31) - a pure permutation of which W rows the DMAs fetch into which LDS rows. A wave then owns 64
+    // CONTIGUOUS columns = one whole 128-byte line of every output row, and the full-tile epilogue stores 8 rows x 128 B per instruction instead of
+    // 16 rows x 64 B: half-line writes run at 14.4 B/clk per CU, whole lines at 48.5 (tools/probe/store_rate.hip, profiles/r04j_store_rate_probe.log).
+    // Same MFMAs in the same K order on every output element: bit-identical results.
+    constexpr bool NPERM = EPI != UG_EPI_QKV_ROPE;
+    constexpr int CJ = NPERM ? 32 : 128, CW = NPERM ? 64 : 32;
+    auto bcol = [](int h, int rho) __attribute__((always_inline)) { return NPERM ? (rho >> 5) * 64 + h * 32 + (rho & 31) : h * 128 + rho; };
 #ifdef UG_DIAG_STAMPS
     constexpr int stamp_off = LDS256_BYTES + 16 + (EPI == UG_EPI_QKV_ROPE ? 256 * 8 * 4 : 0);
 #endif
@@ -239,7 +248,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
                 const int row = wave * 16 + i * 8 + (lane >> 3);
                 const int c = (lane & 7) ^ (row & 7);
                 int64_t am = t.m0 + h * 128 + row; if (am > M - 1) am = M - 1;
-                int64_t wn = t.n0 + h * 128 + row; if (wn > N - 1) wn = N - 1;
+                int64_t wn = t.n0 + bcol(h, row); if (wn > N - 1) wn = N - 1;
                 if constexpr (CONV) {
                     const unsigned hw = (unsigned)(cv.Ho * cv.Wo), bb = (unsigned)am / hw, rr = (unsigned)am - bb * hw, oy = rr / (unsigned)cv.Wo;
                     t.pk[h][i] = bb << 24 | oy << 12 | (rr - oy * (unsigned)cv.Wo);
@@ -268,7 +277,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
             const int row = wave * 16 + i * 8 + (lane_l >> 3);
             const int c = (lane_l & 7) ^ (row & 7);
             int64_t am = t.m0 + h * 128 + row; if (am > M - 1) am = M - 1;
-            int64_t wn = t.n0 + h * 128 + row; if (wn > N - 1) wn = N - 1;
+            int64_t wn = t.n0 + bcol(h, row); if (wn > N - 1) wn = N - 1;
             t.a[h][i] = (const bf16_t*)p.lora_T + am * p.ldt + c * 8 - p.K;
             t.b[h][i] = (const bf16_t*)p.lora_B + wn * p.ldb + c * 8 - p.K;
         }
@@ -298,7 +307,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
             const int row = wave * 16 + i * 8 + (lane_l >> 3);
             const int c = (lane_l & 7) ^ (row & 7);
             int64_t am = nx_m0 + h * 128 + row; if (am > M - 1) am = M - 1;
-            int64_t wn = nx_n0 + h * 128 + row; if (wn > N - 1) wn = N - 1;
+            int64_t wn = nx_n0 + bcol(h, row); if (wn > N - 1) wn = N - 1;
             t.a[h][i] = Ab + (int64_t)rowmap32((unsigned)am, (unsigned)p.a_rpb, (unsigned)p.a_bstride) * p.lda + c * 8;
             t.b[h][i] = Wb + wn * p.ldw + c * 8;
         }
@@ -521,7 +530,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
-                    const int64_t n = n0 + j * 128 + wc * 32 + nt * 16 + (lane_e >> 4) * 4;
+                    const int64_t n = n0 + j * CJ + wc * CW + nt * 16 + (lane_e >> 4) * 4;
                     pb[j][nt] = (u32x2){0u, 0u}; pg[j][nt] = (u32x2){0u, 0u};
                     if (bias) pb[j][nt] = *(const u32x2*)(bias + n);
                     if constexpr (EPI == UG_EPI_RES_GATE) pg[j][nt] = *(const u32x2*)(gate + n);
@@ -710,7 +719,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
             // 8 row-groups of 16 rows x 2 column halves; the residual chunks of row-group rg+1 are loaded before row-group rg is
             // computed and stored (older than those stores on the in-order VM counter, so waiting for them does not wait for stores).
             const int lg = lane_e >> 4;
-            const int colb = (int)n0 + wc * 32 + (lg & 1) * 16 + 8 * (lg >> 1);
+            const int colb = (int)n0 + wc * CW + (lg & 1) * 16 + 8 * (lg >> 1);
             const TileSplit ts = tile_split<EPI>(p, n0);
             bf16_t* const Cb = (bf16_t*)p.C + (int64_t)g * p.c_gstride + colb + ts.cshift;
             const bf16_t* const Rb = RES ? (const bf16_t*)p.R + (int64_t)g * p.r_gstride + colb : nullptr;
@@ -719,18 +728,29 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
             // 64-bit multiply: ~45 of the ~190 VALU instructions per row-group of this VALU-bound epilogue.)
             const int rl = wr * 64 + (lane_e & 15);
             bf16_t* const c_lane = Cb + (int64_t)(rowmap32((unsigned)m0, (unsigned)p.c_rpb, (unsigned)p.c_bstride) + (unsigned)rl) * p.ldc;
+            // NPERM: whole-line stores. Per 16-row group a lane (r = lane & 15, lg) holds o[0] / o[1] = its 16-byte chunk of the row's first / second
+            // 64-byte half. Lanes r and r ^ 8 trade through DPP row_ror:8 (same lg, so the chunk position inside a half is unchanged):
+            //   store A = rows 0-7:  lanes r < 8 their own o[0] at half 0 | lanes r >= 8 row (r - 8)'s o[1] at half 1
+            //   store B = rows 8-15: lanes r >= 8 their own o[0] at half 0 | lanes r < 8 row (r + 8)'s o[1] at half 1
+            // -> each instruction writes 8 rows x 128 contiguous bytes. (R may alias C: every residual chunk of the row group was loaded AND waited for
+            // by this wave before its first store, and no other wave touches these rows' columns.)
+            const int r16 = lane_e & 15;
+            bf16_t* const c_laneA = c_lane + (int64_t)((r16 & 7) - r16) * p.ldc + (r16 >> 3) * 32;
+            const int dB = 8 * (int)p.ldc + (r16 < 8 ? 32 : -32);      // store B's address = store A's + 8 rows, other half (elements; ldc < 2^27 checked by the launcher's 31-bit row limits)
             const bf16_t* r_lane = nullptr;
             if constexpr (RES) r_lane = Rb + (int64_t)(rowmap32((unsigned)m0, (unsigned)p.r_rpb, (unsigned)p.r_bstride) + (unsigned)rl) * p.ldr;
             // Residual chunks are requested PF row-groups ahead (round 3: all 8, was 2). In-kernel stamps (tools/gemm_stamps.py) showed the R + gate * v
             // epilogue at 8.3 us per tile against 3.7 us for bias only at equal stores: with one row-group of lead every row-group waited out a
             // full memory latency behind the next tile's 16 ring DMAs. The fragment registers of the K loop are dead here, so 8 x 8 registers are free; what the stamps also show: wave 0 finishes earlier (8.3 -> 7.0 us) but then waits longer at the next tile's first barrier - the workgroup's epilogue is bound by the CU's memory path (ring prefetch + R + C = 384 KB), not by one wave's latency chain.
-            constexpr int PF = UG_EPI_RES_PREFETCH;
+            // (RES_GATE with whole-line stores: 7 - the eighth row-group's 8 registers are what the two extra store pointers and the DPP temporaries need; at 8
+            // hipcc spilled one register of the edge-tile path to scratch)
+            constexpr int PF = (EPI == UG_EPI_RES_GATE && NPERM && UG_EPI_RES_PREFETCH > 7) ? 7 : UG_EPI_RES_PREFETCH;
             u32x4 rbuf[PF][2];
             auto open_rows = [&](int rg) {
                 if constexpr (RES) {
                     const bf16_t* rp = r_lane + (int64_t)((rg >> 2) * 128 + (rg & 3) * 16) * p.ldr;
                     rbuf[rg % PF][0] = gload16_asm(rp);
-                    rbuf[rg % PF][1] = gload16_asm_256(rp);
+                    if constexpr (NPERM) rbuf[rg % PF][1] = gload16_asm_64(rp); else rbuf[rg % PF][1] = gload16_asm_256(rp);      // quadrant j = 1: CJ columns further
                 } else {
                     rbuf[rg % PF][0] = rbuf[rg % PF][1] = (u32x4){0u, 0u, 0u, 0u};
                 }
@@ -756,23 +776,28 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
                         default: ug_wait_vm<14>(rbuf[rg % PF][0], rbuf[rg % PF][1]); break;
                     }
                 }
-                bf16_t* const cpr = c_lane + (int64_t)((rg >> 2) * 128 + (rg & 3) * 16) * p.ldc;
+                const int64_t rgoff = (int64_t)((rg >> 2) * 128 + (rg & 3) * 16) * p.ldc;
+                u32x4 o[2];
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const u32x4 o = (EPI_A == UG_EPI_BIAS_GELU && !ts.gelu)
+                for (int j = 0; j < 2; ++j)
+                    o[j] = (EPI_A == UG_EPI_BIAS_GELU && !ts.gelu)
                         ? epi_chunk_full<UG_EPI_BIAS>(p.alpha, acc[rg >> 2][j][rg & 3][0], acc[rg >> 2][j][rg & 3][1], fb[j][0], fb[j][1],
                                                       fg[j][0], fg[j][1], rbuf[rg % PF][j])
                         : epi_chunk_full<EPI_A>(p.alpha, acc[rg >> 2][j][rg & 3][0], acc[rg >> 2][j][rg & 3][1], fb[j][0], fb[j][1],
                                               fg[j][0], fg[j][1], rbuf[rg % PF][j]);
-#ifdef UG_DIAG_FULLLINE     /* TIMING ONLY (wrong layout): the same 16 bytes per lane, but one instruction = 8 rows x 128 B (whole lines) instead of 16 rows x 64 B */
-                    {
-                        bf16_t* const dg = Cb - colb + (int)n0 + (int64_t)(rowmap32((unsigned)m0, (unsigned)p.c_rpb, (unsigned)p.c_bstride) + (unsigned)(wr * 64 + (rg >> 2) * 128 + (rg & 3) * 16 + 8 * j + ((lane_e & 15) >> 1))) * p.ldc
-                                           + wc * 64 + (lane_e & 1) * 32 + (lane_e >> 4) * 8;
-                        __builtin_nontemporal_store(o, (u32x4*)dg);
+                if constexpr (NPERM) {
+                    u32x4 xa, xb;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        // v_mov_b32_dpp row_ror:8, bank_mask selects which lanes of every 16-lane row take the neighbour's value (banks 2,3 = lanes 8-15; 0,1 = lanes 0-7)
+                        xa[q] = (unsigned)__builtin_amdgcn_update_dpp((int)o[0][q], (int)o[1][q], 0x128, 0xF, 0xC, false);
+                        xb[q] = (unsigned)__builtin_amdgcn_update_dpp((int)o[0][q], (int)o[1][q], 0x128, 0xF, 0x3, false);
                     }
-#else
-                    __builtin_nontemporal_store(o, (u32x4*)(cpr + j * 128));
-#endif
+                    __builtin_nontemporal_store(xa, (u32x4*)(c_laneA + rgoff));
+                    __builtin_nontemporal_store(xb, (u32x4*)(c_laneA + rgoff + dB));
+                } else {
+                    __builtin_nontemporal_store(o[0], (u32x4*)(c_lane + rgoff));
+                    __builtin_nontemporal_store(o[1], (u32x4*)(c_lane + rgoff + 128));
                 }
             }
             UG_STAMP(4);
@@ -787,7 +812,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
-                const int64_t n = n0 + j * 128 + wc * 32 + nt * 16 + (lane_e >> 4) * 4;
+                const int64_t n = n0 + j * CJ + wc * CW + nt * 16 + (lane_e >> 4) * 4;
                 load_bias4(n < N ? bias : nullptr, n, bv[j][nt]);
             }
         const TileSplit tsl = tile_split<EPI>(p, n0);
@@ -803,9 +828,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
                         if (EPI_A == UG_EPI_BIAS_GELU && !tsl.gelu)
-                            epi_store_pair16<UG_EPI_BIAS>(p, rc, row_ok, n0 + j * 128 + wc * 32, N, lane_e, acc[i][j][mt][0], acc[i][j][mt][1], bv[j][0], bv[j][1]);
+                            epi_store_pair16<UG_EPI_BIAS>(p, rc, row_ok, n0 + j * CJ + wc * CW, N, lane_e, acc[i][j][mt][0], acc[i][j][mt][1], bv[j][0], bv[j][1]);
                         else
-                            epi_store_pair16<EPI_A>(p, rc, row_ok, n0 + j * 128 + wc * 32, N, lane_e, acc[i][j][mt][0], acc[i][j][mt][1], bv[j][0], bv[j][1]);
+                            epi_store_pair16<EPI_A>(p, rc, row_ok, n0 + j * CJ + wc * CW, N, lane_e, acc[i][j][mt][0], acc[i][j][mt][1], bv[j][0], bv[j][1]);
                     }
                 }
         } else {
@@ -821,7 +846,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
                     for (int j = 0; j < 2; ++j)
 #pragma unroll
                         for (int nt = 0; nt < 2; ++nt) {
-                            const int64_t n = n0 + j * 128 + wc * 32 + nt * 16 + (lane_e >> 4) * 4;
+                            const int64_t n = n0 + j * CJ + wc * CW + nt * 16 + (lane_e >> 4) * 4;
                             if (n >= N) continue;
                             if (EPI_A == UG_EPI_BIAS_GELU && !tsl.gelu) epi_store<UG_EPI_BIAS>(p, rc, n, acc[i][j][mt][nt], bv[j][nt]);
                             else epi_store<EPI_A>(p, rc, n, acc[i][j][mt][nt], bv[j][nt]);
