@@ -83,6 +83,62 @@ static void run(const char* name, unsigned char* out, long ldc, unsigned long lo
            iss[iss.size() / 2], iss.back(), don[don.size() / 2], don.back(), 131072.0 / don[don.size() / 2], ms);
 }
 
+// The same bursts as LOADS (the residual epilogues read R in the epilogue's pattern): PAT 0 = 16 rows x 64 B per instruction, PAT 2 = 8 rows x 128 B
+template <int PAT>
+__global__ __launch_bounds__(512, 2) void kl(const unsigned char* in, long ldc_bytes, unsigned long long* stamps, int bursts, int gap_iters, unsigned* sink) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned char* tile = in + (size_t)blockIdx.x * 256 * ldc_bytes;
+    const int wr = wave >> 2, wc = wave & 3;
+    unsigned long long t_issue = 0, t_done = 0;
+    unsigned acc = 0;
+    __builtin_amdgcn_s_barrier();
+    for (int b = 0; b < bursts; ++b) {
+        unsigned long long t0, t1, t2;
+        u32x4 v[16];
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            long off;
+            if (PAT == 0) {
+                const int i = s >> 3, mt = (s >> 1) & 3, j = s & 1;
+                const int row = i * 128 + wr * 64 + mt * 16 + (lane & 15);
+                off = (long)row * ldc_bytes + j * 256 + wc * 64 + (lane >> 4) * 16;
+            } else {
+                const int row = (wave * 16 + s) * 8 + lane / 8;
+                off = (long)(row & 255) * ldc_bytes + (long)(row >> 8) * 1024 + (lane % 8) * 16;
+            }
+            const unsigned char* p = tile + off + (size_t)(b & 7) * 0;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v[s]) : "v"(p) : "memory");
+        }
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t2), "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
+                     "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15])::"memory");
+#pragma unroll
+        for (int s = 0; s < 16; ++s) acc ^= v[s].x;
+        t_issue += t1 - t0; t_done += t2 - t0;
+        for (int g = 0; g < gap_iters; ++g) asm volatile("s_sleep 8");
+        __builtin_amdgcn_s_barrier();
+    }
+    if (acc == 0x12345678u) sink[0] = acc;
+    if (lane == 0) { stamps[((size_t)blockIdx.x * 8 + wave) * 2] = t_issue; stamps[((size_t)blockIdx.x * 8 + wave) * 2 + 1] = t_done; }
+}
+
+template <int PAT>
+static void runl(const char* name, unsigned char* out, long ldc, unsigned long long* st, int blocks) {
+    const int bursts = 64;
+    std::vector<unsigned long long> h(blocks * 16);
+    unsigned* sink; hipMalloc(&sink, 64);
+    hipLaunchKernelGGL((kl<PAT>), dim3(blocks), dim3(512), 0, 0, out, ldc, st, 4, 50, sink);
+    hipLaunchKernelGGL((kl<PAT>), dim3(blocks), dim3(512), 0, 0, out, ldc, st, bursts, 50, sink);
+    hipDeviceSynchronize();
+    hipMemcpy(h.data(), st, h.size() * 8, hipMemcpyDeviceToHost);
+    std::vector<double> iss, don;
+    for (int w = 0; w < blocks * 8; ++w) { iss.push_back(h[2 * w] / (double)bursts); don.push_back(h[2 * w + 1] / (double)bursts); }
+    std::sort(iss.begin(), iss.end()); std::sort(don.begin(), don.end());
+    printf("%-34s issue median %7.0f max %7.0f | done median %7.0f max %7.0f cycles per 16-load burst -> %5.1f B/clk/CU\n", name,
+           iss[iss.size() / 2], iss.back(), don[don.size() / 2], don.back(), 131072.0 / don[don.size() / 2]);
+}
+
 int main(int argc, char** argv) {
     const int blocks = argc > 1 ? atoi(argv[1]) : 256;
     const long ldc = 6144;                                   // bytes: a [M][3072] bf16 C
@@ -102,5 +158,7 @@ int main(int argc, char** argv) {
     run<1, 6>("16 x 64 B pieces of one 1 KiB run, nt", out, ldc, st, blocks);
     run<1, 1>("1 KiB contiguous, vaddr64, nt", out, ldc, st, blocks);
     run<3, 1>("1 KiB contiguous, saddr+voff32, nt", out, ldc, st, blocks);
+    runl<0>("LOADS gemm rows (16 x 64 B)", out, ldc, st, blocks);
+    runl<2>("LOADS 8 rows x 128 B", out, ldc, st, blocks);
     return 0;
 }

@@ -739,6 +739,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
             const int dB = 8 * (int)p.ldc + (r16 < 8 ? 32 : -32);      // store B's address = store A's + 8 rows, other half (elements; ldc < 2^27 checked by the launcher's 31-bit row limits)
             const bf16_t* r_lane = nullptr;
             if constexpr (RES) r_lane = Rb + (int64_t)(rowmap32((unsigned)m0, (unsigned)p.r_rpb, (unsigned)p.r_bstride) + (unsigned)rl) * p.ldr;
+            // ... and whole-line residual LOADS the same way (half-line loads issue at 20 B/clk per CU, whole lines at 50: tools/probe/store_rate.hip):
+            // load A = rows 0-7 (lanes r >= 8 fetch row (r - 8)'s second half), load B = rows 8-15 (lanes r < 8 fetch row (r + 8)'s second half); the two
+            // loads are turned back into this lane's own (first-half, second-half) chunks right before use (res_own below).
+            const bf16_t* r_laneA = nullptr; int dBr = 0;
+            if constexpr (RES && NPERM) { r_laneA = r_lane + (int64_t)((r16 & 7) - r16) * p.ldr + (r16 >> 3) * 32; dBr = 8 * (int)p.ldr + (r16 < 8 ? 32 : -32); }
             // Residual chunks are requested PF row-groups ahead (round 3: all 8, was 2). In-kernel stamps (tools/gemm_stamps.py) showed the R + gate * v
             // epilogue at 8.3 us per tile against 3.7 us for bias only at equal stores: with one row-group of lead every row-group waited out a
             // full memory latency behind the next tile's 16 ring DMAs. The fragment registers of the K loop are dead here, so 8 x 8 registers are free; what the stamps also show: wave 0 finishes earlier (8.3 -> 7.0 us) but then waits longer at the next tile's first barrier - the workgroup's epilogue is bound by the CU's memory path (ring prefetch + R + C = 384 KB), not by one wave's latency chain.
@@ -747,10 +752,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
             constexpr int PF = (EPI == UG_EPI_RES_GATE && NPERM && UG_EPI_RES_PREFETCH > 7) ? 7 : UG_EPI_RES_PREFETCH;
             u32x4 rbuf[PF][2];
             auto open_rows = [&](int rg) {
-                if constexpr (RES) {
+                if constexpr (RES && NPERM) {
+                    const bf16_t* rp = r_laneA + (int64_t)((rg >> 2) * 128 + (rg & 3) * 16) * p.ldr;
+                    rbuf[rg % PF][0] = gload16_asm(rp);                 // load A: 8 rows x 128 B
+                    rbuf[rg % PF][1] = gload16_asm(rp + dBr);           // load B
+                } else if constexpr (RES) {
                     const bf16_t* rp = r_lane + (int64_t)((rg >> 2) * 128 + (rg & 3) * 16) * p.ldr;
                     rbuf[rg % PF][0] = gload16_asm(rp);
-                    if constexpr (NPERM) rbuf[rg % PF][1] = gload16_asm_64(rp); else rbuf[rg % PF][1] = gload16_asm_256(rp);      // quadrant j = 1: CJ columns further
+                    rbuf[rg % PF][1] = gload16_asm_256(rp);
                 } else {
                     rbuf[rg % PF][0] = rbuf[rg % PF][1] = (u32x4){0u, 0u, 0u, 0u};
                 }
@@ -777,14 +786,25 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
                     }
                 }
                 const int64_t rgoff = (int64_t)((rg >> 2) * 128 + (rg & 3) * 16) * p.ldc;
+                u32x4 res_own[2] = {rbuf[rg % PF][0], rbuf[rg % PF][1]};
+                if constexpr (RES && NPERM) {
+                    // loads A / B -> this lane's own chunks: first half = (r < 8 ? A : B); second half = row_ror:8 of (r >= 8 ? A : B)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int la = (int)rbuf[rg % PF][0][q], lb = (int)rbuf[rg % PF][1][q];
+                        res_own[0][q] = (unsigned)__builtin_amdgcn_update_dpp(la, lb, 0xE4, 0xF, 0xC, false);          // lanes 8-15 of every row take B (same lane: quad_perm identity)
+                        const int z = __builtin_amdgcn_update_dpp(lb, la, 0xE4, 0xF, 0xC, false);                         // lanes 8-15 take A, lanes 0-7 keep B
+                        res_own[1][q] = (unsigned)__builtin_amdgcn_update_dpp(z, z, 0x128, 0xF, 0xF, false);              // row_ror:8
+                    }
+                }
                 u32x4 o[2];
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     o[j] = (EPI_A == UG_EPI_BIAS_GELU && !ts.gelu)
                         ? epi_chunk_full<UG_EPI_BIAS>(p.alpha, acc[rg >> 2][j][rg & 3][0], acc[rg >> 2][j][rg & 3][1], fb[j][0], fb[j][1],
-                                                      fg[j][0], fg[j][1], rbuf[rg % PF][j])
+                                                      fg[j][0], fg[j][1], res_own[j])
                         : epi_chunk_full<EPI_A>(p.alpha, acc[rg >> 2][j][rg & 3][0], acc[rg >> 2][j][rg & 3][1], fb[j][0], fb[j][1],
-                                              fg[j][0], fg[j][1], rbuf[rg % PF][j]);
+                                              fg[j][0], fg[j][1], res_own[j]);
                 if constexpr (NPERM) {
                     u32x4 xa, xb;
 #pragma unroll
