@@ -41,6 +41,10 @@ __global__ __launch_bounds__(512, 2) void k(unsigned char* out, long ldc_bytes, 
                 constexpr int LPR = 64 / R;                          // lanes per row
                 const int row = (wave * 16 + s) * R + lane / LPR;      // 8 waves x 16 instructions x R rows <= 1024 rows: the tile region is 256 rows, wrap into it
                 off = (long)(row & 255) * ldc_bytes + (long)(row >> 8) * 1024 + (lane % LPR) * 16;
+            } else if (PAT == 7) {
+                // the attention forward's epilogue (T21 form): one instruction = 32 rows x 32 B (lane l: row l & 31, bytes 16 (l >> 5) .. + 15 of a 32-byte group), 8 groups per 256-byte row
+                const int row = wave * 32 + (lane & 31);
+                off = (long)row * ldc_bytes + (s & 7) * 32 + (lane >> 5) * 16 + (long)(s >> 3) * 256;
             } else {
                 // PAT 6: the GEMM pattern's shape (16 rows x 64 B per instruction) with the rows only 64 B apart (one 1 KiB run): lines, not pages
                 off = (long)(wave * 16 + s) * 1024 + (lane & 15) * 64 + (lane >> 4) * 16;
@@ -143,7 +147,7 @@ int main(int argc, char** argv) {
     const int blocks = argc > 1 ? atoi(argv[1]) : 256;
     const long ldc = 6144;                                   // bytes: a [M][3072] bf16 C
     unsigned char* out; unsigned long long* st;
-    hipMalloc(&out, (size_t)blocks * 256 * ldc + (1 << 20)); hipMalloc(&st, blocks * 16 * 8);
+    hipMalloc(&out, (size_t)blocks * 256 * 49152 + (1 << 20)); hipMalloc(&st, blocks * 16 * 8);
     printf("blocks %d (one 8-wave workgroup each), 16 x dwordx4 per wave per burst, bursts separated by sleep + barrier\n", blocks);
     run<0, 0>("gemm rows, vaddr64, plain", out, ldc, st, blocks);
     run<1, 0>("gemm rows, vaddr64, nt", out, ldc, st, blocks);
@@ -158,6 +162,10 @@ int main(int argc, char** argv) {
     run<1, 6>("16 x 64 B pieces of one 1 KiB run, nt", out, ldc, st, blocks);
     run<1, 1>("1 KiB contiguous, vaddr64, nt", out, ldc, st, blocks);
     run<3, 1>("1 KiB contiguous, saddr+voff32, nt", out, ldc, st, blocks);
+    run<1, 7>("attention O: 32 rows x 32 B, nt", out, ldc, st, blocks);
+    run<0, 7>("attention O: 32 rows x 32 B, plain", out, ldc, st, blocks);
+    run<0, 7>("attention O, row stride 48 KiB, plain", out, 49152, st, blocks);
+    run<0, 3>("4 rows x 256 B, row stride 48 KiB", out, 49152, st, blocks);
     runl<0>("LOADS gemm rows (16 x 64 B)", out, ldc, st, blocks);
     runl<2>("LOADS 8 rows x 128 B", out, ldc, st, blocks);
     return 0;
