@@ -179,6 +179,33 @@ int ug_moe_capacity_rts(const float* gates, const int32_t* idx, const float* uni
                         int64_t capacity, int32_t* slot, int32_t* token_of_slot, int64_t* exp_counts, float* l_aux,
                         ug_stream_t stream);
 
+/* ---- top-2 gating (control_params.top_num = 2 -> MoE(..., k = 2), src/UniGenTransformer.py:162,197 / :808,857 / :1565,1650; TopKGate then calls
+ * deepspeed 0.16.5 sharded_moe.top2gating(logits, capacity_factor = 1, min_capacity = 4, drop_tokens = True, top2_2nd_expert_sampling = True),
+ * a dependency that is not in /root/reference: restated from its published source, parity unpinned). Arrays over the two choices are
+ * choice-major [2][S]. ---- */
+
+/* Gate: gates = softmax(logits) fp32 [S][E] as ug_moe_gate_top1; idx[0][s] = argmax; idx[1][s] = argmax over the OTHER experts of
+ * logits[s][e] + noise[s][e] (noise: the Gumbel(0, 1) sample deepspeed adds to the logits for its second choice, fp32 [S][E]; NULL = no
+ * sampling, the second-largest logit). 2 <= E <= 16. */
+int ug_moe_gate_top2(const void* x, const void* c, int64_t ld, const void* wg, int64_t S, int64_t D, int32_t E, const float* noise,
+                     float* gates, int32_t* idx, ug_stream_t stream);
+
+/* Capacity rule of top2gating (no random token selection): per expert the first choices take slots in token order, the second choices
+ * follow behind ALL its first choices; a choice at or beyond `capacity` (= max(ceil(S / E * 2), 4) for the reference's settings) is dropped.
+ * Writes slot int32 [2][S] (-1 = dropped), token_of_slot int32 [E][capacity] (-1 = empty; the layout ug_moe_dispatch_modulate reads),
+ * weights fp32 [2][S] = the kept choices' gate probabilities over their sum clamped at FLT_EPSILON (0 for a dropped choice), exp_counts
+ * int64 [E] = first + second choices before the drop, l_aux fp32 scalar = E * sum_e mean_s(gates[s][e]) * mean_s(idx[0][s] == e). */
+int ug_moe_capacity_top2(const float* gates, const int32_t* idx, int64_t S, int32_t E, int64_t capacity, int32_t* slot,
+                         int32_t* token_of_slot, float* weights, int64_t* exp_counts, float* l_aux, ug_stream_t stream);
+
+/* Combine over a token's K <= 2 (expert, slot) pairs - einsum("sec,ecm->sm") src/UniGenUtils.py:183 with top2gating's combine weights:
+ *   eh = bf16( sum_k bf16(weights[k][s]) * yh[idx[k][s]][slot[k][s]] )   (fp32 sum, one rounding; dropped choices contribute nothing),
+ * ec likewise; residual sums, row map and `accumulate` exactly as ug_moe_combine. weights / idx / slot: [K][kstride], kstride >= S
+ * (a slice of a longer token axis keeps its parent's stride). K = 1 with weights = the gate probability reproduces ug_moe_combine. */
+int ug_moe_combine_topk(const void* yh, const void* yc, const float* weights, const int32_t* idx, const int32_t* slot, int32_t K,
+                        int64_t kstride, int32_t E, int64_t capacity, const void* xs, const void* cs, int64_t ld_s, int64_t s_rpb,
+                        int64_t s_bstride, void* out, int64_t ldo, int64_t S, int64_t D, int32_t accumulate, ug_stream_t stream);
+
 /* Dispatch + expert modulation prologue (replaces einsum("sec,sm->ecm") src/UniGenUtils.py:140 and the s-scaling of
  * modulated_flatten src/UniGenUtils.py:204-228):
  *   out[e][slot][:] = bf16( mod[e][sample(tok)][:] * bf16( x[tok][:] + (add ? add[e][slot][:] : 0) ) ), zeros for empty slots.
@@ -279,6 +306,11 @@ int ug_gather_rows_f32(const void* src, int64_t ld_src, const int32_t* idx, void
                        ug_stream_t stream);
 int ug_moe_gate_top1_f32(const void* x, const void* c, int64_t ld, const void* wg, int64_t S, int64_t D, int32_t E,
                          float* gates, int32_t* idx, ug_stream_t stream);
+int ug_moe_gate_top2_f32(const void* x, const void* c, int64_t ld, const void* wg, int64_t S, int64_t D, int32_t E, const float* noise,
+                         float* gates, int32_t* idx, ug_stream_t stream);
+int ug_moe_combine_topk_f32(const void* yh, const void* yc, const float* weights, const int32_t* idx, const int32_t* slot, int32_t K,
+                            int64_t kstride, int32_t E, int64_t capacity, const void* xs, const void* cs, int64_t ld_s, int64_t s_rpb,
+                            int64_t s_bstride, void* out, int64_t ldo, int64_t S, int64_t D, int32_t accumulate, ug_stream_t stream);
 int ug_moe_dispatch_modulate_f32(const void* x, int64_t ldx, const void* add, const void* mod, int64_t mod_estride, int64_t mod_bstride,
                                  const int32_t* token_of_slot, int32_t E, int64_t capacity, int64_t tokens_per_sample,
                                  int64_t D, void* out, ug_stream_t stream);

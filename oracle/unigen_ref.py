@@ -20,7 +20,7 @@ Everything else is UNPINNED: it restates
 and the published algorithms of its un-vendored dependencies, pinned in /root/reference/environment.yaml:
   diffusers==0.32.2 (FluxTransformerBlock, FluxSingleTransformerBlock, FluxAttnProcessor2_0, AdaLayerNormZero*,
   FluxPosEmbed, apply_rotary_emb, CombinedTimestepTextProjEmbeddings, FlowMatchEulerDiscreteScheduler),
-  deepspeed==0.16.5 (sharded_moe.top1gating / TopKGate), peft==0.15.0 (LoRA Linear)
+  deepspeed==0.16.5 (sharded_moe.top1gating / top2gating / TopKGate), peft==0.15.0 (LoRA Linear)
 and is pinned against drift only by fixtures this file generated itself (tests/golden/make_golden.py).
 
 Everything runs on a flat `state` dict {reference state-dict key: tensor}. `dtype` chooses the arithmetic:
@@ -299,6 +299,97 @@ def routing_from_gates(gates: torch.Tensor, uniform: torch.Tensor, capacity: int
     return idx, slot, token_of_slot
 
 
+def top2gating(logits: torch.Tensor, noise: Optional[torch.Tensor], capacity: int):
+    """deepspeed 0.16.5 deepspeed.moe.sharded_moe.top2gating(drop_tokens=True, top2_2nd_expert_sampling=True) - what TopKGate calls for k = 2,
+    i.e. control_params.top_num = 2 (src/UniGenTransformer.py:162,197 / :808,857 / :1565,1650; src/UniGenUtils.py:33-36 passes k and the
+    defaults capacity_factor = 1, min_capacity = 4, drop_tokens, top2_2nd_expert_sampling). deepspeed is not in /root/reference: restated
+    from its published source, statement by statement; the Gumbel(0, 1) sample it draws from the device RNG (gumbel_rsample) is passed in
+    (None = top2_2nd_expert_sampling off). `capacity` = _capacity(gates, capacity_factor * 2, min_capacity) = moe_capacity(S, E, 2.0).
+    Returns l_aux, combine_weights [S,E,C] fp32, dispatch_mask [S,E,C] bool, exp_counts [E] int64. PARITY UNPINNED."""
+    S, E = logits.shape
+    gates = F.softmax(logits, dim=1)
+    indices1_s = torch.argmax(gates, dim=1)
+    mask1 = F.one_hot(indices1_s, num_classes=E)
+    if noise is not None:
+        logits = logits + noise                                        # logits += gumbel_rsample(...)
+    logits_except1 = logits.masked_fill(mask1.bool(), float("-inf"))
+    indices2_s = torch.argmax(logits_except1, dim=1)
+    mask2 = F.one_hot(indices2_s, num_classes=E)
+    locations1 = torch.cumsum(mask1, dim=0) - 1
+    locations2 = torch.cumsum(mask2, dim=0) - 1
+    locations2 = locations2 + torch.sum(mask1, dim=0, keepdim=True)    # second choices queue behind every first choice of the expert
+    me = torch.mean(gates, dim=0)
+    ce = torch.mean(mask1.float(), dim=0)
+    l_aux = torch.mean(me * ce) * E * E
+    exp_counts = torch.sum(mask1 + mask2, dim=0).detach()
+    mask1 = mask1 * torch.lt(locations1, capacity)
+    mask2 = mask2 * torch.lt(locations2, capacity)
+    locations1_s = torch.sum(locations1 * mask1, dim=1)
+    locations2_s = torch.sum(locations2 * mask2, dim=1)
+    mask1_float, mask2_float = mask1.float(), mask2.float()
+    gates1_s = torch.einsum("se,se->s", gates, mask1_float)
+    gates2_s = torch.einsum("se,se->s", gates, mask2_float)
+    denom_s = torch.clamp(gates1_s + gates2_s, min=torch.finfo(gates.dtype).eps)
+    gates1_s = gates1_s / denom_s
+    gates2_s = gates2_s / denom_s
+    gates1 = torch.einsum("s,se->se", gates1_s, mask1_float)
+    gates2 = torch.einsum("s,se->se", gates2_s, mask2_float)
+    locations1_sc = F.one_hot(locations1_s, num_classes=capacity).float()
+    locations2_sc = F.one_hot(locations2_s, num_classes=capacity).float()
+    combine_weights = torch.einsum("se,sc->sec", gates1, locations1_sc) + torch.einsum("se,sc->sec", gates2, locations2_sc)
+    dispatch_mask = combine_weights.bool()
+    return l_aux, combine_weights, dispatch_mask, exp_counts
+
+
+def routing_top2(gates: torch.Tensor, logits: torch.Tensor, noise: Optional[torch.Tensor], capacity: int, idx: Optional[torch.Tensor] = None):
+    """Index form of top2gating: idx [2, S] (first / second choice), slot [2, S] (-1 = dropped), token_of_slot [E, capacity], weights [2, S] fp32
+    (the normalised gate probabilities, 0 for a dropped choice). Used to check the dense form and the HIP kernels. `idx`: take the two choices
+    as given (a device's, which may differ from the host's on floating-point near-ties) and restate only what follows from them."""
+    S, E = gates.shape
+    if idx is None:
+        i1 = torch.argmax(gates, dim=1)
+        noisy = logits if noise is None else logits + noise
+        i2 = torch.argmax(noisy.masked_fill(F.one_hot(i1, num_classes=E).bool(), float("-inf")), dim=1)
+        idx = torch.stack([i1, i2])
+    i1, i2 = idx[0], idx[1]
+    slot = torch.full((2, S), -1, dtype=torch.int64)
+    token_of_slot = torch.full((E, capacity), -1, dtype=torch.int64)
+    for e in range(E):
+        fill = 0
+        for k in range(2):
+            toks = torch.nonzero(idx[k] == e).flatten()
+            loc = fill + torch.arange(toks.numel())
+            keep = loc < capacity
+            slot[k, toks[keep]] = loc[keep]
+            token_of_slot[e, loc[keep]] = toks[keep]
+            fill += toks.numel()
+    ar = torch.arange(S)
+    g = torch.stack([gates[ar, i1], gates[ar, i2]]) * (slot >= 0).float()
+    weights = g / torch.clamp(g.sum(0, keepdim=True), min=torch.finfo(gates.dtype).eps)
+    return idx, slot, token_of_slot, weights
+
+
+def gate_route(logits: torch.Tensor, draw: Optional[torch.Tensor], top_num: int = 1):
+    """TopKGate.forward's dispatch on k (deepspeed 0.16.5: k = 1 -> top1gating, k = 2 -> top2gating) with the capacity each computes for the
+    reference's settings. `draw`: the random sample the gating function takes from the device RNG - the Uniform(0,1) of Random Token
+    Selection for k = 1, the Gumbel(0,1) added to the logits for k = 2. Returns (l_aux, combine_weights, dispatch_mask, exp_counts, routing)."""
+    S, E = logits.shape
+    gates = F.softmax(logits, dim=1)
+    if top_num == 1:
+        C = moe_capacity(S, E)
+        l_aux, cw, dm, exp_counts = top1gating(logits, draw, C)
+        idx, slot, tos = routing_from_gates(gates, draw, C)
+        routing = dict(gates=gates, idx=idx, slot=slot, token_of_slot=tos, capacity=C, logits=logits)
+    elif top_num == 2:
+        C = moe_capacity(S, E, capacity_factor=2.0)
+        l_aux, cw, dm, exp_counts = top2gating(logits, draw, C)
+        idx, slot, tos, weights = routing_top2(gates, logits, draw, C)
+        routing = dict(gates=gates, idx=idx, slot=slot, token_of_slot=tos, capacity=C, logits=logits, weights=weights)
+    else:
+        raise ValueError("top_num > 2 (deepspeed topkgating) is not restated: no configuration of the reference uses it")
+    return l_aux, cw, dm, exp_counts, routing
+
+
 def modulated_flatten_literal(x: torch.Tensor, w: torch.Tensor, s: torch.Tensor) -> torch.Tensor:
     """src/UniGenUtils.py:204-228, 3-D `s` branch, verbatim semantics (materialises b x n x o x i): tiny sizes only."""
     w = w.unsqueeze(0).unsqueeze(1) * s.unsqueeze(2)
@@ -342,10 +433,8 @@ def comoe_experts(state: State, cfg: FluxConfig, x, c, pooled, cond_pooled, gate
     choice = (x + c).reshape(S, D)
     wg = state["moe.moe_layer.gate.wg.weight"]
     logits = F.linear(choice.float(), wg.float())           # TopKGate.forward: fp32 input and weight
-    C = moe_capacity(S, E)
-    l_aux, combine_weights, dispatch_mask, exp_counts = top1gating(logits, uniform, C)
-    gates = F.softmax(logits, dim=1)
-    idx, slot, token_of_slot = routing_from_gates(gates, uniform, C)
+    l_aux, combine_weights, dispatch_mask, exp_counts, routing = gate_route(logits, uniform, cfg.top_num)
+    C, token_of_slot = routing["capacity"], routing["token_of_slot"]
 
     def dispatch(t2d):  # einsum("sec,sm->ecm") with a one-hot mask == row gather, zeros for empty slots
         out = torch.zeros(E, C, t2d.shape[-1], dtype=t2d.dtype)
@@ -367,7 +456,6 @@ def comoe_experts(state: State, cfg: FluxConfig, x, c, pooled, cond_pooled, gate
     cw = combine_weights.to(dt)
     eh = torch.einsum("sec,ecm->sm", cw, yh).reshape(B, N, D)
     ec = torch.einsum("sec,ecm->sm", cw, yc).reshape(B, N, D)
-    routing = dict(gates=gates, idx=idx, slot=slot, token_of_slot=token_of_slot, capacity=C, logits=logits)
     return eh, ec, l_aux, exp_counts, routing
 
 
@@ -697,6 +785,7 @@ class SD3Config:
     use_shared_expert: bool = True
     expert_num_each_condition: int = 3
     expert_num: Optional[int] = None
+    top_num: int = 1
 
     @property
     def inner_dim(self) -> int:
@@ -827,14 +916,12 @@ def sd3_comoe(state: State, cfg: SD3Config, x, c, ctrl_enc, control_temb, condit
     E, S, H, dt = cfg.expert_nums, B * N, cfg.num_attention_heads, x.dtype
     if cfg.use_modulate:
         fcfg = FluxConfig(attention_head_dim=cfg.attention_head_dim, num_attention_heads=H, condition_nums=cfg.condition_nums,
-                          expert_num_each_condition=cfg.expert_num_each_condition, expert_num=cfg.expert_num)
+                          expert_num_each_condition=cfg.expert_num_each_condition, expert_num=cfg.expert_num, top_num=cfg.top_num)
         eh, ec, l_aux, exp_counts, routing = comoe_experts(state, fcfg, x, c, pooled, cond_pooled, None, uniform)
     else:
         logits = F.linear((x + c).reshape(S, D).float(), state["moe.moe_layer.gate.wg.weight"].float())
-        C = moe_capacity(S, E)
-        l_aux, combine_weights, _, exp_counts = top1gating(logits, uniform, C)
-        gates = F.softmax(logits, dim=1)
-        idx, slot, tos = routing_from_gates(gates, uniform, C)
+        l_aux, combine_weights, _, exp_counts, routing = gate_route(logits, uniform, cfg.top_num)
+        C, tos = routing["capacity"], routing["token_of_slot"]
 
         def dispatch(t2d):
             out = torch.zeros(E, C, t2d.shape[-1], dtype=t2d.dtype)
@@ -853,7 +940,6 @@ def sd3_comoe(state: State, cfg: SD3Config, x, c, ctrl_enc, control_temb, condit
         cw = combine_weights.to(dt)
         eh = torch.einsum("sec,ecm->sm", cw, torch.stack(yh)).reshape(B, N, D)
         ec = torch.einsum("sec,ecm->sm", cw, torch.stack(yc)).reshape(B, N, D)
-        routing = dict(gates=gates, idx=idx, slot=slot, token_of_slot=tos, capacity=C)
     if not cfg.use_shared_expert:
         return eh, ec, l_aux, exp_counts, routing
     cond_s, x_s = sd3_joint_block(state, "shared_expert.0", H, x, c, condition_temb, context_pre_only=False, dual=False)

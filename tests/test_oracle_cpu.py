@@ -82,6 +82,58 @@ def test_top1gating_dense_equals_index_form():
     assert R.moe_capacity(10, 6) == 4 and R.moe_capacity(16384, 6) == 2731
 
 
+def test_top2gating_dense_equals_index_form():
+    """deepspeed top2gating (k = 2, control_params.top_num = 2): the S x E x C tensors say what (idx, slot, weights) say - first choices take an
+    expert's slots in token order, second choices queue behind ALL its first choices, whatever lands at or beyond the capacity is dropped,
+    the two kept gate probabilities are normalised by their sum - with and without the Gumbel draw, and through comoe_experts' two paths."""
+    g = torch.Generator().manual_seed(0)
+    for S, E in [(200, 6), (64, 3), (37, 2)]:
+        logits = torch.randn(S, E, generator=g) * 2
+        logits[:, 1] += 1.5
+        noise = -torch.log(-torch.log(torch.rand(S, E, generator=g).clamp_(1e-7, 1 - 1e-7)))
+        for nz in (noise, None):
+            C = R.moe_capacity(S, E, capacity_factor=2.0)
+            assert C == max(-(-2 * S // E), 4)
+            l_aux, cw, dm, cnt = R.top2gating(logits, nz, C)
+            gates = F.softmax(logits, dim=1)
+            idx, slot, tos, w = R.routing_top2(gates, logits, nz, C)
+            assert torch.equal(idx[0], gates.argmax(1)) and bool((idx[0] != idx[1]).all())
+            assert torch.equal(cnt, torch.stack([(idx == e).sum() for e in range(E)])) and int(cnt.sum()) == 2 * S
+            dense = torch.zeros_like(cw)
+            for k in range(2):
+                for s in range(S):
+                    if slot[k, s] >= 0:
+                        dense[s, idx[k, s], slot[k, s]] += w[k, s]
+                        assert int(tos[idx[k, s], slot[k, s]]) == s
+            assert torch.equal(dense, cw) and torch.equal(dm, cw.bool())
+            kept = (slot >= 0).float()
+            assert torch.allclose((w * kept).sum(0)[kept.sum(0) > 0], torch.ones(int((kept.sum(0) > 0).sum())), atol=1e-6)      # normalised over the kept choices
+            for e in range(E):
+                n1 = int((idx[0] == e).sum())
+                first, second = torch.nonzero(idx[0] == e).flatten(), torch.nonzero(idx[1] == e).flatten()
+                assert torch.equal(slot[0, first[:C]], torch.arange(min(n1, C)))                       # token order, first choices first
+                assert bool((slot[0, first[C:]] == -1).all())
+                room = max(C - n1, 0)
+                assert torch.equal(slot[1, second[:room]], n1 + torch.arange(min(room, second.numel()))) and bool((slot[1, second[room:]] == -1).all())
+            if E > 2 and nz is None:
+                assert torch.equal(idx[1], torch.topk(logits, 2, dim=1)[1][:, 1])                      # no sampling: the second-largest logit
+            me, ce = gates.mean(0), F.one_hot(idx[0], E).float().mean(0)
+            assert abs(float(l_aux) - float((me * ce).mean() * E * E)) < 1e-6
+    with pytest.raises(ValueError):
+        R.gate_route(torch.randn(8, 4), None, 3)
+    # the literal dense-einsum path of MOELayer.forward and the index path give the same CoMoE output with two choices per token
+    cfg = R.FluxConfig(top_num=2, **TINY)
+    st = {k: v.float() for k, v in R.make_state(cfg, seed=3, std=0.05, bias_std=0.02).items()}
+    B, N, D = 2, 16, cfg.inner_dim
+    x, c = torch.randn(B, N, D, generator=g), torch.randn(B, N, D, generator=g)
+    pooled, cpooled = torch.randn(B, 64, generator=g), torch.randn(B, 64, generator=g)
+    noise = -torch.log(-torch.log(torch.rand(B * N, cfg.expert_nums, generator=g).clamp_(1e-7, 1 - 1e-7)))
+    a = R.comoe_experts(st, cfg, x, c, pooled, cpooled, None, noise, literal=True)
+    b = R.comoe_experts(st, cfg, x, c, pooled, cpooled, None, noise, literal=False)
+    assert torch.allclose(a[0], b[0], rtol=1e-4, atol=1e-5) and torch.allclose(a[1], b[1], rtol=1e-4, atol=1e-5)
+    assert torch.equal(a[3], b[3]) and int(a[3].sum()) == 2 * B * N
+
+
 def test_modulated_flatten_literal_equals_linear_of_scaled_input():
     """src/UniGenUtils.py:204-228 (b x n x o x i temp) == Linear_W(s * x): the restatement used at scale."""
     g = torch.Generator().manual_seed(1)

@@ -30,17 +30,22 @@ def _step(fwd, target, dtype):
     return out.detach(), float(loss), extra
 
 
-@pytest.mark.parametrize("n_cond,cls_name", [(1, "UniGenFlux"), (2, "MultiCondtionUniGenFlux")])
-def test_control_module_gradients_match_oracle_autograd(gpu, n_cond, cls_name):
+@pytest.mark.parametrize("n_cond,cls_name,top_num", [(1, "UniGenFlux", 1), (2, "MultiCondtionUniGenFlux", 1), (1, "UniGenFlux", 2)])
+def test_control_module_gradients_match_oracle_autograd(gpu, n_cond, cls_name, top_num):
+    """top_num = 2: deepspeed top2gating - the gradient reaches the gate through BOTH kept probabilities and their normalising sum."""
     import importlib
     cls = getattr(importlib.import_module("src.UniGenTransformer"), cls_name)
     B, grid, T = 2, 8, 64                     # N = 64 image tokens, every joint length a multiple of 64 (attention backward contraction lengths)
-    rcfg = R.FluxConfig(condition_nums=n_cond, **TINY)
+    CONTROL = dict(globals()["CONTROL"], top_num=top_num)
+    rcfg = R.FluxConfig(condition_nums=n_cond, top_num=top_num, **TINY)
     base = cls.from_config(dict(TINY), device=gpu, dtype=BF)
     base.init_condition_block(condition_nums=n_cond, condition_types=["canny", "depth"][:n_cond], control_params=dict(CONTROL))
     base.init_synthetic_(seed=3, std=0.05, bias_std=0.02)
     state = {k: v.detach().cpu() for k, v in base.state_dict().items()}
     inp = R.make_inputs(rcfg, B=B, grid=grid, T=T, n_cond=n_cond)
+    if top_num == 2:                          # the gate's random draw is the Gumbel(0, 1) sample of the second choice
+        u = torch.rand(B * grid * grid, rcfg.expert_nums, generator=torch.Generator().manual_seed(8)).clamp_(1e-7, 1 - 1e-7)
+        inp["gate_uniform"] = -torch.log(-torch.log(u))
     t = torch.full((B,), 0.75, dtype=BF)
     target = torch.randn(B, grid * grid, 64, generator=torch.Generator().manual_seed(5))
     base.init_trainable_param()
@@ -72,7 +77,7 @@ def test_control_module_gradients_match_oracle_autograd(gpu, n_cond, cls_name):
     rel = lambda a, b: float((a - b).norm() / b.norm())
     # fp32 verification path
     out32, loss32, g32, _ = hip_grads(torch.float32)
-    m = report(f"train_{cls_name}_f32_forward", out32, truth_out)
+    m = report(f"train_{cls_name}_k{top_num}_f32_forward", out32, truth_out)
     e_all = rel(cat(g32), cat(truth))
     floor = 1e-3 * float(cat(truth).norm()) / len(names) ** 0.5          # gradients that are themselves rounding noise (e.g. a key bias) do not count
     worst = max((float((z(g32, k) - truth[k]).norm() / max(float(truth[k].norm()), floor)), k) for k in live)
@@ -84,9 +89,9 @@ def test_control_module_gradients_match_oracle_autograd(gpu, n_cond, cls_name):
     out16, loss16, g16, extra = hip_grads(BF)
     e_hip, e_ref = rel(cat(g16), cat(truth)), rel(cat(gref), cat(truth))
     print(f"training bf16: loss {loss16:.5f} (oracle bf16 {ref_loss:.5f}, fp32 {truth_loss:.5f}); gradients vs fp32: hip {e_hip:.3e}, oracle bf16 {e_ref:.3e}")
-    report(f"train_{cls_name}_bf16_grads", cat(g16), cat(truth), err_hip_vs_fp32=e_hip, err_oraclebf16_vs_fp32=e_ref)
+    report(f"train_{cls_name}_k{top_num}_bf16_grads", cat(g16), cat(truth), err_hip_vs_fp32=e_hip, err_oraclebf16_vs_fp32=e_ref)
     assert e_hip <= 1.5 * e_ref + 5e-3 and abs(loss16 - truth_loss) <= 3e-2 * abs(truth_loss), (e_hip, e_ref, loss16, truth_loss)
-    assert int(extra["expert_counts"].sum()) == B * grid * grid
+    assert int(extra["expert_counts"].sum()) == top_num * B * grid * grid
 
 
 SD3_TINY = dict(sample_size=16, num_layers=3, attention_head_dim=64, num_attention_heads=2, joint_attention_dim=64, caption_projection_dim=128,

@@ -266,16 +266,21 @@ def linear_n(x: torch.Tensor, ws, bs):
 
 class MoeGate(torch.autograd.Function):
     """gates = softmax(F.linear((x + c).float(), wg.float())) [S, E] fp32 and the arg-max expert per token: ug_moe_gate_top1 forward,
-    ug_moe_gate_bwd backward (deepspeed TopKGate, src/UniGenUtils.py:99). idx is not differentiable."""
+    ug_moe_gate_bwd backward (deepspeed TopKGate, src/UniGenUtils.py:99). top_k = 2 (top2gating): ug_moe_gate_top2, idx [2, S] with the second
+    choice drawn through `noise` (the Gumbel sample added to the logits). idx is not differentiable, and neither is the noised arg-max."""
 
     @staticmethod
-    def forward(ctx, x, c, wg):
+    def forward(ctx, x, c, wg, top_k=1, noise=None):
         S, D = x.shape
         E = wg.shape[0]
         gates = torch.empty(S, E, device=x.device, dtype=torch.float32)
-        idx = torch.empty(S, device=x.device, dtype=torch.int32)
         wgc = wg.contiguous()
-        ops.moe_gate_top1(x, c, wgc, gates, idx)
+        if top_k == 1:
+            idx = torch.empty(S, device=x.device, dtype=torch.int32)
+            ops.moe_gate_top1(x, c, wgc, gates, idx)
+        else:
+            idx = torch.empty(2, S, device=x.device, dtype=torch.int32)
+            ops.moe_gate_top2(x, c, wgc, noise, gates, idx)
         ctx.save_for_backward(gates, x, c, wgc)
         ctx.mark_non_differentiable(idx)
         return gates, idx
@@ -284,7 +289,7 @@ class MoeGate(torch.autograd.Function):
     def backward(ctx, dgates, _didx):
         gates, x, c, wg = ctx.saved_tensors
         dxc, dwg = ops.moe_gate_bwd(gates, dgates.float().contiguous(), x, c, wg)
-        return (dxc if ctx.needs_input_grad[0] else None), (dxc if ctx.needs_input_grad[1] else None), (dwg if ctx.needs_input_grad[2] else None)
+        return (dxc if ctx.needs_input_grad[0] else None), (dxc if ctx.needs_input_grad[1] else None), (dwg if ctx.needs_input_grad[2] else None), None, None
 
 
 def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor]) -> torch.Tensor:

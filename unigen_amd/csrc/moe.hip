@@ -11,10 +11,12 @@ namespace {
 constexpr int GATE_MAXE = 16;
 
 // one wave per token: logits[e] = sum_d bf16(x+c)[d] * wg[e][d] in fp32 (TopKGate: F.linear(input.float(), wg.float()))
-template <typename T>
+// TOP2 (deepspeed top2gating): idx[S + s] = the arg-max of logits + noise over the experts other than the first choice (the Gumbel-max draw of
+// `top2_2nd_expert_sampling`; noise == nullptr: the plain second-largest logit).
+template <typename T, bool TOP2>
 __global__ __launch_bounds__(256) void moe_gate_kernel(const T* __restrict__ x, const T* __restrict__ c, int64_t ld,
                                                        const T* __restrict__ wg, int64_t S, int D, int E,
-                                                       float* __restrict__ gates, int32_t* __restrict__ idx) {
+                                                       const float* __restrict__ noise, float* __restrict__ gates, int32_t* __restrict__ idx) {
     using EL = ElemT<T>;
     const int lane = threadIdx.x & 63;
     const int64_t s = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -48,6 +50,18 @@ __global__ __launch_bounds__(256) void moe_gate_kernel(const T* __restrict__ x, 
             if (acc[e] > mx) { mx = acc[e]; best = e; }     // first maximum wins, as torch.argmax
         }
     }
+    int second = 0;
+    if constexpr (TOP2) {
+        float m2 = -INFINITY;
+        second = best == 0 ? 1 : 0;
+#pragma unroll
+        for (int e = 0; e < GATE_MAXE; ++e) {
+            if (e < E && e != best) {                       // logits.masked_fill(mask1, -inf) after logits += gumbel
+                const float v = acc[e] + (noise ? noise[s * E + e] : 0.f);
+                if (v > m2) { m2 = v; second = e; }
+            }
+        }
+    }
     float den = 0.f;
 #pragma unroll
     for (int e = 0; e < GATE_MAXE; ++e)
@@ -55,6 +69,7 @@ __global__ __launch_bounds__(256) void moe_gate_kernel(const T* __restrict__ x, 
     if (lane == 0) {
         for (int e = 0; e < E; ++e) gates[s * E + e] = acc[e] / den;
         idx[s] = best;
+        if constexpr (TOP2) idx[S + s] = second;
     }
 }
 
@@ -150,22 +165,70 @@ __global__ __launch_bounds__(1024) void moe_capacity_kernel(const int32_t* __res
     for (int c = base_kept + tid; c < capacity; c += 1024) token_of_slot[(int64_t)e * capacity + c] = -1;
 }
 
-// l_aux = E * sum_e mean_s(gates[s][e]) * (exp_counts[e] / S); single block, fixed summation order
-__global__ __launch_bounds__(1024) void moe_laux_kernel(const float* __restrict__ gates, const int64_t* __restrict__ exp_counts,
+// deepspeed top2gating's capacity rule (no random token selection): first choices take an expert's slots in token order, second choices follow
+// behind ALL its first choices (locations2 += sum(mask1)); whatever lands at or beyond `capacity` is dropped. One block (1024 threads) per
+// expert. idx / slot are [2][S] (choice-major); exp_counts = first + second choices before the drop (torch.sum(mask1 + mask2, dim=0)).
+__global__ __launch_bounds__(1024) void moe_capacity_top2_kernel(const int32_t* __restrict__ idx, int S, int capacity, int32_t* __restrict__ slot,
+                                                                 int32_t* __restrict__ token_of_slot, int64_t* __restrict__ exp_counts) {
+    __shared__ int wsum[17];
+    const int e = blockIdx.x;
+    const int tid = threadIdx.x;
+    int base = 0;
+    for (int k = 0; k < 2; ++k) {
+        const int32_t* ik = idx + (int64_t)k * S;
+        int32_t* sk = slot + (int64_t)k * S;
+        for (int s0 = 0; s0 < S; s0 += 1024) {
+            const int s = s0 + tid;
+            const bool mine = s < S && ik[s] == e;
+            int tot;
+            const int r = block_excl_scan(mine ? 1 : 0, wsum, &tot);
+            if (mine) {
+                const int loc = base + r;
+                const bool kept = loc < capacity;
+                sk[s] = kept ? loc : -1;
+                if (kept) token_of_slot[(int64_t)e * capacity + loc] = s;
+            }
+            base += tot;
+        }
+    }
+    if (tid == 0) exp_counts[e] = (int64_t)base;
+    for (int c = base + tid; c < capacity; c += 1024) token_of_slot[(int64_t)e * capacity + c] = -1;
+}
+
+// combine weights of top2gating: the two gate probabilities of a token (zero for a dropped choice) normalised by their sum clamped at
+// finfo(float32).eps. weights [2][S].
+__global__ __launch_bounds__(256) void moe_weights_top2_kernel(const float* __restrict__ gates, const int32_t* __restrict__ idx,
+                                                               const int32_t* __restrict__ slot, int S, int E, float* __restrict__ weights) {
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= S) return;
+    const float g1 = slot[s] >= 0 ? gates[(int64_t)s * E + idx[s]] : 0.f;
+    const float g2 = slot[S + s] >= 0 ? gates[(int64_t)s * E + idx[S + s]] : 0.f;
+    const float den = fmaxf(g1 + g2, 1.1920928955078125e-07f);
+    weights[s] = g1 / den;
+    weights[S + s] = g2 / den;
+}
+
+// l_aux = E * sum_e mean_s(gates[s][e]) * (n_e / S), n_e = tokens whose FIRST choice is e: exp_counts[e] (top-1: the same thing) or, when
+// idx1 is given (top-2: exp_counts holds both choices), counted from idx1; single block, fixed summation order
+__global__ __launch_bounds__(1024) void moe_laux_kernel(const float* __restrict__ gates, const int64_t* __restrict__ exp_counts, const int32_t* __restrict__ idx1,
                                                         int S, int E, float* __restrict__ l_aux) {
     __shared__ float part[16];
+    __shared__ int ipart[16];
     __shared__ float terms[GATE_MAXE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int e = 0; e < E; ++e) {
         float a = 0.f;
-        for (int s = tid; s < S; s += 1024) a += gates[(int64_t)s * E + e];
+        int n = 0;
+        for (int s = tid; s < S; s += 1024) { a += gates[(int64_t)s * E + e]; if (idx1) n += (idx1[s] == e); }
         a = wave_sum(a);
-        if (lane == 0) part[wave] = a;
+        for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);
+        if (lane == 0) { part[wave] = a; ipart[wave] = n; }
         __syncthreads();
         if (tid == 0) {
             float t = 0.f;
-            for (int w = 0; w < 16; ++w) t += part[w];
-            terms[e] = (t / (float)S) * ((float)exp_counts[e] / (float)S);
+            int nt = 0;
+            for (int w = 0; w < 16; ++w) { t += part[w]; nt += ipart[w]; }
+            terms[e] = (t / (float)S) * ((idx1 ? (float)nt : (float)exp_counts[e]) / (float)S);
         }
         __syncthreads();
     }
@@ -266,20 +329,78 @@ __global__ __launch_bounds__(256) void moe_combine_kernel(const T* __restrict__ 
     }
 }
 
+// top-k combine (k = 2: deepspeed top2gating): einsum("sec,ecm->sm") over a token's K (expert, slot) pairs in the activation dtype =
+// ONE rounding of the fp32 sum of the products  weight_k.type_as(y) * y[e_k][slot_k]; the residual sums around it as in moe_combine_kernel.
+// weights fp32 / idx / slot: [K][kstride].
+template <typename T>
+__global__ __launch_bounds__(256) void moe_combine_topk_kernel(const T* __restrict__ yh, const T* __restrict__ yc,
+                                                               const float* __restrict__ weights, const int32_t* __restrict__ idx,
+                                                               const int32_t* __restrict__ slot, int K, int64_t kstride, int capacity,
+                                                               const T* __restrict__ xs, const T* __restrict__ cs, int64_t ld_s,
+                                                               int64_t s_rpb, int64_t s_bstride,
+                                                               T* __restrict__ out, int64_t ldo, int64_t S, int D, int accumulate) {
+    using EL = ElemT<T>;
+    const int lane = threadIdx.x & 63;
+    const int64_t s = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (s >= S) return;
+    const int64_t srow = ug_rowmap(s, s_rpb, s_bstride);
+    const int nchunk = D >> 3;
+    for (int ch = lane; ch < nchunk; ch += 64) {
+        float h[8], c[8], o[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { h[i] = 0.f; c[i] = 0.f; }
+        for (int k = 0; k < K; ++k) {
+            const int sl = slot[k * kstride + s];
+            if (sl < 0) continue;
+            const float p = EL::rnd(weights[k * kstride + s]);
+            const int64_t yrow = ((int64_t)idx[k * kstride + s] * capacity + sl) * D;
+            float a[8], b[8];
+            EL::load8(yh + yrow + ch * 8, a);
+            EL::load8(yc + yrow + ch * 8, b);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { h[i] = fmaf(p, a[i], h[i]); c[i] = fmaf(p, b[i], c[i]); }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { h[i] = EL::rnd(h[i]); c[i] = EL::rnd(c[i]); }
+        if (xs) {
+            float a[8], b[8];
+            EL::load8(xs + srow * ld_s + ch * 8, a);
+            EL::load8(cs + srow * ld_s + ch * 8, b);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = EL::rnd(a[i] + h[i]) + EL::rnd(b[i] + c[i]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = h[i] + c[i];
+        }
+        if (accumulate) {
+            float prev[8];
+            EL::load8(out + s * ldo + ch * 8, prev);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = prev[i] + EL::rnd(o[i]);
+        }
+        EL::store8(out + s * ldo + ch * 8, o);
+    }
+}
+
 }  // namespace
 
 namespace {
 
 template <typename T>
-int moe_gate_impl(const void* x, const void* c, int64_t ld, const void* wg, int64_t S, int64_t D, int32_t E, float* gates, int32_t* idx, ug_stream_t stream) {
+int moe_gate_impl(const void* x, const void* c, int64_t ld, const void* wg, int64_t S, int64_t D, int32_t E, const float* noise, bool top2, float* gates,
+                  int32_t* idx, ug_stream_t stream) {
     if (S == 0) return UG_OK;
     UG_REQUIRE(x && c && wg && gates && idx && S > 0 && D > 0, UG_ERR_BAD_SHAPE, "ug_moe_gate_top1: bad arguments");
-    UG_REQUIRE(E >= 1 && E <= GATE_MAXE, UG_ERR_UNSUPPORTED, "ug_moe_gate_top1: E=%d not in [1,%d]", E, GATE_MAXE);
+    UG_REQUIRE(E >= (top2 ? 2 : 1) && E <= GATE_MAXE, UG_ERR_UNSUPPORTED, "ug_moe_gate_top%d: E=%d not in [%d,%d]", top2 ? 2 : 1, E, top2 ? 2 : 1, GATE_MAXE);
     UG_REQUIRE(D % 8 == 0 && ld % 8 == 0 && ug_aligned(x, 16) && ug_aligned(c, 16) && ug_aligned(wg, 16), UG_ERR_BAD_ALIGN,
                "ug_moe_gate_top1: 16-byte alignment required");
-    hipLaunchKernelGGL(moe_gate_kernel<T>, dim3((unsigned)((S + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const T*)x,
-                       (const T*)c, ld, (const T*)wg, S, (int)D, (int)E, gates, idx);
-    UG_CHECK_LAUNCH("ug_moe_gate_top1");
+    if (top2)
+        hipLaunchKernelGGL((moe_gate_kernel<T, true>), dim3((unsigned)((S + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const T*)x,
+                           (const T*)c, ld, (const T*)wg, S, (int)D, (int)E, noise, gates, idx);
+    else
+        hipLaunchKernelGGL((moe_gate_kernel<T, false>), dim3((unsigned)((S + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const T*)x,
+                           (const T*)c, ld, (const T*)wg, S, (int)D, (int)E, (const float*)nullptr, gates, idx);
+    UG_CHECK_LAUNCH("ug_moe_gate");
     return UG_OK;
 }
 
@@ -316,13 +437,39 @@ int moe_combine_impl(const void* yh, const void* yc, const float* gates, const i
     return UG_OK;
 }
 
+template <typename T>
+int moe_combine_topk_impl(const void* yh, const void* yc, const float* weights, const int32_t* idx, const int32_t* slot, int32_t K, int64_t kstride,
+                          int32_t E, int64_t capacity, const void* xs, const void* cs, int64_t ld_s, int64_t s_rpb, int64_t s_bstride, void* out,
+                          int64_t ldo, int64_t S, int64_t D, int32_t accumulate, ug_stream_t stream) {
+    if (S == 0) return UG_OK;
+    UG_REQUIRE(yh && yc && weights && idx && slot && out && E > 0 && capacity > 0 && K >= 1 && K <= 2 && kstride >= S, UG_ERR_BAD_SHAPE,
+               "ug_moe_combine_topk: bad arguments");
+    UG_REQUIRE((xs == nullptr) == (cs == nullptr), UG_ERR_BAD_SHAPE, "ug_moe_combine_topk: xs and cs must both be given or both NULL");
+    UG_REQUIRE(s_rpb >= 0 && s_bstride >= 0, UG_ERR_BAD_SHAPE, "ug_moe_combine_topk: bad row map");
+    UG_REQUIRE(D % 8 == 0 && ldo % 8 == 0 && (!xs || ld_s % 8 == 0) && ug_aligned(yh, 16) && ug_aligned(yc, 16) && ug_aligned(out, 16) &&
+               (!xs || (ug_aligned(xs, 16) && ug_aligned(cs, 16))), UG_ERR_BAD_ALIGN, "ug_moe_combine_topk: 16-byte alignment required");
+    hipLaunchKernelGGL(moe_combine_topk_kernel<T>, dim3((unsigned)((S + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const T*)yh,
+                       (const T*)yc, weights, idx, slot, (int)K, kstride, (int)capacity, (const T*)xs, (const T*)cs, ld_s, s_rpb, s_bstride,
+                       (T*)out, ldo, S, (int)D, (int)accumulate);
+    UG_CHECK_LAUNCH("ug_moe_combine_topk");
+    return UG_OK;
+}
+
 }  // namespace
 
 extern "C" int ug_moe_gate_top1(const void* x, const void* c, int64_t ld, const void* wg, int64_t S, int64_t D, int32_t E, float* gates, int32_t* idx, ug_stream_t s) {
-    return moe_gate_impl<bf16_t>(x, c, ld, wg, S, D, E, gates, idx, s);
+    return moe_gate_impl<bf16_t>(x, c, ld, wg, S, D, E, nullptr, false, gates, idx, s);
 }
 extern "C" int ug_moe_gate_top1_f32(const void* x, const void* c, int64_t ld, const void* wg, int64_t S, int64_t D, int32_t E, float* gates, int32_t* idx, ug_stream_t s) {
-    return moe_gate_impl<float>(x, c, ld, wg, S, D, E, gates, idx, s);
+    return moe_gate_impl<float>(x, c, ld, wg, S, D, E, nullptr, false, gates, idx, s);
+}
+extern "C" int ug_moe_gate_top2(const void* x, const void* c, int64_t ld, const void* wg, int64_t S, int64_t D, int32_t E, const float* noise, float* gates,
+                                int32_t* idx, ug_stream_t s) {
+    return moe_gate_impl<bf16_t>(x, c, ld, wg, S, D, E, noise, true, gates, idx, s);
+}
+extern "C" int ug_moe_gate_top2_f32(const void* x, const void* c, int64_t ld, const void* wg, int64_t S, int64_t D, int32_t E, const float* noise, float* gates,
+                                    int32_t* idx, ug_stream_t s) {
+    return moe_gate_impl<float>(x, c, ld, wg, S, D, E, noise, true, gates, idx, s);
 }
 
 extern "C" int ug_moe_capacity_rts(const float* gates, const int32_t* idx, const float* uniform, int64_t S, int32_t E,
@@ -335,8 +482,23 @@ extern "C" int ug_moe_capacity_rts(const float* gates, const int32_t* idx, const
     hipLaunchKernelGGL(moe_capacity_kernel, dim3((unsigned)E), dim3(1024), 0, s, idx, uniform, (int)S, (int)E, (int)capacity, slot,
                        token_of_slot, exp_counts);
     UG_CHECK_LAUNCH("ug_moe_capacity_rts");
-    hipLaunchKernelGGL(moe_laux_kernel, dim3(1), dim3(1024), 0, s, gates, (const int64_t*)exp_counts, (int)S, (int)E, l_aux);
+    hipLaunchKernelGGL(moe_laux_kernel, dim3(1), dim3(1024), 0, s, gates, (const int64_t*)exp_counts, (const int32_t*)nullptr, (int)S, (int)E, l_aux);
     UG_CHECK_LAUNCH("ug_moe_capacity_rts(l_aux)");
+    return UG_OK;
+}
+
+extern "C" int ug_moe_capacity_top2(const float* gates, const int32_t* idx, int64_t S, int32_t E, int64_t capacity, int32_t* slot,
+                                    int32_t* token_of_slot, float* weights, int64_t* exp_counts, float* l_aux, ug_stream_t stream) {
+    UG_REQUIRE(gates && idx && slot && token_of_slot && weights && exp_counts && l_aux, UG_ERR_BAD_SHAPE, "ug_moe_capacity_top2: null argument");
+    UG_REQUIRE(S > 0 && S < (1ll << 29) && E >= 2 && E <= GATE_MAXE && capacity > 0 && capacity < (1ll << 30), UG_ERR_BAD_SHAPE,
+               "ug_moe_capacity_top2: bad S/E/capacity");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(moe_capacity_top2_kernel, dim3((unsigned)E), dim3(1024), 0, s, idx, (int)S, (int)capacity, slot, token_of_slot, exp_counts);
+    UG_CHECK_LAUNCH("ug_moe_capacity_top2");
+    hipLaunchKernelGGL(moe_weights_top2_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, s, gates, idx, (const int32_t*)slot, (int)S, (int)E, weights);
+    UG_CHECK_LAUNCH("ug_moe_capacity_top2(weights)");
+    hipLaunchKernelGGL(moe_laux_kernel, dim3(1), dim3(1024), 0, s, gates, (const int64_t*)exp_counts, idx, (int)S, (int)E, l_aux);
+    UG_CHECK_LAUNCH("ug_moe_capacity_top2(l_aux)");
     return UG_OK;
 }
 
@@ -360,4 +522,15 @@ extern "C" int ug_moe_combine_f32(const void* yh, const void* yc, const float* g
                                   int64_t capacity, const void* xs, const void* cs, int64_t ld_s, int64_t s_rpb, int64_t s_bstride, void* out, int64_t ldo,
                                   int64_t S, int64_t D, int32_t accumulate, ug_stream_t s) {
     return moe_combine_impl<float>(yh, yc, gates, idx, slot, E, capacity, xs, cs, ld_s, s_rpb, s_bstride, out, ldo, S, D, accumulate, s);
+}
+
+extern "C" int ug_moe_combine_topk(const void* yh, const void* yc, const float* weights, const int32_t* idx, const int32_t* slot, int32_t K, int64_t kstride,
+                                   int32_t E, int64_t capacity, const void* xs, const void* cs, int64_t ld_s, int64_t s_rpb, int64_t s_bstride, void* out,
+                                   int64_t ldo, int64_t S, int64_t D, int32_t accumulate, ug_stream_t s) {
+    return moe_combine_topk_impl<bf16_t>(yh, yc, weights, idx, slot, K, kstride, E, capacity, xs, cs, ld_s, s_rpb, s_bstride, out, ldo, S, D, accumulate, s);
+}
+extern "C" int ug_moe_combine_topk_f32(const void* yh, const void* yc, const float* weights, const int32_t* idx, const int32_t* slot, int32_t K, int64_t kstride,
+                                       int32_t E, int64_t capacity, const void* xs, const void* cs, int64_t ld_s, int64_t s_rpb, int64_t s_bstride, void* out,
+                                       int64_t ldo, int64_t S, int64_t D, int32_t accumulate, ug_stream_t s) {
+    return moe_combine_topk_impl<float>(yh, yc, weights, idx, slot, K, kstride, E, capacity, xs, cs, ld_s, s_rpb, s_bstride, out, ldo, S, D, accumulate, s);
 }

@@ -102,6 +102,15 @@ class _Stream:
         self.map = RowMap() if (bstride is None or bstride == Ls) else RowMap(Ls, bstride)
 
 
+class _Routing:
+    """One gate decision in index form: K choices per token; idx / slot are [S] (K = 1) or [2, S]; tos [E, C]; weights [2, S] (K = 2)."""
+    __slots__ = ("K", "E", "C", "gates", "idx", "slot", "tos", "weights", "exp_counts", "l_aux")
+
+    def __init__(self, K, E, C, gates, idx, slot, tos, weights, exp_counts, l_aux):
+        self.K, self.E, self.C, self.gates, self.idx, self.slot, self.tos = K, E, C, gates, idx, slot, tos
+        self.weights, self.exp_counts, self.l_aux = weights, exp_counts, l_aux
+
+
 class HipModule(nn.Module):
     """Base of the drop-in transformer classes: holds parameters, never computes in torch."""
 
@@ -251,6 +260,44 @@ class HipModule(nn.Module):
     # ------------------------------------------------------------------ small pieces ----------------------------------
     def _w(self, name, shape, dtype=None):
         return self._ws.get(name, shape, dtype if dtype is not None else self.dtype, self.device)
+
+    # ------------------------------------------------------------------ CoMoE routing ---------------------------------
+    def _route(self, x: torch.Tensor, c: torch.Tensor, E: int, top_k: int, draw: Optional[torch.Tensor]) -> "_Routing":
+        """TopKGate.forward on (x + c) [S, D] + deepspeed's top1gating (k = 1: capacity ceil(S / E), Random Token Selection; `draw` = its
+        Uniform(0, 1) sample [S, E]) or top2gating (k = 2: capacity ceil(2 S / E), second choice by Gumbel-max; `draw` = its Gumbel(0, 1) sample)
+        in index form (src/UniGenUtils.py:99; include/unigen_hip.h). A missing draw is taken from the device RNG, as the reference does."""
+        S, dev = x.shape[0], x.device
+        wg = self._P("moe.moe_layer.gate.wg.weight")
+        gates = self._w("moe_gates", (S, E), torch.float32)
+        exp_counts = torch.empty(E, device=dev, dtype=torch.int64)
+        l_aux = torch.empty(1, device=dev, dtype=torch.float32)
+        if top_k == 1:
+            C = max(int(math.ceil(S / E)), 4)          # deepspeed _capacity(capacity_factor=1, min_capacity=4)
+            idx, slot, tos = self._w("moe_idx", (S,), torch.int32), self._w("moe_slot", (S,), torch.int32), self._w("moe_tos", (E, C), torch.int32)
+            ops.moe_gate_top1(x, c, wg, gates, idx)
+            if draw is None:
+                draw = torch.rand(S, E, device=dev, dtype=torch.float32)   # RTS draw; the reference consumes the global device RNG too
+            ops.moe_capacity_rts(gates, idx, draw.contiguous(), C, slot, tos, exp_counts, l_aux)
+            return _Routing(1, E, C, gates, idx, slot, tos, None, exp_counts, l_aux)
+        if top_k != 2:
+            raise ValueError("top_num must be 1 or 2 (deepspeed's topkgating for k > 2 is used by no configuration of the reference)")
+        C = max(int(math.ceil((S / E) * 2.0)), 4)      # top2gating: _capacity(gates, capacity_factor * 2, min_capacity)
+        idx, slot, tos = self._w("moe_idx2", (2, S), torch.int32), self._w("moe_slot2", (2, S), torch.int32), self._w("moe_tos", (E, C), torch.int32)
+        weights = self._w("moe_w2", (2, S), torch.float32)
+        if draw is None:                               # gumbel_rsample: torch.distributions.gumbel.Gumbel(0, 1).rsample on the device
+            draw = torch.distributions.gumbel.Gumbel(torch.tensor(0.0, device=dev), torch.tensor(1.0, device=dev)).rsample((S, E))
+        ops.moe_gate_top2(x, c, wg, draw.to(torch.float32).contiguous(), gates, idx)
+        ops.moe_capacity_top2(gates, idx, C, slot, tos, weights, exp_counts, l_aux)
+        return _Routing(2, E, C, gates, idx, slot, tos, weights, exp_counts, l_aux)
+
+    def _combine(self, rt: "_Routing", yh: torch.Tensor, yc: torch.Tensor, out: torch.Tensor, rows: Optional[slice] = None, **kw) -> None:
+        """einsum("sec,ecm->sm") with the routing's combine weights, fused with the CoMoE residual sums (ops.moe_combine / moe_combine_topk);
+        rows: a slice of the token axis (one sample)."""
+        sl = rows if rows is not None else slice(None)
+        if rt.K == 1:
+            ops.moe_combine(yh, yc, rt.gates[sl], rt.idx[sl], rt.slot[sl], out, E=rt.E, capacity=rt.C, **kw)
+        else:
+            ops.moe_combine_topk(yh, yc, rt.weights[:, sl], rt.idx[:, sl], rt.slot[:, sl], out, E=rt.E, capacity=rt.C, **kw)
 
     def _time_text_embed(self, prefix: str, t_f32: torch.Tensor, pooled: torch.Tensor, g_f32: Optional[torch.Tensor], tag: str) -> torch.Tensor:
         """CombinedTimestep(Guidance)TextProjEmbeddings (diffusers embeddings.py)."""

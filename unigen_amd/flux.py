@@ -207,8 +207,10 @@ class UniGenFlux(HipModule):
             expert_nums=int(expert_num) if expert_num is not None else (condition_nums + 1) * int(get("expert_num_each_condition", 3)),
             top_k=int(get("top_num", 1)),
         )
-        if ctl.top_k != 1:
-            raise ValueError("only top-1 gating is implemented (top_num=1 in every shipped configuration)")
+        if ctl.top_k not in (1, 2):
+            raise ValueError("top_num must be 1 (deepspeed top1gating) or 2 (top2gating); topkgating (k > 2) is used by no configuration of the reference")
+        if ctl.top_k == 2 and ctl.expert_nums < 2:
+            raise ValueError("top_num = 2 needs at least two experts")
         if ctl.expert_nums > 16:
             raise ValueError("at most 16 experts are supported")
         self._ctl = ctl
@@ -324,19 +326,12 @@ class UniGenFlux(HipModule):
         and writes / accumulates expert_hidden + expert_condition into z0 [B*N, D]."""
         ctl, D, dev = self._ctl, self.inner_dim, self.device
         E, S = ctl.expert_nums, B * N
-        C = max(int(math.ceil(S / E)), 4)          # deepspeed _capacity(capacity_factor=1, min_capacity=4)
         # condition tokens -> D   (control_x_embedder, :1040)
         c = self._w("moe_c", (S, D))
         ops.gemm(cond_tokens.reshape(S, -1), self._P("control_x_embedder.weight"), self._P("control_x_embedder.bias"), c, M=S)
-        # gate on (x + c)
-        gates, idx = self._w("moe_gates", (S, E), torch.float32), self._w("moe_idx", (S,), torch.int32)
-        ops.moe_gate_top1(x, c, self._P("moe.moe_layer.gate.wg.weight"), gates, idx)
-        if uniform is None:
-            uniform = torch.rand(S, E, device=dev, dtype=torch.float32)   # RTS draw; the reference consumes the global device RNG too
-        slot, tos = self._w("moe_slot", (S,), torch.int32), self._w("moe_tos", (E, C), torch.int32)
-        exp_counts = torch.empty(E, device=dev, dtype=torch.int64)
-        l_aux = torch.empty(1, device=dev, dtype=torch.float32)
-        ops.moe_capacity_rts(gates, idx, uniform.contiguous(), C, slot, tos, exp_counts, l_aux)
+        # gate on (x + c): top-1 with Random Token Selection or top-2 (control_params.top_num); `uniform` is the gate's random draw
+        rt = self._route(x, c, E, ctl.top_k, uniform)
+        C, tos, l_aux, exp_counts = rt.C, rt.tos, rt.l_aux, rt.exp_counts
         # expert modulation: s = Linear(768 -> D)(pooled) per (expert, sample): all E experts' linears as one launch over their stacked
         # weights [E*D, 768] -> [B, E*D] (row of (expert e, sample b) at e*D + b*E*D)
         pe = "moe.moe_layer.experts.deepspeed_experts."
@@ -366,10 +361,9 @@ class UniGenFlux(HipModule):
             ehc = self._w("moe_ehc", (B, 2 * N, D))            # per sample [expert hidden | consistency condition states]
             ehc2 = ehc.view(B * 2 * N, D)
             ect = self._w("moe_ect", (S, D))                   # expert condition states, token order
-            ops.moe_combine(zero, yc, gates, idx, slot, ect, E=E, capacity=C)
+            self._combine(rt, zero, yc, ect)
             for b in range(B):                                 # token rows of one sample are contiguous in ehc[b, :N]
-                sl = slice(b * N, (b + 1) * N)
-                ops.moe_combine(yh, zero, gates[sl], idx[sl], slot[sl], ehc[b, :N], E=E, capacity=C)
+                self._combine(rt, yh, zero, ehc[b, :N], rows=slice(b * N, (b + 1) * N))
             round_to = img_ids.dtype if ctl.use_rope else None
             rope_a = self._rope([cond_ids, cond_ids], round_to) if ctl.use_rope else None
             self._double_block("consis_module.0", B, _Stream(ect, N), _Stream(ehc2[N:], N, 2 * N), _Stream(c, N), None, condition_temb, rope_a, "cs0")
@@ -414,7 +408,7 @@ class UniGenFlux(HipModule):
                     ops.add(a_, b_, z3[b])
             return l_aux, exp_counts
         # combine + CoMoE residual sums for all B samples in one launch (:1024, 1089)
-        ops.moe_combine(yh, yc, gates, idx, slot, z0, E=E, capacity=C, xs=xs, cs=cs, s_map=s_map, accumulate=accumulate)
+        self._combine(rt, yh, yc, z0, xs=xs, cs=cs, s_map=s_map, accumulate=accumulate)
         return l_aux, exp_counts
 
     # ------------------------------------------------------------------ forward ---------------------------------------

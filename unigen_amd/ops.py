@@ -370,6 +370,46 @@ def moe_capacity_rts(gates, idx, uniform, capacity: int, slot, token_of_slot, ex
                                          token_of_slot.data_ptr(), exp_counts.data_ptr(), l_aux.data_ptr(), _stream()), "ug_moe_capacity_rts")
 
 
+def moe_gate_top2(x: torch.Tensor, c: torch.Tensor, wg: torch.Tensor, noise: Optional[torch.Tensor], gates: torch.Tensor, idx: torch.Tensor) -> None:
+    """top2gating's gate: gates [S, E] fp32, idx int32 [2, S] (first choice = argmax, second = argmax of logits + noise over the others)."""
+    dt = _act(x, "x")
+    _chk(c, "c", dt); _chk(wg, "wg", dt); _chk(gates, "gates", torch.float32); _chk(idx, "idx", torch.int32)
+    S, D = x.shape
+    E = wg.shape[0]
+    assert x.stride(0) == c.stride(0) and wg.is_contiguous() and gates.is_contiguous() and idx.is_contiguous() and idx.shape == (2, S)
+    if noise is not None:
+        _chk(noise, "noise", torch.float32); assert noise.shape == (S, E) and noise.is_contiguous()
+    L.check(_fn("ug_moe_gate_top2", dt)(x.data_ptr(), c.data_ptr(), x.stride(0), wg.data_ptr(), S, D, E, _p(noise), gates.data_ptr(), idx.data_ptr(), _stream()),
+            "ug_moe_gate_top2")
+
+
+def moe_capacity_top2(gates, idx, capacity: int, slot, token_of_slot, weights, exp_counts, l_aux) -> None:
+    _chk(gates, "gates", torch.float32); _chk(idx, "idx", torch.int32); _chk(slot, "slot", torch.int32); _chk(token_of_slot, "token_of_slot", torch.int32)
+    _chk(weights, "weights", torch.float32); _chk(exp_counts, "exp_counts", torch.int64); _chk(l_aux, "l_aux", torch.float32)
+    S, E = gates.shape
+    assert idx.shape == slot.shape == weights.shape == (2, S) and idx.is_contiguous() and slot.is_contiguous() and weights.is_contiguous()
+    assert token_of_slot.numel() == E * capacity and token_of_slot.is_contiguous() and gates.is_contiguous()
+    L.check(L.load().ug_moe_capacity_top2(gates.data_ptr(), idx.data_ptr(), S, E, capacity, slot.data_ptr(), token_of_slot.data_ptr(), weights.data_ptr(),
+                                          exp_counts.data_ptr(), l_aux.data_ptr(), _stream()), "ug_moe_capacity_top2")
+
+
+def moe_combine_topk(yh, yc, weights, idx, slot, out, *, E: int, capacity: int, xs=None, cs=None, s_map: RowMap = IDENT, accumulate: bool = False) -> torch.Tensor:
+    """weights fp32 / idx / slot [K, S'] (S' >= S: column slices of longer arrays keep their row stride); otherwise as moe_combine."""
+    dt = _act(yh, "yh")
+    _chk(yc, "yc", dt); _chk(out, "out", dt); _chk(weights, "weights", torch.float32); _chk(idx, "idx", torch.int32); _chk(slot, "slot", torch.int32)
+    S, D = out.shape[-2], out.shape[-1]
+    K = weights.shape[0]
+    ks = weights.stride(0) if K > 1 else max(S, 1)
+    assert weights.shape == idx.shape == slot.shape == (K, S) and weights.stride(1) == idx.stride(1) == slot.stride(1) == 1
+    assert K == 1 or (idx.stride(0) == ks and slot.stride(0) == ks)
+    if xs is not None:
+        _chk(xs, "xs", dt); _chk(cs, "cs", dt); assert xs.stride(-2) == cs.stride(-2)
+    L.check(_fn("ug_moe_combine_topk", dt)(yh.data_ptr(), yc.data_ptr(), weights.data_ptr(), idx.data_ptr(), slot.data_ptr(), K, ks, E, capacity, _p(xs), _p(cs),
+                                            xs.stride(-2) if xs is not None else 0, s_map.rpb, s_map.bstride, out.data_ptr(), out.stride(-2), S, D,
+                                            1 if accumulate else 0, _stream()), "ug_moe_combine_topk")
+    return out
+
+
 def moe_dispatch_modulate(x, add_, mod, token_of_slot, out, *, E: int, capacity: int, tokens_per_sample: int,
                           mod_estride: int = 0, mod_bstride: int = 0) -> torch.Tensor:
     """mod: the expert-modulation vectors, row of (expert e, sample b) at element offset e * mod_estride + b * mod_bstride."""

@@ -188,9 +188,10 @@ class UniGenSD3(HipModule):
             use_pooled_prompt_embeds=bool(get("use_pooled_prompt_embeds", True)),
             use_shared_expert=bool(get("use_shared_expert", False)),
             expert_nums=int(expert_num) if expert_num is not None else (condition_nums + 1) * int(get("expert_num_each_condition", 3)),
+            top_k=int(get("top_num", 1)),
         )
-        if int(get("top_num", 1)) != 1 or ctl.expert_nums > 16:
-            raise ValueError("top-1 gating with at most 16 experts is implemented")
+        if ctl.top_k not in (1, 2) or ctl.expert_nums > 16 or ctl.expert_nums < ctl.top_k:
+            raise ValueError("top_num 1 or 2 (deepspeed top1gating / top2gating) with top_num..16 experts is implemented")
         self._ctl = ctl
         dev_, dt_ = self.device, self.dtype
         shapes = sd3_control_param_shapes(self.config, ctl)
@@ -321,15 +322,8 @@ class UniGenSD3(HipModule):
     def _comoe(self, B, N, T, x, c, ctrl_enc, control_temb, condition_temb, pooled, cond_pooled, uniform, z0):
         ctl, D, dev = self._ctl, self.inner_dim, self.device
         E, S = ctl.expert_nums, B * N
-        C = max(int(math.ceil(S / E)), 4)
-        gates, idx = self._w("moe_gates", (S, E), torch.float32), self._w("moe_idx", (S,), torch.int32)
-        ops.moe_gate_top1(x, c, self._P("moe.moe_layer.gate.wg.weight"), gates, idx)
-        if uniform is None:
-            uniform = torch.rand(S, E, device=dev, dtype=torch.float32)
-        slot, tos = self._w("moe_slot", (S,), torch.int32), self._w("moe_tos", (E, C), torch.int32)
-        exp_counts = torch.empty(E, device=dev, dtype=torch.int64)
-        l_aux = torch.empty(1, device=dev, dtype=torch.float32)
-        ops.moe_capacity_rts(gates, idx, uniform.contiguous(), C, slot, tos, exp_counts, l_aux)
+        rt = self._route(x, c, E, ctl.top_k, uniform)          # top-1 + RTS or top-2 (control_params.top_num); `uniform` = the gate's random draw
+        C, tos, l_aux, exp_counts = rt.C, rt.tos, rt.l_aux, rt.exp_counts
         if ctl.modulated:
             yh, yc = self._experts_modulated(B, N, x, c, pooled, cond_pooled, tos, C)
         else:
@@ -348,7 +342,7 @@ class UniGenSD3(HipModule):
             xcs = _Stream(xc2, 2 * N)
             self._double_block("shared_expert.1", B, xcs, xcs, _Stream(ctrl_enc, T), None, control_temb, None, "se1", dual=True, ctx_continuous=True)
             xs, cs, s_map = xc2, xc2[N:], ops.RowMap(N, 2 * N)
-        ops.moe_combine(yh, yc, gates, idx, slot, z0, E=E, capacity=C, xs=xs, cs=cs, s_map=s_map)      # all B samples in one launch
+        self._combine(rt, yh, yc, z0, xs=xs, cs=cs, s_map=s_map)      # all B samples in one launch
         return l_aux, exp_counts
 
     # ------------------------------------------------------------------ forward ---------------------------------------

@@ -129,9 +129,9 @@ def _single_block_body(model, prefix: str, h, temb, rope):
 
 
 class _GatherRows(torch.autograd.Function):
-    """y[m] = x[idx[m]] * valid[m]. The valid indices are distinct (a token sits in at most one capacity slot, a slot holds at most one token), so
-    the backward is an atomic index_add whose only duplicates add zeros - torch's generic index backward sorts the indices first (1.1 ms per call
-    at 4096 x 3072)."""
+    """y[m] = x[idx[m]] * valid[m]. A slot holds at most one token and a token sits in at most top_num <= 2 capacity slots, so the backward is an
+    atomic index_add with at most two non-zero addends per row (a + b in either order: the same bits) plus zeros - torch's generic index
+    backward sorts the indices first (1.1 ms per call at 4096 x 3072)."""
 
     @staticmethod
     def forward(ctx, x, idx, valid):
@@ -164,26 +164,51 @@ class _BroadcastSamples(torch.autograd.Function):
 
 
 def _route(model, x, c, uniform):
-    """TopKGate + top1gating (deepspeed 0.16.5): fp32 gate softmax on (x + c); routing decisions (argmax, capacity, Random Token
-    Selection) from the HIP kernel; what is differentiable - the gate probabilities in the combine weights and in l_aux - stays on the tape."""
+    """TopKGate + top1gating / top2gating (deepspeed 0.16.5; control_params.top_num): fp32 gate softmax on (x + c); routing decisions
+    (arg-max, capacity, Random Token Selection or the Gumbel-max second choice) from the HIP kernels; what is differentiable - the gate
+    probabilities in the combine weights and in l_aux - stays on the tape. `uniform`: the gate's random draw (Uniform for k = 1, Gumbel for k = 2)."""
     B, N, D = x.shape
-    E, S = model._ctl.expert_nums, B * N
-    C = max(int(math.ceil(S / E)), 4)
-    # gate logits / softmax / arg-max and their backward: HIP kernels (round 2 ran F.linear + F.softmax here: vendor BLAS on a product path)
-    gates, idx = A.MoeGate.apply(x.reshape(S, D).contiguous(), c.reshape(S, D).contiguous(), model.get_parameter("moe.moe_layer.gate.wg.weight"))
-    if uniform is None:
-        uniform = torch.rand(S, E, device=x.device, dtype=torch.float32)
-    slot, tos = torch.empty(S, device=x.device, dtype=torch.int32), torch.empty(E, C, device=x.device, dtype=torch.int32)
-    exp_counts, l_aux_k = torch.empty(E, device=x.device, dtype=torch.int64), torch.empty(1, device=x.device, dtype=torch.float32)
-    ops.moe_capacity_rts(gates.detach().contiguous(), idx, uniform.contiguous(), C, slot, tos, exp_counts, l_aux_k)
-    l_aux = torch.sum(gates.mean(0) * F.one_hot(idx.long(), E).float().mean(0)) * E
+    E, S, K = model._ctl.expert_nums, B * N, getattr(model._ctl, "top_k", 1)
+    dev = x.device
+    wg = model.get_parameter("moe.moe_layer.gate.wg.weight")
+    x2, c2 = x.reshape(S, D).contiguous(), c.reshape(S, D).contiguous()
+    exp_counts, l_aux_k = torch.empty(E, device=dev, dtype=torch.int64), torch.empty(1, device=dev, dtype=torch.float32)
+    if K == 1:
+        C = max(int(math.ceil(S / E)), 4)
+        # gate logits / softmax / arg-max and their backward: HIP kernels (round 2 ran F.linear + F.softmax here: vendor BLAS on a product path)
+        gates, idx = A.MoeGate.apply(x2, c2, wg)
+        if uniform is None:
+            uniform = torch.rand(S, E, device=dev, dtype=torch.float32)
+        slot, tos = torch.empty(S, device=dev, dtype=torch.int32), torch.empty(E, C, device=dev, dtype=torch.int32)
+        ops.moe_capacity_rts(gates.detach().contiguous(), idx, uniform.contiguous(), C, slot, tos, exp_counts, l_aux_k)
+        l_aux = torch.sum(gates.mean(0) * F.one_hot(idx.long(), E).float().mean(0)) * E
+        kept = (slot >= 0).unsqueeze(0)
+        flat = (idx.long() * C + slot.long()).clamp_min(0).unsqueeze(0)
+        w = (gates.gather(1, idx.long().unsqueeze(1)).squeeze(1) * kept[0].float()).to(x.dtype).unsqueeze(0)      # combine weight, rounded as `cw.to(dt)`
+    else:
+        C = max(int(math.ceil((S / E) * 2.0)), 4)
+        if uniform is None:                            # gumbel_rsample
+            uniform = torch.distributions.gumbel.Gumbel(torch.tensor(0.0, device=dev), torch.tensor(1.0, device=dev)).rsample((S, E))
+        gates, idx = A.MoeGate.apply(x2, c2, wg, 2, uniform.to(torch.float32).contiguous())
+        slot, tos = torch.empty(2, S, device=dev, dtype=torch.int32), torch.empty(E, C, device=dev, dtype=torch.int32)
+        w_dev = torch.empty(2, S, device=dev, dtype=torch.float32)      # the kernel's weights: not on the tape, recomputed below from `gates`
+        ops.moe_capacity_top2(gates.detach().contiguous(), idx, C, slot, tos, w_dev, exp_counts, l_aux_k)
+        l_aux = torch.mean(gates.mean(0) * F.one_hot(idx[0].long(), E).float().mean(0)) * E * E
+        kept = slot >= 0
+        flat = (idx.long() * C + slot.long()).clamp_min(0)
+        g = torch.stack([gates.gather(1, idx[k].long().unsqueeze(1)).squeeze(1) for k in range(2)]) * kept.float()
+        w = (g / torch.clamp(g.sum(0, keepdim=True), min=torch.finfo(torch.float32).eps)).to(x.dtype)             # gates1_s / denom_s, gates2_s / denom_s
     tos_l = tos.view(-1).long()
     valid, src = tos_l >= 0, tos_l.clamp_min(0)
     dispatch = lambda t2d: _GatherRows.apply(t2d, src, valid).view(E, C, -1)                    # einsum("sec,sm->ecm") with a one-hot mask
-    kept = slot >= 0
-    flat = (idx.long() * C + slot.long()).clamp_min(0)
-    w = (gates.gather(1, idx.long().unsqueeze(1)).squeeze(1) * kept.float()).to(x.dtype).unsqueeze(1)    # combine weight, rounded as `cw.to(dt)`
-    combine = lambda y: (w * _GatherRows.apply(y.reshape(E * C, D), flat, kept)).view(B, N, D)   # einsum("sec,ecm->sm")
+
+    def combine(y):                                                                             # einsum("sec,ecm->sm"): fp32 sum, one rounding
+        y2 = y.reshape(E * C, D)
+        if K == 1:
+            return (w[0].unsqueeze(1) * _GatherRows.apply(y2, flat[0], kept[0])).view(B, N, D)
+        acc = sum(w[k].float().unsqueeze(1) * _GatherRows.apply(y2, flat[k], kept[k]).float() for k in range(K))
+        return acc.to(y.dtype).view(B, N, D)
+
     return dispatch, combine, src // N, l_aux, exp_counts, E, C
 
 
