@@ -1,0 +1,72 @@
+"""Where an attention-forward workgroup's time goes: s_memtime stamps of a -DUG_ATTN_STAMPS build of attention.hip (kernel entry, end of the
+prologue, end of the tile loop, end of the epilogue, per wave group; the CU it ran on), written into the buffer passed as the log-sum-exp output.
+Build:  hipcc -DUG_ATTN_STAMPS ... attention.hip  linked with the other objects into tools/probe/bin/libunigen_attn_stamps.so
+run:    UG_LIB_PATH=tools/probe/bin/libunigen_attn_stamps.so python tools/attn_stamps.py
+Per shape, medians over workgroups (group A = waves 0-3, group B = waves 4-7, one segment behind):
+  prologue = entry -> first S^T segment may start      loop = the tile loop      epilogue = loop end -> O stores issued (A: incl. its trailing barrier)
+  gap      = on one CU: a workgroup's entry minus the previous workgroup's last epilogue end (dispatch of the next workgroup)
+  span     = first entry -> last end on a CU, against the sum of its workgroups' in-kernel times"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from unigen_amd import ops, lib as L
+
+assert "stamps" in L.LIB_PATH, "set UG_LIB_PATH to the -DUG_ATTN_STAMPS build"
+dev, BF = torch.device("cuda:0"), torch.bfloat16
+g = torch.Generator(device=dev).manual_seed(0)
+B, H, dh = 4, 24, 128
+D = H * dh
+for Lq, Lkv in [(4608, 4608), (4096, 4608), (8192, 8704)]:
+    qkv = (torch.randn(B, Lkv, 3 * D, generator=g, device=dev)).to(BF)
+    out = torch.empty(B, Lq, D, device=dev, dtype=BF)
+    nwg = B * H * ((Lq + 255) // 256)
+    lse = torch.zeros(B, H, max(Lq, (nwg * 2 * 16 + B * H - 1) // (B * H)), device=dev, dtype=torch.float32)
+    st = (3 * D, Lkv * 3 * D)
+    run = lambda: ops.flash_attn(qkv[0, Lkv - Lq:], qkv[0, 0, D:], qkv[0, 0, 2 * D:], out, batches=B, heads=H, dh=dh, Lq=Lq, Lkv=Lkv, q_strides=st, k_strides=st,
+                                 v_strides=st, o_strides=(D, Lq * D), lse=lse)
+    for _ in range(30):
+        run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); run(); e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1)
+    raw = lse.view(-1).cpu().numpy().view(np.uint64)[: nwg * 2 * 8].reshape(nwg, 2, 8).astype(np.int64)
+    st_ = raw[:, :, 0:4]                                    # [wg][group][stamp]
+    clk = (raw[:, :, 3] - raw[:, :, 0]) / np.maximum(raw[:, :, 5] - raw[:, :, 4], 1) * 100e6       # Hz, per workgroup
+    ghz = float(np.median(clk)) / 1e9
+    us = lambda cyc: cyc / (ghz * 1e3)
+    hw, xcc = raw[:, 0, 6] & 0xffffffff, (raw[:, 0, 6] >> 32) & 0xf
+    cu = (xcc << 8) | (((hw >> 13) & 7) << 5) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 0xf)
+    pro, loop, epi = st_[:, :, 1] - st_[:, :, 0], st_[:, :, 2] - st_[:, :, 1], st_[:, :, 3] - st_[:, :, 2]
+    tot = st_[:, :, 3].max(1) - st_[:, :, 0].min(1)
+    gaps, spans, busy, per_cu = [], [], [], []
+    for c in np.unique(cu):
+        w = np.nonzero(cu == c)[0]
+        w = w[np.argsort(st_[w, 0, 0])]
+        per_cu.append(len(w))
+        ends = st_[w, :, 3].max(1)
+        starts = st_[w, :, 0].min(1)
+        gaps += list(starts[1:] - ends[:-1])
+        spans.append(ends[-1] - starts[0]); busy.append(int(tot[w].sum()))
+    med = lambda a: float(np.median(np.asarray(a)))
+    # chip-wide picture on the 100 MHz real-time counter (one counter for all XCDs): when each CU enters its first / leaves its last workgroup
+    rt0, rt1 = raw[:, :, 4].min(1), raw[:, :, 5].max(1)
+    first = np.array([rt0[cu == c].min() for c in np.unique(cu)]) - rt0.min()
+    last = np.array([rt1[cu == c].max() for c in np.unique(cu)]) - rt0.min()
+    ntile = (Lkv + 63) // 64
+    print(f"{Lq} x {Lkv}: launch {ms * 1e3:8.1f} us ({4.0 * B * H * Lq * Lkv * dh / ms / 1e9:7.1f} TFLOP/s), {nwg} workgroups on {len(per_cu)} CUs "
+          f"({min(per_cu)}-{max(per_cu)} per CU), {ntile} key tiles, in-kernel clock {ghz:.2f} GHz")
+    for gi, gn in enumerate("AB"):
+        print(f"   group {gn}: prologue {us(med(pro[:, gi])):6.2f}  loop {us(med(loop[:, gi])):7.2f} ({us(med(loop[:, gi])) / ntile * 1e3:6.1f} ns per key tile)  "
+              f"epilogue {us(med(epi[:, gi])):6.2f} us")
+    print(f"   workgroup entry -> last end {us(med(tot)):7.2f} us; gap to the next workgroup on the CU: median {us(med(gaps)):5.2f}  p10 {us(np.percentile(gaps, 10)):5.2f}  "
+          f"p90 {us(np.percentile(gaps, 90)):5.2f} us; CU span {us(med(spans)):8.1f} us of which in workgroups {us(med(busy)):8.1f} us "
+          f"({med(busy) / med(spans) * 100:.1f} %); launch / CU span = {ms * 1e3 / us(med(spans)):.3f}")
+    print(f"   real time from the first entry on the chip: CUs enter their first workgroup at median {med(first) / 100:6.1f}  p90 {np.percentile(first, 90) / 100:6.1f}  max {first.max() / 100:6.1f} us; "
+          f"leave their last one at min {last.min() / 100:7.1f}  median {med(last) / 100:7.1f}  max {last.max() / 100:7.1f} us")
+    per_x = [f"{int(x)}:{med(last[(np.unique(cu) >> 8) == x]) / 100:.0f}" for x in np.unique(np.unique(cu) >> 8)]
+    print(f"   median last-end per XCD (us): {' '.join(per_x)}")
+    wx = cu >> 8
+    print("   per XCD: in-kernel clock GHz / loop us per key tile: " + "  ".join(
+        f"{int(x)}: {np.median(clk[wx == x]) / 1e9:.3f} / {np.median(loop[wx == x, 0] / clk[wx == x, 0]) * 1e6 / ntile:.3f}" for x in np.unique(wx)))

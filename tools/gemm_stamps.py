@@ -40,7 +40,10 @@ for label, M, N, K, epi in SHAPES:
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); ops.gemm(a, w, b, out, **kw); e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3
-    st = ws[4096:4096 + 256 * 250 * 8].view(torch.int64).view(256, 50, 5).cpu()
+    raw = ws[4096:4096 + 256 * 250 * 8].view(torch.int64).view(256, 250).cpu()
+    rt_in, rt_out = raw[:, 248].clone(), raw[:, 249].clone()
+    raw[:, 245:] = 0
+    st = raw.view(256, 50, 5)
     ok = st[:, :, 0] > 0
     ntile = ok.sum(1)
     wg = ntile > 0
@@ -55,3 +58,14 @@ for label, M, N, K, epi in SHAPES:
     print(f"{label:38s} {M}x{N}x{K}: launch {us:7.1f} us ({2.0 * M * N * K / us / 1e6:6.1f} TFLOP/s), {int(ntile.max())} tiles per workgroup, {tick_us / 1e3:.2f} GHz | per tile: "
           f"wait0 {med(wait0):5.2f}  loop {med(loop):6.2f} ({med(loop) / nk * 1e3:5.0f} ns per K-tile)  next {med(nxt):4.2f}  epilogue {med(epi_t):5.2f}  gap {med(gaps):4.2f} us"
           f"  -> non-loop share {1 - med(loop) / tot:.1%}; first tile wait0 {float(d(st[:, 0, 1] - st[:, 0, 0])[wg].median()) / tick_us:.2f} us", flush=True)
+    # per XCD (workgroup b runs on XCD b & 7): when its workgroups left the kernel on the chip-wide 100 MHz counter, and the clock they ran at
+    t0 = int(rt_in[rt_in > 0].min())
+    xs = []
+    for x in range(8):
+        sel = torch.arange(256)[(torch.arange(256) & 7) == x]
+        sel = sel[wg[sel]]
+        ticks = torch.stack([st[i, :ntile[i], 4].max() - st[i, 0, 0] for i in sel]).double()
+        dur = (rt_out[sel] - rt_in[sel]).double() / 100.0
+        xs.append(f"{x}: {float((rt_out[sel] - t0).double().median()) / 100.0:7.1f} us @ {float((ticks / dur).median()) / 1e3:.3f} GHz")
+    print("      per XCD, median exit time / clock:  " + "   ".join(xs), flush=True)
+

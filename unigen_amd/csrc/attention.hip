@@ -119,6 +119,16 @@ __global__ __launch_bounds__(64 * NW, OCC) void flash_attn_kernel(
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [2][K tile | V tile]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
+    /* -DUG_ATTN_STAMPS (tools/attn_stamps.py, a separate library build; never the product): wave 0 / wave 4 of every workgroup record s_memtime at
+     * the kernel's entry, the end of the prologue, the end of the tile loop and the end of the epilogue, s_memrealtime at both ends and the CU they
+     * ran on, into the buffer the caller passes as `lse_out` (16 dwords per workgroup and wave group; the log-sum-exp is then not written). */
+#ifdef UG_ATTN_STAMPS
+    unsigned long long ug_st[4], ug_rt0 = __builtin_amdgcn_s_memrealtime();
+#define UG_ASTAMP(I) do { ug_st[I] = __builtin_amdgcn_s_memtime(); } while (0)
+    UG_ASTAMP(0);
+#else
+#define UG_ASTAMP(I) do { } while (0)
+#endif
 
     // XCD-aware block order: all query tiles of one (batch, head) run on one XCD so its K/V stay in that L2.
     const int nwg = gridDim.x;
@@ -566,6 +576,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void flash_attn_kernel(
             fetch(1, 0);                               // segment 0 (even): K(1), V(0) in flight
         }
         if (!groupA) seg_barrier();                    // B idles through segment 0
+        UG_ASTAMP(1);
         do_QK(0, std::integral_constant<int, 0>{});    // A: segment 0 | B: segment 1
         if (!groupA) { if constexpr (DMA) dma_wait(); else publish(1, 0); }    // end of segment 1 (B)
         seg_barrier();
@@ -595,13 +606,16 @@ __global__ __launch_bounds__(64 * NW, OCC) void flash_attn_kernel(
             tile(t, std::integral_constant<int, 0>{});
             if (t + 1 < ntiles) tile(t + 1, std::integral_constant<int, 1>{});
         }
+        UG_ASTAMP(2);
         if (groupA) seg_barrier();                     // A's trailing (empty) segment pairs with B's last one
     }
 
     // ---- epilogue: O[q][d] = O^T / l ----
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     // training: log2 sum_k 2^(c s) of the row for the backward kernels (m_run is the row's reference point, shared by both lane halves)
+#ifndef UG_ATTN_STAMPS
     if (lse_out != nullptr && h == 0 && q_row < Lq) lse_out[(int64_t)bh * lse_ld + q_row] = __builtin_amdgcn_logf(l_tot) + m_run * c;
+#endif
     const float inv = 1.0f / l_tot;
     if constexpr (WIDE) {
         // Lane (r, h) holds, per 8-column group g4 of a 32-wide d block, columns 8 g4 + 4 h .. + 3 of its query row (8 bytes). One
@@ -632,6 +646,16 @@ __global__ __launch_bounds__(64 * NW, OCC) void flash_attn_kernel(
                 *(u32x2*)(Orow + 32 * db + 8 * g4 + 4 * h) = w;
             }
     }
+#ifdef UG_ATTN_STAMPS
+    UG_ASTAMP(3);
+    if (lse_out != nullptr && lane == 0 && (wave & 3) == 0) {
+        unsigned long long* d = (unsigned long long*)lse_out + ((int64_t)blockIdx.x * 2 + (wave >> 2)) * 8;
+        d[0] = ug_st[0]; d[1] = ug_st[1]; d[2] = ug_st[2]; d[3] = ug_st[3]; d[4] = ug_rt0; d[5] = __builtin_amdgcn_s_memrealtime();
+        d[6] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);   // XCC_ID | HW_ID
+        d[7] = (unsigned long long)logical;
+    }
+#endif
+#undef UG_ASTAMP
 }
 
 

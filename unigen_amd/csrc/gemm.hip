@@ -371,6 +371,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
 #ifdef UG_DIAG_STAMPS
     unsigned long long* const stamp_lds = (unsigned long long*)(smem + stamp_off);
     int tile_seq = 0;
+    if (threadIdx.x == 0) stamp_lds[250] = __builtin_amdgcn_s_memrealtime();      // 100 MHz, one counter for the chip: when this workgroup entered
 #define UG_STAMP(I) do { if (threadIdx.x == 0 && tile_seq < 50) stamp_lds[tile_seq * 5 + (I)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define UG_STAMP(I) do { } while (0)
@@ -879,7 +880,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (threadIdx.x == 0 && slabs != nullptr) {
         unsigned long long* out = (unsigned long long*)slabs + (size_t)blockIdx.x * 250;
-        for (int i = 0; i < 250; ++i) out[i] = i < tile_seq * 5 ? stamp_lds[i] : 0ull;
+        for (int i = 0; i < 248; ++i) out[i] = i < tile_seq * 5 ? stamp_lds[i] : 0ull;
+        out[248] = stamp_lds[250]; out[249] = __builtin_amdgcn_s_memrealtime();    // entry / exit on the chip-wide real-time counter (per-XCD finish times)
     }
 #endif
 #undef UG_STAMP
