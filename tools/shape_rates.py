@@ -33,6 +33,7 @@ groups = collections.defaultdict(list)
 for kind, flops, e0, e1 in timer.records:
     groups[(kind, round(flops / 1e9))].append(e0.elapsed_time(e1))
 tot = sum(sum(v) for v in groups.values())
+print(f"sum of the timed launches: {tot / 3:.1f} ms per forward")
 print(f"{'kind':5s} {'GFLOP/launch':>13s} {'launches':>8s} {'avg us':>9s} {'TFLOP/s':>9s} {'share':>7s}")
 for (kind, gf), v in sorted(groups.items(), key=lambda kv: -sum(kv[1])):
     avg = sum(v) / len(v)
