@@ -13,6 +13,8 @@ tests/test_ref_leaf_cpu.py holds these rows of this file to their outputs (tests
   adaln_zero_x                                  <- sd35adanormX_forward       src/UniGenUtils.py:340-352
   adaln_continuous                              <- adanormContinuous_forward  src/UniGenUtils.py:365-373
   expert_forward                                <- UniGenFlux.expert_forward  src/UniGenTransformer.py:925-967 (== UniGenBase :225-267)
+  sd3_attention (sample-first joint attention:  <- JointAttnRopeProcessor.__call__  src/UniGenUtils.py:533-622, run without RoPE and q/k norms
+   concatenation order, split, projections)        (those two branches need diffusers symbols and stay restated)
 Everything else is UNPINNED: it restates
   * src/UniGenTransformer.py:712-1450   (UniGenFlux, MultiCondtionUniGenFlux)
   * src/UniGenUtils.py:17-228,340-622   (MoE glue, modulated_flatten, JointAttnRopeProcessor)

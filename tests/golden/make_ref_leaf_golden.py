@@ -7,6 +7,9 @@ functions are self-contained PyTorch. This script parses the reference's files w
 
     src/UniGenUtils.py        zero_module :194, modulated_flatten :204, sd35adanormX_forward :340, adanorm_forward :354,
                               adanormContinuous_forward :365
+                              JointAttnRopeProcessor.__call__ :533 (the control branch's attention: sample-first concatenation, split, to_add_out
+                              unless context_pre_only) with rope_embed = None and an `attn` bag without q/k norms - the two branches that need
+                              diffusers' apply_rotary_emb / RMSNorm are not taken (a tripwire raises if they were)
     src/UniGenTransformer.py  UniGenFlux.expert_forward :925 and UniGenBase.expert_forward :225 (method bodies, called as plain functions)
 
 into a namespace that holds nothing but `torch`, `torch.nn`, `torch.nn.functional`, `typing.List` and (for expert_forward) the reference's own
@@ -41,13 +44,20 @@ def _find(tree: ast.AST, name: str, cls: str | None = None) -> ast.FunctionDef:
     return next(n for n in body if isinstance(n, ast.FunctionDef) and n.name == name)
 
 
-def compile_reference_function(path: str, name: str, cls: str | None = None, extra: dict | None = None):
+def _tripwire(name: str):
+    def _raise(*a, **k):
+        raise AssertionError(f"the fixture reached `{name}`, a third-party symbol the namespace does not provide")
+    return _raise
+
+
+def compile_reference_function(path: str, name: str, cls: str | None = None, extra: dict | None = None, not_taken: tuple = ()):
     """Compile one function definition of a reference file in a namespace of torch symbols only. Annotations are dropped (they name typing
-    symbols the namespace does not hold); the body is untouched."""
+    symbols the namespace does not hold); the body is untouched. `not_taken`: third-party names that only occur on a branch the fixture's
+    arguments never take - they are bound to a tripwire that raises if the branch is entered after all (not to an implementation)."""
     with open(os.path.join(REF, path)) as f:
         tree = ast.parse(f.read())
     fn = _find(tree, name, cls)
-    for a in fn.args.args + fn.args.kwonlyargs:
+    for a in fn.args.args + fn.args.kwonlyargs + [x for x in (fn.args.vararg, fn.args.kwarg) if x is not None]:
         a.annotation = None
     fn.returns = None
     fn.decorator_list = []
@@ -55,12 +65,14 @@ def compile_reference_function(path: str, name: str, cls: str | None = None, ext
     ast.fix_missing_locations(mod)
     ns = dict(ALLOWED)
     ns.update(extra or {})
+    ns.update({n: _tripwire(n) for n in not_taken})
     code = compile(mod, f"<{path}:{fn.lineno} {name}>", "exec")
     exec(code, ns)
     f_obj = ns[name]
     # every global the body can reach is a torch symbol we put there, a builtin, or an attribute name (attribute names also appear in co_names)
     loads = {n.id for n in ast.walk(fn) if isinstance(n, ast.Name) and isinstance(n.ctx, ast.Load)}
     local = {a.arg for a in fn.args.args + fn.args.kwonlyargs} | ({fn.args.kwarg.arg} if fn.args.kwarg else set()) | \
+            ({fn.args.vararg.arg} if fn.args.vararg else set()) | \
             {n.id for n in ast.walk(fn) if isinstance(n, ast.Name) and isinstance(n.ctx, ast.Store)}
     free = loads - local
     unknown = {n for n in free if n not in ns and not hasattr(builtins, n)}
@@ -95,7 +107,8 @@ def main() -> None:
     T = "src/UniGenTransformer.py"
     exp_flux, l5 = compile_reference_function(T, "expert_forward", "UniGenFlux", {"modulated_flatten": modulated_flatten})
     exp_base, l6 = compile_reference_function(T, "expert_forward", "UniGenBase", {"modulated_flatten": modulated_flatten})
-    print("compiled reference definitions at lines", l0, l1, l2, l3, l4, l5, l6)
+    attn_call, l7 = compile_reference_function(U, "__call__", "JointAttnRopeProcessor", not_taken=("apply_rotary_emb",))
+    print("compiled reference definitions at lines", l0, l1, l2, l3, l4, l5, l6, l7)
     g = torch.Generator().manual_seed(12443)
     rnd = lambda *s, scale=1.0: (torch.randn(*s, generator=g) * scale).bfloat16().float()
     fx: dict = {}
@@ -174,6 +187,31 @@ def main() -> None:
         assert all(torch.equal(a, b_) for a, b_ in zip(outs["flux"], outs["base"])), "the two expert_forward definitions disagree"
         put(f"expert.{tag}", out_h=outs["flux"][0], out_c=outs["flux"][1])
         experts.float()
+
+    # ---- JointAttnRopeProcessor.__call__ (src/UniGenUtils.py:533-622): joint attention, sample rows first; no RoPE, no q/k norm ----------------------
+    # (drawn after everything above: the earlier tensors of the fixture keep their values)
+    H, dh, B, N, Tc = 2, 64, 2, 20, 12
+    D = H * dh
+    names = ("to_q", "to_k", "to_v", "add_q_proj", "add_k_proj", "add_v_proj", "to_out0", "to_add_out")
+    lins = {nm: _lin(D, D, g, 1.0) for nm in names}
+    xs, es = rnd(B, N, D), rnd(B, Tc, D)
+    put("attn", x=xs.bfloat16(), enc=es.bfloat16())
+    for nm, lin in lins.items():
+        put(f"attn.w.{nm}", weight=lin.weight.bfloat16(), bias=lin.bias.bfloat16())
+    for tag, dt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+        mods = {nm: lin.to(dt) for nm, lin in lins.items()}
+        for cpo in (False, True):
+            attn = bag(heads=H, norm_q=None, norm_k=None, norm_added_q=None, norm_added_k=None, context_pre_only=cpo,
+                       to_q=mods["to_q"], to_k=mods["to_k"], to_v=mods["to_v"], add_q_proj=mods["add_q_proj"], add_k_proj=mods["add_k_proj"],
+                       add_v_proj=mods["add_v_proj"], to_out=nn.ModuleList([mods["to_out0"], nn.Dropout(0.0)]), to_add_out=mods["to_add_out"])
+            with torch.no_grad():
+                ho, eo = attn_call(None, attn, xs.to(dt), encoder_hidden_states=es.to(dt))
+            put(f"attn.joint.cpo{int(cpo)}.{tag}", out=ho, ctx=eo)
+        with torch.no_grad():
+            so = attn_call(None, attn, xs.to(dt))
+        put(f"attn.self.{tag}", out=so)
+        for lin in lins.values():
+            lin.float()
 
     out = os.path.join(HERE, "ref_leaf.safetensors")
     save_file(fx, out, metadata={"origin": "reference functions executed by tests/golden/make_ref_leaf_golden.py", "seed": "12443"})

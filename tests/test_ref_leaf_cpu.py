@@ -109,3 +109,36 @@ def test_expert_forward_matches_the_reference_method(fx, tag):
 def test_zero_module_fixture_is_all_zero(fx):
     """zero_module (src/UniGenUtils.py:194-197) zeroes every parameter: what `controlnet_add_*` must look like after init_condition_block."""
     assert not fx["zero_module.weight"].any() and not fx["zero_module.bias"].any()
+
+
+def _attn_state(fx, dt):
+    m = {"to_q": "to_q", "to_k": "to_k", "to_v": "to_v", "add_q_proj": "add_q_proj", "add_k_proj": "add_k_proj", "add_v_proj": "add_v_proj",
+         "to_out0": "to_out.0", "to_add_out": "to_add_out"}
+    st = {}
+    for src, dst in m.items():
+        st[f"a.{dst}.weight"], st[f"a.{dst}.bias"] = fx[f"attn.w.{src}.weight"].to(dt), fx[f"attn.w.{src}.bias"].to(dt)
+    return st
+
+
+@pytest.mark.parametrize("tag", ["f32", "bf16"])
+def test_joint_attention_matches_the_reference_processor(fx, tag):
+    """JointAttnRopeProcessor.__call__ (src/UniGenUtils.py:533-622), the attention of the control branch's joint blocks, run from the reference's
+    source with rope_embed = None and no q/k norms: per-head view, SAMPLE rows first in the concatenation, SDPA, split at the sample length,
+    to_out[0] / to_add_out (skipped when context_pre_only). The oracle's sd3_attention is the same torch ops in the same order: bit-equal in
+    bf16 eager too. Pins the concatenation order and the split of every sample-first attention of the oracle (joint_attention text_first=False
+    and sd3_attention share them); the branches behind diffusers' RMSNorm / apply_rotary_emb stay restated."""
+    dt = DT[tag]
+    st = _attn_state(fx, dt)
+    x, enc = fx["attn.x"].to(dt), fx["attn.enc"].to(dt)
+    for cpo in (False, True):
+        xo, eo = R.sd3_attention(st, "a", 2, x, enc, context_pre_only=cpo)
+        assert torch.equal(xo, fx[f"attn.joint.cpo{int(cpo)}.{tag}.out"]) or rel(xo, fx[f"attn.joint.cpo{int(cpo)}.{tag}.out"]) < 2e-6
+        if not cpo:
+            assert torch.equal(eo, fx[f"attn.joint.cpo0.{tag}.ctx"]) or rel(eo, fx[f"attn.joint.cpo0.{tag}.ctx"]) < 2e-6
+        else:
+            assert eo is None                         # the reference hands back the raw context rows; every caller drops them (context_pre_only)
+    so, _ = R.sd3_attention(st, "a", 2, x, None)
+    assert torch.equal(so, fx[f"attn.self.{tag}.out"]) or rel(so, fx[f"attn.self.{tag}.out"]) < 2e-6
+    # a context-first concatenation (the base FLUX blocks' order) is a different function: the fixture tells the two apart
+    q = torch.cat([enc, x], 1)
+    assert rel(R.sd3_attention(st, "a", 2, q[:, :x.shape[1]], q[:, x.shape[1]:])[0], fx[f"attn.joint.cpo0.{tag}.out"]) > 1e-2
