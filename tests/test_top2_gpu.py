@@ -259,3 +259,46 @@ def test_top2_draws_its_own_gumbel_sample(gpu):
     i2 = model._w("moe_idx2", (2, 128), torch.int32)
     assert torch.isfinite(o1.float()).all() and int(c1["expert_counts"].sum()) == 256
     assert torch.equal(i1[0], i2[0]) and not torch.equal(i1[1], i2[1])
+
+
+def test_top2_routing_at_full_size_properties(gpu):
+    """cfg2's token count (S = 4 x 4096, E = 6, D = 3072) with two choices per token: capacity ceil(2 S / E) = 5462; properties that need no
+    oracle run - every kept (token, choice) owns exactly one slot and every occupied slot names the token that owns it, the two choices differ,
+    counts = 2 S before the drop, drops only where an expert's queue is full, weights of a token's kept choices sum to 1, bitwise repeatable."""
+    from unigen_amd import ops
+    S, E, D = 16384, 6, 3072
+    g = torch.Generator(device=gpu).manual_seed(4)
+    x, c = (torch.randn(S, D, generator=g, device=gpu)).to(BF), (torch.randn(S, D, generator=g, device=gpu)).to(BF)
+    wg = (torch.randn(E, D, generator=g, device=gpu) * 0.02).to(BF)
+    wg[0] += 0.004                                                  # a favoured expert: its queue overflows
+    u = torch.rand(S, E, generator=g, device=gpu).clamp_(1e-7, 1 - 1e-7)
+    noise = -torch.log(-torch.log(u))
+    C = max(-(-2 * S // E), 4)
+    res = []
+    for _ in range(2):
+        gates, idx = torch.empty(S, E, device=gpu, dtype=F32), torch.empty(2, S, device=gpu, dtype=torch.int32)
+        slot, tos = torch.empty(2, S, device=gpu, dtype=torch.int32), torch.empty(E, C, device=gpu, dtype=torch.int32)
+        w, cnt, l_aux = torch.empty(2, S, device=gpu, dtype=F32), torch.empty(E, device=gpu, dtype=torch.int64), torch.empty(1, device=gpu, dtype=F32)
+        ops.moe_gate_top2(x, c, wg, noise, gates, idx)
+        ops.moe_capacity_top2(gates, idx, C, slot, tos, w, cnt, l_aux)
+        res.append((gates, idx, slot, tos, w, cnt, l_aux))
+    assert all(torch.equal(a, b) for a, b in zip(res[0], res[1])), "not bitwise repeatable"
+    gates, idx, slot, tos, w, cnt, l_aux = (t.cpu() for t in res[0])
+    idx, slot, tos = idx.long(), slot.long(), tos.long()
+    assert C == 5462 and bool((idx[0] != idx[1]).all()) and int(cnt.sum()) == 2 * S
+    assert torch.equal(idx[0], gates.argmax(1)) or float((idx[0] == gates.argmax(1)).float().mean()) > 0.9999
+    kept = slot >= 0
+    flat = (idx * C + slot)[kept]
+    assert flat.unique().numel() == flat.numel(), "two (token, choice) pairs share a slot"
+    tok = torch.arange(S).expand(2, S)[kept]
+    assert torch.equal(tos.view(-1)[flat], tok), "an occupied slot does not name its owner"
+    assert int((tos >= 0).sum()) == int(kept.sum())
+    for e in range(E):
+        n = int(cnt[e])
+        assert int((tos[e] >= 0).sum()) == min(n, C)
+        assert bool((tos[e, :min(n, C)] >= 0).all())                # slots fill from the front, no holes
+    assert int((~kept).sum()) == int((cnt - C).clamp_min(0).sum()) > 0
+    ws = (w * kept.float()).sum(0)
+    anyk = kept.any(0)
+    assert torch.allclose(ws[anyk], torch.ones(int(anyk.sum())), atol=1e-6) and bool((w[~kept] == 0).all())
+    assert abs(float(l_aux) - float((gates.mean(0) * torch.bincount(idx[0], minlength=E).float() / S).sum() * E)) < 1e-5
