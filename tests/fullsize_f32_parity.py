@@ -27,7 +27,7 @@ else:
     CTL = dict(use_rope=True, use_shared_expert=True, use_consis_module=False, use_single_trans_blocks=True, single_control_dev=2,
                single_block_control_method="overall_add", top_num=1, expert_num_each_condition=3)
     cfg = R.FluxConfig(condition_nums=3) if MULTI else R.FluxConfig()
-    GRID = int(sys.argv[2]) if len(sys.argv) > 2 else 32            # 64: the metric's own size, 1024^2 (N = 4096)
+    GRID = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else 32            # 64: the metric's own size, 1024^2 (N = 4096)
     inp = R.make_inputs(cfg, B=1, grid=GRID, T=512, n_cond=3 if MULTI else 1)
     t = torch.full((1,), 0.75, dtype=BF)
     oracle = R.unigen_flux_forward

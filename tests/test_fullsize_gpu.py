@@ -428,7 +428,7 @@ def test_full_model_forward_parity(gpu, which):
     "sd3":    UniGenSD3 at SD3.5-medium size (24 joint blocks with dual attention in 0-12, D = 1536, 24 heads of 64; N = 1024, T = 333)."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    argv = {"flux64": ["flux", "64", "--no-ref16"], "multi": ["multi"], "sd3": ["sd3"]}[which]
+    argv = {"flux64": ["flux", "64", "--no-ref16"], "multi": ["multi", "--no-ref16"], "sd3": ["sd3"]}[which]
     p = subprocess.run([sys.executable, os.path.join(root, "tests", "fullsize_f32_parity.py"), *argv], capture_output=True, text=True, timeout=1100, cwd=root)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     line = [l for l in p.stdout.splitlines() if l.startswith("FULLSIZE_PARITY")][-1]
@@ -437,8 +437,9 @@ def test_full_model_forward_parity(gpu, which):
     assert r["rel_l2_hip_f32_vs_oracle_f32"] <= 1e-3, r
     if r["rel_l2_oracle_bf16_vs_oracle_f32"] is not None:
         assert r["rel_l2_hip_bf16_vs_oracle_f32"] <= 1.25 * r["rel_l2_oracle_bf16_vs_oracle_f32"] + 1e-3, r
-    else:       # flux64: the oracle's own bf16 evaluation (2.11e-2 at this size, round 2) is not re-run inside the suite's time budget
-        assert r["rel_l2_hip_bf16_vs_oracle_f32"] <= 2.8e-2, r
+    else:       # flux64 / multi: the oracle's own bf16 evaluation (2.11e-2 / 1.944e-2 at these sizes, rounds 2 / 3: profiles/r02g_fullsize_parity_1024.log,
+                # r03f_*) is not re-run inside the suite's time budget (bf16 matmuls on the host cores: ~40 s each); the bound is 1.25x that + 1e-3
+        assert r["rel_l2_hip_bf16_vs_oracle_f32"] <= (2.8e-2 if which == "flux64" else 2.55e-2), r
 
 
 def test_full_depth_gradient_parity(gpu):
