@@ -245,6 +245,12 @@ __global__ __launch_bounds__(256, 1) void gemm_pwg64_kernel(const ug_gemm_desc p
             b0 = Wb + (n0 + row) * p.ldw + c * 8;
         }
         const int64_t a_pc = 8 * p.lda, b_pc = 8 * p.ldw;      // elements between consecutive pieces
+        // buffer form (VAR & 2): resources over the whole operand, per-lane byte offsets of this tile's first piece (the launcher checks they fit 32 bits)
+        const bf16_t* const Ab_ = (const bf16_t*)p.A + (int64_t)g * p.a_gstride;
+        const bf16_t* const Wb_ = (const bf16_t*)p.W + (int64_t)g * p.w_gstride;
+        const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)Ab_, 0, 0xffffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)Wb_, 0, 0xffffffff, 0x00020000);
+        const int vo_a = (int)((a0 - Ab_) * 2), vo_b = (int)((b0 - Wb_) * 2);
         auto stage_unit = [&](int u, int pc0, int pc1) __attribute__((always_inline)) {     // pieces [pc0, pc1) of unit u (K-tile u >> 1, past the end: clamped re-reads)
             int T = u >> 1; if (T > nkt - 1) T = nkt - 1;
             unsigned char* dst = smem + (u % QRING) * QU + wave * 64 * 128;
@@ -254,7 +260,17 @@ __global__ __launch_bounds__(256, 1) void gemm_pwg64_kernel(const ug_gemm_desc p
             const bf16_t* base = (u & 1) ? b0 : a0;
             asm volatile("" : "+v"(base));
             const int64_t pc = (u & 1) ? b_pc : a_pc;
-            for (int i = pc0; i < pc1; ++i) glds16(base + (ko + i * pc), dst + i * 1024);
+            if constexpr (VAR & 2) {
+                // round 4: the vendor kernel's DMA form (hipBLASLt Custom_Cijk_..._MT256x256x64: buffer_load_dwordx4 ... offen lds) - a buffer resource per
+                // operand, ONE loop-invariant per-lane byte offset, the K / piece offset as a scalar, M0 the destination: no VALU per DMA at all
+                for (int i = pc0; i < pc1; ++i) {
+                    const int so = (int)((ko + i * pc) * 2);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds((u & 1) ? rs_b : rs_a, (__attribute__((address_space(3))) void*)(dst + i * 1024), 16,
+                                                             (u & 1) ? vo_b : vo_a, so, 0, 0);
+                }
+            } else {
+                for (int i = pc0; i < pc1; ++i) glds16(base + (ko + i * pc), dst + i * 1024);
+            }
         };
         f32x4 acc[8][8];
 #pragma unroll
@@ -340,6 +356,321 @@ __global__ __launch_bounds__(256, 1) void gemm_pwg64_kernel(const ug_gemm_desc p
     }
 }
 
+// =====================================================================================================================
+// Round 4: the same one-wave-per-SIMD structure with the instruction economy of the vendor's hand-written kernel (hipBLASLt
+// Custom_Cijk_..._MT256x256x64_MI16x16x1: 128 MFMAs, 32 ds_read_b128, 16 buffer_load ... lds, 3 barriers, 4 waits and TWO VALU instructions per
+// K-tile and wave - profiles/r04x_*): gemm_pwg64_kernel above spends 47 VALU and ~60 scalar instructions per K-tile on ring-slot arithmetic
+// (slot = unit % 5 at run time) and 64-bit DMA addresses. Here
+//   * the ring is TWO K-tiles deep (A | W of tile parity 0, A | W of parity 1: 128 KiB) and the K loop is unrolled by two, so every LDS address is
+//     a loop-invariant lane offset plus an immediate;
+//   * the DMAs are buffer_load_dwordx4 ... offen lds: one resource per operand, ONE loop-invariant per-lane byte offset, the K-tile / piece offset
+//     in an SGPR, the destination in M0 - no VALU;
+//   * K-tile T + 2 is requested into parity (T & 1) during steps (T, 1) and (T + 1, 0), right after the barrier on top of step (T, 1) has released
+//     that parity's slots (every wave's fragments of (T, 1) are in registers), and is waited for on top of step (T + 1, 1).
+// Same fragments, same MFMA order per accumulator as gemm_pwg64_kernel: bit-identical results. Whole tiles, generic epilogue (measurement build).
+// =====================================================================================================================
+struct Pwg2Tile { int g; int64_t m0, n0; int vo_a, vo_b; const bf16_t* ab; const bf16_t* wb; };     // per-tile staging parameters of gemm_pwg2_kernel
+template <int EPI, int VAR = 0>      // VAR bit 0: the next K-tile's wait + barrier in the MIDDLE of the odd step (1.25 K-tiles of DMA lead); bit 1: no epilogue
+                                     // (timing only); bit 2: the generic epilogue and no cross-tile prefetch (the first build of this kernel)
+__global__ __launch_bounds__(256, 1) void gemm_pwg2_kernel(const ug_gemm_desc p, const int tiles_per_group, const int total_tiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int64_t M = p.M, N = p.N;
+    const int nM = (int)((M + 255) / 256), nN = (int)((N + 255) / 256);
+    const int nkt = (int)(p.K / 64);                 // >= 4, even (launcher)
+    using lds_ptr = __attribute__((address_space(3))) void*;
+    constexpr auto P0 = std::integral_constant<int, 0>{}; constexpr auto P1 = std::integral_constant<int, 1>{};
+    constexpr bool RES = EPI == UG_EPI_RES_GATE || EPI == UG_EPI_RES_SCALE;
+    constexpr bool FASTEPI = !(VAR & 4);
+    // full-tile epilogue conditions that do not depend on the tile (the launcher admits whole tiles only): 16-byte granularity, row maps that never split a tile
+    const bool fast_ok = FASTEPI && p.N % 8 == 0 && p.ldc % 8 == 0 && p.c_gstride % 8 == 0 && p.c_rpb % 256 == 0 && (!RES || (p.ldr % 8 == 0 && p.r_gstride % 8 == 0 && p.r_rpb % 256 == 0));
+
+    // per-tile staging parameters: buffer resources over the group's operands, this lane's byte offset of piece 0 of K-tile 0 (wave w stages rows
+    // [64 w, 64 w + 64) of a unit, 8 rows = 1 KiB per piece)
+    auto params = [&](int tile) __attribute__((always_inline)) {
+        Pwg2Tile t;
+        int lane_m = lane;
+        asm volatile("" : "+v"(lane_m));
+        t.g = tile / tiles_per_group;
+        const TileCoord tc = tile_of_block(tile - t.g * tiles_per_group, nM, nN, 4);
+        t.m0 = (int64_t)tc.tm * 256; t.n0 = (int64_t)tc.tn * 256;
+        const bf16_t* const Ab = (const bf16_t*)p.A + (int64_t)t.g * p.a_gstride;
+        const bf16_t* const Wb = (const bf16_t*)p.W + (int64_t)t.g * p.w_gstride;
+        t.ab = Ab; t.wb = Wb;
+        const int row = wave * 64 + (lane_m >> 3);
+        const int c = (lane_m & 7) ^ (row & 7);
+        t.vo_a = (int)(((int64_t)rowmap32((unsigned)(t.m0 + row), (unsigned)p.a_rpb, (unsigned)p.a_bstride) * p.lda + c * 8) * 2);
+        t.vo_b = (int)(((t.n0 + row) * p.ldw + c * 8) * 2);
+        return t;
+    };
+    const int a_pc = (int)(8 * p.lda * 2), b_pc = (int)(8 * p.ldw * 2);        // bytes between consecutive pieces
+    // pieces [pc0, pc1) of unit (parity PAR, operand OP) of K-tile T of tile t
+    auto dma = [&](const Pwg2Tile& t, auto par_c, auto op_c, int T, int pc0, int pc1) __attribute__((always_inline)) {
+        constexpr int PAR = decltype(par_c)::value, OP = decltype(op_c)::value;
+        unsigned char* dst = smem + (2 * PAR + OP) * QU + wave * 64 * 128;
+        // K-tiles past the end (the branch-free loop body requests two per tile pair regardless): an offset beyond the resource's range - the buffer
+        // unit answers such a piece with zeros at once, no memory traffic, so the drain behind the loop does not wait out a memory latency for data
+        // nobody reads (the first build re-read the last K-tile instead: ~1.5 us per tile)
+        const int so = T < nkt ? T * 128 : 0x7ffffff0;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(OP ? t.wb : t.ab), 0, 0x7fffff00, 0x00020000);
+        for (int i = pc0; i < pc1; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(dst + i * 1024), 16, OP ? t.vo_b : t.vo_a, so + i * (OP ? b_pc : a_pc), 0, 0);
+    };
+    auto request_first = [&](const Pwg2Tile& t) __attribute__((always_inline)) {      // K-tiles 0 and 1 of a tile: 32 pieces per wave
+        dma(t, P0, P0, 0, 0, 8); dma(t, P0, P1, 0, 0, 8); dma(t, P1, P0, 1, 0, 8); dma(t, P1, P1, 1, 0, 8);
+    };
+
+    Pwg2Tile cur = params(blockIdx.x);
+    bool prefetched = false;             // the previous epilogue requested this tile's K-tiles 0, 1 and left exactly 32 C stores per wave behind them
+    for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+        int lane_m = lane;
+        asm volatile("" : "+v"(lane_m));
+        const int frow = lane_m & 15, fch = lane_m >> 4;
+        // lane offsets of the fragment reads inside a 32 KiB unit: k-half 0 / 1 (chunk fch / 4 + fch of the lane's row), before tile * 2048
+        const int a_h0 = (wr * 128 + frow) * 128 + ((fch ^ (frow & 7)) << 4), a_h1 = (wr * 128 + frow) * 128 + (((4 + fch) ^ (frow & 7)) << 4);
+        const int b_h0 = (wc * 128 + frow) * 128 + ((fch ^ (frow & 7)) << 4), b_h1 = (wc * 128 + frow) * 128 + (((4 + fch) ^ (frow & 7)) << 4);
+        bf16x8 af[2][8], bf[2][8];
+        const bool relax = prefetched;
+        if (!prefetched) {
+            __builtin_amdgcn_s_barrier();                   // the previous tile's last reads retired (its MFMAs consumed them)
+            request_first(cur);
+            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // K-tile 0 landed
+        } else {
+            asm volatile("s_waitcnt vmcnt(48)" ::: "memory");   // ... with K-tile 1's 16 pieces and the epilogue's 32 stores still allowed in flight
+        }
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int t = 0; t < 8; ++t) af[0][t] = *(const bf16x8*)(smem + 0 * QU + a_h0 + t * 2048);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) bf[0][t] = *(const bf16x8*)(smem + 1 * QU + b_h0 + t * 2048);
+        // (zeroed HERE, behind the branchy prologue: initialised ahead of it hipcc carried the 256 zeros through the branch in VGPRs and spilled 65 of them)
+        f32x4 acc[8][8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; asm volatile("" : "+a"(acc[i][j])); }
+
+        // one 32-deep step: 64 MFMAs on fragment set SET; between them the 16 reads of the next step's fragments (unit pair NPAR, k-half NH) and, in the
+        // second step of a K-tile, the 16 DMA pieces of K-tile dT into the parity that step's top barrier has just freed (DPAR) - every address a
+        // lane constant + an immediate
+        auto step = [&](auto set_c, auto npar_c, auto nh_c, auto dpar_c, auto dma_c, int dT, bool rlx) __attribute__((always_inline)) {
+            constexpr int SET = decltype(set_c)::value, NPAR = decltype(npar_c)::value, NH = decltype(nh_c)::value;
+            constexpr bool DO_DMA = decltype(dma_c)::value != 0;
+            const unsigned char* ua = smem + (2 * NPAR) * QU + (NH ? a_h1 : a_h0);
+            const unsigned char* ub = smem + (2 * NPAR + 1) * QU + (NH ? b_h1 : b_h0);
+            // the vendor kernel's grain: ONE other instruction in the shadow of each MFMA (a 16x16x32 MFMA holds the pipe 16 cycles and the wave's issue
+            // 4): read behind the group's first MFMA, DMA behind its second - not both behind four MFMAs issued back to back
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+#pragma unroll
+                for (int q = 4 * i; q < 4 * i + 4; ++q) {
+                    const int mt = q / 8, nt = q % 8;
+                    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[mt][nt]) : "v"(bf[SET][nt]), "v"(af[SET][mt]));
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr ((VAR & 1) && DO_DMA) {
+                        // odd step, late reads: nothing in groups 0-7; the landed K-tile's wait + barrier before group 8; two reads per group after it
+                        if (q == 32) {
+                            // everything but this step's own first 8 pieces (and, in a prefetched tile's first odd step, the previous epilogue's 32 stores
+                            // that sit between K-tile 1's pieces and them on the in-order counter): the K-tile requested a tile ago
+                            if (rlx) asm volatile("s_waitcnt vmcnt(40)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                            __builtin_amdgcn_sched_barrier(0);
+                            __builtin_amdgcn_s_barrier();
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        if (i >= 8 && (q == 4 * i || q == 4 * i + 2)) {
+                            const int r = 2 * (i - 8) + (q == 4 * i ? 0 : 1);
+                            if (r < 8) af[SET ^ 1][r] = *(const bf16x8*)(ua + r * 2048);
+                            else bf[SET ^ 1][r - 8] = *(const bf16x8*)(ub + (r - 8) * 2048);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    } else if (q == 4 * i) {
+                        if (i < 8) af[SET ^ 1][i] = *(const bf16x8*)(ua + i * 2048);
+                        else bf[SET ^ 1][i - 8] = *(const bf16x8*)(ub + (i - 8) * 2048);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (q == 4 * i + 1) {
+                        if constexpr (DO_DMA) { if (i < 8) dma(cur, dpar_c, P0, dT, i, i + 1); else dma(cur, dpar_c, P1, dT, i - 8, i - 7); }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+        };
+        // K-tile pair (T, T + 1), T even: parities 0, 1. K-tile T + 2 is requested in step (T, 1), one whole K-tile before its first read.
+        for (int T = 0; T < nkt; T += 2) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            step(P0, P0, P1, P0, P0, 0, false);              // (T, 0): reads (T, 1)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if constexpr (!(VAR & 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // K-tile T + 1 landed (this wave's pieces; the barrier makes it everybody's)
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();                   // parity 0 free (every wave holds its (T, 1) fragments); parity 1 visible
+            __builtin_amdgcn_sched_barrier(0);
+            step(P1, P1, P0, P0, P1, T + 2, relax && T == 0);   // (T, 1): reads (T + 1, 0); DMA K-tile T + 2 into parity 0
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            step(P0, P1, P1, P0, P0, 0, false);              // (T + 1, 0): reads (T + 1, 1)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if constexpr (!(VAR & 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // K-tile T + 2 landed
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();                   // parity 1 free; parity 0 (K-tile T + 2) visible
+            __builtin_amdgcn_sched_barrier(0);
+            step(P1, P0, P0, P1, P1, T + 3, false);   // (T + 1, 1): reads (T + 2, 0) (past the end: stale, never used); DMA K-tile T + 3 into parity 1
+        }
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15" ::: "memory");
+
+        const int g = cur.g;
+        const int64_t m0 = cur.m0, n0 = cur.n0;
+        prefetched = false;
+        if constexpr (VAR & 2) { asm volatile("" :: "a"(acc[0][0]), "a"(acc[7][7])); if (tile + (int)gridDim.x < total_tiles) cur = params(tile + gridDim.x); continue; }      // timing only: no epilogue
+        int lane_e = lane_m;
+        asm volatile("" : "+v"(lane_e));
+        const TileSplit ts = tile_split<EPI>(p, n0);
+        bool fast = fast_ok;
+        unsigned sample = 0;
+        if constexpr (EPI == UG_EPI_RES_GATE) {
+            sample = (unsigned)m0 / (unsigned)p.rows_per_sample;
+            fast = fast && ((unsigned)m0 + 255u) / (unsigned)p.rows_per_sample == sample;
+        }
+        if (fast) {
+            // ---- full-tile epilogue (round 4), the product kernel's whole-line scheme on this kernel's accumulator layout. Lane (r = lane & 15, lg = lane >> 4)
+            // holds, per 16-row block mt and 16-column tile nt, columns nt * 16 + 4 lg .. + 3 of row mt * 16 + r. epi_chunk_full pairs two tiles into this
+            // lane's 16-byte chunk of a 64-byte half-line (columns (lg & 1) * 16 + 8 (lg >> 1) .. + 7 of the pair); a 128-byte line = tiles 4 L .. 4 L + 3
+            // = halves (4 L, 4 L + 1), (4 L + 2, 4 L + 3); lanes r and r ^ 8 trade halves through DPP row_ror:8, so every store (and residual load) covers
+            // 8 rows x 128 contiguous bytes. Order on the in-order VM counter: bias / gate / ALL residual chunks (32 x 16 bytes per lane: the K loop's 128
+            // fragment registers are dead) -> the next tile's first 32 DMA pieces -> the 32 C stores: no wait of this epilogue depends on the DMAs, and
+            // the next tile's first waits allow for exactly 32 stores.
+            const int lg = lane_e >> 4, r16 = lane_e & 15;
+            const int colc = (int)n0 + wc * 128 + (lg & 1) * 16 + 8 * (lg >> 1);        // this lane's chunk column inside half 0 of line 0
+            bf16_t* const Cb = (bf16_t*)p.C + (int64_t)g * p.c_gstride + colc + ts.cshift;
+            const int rl = wr * 128 + (r16 & 7);                                        // store / load A row of this lane inside block mt = 0
+            bf16_t* const c_laneA = Cb + (int64_t)(rowmap32((unsigned)m0, (unsigned)p.c_rpb, (unsigned)p.c_bstride) + (unsigned)rl) * p.ldc + (r16 >> 3) * 32;
+            const int dB = 8 * (int)p.ldc + (r16 < 8 ? 32 : -32);
+            float fb[8][4], fg[8][4];
+            {
+                const bf16_t* bias = p.bias ? (const bf16_t*)p.bias + (int64_t)g * p.bias_gstride : nullptr;
+                const bf16_t* gate = nullptr;
+                if constexpr (EPI == UG_EPI_RES_GATE) gate = (const bf16_t*)p.gate + (int64_t)g * p.gate_gstride + (int64_t)sample * p.gate_ld;
+#pragma unroll
+                for (int nt = 0; nt < 8; ++nt) {
+                    const int64_t n = n0 + wc * 128 + nt * 16 + lg * 4;
+                    u32x2 pb = (u32x2){0u, 0u}, pg = (u32x2){0u, 0u};
+                    if (bias) pb = *(const u32x2*)(bias + n);
+                    if constexpr (EPI == UG_EPI_RES_GATE) pg = *(const u32x2*)(gate + n);
+                    fb[nt][0] = bflo(pb.x); fb[nt][1] = bfhi(pb.x); fb[nt][2] = bflo(pb.y); fb[nt][3] = bfhi(pb.y);
+                    fg[nt][0] = bflo(pg.x); fg[nt][1] = bfhi(pg.x); fg[nt][2] = bflo(pg.y); fg[nt][3] = bfhi(pg.y);
+                }
+            }
+            u32x4 rbuf[16][2];            // residual: load A / load B of row-line group (mt, L) = 2 mt + L
+            if constexpr (RES) {
+                const bf16_t* const Rb = (const bf16_t*)p.R + (int64_t)g * p.r_gstride + colc;
+                const bf16_t* const r_laneA = Rb + (int64_t)(rowmap32((unsigned)m0, (unsigned)p.r_rpb, (unsigned)p.r_bstride) + (unsigned)rl) * p.ldr + (r16 >> 3) * 32;
+                const int dBr = 8 * (int)p.ldr + (r16 < 8 ? 32 : -32);
+#pragma unroll
+                for (int rg = 0; rg < 16; ++rg) {
+                    const bf16_t* rp = r_laneA + (int64_t)((rg >> 1) * 16) * p.ldr + (rg & 1) * 64;
+                    rbuf[rg][0] = gload16_asm(rp);
+                    rbuf[rg][1] = gload16_asm(rp + dBr);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (tile + (int)gridDim.x < total_tiles) {
+                cur = params(tile + gridDim.x);
+                __builtin_amdgcn_s_barrier();               // every wave's last LDS reads retired (their MFMAs consumed them: s_nop above): the ring is free
+                request_first(cur);
+                prefetched = true;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int rg = 0; rg < 16; ++rg) {
+                const int mt = rg >> 1, L = rg & 1;
+                u32x4 res_own[2] = {(u32x4){0u, 0u, 0u, 0u}, (u32x4){0u, 0u, 0u, 0u}};
+                if constexpr (RES) {
+                    // younger than this group's two loads: the later groups' loads, the 32 DMA pieces (when requested) and the stores so far
+                    if (rg == 0) { if (prefetched) asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int la = (int)rbuf[rg][0][q], lb = (int)rbuf[rg][1][q];
+                        res_own[0][q] = (unsigned)__builtin_amdgcn_update_dpp(la, lb, 0xE4, 0xF, 0xC, false);
+                        const int z = __builtin_amdgcn_update_dpp(lb, la, 0xE4, 0xF, 0xC, false);
+                        res_own[1][q] = (unsigned)__builtin_amdgcn_update_dpp(z, z, 0x128, 0xF, 0xF, false);
+                    }
+                }
+                u32x4 o[2];
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const int nt = 4 * L + 2 * hh;
+                    o[hh] = (EPI == UG_EPI_BIAS_GELU && !ts.gelu)
+                        ? epi_chunk_full<UG_EPI_BIAS>(p.alpha, acc[mt][nt], acc[mt][nt + 1], fb[nt], fb[nt + 1], fg[nt], fg[nt + 1], res_own[hh])
+                        : epi_chunk_full<EPI>(p.alpha, acc[mt][nt], acc[mt][nt + 1], fb[nt], fb[nt + 1], fg[nt], fg[nt + 1], res_own[hh]);
+                }
+                u32x4 xa, xb;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    xa[q] = (unsigned)__builtin_amdgcn_update_dpp((int)o[0][q], (int)o[1][q], 0x128, 0xF, 0xC, false);
+                    xb[q] = (unsigned)__builtin_amdgcn_update_dpp((int)o[0][q], (int)o[1][q], 0x128, 0xF, 0x3, false);
+                }
+                bf16_t* cp = c_laneA + (int64_t)(mt * 16) * p.ldc + L * 64;
+                __builtin_nontemporal_store(xa, (u32x4*)cp);
+                __builtin_nontemporal_store(xb, (u32x4*)(cp + dB));
+                __builtin_amdgcn_sched_barrier(0);          // one row-line group at a time: hoisting the accumulator reads of later groups spilled 65 registers
+            }
+            continue;
+        }
+        // ---- generic epilogue: lane holds, for row m = .. + mt * 16 + (lane & 15), columns nt * 16 + 4 (lane >> 4) .. + 3 ----
+        if (tile + (int)gridDim.x < total_tiles) cur = params(tile + gridDim.x);
+        const bf16_t* bias = p.bias ? (const bf16_t*)p.bias + (int64_t)g * p.bias_gstride : nullptr;
+        float bv[8][4];
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt) {
+            const int64_t n = n0 + wc * 128 + nt * 16 + (lane_e >> 4) * 4;
+            load_bias4(n < N ? bias : nullptr, n, bv[nt]);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+            const int64_t m = m0 + wr * 128 + mt * 16 + (lane_e & 15);
+            const bool row_ok = m < M;
+            RowCtx rc = row_ctx<EPI>(p, g, (unsigned)(row_ok ? m : M - 1));
+            rc.coff += ts.cshift;
+#pragma unroll
+            for (int np = 0; np < 4; ++np) {
+                if (EPI == UG_EPI_BIAS_GELU && !ts.gelu)
+                    epi_store_pair16<UG_EPI_BIAS>(p, rc, row_ok, n0 + wc * 128 + np * 32, N, lane_e, acc[mt][2 * np], acc[mt][2 * np + 1], bv[2 * np], bv[2 * np + 1]);
+                else
+                    epi_store_pair16<EPI>(p, rc, row_ok, n0 + wc * 128 + np * 32, N, lane_e, acc[mt][2 * np], acc[mt][2 * np + 1], bv[2 * np], bv[2 * np + 1]);
+            }
+        }
+    }
+}
+
+template <int EPI, int VAR = 0>
+int launch_pwg2_t(const ug_gemm_desc& d, hipStream_t s) {
+    constexpr int PLDS = 4 * QU;
+    const int groups = d.groups > 0 ? d.groups : 1;
+    const int64_t t256 = ((d.M + 255) / 256) * ((d.N + 255) / 256) * groups;
+    UG_REQUIRE(d.K % 128 == 0 && d.K >= 256 && d.M % 256 == 0 && d.N % 256 == 0 && d.a_rpb % 256 == 0, UG_ERR_UNSUPPORTED,
+               "ug_gemm_bf16(pwg2): whole 256^2 tiles only, K a multiple of 128 and >= 256 (M=%lld N=%lld K=%lld)", (long long)d.M, (long long)d.N, (long long)d.K);
+    UG_REQUIRE((double)d.M * d.lda * 2 < 4.0e9 && (double)d.N * d.ldw * 2 < 4.0e9, UG_ERR_UNSUPPORTED, "ug_gemm_bf16(pwg2): operands beyond 32-bit byte offsets");
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_pwg2_kernel<EPI, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS);
+        attr_set = true;
+    }
+    static int ncu = 0;
+    if (ncu == 0) {
+        int dev = 0; hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
+        if (ncu <= 0) ncu = 256;
+    }
+    const int total = (int)t256;
+    dim3 grid((unsigned)(total < ncu ? total : ncu), 1, 1);
+    hipLaunchKernelGGL((gemm_pwg2_kernel<EPI, VAR>), grid, dim3(256), PLDS, s, d, (int)(t256 / groups), total);
+    UG_CHECK_LAUNCH("ug_gemm_bf16(pwg2)");
+    return UG_OK;
+}
+
 template <int EPI, int VAR>
 int launch_pwg64_t(const ug_gemm_desc& d, hipStream_t s) {
     constexpr int PLDS = QRING * QU;
@@ -395,9 +726,22 @@ int launch_pwg_t(const ug_gemm_desc& d, hipStream_t s) {
 int ug_gemm_launch_pwg(const ug_gemm_desc& d, hipStream_t s) {
     const int mode = ug_env_int("UG_GEMM_PWG", 0);
     const int var = ug_env_int("UG_PWG_VAR", 0);
+    if (mode == 4) {                  // round 4: two-K-tile ring, unrolled, buffer-form DMAs, full-tile epilogue + cross-tile prefetch (gemm_pwg2_kernel)
+#define UG_PWG2_CASE(E)                                                                                                    \
+    case E: return var == 3 ? launch_pwg2_t<E, 3>(d, s) : var == 5 ? launch_pwg2_t<E, 5>(d, s) : var == 0 ? launch_pwg2_t<E, 0>(d, s) : launch_pwg2_t<E, 1>(d, s);
+        switch (d.epilogue) {
+            UG_PWG2_CASE(UG_EPI_BIAS)
+            UG_PWG2_CASE(UG_EPI_BIAS_GELU)
+            UG_PWG2_CASE(UG_EPI_RES_GATE)
+            UG_PWG2_CASE(UG_EPI_RES_SCALE)
+            default: UG_FAIL(UG_ERR_UNSUPPORTED, "ug_gemm_bf16(pwg2): epilogue %d", d.epilogue);
+        }
+#undef UG_PWG2_CASE
+    }
     if (mode == 3) {                  // round 3: whole-line (64-deep ring units) one-wave-per-SIMD kernel; var 1 = no DMA, 16 = no MFMA (timing only)
         switch (d.epilogue) {
-            case UG_EPI_BIAS: return var == 1 ? launch_pwg64_t<UG_EPI_BIAS, 1>(d, s) : var == 16 ? launch_pwg64_t<UG_EPI_BIAS, 16>(d, s) : launch_pwg64_t<UG_EPI_BIAS, 0>(d, s);
+            case UG_EPI_BIAS: return var == 1 ? launch_pwg64_t<UG_EPI_BIAS, 1>(d, s) : var == 16 ? launch_pwg64_t<UG_EPI_BIAS, 16>(d, s) :
+                                     var == 2 ? launch_pwg64_t<UG_EPI_BIAS, 2>(d, s) : launch_pwg64_t<UG_EPI_BIAS, 0>(d, s);
             case UG_EPI_BIAS_GELU: return launch_pwg64_t<UG_EPI_BIAS_GELU, 0>(d, s);
             case UG_EPI_RES_GATE: return launch_pwg64_t<UG_EPI_RES_GATE, 0>(d, s);
             case UG_EPI_RES_SCALE: return launch_pwg64_t<UG_EPI_RES_SCALE, 0>(d, s);

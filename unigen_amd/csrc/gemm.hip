@@ -935,7 +935,9 @@ int launch(const ug_gemm_desc& d, hipStream_t s) {
         // profiles/r03d_gemm_cplain.log: the per-tile store cost is not the cache policy.)
         // UG_GEMM_PWG=1: the one-wave-per-SIMD kernel (gemm_pwg.hip) takes every shape it supports
 #ifdef UG_PROBE_BUILD
-        if (EPI != UG_EPI_F32 && (wide16 & 1) && !lora && ug_env_int("UG_GEMM_PWG", 0)) return ug_gemm_launch_pwg(d, s);
+        if (EPI != UG_EPI_F32 && (wide16 & 1) && !lora && ug_env_int("UG_GEMM_PWG", 0) && d.K <= ug_env_int("UG_PWG_MAXK", 1 << 30) &&
+            (ug_env_int("UG_GEMM_PWG", 0) != 4 || (d.M % 256 == 0 && d.N % 256 == 0 && d.K % 128 == 0 && d.K >= 256 && d.a_rpb % 256 == 0 && total >= ncu)))
+            return ug_gemm_launch_pwg(d, s);
 #endif
         // split-K tail (see the kernel header): needs the caller's workspace for the slabs and tickets
         int full = total, nsl = 1;
