@@ -492,7 +492,7 @@ __global__ __launch_bounds__(256, 1) void gemm_pwg2_kernel(const ug_gemm_desc p,
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     if (q == 4 * i + 1) {
-                        if constexpr (DO_DMA) { if (i < 8) dma(cur, dpar_c, P0, dT, i, i + 1); else dma(cur, dpar_c, P1, dT, i - 8, i - 7); }
+                        if constexpr (DO_DMA && !(VAR & 8)) { if (i < 8) dma(cur, dpar_c, P0, dT, i, i + 1); else dma(cur, dpar_c, P1, dT, i - 8, i - 7); }
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -728,7 +728,7 @@ int ug_gemm_launch_pwg(const ug_gemm_desc& d, hipStream_t s) {
     const int var = ug_env_int("UG_PWG_VAR", 0);
     if (mode == 4) {                  // round 4: two-K-tile ring, unrolled, buffer-form DMAs, full-tile epilogue + cross-tile prefetch (gemm_pwg2_kernel)
 #define UG_PWG2_CASE(E)                                                                                                    \
-    case E: return var == 3 ? launch_pwg2_t<E, 3>(d, s) : var == 5 ? launch_pwg2_t<E, 5>(d, s) : var == 0 ? launch_pwg2_t<E, 0>(d, s) : launch_pwg2_t<E, 1>(d, s);
+    case E: return var == 3 ? launch_pwg2_t<E, 3>(d, s) : var == 5 ? launch_pwg2_t<E, 5>(d, s) : var == 0 ? launch_pwg2_t<E, 0>(d, s) : var == 11 ? launch_pwg2_t<E, 11>(d, s) : launch_pwg2_t<E, 1>(d, s);
         switch (d.epilogue) {
             UG_PWG2_CASE(UG_EPI_BIAS)
             UG_PWG2_CASE(UG_EPI_BIAS_GELU)
