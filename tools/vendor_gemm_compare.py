@@ -27,13 +27,12 @@ for label, M, N, K in SHAPES:
         return f
     runs = [("hipBLASLt (F.linear)", lambda: F.linear(a, w, b)), ("ug_gemm_bf16", ug())]
     if PROBE:
-        runs += [("pwg2 generic epilogue", ug(UG_GEMM_PWG="4", UG_PWG_VAR="5")), ("pwg2 full-tile epilogue + prefetch", ug(UG_GEMM_PWG="4", UG_PWG_VAR="1")),
-                 ("pwg2 no epilogue (timing only)", ug(UG_GEMM_PWG="4", UG_PWG_VAR="3")), ("pwg2 no epilogue, no loop DMA (timing only)", ug(UG_GEMM_PWG="4", UG_PWG_VAR="11"))]
+        runs += [("pwg2", ug(UG_GEMM_PWG="4", UG_PWG_VAR="1")), ("pwg2 shared first operand", ug(UG_GEMM_PWG="4", UG_PWG_VAR="17"))]
     for _, f in runs:
         f(); f()
     torch.cuda.synchronize()
     ref = F.linear(a, w, b)
-    runs[-3 if PROBE else -1][1]()
+    runs[-1][1]()
     rel = float((out.float() - ref.float()).norm() / ref.float().norm())
     times = [[] for _ in runs]
     for rnd in range(5):

@@ -356,6 +356,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
 #define UG_MMA_QUADRANT(I, J, BR)                                                                                      \
     do {                                                                                                               \
         UG_GEMM_PRIO(1);                                                                                               \
+        /* (Measured and dropped, round 4: nt outside mt, so that consecutive MFMAs share their FIRST source operand as in the vendor's loop - +1.5...+2.5 % */ \
+        /* on the one-wave-per-SIMD probe kernel, -1...-1.5 % per shape and -1.2 % in the forward here: profiles/r04y_mfma_order.log) */              \
         _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                               \
             _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                           \
                 _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                       \
