@@ -384,6 +384,7 @@ __global__ __launch_bounds__(256, 1) void gemm_pwg2_kernel(const ug_gemm_desc p,
     using lds_ptr = __attribute__((address_space(3))) void*;
     constexpr auto P0 = std::integral_constant<int, 0>{}; constexpr auto P1 = std::integral_constant<int, 1>{};
     constexpr bool RES = EPI == UG_EPI_RES_GATE || EPI == UG_EPI_RES_SCALE;
+    constexpr int EPI_A = EPI == UG_EPI_QKV_ROPE ? UG_EPI_BIAS_GELU : EPI;      // what a tile outside the q | k columns runs
     constexpr bool FASTEPI = !(VAR & 4);
     // full-tile epilogue conditions that do not depend on the tile (the launcher admits whole tiles only): 16-byte granularity, row maps that never split a tile
     const bool fast_ok = FASTEPI && p.N % 8 == 0 && p.ldc % 8 == 0 && p.c_gstride % 8 == 0 && p.c_rpb % 256 == 0 && (!RES || (p.ldr % 8 == 0 && p.r_gstride % 8 == 0 && p.r_rpb % 256 == 0));
@@ -564,6 +565,110 @@ __global__ __launch_bounds__(256, 1) void gemm_pwg2_kernel(const ug_gemm_desc p,
                     fg[nt][0] = bflo(pg.x); fg[nt][1] = bfhi(pg.x); fg[nt][2] = bflo(pg.y); fg[nt][3] = bfhi(pg.y);
                 }
             }
+            if constexpr (EPI == UG_EPI_QKV_ROPE) {
+                if (n0 < p.qk_until_n) {
+                    // ---- q | k tile (head width 128): on this layout a head IS one wave's 128 columns, so the RMSNorm row sum needs no LDS and no other wave -
+                    // 32 values per lane, then the four lane groups of the row by permlane swaps (sum_row_groups). Per 16-row block: v = bf16(acc + bias),
+                    // rs = rsqrt(mean v^2 + eps), x = bf16(bf16(v rs) w), rotation pairs (x0, x1), (x2, x3) by this lane's (cos, sin) pairs of the row's
+                    // position, then the whole-line stores of the generic path. Rounding points as gemm256_kernel's q | k epilogue: same bits.
+                    const bf16_t* const wsel = (const bf16_t*)(2 * n0 >= p.qk_until_n ? p.qk_wk : p.qk_wq);
+                    float fw[8][4];
+#pragma unroll
+                    for (int nt = 0; nt < 8; ++nt) {
+                        const u32x2 pw = *(const u32x2*)(wsel + nt * 16 + lg * 4);
+                        fw[nt][0] = bflo(pw.x); fw[nt][1] = bfhi(pw.x); fw[nt][2] = bflo(pw.y); fw[nt][3] = bfhi(pw.y);
+                    }
+                    unsigned rpb = (unsigned)p.rope_rpb;
+                    asm volatile("" : "+s"(rpb));
+                    const unsigned wrap = rpb ? rpb : 0xffffffffu;
+                    const unsigned mrow = (unsigned)m0 + wr * 128 + r16;
+                    const unsigned rr0 = rpb ? mrow % rpb : mrow;
+                    const float* const csb = p.rope_cs + lg * 4;
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (tile + (int)gridDim.x < total_tiles) {
+                        cur = params(tile + gridDim.x);
+                        __builtin_amdgcn_s_barrier();
+                        request_first(cur);
+                        prefetched = true;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    u32x4 cbuf[2][8];
+                    auto open_rows = [&](int mt) __attribute__((always_inline)) {
+                        unsigned rr = rr0 + mt * 16;
+                        if (rr >= wrap) rr -= wrap;
+                        const float* q = csb + ((int64_t)p.rope_pos0 + rr) * 128;
+                        cbuf[mt & 1][0] = gload16_asm(q);
+                        asm volatile("global_load_dwordx4 %0, %1, off offset:64" : "=v"(cbuf[mt & 1][1]) : "v"(q) : "memory");
+                        asm volatile("global_load_dwordx4 %0, %1, off offset:128" : "=v"(cbuf[mt & 1][2]) : "v"(q) : "memory");
+                        asm volatile("global_load_dwordx4 %0, %1, off offset:192" : "=v"(cbuf[mt & 1][3]) : "v"(q) : "memory");
+                        asm volatile("global_load_dwordx4 %0, %1, off offset:256" : "=v"(cbuf[mt & 1][4]) : "v"(q) : "memory");
+                        asm volatile("global_load_dwordx4 %0, %1, off offset:320" : "=v"(cbuf[mt & 1][5]) : "v"(q) : "memory");
+                        asm volatile("global_load_dwordx4 %0, %1, off offset:384" : "=v"(cbuf[mt & 1][6]) : "v"(q) : "memory");
+                        asm volatile("global_load_dwordx4 %0, %1, off offset:448" : "=v"(cbuf[mt & 1][7]) : "v"(q) : "memory");
+                    };
+                    open_rows(0);
+#pragma unroll
+                    for (int mt = 0; mt < 8; ++mt) {
+                        if (mt + 1 < 8) open_rows(mt + 1);
+                        // younger than this block's 8 loads on the in-order counter: the next block's 8 loads and the previous block's 4 stores
+                        if (mt == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                        else if (mt == 7) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                        else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+#pragma unroll
+                        for (int t8 = 0; t8 < 8; ++t8) asm volatile("" : "+v"(cbuf[mt & 1][t8]));
+                        float ss = 0.f;
+                        float v[8][4];
+#pragma unroll
+                        for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+                            for (int q = 0; q < 4; q += 2) {
+                                float v0 = acc[mt][nt][q] + fb[nt][q], v1 = acc[mt][nt][q + 1] + fb[nt][q + 1];
+                                rbf2(v0, v1);
+                                v[nt][q] = v0; v[nt][q + 1] = v1;
+                                ss += v0 * v0; ss += v1 * v1;
+                            }
+                        const float tot = sum_row_groups(ss);
+                        const float rs = __builtin_amdgcn_rsqf(tot * (1.0f / 128.0f) + p.qk_eps);
+                        u32x4 o[4];               // the four 64-byte halves of the row's two lines: tiles (0, 1), (2, 3) | (4, 5), (6, 7)
+#pragma unroll
+                        for (int pr = 0; pr < 4; ++pr) {
+                            unsigned pk[2][2];
+#pragma unroll
+                            for (int e = 0; e < 2; ++e) {
+                                const int nt = 2 * pr + e;
+                                const u32x4 cs = cbuf[mt & 1][nt];
+                                const float c0 = __builtin_bit_cast(float, (unsigned)cs.x), s0 = __builtin_bit_cast(float, (unsigned)cs.y);
+                                const float c1 = __builtin_bit_cast(float, (unsigned)cs.z), s1 = __builtin_bit_cast(float, (unsigned)cs.w);
+                                float x[4];
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) x[q] = v[nt][q] * rs;
+                                rbf2(x[0], x[1]); rbf2(x[2], x[3]);
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) x[q] = x[q] * fw[nt][q];
+                                rbf2(x[0], x[1]); rbf2(x[2], x[3]);
+                                pk[e][0] = pack2bf(x[0] * c0 + (-x[1]) * s0, x[1] * c0 + x[0] * s0);
+                                pk[e][1] = pack2bf(x[2] * c1 + (-x[3]) * s1, x[3] * c1 + x[2] * s1);
+                            }
+                            swap16(pk[0][0], pk[1][0]); swap16(pk[0][1], pk[1][1]);
+                            o[pr].x = pk[0][0]; o[pr].y = pk[0][1]; o[pr].z = pk[1][0]; o[pr].w = pk[1][1];
+                        }
+#pragma unroll
+                        for (int L = 0; L < 2; ++L) {
+                            u32x4 xa, xb;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                xa[q] = (unsigned)__builtin_amdgcn_update_dpp((int)o[2 * L][q], (int)o[2 * L + 1][q], 0x128, 0xF, 0xC, false);
+                                xb[q] = (unsigned)__builtin_amdgcn_update_dpp((int)o[2 * L][q], (int)o[2 * L + 1][q], 0x128, 0xF, 0x3, false);
+                            }
+                            bf16_t* cp = c_laneA + (int64_t)(mt * 16) * p.ldc + L * 64;
+                            __builtin_nontemporal_store(xa, (u32x4*)cp);
+                            __builtin_nontemporal_store(xb, (u32x4*)(cp + dB));
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    continue;
+                }
+            }
             u32x4 rbuf[16][2];            // residual: load A / load B of row-line group (mt, L) = 2 mt + L
             if constexpr (RES) {
                 const bf16_t* const Rb = (const bf16_t*)p.R + (int64_t)g * p.r_gstride + colc;
@@ -603,9 +708,9 @@ __global__ __launch_bounds__(256, 1) void gemm_pwg2_kernel(const ug_gemm_desc p,
 #pragma unroll
                 for (int hh = 0; hh < 2; ++hh) {
                     const int nt = 4 * L + 2 * hh;
-                    o[hh] = (EPI == UG_EPI_BIAS_GELU && !ts.gelu)
+                    o[hh] = (EPI_A == UG_EPI_BIAS_GELU && !ts.gelu)
                         ? epi_chunk_full<UG_EPI_BIAS>(p.alpha, acc[mt][nt], acc[mt][nt + 1], fb[nt], fb[nt + 1], fg[nt], fg[nt + 1], res_own[hh])
-                        : epi_chunk_full<EPI>(p.alpha, acc[mt][nt], acc[mt][nt + 1], fb[nt], fb[nt + 1], fg[nt], fg[nt + 1], res_own[hh]);
+                        : epi_chunk_full<EPI_A>(p.alpha, acc[mt][nt], acc[mt][nt + 1], fb[nt], fb[nt + 1], fg[nt], fg[nt + 1], res_own[hh]);
                 }
                 u32x4 xa, xb;
 #pragma unroll
@@ -633,14 +738,14 @@ __global__ __launch_bounds__(256, 1) void gemm_pwg2_kernel(const ug_gemm_desc p,
         for (int mt = 0; mt < 8; ++mt) {
             const int64_t m = m0 + wr * 128 + mt * 16 + (lane_e & 15);
             const bool row_ok = m < M;
-            RowCtx rc = row_ctx<EPI>(p, g, (unsigned)(row_ok ? m : M - 1));
+            RowCtx rc = row_ctx<EPI_A>(p, g, (unsigned)(row_ok ? m : M - 1));
             rc.coff += ts.cshift;
 #pragma unroll
             for (int np = 0; np < 4; ++np) {
-                if (EPI == UG_EPI_BIAS_GELU && !ts.gelu)
+                if (EPI_A == UG_EPI_BIAS_GELU && !ts.gelu)
                     epi_store_pair16<UG_EPI_BIAS>(p, rc, row_ok, n0 + wc * 128 + np * 32, N, lane_e, acc[mt][2 * np], acc[mt][2 * np + 1], bv[2 * np], bv[2 * np + 1]);
                 else
-                    epi_store_pair16<EPI>(p, rc, row_ok, n0 + wc * 128 + np * 32, N, lane_e, acc[mt][2 * np], acc[mt][2 * np + 1], bv[2 * np], bv[2 * np + 1]);
+                    epi_store_pair16<EPI_A>(p, rc, row_ok, n0 + wc * 128 + np * 32, N, lane_e, acc[mt][2 * np], acc[mt][2 * np + 1], bv[2 * np], bv[2 * np + 1]);
             }
         }
     }
@@ -721,6 +826,11 @@ int launch_pwg_t(const ug_gemm_desc& d, hipStream_t s) {
 }
 
 }  // namespace
+
+// UG_GEMM_PWG=4 and the fused q/k RMSNorm + RoPE launch (head width 128, with RoPE): called by gemm.hip's launch_qkrope in the probe build
+int ug_gemm_launch_pwg2_qkrope(const ug_gemm_desc& d, hipStream_t s) {
+    return launch_pwg2_t<UG_EPI_QKV_ROPE, 1>(d, s);
+}
 
 // Called by gemm.hip's dispatcher for shapes the 256^2 tiles fill (no LoRA segment, 16-byte epilogue granularity, not UG_EPI_F32).
 // mode (UG_GEMM_PWG): 1 = one wave per SIMD, 2 = two waves per SIMD.

@@ -1009,6 +1009,12 @@ int launch_qkrope(const ug_gemm_desc& d, hipStream_t s) {
     const int total = (int)((d.M / 256) * (d.N / 256));
     UG_REQUIRE(d.c_rpb % 256 == 0, UG_ERR_UNSUPPORTED, "ug_gemm_bf16: UG_EPI_QKV_ROPE needs the C row map's rows per batch (%lld) to be a multiple of 256",
                (long long)d.c_rpb);
+#ifdef UG_PROBE_BUILD
+    // UG_GEMM_PWG=4: the one-wave-per-SIMD probe kernel's port of this epilogue (head width 128 with RoPE, whole rounds, K a multiple of 128)
+    if (ug_env_int("UG_GEMM_PWG", 0) == 4 && qdh == 128 && d.rope_cs && d.K % 128 == 0 && d.K >= 256 && d.a_rpb % 256 == 0 && total >= ncu &&
+        d.K <= ug_env_int("UG_PWG_MAXK", 1 << 30))
+        return ug_gemm_launch_pwg2_qkrope(d, s);
+#endif
     const int wgm = 3 | (UG_TUNE("UG_GEMM_XTILE", 0) ? 4 : 0) | ((UG_TUNE("UG_GEMM_GROUP_M", 4) & 0xff) << 8) | ((UG_TUNE("UG_GEMM_WALK", 0) & 3) << 16);
     const dim3 grid((unsigned)(total < ncu ? total : ncu));
     float* stamps = nullptr;

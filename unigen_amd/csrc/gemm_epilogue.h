@@ -6,6 +6,7 @@
 #ifdef UG_PROBE_BUILD
 // one-wave-per-SIMD 256^2 kernels (gemm_pwg.hip, probe library only: measured 8-11 % behind the 8-phase kernel); UG_GEMM_PWG selects them
 int ug_gemm_launch_pwg(const ug_gemm_desc& d, hipStream_t s);
+int ug_gemm_launch_pwg2_qkrope(const ug_gemm_desc& d, hipStream_t s);
 #endif
 
 // Implicit-GEMM convolution on the 256^2 kernel (vae.hip -> gemm.hip): the A operand of ug_gemm_desc is the NHWC activation, gathered per filter tap.
