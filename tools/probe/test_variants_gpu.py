@@ -319,3 +319,63 @@ def test_gemm_tn_weight_gradient(gpu, R_, I, J):
     wide_a[:, 8:8 + I], wide_b[:, 16:16 + J] = a, b
     out2 = gemm_tn(wide_a.to(gpu)[:, 8:8 + I], wide_b.to(gpu)[:, 16:16 + J])
     assert torch.equal(out2, out)
+
+
+def test_gemm_pwg2_two_tile_ring_kernel_matches_default(gpu):
+    """Round 4: gemm_pwg2_kernel (UG_GEMM_PWG=4) - the one-wave-per-SIMD kernel on the vendor loop's economy (two-K-tile ring, unrolled; buffer-form
+    DMAs; whole-line full-tile epilogue; the next tile's first DMA pieces ahead of the C stores). Same MFMA shape and K order per accumulator as the
+    8-phase kernel -> bit-identical under bias / GELU / gated and scaled residual epilogues, with one and with several tiles per workgroup, a
+    row-mapped A, K = 256 (the ring's minimum) .. 3072; the ported q/k RMSNorm + RoPE epilogue sums a head's squares inside one wave instead of
+    across four, so a few q / k elements may differ by the last bf16 bit of a rotation operand (<= 1e-5 of them, <= 2^-4 absolute at these magnitudes)."""
+    import subprocess
+    code = r"""
+import os, sys
+os.environ["UG_ENV_DYNAMIC"] = "1"
+sys.path.insert(0, %r)
+import torch
+from unigen_amd import ops, lib as L
+from unigen_amd.ops import RowMap, QkRope
+dev = torch.device("cuda:0")
+g = torch.Generator(device=dev).manual_seed(0)
+rn = lambda *s: torch.randn(*s, generator=g, device=dev).to(torch.bfloat16)
+bad = 0
+for (M, N, K, epi, mapped) in [(4096, 4096, 256, L.EPI_BIAS, False), (4096, 4096, 384, L.EPI_BIAS_GELU, False), (8192, 4096, 3072, L.EPI_RES_GATE, False),
+                               (4096, 8192, 512, L.EPI_RES_SCALE, True), (16384, 3072, 1024, L.EPI_BIAS_GELU, False), (8192, 6144, 640, "qkrope", False)]:
+    rows = M // 2 if mapped else 0
+    a = rn(M + (256 if mapped else 0), K)                 # mapped: two batches of M / 2 rows at a stride of M / 2 + 256 rows
+    w, b = rn(N, K) * 0.1, rn(N)
+    r, gate = rn(M, N), rn(M // 1024, N)
+    outs = []
+    kw = dict(M=M)
+    if epi == "qkrope":
+        rpb = M // 2
+        cs = (torch.rand(rpb, 64, 2, generator=g, device=dev) * 2 - 1).contiguous()
+        kw.update(qk_rope=QkRope(rn(128) + 1, rn(128) + 1, cs, rpb, 0, 4096, 1e-6, 128), gelu_from_n=5120)
+    else:
+        kw.update(epilogue=epi)
+    if mapped:
+        kw.update(a_map=RowMap(rows, rows + 256))
+    if epi in (L.EPI_RES_GATE, L.EPI_RES_SCALE):
+        kw.update(residual=r, alpha=0.7)
+    if epi == L.EPI_RES_GATE:
+        kw.update(gate=gate, gate_ld=N, rows_per_sample=1024)
+    for mode in ("0", "4"):
+        os.environ["UG_GEMM_PWG"] = mode
+        out = torch.zeros(M, N, device=dev, dtype=torch.bfloat16)
+        for _ in range(2):
+            ops.gemm(a, w, b, out, **kw)
+        outs.append(out)
+    torch.cuda.synchronize()
+    diff = (outs[0] != outs[1])
+    frac = float(diff.float().mean())
+    ok = torch.isfinite(outs[1].float()).all() and (frac == 0.0 if epi != "qkrope" else (frac <= 1e-5 and not diff[:, 4096:].any() and
+          float((outs[0].float() - outs[1].float()).abs().max()) <= 2.0 ** -4))      # one ulp of a rotation's operands (values of a few units), not of the rotated result
+    print(M, N, K, epi, mapped, "differing elements", frac)
+    if not ok:
+        bad += 1
+        print("MISMATCH", M, N, K, epi, mapped, float((outs[1].float() - outs[0].float()).abs().max()))
+sys.exit(1 if bad else 0)
+""" % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    print(r.stdout[-2000:])
+    assert r.returncode == 0, r.stdout + r.stderr
