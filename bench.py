@@ -346,12 +346,80 @@ def _dry_run(args, world, rank):
         dist.destroy_process_group()
 
 
-def _timed(one_step, steps, warmup, dev, world, timer, ops):
+class _PowerSampler:
+    """Package power and shader clock of THIS rank's GPU during the timed region, read from the amdgpu hwmon files of the device with torch's PCI
+    address (power1_input in microwatts, freq1_input in Hz; plain file reads on a side thread every 0.2 s - no subprocess, no HIP call). The
+    forward runs at the package power cap (profiles/r04s_power.log); the line carries the evidence for its own run. None where sysfs is not readable."""
+
+    def __init__(self, dev):
+        self.dir, self.samples, self._stop, self._thread = None, [], None, None
+        try:
+            if dev.type != "cuda":
+                return
+            pr = torch.cuda.get_device_properties(dev)
+            want = (int(getattr(pr, "pci_domain_id", 0)), int(pr.pci_bus_id), int(pr.pci_device_id))
+            base = "/sys/class/drm"
+            for card in sorted(os.listdir(base)):
+                if not card.startswith("card") or "-" in card:
+                    continue
+                real = os.path.realpath(os.path.join(base, card, "device"))
+                parts = os.path.basename(real).replace(".", ":").split(":")          # 0000:dc:00.0
+                if len(parts) != 4 or (int(parts[0], 16), int(parts[1], 16), int(parts[2], 16)) != want:
+                    continue
+                hw = os.path.join(real, "hwmon")
+                for h in sorted(os.listdir(hw)):
+                    if os.path.exists(os.path.join(hw, h, "power1_input")):
+                        self.dir = os.path.join(hw, h)
+                        return
+        except Exception:
+            self.dir = None
+
+    @staticmethod
+    def _read(path):
+        with open(path) as f:
+            return float(f.read().strip())
+
+    def start(self):
+        if self.dir is None:
+            return
+        import threading
+        self._stop = threading.Event()
+
+        def loop():
+            while not self._stop.is_set():
+                try:
+                    self.samples.append((self._read(os.path.join(self.dir, "power1_input")) / 1e6, self._read(os.path.join(self.dir, "freq1_input")) / 1e6))
+                except Exception:
+                    return
+                self._stop.wait(0.2)
+        self._thread = threading.Thread(target=loop, daemon=True)
+        self._thread.start()
+
+    def stop(self):
+        if self._thread is None:
+            return None
+        self._stop.set()
+        self._thread.join(timeout=2.0)
+        if len(self.samples) < 2:
+            return None
+        w, f = sorted(x[0] for x in self.samples), sorted(x[1] for x in self.samples)
+        cap = None
+        try:
+            cap = self._read(os.path.join(self.dir, "power1_cap")) / 1e6
+        except Exception:
+            pass
+        return dict(watts_median=w[len(w) // 2], watts_min=w[0], watts_max=w[-1], cap_watts=cap, sclk_mhz_median=f[len(f) // 2], samples=len(w),
+                    source="amdgpu hwmon power1_input / freq1_input of this rank's device, every 0.2 s inside the timed region")
+
+
+def _timed(one_step, steps, warmup, dev, world, timer, ops, power=None):
     from unigen_amd import dist_utils as DU
     for _ in range(warmup):
         out = one_step()
     DU.barrier(dev, world)
     ops.set_timer(timer)
+    if power is not None:
+        power.start()
     t0 = time.perf_counter()
     for _ in range(steps):
         out = one_step()
@@ -439,7 +507,9 @@ def main():
             graph.replay()
             return graph_out
     timer = None if (args.no_kernel_timer or args.graph) else ops.KernelTimer()
-    elapsed, out, own_elapsed = _timed(one_step, args.steps, args.warmup, dev, world, timer, ops)
+    sampler = _PowerSampler(dev) if rank == 0 else None
+    elapsed, out, own_elapsed = _timed(one_step, args.steps, args.warmup, dev, world, timer, ops, power=sampler)
+    power = sampler.stop() if sampler is not None else None
     # one all_gather of every rank's own record, so that a straggler (or a rank on the wrong device) shows in the one JSON line.
     # The measured MFMA-only rate of each rank's chip rides along: boxes differ by 8-12 % (DVFS), and cross-box comparisons need it.
     probe = not (args.no_kernel_timer or args.graph)          # profiling runs (--no-kernel-timer) keep the probe's launches out of the kernel statistics
@@ -490,6 +560,8 @@ def main():
                 line["mfma_probe_tflops"] = dict(shape_16x16x32=pk16, shape_32x32x16=pk32, note="ug_probe_mfma_bf16, same run, rank 0's device")
         if scaling_base is not None:
             line["scaling_base"] = scaling_base
+        if power is not None:
+            line["power"] = power             # rank 0's GPU inside the timed region: the forward sits at the package power cap
         if s:
             gm, at = s.get("gemm"), s.get("attn")
             ach = gm["flops"] / (gm["ms"] * 1e-3) / 1e12
