@@ -425,14 +425,14 @@ def expert_forward(state: State, xd: torch.Tensor, cd: torch.Tensor, pd: torch.T
 
 
 def comoe_experts(state: State, cfg: FluxConfig, x, c, pooled, cond_pooled, gates_in: Optional[torch.Tensor],
-                  uniform: torch.Tensor, literal: bool = False):
+                  uniform: torch.Tensor, literal: bool = False, choice: Optional[torch.Tensor] = None):
     """MOELayer.forward + UniGenFlux.expert_forward with modulated experts. x, c: [B, N, D]. Returns
     (expert_h [B,N,D], expert_c [B,N,D], l_aux, exp_counts, routing dict)."""
     B, N, D = x.shape
     E = cfg.expert_nums
     S = B * N
     dt = x.dtype
-    choice = (x + c).reshape(S, D)
+    choice = (x + c if choice is None else choice).reshape(S, D)        # choice_expert_input (src/UniGenTransformer.py:979)
     wg = state["moe.moe_layer.gate.wg.weight"]
     logits = F.linear(choice.float(), wg.float())           # TopKGate.forward: fp32 input and weight
     l_aux, combine_weights, dispatch_mask, exp_counts, routing = gate_route(logits, uniform, cfg.top_num)
@@ -461,34 +461,190 @@ def comoe_experts(state: State, cfg: FluxConfig, x, c, pooled, cond_pooled, gate
     return eh, ec, l_aux, exp_counts, routing
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# Wiring of UniGenFlux / MultiCondtionUniGenFlux: the reference's own methods (moe_forward, preprocess_moe_forward, control_forward,
+# base_forward), written against INJECTED module callables `m` - the attributes of `self` those methods call. REFERENCE-PINNED:
+# tests/test_ref_wiring_cpu.py runs these very functions on the deterministic stand-in modules of tests/wiring_cases.py and holds them, bit for
+# bit, to the outputs of the reference's methods executed from /root/reference on the same stand-ins (tests/golden/ref_wiring.safetensors,
+# written by tests/golden/make_ref_wiring_golden.py). unigen_flux_forward below calls the same functions with modules built from a state dict.
+#
+#   m.double(i, x, enc, temb) -> (enc, x)                                transformer_blocks[i] (base RoPE table inside)
+#   m.single(j, h, temb) -> h                                            single_transformer_blocks[j]
+#   m.control_joint(k, z, enc, temb, hd_ids, encoder_hd_ids) -> (enc, z) control_joint_trans_blocks[k]; ids None = no RoPE ({} kwargs)
+#   m.control_single(k, h, temb, hd_ids) -> h                            control_single_trans_blocks[k]
+#   m.add_joint(k, z), m.add_single(k, z)                                controlnet_add_*_blocks[k] (zero-res projections)
+#   m.control_x_embedder(c), m.control_context_embedder(enc)
+#   m.control_time_text_embed(timestep, pooled, guidance), m.control_condition_embed(timestep, cond_pooled, guidance)
+#   m.moe_layer(choice_expert_input=, hidden_states=, condition_hidden_states=, encoder_hidden_states=, temb=, condition_temb=,
+#               condition_pooled_projections=, pooled_projections=) -> (expert_h, expert_c, l_aux, exp_counts)      self.moe.moe_layer
+#   m.shared_expert(k, x, enc, temb, hd_ids, encoder_hd_ids) -> (enc, x);  m.consis_module(k, ...) likewise
+# ---------------------------------------------------------------------------------------------------------------------
+
+def _cat_ids(*ids):
+    return torch.cat(list(ids), dim=0)
+
+
+def flux_moe_forward(m, cfg: FluxConfig, x, c, *, ctrl_enc, control_temb, condition_temb, pooled, cond_pooled, ids: Optional[Dict[str, torch.Tensor]]):
+    """UniGenFlux.moe_forward (src/UniGenTransformer.py:969-1026; UniGenBase.moe_forward :269-296 is the same text without the consistency
+    module). x = hidden states, c = embedded condition tokens, kwargs['temb'] = control_temb (:1055). `ids` None <=> use_rope False.
+    Returns ((hidden + expert_h, condition + expert_c), l_aux, exp_counts)."""
+    rope = ids is not None
+    eh, ec, l_aux, exp_counts = m.moe_layer(choice_expert_input=x + c, hidden_states=x, condition_hidden_states=c, encoder_hidden_states=ctrl_enc,
+                                            temb=control_temb, condition_temb=condition_temb, condition_pooled_projections=cond_pooled,
+                                            pooled_projections=pooled)
+    out = (eh, ec)
+    if getattr(cfg, "use_consis_module", False):
+        # "V2" (:984-1004): consis_module[0] is called TWICE, consis_module[1] is built (:909-920) but never called; both keep the sample stream
+        #   1. sample = expert condition states, context = condition tokens c, temb = condition_temb, ids (condition_ids | condition_ids)
+        #   2. sample = [expert hidden | result of 1], context = hidden states x, temb = kwargs['temb'], ids ([img | cond] | img)
+        _, cech = m.consis_module(0, ec, c, condition_temb, ids["condition_ids"] if rope else None, ids["condition_ids"] if rope else None)
+        _, y = m.consis_module(0, torch.cat([eh, cech], dim=1), x, control_temb,
+                               _cat_ids(ids["img_ids"], ids["condition_ids"]) if rope else None, ids["img_ids"] if rope else None)
+        n0 = eh.shape[1]
+        eh, ec = eh + y[:, :n0, :], ec + y[:, n0:, :]
+        # reference quirk (found by the wiring fixture, case flux_consis_rope_no_single): the consistency terms are added to the local
+        # variables only; the returned tuple `expert_output` is rebuilt from them inside `if self.use_shared_expert` (:1024) and nowhere else, so
+        # with use_consis_module and WITHOUT use_shared_expert the reference returns the raw MoE output and the module's work is discarded.
+    if cfg.use_shared_expert:
+        # shared_expert[0](hidden = x, encoder = c, temb = condition_temb), sample rows first: [img | cond]            (:1013-1015)
+        cond_s, x_s = m.shared_expert(0, x, c, condition_temb, ids["img_ids"] if rope else None, ids["condition_ids"] if rope else None)
+        # shared_expert[1](hidden = [x_s | cond_s], encoder = ctrl_enc, temb = kwargs['temb'])                        (:1017-1022)
+        _, hc = m.shared_expert(1, torch.cat([x_s, cond_s], dim=1), ctrl_enc, control_temb,
+                                _cat_ids(ids["img_ids"], ids["condition_ids"]) if rope else None, ids["prompt_ids"] if rope else None)
+        n = x_s.shape[1]
+        x_s, cond_s = hc[:, :n, :], hc[:, n:, :]
+        out = (x_s + eh, cond_s + ec)
+    return out, l_aux, exp_counts
+
+
+def flux_preprocess_moe_forward(m, cfg: FluxConfig, x, condition_hidden_states, enc, pooled, condition_pooled_projections, timestep, *,
+                                guidance, img_ids, prompt_ids, condition_ids, trace: Optional[dict] = None):
+    """UniGenFlux.preprocess_moe_forward (src/UniGenTransformer.py:1028-1068) and, when the condition arguments are lists,
+    MultiCondtionUniGenFlux.preprocess_moe_forward (:1275-1322: the whole MoE per condition; sum of (expert_h + expert_c) and of the
+    condition tembs; l_aux / exp_counts of the LAST condition). Returns dict(z0, ctrl_enc, control_temb, condition_temb, l_aux, exp_counts)."""
+    multi = isinstance(condition_hidden_states, (list, tuple))
+    control_pooled = pooled if cfg.use_pooled_prompt_embeds else torch.zeros_like(pooled)
+    control_temb = m.control_time_text_embed(timestep, control_pooled, guidance)
+    if multi:
+        ctrl_enc = m.control_context_embedder(enc)
+        merged, merged_temb = [], []
+        for k, (cid, ct, cp) in enumerate(zip(condition_ids, condition_hidden_states, condition_pooled_projections)):
+            if cp.dim() == 1:
+                cp = cp.unsqueeze(0)
+            if ct.dim() == 2:
+                ct = ct.unsqueeze(0)
+            c = m.control_x_embedder(ct)
+            condition_temb = m.control_condition_embed(timestep, cp, guidance)
+            ids = dict(img_ids=img_ids, prompt_ids=prompt_ids, condition_ids=cid) if cfg.use_rope else None
+            if hasattr(m, "select_condition"):
+                m.select_condition(k)
+            (oh, oc), l_aux, exp_counts = flux_moe_forward(m, cfg, x, c, ctrl_enc=ctrl_enc, control_temb=control_temb, condition_temb=condition_temb,
+                                                           pooled=pooled, cond_pooled=cp, ids=ids)
+            merged.append(oh + oc)
+            merged_temb.append(condition_temb)
+        z0, condition_temb = sum(merged), sum(merged_temb)
+    else:
+        c = m.control_x_embedder(condition_hidden_states)
+        condition_temb = m.control_condition_embed(timestep, condition_pooled_projections, guidance)
+        ctrl_enc = m.control_context_embedder(enc)
+        ids = dict(img_ids=img_ids, prompt_ids=prompt_ids, condition_ids=condition_ids) if cfg.use_rope else None
+        (oh, oc), l_aux, exp_counts = flux_moe_forward(m, cfg, x, c, ctrl_enc=ctrl_enc, control_temb=control_temb, condition_temb=condition_temb,
+                                                       pooled=pooled, cond_pooled=condition_pooled_projections, ids=ids)
+        z0 = oh + oc                                                                     # control_forward :1089
+    if trace is not None:
+        trace["z0"] = z0
+    return dict(z0=z0, ctrl_enc=ctrl_enc, control_temb=control_temb, condition_temb=condition_temb, l_aux=l_aux, exp_counts=exp_counts)
+
+
+def flux_base_forward(m, cfg: FluxConfig, x, condition_hidden_states, enc, pooled, condition_pooled_projections, timestep, *,
+                      conditioning_scale, temb, guidance, img_ids, prompt_ids, condition_ids, trace: Optional[dict] = None):
+    """UniGenFlux.base_forward (src/UniGenTransformer.py:1106-1180) with control_forward (:1070-1104; MultiCondtionUniGenFlux's :1324-1357 is the
+    same with the merged keys) inlined: loop A (base double block -> control block on the BASE stream -> zero-res add), concat [text | image],
+    loop B (base single block -> control single block -> zero-res add), slice. The control blocks are not chained: each reads the base stream
+    (only the first reads the CoMoE output); ctrl_enc / condition_temb are fixed after base block 0. Returns (x, enc, moe_out)."""
+    moe_out = None
+    n_d, n_cj = cfg.num_layers, cfg.cn_joint_layers
+    for i in range(n_d):
+        k = int(i / (n_d / n_cj))                                                        # :1126-1127
+        enc, x = m.double(i, x, enc, temb)
+        if moe_out is None:                                                              # :1085-1089, once, with the text stream AFTER base block 0
+            moe_out = flux_preprocess_moe_forward(m, cfg, x, condition_hidden_states, enc, pooled, condition_pooled_projections, timestep,
+                                                  guidance=guidance, img_ids=img_ids, prompt_ids=prompt_ids, condition_ids=condition_ids, trace=trace)
+            z_in = moe_out["z0"]
+        else:
+            z_in = x
+        _, z = m.control_joint(k, z_in, moe_out["ctrl_enc"], moe_out["condition_temb"],
+                               img_ids if cfg.use_rope else None, prompt_ids if cfg.use_rope else None)          # :1095-1097
+        x = x + m.add_joint(k, z) * conditioning_scale                                   # :1104, :1141
+        if trace is not None:
+            trace.setdefault("x_after_double", []).append(x)
+    T = enc.shape[1]
+    h = torch.cat([enc, x], dim=1)
+    n_s, n_cs = cfg.num_single_layers, cfg.cn_single_layers
+    for j in range(n_s):
+        h = m.single(j, h, temb)
+        if cfg.use_single_trans_blocks:                                                  # hasattr(self, 'control_single_trans_blocks') :1159
+            k = int(j / (n_s / n_cs))
+            z = m.control_single(k, h, moe_out["condition_temb"], _cat_ids(prompt_ids, img_ids) if cfg.use_rope else None)   # :1099-1102
+            y = m.add_single(k, z) * conditioning_scale
+            if cfg.single_block_control_method == "overall_add":
+                h = h + y
+            else:                                                                        # "in flux controlnet": image rows only (:1168-1172)
+                h = torch.cat([h[:, :T, ...], h[:, T:, ...] + y[:, T:, ...]], dim=1)
+    return h[:, T:, ...], enc, moe_out
+
+
+def flux_modules(state: State, cfg: FluxConfig, rope, gate_uniform, n_cond: int = 1, trace: Optional[dict] = None):
+    """The injected callables of the wiring above, built from a flat state dict (the reference's module tree by parameter name)."""
+    from types import SimpleNamespace
+    m = SimpleNamespace()
+    unis = gate_uniform if isinstance(gate_uniform, (list, tuple)) else [gate_uniform] * n_cond
+    sel = dict(k=0)
+
+    def crope(hd_ids, encoder_hd_ids=None):
+        # JointAttnRopeProcessor (src/UniGenUtils.py:590-597): table over cat([hd_ids, encoder_hd_ids]), cast to the ids' dtype
+        if hd_ids is None:
+            return None
+        return control_rope(cfg, hd_ids if encoder_hd_ids is None else torch.cat([hd_ids, encoder_hd_ids], dim=0))
+
+    def joint(prefix):
+        return lambda k, x, enc, temb, hd_ids, encoder_hd_ids: flux_double_block(state, f"{prefix}.{k}", cfg, x, enc, temb, crope(hd_ids, encoder_hd_ids), text_first=False)
+
+    def moe_layer(*, choice_expert_input, hidden_states, condition_hidden_states, encoder_hidden_states, temb, condition_temb,
+                  condition_pooled_projections, pooled_projections):
+        eh, ec, l_aux, exp_counts, routing = comoe_experts(state, cfg, hidden_states, condition_hidden_states, pooled_projections,
+                                                           condition_pooled_projections, None, unis[sel["k"]], choice=choice_expert_input)
+        if trace is not None:
+            trace.setdefault("routing", []).append(routing)
+        return eh, ec, l_aux, exp_counts
+
+    m.select_condition = lambda k: sel.update(k=k)
+    m.double = lambda i, x, enc, temb: flux_double_block(state, f"transformer_blocks.{i}", cfg, x, enc, temb, rope, text_first=True)
+    m.single = lambda j, h, temb: flux_single_block(state, f"single_transformer_blocks.{j}", cfg, h, temb, rope)
+    m.control_joint = joint("control_joint_trans_blocks")
+    m.control_single = lambda k, h, temb, hd_ids: flux_single_block(state, f"control_single_trans_blocks.{k}", cfg, h, temb, crope(hd_ids))
+    m.add_joint = lambda k, z: linear(state, f"controlnet_add_joint_blocks.{k}", z)
+    m.add_single = lambda k, z: linear(state, f"controlnet_add_single_blocks.{k}", z)
+    m.control_x_embedder = lambda c: linear(state, "control_x_embedder", c)
+    m.control_context_embedder = lambda e: linear(state, "control_context_embedder", e)
+    m.control_time_text_embed = lambda t, p, g: time_text_embed(state, "control_time_text_embed", t, p, g)
+    m.control_condition_embed = lambda t, p, g: time_text_embed(state, "control_condition_embed", t, p, g)
+    m.moe_layer = moe_layer
+    m.shared_expert = joint("shared_expert")
+    m.consis_module = joint("consis_module")
+    return m
+
+
 def comoe(state: State, cfg: FluxConfig, x, cond_tokens, ctrl_enc, control_temb, condition_temb, pooled, cond_pooled,
           ids: Dict[str, torch.Tensor], uniform: torch.Tensor):
-    """One condition's CoMoE: control_x_embedder + MoE experts + shared experts (src/UniGenTransformer.py:969-1026,1040).
-    Returns (expert_hidden_states, expert_condition_hidden_states, l_aux, exp_counts, routing)."""
-    c = linear(state, "control_x_embedder", cond_tokens)
-    eh, ec, l_aux, exp_counts, routing = comoe_experts(state, cfg, x, c, pooled, cond_pooled, None, uniform)
-    if cfg.use_consis_module:
-        # "V2" consistency module (src/UniGenTransformer.py:984-1004): consis_module[0] is called TWICE, consis_module[1] is built (:909-920,
-        # so it is in the state dict and in trainable_control_modules) but never called. Both calls keep only the sample-stream output.
-        #   1. sample = expert condition states, context = condition tokens c, temb = condition_temb, ids (condition_ids | condition_ids)
-        #   2. sample = [expert hidden | result of 1], context = hidden states x, temb = kwargs['temb'] = control_temb (:1055), ids (img | cond | img)
-        N0 = x.shape[1]
-        rope_a = control_rope(cfg, torch.cat([ids["condition_ids"], ids["condition_ids"]], 0)) if cfg.use_rope else None
-        _, cech = flux_double_block(state, "consis_module.0", cfg, ec, c, condition_temb, rope_a, text_first=False)
-        rope_b = control_rope(cfg, torch.cat([ids["img_ids"], ids["condition_ids"], ids["img_ids"]], 0)) if cfg.use_rope else None
-        _, y = flux_double_block(state, "consis_module.0", cfg, torch.cat([eh, cech], 1), x, control_temb, rope_b, text_first=False)
-        eh, ec = eh + y[:, :N0], ec + y[:, N0:]
-    if not cfg.use_shared_expert:
-        return eh, ec, l_aux, exp_counts, routing
-    # shared_expert[0](hidden=x, encoder=c, temb=condition_temb): sample-first [img | cond]   (:1013-1015)
-    rope0 = control_rope(cfg, torch.cat([ids["img_ids"], ids["condition_ids"]], 0)) if cfg.use_rope else None
-    cond_s, x_s = flux_double_block(state, "shared_expert.0", cfg, x, c, condition_temb, rope0, text_first=False)
-    # shared_expert[1](hidden=[x_s | cond_s], encoder=ctrl_enc, temb=control_temb)                 (:1017-1022)
-    rope1 = control_rope(cfg, torch.cat([ids["img_ids"], ids["condition_ids"], ids["prompt_ids"]], 0)) if cfg.use_rope else None
-    _, hc = flux_double_block(state, "shared_expert.1", cfg, torch.cat([x_s, cond_s], 1), ctrl_enc, control_temb, rope1, text_first=False)
-    N = x.shape[1]
-    x_s, cond_s = hc[:, :N], hc[:, N:]
-    return x_s + eh, cond_s + ec, l_aux, exp_counts, routing
+    """One condition's CoMoE: control_x_embedder + MoE experts + shared experts (src/UniGenTransformer.py:969-1026,1040) through the pinned
+    wiring. Returns (expert_hidden_states, expert_condition_hidden_states, l_aux, exp_counts, routing)."""
+    trace: dict = {}
+    m = flux_modules(state, cfg, None, uniform, trace=trace)
+    c = m.control_x_embedder(cond_tokens)
+    (oh, oc), l_aux, exp_counts = flux_moe_forward(m, cfg, x, c, ctrl_enc=ctrl_enc, control_temb=control_temb, condition_temb=condition_temb,
+                                                   pooled=pooled, cond_pooled=cond_pooled, ids=ids if cfg.use_rope else None)
+    return oh, oc, l_aux, exp_counts, trace["routing"][0]
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -499,7 +655,8 @@ def unigen_flux_forward(state: State, cfg: FluxConfig, *, hidden_states, conditi
                         pooled_projections, condition_pooled_projections, timestep, img_ids, txt_ids, condition_ids,
                         guidance=None, conditioning_scale: float = 1.0, gate_uniform=None, dtype=torch.bfloat16,
                         io_dtype=torch.bfloat16, trace: Optional[dict] = None):
-    """src/UniGenTransformer.py:1182-1271 (single condition) and :1360-1450 (lists => MultiCondtionUniGenFlux).
+    """src/UniGenTransformer.py:1182-1271 (single condition) and :1360-1450 (lists => MultiCondtionUniGenFlux): embeds, the base RoPE table,
+    base_forward through the reference-pinned wiring above, norm_out + proj_out.
     gate_uniform: [S, E] fp32 uniforms (one tensor, or a list per condition) standing in for the RTS draw."""
     multi = isinstance(condition_hidden_states, (list, tuple))
     dt = dtype
@@ -514,59 +671,13 @@ def unigen_flux_forward(state: State, cfg: FluxConfig, *, hidden_states, conditi
     temb = time_text_embed(state, "time_text_embed", timestep, pooled, guidance)
     enc = linear(state, "context_embedder", cast(encoder_hidden_states))
     rope = flux_pos_embed(torch.cat((txt_ids, img_ids), dim=0), cfg.axes_dims_rope)   # base path: fp32 tables
-    ids = dict(img_ids=img_ids, prompt_ids=txt_ids)
-    T = enc.shape[1]
-
-    moe_out = None
-    n_d, n_cj = cfg.num_layers, cfg.cn_joint_layers
-    for i in range(n_d):
-        enc, x = flux_double_block(state, f"transformer_blocks.{i}", cfg, x, enc, temb, rope, text_first=True)
-        m = int(i / (n_d / n_cj))
-        if moe_out is None:  # preprocess_moe_forward, once per step, with the text stream AFTER base block 0 (:1137 -> :1051)
-            control_pooled = pooled if cfg.use_pooled_prompt_embeds else torch.zeros_like(pooled)
-            control_temb = time_text_embed(state, "control_time_text_embed", timestep, control_pooled, guidance)
-            ctrl_enc = linear(state, "control_context_embedder", enc)
-            conds = list(zip(condition_hidden_states, condition_pooled_projections, condition_ids)) if multi else \
-                [(condition_hidden_states, condition_pooled_projections, condition_ids)]
-            unis = gate_uniform if isinstance(gate_uniform, (list, tuple)) else [gate_uniform] * len(conds)
-            merged, merged_temb = None, None
-            for (ct, cp, cid), uni in zip(conds, unis):
-                cp = cast(cp)
-                condition_temb = time_text_embed(state, "control_condition_embed", timestep, cp, guidance)
-                eh, ec, l_aux, exp_counts, routing = comoe(state, cfg, x, cast(ct), ctrl_enc, control_temb, condition_temb, pooled, cp,
-                                                           dict(ids, condition_ids=cid), uni)
-                z = eh + ec
-                merged = z if merged is None else merged + z              # sum(list) (:1316)
-                merged_temb = condition_temb if merged_temb is None else merged_temb + condition_temb
-                if trace is not None:
-                    trace.setdefault("routing", []).append(routing)
-            moe_out = dict(ctrl_enc=ctrl_enc, condition_temb=merged_temb, l_aux=l_aux, exp_counts=exp_counts)
-            z_in = merged
-            if trace is not None:
-                trace["z0"] = merged
-        else:
-            z_in = x
-        crope = control_rope(cfg, torch.cat([img_ids, txt_ids], 0)) if cfg.use_rope else None
-        _, z = flux_double_block(state, f"control_joint_trans_blocks.{m}", cfg, z_in, moe_out["ctrl_enc"], moe_out["condition_temb"],
-                                 crope, text_first=False)
-        x = x + linear(state, f"controlnet_add_joint_blocks.{m}", z) * conditioning_scale
-        if trace is not None:
-            trace.setdefault("x_after_double", []).append(x)
-
-    h = torch.cat([enc, x], dim=1)
-    n_s, n_cs = cfg.num_single_layers, cfg.cn_single_layers
-    for j in range(n_s):
-        h = flux_single_block(state, f"single_transformer_blocks.{j}", cfg, h, temb, rope)
-        if cfg.use_single_trans_blocks:
-            m = int(j / (n_s / n_cs))
-            crope = control_rope(cfg, torch.cat([txt_ids, img_ids], 0)) if cfg.use_rope else None
-            z = flux_single_block(state, f"control_single_trans_blocks.{m}", cfg, h, moe_out["condition_temb"], crope)
-            y = linear(state, f"controlnet_add_single_blocks.{m}", z) * conditioning_scale
-            if cfg.single_block_control_method == "overall_add":
-                h = h + y
-            else:
-                h = torch.cat([h[:, :T], h[:, T:] + y[:, T:]], dim=1)
-    x = h[:, T:]
+    if multi:
+        cond, cpool = [cast(t) for t in condition_hidden_states], [cast(t) for t in condition_pooled_projections]
+    else:
+        cond, cpool = cast(condition_hidden_states), cast(condition_pooled_projections)
+    m = flux_modules(state, cfg, rope, gate_uniform, n_cond=len(cond) if multi else 1, trace=trace)
+    x, enc, moe_out = flux_base_forward(m, cfg, x, cond, enc, pooled, cpool, timestep, conditioning_scale=conditioning_scale, temb=temb,
+                                        guidance=guidance, img_ids=img_ids, prompt_ids=txt_ids, condition_ids=condition_ids, trace=trace)
     x = adaln_continuous(state, "norm_out", x, temb)
     out = linear(state, "proj_out", x)
     return out, dict(moe_loss=moe_out["l_aux"] * 0.1), dict(expert_counts=moe_out["exp_counts"])
@@ -788,6 +899,7 @@ class SD3Config:
     expert_num_each_condition: int = 3
     expert_num: Optional[int] = None
     top_num: int = 1
+    use_rope: bool = False          # only the wiring restates it (ids handed to the injected blocks); the SD3 blocks here have no RoPE
 
     @property
     def inner_dim(self) -> int:
@@ -911,50 +1023,128 @@ def sd3_single_block(state: State, prefix: str, H: int, x, temb):
     return x + _gate(gm, feed_forward(state, prefix + ".ff", _mod(layer_norm(x), scm, shm)))
 
 
-def sd3_comoe(state: State, cfg: SD3Config, x, c, ctrl_enc, control_temb, condition_temb, pooled, cond_pooled, uniform):
-    """UniGenBase.moe_forward + expert_forward (src/UniGenTransformer.py:225-296): MoE experts (modulated linears or two
-    SD3SingleTransformerBlocks fed per-token tembs, attending over the expert's capacity slots) + the two shared joint blocks."""
+def _sd3_experts(state: State, cfg: SD3Config, x, c, control_temb, condition_temb, pooled, cond_pooled, uniform, choice=None):
+    """MOELayer.forward + UniGenBase.expert_forward (src/UniGenTransformer.py:225-267): modulated linears, or two SD3SingleTransformerBlocks per
+    expert fed per-token tembs, attending over the expert's capacity slots. Returns (expert_h, expert_c, l_aux, exp_counts, routing)."""
     B, N, D = x.shape
     E, S, H, dt = cfg.expert_nums, B * N, cfg.num_attention_heads, x.dtype
     if cfg.use_modulate:
         fcfg = FluxConfig(attention_head_dim=cfg.attention_head_dim, num_attention_heads=H, condition_nums=cfg.condition_nums,
                           expert_num_each_condition=cfg.expert_num_each_condition, expert_num=cfg.expert_num, top_num=cfg.top_num)
-        eh, ec, l_aux, exp_counts, routing = comoe_experts(state, fcfg, x, c, pooled, cond_pooled, None, uniform)
-    else:
-        logits = F.linear((x + c).reshape(S, D).float(), state["moe.moe_layer.gate.wg.weight"].float())
-        l_aux, combine_weights, _, exp_counts, routing = gate_route(logits, uniform, cfg.top_num)
-        C, tos = routing["capacity"], routing["token_of_slot"]
+        return comoe_experts(state, fcfg, x, c, pooled, cond_pooled, None, uniform, choice=choice)
+    logits = F.linear((x + c if choice is None else choice).reshape(S, D).float(), state["moe.moe_layer.gate.wg.weight"].float())
+    l_aux, combine_weights, _, exp_counts, routing = gate_route(logits, uniform, cfg.top_num)
+    C, tos = routing["capacity"], routing["token_of_slot"]
 
-        def dispatch(t2d):
-            out = torch.zeros(E, C, t2d.shape[-1], dtype=t2d.dtype)
-            valid = tos >= 0
-            out[valid] = t2d[tos[valid]]
-            return out
+    def dispatch(t2d):
+        out = torch.zeros(E, C, t2d.shape[-1], dtype=t2d.dtype)
+        valid = tos >= 0
+        out[valid] = t2d[tos[valid]]
+        return out
 
-        xd, cd = dispatch(x.reshape(S, D)), dispatch(c.reshape(S, D))
-        td = dispatch(control_temb.unsqueeze(1).expand(-1, N, -1).reshape(S, D))
-        ctd = dispatch(condition_temb.unsqueeze(1).expand(-1, N, -1).reshape(S, D))
-        yh, yc = [], []
-        for e in range(E):
-            p = f"moe.moe_layer.experts.deepspeed_experts.{e}"
-            yh.append(sd3_single_block(state, p + ".0", H, xd[e][None], td[e][None])[0])        # expert[0](hidden, temb)        (:261)
-            yc.append(sd3_single_block(state, p + ".1", H, cd[e][None], ctd[e][None])[0])       # expert[1](condition, cond_temb) (:262)
-        cw = combine_weights.to(dt)
-        eh = torch.einsum("sec,ecm->sm", cw, torch.stack(yh)).reshape(B, N, D)
-        ec = torch.einsum("sec,ecm->sm", cw, torch.stack(yc)).reshape(B, N, D)
-    if not cfg.use_shared_expert:
-        return eh, ec, l_aux, exp_counts, routing
-    cond_s, x_s = sd3_joint_block(state, "shared_expert.0", H, x, c, condition_temb, context_pre_only=False, dual=False)
-    _, hc = sd3_joint_block(state, "shared_expert.1", H, torch.cat([x_s, cond_s], 1), ctrl_enc, control_temb, context_pre_only=True, dual=True)
-    x_s, cond_s = hc[:, :N], hc[:, N:]
-    return x_s + eh, cond_s + ec, l_aux, exp_counts, routing
+    xd, cd = dispatch(x.reshape(S, D)), dispatch(c.reshape(S, D))
+    td = dispatch(control_temb.unsqueeze(1).expand(-1, N, -1).reshape(S, D))
+    ctd = dispatch(condition_temb.unsqueeze(1).expand(-1, N, -1).reshape(S, D))
+    yh, yc = [], []
+    for e in range(E):
+        p = f"moe.moe_layer.experts.deepspeed_experts.{e}"
+        yh.append(sd3_single_block(state, p + ".0", H, xd[e][None], td[e][None])[0])        # expert[0](hidden, temb)        (:261)
+        yc.append(sd3_single_block(state, p + ".1", H, cd[e][None], ctd[e][None])[0])       # expert[1](condition, cond_temb) (:262)
+    cw = combine_weights.to(dt)
+    eh = torch.einsum("sec,ecm->sm", cw, torch.stack(yh)).reshape(B, N, D)
+    ec = torch.einsum("sec,ecm->sm", cw, torch.stack(yc)).reshape(B, N, D)
+    return eh, ec, l_aux, exp_counts, routing
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Wiring of UniGenSD3 against injected module callables `m` (REFERENCE-PINNED like the FLUX wiring above: tests/test_ref_wiring_cpu.py).
+# UniGenBase.moe_forward (src/UniGenTransformer.py:269-296) is flux_moe_forward's text without the consistency module - the same function.
+#   m.block(i, x, enc, temb) -> (enc | None, x)          transformer_blocks[i]
+#   m.control_block(k, z, enc, temb, hd_ids, encoder_hd_ids) -> (enc, z);   m.add(k, z)
+#   m.control_pos_embed_input(latent), m.control_context_embedder(enc), m.control_time_text_embed(t, pooled), m.control_condition_embed(t, pooled)
+#   m.moe_layer(...), m.shared_expert(k, x, enc, temb, hd_ids, encoder_hd_ids)  as for FLUX
+# ---------------------------------------------------------------------------------------------------------------------
+
+def sd3_preprocess_moe_forward(m, cfg: SD3Config, x, condition_hidden_states, enc, pooled, cond_pooled, timestep, *, ids=None, trace=None):
+    """UniGenSD3.preprocess_moe_forward (src/UniGenTransformer.py:498-537)."""
+    c = m.control_pos_embed_input(condition_hidden_states)
+    control_pooled = pooled if cfg.use_pooled_prompt_embeds else torch.zeros_like(pooled)
+    control_temb = m.control_time_text_embed(timestep, control_pooled)
+    condition_temb = m.control_condition_embed(timestep, cond_pooled)
+    ctrl_enc = m.control_context_embedder(enc)
+    (oh, oc), l_aux, exp_counts = flux_moe_forward(m, cfg, x, c, ctrl_enc=ctrl_enc, control_temb=control_temb, condition_temb=condition_temb,
+                                                   pooled=pooled, cond_pooled=cond_pooled, ids=ids if cfg.use_rope else None)
+    z0 = oh + oc                                                                         # control_forward :563
+    if trace is not None:
+        trace["z0"] = z0
+    return dict(z0=z0, ctrl_enc=ctrl_enc, control_temb=control_temb, condition_temb=condition_temb, l_aux=l_aux, exp_counts=exp_counts)
+
+
+def sd3_base_forward(m, cfg: SD3Config, x, condition_hidden_states, enc, pooled, cond_pooled, timestep, *, conditioning_scale, temb,
+                     n_control: Optional[int] = None, ids=None, trace=None):
+    """UniGenSD3.base_forward (src/UniGenTransformer.py:581-623) with control_forward (:539-579, the use_encoder_hidden_states branch - the only one
+    UniGenSD3.init_control_block admits, :496) inlined: base block i -> control block int(i / (L / n_control)) on the BASE stream (the first one on
+    the CoMoE output) with the fixed ctrl_enc / condition_temb -> zero-res add. Returns (x, enc, moe_out)."""
+    L = cfg.num_layers
+    n_control = L if n_control is None else n_control
+    rope = cfg.use_rope and ids is not None
+    moe_out = None
+    for i in range(L):
+        enc, x = m.block(i, x, enc, temb)
+        k = int(i / (L / n_control))                                                     # :552-553
+        if i == 0:                                                                       # :559-563, text stream AFTER base block 0
+            moe_out = sd3_preprocess_moe_forward(m, cfg, x, condition_hidden_states, enc, pooled, cond_pooled, timestep, ids=ids, trace=trace)
+            z_in = moe_out["z0"]
+        else:
+            z_in = x
+        _, z = m.control_block(k, z_in, moe_out["ctrl_enc"], moe_out["condition_temb"], ids["img_ids"] if rope else None, ids["prompt_ids"] if rope else None)
+        x = x + m.add(k, z) * conditioning_scale                                         # :579, :614
+    return x, enc, moe_out
+
+
+def sd3_modules(state: State, cfg: SD3Config, gate_uniform, trace: Optional[dict] = None):
+    """The injected callables of the SD3 wiring, built from a flat state dict. (use_rope is not restated for SD3: the shipped yaml has none.)"""
+    from types import SimpleNamespace
+    m, H, L = SimpleNamespace(), cfg.num_attention_heads, cfg.num_layers
+
+    def moe_layer(*, choice_expert_input, hidden_states, condition_hidden_states, encoder_hidden_states, temb, condition_temb,
+                  condition_pooled_projections, pooled_projections):
+        eh, ec, l_aux, exp_counts, routing = _sd3_experts(state, cfg, hidden_states, condition_hidden_states, temb, condition_temb,
+                                                          pooled_projections, condition_pooled_projections, gate_uniform, choice=choice_expert_input)
+        if trace is not None:
+            trace["routing"] = routing
+        return eh, ec, l_aux, exp_counts
+
+    m.block = lambda i, x, enc, temb: sd3_joint_block(state, f"transformer_blocks.{i}", H, x, enc, temb, context_pre_only=i == L - 1,
+                                                      dual=i in cfg.dual_attention_layers)
+    m.control_block = lambda k, z, enc, temb, hd_ids, ehd_ids: sd3_joint_block(state, f"control_transformer_blocks.{k}", H, z, enc, temb,
+                                                                               context_pre_only=False, dual=k in cfg.dual_attention_layers)
+    m.add = lambda k, z: linear(state, f"controlnet_add_blocks.{k}", z)
+    m.control_pos_embed_input = lambda lat: patch_embed(state, "control_pos_embed_input", cfg, lat)
+    m.control_context_embedder = lambda e: linear(state, "control_context_embedder", e)
+    m.control_time_text_embed = lambda t, p: time_text_embed(state, "control_time_text_embed", t, p)
+    m.control_condition_embed = lambda t, p: time_text_embed(state, "control_condition_embed", t, p)
+    m.moe_layer = moe_layer
+    # shared experts (:205-222): JointTransformerBlock(context_pre_only=False) then JointTransformerBlock(context_pre_only=True, dual attention)
+    m.shared_expert = lambda k, x, enc, temb, hd_ids, ehd_ids: sd3_joint_block(state, f"shared_expert.{k}", H, x, enc, temb,
+                                                                               context_pre_only=k == 1, dual=k == 1)
+    return m
+
+
+def sd3_comoe(state: State, cfg: SD3Config, x, c, ctrl_enc, control_temb, condition_temb, pooled, cond_pooled, uniform):
+    """UniGenBase.moe_forward + expert_forward (src/UniGenTransformer.py:225-296) through the pinned wiring; c = embedded condition tokens."""
+    trace: dict = {}
+    m = sd3_modules(state, cfg, uniform, trace=trace)
+    (oh, oc), l_aux, exp_counts = flux_moe_forward(m, cfg, x, c, ctrl_enc=ctrl_enc, control_temb=control_temb, condition_temb=condition_temb,
+                                                   pooled=pooled, cond_pooled=cond_pooled, ids=None)
+    return oh, oc, l_aux, exp_counts, trace["routing"]
 
 
 def unigen_sd3_forward(state: State, cfg: SD3Config, *, hidden_states, condition_hidden_states, encoder_hidden_states, pooled_projections,
                        condition_pooled_projections, timestep, conditioning_scale: float = 1.0, gate_uniform=None, dtype=torch.bfloat16,
                        io_dtype=torch.bfloat16, trace: Optional[dict] = None):
     """UniGenSD3.forward (src/UniGenTransformer.py:625-710): latents NCHW in, NCHW out. The timestep is used as given (no x1000)."""
-    dt, H, L = dtype, cfg.num_attention_heads, cfg.num_layers
+    dt = dtype
     cast = lambda t: t.to(dt)
     height, width = hidden_states.shape[-2:]
     x = patch_embed(state, "pos_embed", cfg, cast(hidden_states))
@@ -963,27 +1153,9 @@ def unigen_sd3_forward(state: State, cfg: SD3Config, *, hidden_states, condition
     tstep = timestep.float()      # SD3 passes the scheduler timestep unscaled; time_proj works on timesteps.float()
     temb = time_text_embed(state, "time_text_embed", tstep, pooled)
     enc = linear(state, "context_embedder", cast(encoder_hidden_states))
-    moe_out = None
-    for i in range(L):
-        last = i == L - 1
-        enc_new, x = sd3_joint_block(state, f"transformer_blocks.{i}", H, x, enc, temb, context_pre_only=last, dual=i in cfg.dual_attention_layers)
-        if moe_out is None:      # preprocess_moe_forward at base_block_idx == 0 (:559-563), text stream AFTER base block 0
-            c = patch_embed(state, "control_pos_embed_input", cfg, cast(condition_hidden_states))
-            control_pooled = pooled if cfg.use_pooled_prompt_embeds else torch.zeros_like(pooled)
-            control_temb = time_text_embed(state, "control_time_text_embed", tstep, control_pooled)
-            condition_temb = time_text_embed(state, "control_condition_embed", tstep, cpooled)
-            ctrl_enc = linear(state, "control_context_embedder", enc_new)
-            eh, ec, l_aux, exp_counts, routing = sd3_comoe(state, cfg, x, c, ctrl_enc, control_temb, condition_temb, pooled, cpooled, gate_uniform)
-            moe_out = dict(ctrl_enc=ctrl_enc, condition_temb=condition_temb, l_aux=l_aux, exp_counts=exp_counts)
-            z_in = eh + ec
-            if trace is not None:
-                trace["routing"], trace["z0"] = routing, z_in
-        else:
-            z_in = x
-        enc = enc_new
-        _, z = sd3_joint_block(state, f"control_transformer_blocks.{i}", H, z_in, moe_out["ctrl_enc"], moe_out["condition_temb"],
-                               context_pre_only=False, dual=i in cfg.dual_attention_layers)
-        x = x + linear(state, f"controlnet_add_blocks.{i}", z) * conditioning_scale
+    m = sd3_modules(state, cfg, gate_uniform, trace=trace)
+    x, _, moe_out = sd3_base_forward(m, cfg, x, cast(condition_hidden_states), enc, pooled, cpooled, tstep, conditioning_scale=conditioning_scale, temb=temb,
+                                     trace=trace)
     x = adaln_continuous(state, "norm_out", x, temb)
     x = linear(state, "proj_out", x)
     p = cfg.patch_size

@@ -21,78 +21,16 @@ bf16 eager and in fp32). /root/reference does not travel to the GPU box; the tes
 """
 from __future__ import annotations
 
-import ast
-import builtins
 import os
 import sys
-from typing import List
 
 import torch
-import torch.nn.functional as F
 from safetensors.torch import save_file
 from torch import nn
 
-REF = os.environ.get("UNIGEN_REFERENCE", "/root/reference")
 HERE = os.path.dirname(os.path.abspath(__file__))
-ALLOWED = {"torch": torch, "nn": nn, "F": F, "List": List}
-
-
-def _find(tree: ast.AST, name: str, cls: str | None = None) -> ast.FunctionDef:
-    body = tree.body
-    if cls is not None:
-        body = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == cls).body
-    return next(n for n in body if isinstance(n, ast.FunctionDef) and n.name == name)
-
-
-def _tripwire(name: str):
-    def _raise(*a, **k):
-        raise AssertionError(f"the fixture reached `{name}`, a third-party symbol the namespace does not provide")
-    return _raise
-
-
-def compile_reference_function(path: str, name: str, cls: str | None = None, extra: dict | None = None, not_taken: tuple = ()):
-    """Compile one function definition of a reference file in a namespace of torch symbols only. Annotations are dropped (they name typing
-    symbols the namespace does not hold); the body is untouched. `not_taken`: third-party names that only occur on a branch the fixture's
-    arguments never take - they are bound to a tripwire that raises if the branch is entered after all (not to an implementation)."""
-    with open(os.path.join(REF, path)) as f:
-        tree = ast.parse(f.read())
-    fn = _find(tree, name, cls)
-    for a in fn.args.args + fn.args.kwonlyargs + [x for x in (fn.args.vararg, fn.args.kwarg) if x is not None]:
-        a.annotation = None
-    fn.returns = None
-    fn.decorator_list = []
-    mod = ast.Module(body=[fn], type_ignores=[])
-    ast.fix_missing_locations(mod)
-    ns = dict(ALLOWED)
-    ns.update(extra or {})
-    ns.update({n: _tripwire(n) for n in not_taken})
-    code = compile(mod, f"<{path}:{fn.lineno} {name}>", "exec")
-    exec(code, ns)
-    f_obj = ns[name]
-    # every global the body can reach is a torch symbol we put there, a builtin, or an attribute name (attribute names also appear in co_names)
-    loads = {n.id for n in ast.walk(fn) if isinstance(n, ast.Name) and isinstance(n.ctx, ast.Load)}
-    local = {a.arg for a in fn.args.args + fn.args.kwonlyargs} | ({fn.args.kwarg.arg} if fn.args.kwarg else set()) | \
-            ({fn.args.vararg.arg} if fn.args.vararg else set()) | \
-            {n.id for n in ast.walk(fn) if isinstance(n, ast.Name) and isinstance(n.ctx, ast.Store)}
-    free = loads - local
-    unknown = {n for n in free if n not in ns and not hasattr(builtins, n)}
-    assert not unknown, f"{name}: reaches names outside torch: {unknown}"
-    return f_obj, fn.lineno
-
-
-def bag(**kw) -> nn.Module:
-    m = nn.Module()
-    for k, v in kw.items():
-        setattr(m, k, v)
-    return m
-
-
-def _lin(i: int, o: int, g: torch.Generator, std: float = 0.3) -> nn.Linear:
-    lin = nn.Linear(i, o)
-    with torch.no_grad():
-        lin.weight.copy_((torch.randn(o, i, generator=g) * std / i ** 0.5).bfloat16().float())
-        lin.bias.copy_((torch.randn(o, generator=g) * 0.1).bfloat16().float())
-    return lin
+sys.path.insert(0, HERE)
+from ref_harness import REF, bag, compile_reference_function, lin as _lin  # noqa: E402
 
 
 def main() -> None:
@@ -214,7 +152,8 @@ def main() -> None:
             lin.float()
 
     out = os.path.join(HERE, "ref_leaf.safetensors")
-    save_file(fx, out, metadata={"origin": "reference functions executed by tests/golden/make_ref_leaf_golden.py", "seed": "12443"})
+    # ONE metadata key: safetensors writes the metadata map in an unspecified order, a second key makes the file's bytes vary run to run
+    save_file(fx, out, metadata={"origin": "reference functions executed by tests/golden/make_ref_leaf_golden.py, seed 12443"})
     print(f"wrote {out}: {len(fx)} tensors, {os.path.getsize(out) / 1024:.0f} KiB")
 
 

@@ -353,7 +353,9 @@ class UniGenFlux(HipModule):
         ops.moe_dispatch_modulate(x, yc, mod_h, tos, xd, **mk)
         ops.gemm(xd, w_h, b_h, yh, M=C, groups=E, a_gstride=C * D, w_gstride=D * D, bias_gstride=D, c_gstride=C * D)
         consis = None
-        if ctl.use_consis_module:
+        # Reference quirk, pinned by tests/test_ref_wiring_cpu.py[flux_consis_rope_no_single]: moe_forward adds the consistency terms to locals and
+        # rebuilds its return value from them only inside `if self.use_shared_expert` (:1024) - without shared experts the module's work is discarded.
+        if ctl.use_consis_module and ctl.use_shared_expert:
             # "V2" consistency module (src/UniGenTransformer.py:984-1004; off in every shipped configuration, round 3): needs the experts' outputs in
             # TOKEN order and separately - ug_moe_combine with the other operand zero gives exactly bf16(p * y). consis_module[0] runs twice
             # (consis_module[1] only holds parameters), both times keeping the sample stream only (context = K / V).

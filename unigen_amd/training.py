@@ -236,7 +236,8 @@ def _comoe(model, x, cond_tokens, ctrl_enc, control_temb, condition_temb, pooled
     c = _lin(model, "control_x_embedder", cond_tokens)
     eh, ec, l_aux, exp_counts = _experts_modulated(model, x, c, pooled, cond_pooled, uniform)
     round_to = img_ids.dtype if ctl.use_rope else None
-    if ctl.use_consis_module:            # "V2" consistency module (:984-1004): consis_module[0] twice, sample-stream outputs only
+    if ctl.use_consis_module and ctl.use_shared_expert:     # "V2" consistency module (:984-1004): consis_module[0] twice, sample-stream outputs only;
+        # without shared experts the reference discards its result (the return tuple is rebuilt only at :1024) - tests/test_ref_wiring_cpu.py
         rope_a = model._rope([cond_ids, cond_ids], round_to) if ctl.use_rope else None
         _, cech = _double_block(model, "consis_module.0", ec, c, condition_temb, rope_a, text_first=False)
         rope_b = model._rope([img_ids, cond_ids, img_ids], round_to) if ctl.use_rope else None
