@@ -293,6 +293,13 @@ def _self_launch(args, argv):
     sharing = os.environ.get("UG_DIST_BACKEND", "") == "gloo"          # rehearsal: ranks may share a GPU (no RCCL communicator)
     if not args.dry_run and ndev < n and not sharing:
         raise SystemExit(f"bench.py --gpus {n}: this node shows only {ndev} GPU(s) (torch.cuda.device_count()); nothing was measured")
+    # Build the HIP library ONCE, here, before any rank exists: on a clean clone every rank's lib.load() would otherwise start the same hipcc
+    # build at the same time (it is serialised by a file lock in unigen_amd.build, but N - 1 ranks would sit in it). hipcc only: this parent
+    # never touches the GPU, the ranks stay fresh processes.
+    from unigen_amd import build as _build
+    t_b = time.perf_counter()
+    lib_path = _build.build()
+    print(f"[bench] self-launch: {lib_path} ready ({time.perf_counter() - t_b:.1f} s in unigen_amd.build.build())", file=sys.stderr, flush=True)
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -339,7 +346,7 @@ def _dry_run(args, world, rank):
     if rank == 0:
         print(json.dumps(dict(metric="DRY RUN (no GPU work): harness rehearsal only", dry_run=True, value=None, unit="images/s", n_gpus=world,
                               steps=args.steps, warmup=args.warmup, ms_per_step=1000.0 * elapsed / args.steps, higher_is_better=True, scaling="weak",
-                              vs_baseline=None, data="none", config=dict(workload="none"), per_rank=per_rank)), flush=True)
+                              vs_baseline=None, data="none", config=dict(workload="none"), per_rank=per_rank, dist=DU.describe(world))), flush=True)
     if world > 1:
         import torch.distributed as dist
         dist.barrier()
@@ -412,6 +419,78 @@ class _PowerSampler:
                     source="amdgpu hwmon power1_input / freq1_input of this rank's device, every 0.2 s inside the timed region")
 
 
+def _roofline_blocks(s, elapsed, pk16, pk32, attn_kernel, traffic_file=None):
+    """`roofline` (the bf16 MFMA GEMM, the dominant kernel) and `roofline_attention` from a KernelTimer summary: algorithmic FLOPs of the launches
+    inside the timed region / their HIP-event durations, against the 2.5 PFLOP/s datasheet peak and the bare-MFMA rate measured in this run."""
+    out = {}
+    gm, at = s.get("gemm"), s.get("attn")
+    ach = gm["flops"] / (gm["ms"] * 1e-3) / 1e12
+    traffic, traffic_note, traffic_src, pmc = None, None, None, {}
+    if traffic_file is not None:
+        with open(traffic_file) as f:
+            tj = json.load(f)
+        base = os.path.basename(traffic_file)
+        traffic = tj["kernels"]["gemm_all"]["hbm_bytes_per_launch"]
+        traffic_src = dict(measured_in_this_run=False, file=f"profiles/{base}",
+                           collected_utc=tj.get("collected_utc", "not recorded (profile of an earlier round)"), collected=tj.get("source"))
+        traffic_note = (f"NOT measured in this run - counters need their own rocprofv3 passes - read from an earlier profile of the same command on another box: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, profiles/{base}): (2*FETCH_SIZE + WRITE_SIZE)*1024 per "
+                        "launch; the L2-fabric counters include Infinity-Cache hits, so this is traffic beyond the XCD L2, an upper bound on HBM bytes")
+        g256 = tj["kernels"].get("gemm256", {})
+        if "mfma_busy_frac" in g256:
+            pmc = dict(measured_in_this_run=False, file=f"profiles/{base}", mfma_busy=g256["mfma_busy_frac"], effective_clock_ghz=g256["effective_clock_ghz"],
+                       hbm_side_gbps=g256["hbm_bytes_per_launch"] / (g256["avg_launch_us_profiled"] * 1e-6) / 1e9)
+    # second denominator (SURVEY 8(d)): the measured MFMA-only rate of this chip, at the clock it holds under matrix load (pk16 / pk32)
+    meas = (lambda a, pk: a / pk) if pk16 else (lambda a, pk: None)
+    out["roofline"] = dict(bound="mfma", kernel="gemm256_kernel / gemm128_kernel (ug_gemm_bf16)", achieved=ach, peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s",
+                           frac=ach / MFMA_BF16_PEAK_TFLOPS, peak_measured=pk16 or None, frac_of_measured=meas(ach, pk16),
+                           peak_measured_note=("ug_probe_mfma_bf16: bare v_mfma_f32_16x16x32_bf16 loop (the GEMM's shape), register operands with random values, "
+                                               f"one wave per SIMD on every CU, HIP events; the 32x32x16 shape (attention) measures {pk32:.0f}"),
+                           traffic=traffic, traffic_note=traffic_note, traffic_source=traffic_src, pmc_gemm256=pmc or None, launches=gm["launches"],
+                           avg_launch_us=1000.0 * gm["ms"] / gm["launches"], avg_launch_gflop=gm["flops"] / gm["launches"] / 1e9,
+                           share_of_step_time=gm["ms"] * 1e-3 / elapsed)
+    if at:
+        a2 = at["flops"] / (at["ms"] * 1e-3) / 1e12
+        out["roofline_attention"] = dict(bound="mfma", kernel=attn_kernel, achieved=a2, peak=MFMA_BF16_PEAK_TFLOPS,
+                                         unit="TFLOP/s", frac=a2 / MFMA_BF16_PEAK_TFLOPS, peak_measured=pk32 or None, frac_of_measured=meas(a2, pk32),
+                                         launches=at["launches"],
+                                         avg_launch_us=1000.0 * at["ms"] / at["launches"], share_of_step_time=at["ms"] * 1e-3 / elapsed)
+    return out
+
+
+WORKLOAD_NAMES = dict(
+    cfg2=lambda B, world: f"cfg2: UniGenFlux canny single-condition, 1024x1024, batch={B}, ",
+    cfg4=lambda B, world: f"cfg4: UniGenFlux canny, 1024x1024, global batch {B * world} sharded over {world} x MI355X (B={B} per GPU; 64 = 8 x 8 at N=8), ",
+    cfg3=lambda B, world: f"cfg3: MultiCondtionUniGenFlux depth+canny+openpose multi-condition (per-condition CoMoE, summed), 1024x1024, batch={B}" + (f" per GPU x {world}" if world > 1 else "") + ", ",
+    cfg5=lambda B, world: f"cfg5: UniGenSD3 (SD3.5-medium backbone) depth single-condition, 1024x1024, batch={B}" + (f" per GPU x {world}" if world > 1 else "") + ", ")
+METRIC_NAMES = dict(cfg2="images/sec at 1024^2, FLUX-schnell+canny, 4-step", cfg4="images/sec at 1024^2, FLUX-schnell+canny, 4-step",
+                    cfg3="images/sec at 1024^2, FLUX-schnell + depth+canny+openpose, 4-step", cfg5="images/sec at 1024^2, SD3.5-medium + depth, 28-step CFG")
+
+
+def measure_other_config(config, rank, dev, ops, pk16, pk32, steps=1, warmup=1):
+    """BASELINE.json configs[2] (cfg3) / configs[4] (cfg5) at their stated batch (B = 8) inside the default N = 1 run, so the driver's own record carries
+    them: the same fields as the headline block (value, ms_per_step, roofline, roofline_attention), `warmup` + `steps` passes of the hot path."""
+    B = 8
+    if config == "cfg5":
+        model, one_step, info = _sd3_workload(B, rank, dev, False)
+    else:
+        model, one_step, info = _flux_workload(config, B, rank, dev, False)
+    timer = ops.KernelTimer()
+    elapsed, _, _ = _timed(one_step, steps, warmup, dev, 1, timer, ops)
+    s = timer.summary()
+    value = B * steps / elapsed
+    fl_img = info["flops_per_image"]
+    if fl_img is None:
+        fl_img = sum(d["flops"] for d in s.values()) / (B * steps)
+    d = dict(metric=METRIC_NAMES[config], value=value, unit="images/s", n_gpus=1, steps=steps, warmup=warmup, ms_per_step=1000.0 * elapsed / steps,
+             dtype="bf16", data="synthetic", config=dict(workload=WORKLOAD_NAMES[config](B, 1) + info["geom"], baseline_config=config, per_gpu_batch=B, step=info["step"]),
+             flops_per_image=fl_img, flops_per_image_kind=info["flops_kind"], e2e_mfma_frac=value * fl_img / (MFMA_BF16_PEAK_TFLOPS * 1e12))
+    if pk16:
+        d["e2e_frac_of_measured"] = value * fl_img / (pk16 * 1e12)
+    d.update(_roofline_blocks(s, elapsed, pk16, pk32, info["attn_kernel"]))
+    del model, one_step
+    return d
+
+
 def _timed(one_step, steps, warmup, dev, world, timer, ops, power=None):
     from unigen_amd import dist_utils as DU
     for _ in range(warmup):
@@ -448,6 +527,7 @@ def main():
                     help="full = one full-depth 1024^2 oracle forward x 4 (needs ~90 GB host RAM); cfg1 = BASELINE configs[0] end to end (512^2, B = 1, 4 steps) on CPU and GPU")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--no-scaling-base", action="store_true", help="N = 1, cfg2 only: skip the extra B = 8 measurement (cfg4's per-GPU shape, the like-for-like base of the 1 -> 8 curve)")
+    ap.add_argument("--no-other-configs", action="store_true", help="N = 1, cfg2 only: skip the cfg3 / cfg5 blocks (other_configs: 1 warm-up + 1 step each at B = 8)")
     ap.add_argument("--small", action="store_true", help="debug: reduced depth (NOT the headline configuration)")
     ap.add_argument("--graph", action="store_true", help="capture one step (the whole denoise loop) in a HIP graph and replay it (SURVEY 8(f) rank 1)")
     ap.add_argument("--dry-run", action="store_true", help="no GPU work: rehearse the multi-process harness (spawn, rendezvous, barriers, JSON) on the CPU with gloo")
@@ -532,18 +612,15 @@ def main():
     if rank == 0:
         images = B * args.steps * world
         value = images / elapsed
-        names = dict(cfg2=f"cfg2: UniGenFlux canny single-condition, 1024x1024, batch={B}, ",
-                     cfg4=f"cfg4: UniGenFlux canny, 1024x1024, global batch {B * world} sharded over {world} x MI355X (B={B} per GPU; 64 = 8 x 8 at N=8), ",
-                     cfg3=f"cfg3: MultiCondtionUniGenFlux depth+canny+openpose multi-condition (per-condition CoMoE, summed), 1024x1024, batch={B}" + (f" per GPU x {world}" if world > 1 else "") + ", ",
-                     cfg5=f"cfg5: UniGenSD3 (SD3.5-medium backbone) depth single-condition, 1024x1024, batch={B}" + (f" per GPU x {world}" if world > 1 else "") + ", ")
-        metric = ("images/sec at 1024^2, FLUX-schnell+canny, 4-step" if config in ("cfg2", "cfg4") else
-                  "images/sec at 1024^2, FLUX-schnell + depth+canny+openpose, 4-step" if config == "cfg3" else "images/sec at 1024^2, SD3.5-medium + depth, 28-step CFG")
+        names = {k: f(B, world) for k, f in WORKLOAD_NAMES.items()}
+        metric = METRIC_NAMES[config]
         line = dict(metric=metric, value=value, unit="images/s", n_gpus=world, steps=args.steps,
                     warmup=args.warmup, ms_per_step=1000.0 * elapsed / args.steps, higher_is_better=True, scaling="weak", vs_baseline=None,
                     dtype="bf16", data="synthetic",
                     config=dict(workload=names[config] + info["geom"], baseline_config=config, per_gpu_batch=B, global_batch=B * world,
                                 parallelism=f"dp{world} (independent samples, RCCL barrier only)", step=info["step"]),
-                    hip_graph=bool(args.graph), device_count=ndev, per_rank=per_rank)
+                    hip_graph=bool(args.graph), device_count=ndev, per_rank=per_rank,
+                    dist=DU.describe(world))          # the communicator the barriers / reductions of this run went through (torch.distributed, rank 0)
         s = timer.summary() if timer is not None else {}
         fl_img = info["flops_per_image"]
         if fl_img is None and s:
@@ -563,37 +640,12 @@ def main():
         if power is not None:
             line["power"] = power             # rank 0's GPU inside the timed region: the forward sits at the package power cap
         if s:
-            gm, at = s.get("gemm"), s.get("attn")
-            ach = gm["flops"] / (gm["ms"] * 1e-3) / 1e12
-            traffic, traffic_note, traffic_src, pmc = None, None, None, {}
+            traffic_file = None
             cands = sorted(p for p in os.listdir(os.path.join(ROOT, "profiles")) if p.endswith("_pmc.json"))      # newest round's PMC summary
             tf = os.path.join(ROOT, "profiles", cands[-1] if cands else "r01_hbm_traffic.json")
             if os.path.exists(tf) and not args.small and config == "cfg2" and B == 4:      # PMC passes of this same command (see the file's `source`, tools/pmc_summary.py)
-                with open(tf) as f:
-                    tj = json.load(f)
-                traffic = tj["kernels"]["gemm_all"]["hbm_bytes_per_launch"]
-                traffic_src = dict(measured_in_this_run=False, file=f"profiles/{os.path.basename(tf)}",
-                                   collected_utc=tj.get("collected_utc", "not recorded (profile of an earlier round)"), collected=tj.get("source"))
-                traffic_note = (f"NOT measured in this run - counters need their own rocprofv3 passes - read from an earlier profile of the same command on another box: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, profiles/{os.path.basename(tf)}): (2*FETCH_SIZE + WRITE_SIZE)*1024 per "
-                                "launch; the L2-fabric counters include Infinity-Cache hits, so this is traffic beyond the XCD L2, an upper bound on HBM bytes")
-                g256 = tj["kernels"].get("gemm256", {})
-                if "mfma_busy_frac" in g256:
-                    pmc = dict(measured_in_this_run=False, file=f"profiles/{os.path.basename(tf)}", mfma_busy=g256["mfma_busy_frac"], effective_clock_ghz=g256["effective_clock_ghz"],
-                               hbm_side_gbps=g256["hbm_bytes_per_launch"] / (g256["avg_launch_us_profiled"] * 1e-6) / 1e9)
-            # second denominator: the measured MFMA-only rate of this chip, at the clock it holds under matrix load (pk16 / pk32 above)
-            line["roofline"] = dict(bound="mfma", kernel="gemm256_kernel / gemm128_kernel (ug_gemm_bf16)", achieved=ach, peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s",
-                                    frac=ach / MFMA_BF16_PEAK_TFLOPS, peak_measured=pk16, frac_of_measured=ach / pk16,
-                                    peak_measured_note=("ug_probe_mfma_bf16: bare v_mfma_f32_16x16x32_bf16 loop (the GEMM's shape), register operands with random values, "
-                                                        f"one wave per SIMD on every CU, HIP events; the 32x32x16 shape (attention) measures {pk32:.0f}"),
-                                    traffic=traffic, traffic_note=traffic_note, traffic_source=traffic_src, pmc_gemm256=pmc or None, launches=gm["launches"],
-                                    avg_launch_us=1000.0 * gm["ms"] / gm["launches"], avg_launch_gflop=gm["flops"] / gm["launches"] / 1e9,
-                                    share_of_step_time=gm["ms"] * 1e-3 / elapsed)
-            if at:
-                a2 = at["flops"] / (at["ms"] * 1e-3) / 1e12
-                line["roofline_attention"] = dict(bound="mfma", kernel=info["attn_kernel"], achieved=a2, peak=MFMA_BF16_PEAK_TFLOPS,
-                                                  unit="TFLOP/s", frac=a2 / MFMA_BF16_PEAK_TFLOPS, peak_measured=pk32, frac_of_measured=a2 / pk32,
-                                                  launches=at["launches"],
-                                                  avg_launch_us=1000.0 * at["ms"] / at["launches"], share_of_step_time=at["ms"] * 1e-3 / elapsed)
+                traffic_file = tf
+            line.update(_roofline_blocks(s, elapsed, pk16, pk32, info["attn_kernel"], traffic_file))
         if world == 1 and not args.no_cpu_baseline:
             if config in ("cfg3", "cfg5"):
                 line["cpu_baseline"] = cpu_baseline_other(model, config)
@@ -604,6 +656,21 @@ def main():
             line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
             if config != "cfg5":
                 line["parity"] = fixture_parity(dev)
+        if world == 1 and config == "cfg2" and B == 4 and not (args.small or args.graph or args.no_other_configs or args.no_kernel_timer):
+            # BASELINE configs[2] and [4] inside the driver's own record: one warm-up + one pass each at their stated B = 8,
+            # after everything of the headline block is final - the cfg2 numbers above are untouched by this
+            import gc
+            model = one_step = step8 = out = None       # every reference to the cfg2 model and its workspaces (37 GB of weights) goes first
+            others = {}
+            for oc in ("cfg3", "cfg5"):
+                gc.collect(); torch.cuda.empty_cache()
+                t_o = time.perf_counter()
+                try:
+                    others[oc] = measure_other_config(oc, rank, dev, ops, pk16, pk32)
+                    others[oc]["wall_s_including_model_init"] = time.perf_counter() - t_o
+                except Exception as e:                      # the headline line must survive: the failure is recorded, never hidden
+                    others[oc] = dict(error=f"{type(e).__name__}: {e}")
+            line["other_configs"] = others
         print(json.dumps(line), flush=True)
     if world > 1:
         import torch.distributed as dist

@@ -641,3 +641,108 @@ def test_consis_module_parameters_follow_the_reference():
     assert "consis_module" in on.trainable_control_modules and "consis_module" not in off.trainable_control_modules
     w = on.state_dict()["consis_module.0.attn.to_q.weight"].float()
     assert float(w.std()) > 0 and torch.equal(on.state_dict()["consis_module.1.attn.norm_q.weight"], torch.ones(TINY["attention_head_dim"], dtype=w.dtype if False else on.state_dict()["consis_module.1.attn.norm_q.weight"].dtype))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# first contact on a clean clone with N ranks: one build, serialised, outputs appear atomically
+# ----------------------------------------------------------------------------------------------------------------------
+
+_FAKE_HIPCC = r"""#!/usr/bin/env python3
+# stands for hipcc in the race tests: logs the call, takes a while, then writes its -o target in two halves (a reader in between would see a torn file)
+import os, sys, time
+out = sys.argv[sys.argv.index("-o") + 1]
+with open(os.environ["FAKE_HIPCC_LOG"], "a") as f:
+    f.write(f"{os.getpid()} {time.time():.3f} start {'link' if '-shared' in sys.argv else 'cc'} {os.path.basename(out)}\n")
+with open(out, "w") as f:
+    f.write("first half;")
+    f.flush()
+    time.sleep(0.15)
+    f.write("second half")
+with open(os.environ["FAKE_HIPCC_LOG"], "a") as f:
+    f.write(f"{os.getpid()} {time.time():.3f} end {os.path.basename(out)}\n")
+"""
+
+
+def _clean_clone(tmp_path):
+    """A copy of the tree as a clean clone has it (sources, no *.o / *.so) with a stand-in hipcc."""
+    import shutil
+    root = tmp_path / "clone"
+    shutil.copytree(os.path.join(ROOT, "unigen_amd"), root / "unigen_amd", ignore=shutil.ignore_patterns("*.o", "*.so", "__pycache__", ".build.lock", "*.tmp*"))
+    shutil.copytree(os.path.join(ROOT, "include"), root / "include")
+    shutil.copy(os.path.join(ROOT, "bench.py"), root / "bench.py")
+    fake = tmp_path / "fake_hipcc"
+    fake.write_text(_FAKE_HIPCC)
+    fake.chmod(0o755)
+    log = tmp_path / "hipcc.log"
+    log.write_text("")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "UG_LIB_PATH")}
+    env.update(HIPCC=str(fake), FAKE_HIPCC_LOG=str(log))
+    return root, log, env
+
+
+def test_concurrent_builds_are_serialised_and_atomic(tmp_path):
+    """Four processes call unigen_amd.build.build() at once on a clean clone (what every rank's lib.load() does): exactly ONE of them compiles
+    (the others wait on the lock, then find fresh outputs), and a watcher polling the final .so path never sees a partially written file."""
+    root, log, env = _clean_clone(tmp_path)
+    so = root / "unigen_amd" / "libunigen_hip.so"
+    code = f"import sys; sys.path.insert(0, {str(root)!r}); from unigen_amd import build; print(build.build())"
+    procs = [subprocess.Popen([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for _ in range(4)]
+    torn = 0
+    while any(p.poll() is None for p in procs):
+        if so.exists() and so.read_text() != "first half;second half":
+            torn += 1
+    outs = [p.communicate(timeout=60) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert all(o[0].strip() == str(so) for o in outs)
+    assert torn == 0 and so.read_text() == "first half;second half"
+    from unigen_amd import build as B
+    calls = [ln.split() for ln in log.read_text().splitlines() if " start " in ln]
+    assert len(calls) == len(B.SOURCES) + 1, calls                     # every source once + one link: no second build
+    assert [c for c in calls if c[3] == "link"][0] == calls[-1]         # the link after every object
+    assert not [f for f in os.listdir(root / "unigen_amd" / "csrc") if ".tmp" in f] and not [f for f in os.listdir(root / "unigen_amd") if ".tmp" in f]
+
+
+def test_bench_parent_builds_before_it_spawns_ranks(tmp_path):
+    """`python bench.py --gpus 2` on a clean clone: the parent builds the library (hipcc only, it never touches the GPU) BEFORE the ranks exist,
+    so they never race in lib.load(); rehearsed with --dry-run over gloo."""
+    root, log, env = _clean_clone(tmp_path)
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--dry-run"], capture_output=True, text=True,
+                       timeout=300, env=env, cwd=str(root))
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert (root / "unigen_amd" / "libunigen_hip.so").exists()
+    err = r.stderr
+    assert "libunigen_hip.so ready" in err
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    # the communicator as torch.distributed reports it on rank 0 (VERDICT r4 item 5b)
+    assert d["dist"] == dict(initialized=True, backend="gloo", world_size=2, rank=0, note="backend nccl = RCCL on ROCm")
+    pids = {ln.split()[0] for ln in log.read_text().splitlines()}
+    from unigen_amd import build as B
+    assert len([ln for ln in log.read_text().splitlines() if " start " in ln]) == len(B.SOURCES) + 1 and len(pids) == len(B.SOURCES) + 1
+
+
+def test_alternating_pack_groupings_keep_the_weight_bytes_constant():
+    """a three-way q|k|v pack after the four-way [q|k|v|proj_mlp] pack of the same block must not leave proj_mlp pointing into the old
+    buffer (that keeps the whole old storage alive beside the new copy): the storage the parameters hold stays the size of the parameters."""
+    cls = importlib.import_module("src.UniGenTransformer").UniGenFlux
+    model = cls.from_config(dict(TINY), device="cpu", dtype=torch.bfloat16)
+    p = "single_transformer_blocks.0"
+
+    def held_bytes():
+        seen = {}
+        for q in model.parameters():
+            st = q.data.untyped_storage()
+            seen[st.data_ptr()] = st.nbytes()
+        return sum(seen.values())
+
+    want = sum(q.numel() * q.element_size() for q in model.parameters())
+    before = {n: q.detach().clone() for n, q in model.named_parameters() if n.startswith(p)}
+    assert model._single_qkv_mlp(p) is not None and held_bytes() == want
+    for _ in range(3):
+        model._attn_qkv(p + ".attn")
+        assert held_bytes() == want, (held_bytes(), want)
+        model._single_qkv_mlp(p)
+        assert held_bytes() == want, (held_bytes(), want)
+    assert all(torch.equal(before[n], q) for n, q in model.named_parameters() if n.startswith(p))
+    assert len([k for k in model._packed if k.startswith(p)]) <= 4

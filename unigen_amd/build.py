@@ -38,29 +38,50 @@ def _stale(target: str, deps: list[str]) -> bool:
 
 
 def build(force: bool = False, verbose: bool = False, probe: bool = False) -> str:
-    """Compile every .hip source to an object and link the shared library. Returns the library path."""
+    """Compile every .hip source to an object and link the shared library. Returns the library path.
+
+    Safe to call from several processes at once (every rank of a multi-GPU job calls lib.load() on a clean clone): the whole build runs under an
+    exclusive flock on <objdir>/.build.lock, staleness is re-checked after the lock is taken (the second process finds fresh outputs and returns),
+    and every output is written under a temporary name and os.replace()d into place, so a reader never sees a half-written .o or .so."""
+    import fcntl
+    objdir = os.path.join(PROBE_DIR, "obj") if probe else CSRC
+    os.makedirs(objdir, exist_ok=True)
+    with open(os.path.join(objdir, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return _build_locked(force, verbose, probe, objdir)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(force: bool, verbose: bool, probe: bool, objdir: str) -> str:
     hdrs = [os.path.join(CSRC, "ug_common.h"), os.path.join(CSRC, "gemm_epilogue.h"), os.path.join(ROOT, "include", "unigen_hip.h")]
     sources = SOURCES + (PROBE_ONLY_SOURCES if probe else [])
-    objdir = os.path.join(PROBE_DIR, "obj") if probe else CSRC
     lib = PROBE_LIB if probe else LIB
     flags = (["-DUG_PROBE_BUILD", "-I", CSRC] if probe else []) + FLAGS
     if probe:
-        os.makedirs(objdir, exist_ok=True)
         hdrs.append(os.path.join(PROBE_DIR, "unigen_hip_probe.h"))
+    tmp_tag = f".tmp{os.getpid()}"
     objs, jobs = [], []
     for src in sources:
         s = os.path.join(PROBE_DIR, "csrc", src) if src in PROBE_ONLY_SOURCES else os.path.join(CSRC, src)
         o = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            jobs.append([HIPCC, *flags, *EXTRA.get(src, []), "-c", s, "-o", o])
+            jobs.append(([HIPCC, *flags, *EXTRA.get(src, []), "-c", s, "-o", o + tmp_tag], o))
 
-    def run(cmd):
+    def run(job):
+        cmd, final = job
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
+            try:
+                os.unlink(final + tmp_tag)
+            except OSError:
+                pass
             raise RuntimeError(f"hipcc failed: {' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
+        os.replace(final + tmp_tag, final)
         if verbose and r.stderr.strip():
             print(r.stderr, file=sys.stderr)
 
@@ -68,7 +89,7 @@ def build(force: bool = False, verbose: bool = False, probe: bool = False) -> st
         with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
             list(ex.map(run, jobs))
     if force or jobs or _stale(lib, objs):
-        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs])
+        run(([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib + tmp_tag, *objs], lib))
     return lib
 
 

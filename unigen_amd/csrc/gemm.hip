@@ -205,7 +205,19 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
     const int nkA = (int)(p.K / BK);
     const int nk = nkA + (LORA ? p.lora_r / BK : 0);
 
-    struct TileSrc { const bf16_t* a[2][2]; const bf16_t* b[2][2]; int64_t m0, n0; int g; int nk; int rem; int slice; unsigned pk[2][2]; };
+    // BUF (round 5): the LDS-DMAs of the plain product kernel are issued in BUFFER form - buffer_load_dwordx4 ... offen lds with one resource per operand
+    // (base = the tile's first row of the group's matrix, wave-uniform), a per-lane byte offset that is constant through the whole K loop and the K
+    // offset in an SGPR - instead of the global form's 64-bit per-lane address, which costs a 64-bit VALU add per DMA (2 of the loop's VALU
+    // instructions each: tools/loop_census.py) and 16 VGPRs of pointers instead of 8 of offsets. Offsets are tile-relative, so they fit 32 bits for
+    // any matrix size (the launcher checks the one bound that remains, a row map's batch jump inside a tile). The LoRA segment and the convolution
+    // gather switch base addresses inside the K loop (lora_src / conv_src) and keep the global form, as do the probe build's cross-tile streams.
+#ifdef UG_PROBE_BUILD
+    constexpr bool BUF = false;
+#else
+    constexpr bool BUF = !LORA && !CONV;
+#endif
+    struct TileSrc { const bf16_t* a[2][2]; const bf16_t* b[2][2]; int64_t m0, n0; int g; int nk; int rem; int slice; unsigned pk[2][2];
+                     const bf16_t* abase; const bf16_t* wbase; int vo_a[2][2], vo_b[2][2]; };
     // CONV (AutoencoderKL 3x3 convolutions, vae.hip): A row m is output pixel (b, oy, ox), kept packed per staging row (b << 24 | oy << 12 | ox);
     // the K axis runs tap by tap (ktp K-tiles each), and a half-tile pair's A pointers are re-derived for the next tap right before that tap's
     // first K-tile is staged (the LoRA segment's switch, once per tap): source pixel of the tap (stride, one-sided padding and nearest-2x
@@ -241,6 +253,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
         t.m0 = (int64_t)tc.tm * 256; t.n0 = (int64_t)tc.tn * 256;
         const bf16_t* Ab = (const bf16_t*)p.A + (int64_t)t.g * p.a_gstride;
         const bf16_t* Wb = (const bf16_t*)p.W + (int64_t)t.g * p.w_gstride;
+        const unsigned pr0 = BUF ? rowmap32((unsigned)t.m0, (unsigned)p.a_rpb, (unsigned)p.a_bstride) : 0u;      // physical row of the tile's first A row
+        if constexpr (BUF) {
+            t.abase = Ab + (int64_t)pr0 * p.lda + (int64_t)kb * BK;
+            t.wbase = Wb + t.n0 * p.ldw + (int64_t)kb * BK;
+        }
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -249,6 +266,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
                 const int c = (lane & 7) ^ (row & 7);
                 int64_t am = t.m0 + h * 128 + row; if (am > M - 1) am = M - 1;
                 int64_t wn = t.n0 + bcol(h, row); if (wn > N - 1) wn = N - 1;
+                if constexpr (BUF) {       // byte offsets from the tile's bases; row maps are monotonic, so both are >= 0
+                    t.vo_a[h][i] = (int)(((int64_t)(rowmap32((unsigned)am, (unsigned)p.a_rpb, (unsigned)p.a_bstride) - pr0) * p.lda + c * 8) * 2);
+                    t.vo_b[h][i] = (int)(((wn - t.n0) * p.ldw + c * 8) * 2);
+                    continue;
+                }
                 if constexpr (CONV) {
                     const unsigned hw = (unsigned)(cv.Ho * cv.Wo), bb = (unsigned)am / hw, rr = (unsigned)am - bb * hw, oy = rr / (unsigned)cv.Wo;
                     t.pk[h][i] = bb << 24 | oy << 12 | (rr - oy * (unsigned)cv.Wo);
@@ -316,11 +338,24 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
         glds16(src[0] + ko, slot + st_off);
         glds16(src[1] + ko, slot + st_off + 8 * 128);
     };
+    using lds_ptr = __attribute__((address_space(3))) void*;
+    auto stage_buf = [&](unsigned char* slot, const bf16_t* base, const int (&vo)[2], int64_t ko) __attribute__((always_inline)) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0xffffffff, 0x00020000);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(slot + st_off), 16, vo[0], (int)ko * 2, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(slot + st_off + 8 * 128), 16, vo[1], (int)ko * 2, 0, 0);
+    };
+    // half-tile h of operand A / B of this work item, K offset ko (elements), into `slot`
+    auto stA = [&](unsigned char* slot, const TileSrc& t, int h, int64_t ko) __attribute__((always_inline)) {
+        if constexpr (BUF) stage_buf(slot, t.abase, t.vo_a[h], ko); else stage(slot, t.a[h], ko);
+    };
+    auto stB = [&](unsigned char* slot, const TileSrc& t, int h, int64_t ko) __attribute__((always_inline)) {
+        if constexpr (BUF) stage_buf(slot, t.wbase, t.vo_b[h], ko); else stage(slot, t.b[h], ko);
+    };
     auto stage_first = [&](const TileSrc& t) {
-        stage(smem + SLOT_A0, t.a[0], 0); stage(smem + SLOT_B0, t.b[0], 0);
-        stage(smem + SLOT_B1, t.b[1], 0); stage(smem + SLOT_A1, t.a[1], 0);
-        if (t.nk > 1) { stage(smem + KT_BYTES + SLOT_A0, t.a[0], BK); stage(smem + KT_BYTES + SLOT_B0, t.b[0], BK); }
-        if (t.nk >= 3) { stage(smem + KT_BYTES + SLOT_B1, t.b[1], BK); stage(smem + KT_BYTES + SLOT_A1, t.a[1], BK); }   // the whole ring
+        stA(smem + SLOT_A0, t, 0, 0); stB(smem + SLOT_B0, t, 0, 0);
+        stB(smem + SLOT_B1, t, 1, 0); stA(smem + SLOT_A1, t, 1, 0);
+        if (t.nk > 1) { stA(smem + KT_BYTES + SLOT_A0, t, 0, BK); stB(smem + KT_BYTES + SLOT_B0, t, 0, BK); }
+        if (t.nk >= 3) { stB(smem + KT_BYTES + SLOT_B1, t, 1, BK); stA(smem + KT_BYTES + SLOT_A1, t, 1, BK); }   // the whole ring
     };
     bf16x8 areg[4][2], breg[2][2], breg0[2][2];    // breg0: B0 fragments, kept from phase 0 to phase 3
     auto read_A = [&](const unsigned char* slot) {
@@ -467,7 +502,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
             // phase 0: quadrant (0,0)
             read_A(cb + SLOT_A0); read_B(breg0, cb + SLOT_B0);
             if (pre0) UG_WAIT_VM(10, x01);
-            else if (n1) { stage(nb + SLOT_B1, cur.b[1], k1); UG_WAIT_VM(8, x01); }   // B1(kt) landed
+            else if (n1) { stB(nb + SLOT_B1, cur, 1, k1); UG_WAIT_VM(8, x01); }   // B1(kt) landed
             else UG_WAIT_VM(2, x01);
             UG_BARRIER();
             UG_MMA_QUADRANT(0, 0, breg0);
@@ -475,7 +510,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
             // phase 1: quadrant (0,1)
             read_B(breg, cb + SLOT_B1);
             if (pre0) UG_WAIT_VM(8, x01);
-            else if (n1) { stage(nb + SLOT_A1, cur.a[1], k1); UG_WAIT_VM(8, x01); }   // A1(kt) landed
+            else if (n1) { stA(nb + SLOT_A1, cur, 1, k1); UG_WAIT_VM(8, x01); }   // A1(kt) landed
             else UG_WAIT_VM(0, x01);
             UG_BARRIER();
             UG_MMA_QUADRANT(0, 1, breg);
@@ -485,12 +520,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
             if (LORA && kt + 2 == nkA) lora_src(cur, 0);
             if (!LORA && xt && kt + 2 == nk) next_src(cur, 0, nk);
             if (CONV && n2 && ((kt + 2) & (cv.ktp - 1)) == 0) conv_src(cur, 0, (kt + 2) / cv.ktp);
-            if (n2) stage(cb + SLOT_A0, cur.a[0], k2);
+            if (n2) stA(cb + SLOT_A0, cur, 0, k2);
             UG_BARRIER();
             UG_MMA_QUADRANT(1, 1, breg);
             UG_BARRIER();
             // phase 3: quadrant (1,0), B0 from registers
-            if (n2) { stage(cb + SLOT_B0, cur.b[0], k2); UG_WAIT_VM(8, x3); }    // A0, B0(kt+1) landed
+            if (n2) { stB(cb + SLOT_B0, cur, 0, k2); UG_WAIT_VM(8, x3); }    // A0, B0(kt+1) landed
             else if (n1) UG_WAIT_VM(4, x3);
             UG_BARRIER();
             UG_MMA_QUADRANT(1, 0, breg0);
@@ -910,6 +945,10 @@ int launch(const ug_gemm_desc& d, hipStream_t s) {
     const int f = forced_tile();
     if (f == 128) big = false;
     if (f == 256 && (!lora || (d.K >= 2 * BK && EPI != UG_EPI_F32))) big = true;
+    // the 256^2 kernel's buffer-form DMAs carry 32-bit byte offsets relative to the tile's first row: 255 rows plus at most one batch jump of the A row map
+    const int64_t a_jump = d.a_rpb > 0 && d.a_bstride > d.a_rpb ? d.a_bstride - d.a_rpb : 0;
+    if (!lora && ((255 + a_jump) * d.lda + d.K) * 2 + 256 >= (int64_t)1 << 31) big = false;
+    if (!lora && (255 * d.ldw + d.K) * 2 + 256 >= (int64_t)1 << 31) big = false;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)gemm128_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);

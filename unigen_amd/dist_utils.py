@@ -29,16 +29,32 @@ def init_distributed(device: torch.device, force: bool = False):
     rank = int(os.environ.get("RANK", "0"))
     if world > 1 or force:
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        os.environ.setdefault("RANK", str(rank)); os.environ.setdefault("WORLD_SIZE", str(world))
         if not dist.is_initialized():
+            addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
+            port = os.environ.get("MASTER_PORT")
+            if port is None:
+                if world > 1:
+                    raise RuntimeError("WORLD_SIZE > 1 without MASTER_PORT: launch with torchrun or `python bench.py --gpus N` (both set it)")
+                import socket                      # a forced 1-rank group: any free port (a fixed default collides with other jobs on the host)
+                with socket.socket() as s:
+                    s.bind(("127.0.0.1", 0))
+                    port = s.getsockname()[1]
+            init = f"tcp://{addr}:{port}"          # rank / world handed over explicitly: nothing is written into os.environ (children would inherit it)
             backend = os.environ.get("UG_DIST_BACKEND", "nccl" if device.type == "cuda" else "gloo")   # nccl = RCCL over xGMI
             if backend == "nccl":
-                dist.init_process_group("nccl", device_id=device)
+                dist.init_process_group("nccl", init_method=init, rank=rank, world_size=world, device_id=device)
             else:
-                dist.init_process_group(backend)      # rehearsals: several ranks sharing one GPU cannot form an RCCL communicator
+                dist.init_process_group(backend, init_method=init, rank=rank, world_size=world)      # rehearsals: several ranks sharing one GPU cannot form an RCCL communicator
     return rank, world
+
+
+def describe(world: int) -> dict:
+    """What the bench line records about the communicator its collectives ran on: torch.distributed's own answer, not the launcher's environment."""
+    if not _group_up(world):
+        return dict(initialized=False, backend=None, world_size=1, note="single process: no process group, barriers are device synchronisations")
+    import torch.distributed as dist
+    return dict(initialized=True, backend=str(dist.get_backend()), world_size=int(dist.get_world_size()), rank=int(dist.get_rank()),
+                note="backend nccl = RCCL on ROCm")
 
 
 def _group_up(world: int) -> bool:

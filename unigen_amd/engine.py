@@ -205,8 +205,17 @@ class HipModule(nn.Module):
         """A new pack of these parameters replaces every older pack that still holds one of them (a second grouping of the same weights would
         otherwise keep a stale duplicate of their storage alive in self._packed)."""
         ptrs = {p.data.untyped_storage().data_ptr() for p in params}
-        for k in [k for k, t in self._packed.items() if k != key and t.untyped_storage().data_ptr() in ptrs]:
+        dropped = {t.untyped_storage().data_ptr() for k, t in self._packed.items() if k != key and t.untyped_storage().data_ptr() in ptrs}
+        if not dropped:
+            return
+        for k in [k for k, t in self._packed.items() if k != key and t.untyped_storage().data_ptr() in dropped]:
             del self._packed[k]
+        # members of a dropped pack that the new grouping does not take (proj_mlp after a three-way q|k|v re-pack of the four-way pack) would keep
+        # the WHOLE old buffer alive next to the new copy: give them storage of their own
+        mine = {id(p) for p in params}
+        for p in self.parameters():
+            if id(p) not in mine and p.data.untyped_storage().data_ptr() in dropped:
+                p.data = p.data.clone()
 
     def _pack(self, key: str, names: Sequence[str]) -> torch.Tensor:
         """Concatenate parameters along dim 0 into one buffer and re-point them at views of it (no duplicate storage)."""

@@ -139,7 +139,7 @@ def load() -> C.CDLL:
             raise UniGenHipError(f"UG_LIB_PATH={LIB_PATH} not found (probe library: `python -m unigen_amd.build --probe`)")
         try:
             from . import build as _build
-            _build.build()
+            _build.build()          # serialised across processes by a file lock; outputs appear atomically (os.replace)
         except Exception as e:      # no hipcc, compile error: fail loudly, never fall back
             raise UniGenHipError(f"{LIB_PATH} not found and `python -m unigen_amd.build` (hipcc --offload-arch=gfx950) failed: {e}. "
                                  "unigen_amd has no CPU fallback for the hot path.") from e
