@@ -67,3 +67,15 @@ res.update(workload=("UniGenSD3, SD3.5-medium depth and width, N=1024, T=333, B=
            rel_l2_hip_bf16_vs_oracle_f32=rel(out16, truth), rel_l2_oracle_bf16_vs_oracle_f32=(rel(ref16, truth) if ref16 is not None else None),
            rel_l2_hip_bf16_vs_oracle_bf16=(rel(out16, ref16) if ref16 is not None else None))
 print("FULLSIZE_PARITY", json.dumps(res))
+if "--write-bounds" in sys.argv and res["rel_l2_oracle_bf16_vs_oracle_f32"] is not None:
+    # the record tests/test_fullsize_gpu.py::test_full_model_forward_parity reads when it skips the oracle's own bf16 evaluation (--no-ref16): written
+    # under gpurun_out/ (the only directory a GPU box hands back); the builder copies it into tests/golden/fullsize_bounds.json
+    which = "sd3" if SD3 else ("multi" if MULTI else f"flux{GRID}")
+    commit = sys.argv[sys.argv.index("--commit") + 1] if "--commit" in sys.argv else "unknown"
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", f"fullsize_bounds_{which}.json")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    with open(out, "w") as f:
+        json.dump({which: dict(rel_l2_oracle_bf16_vs_oracle_f32=res["rel_l2_oracle_bf16_vs_oracle_f32"], rel_l2_hip_bf16_vs_oracle_f32=res["rel_l2_hip_bf16_vs_oracle_f32"],
+                               rel_l2_hip_f32_vs_oracle_f32=res["rel_l2_hip_f32_vs_oracle_f32"], workload=res["workload"], written_utc=time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime()),
+                               commit=commit, written_by="tests/fullsize_f32_parity.py --write-bounds")}, f, indent=1)
+    print("wrote", out)

@@ -437,9 +437,12 @@ def test_full_model_forward_parity(gpu, which):
     assert r["rel_l2_hip_f32_vs_oracle_f32"] <= 1e-3, r
     if r["rel_l2_oracle_bf16_vs_oracle_f32"] is not None:
         assert r["rel_l2_hip_bf16_vs_oracle_f32"] <= 1.25 * r["rel_l2_oracle_bf16_vs_oracle_f32"] + 1e-3, r
-    else:       # flux64 / multi: the oracle's own bf16 evaluation (2.11e-2 / 1.944e-2 at these sizes, rounds 2 / 3: profiles/r02g_fullsize_parity_1024.log,
-                # r03f_*) is not re-run inside the suite's time budget (bf16 matmuls on the host cores: ~40 s each); the bound is 1.25x that + 1e-3
-        assert r["rel_l2_hip_bf16_vs_oracle_f32"] <= (2.8e-2 if which == "flux64" else 2.55e-2), r
+    else:       # flux64 / multi: the oracle's own bf16 evaluation is not re-run inside the suite's time budget (bf16 matmuls on the host cores: ~40-65 s each). Its
+                # error against the fp32 oracle on THESE weights and inputs is read from the committed record tests/golden/fullsize_bounds.json (written by
+                # `tests/fullsize_f32_parity.py ... --write-bounds` on a GPU box: date and commit inside), and the bar is the suite's usual 1.25 x that + 1e-3
+        with open(os.path.join(root, "tests", "golden", "fullsize_bounds.json")) as f:
+            rec = json.load(f)[which]
+        assert r["rel_l2_hip_bf16_vs_oracle_f32"] <= 1.25 * rec["rel_l2_oracle_bf16_vs_oracle_f32"] + 1e-3, (r, rec)
 
 
 def test_full_depth_gradient_parity(gpu):

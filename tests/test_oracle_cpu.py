@@ -265,3 +265,34 @@ def test_training_golden_pins_the_oracle_backward():
         assert abs(float(gr.norm()) - float(ref[0])) <= 1e-4 * float(ref[0]) + 1e-9, k
         n = min(8, gr.numel())
         assert torch.allclose(gr.flatten()[:n], ref[1:1 + n], rtol=1e-3, atol=1e-6 + 1e-4 * float(ref[0]) / max(gr.numel(), 1) ** 0.5), k
+
+
+def test_routing_indices_stay_in_range_at_two_full_samples():
+    """the oracle's index-form routing and dispatch at the token count of the round-4 GPU fault's process (tests/eager_reference_timing.py
+    --batch 2: S = 2 x 4096 tokens, E = 6) on the CPU build, where an out-of-range index raises instead of faulting: top-1 gate + RTS capacity
+    selection, token_of_slot / slot / idx ranges, the dispatch gather (zero rows for empty slots) and the combine, equal to the dense einsum form."""
+    B, N, D, E = 2, 4096, 32, 6
+    S = B * N
+    g = torch.Generator().manual_seed(11)
+    logits = torch.randn(S, E, generator=g) * 2.0
+    logits[:, 0] += 1.5                                   # a popular expert: many tokens over capacity, so RTS really drops some
+    uniform = torch.rand(S, E, generator=g)
+    C = R.moe_capacity(S, E)
+    assert C == 1366
+    l_aux, combine, dispatch, counts, rt = R.gate_route(logits, uniform, 1)
+    assert rt["capacity"] == C
+    idx, slot, tos = rt["idx"], rt["slot"], rt["token_of_slot"]
+    assert tos.shape == (E, C) and int(tos.max()) < S and int(tos.min()) >= -1
+    assert idx.shape == (S,) and int(idx.min()) >= 0 and int(idx.max()) < E
+    assert int(slot.max()) < C and int(slot.min()) >= -1
+    kept = slot >= 0
+    assert int(kept.sum()) == int((tos >= 0).sum()) and int(counts.sum()) == S and int(kept.sum()) < S      # some were dropped
+    assert torch.equal(tos[idx[kept], slot[kept]], torch.nonzero(kept).flatten().to(tos.dtype))              # slot <-> token maps are inverse
+    x = torch.randn(S, D, generator=g)
+    out = torch.zeros(E, C, D)
+    valid = tos >= 0
+    out[valid] = x[tos[valid]]                             # the oracle's dispatch (comoe_experts.dispatch): raises on a bad index on this build
+    dense = torch.einsum("sec,sm->ecm", dispatch.to(x.dtype), x)
+    assert torch.equal(out, dense)
+    y = torch.einsum("sec,ecm->sm", combine, out)
+    assert torch.equal(y[~kept], torch.zeros_like(y[~kept])) and torch.isfinite(y).all()

@@ -93,7 +93,7 @@ def classify(ins: str) -> str:
 
 
 def hot_loop(body):
-    """The innermost backward branch span with the most MFMAs."""
+    """The backward-branch span with the highest MFMA density: the steady-state K loop."""
     addr_idx = {a: i for i, (a, _) in enumerate(body)}
     best = None
     for i, (a, ins) in enumerate(body):
@@ -111,10 +111,10 @@ def hot_loop(body):
         n_mfma = sum(1 for _, x in span if classify(x) == "mfma")
         if n_mfma == 0:
             continue
-        # innermost: no other mfma-holding backward branch strictly inside is handled by preferring the SHORTEST span among those with the max MFMA density
-        cand = (n_mfma, -(i - j), j, i)
-        if best is None or n_mfma > best[0] or (n_mfma == best[0] and (i - j) < -best[1]):
-            best = cand
+        # the K loop is the span with the highest MFMA density (an enclosing tile loop adds its epilogue, a peeled generic copy its branches)
+        dens = n_mfma / float(i - j + 1)
+        if best is None or dens > best[0]:
+            best = (dens, 0, j, i)
     if best is None:
         return None
     return body[best[2]:best[3] + 1]

@@ -489,25 +489,44 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
         UG_BARRIER();
         UG_STAMP(1);
         if (wr == 1) UG_BARRIER();          // waves 4-7 run one barrier behind
-        for (int kt = 0; kt < nk; ++kt) {
-            unsigned char* cb = smem + (kt & 1) * KT_BYTES;
-            unsigned char* nb = smem + ((kt & 1) ^ 1) * KT_BYTES;
-            const bool n1 = kt + 1 < nk || xt, n2 = kt + 2 < nk || xt;
-            const bool pre0 = pre && kt == 0;
-            const bool x01 = sif && (kt == 0 || (pre && kt == 1)), x3 = sif && kt == 0;
+        // One K-tile = four phases. STEADY (round 5): the K-tiles 2 .. nk - 3 of the plain kernel - nothing about them depends on the tile (both
+        // look-ahead K-tiles exist, no wait has to allow for the previous epilogue's stores, the prefetched ring is used up) - run a copy of the body in
+        // which every wait is a constant and every stage is unconditional; the generic copy, whose wait selection is a scalar branch per wait
+        // (~45 branches and ~130 SALU instructions per 128 MFMAs: tools/loop_census.py, profiles/r05_loop_census_*.json), runs the first two and
+        // the last two K-tiles of a tile only.
+        // MODE 0 = generic, MODE 2 = steady (round 5, second step): in the steady state the B1 half-tile's two DMA pieces are issued one L segment
+        // EARLIER - at the end of phase 3 of the K-tile before (the phase that reads nothing) instead of the start of phase 0 (the phase that reads
+        // twelve fragments: a DMA piece issued among ds_reads costs 100-185 cycles of the segment, 25-60 in a gap without them:
+        // MI355X_MICROARCH.md, LDS-DMA piece issue cost). Same issue ORDER, so every counted wait keeps its meaning; only the wait that now follows
+        // five young half-tiles instead of four becomes vmcnt(10). The hand-overs are two flags of the generic body: the generic K-tile before the
+        // first steady one stages B1 for it in its phase 3 (early_b1), the generic K-tile after the last steady one finds its B1 already staged (skip_b1).
+        const int steady_from = 2, steady_to = (BUF && nk >= 6) ? ((nk & 1) ? nk - 4 : nk - 3) : 1;      // steady K-tiles [from, to]: an even count
+        auto ktile = [&](const int kt, auto mode_c, auto par_c) __attribute__((always_inline)) {
+            constexpr int MODE = decltype(mode_c)::value;
+            constexpr bool STEADY = MODE != 0;
+            const bool early_b1 = !STEADY && kt + 1 == steady_from && steady_to >= steady_from;
+            const bool skip_b1 = !STEADY && kt == steady_to + 1 && steady_to >= steady_from;
+            constexpr int PAR = decltype(par_c)::value;             // the K-tile's ring parity when the caller knows it (steady pairs), else -1
+            unsigned char* cb = smem + (PAR >= 0 ? PAR : (kt & 1)) * KT_BYTES;
+            unsigned char* nb = smem + (PAR >= 0 ? PAR ^ 1 : ((kt & 1) ^ 1)) * KT_BYTES;
+            const bool n1 = STEADY || kt + 1 < nk || xt, n2 = STEADY || kt + 2 < nk || xt;
+            const bool pre0 = !STEADY && pre && kt == 0;
+            const bool x01 = !STEADY && sif && (kt == 0 || (pre && kt == 1)), x3 = !STEADY && sif && kt == 0;
             const int64_t k1 = (int64_t)(kt + 1) * BK, k2 = (int64_t)(kt + 2) * BK;
             if (LORA && kt + 1 == nkA) lora_src(cur, 1);
-            if (!LORA && xt && kt + 1 == nk) next_src(cur, 1, nk);
+            if (!LORA && !STEADY && xt && kt + 1 == nk) next_src(cur, 1, nk);
             if (CONV && n1 && ((kt + 1) & (cv.ktp - 1)) == 0) conv_src(cur, 1, (kt + 1) / cv.ktp);
             // phase 0: quadrant (0,0)
             read_A(cb + SLOT_A0); read_B(breg0, cb + SLOT_B0);
-            if (pre0) UG_WAIT_VM(10, x01);
-            else if (n1) { stB(nb + SLOT_B1, cur, 1, k1); UG_WAIT_VM(8, x01); }   // B1(kt) landed
+            if (MODE >= 2) UG_WAIT_VM(8, false);                                     // B1(kt) landed; B1(kt+1) was staged in the phase 3 before
+            else if (pre0) UG_WAIT_VM(10, x01);
+            else if (n1) { if (!skip_b1) stB(nb + SLOT_B1, cur, 1, k1); UG_WAIT_VM(8, x01); }   // B1(kt) landed
             else UG_WAIT_VM(2, x01);
             UG_BARRIER();
             UG_MMA_QUADRANT(0, 0, breg0);
             UG_BARRIER();
             // phase 1: quadrant (0,1)
+            // (Measured and dropped the same day: the steady copy issuing this phase's two DMA pieces BEFORE its four reads: +-0.5 % per shape)
             read_B(breg, cb + SLOT_B1);
             if (pre0) UG_WAIT_VM(8, x01);
             else if (n1) { stA(nb + SLOT_A1, cur, 1, k1); UG_WAIT_VM(8, x01); }   // A1(kt) landed
@@ -518,18 +537,37 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
             // phase 2: quadrant (1,1)
             read_A(cb + SLOT_A1);
             if (LORA && kt + 2 == nkA) lora_src(cur, 0);
-            if (!LORA && xt && kt + 2 == nk) next_src(cur, 0, nk);
+            if (!LORA && !STEADY && xt && kt + 2 == nk) next_src(cur, 0, nk);
             if (CONV && n2 && ((kt + 2) & (cv.ktp - 1)) == 0) conv_src(cur, 0, (kt + 2) / cv.ktp);
             if (n2) stA(cb + SLOT_A0, cur, 0, k2);
             UG_BARRIER();
             UG_MMA_QUADRANT(1, 1, breg);
             UG_BARRIER();
             // phase 3: quadrant (1,0), B0 from registers
-            if (n2) { stB(cb + SLOT_B0, cur, 0, k2); UG_WAIT_VM(8, x3); }    // A0, B0(kt+1) landed
+            // (Measured and dropped the same day: A0(kt+2) in this phase too - six pieces, issue order unchanged - is 2-7 % SLOWER: profiles/r05_gemm_loop_ab.log)
+            if (MODE == 2) { stB(cb + SLOT_B0, cur, 0, k2); stB(cb + SLOT_B1, cur, 1, k2); UG_WAIT_VM(10, false); }   // + B1(kt+2): its slot's last read was phase 1
+            else if (n2 && early_b1) { stB(cb + SLOT_B0, cur, 0, k2); stB(cb + SLOT_B1, cur, 1, k2); UG_WAIT_VM(10, x3); }
+            else if (n2) { stB(cb + SLOT_B0, cur, 0, k2); UG_WAIT_VM(8, x3); }    // A0, B0(kt+1) landed
             else if (n1) UG_WAIT_VM(4, x3);
             UG_BARRIER();
             UG_MMA_QUADRANT(1, 0, breg0);
             UG_BARRIER();
+        };
+        {
+            constexpr auto GENERIC = std::integral_constant<int, 0>{};
+            constexpr auto MID = std::integral_constant<int, 2>{};
+            constexpr auto DYN = std::integral_constant<int, -1>{};
+            constexpr auto P0 = std::integral_constant<int, 0>{};
+            constexpr auto P1 = std::integral_constant<int, 1>{};
+            int kt = 0;
+            if constexpr (BUF) {
+                if (steady_to >= steady_from) {
+                    for (; kt < steady_from; ++kt) ktile(kt, GENERIC, DYN);
+                    // pairs with their ring parity at compile time (steady_from is even): every LDS address is a lane constant + an immediate
+                    for (; kt < steady_to; kt += 2) { ktile(kt, MID, P0); ktile(kt + 1, MID, P1); }
+                }
+            }
+            for (; kt < nk; ++kt) ktile(kt, GENERIC, DYN);
         }
 #undef UG_WAIT_VM
         if (wr == 0) UG_BARRIER();          // both groups level again; every LDS read of this tile has retired
