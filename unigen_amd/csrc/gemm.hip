@@ -210,12 +210,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
     // offset in an SGPR - instead of the global form's 64-bit per-lane address, which costs a 64-bit VALU add per DMA (2 of the loop's VALU
     // instructions each: tools/loop_census.py) and 16 VGPRs of pointers instead of 8 of offsets. Offsets are tile-relative, so they fit 32 bits for
     // any matrix size (the launcher checks the one bound that remains, a row map's batch jump inside a tile). The LoRA segment and the convolution
-    // gather switch base addresses inside the K loop (lora_src / conv_src) and keep the global form, as do the probe build's cross-tile streams.
-#ifdef UG_PROBE_BUILD
-    constexpr bool BUF = false;
-#else
+    // gather switch base addresses inside the K loop (lora_src / conv_src) and keep the global form.
     constexpr bool BUF = !LORA && !CONV;
-#endif
     struct TileSrc { const bf16_t* a[2][2]; const bf16_t* b[2][2]; int64_t m0, n0; int g; int nk; int rem; int slice; unsigned pk[2][2];
                      const bf16_t* abase; const bf16_t* wbase; int vo_a[2][2], vo_b[2][2]; };
     // CONV (AutoencoderKL 3x3 convolutions, vae.hip): A row m is output pixel (b, oy, ox), kept packed per staging row (b << 24 | oy << 12 | ox);
@@ -304,36 +300,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
             t.b[h][i] = (const bf16_t*)p.lora_B + wn * p.ldb + c * 8 - p.K;
         }
     };
-    // Cross-tile stream (bit 2 of wide16_gm): the ring does not drain at a tile boundary. In the last two K-tiles of a full tile the staging
-    // slots that would idle (K-tiles nk, nk + 1 do not exist) take the NEXT tile's K-tiles 0 and 1 instead - same slots, same phases, same
-    // waits as the steady state - so the next tile's operands arrive under this tile's MFMAs and the epilogue's stores (and residual loads)
-    // have the CU's memory path to themselves. Like the LoRA segment switch, a half-tile pair's pointers are replaced right before its first
-    // use for the next tile, pre-biased by -nk * BK so the running K offsets stay valid; needs an even K-tile count (ring parity).
-    // MEASURED (round 3, profiles/r03o_*): bit-identical; the stamp profile shows the "next" share of a tile falling 2.5 -> 1.1 us and the first
-    // barrier's wait 4.0 -> 3.4 us, but the two K-tiles that now carry DMAs run at the steady-state 1.9 us instead of the DMA-free 1.3 us:
-    // -0.7 ... +0.9 % per cfg2 shape, 2.006 vs 2.012 images/s end to end -> OFF by default (UG_GEMM_XTILE=1 enables). What it establishes: the
-    // bytes a tile has to move are conserved, and the loop already runs at the pace of the CU's LDS / L1 path, not at the pace of its issue.
-#ifdef UG_PROBE_BUILD
-#define UG_XTILE_ON(FLAGS) (((FLAGS) & 4) != 0)
-#else      /* product: the cross-tile stream measured neutral (round 3) and is compiled out - `xt` below is a constant false */
-#define UG_XTILE_ON(FLAGS) false
-#endif
-    int64_t nx_m0 = 0, nx_n0 = 0; int nx_g = 0;
-    auto next_src = [&](TileSrc& t, int h, int nk_cur) __attribute__((always_inline)) {
-        int lane_l = lane;
-        asm volatile("" : "+v"(lane_l));
-        const bf16_t* Ab = (const bf16_t*)p.A + (int64_t)nx_g * p.a_gstride - (int64_t)nk_cur * BK;
-        const bf16_t* Wb = (const bf16_t*)p.W + (int64_t)nx_g * p.w_gstride - (int64_t)nk_cur * BK;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int row = wave * 16 + i * 8 + (lane_l >> 3);
-            const int c = (lane_l & 7) ^ (row & 7);
-            int64_t am = nx_m0 + h * 128 + row; if (am > M - 1) am = M - 1;
-            int64_t wn = nx_n0 + bcol(h, row); if (wn > N - 1) wn = N - 1;
-            t.a[h][i] = Ab + (int64_t)rowmap32((unsigned)am, (unsigned)p.a_rpb, (unsigned)p.a_bstride) * p.lda + c * 8;
-            t.b[h][i] = Wb + wn * p.ldw + c * 8;
-        }
-    };
+    // (Round 3's cross-tile stream - the last two K-tiles of a tile staging the next tile's first two, UG_GEMM_XTILE - measured neutral
+    // (profiles/r03o_*: -0.7...+0.9 % per shape) and lived on in the probe build until round 5, when the buffer-form DMAs replaced the per-lane pointers it
+    // swapped; removed from the source.)
     auto stage = [&](unsigned char* slot, const bf16_t* const (&src)[2], int64_t ko) {
         glds16(src[0] + ko, slot + st_off);
         glds16(src[1] + ko, slot + st_off + 8 * 128);
@@ -422,16 +391,6 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
     for (; tile < n_items; tile += gridDim.x) {
         const int nk = cur.nk;             // K-tiles of THIS work item (shadows the full count)
         if (nk == 0) break;                // padding item (only ever the last one of a workgroup)
-        bool xt = false;                   // this tile's last two K-tiles stage the next tile's first two (see next_src)
-        if constexpr (!LORA && !CONV) {
-            const int nxt = tile + (int)gridDim.x;
-            if (UG_XTILE_ON(wide16_gm) && nxt < full_tiles && nk >= 4 && !(nk & 1)) {
-                xt = true;
-                nx_g = nxt / tiles_per_group;
-                const TileCoord tc = tile_of_block(nxt - nx_g * tiles_per_group, nM, nN, ((wide16_gm >> 8) & 0xff) ? ((wide16_gm >> 8) & 0xff) : 8, (wide16_gm >> 16) & 3);
-                nx_m0 = (int64_t)tc.tm * 256; nx_n0 = (int64_t)tc.tn * 256;
-            }
-        }
         {   // Lane-derived constants of the K loop, re-derived per tile from an opaque copy of the lane id so that they are not live
             // through the epilogue (kept live across the whole tile loop, hipcc spilled a_off / b_off and reloaded them - with a
             // vmcnt(0) that drains the DMA ring - in every K-tile).
@@ -509,12 +468,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
             constexpr int PAR = decltype(par_c)::value;             // the K-tile's ring parity when the caller knows it (steady pairs), else -1
             unsigned char* cb = smem + (PAR >= 0 ? PAR : (kt & 1)) * KT_BYTES;
             unsigned char* nb = smem + (PAR >= 0 ? PAR ^ 1 : ((kt & 1) ^ 1)) * KT_BYTES;
-            const bool n1 = STEADY || kt + 1 < nk || xt, n2 = STEADY || kt + 2 < nk || xt;
+            const bool n1 = STEADY || kt + 1 < nk, n2 = STEADY || kt + 2 < nk;
             const bool pre0 = !STEADY && pre && kt == 0;
             const bool x01 = !STEADY && sif && (kt == 0 || (pre && kt == 1)), x3 = !STEADY && sif && kt == 0;
             const int64_t k1 = (int64_t)(kt + 1) * BK, k2 = (int64_t)(kt + 2) * BK;
             if (LORA && kt + 1 == nkA) lora_src(cur, 1);
-            if (!LORA && !STEADY && xt && kt + 1 == nk) next_src(cur, 1, nk);
             if (CONV && n1 && ((kt + 1) & (cv.ktp - 1)) == 0) conv_src(cur, 1, (kt + 1) / cv.ktp);
             // phase 0: quadrant (0,0)
             read_A(cb + SLOT_A0); read_B(breg0, cb + SLOT_B0);
@@ -537,7 +495,6 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
             // phase 2: quadrant (1,1)
             read_A(cb + SLOT_A1);
             if (LORA && kt + 2 == nkA) lora_src(cur, 0);
-            if (!LORA && !STEADY && xt && kt + 2 == nk) next_src(cur, 0, nk);
             if (CONV && n2 && ((kt + 2) & (cv.ktp - 1)) == 0) conv_src(cur, 0, (kt + 2) / cv.ktp);
             if (n2) stA(cb + SLOT_A0, cur, 0, k2);
             UG_BARRIER();
@@ -545,6 +502,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
             UG_BARRIER();
             // phase 3: quadrant (1,0), B0 from registers
             // (Measured and dropped the same day: A0(kt+2) in this phase too - six pieces, issue order unchanged - is 2-7 % SLOWER: profiles/r05_gemm_loop_ab.log)
+            // (... and: A1 + B1(kt+1) in phase 1, A0 + B0(kt+2) here, phases 0 / 2 reads only - four pieces among four reads, four alone: 0.9-2.1 % SLOWER)
             if (MODE == 2) { stB(cb + SLOT_B0, cur, 0, k2); stB(cb + SLOT_B1, cur, 1, k2); UG_WAIT_VM(10, false); }   // + B1(kt+2): its slot's last read was phase 1
             else if (n2 && early_b1) { stB(cb + SLOT_B0, cur, 0, k2); stB(cb + SLOT_B1, cur, 1, k2); UG_WAIT_VM(10, x3); }
             else if (n2) { stB(cb + SLOT_B0, cur, 0, k2); UG_WAIT_VM(8, x3); }    // A0, B0(kt+1) landed
@@ -616,7 +574,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
                                                         (lane_e >> 4) * 4);
                     }
                 }
-            if (!xt) { if (tile + (int)gridDim.x < n_items) cur = tile_src(tile + gridDim.x, lane_e); else cur.nk = 0; }
+            if (tile + (int)gridDim.x < n_items) cur = tile_src(tile + gridDim.x, lane_e); else cur.nk = 0;
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -625,20 +583,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
                     fg[j][nt][0] = bflo(pg[j][nt].x); fg[j][nt][1] = bfhi(pg[j][nt].x); fg[j][nt][2] = bflo(pg[j][nt].y); fg[j][nt][3] = bfhi(pg[j][nt].y);
                 }
             __builtin_amdgcn_sched_barrier(0);
-        } else if (!xt) {
+        } else {
             if (tile + (int)gridDim.x < n_items) cur = tile_src(tile + gridDim.x, lane_e); else cur.nk = 0;
         }
-        if (xt) {
-            // K-tiles 0 and 1 (A0 B0 B1 A1 | A0 B0) of the next tile were requested inside the K loop; the ring's last two half-tiles follow
-            // here (their slots were read in this tile's last K-tile), so the next tile starts exactly as after stage_first.
-            const int64_t unbias = (int64_t)nk * BK;
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int i = 0; i < 2; ++i) { cur.a[h][i] += unbias; cur.b[h][i] += unbias; }
-            stage(smem + KT_BYTES + SLOT_B1, cur.b[1], BK); stage(smem + KT_BYTES + SLOT_A1, cur.a[1], BK);
-            cur.m0 = nx_m0; cur.n0 = nx_n0; cur.g = nx_g;
-        } else if (cur.nk > 0) stage_first(cur);
+        if (cur.nk > 0) stage_first(cur);
         UG_STAMP(3);
         if (rem >= 0) {
             // ---- split-K tail: slab out, ticket, last arriver reduces (cdna guide section 5, "in-launch split-K reduction") ----
@@ -961,7 +909,6 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
 #endif
 #undef UG_STAMP
 #undef UG_MMA_QUADRANT
-#undef UG_XTILE_ON
 #undef UG_BARRIER
 }
 
@@ -1008,8 +955,7 @@ int launch(const ug_gemm_desc& d, hipStream_t s) {
         const bool res = d.epilogue == UG_EPI_RES_GATE || d.epilogue == UG_EPI_RES_SCALE;
         const int wide16 = (d.N % 8 == 0 && d.ldc % 8 == 0 && d.c_gstride % 8 == 0 && ug_aligned(d.C, 16) &&
                             (!res || (d.ldr % 8 == 0 && d.r_gstride % 8 == 0 && ug_aligned(d.R, 16)))) |
-                           ((d.c_rpb % 256 == 0 && (!res || d.r_rpb % 256 == 0) && UG_TUNE("UG_GEMM_EPI_ROWS_CONTIG", 1)) ? 2 : 0) |
-                           (UG_TUNE("UG_GEMM_XTILE", 0) ? 4 : 0);
+                           ((d.c_rpb % 256 == 0 && (!res || d.r_rpb % 256 == 0) && UG_TUNE("UG_GEMM_EPI_ROWS_CONTIG", 1)) ? 2 : 0);
         // (Measured and dropped, round 3: plain instead of non-temporal C stores in the full-tile epilogue - +-0.5 % on every cfg2 shape,
         // profiles/r03d_gemm_cplain.log: the per-tile store cost is not the cache policy.)
         // UG_GEMM_PWG=1: the one-wave-per-SIMD kernel (gemm_pwg.hip) takes every shape it supports
@@ -1092,7 +1038,7 @@ int launch_qkrope(const ug_gemm_desc& d, hipStream_t s) {
         d.K <= ug_env_int("UG_PWG_MAXK", 1 << 30))
         return ug_gemm_launch_pwg2_qkrope(d, s);
 #endif
-    const int wgm = 3 | (UG_TUNE("UG_GEMM_XTILE", 0) ? 4 : 0) | ((UG_TUNE("UG_GEMM_GROUP_M", 4) & 0xff) << 8) | ((UG_TUNE("UG_GEMM_WALK", 0) & 3) << 16);
+    const int wgm = 3 | ((UG_TUNE("UG_GEMM_GROUP_M", 4) & 0xff) << 8) | ((UG_TUNE("UG_GEMM_WALK", 0) & 3) << 16);
     const dim3 grid((unsigned)(total < ncu ? total : ncu));
     float* stamps = nullptr;
 #ifdef UG_DIAG_STAMPS
