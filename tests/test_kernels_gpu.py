@@ -667,3 +667,52 @@ def test_gemm_fused_qk_rmsnorm_rope_epilogue(gpu):
         ops.gemm(xd[:300], wd, bd, torch.empty(300, 3 * D, device=gpu, dtype=BF), M=300, qk_rope=ops.QkRope(wqd, wkd, cs, 0, 0, 2 * D))
     with pytest.raises(ValueError, match="positions"):
         ops.gemm(xd, wd, bd, one[Lc:], M=M, ldc=3 * D, c_map=ops.RowMap(Ls, Ljn), qk_rope=ops.QkRope(wqd, wkd, cs, Ls, Ljn, 2 * D))
+
+
+def test_gemm256_every_k_tile_count_class_matches_the_128_kernel(gpu):
+    """Round 5: the 256^2 kernel's K loop has a generic copy (first two and last two or three K-tiles) and a steady copy (pairs, static ring
+    parity, B1's DMA pieces issued a phase early) with two hand-over flags between them. Every class of K-tile count goes through it here -
+    1 .. 5 (generic only), 6 (one steady pair), odd and even counts with one, two and many pairs - on shapes of several tile rounds with ragged
+    M / N edges, with and without the residual epilogue, against the 128^2 kernel (plain double buffer, same MFMA shape and K order): bit-identical.
+    A child process, because UG_GEMM_FORCE_TILE is read per call only with UG_ENV_DYNAMIC=1."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import os, sys
+os.environ["UG_ENV_DYNAMIC"] = "1"
+sys.path.insert(0, %r)
+import torch
+from unigen_amd import ops, lib as L
+dev = torch.device("cuda:0")
+g = torch.Generator(device=dev).manual_seed(0)
+rn = lambda *s: torch.randn(*s, generator=g, device=dev).to(torch.bfloat16)
+bad = []
+for nk in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 17, 20, 33):
+    for (M, N, epi) in ((4096 + 70, 4096, L.EPI_BIAS), (8192, 2048 + 24, L.EPI_RES_GATE)):
+        K = 64 * nk
+        a, w, b = rn(M, K), rn(N, K) * 0.1, rn(N)
+        res, gate = rn(M, N), rn((M + 999) // 1000, N)
+        outs = []
+        for tile in ("128", "256"):
+            os.environ["UG_GEMM_FORCE_TILE"] = tile
+            out = torch.zeros(M, N, device=dev, dtype=torch.bfloat16)
+            kw = dict(M=M, epilogue=epi)
+            if epi == L.EPI_RES_GATE:
+                kw.update(residual=res, alpha=0.7, gate=gate, gate_ld=N, rows_per_sample=1000)
+            ops.gemm(a, w, b, out, **kw)
+            outs.append(out)
+        torch.cuda.synchronize()
+        if not torch.equal(outs[0], outs[1]):
+            bad.append((nk, M, N, epi, float((outs[0] != outs[1]).float().mean())))
+        ref = (a.float() @ w.float().t() + b.float()).to(torch.bfloat16)
+        if epi == L.EPI_RES_GATE:
+            ref = res + gate.repeat_interleave(1000, 0)[:M] * ref
+        e = float((outs[1].float() - ref.float()).norm() / ref.float().norm())
+        if not e < 2e-3:
+            bad.append((nk, M, N, epi, "vs formula", e))
+print("KTILE_CLASSES", bad)
+""" % root
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("KTILE_CLASSES")][-1]
+    assert line == "KTILE_CLASSES []", line

@@ -1,3 +1,5 @@
+# Interleaved bench.py A/B of TWO BUILDS of the library on one box, three runs each: tools/probe/bin/libunigen_<name>.so, or "tree" for the in-tree build.
+#   bash tools/ab_bench.sh base tree gpurun_out/out.log
 set -e
 A=$1; Bn=$2; OUT=$3
 : > $OUT
