@@ -198,7 +198,21 @@ int ug_moe_gate_top2(const void* x, const void* c, int64_t ld, const void* wg, i
 int ug_moe_capacity_top2(const float* gates, const int32_t* idx, int64_t S, int32_t E, int64_t capacity, int32_t* slot,
                          int32_t* token_of_slot, float* weights, int64_t* exp_counts, float* l_aux, ug_stream_t stream);
 
-/* Combine over a token's K <= 2 (expert, slot) pairs - einsum("sec,ecm->sm") src/UniGenUtils.py:183 with top2gating's combine weights:
+/* deepspeed topkgating (TopKGate with k > 2: control_params.top_num > 2, src/UniGenTransformer.py:808 -> src/UniGenUtils.py:33-36): the gate.
+ * gates fp32 [S][E] = softmax of the fp32 logits of bf16(x + c), logits fp32 [S][E] (the capacity rule ranks LOGITS), idx int32 [K][S] = the
+ * token's K choices by descending logit (the lower expert index first among equal logits). 1 <= K <= E <= 16. No random draw. */
+int ug_moe_gate_topk(const void* x, const void* c, int64_t ld, const void* wg, int64_t S, int64_t D, int32_t E, int32_t K, float* gates,
+                     float* logits, int32_t* idx, ug_stream_t stream);
+
+/* Capacity rule of topkgating (drop_policy "probs"): expert e keeps the `capacity` (= max(ceil(S / E * K), 4) for the reference's settings) largest
+ * entries of its column of [logit if e is one of the token's K choices, else 0] over ALL S tokens - a chosen logit below zero loses to every
+ * non-chooser's zero - ties in token order; a choice survives if its entry is kept. Writes slot int32 [K][S] (-1 = dropped; slots in token order
+ * among the kept), token_of_slot int32 [E][capacity] (-1 = empty), weights fp32 [K][S] = the kept choices' gate probabilities over their sum
+ * clamped at FLT_EPSILON, exp_counts int64 [E] = choosers before the drop, l_aux fp32 scalar = (E / K) * sum_e mean_s(gates[s][e]) * exp_counts[e] / S. */
+int ug_moe_capacity_topk(const float* gates, const float* logits, const int32_t* idx, int64_t S, int32_t E, int32_t K, int64_t capacity,
+                         int32_t* slot, int32_t* token_of_slot, float* weights, int64_t* exp_counts, float* l_aux, ug_stream_t stream);
+
+/* Combine over a token's K <= 16 (expert, slot) pairs - einsum("sec,ecm->sm") src/UniGenUtils.py:183 with top2gating's / topkgating's combine weights:
  *   eh = bf16( sum_k bf16(weights[k][s]) * yh[idx[k][s]][slot[k][s]] )   (fp32 sum, one rounding; dropped choices contribute nothing),
  * ec likewise; residual sums, row map and `accumulate` exactly as ug_moe_combine. weights / idx / slot: [K][kstride], kstride >= S
  * (a slice of a longer token axis keeps its parent's stride). K = 1 with weights = the gate probability reproduces ug_moe_combine. */
@@ -308,6 +322,8 @@ int ug_moe_gate_top1_f32(const void* x, const void* c, int64_t ld, const void* w
                          float* gates, int32_t* idx, ug_stream_t stream);
 int ug_moe_gate_top2_f32(const void* x, const void* c, int64_t ld, const void* wg, int64_t S, int64_t D, int32_t E, const float* noise,
                          float* gates, int32_t* idx, ug_stream_t stream);
+int ug_moe_gate_topk_f32(const void* x, const void* c, int64_t ld, const void* wg, int64_t S, int64_t D, int32_t E, int32_t K, float* gates,
+                         float* logits, int32_t* idx, ug_stream_t stream);
 int ug_moe_combine_topk_f32(const void* yh, const void* yc, const float* weights, const int32_t* idx, const int32_t* slot, int32_t K,
                             int64_t kstride, int32_t E, int64_t capacity, const void* xs, const void* cs, int64_t ld_s, int64_t s_rpb,
                             int64_t s_bstride, void* out, int64_t ldo, int64_t S, int64_t D, int32_t accumulate, ug_stream_t stream);

@@ -371,8 +371,68 @@ def routing_top2(gates: torch.Tensor, logits: torch.Tensor, noise: Optional[torc
     return idx, slot, token_of_slot, weights
 
 
+def topkgating(logits: torch.Tensor, k: int, capacity: int):
+    """deepspeed 0.16.5 deepspeed.moe.sharded_moe.topkgating(drop_tokens=True, drop_policy="probs") - what TopKGate calls for k > 2, i.e.
+    control_params.top_num > 2 (src/UniGenTransformer.py:808 -> src/UniGenUtils.py:33-36). deepspeed is not in /root/reference: restated from its
+    published source, statement by statement. `capacity` = _capacity(gates, capacity_factor * k, min_capacity) = moe_capacity(S, E, k). No random
+    draw. Two properties of the published code that the restatement keeps: the capacity rule ranks the top-k LOGITS (not probabilities) of an
+    expert's column against ZEROS for the tokens that did not choose it, so a chosen logit below zero loses to every non-chooser and is dropped
+    whenever choosers-above-zero + non-choosers fill the capacity; and the kept probabilities are renormalised by their sum.
+    Returns l_aux, combine_weights [S,E,C] fp32, dispatch_mask [S,E,C] bool, exp_counts [E] int64. PARITY UNPINNED."""
+    S, E = logits.shape
+    top_gate, top_idx = torch.topk(logits, k=k, dim=1)
+    gates = F.softmax(logits, dim=1)
+    topk_masked_gates = torch.zeros_like(logits).scatter(1, top_idx, top_gate)
+    mask = torch.zeros_like(gates, dtype=torch.bool).scatter_(1, top_idx, 1)
+    exp_counts = torch.sum(mask, dim=0).detach()
+    me = torch.mean(gates, dim=0)
+    ce = torch.mean(mask.float(), dim=0)
+    l_aux = torch.mean(me * ce) * E * E / k
+    capacity_indices = torch.topk(topk_masked_gates, k=capacity, dim=0, sorted=False)[1]
+    capacity_mask = torch.zeros_like(logits).scatter(0, capacity_indices, 1)
+    mask = torch.logical_and(mask, capacity_mask)
+    locations = torch.cumsum(mask, dim=0) - 1
+    gates_masked = gates * mask
+    gates_s = torch.sum(gates_masked, dim=-1, keepdim=True)
+    denom_s = torch.clamp(gates_s, min=torch.finfo(gates_masked.dtype).eps)
+    gates_masked = gates_masked / denom_s
+    locations_sc = F.one_hot(locations * mask, num_classes=capacity).float()          # _one_hot_to_float
+    combine_weights = torch.einsum("se,sec->sec", gates_masked, locations_sc)
+    dispatch_mask = combine_weights.bool()
+    return l_aux, combine_weights, dispatch_mask, exp_counts
+
+
+def routing_topk(gates: torch.Tensor, logits: torch.Tensor, k: int, capacity: int, idx: Optional[torch.Tensor] = None):
+    """Index form of topkgating: idx [k, S] (choices by descending logit), slot [k, S] (-1 = dropped), token_of_slot [E, capacity], weights [k, S]
+    fp32. An expert keeps the `capacity` largest entries of its column (chosen logit, or 0 for a non-chooser), ties in token order (torch.topk's
+    own choice among exact ties is unspecified; between a chosen logit and the zeros of non-choosers a tie needs a logit of exactly 0);
+    slots in token order among the kept. `idx`: take the choices as given (a device's) and restate only what follows from them."""
+    S, E = gates.shape
+    if idx is None:
+        idx = torch.topk(logits, k=k, dim=1)[1].t().contiguous()
+    slot = torch.full((k, S), -1, dtype=torch.int64)
+    token_of_slot = torch.full((E, capacity), -1, dtype=torch.int64)
+    ar = torch.arange(S)
+    for e in range(E):
+        chosen = (idx == e).any(0)
+        col = torch.where(chosen, logits[:, e], torch.zeros(()))
+        order = torch.sort(col, descending=True, stable=True)[1]                       # value descending, token ascending among equals
+        in_cap = torch.zeros(S, dtype=torch.bool)
+        in_cap[order[:capacity]] = True
+        kept = chosen & in_cap
+        toks = ar[kept]
+        token_of_slot[e, : toks.numel()] = toks
+        loc = torch.cumsum(kept.long(), 0) - 1
+        for kk in range(k):
+            sel = (idx[kk] == e) & kept
+            slot[kk, sel] = loc[sel]
+    g = torch.stack([gates[ar, idx[kk]] for kk in range(k)]) * (slot >= 0).float()
+    weights = g / torch.clamp(g.sum(0, keepdim=True), min=torch.finfo(gates.dtype).eps)
+    return idx, slot, token_of_slot, weights
+
+
 def gate_route(logits: torch.Tensor, draw: Optional[torch.Tensor], top_num: int = 1):
-    """TopKGate.forward's dispatch on k (deepspeed 0.16.5: k = 1 -> top1gating, k = 2 -> top2gating) with the capacity each computes for the
+    """TopKGate.forward's dispatch on k (deepspeed 0.16.5: k = 1 -> top1gating, k = 2 -> top2gating, k > 2 -> topkgating) with the capacity each computes for the
     reference's settings. `draw`: the random sample the gating function takes from the device RNG - the Uniform(0,1) of Random Token
     Selection for k = 1, the Gumbel(0,1) added to the logits for k = 2. Returns (l_aux, combine_weights, dispatch_mask, exp_counts, routing)."""
     S, E = logits.shape
@@ -387,8 +447,13 @@ def gate_route(logits: torch.Tensor, draw: Optional[torch.Tensor], top_num: int 
         l_aux, cw, dm, exp_counts = top2gating(logits, draw, C)
         idx, slot, tos, weights = routing_top2(gates, logits, draw, C)
         routing = dict(gates=gates, idx=idx, slot=slot, token_of_slot=tos, capacity=C, logits=logits, weights=weights)
-    else:
-        raise ValueError("top_num > 2 (deepspeed topkgating) is not restated: no configuration of the reference uses it")
+    else:                                                                               # k > 2: topkgating, no random draw
+        if not 2 < top_num <= E:
+            raise ValueError(f"top_num {top_num} with {E} experts")
+        C = moe_capacity(S, E, capacity_factor=float(top_num))
+        l_aux, cw, dm, exp_counts = topkgating(logits, top_num, C)
+        idx, slot, tos, weights = routing_topk(gates, logits, top_num, C)
+        routing = dict(gates=gates, idx=idx, slot=slot, token_of_slot=tos, capacity=C, logits=logits, weights=weights)
     return l_aux, cw, dm, exp_counts, routing
 
 

@@ -120,7 +120,7 @@ def test_top2gating_dense_equals_index_form():
             me, ce = gates.mean(0), F.one_hot(idx[0], E).float().mean(0)
             assert abs(float(l_aux) - float((me * ce).mean() * E * E)) < 1e-6
     with pytest.raises(ValueError):
-        R.gate_route(torch.randn(8, 4), None, 3)
+        R.gate_route(torch.randn(8, 4), None, 5)          # more choices than experts (k = 3, 4 run deepspeed's topkgating: the next test)
     # the literal dense-einsum path of MOELayer.forward and the index path give the same CoMoE output with two choices per token
     cfg = R.FluxConfig(top_num=2, **TINY)
     st = {k: v.float() for k, v in R.make_state(cfg, seed=3, std=0.05, bias_std=0.02).items()}
@@ -296,3 +296,39 @@ def test_routing_indices_stay_in_range_at_two_full_samples():
     assert torch.equal(out, dense)
     y = torch.einsum("sec,ecm->sm", combine, out)
     assert torch.equal(y[~kept], torch.zeros_like(y[~kept])) and torch.isfinite(y).all()
+
+
+@pytest.mark.parametrize("S,E,k", [(64, 6, 3), (200, 6, 4), (37, 12, 5), (16, 6, 6), (512, 16, 3)])
+def test_topkgating_dense_form_equals_index_form(S, E, k):
+    """deepspeed topkgating (top_num > 2; restated, parity unpinned): the dense [S, E, C] combine weights / dispatch mask say the same thing as the
+    index form the kernels produce (idx / slot / token_of_slot / weights) - including the rule's odd corner, a chosen logit below zero losing to the
+    zeros of the tokens that did not choose the expert."""
+    g = torch.Generator().manual_seed(S + E + k)
+    logits = torch.randn(S, E, generator=g) * 1.5
+    logits[:, 0] += 1.0
+    l_aux, cw, dm, cnt, rt = R.gate_route(logits, None, k)
+    C, idx, slot, tos, w = rt["capacity"], rt["idx"], rt["slot"], rt["token_of_slot"], rt["weights"]
+    assert C == R.moe_capacity(S, E, float(k)) and idx.shape == (k, S)
+    cw2 = torch.zeros(S, E, C)
+    for kk in range(k):
+        keep = slot[kk] >= 0
+        cw2[torch.arange(S)[keep], idx[kk][keep], slot[kk][keep]] = w[kk][keep]
+    assert torch.equal(cw2.bool(), dm) and torch.allclose(cw2, cw, rtol=1e-5, atol=1e-7)
+    assert int(cnt.sum()) == k * S
+    # dropped choices are exactly the chosen entries outside their column's `capacity` largest of [chosen logit | 0]
+    chosen = torch.zeros(S, E, dtype=torch.bool).scatter_(1, idx.t(), True)
+    col = torch.where(chosen, logits, torch.zeros(()))
+    thr = torch.topk(col, k=min(C, S), dim=0)[0][-1]
+    must_keep, must_drop = chosen & (col > thr), chosen & (col < thr)
+    kept = torch.zeros(S, E, dtype=torch.bool)
+    for kk in range(k):
+        keep = slot[kk] >= 0
+        kept[torch.arange(S)[keep], idx[kk][keep]] = True
+    assert bool((kept | ~must_keep).all()) and not bool((kept & must_drop).any())
+    if 2 * k >= E and k < E:         # with half the experts chosen per token, some chosen logits are negative
+        assert bool((chosen & (logits < 0) & ~kept).any()), "the case should show a below-zero choice losing to a non-chooser's zero"
+    x = torch.randn(S, 8, generator=g)
+    out = torch.zeros(E, C, 8)
+    v = tos >= 0
+    out[v] = x[tos[v]]
+    assert torch.equal(torch.einsum("sec,sm->ecm", dm.float(), x), out)

@@ -17,6 +17,8 @@ CONTROL = dict(use_rope=True, use_shared_expert=True, use_single_trans_blocks=Tr
 
 
 def _dev(v, gpu, dt=None):
+    if v is None:
+        return None
     if isinstance(v, (list, tuple)):
         return [_dev(t, gpu, dt) for t in v]
     return v.to(gpu) if (dt is None or not v.is_floating_point()) else v.to(gpu).to(dt)
@@ -30,9 +32,10 @@ def _step(fwd, target, dtype):
     return out.detach(), float(loss), extra
 
 
-@pytest.mark.parametrize("n_cond,cls_name,top_num", [(1, "UniGenFlux", 1), (2, "MultiCondtionUniGenFlux", 1), (1, "UniGenFlux", 2)])
+@pytest.mark.parametrize("n_cond,cls_name,top_num", [(1, "UniGenFlux", 1), (2, "MultiCondtionUniGenFlux", 1), (1, "UniGenFlux", 2), (1, "UniGenFlux", 3)])
 def test_control_module_gradients_match_oracle_autograd(gpu, n_cond, cls_name, top_num):
-    """top_num = 2: deepspeed top2gating - the gradient reaches the gate through BOTH kept probabilities and their normalising sum."""
+    """top_num = 2: deepspeed top2gating - the gradient reaches the gate through BOTH kept probabilities and their normalising sum. top_num = 3:
+    topkgating (no random draw) - through all kept probabilities of a token and their sum."""
     import importlib
     cls = getattr(importlib.import_module("src.UniGenTransformer"), cls_name)
     B, grid, T = 2, 8, 64                     # N = 64 image tokens, every joint length a multiple of 64 (attention backward contraction lengths)
@@ -46,6 +49,8 @@ def test_control_module_gradients_match_oracle_autograd(gpu, n_cond, cls_name, t
     if top_num == 2:                          # the gate's random draw is the Gumbel(0, 1) sample of the second choice
         u = torch.rand(B * grid * grid, rcfg.expert_nums, generator=torch.Generator().manual_seed(8)).clamp_(1e-7, 1 - 1e-7)
         inp["gate_uniform"] = -torch.log(-torch.log(u))
+    if top_num > 2:
+        inp["gate_uniform"] = None
     t = torch.full((B,), 0.75, dtype=BF)
     target = torch.randn(B, grid * grid, 64, generator=torch.Generator().manual_seed(5))
     base.init_trainable_param()

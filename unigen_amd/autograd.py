@@ -278,9 +278,14 @@ class MoeGate(torch.autograd.Function):
         if top_k == 1:
             idx = torch.empty(S, device=x.device, dtype=torch.int32)
             ops.moe_gate_top1(x, c, wgc, gates, idx)
-        else:
+        elif top_k == 2:
             idx = torch.empty(2, S, device=x.device, dtype=torch.int32)
             ops.moe_gate_top2(x, c, wgc, noise, gates, idx)
+        else:                                    # topkgating: idx [K, S]
+            idx = torch.empty(top_k, S, device=x.device, dtype=torch.int32)
+            logits = torch.empty(S, E, device=x.device, dtype=torch.float32)
+            ops.moe_gate_topk(x, c, wgc, top_k, gates, logits, idx)
+            MoeGate.last_logits = logits           # read by training._route right after apply() (the capacity rule ranks logits; not differentiable)
         ctx.save_for_backward(gates, x, c, wgc)
         ctx.mark_non_differentiable(idx)
         return gates, idx

@@ -73,6 +73,62 @@ __global__ __launch_bounds__(256) void moe_gate_kernel(const T* __restrict__ x, 
     }
 }
 
+// TOPK (deepspeed topkgating, k > 2): the K largest LOGITS per token (descending; the lower expert index first among equals), the softmax
+// probabilities, and the logits themselves - topkgating's capacity rule ranks logits, not probabilities.
+template <typename T>
+__global__ __launch_bounds__(256) void moe_gate_topk_kernel(const T* __restrict__ x, const T* __restrict__ c, int64_t ld,
+                                                            const T* __restrict__ wg, int64_t S, int D, int E, int K,
+                                                            float* __restrict__ gates, float* __restrict__ logits, int32_t* __restrict__ idx) {
+    using EL = ElemT<T>;
+    const int lane = threadIdx.x & 63;
+    const int64_t s = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (s >= S) return;
+    float acc[GATE_MAXE];
+#pragma unroll
+    for (int e = 0; e < GATE_MAXE; ++e) acc[e] = 0.f;
+    const int nchunk = D >> 3;
+    for (int ch = lane; ch < nchunk; ch += 64) {
+        float a[8], b[8];
+        EL::load8(x + s * ld + ch * 8, a);
+        EL::load8(c + s * ld + ch * 8, b);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a[i] = EL::rnd(a[i] + b[i]);
+#pragma unroll
+        for (int e = 0; e < GATE_MAXE; ++e) {
+            if (e < E) {
+                float w[8];
+                EL::load8(wg + (int64_t)e * D + ch * 8, w);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[e] += a[i] * w[i];
+            }
+        }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < GATE_MAXE; ++e)
+        if (e < E) { acc[e] = wave_sum(acc[e]); mx = fmaxf(mx, acc[e]); }
+    if (lane == 0) {
+        unsigned taken = 0;
+        for (int k = 0; k < K; ++k) {                       // K rounds of "largest not yet taken"
+            float m = -INFINITY;
+            int best = 0;
+            bool any = false;
+#pragma unroll
+            for (int e = 0; e < GATE_MAXE; ++e)
+                if (e < E && !((taken >> e) & 1u) && (!any || acc[e] > m)) { m = acc[e]; best = e; any = true; }
+            taken |= 1u << best;
+            idx[(int64_t)k * S + s] = best;
+        }
+        float den = 0.f, p[GATE_MAXE];
+#pragma unroll
+        for (int e = 0; e < GATE_MAXE; ++e)
+            if (e < E) { p[e] = expf(acc[e] - mx); den += p[e]; }
+#pragma unroll
+        for (int e = 0; e < GATE_MAXE; ++e)
+            if (e < E) { gates[s * E + e] = p[e] / den; logits[s * E + e] = acc[e]; }
+    }
+}
+
 // block-wide exclusive scan of one flag per thread (1024 threads); returns exclusive prefix, *total = block total
 __device__ __forceinline__ int block_excl_scan(int flag, int* wsum /*[17]*/, int* total) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -208,10 +264,113 @@ __global__ __launch_bounds__(256) void moe_weights_top2_kernel(const float* __re
     weights[S + s] = g2 / den;
 }
 
+// order-preserving map of a float onto unsigned (larger float <-> larger key), for the radix select below
+__device__ __forceinline__ unsigned ug_fkey(float v) {
+    const unsigned u = __float_as_uint(v);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// deepspeed topkgating's capacity rule (drop_policy "probs"): an expert keeps the `capacity` largest entries of its column of
+// topk_masked_gates = (the token's LOGIT if the expert is one of its K choices, else 0), i.e. torch.topk(., k = capacity, dim = 0) over ALL S
+// tokens - non-choosers compete with their zeros - and a choice survives if it is among them. Ties at the threshold: token order (torch's
+// choice among exact ties is unspecified). Slots = rank among the kept tokens in token order (cumsum(mask) - 1). One block (1024 threads) per
+// expert; idx / slot are [K][S]; exp_counts = choosers before the drop.
+__global__ __launch_bounds__(1024) void moe_capacity_topk_kernel(const int32_t* __restrict__ idx, const float* __restrict__ logits, int S, int E, int K,
+                                                                 int capacity, int32_t* __restrict__ slot, int32_t* __restrict__ token_of_slot,
+                                                                 int64_t* __restrict__ exp_counts) {
+    __shared__ int hist[256];
+    __shared__ int wsum[17];
+    __shared__ unsigned sh_prefix;
+    __shared__ int sh_k;
+    const int e = blockIdx.x;
+    const int tid = threadIdx.x;
+    auto choice_of = [&](int s) {                   // which of the token's K choices is expert e (-1: none)
+        int kk = -1;
+        for (int k = 0; k < K; ++k) if (idx[(int64_t)k * S + s] == e) kk = k;
+        return kk;
+    };
+    auto key_of = [&](int s, int kk) { return ug_fkey(kk >= 0 ? logits[(int64_t)s * E + e] : 0.f); };
+    int cnt = 0;
+    for (int s = tid; s < S; s += 1024) cnt += (choice_of(s) >= 0);
+    {
+        const int lane = tid & 63, wave = tid >> 6;
+        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+        if (lane == 0) wsum[wave] = cnt;
+        __syncthreads();
+        cnt = 0;
+        for (int w = 0; w < 16; ++w) cnt += wsum[w];
+        __syncthreads();
+    }
+    if (tid == 0) exp_counts[e] = (int64_t)cnt;
+    // threshold = capacity-th largest key of the whole column (radix select, MSB first); capacity >= S keeps every chooser
+    unsigned T = 0; int k_eq = 0;
+    const bool drop = capacity < S;
+    if (drop) {
+        unsigned prefix = 0, mask = 0; int k = capacity;
+        for (int shift = 24; shift >= 0; shift -= 8) {
+            for (int i = tid; i < 256; i += 1024) hist[i] = 0;
+            __syncthreads();
+            for (int s = tid; s < S; s += 1024) {
+                const unsigned key = key_of(s, choice_of(s));
+                if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255], 1);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int kk = k, d = 255;
+                for (; d > 0; --d) { if (hist[d] >= kk) break; kk -= hist[d]; }
+                sh_prefix = prefix | ((unsigned)d << shift);
+                sh_k = kk;
+            }
+            __syncthreads();
+            prefix = sh_prefix; k = sh_k; mask |= (255u << shift);
+            __syncthreads();
+        }
+        T = prefix; k_eq = k;       // keep every key > T and the first k_eq column entries (choosers or not) with key == T, in token order
+    }
+    int base_eq = 0, base_kept = 0;
+    for (int s0 = 0; s0 < S; s0 += 1024) {
+        const int s = s0 + tid;
+        const int kk = s < S ? choice_of(s) : -1;
+        const bool mine = kk >= 0;
+        bool kept = mine;
+        if (drop) {
+            const unsigned key = s < S ? key_of(s, kk) : 0u;
+            const int feq = s < S && key == T;
+            int tot_eq;
+            const int r_eq = block_excl_scan(feq, wsum, &tot_eq);
+            kept = mine && (key > T || (feq && base_eq + r_eq < k_eq));
+            base_eq += tot_eq;
+        }
+        int tot_k;
+        const int rk = block_excl_scan(kept ? 1 : 0, wsum, &tot_k);
+        if (mine) {
+            const int sl = kept ? base_kept + rk : -1;
+            slot[(int64_t)kk * S + s] = sl;
+            if (kept) token_of_slot[(int64_t)e * capacity + sl] = s;
+        }
+        base_kept += tot_k;
+    }
+    for (int c = base_kept + tid; c < capacity; c += 1024) token_of_slot[(int64_t)e * capacity + c] = -1;
+}
+
+// combine weights of topkgating: a token's kept gate probabilities over their sum clamped at finfo(float32).eps. weights [K][S].
+__global__ __launch_bounds__(256) void moe_weights_topk_kernel(const float* __restrict__ gates, const int32_t* __restrict__ idx,
+                                                               const int32_t* __restrict__ slot, int S, int E, int K, float* __restrict__ weights) {
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= S) return;
+    float g[GATE_MAXE], den = 0.f;
+    for (int k = 0; k < K; ++k) {
+        g[k] = slot[(int64_t)k * S + s] >= 0 ? gates[(int64_t)s * E + idx[(int64_t)k * S + s]] : 0.f;
+        den += g[k];
+    }
+    den = fmaxf(den, 1.1920928955078125e-07f);
+    for (int k = 0; k < K; ++k) weights[(int64_t)k * S + s] = g[k] / den;
+}
+
 // l_aux = E * sum_e mean_s(gates[s][e]) * (n_e / S), n_e = tokens whose FIRST choice is e: exp_counts[e] (top-1: the same thing) or, when
 // idx1 is given (top-2: exp_counts holds both choices), counted from idx1; single block, fixed summation order
 __global__ __launch_bounds__(1024) void moe_laux_kernel(const float* __restrict__ gates, const int64_t* __restrict__ exp_counts, const int32_t* __restrict__ idx1,
-                                                        int S, int E, float* __restrict__ l_aux) {
+                                                        int S, int E, float* __restrict__ l_aux, float scale) {
     __shared__ float part[16];
     __shared__ int ipart[16];
     __shared__ float terms[GATE_MAXE];
@@ -235,7 +394,7 @@ __global__ __launch_bounds__(1024) void moe_laux_kernel(const float* __restrict_
     if (tid == 0) {
         float t = 0.f;
         for (int e = 0; e < E; ++e) t += terms[e];
-        *l_aux = t * (float)E;
+        *l_aux = t * scale;          // top-1 / top-2: E; topkgating: mean(me * ce) * E * E / k = sum * E / k with ce over all k choices
     }
 }
 
@@ -442,7 +601,7 @@ int moe_combine_topk_impl(const void* yh, const void* yc, const float* weights, 
                           int32_t E, int64_t capacity, const void* xs, const void* cs, int64_t ld_s, int64_t s_rpb, int64_t s_bstride, void* out,
                           int64_t ldo, int64_t S, int64_t D, int32_t accumulate, ug_stream_t stream) {
     if (S == 0) return UG_OK;
-    UG_REQUIRE(yh && yc && weights && idx && slot && out && E > 0 && capacity > 0 && K >= 1 && K <= 2 && kstride >= S, UG_ERR_BAD_SHAPE,
+    UG_REQUIRE(yh && yc && weights && idx && slot && out && E > 0 && capacity > 0 && K >= 1 && K <= GATE_MAXE && kstride >= S, UG_ERR_BAD_SHAPE,
                "ug_moe_combine_topk: bad arguments");
     UG_REQUIRE((xs == nullptr) == (cs == nullptr), UG_ERR_BAD_SHAPE, "ug_moe_combine_topk: xs and cs must both be given or both NULL");
     UG_REQUIRE(s_rpb >= 0 && s_bstride >= 0, UG_ERR_BAD_SHAPE, "ug_moe_combine_topk: bad row map");
@@ -482,7 +641,7 @@ extern "C" int ug_moe_capacity_rts(const float* gates, const int32_t* idx, const
     hipLaunchKernelGGL(moe_capacity_kernel, dim3((unsigned)E), dim3(1024), 0, s, idx, uniform, (int)S, (int)E, (int)capacity, slot,
                        token_of_slot, exp_counts);
     UG_CHECK_LAUNCH("ug_moe_capacity_rts");
-    hipLaunchKernelGGL(moe_laux_kernel, dim3(1), dim3(1024), 0, s, gates, (const int64_t*)exp_counts, (const int32_t*)nullptr, (int)S, (int)E, l_aux);
+    hipLaunchKernelGGL(moe_laux_kernel, dim3(1), dim3(1024), 0, s, gates, (const int64_t*)exp_counts, (const int32_t*)nullptr, (int)S, (int)E, l_aux, (float)E);
     UG_CHECK_LAUNCH("ug_moe_capacity_rts(l_aux)");
     return UG_OK;
 }
@@ -497,8 +656,47 @@ extern "C" int ug_moe_capacity_top2(const float* gates, const int32_t* idx, int6
     UG_CHECK_LAUNCH("ug_moe_capacity_top2");
     hipLaunchKernelGGL(moe_weights_top2_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, s, gates, idx, (const int32_t*)slot, (int)S, (int)E, weights);
     UG_CHECK_LAUNCH("ug_moe_capacity_top2(weights)");
-    hipLaunchKernelGGL(moe_laux_kernel, dim3(1), dim3(1024), 0, s, gates, (const int64_t*)exp_counts, idx, (int)S, (int)E, l_aux);
+    hipLaunchKernelGGL(moe_laux_kernel, dim3(1), dim3(1024), 0, s, gates, (const int64_t*)exp_counts, idx, (int)S, (int)E, l_aux, (float)E);
     UG_CHECK_LAUNCH("ug_moe_capacity_top2(l_aux)");
+    return UG_OK;
+}
+
+template <typename T>
+static int moe_gate_topk_impl(const void* x, const void* c, int64_t ld, const void* wg, int64_t S, int64_t D, int32_t E, int32_t K, float* gates,
+                              float* logits, int32_t* idx, ug_stream_t stream) {
+    if (S == 0) return UG_OK;
+    UG_REQUIRE(x && c && wg && gates && logits && idx && S > 0 && D > 0, UG_ERR_BAD_SHAPE, "ug_moe_gate_topk: bad arguments");
+    UG_REQUIRE(E >= 1 && E <= GATE_MAXE && K >= 1 && K <= E, UG_ERR_UNSUPPORTED, "ug_moe_gate_topk: E=%d K=%d not in 1 <= K <= E <= %d", E, K, GATE_MAXE);
+    UG_REQUIRE(D % 8 == 0 && ld % 8 == 0 && ug_aligned(x, 16) && ug_aligned(c, 16) && ug_aligned(wg, 16), UG_ERR_BAD_ALIGN,
+               "ug_moe_gate_topk: 16-byte alignment required");
+    hipLaunchKernelGGL((moe_gate_topk_kernel<T>), dim3((unsigned)((S + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)c, ld,
+                       (const T*)wg, S, (int)D, (int)E, (int)K, gates, logits, idx);
+    UG_CHECK_LAUNCH("ug_moe_gate_topk");
+    return UG_OK;
+}
+extern "C" int ug_moe_gate_topk(const void* x, const void* c, int64_t ld, const void* wg, int64_t S, int64_t D, int32_t E, int32_t K, float* gates,
+                                float* logits, int32_t* idx, ug_stream_t s) {
+    return moe_gate_topk_impl<bf16_t>(x, c, ld, wg, S, D, E, K, gates, logits, idx, s);
+}
+extern "C" int ug_moe_gate_topk_f32(const void* x, const void* c, int64_t ld, const void* wg, int64_t S, int64_t D, int32_t E, int32_t K, float* gates,
+                                    float* logits, int32_t* idx, ug_stream_t s) {
+    return moe_gate_topk_impl<float>(x, c, ld, wg, S, D, E, K, gates, logits, idx, s);
+}
+
+extern "C" int ug_moe_capacity_topk(const float* gates, const float* logits, const int32_t* idx, int64_t S, int32_t E, int32_t K, int64_t capacity,
+                                    int32_t* slot, int32_t* token_of_slot, float* weights, int64_t* exp_counts, float* l_aux, ug_stream_t stream) {
+    UG_REQUIRE(gates && logits && idx && slot && token_of_slot && weights && exp_counts && l_aux, UG_ERR_BAD_SHAPE, "ug_moe_capacity_topk: null argument");
+    UG_REQUIRE(S > 0 && S < (1ll << 27) && E >= 1 && E <= GATE_MAXE && K >= 1 && K <= E && capacity > 0 && capacity < (1ll << 30), UG_ERR_BAD_SHAPE,
+               "ug_moe_capacity_topk: bad S/E/K/capacity");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(moe_capacity_topk_kernel, dim3((unsigned)E), dim3(1024), 0, s, idx, logits, (int)S, (int)E, (int)K, (int)capacity, slot, token_of_slot,
+                       exp_counts);
+    UG_CHECK_LAUNCH("ug_moe_capacity_topk");
+    hipLaunchKernelGGL(moe_weights_topk_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, s, gates, idx, (const int32_t*)slot, (int)S, (int)E, (int)K, weights);
+    UG_CHECK_LAUNCH("ug_moe_capacity_topk(weights)");
+    hipLaunchKernelGGL(moe_laux_kernel, dim3(1), dim3(1024), 0, s, gates, (const int64_t*)exp_counts, (const int32_t*)nullptr, (int)S, (int)E, l_aux,
+                       (float)E / (float)K);
+    UG_CHECK_LAUNCH("ug_moe_capacity_topk(l_aux)");
     return UG_OK;
 }
 

@@ -274,7 +274,7 @@ class HipModule(nn.Module):
     def _route(self, x: torch.Tensor, c: torch.Tensor, E: int, top_k: int, draw: Optional[torch.Tensor]) -> "_Routing":
         """TopKGate.forward on (x + c) [S, D] + deepspeed's top1gating (k = 1: capacity ceil(S / E), Random Token Selection; `draw` = its
         Uniform(0, 1) sample [S, E]) or top2gating (k = 2: capacity ceil(2 S / E), second choice by Gumbel-max; `draw` = its Gumbel(0, 1) sample)
-        in index form (src/UniGenUtils.py:99; include/unigen_hip.h). A missing draw is taken from the device RNG, as the reference does."""
+        in index form (src/UniGenUtils.py:99; include/unigen_hip.h), or topkgating (k > 2: no draw). A missing draw is taken from the device RNG, as the reference does."""
         S, dev = x.shape[0], x.device
         wg = self._P("moe.moe_layer.gate.wg.weight")
         gates = self._w("moe_gates", (S, E), torch.float32)
@@ -288,8 +288,18 @@ class HipModule(nn.Module):
                 draw = torch.rand(S, E, device=dev, dtype=torch.float32)   # RTS draw; the reference consumes the global device RNG too
             ops.moe_capacity_rts(gates, idx, draw.contiguous(), C, slot, tos, exp_counts, l_aux)
             return _Routing(1, E, C, gates, idx, slot, tos, None, exp_counts, l_aux)
-        if top_k != 2:
-            raise ValueError("top_num must be 1 or 2 (deepspeed's topkgating for k > 2 is used by no configuration of the reference)")
+        if top_k > 2:
+            # deepspeed topkgating (k > 2; used by no shipped configuration of the reference, restated from its published source, include/unigen_hip.h):
+            # capacity ceil(k S / E), the K largest logits per token, per expert the `capacity` largest of [chosen logit | 0], renormalised weights
+            if top_k > E:
+                raise ValueError(f"top_num {top_k} exceeds the {E} experts")
+            C = max(int(math.ceil((S / E) * float(top_k))), 4)
+            K = top_k
+            idx, slot, tos = self._w("moe_idxk", (K, S), torch.int32), self._w("moe_slotk", (K, S), torch.int32), self._w("moe_tos", (E, C), torch.int32)
+            weights, logits = self._w("moe_wk", (K, S), torch.float32), self._w("moe_logits", (S, E), torch.float32)
+            ops.moe_gate_topk(x, c, wg, K, gates, logits, idx)
+            ops.moe_capacity_topk(gates, logits, idx, C, slot, tos, weights, exp_counts, l_aux)
+            return _Routing(K, E, C, gates, idx, slot, tos, weights, exp_counts, l_aux)
         C = max(int(math.ceil((S / E) * 2.0)), 4)      # top2gating: _capacity(gates, capacity_factor * 2, min_capacity)
         idx, slot, tos = self._w("moe_idx2", (2, S), torch.int32), self._w("moe_slot2", (2, S), torch.int32), self._w("moe_tos", (E, C), torch.int32)
         weights = self._w("moe_w2", (2, S), torch.float32)

@@ -207,8 +207,8 @@ class UniGenFlux(HipModule):
             expert_nums=int(expert_num) if expert_num is not None else (condition_nums + 1) * int(get("expert_num_each_condition", 3)),
             top_k=int(get("top_num", 1)),
         )
-        if ctl.top_k not in (1, 2):
-            raise ValueError("top_num must be 1 (deepspeed top1gating) or 2 (top2gating); topkgating (k > 2) is used by no configuration of the reference")
+        if not 1 <= ctl.top_k <= max(ctl.expert_nums, 1):
+            raise ValueError(f"top_num {ctl.top_k} must be in 1 .. expert count {ctl.expert_nums} (deepspeed top1gating / top2gating / topkgating)")
         if ctl.top_k == 2 and ctl.expert_nums < 2:
             raise ValueError("top_num = 2 needs at least two experts")
         if ctl.expert_nums > 16:

@@ -70,6 +70,8 @@ SIGNATURES = {
     "ug_moe_capacity_rts": (i32, [vp, vp, vp, i64, i32, i64, vp, vp, vp, vp, vp]),
     "ug_moe_gate_top2": (i32, [vp, vp, i64, vp, i64, i64, i32, vp, vp, vp, vp]),
     "ug_moe_capacity_top2": (i32, [vp, vp, i64, i32, i64, vp, vp, vp, vp, vp, vp]),
+    "ug_moe_gate_topk": (i32, [vp, vp, i64, vp, i64, i64, i32, i32, vp, vp, vp, vp]),
+    "ug_moe_capacity_topk": (i32, [vp, vp, vp, i64, i32, i32, i64, vp, vp, vp, vp, vp, vp]),
     "ug_moe_combine_topk": (i32, [vp, vp, vp, vp, vp, i32, i64, i32, i64, vp, vp, i64, i64, i64, vp, i64, i64, i64, i32, vp]),
     "ug_moe_dispatch_modulate": (i32, [vp, i64, vp, vp, i64, i64, vp, i32, i64, i64, i64, vp, vp]),
     "ug_moe_combine": (i32, [vp, vp, vp, vp, vp, i32, i64, vp, vp, i64, i64, i64, vp, i64, i64, i64, i32, vp]),
@@ -114,7 +116,7 @@ _F32_TWINS = {"ug_gate_residual_f32": "ug_gate_residual", "ug_moe_gate_bwd_f32":
               "ug_euler_step_f32": "ug_euler_step", "ug_cfg_combine_f32": "ug_cfg_combine", "ug_add_f32": "ug_add_bf16",
               "ug_add_rowbcast_f32_f32": "ug_add_rowbcast_f32", "ug_gather_rows_f32": "ug_gather_rows", "ug_moe_gate_top1_f32": "ug_moe_gate_top1",
               "ug_moe_dispatch_modulate_f32": "ug_moe_dispatch_modulate", "ug_moe_combine_f32": "ug_moe_combine",
-              "ug_moe_gate_top2_f32": "ug_moe_gate_top2", "ug_moe_combine_topk_f32": "ug_moe_combine_topk",
+              "ug_moe_gate_top2_f32": "ug_moe_gate_top2", "ug_moe_gate_topk_f32": "ug_moe_gate_topk", "ug_moe_combine_topk_f32": "ug_moe_combine_topk",
               "ug_pack_latents_f32": "ug_pack_latents", "ug_unpack_latents_f32": "ug_unpack_latents",
               "ug_conv2d_nhwc_f32": "ug_conv2d_nhwc", "ug_groupnorm_nhwc_f32": "ug_groupnorm_nhwc", "ug_softmax_rows_f32": "ug_softmax_rows",
               "ug_nchw_to_nhwc_f32": "ug_nchw_to_nhwc", "ug_nhwc_to_nchw_f32": "ug_nhwc_to_nchw", "ug_vae_sample_f32": "ug_vae_sample"}

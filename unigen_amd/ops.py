@@ -393,6 +393,30 @@ def moe_capacity_top2(gates, idx, capacity: int, slot, token_of_slot, weights, e
                                           exp_counts.data_ptr(), l_aux.data_ptr(), _stream()), "ug_moe_capacity_top2")
 
 
+def moe_gate_topk(x: torch.Tensor, c: torch.Tensor, wg: torch.Tensor, K: int, gates: torch.Tensor, logits: torch.Tensor, idx: torch.Tensor) -> None:
+    """topkgating's gate (k > 2): gates, logits [S, E] fp32, idx int32 [K, S] (the token's K choices by descending logit)."""
+    dt = _act(x, "x")
+    _chk(c, "c", dt); _chk(wg, "wg", dt); _chk(gates, "gates", torch.float32); _chk(logits, "logits", torch.float32); _chk(idx, "idx", torch.int32)
+    S, D = x.shape
+    E = wg.shape[0]
+    assert c.shape == x.shape and wg.shape[1] == D and gates.shape == (S, E) and logits.shape == (S, E) and idx.shape == (K, S) and idx.is_contiguous()
+    assert x.stride(0) == c.stride(0) and gates.is_contiguous() and logits.is_contiguous()
+    L.check(_fn("ug_moe_gate_topk", dt)(x.data_ptr(), c.data_ptr(), x.stride(0), wg.data_ptr(), S, D, E, K, gates.data_ptr(), logits.data_ptr(), idx.data_ptr(),
+                                        _stream()), "ug_moe_gate_topk")
+
+
+def moe_capacity_topk(gates, logits, idx, capacity: int, slot, token_of_slot, weights, exp_counts, l_aux) -> None:
+    """topkgating's capacity rule + combine weights + l_aux (include/unigen_hip.h): idx / slot / weights [K, S]."""
+    S, E = gates.shape
+    K = idx.shape[0]
+    for t, dt in ((gates, torch.float32), (logits, torch.float32), (idx, torch.int32), (slot, torch.int32), (token_of_slot, torch.int32), (weights, torch.float32),
+                  (exp_counts, torch.int64), (l_aux, torch.float32)):
+        assert t.is_cuda and t.dtype == dt and t.is_contiguous()
+    assert logits.shape == (S, E) and idx.shape == (K, S) and slot.shape == (K, S) and weights.shape == (K, S) and token_of_slot.shape == (E, capacity)
+    L.check(L.load().ug_moe_capacity_topk(gates.data_ptr(), logits.data_ptr(), idx.data_ptr(), S, E, K, capacity, slot.data_ptr(), token_of_slot.data_ptr(),
+                                          weights.data_ptr(), exp_counts.data_ptr(), l_aux.data_ptr(), _stream()), "ug_moe_capacity_topk")
+
+
 def moe_combine_topk(yh, yc, weights, idx, slot, out, *, E: int, capacity: int, xs=None, cs=None, s_map: RowMap = IDENT, accumulate: bool = False) -> torch.Tensor:
     """weights fp32 / idx / slot [K, S'] (S' >= S: column slices of longer arrays keep their row stride); otherwise as moe_combine."""
     dt = _act(yh, "yh")

@@ -190,8 +190,8 @@ class UniGenSD3(HipModule):
             expert_nums=int(expert_num) if expert_num is not None else (condition_nums + 1) * int(get("expert_num_each_condition", 3)),
             top_k=int(get("top_num", 1)),
         )
-        if ctl.top_k not in (1, 2) or ctl.expert_nums > 16 or ctl.expert_nums < ctl.top_k:
-            raise ValueError("top_num 1 or 2 (deepspeed top1gating / top2gating) with top_num..16 experts is implemented")
+        if ctl.top_k < 1 or ctl.expert_nums > 16 or ctl.expert_nums < ctl.top_k:
+            raise ValueError("top_num 1 .. expert count (deepspeed top1gating / top2gating / topkgating) with at most 16 experts is implemented")
         self._ctl = ctl
         dev_, dt_ = self.device, self.dtype
         shapes = sd3_control_param_shapes(self.config, ctl)

@@ -185,6 +185,19 @@ def _route(model, x, c, uniform):
         kept = (slot >= 0).unsqueeze(0)
         flat = (idx.long() * C + slot.long()).clamp_min(0).unsqueeze(0)
         w = (gates.gather(1, idx.long().unsqueeze(1)).squeeze(1) * kept[0].float()).to(x.dtype).unsqueeze(0)      # combine weight, rounded as `cw.to(dt)`
+    elif K > 2:                                          # deepspeed topkgating: no random draw; the capacity rule ranks the chosen LOGITS against zeros
+        C = max(int(math.ceil((S / E) * float(K))), 4)
+        gates, idx = A.MoeGate.apply(x2, c2, wg, K, None)
+        logits = A.MoeGate.last_logits
+        slot, tos = torch.empty(K, S, device=dev, dtype=torch.int32), torch.empty(E, C, device=dev, dtype=torch.int32)
+        w_dev = torch.empty(K, S, device=dev, dtype=torch.float32)
+        ops.moe_capacity_topk(gates.detach().contiguous(), logits, idx, C, slot, tos, w_dev, exp_counts, l_aux_k)
+        chosen = torch.zeros(S, E, device=dev, dtype=torch.float32).scatter_(1, idx.long().t(), 1.0)
+        l_aux = torch.mean(gates.mean(0) * chosen.mean(0)) * E * E / K
+        kept = slot >= 0
+        flat = (idx.long() * C + slot.long()).clamp_min(0)
+        g = torch.stack([gates.gather(1, idx[k].long().unsqueeze(1)).squeeze(1) for k in range(K)]) * kept.float()
+        w = (g / torch.clamp(g.sum(0, keepdim=True), min=torch.finfo(torch.float32).eps)).to(x.dtype)
     else:
         C = max(int(math.ceil((S / E) * 2.0)), 4)
         if uniform is None:                            # gumbel_rsample
