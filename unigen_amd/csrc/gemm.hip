@@ -459,7 +459,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
         // MI355X_MICROARCH.md, LDS-DMA piece issue cost). Same issue ORDER, so every counted wait keeps its meaning; only the wait that now follows
         // five young half-tiles instead of four becomes vmcnt(10). The hand-overs are two flags of the generic body: the generic K-tile before the
         // first steady one stages B1 for it in its phase 3 (early_b1), the generic K-tile after the last steady one finds its B1 already staged (skip_b1).
-        const int steady_from = 2, steady_to = (BUF && nk >= 6) ? ((nk & 1) ? nk - 4 : nk - 3) : 1;      // steady K-tiles [from, to]: an even count
+        // (Only the plain kernel runs the steady copy. The convolution variant could - its tap-boundary pointer switches are hooks of the body in
+        // either mode and touch the A pointers only - but with its gather registers the second copy of the loop spills 20 VGPRs (84 B of scratch per
+        // lane: checked with -Rpass-analysis=kernel-resource-usage) where the single loop fits in 248; the LoRA variant's segment switch replaces the B1
+        // pointers one K-tile AFTER the early B1 stage would need them.)
+        constexpr bool STEADY_OK = BUF;
+        const int steady_from = 2, steady_to = (STEADY_OK && nk >= 6) ? ((nk & 1) ? nk - 4 : nk - 3) : 1;      // steady K-tiles [from, to]: an even count
         auto ktile = [&](const int kt, auto mode_c, auto par_c) __attribute__((always_inline)) {
             constexpr int MODE = decltype(mode_c)::value;
             constexpr bool STEADY = MODE != 0;
@@ -518,7 +523,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
             constexpr auto P0 = std::integral_constant<int, 0>{};
             constexpr auto P1 = std::integral_constant<int, 1>{};
             int kt = 0;
-            if constexpr (BUF) {
+            if constexpr (STEADY_OK) {
                 if (steady_to >= steady_from) {
                     for (; kt < steady_from; ++kt) ktile(kt, GENERIC, DYN);
                     // pairs with their ring parity at compile time (steady_from is even): every LDS address is a lane constant + an immediate
