@@ -159,7 +159,12 @@ constexpr int SLOT_A0 = 0, SLOT_B0 = HT_BYTES, SLOT_B1 = 2 * HT_BYTES, SLOT_A1 =
 #ifndef UG_EPI_RES_PREFETCH
 #define UG_EPI_RES_PREFETCH 8          /* row-groups of residual chunks in flight in the full-tile epilogue: all 8 (2 = rounds 1-2). Two-library A/B: 4: +-0.5 %, 8: +0.5...+1.1 % on the R + gate * v shapes; no spills (252 registers) */
 #endif
-#ifdef UG_DIAG_STAMPS
+#ifdef UG_DIAG_PHASES          /* tools/gemm_phase_stamps.py: per-segment stamps of one steady K-tile (implies UG_DIAG_STAMPS) */
+#define UG_DIAG_STAMPS
+#endif
+#ifdef UG_DIAG_PHASES
+constexpr int UG_STAMP_LDS = 4096;
+#elif defined(UG_DIAG_STAMPS)
 constexpr int UG_STAMP_LDS = 2048;
 #else
 constexpr int UG_STAMP_LDS = 0;
@@ -379,8 +384,16 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
     int tile_seq = 0;
     if (threadIdx.x == 0) stamp_lds[250] = __builtin_amdgcn_s_memrealtime();      // 100 MHz, one counter for the chip: when this workgroup entered
 #define UG_STAMP(I) do { if (threadIdx.x == 0 && tile_seq < 50) stamp_lds[tile_seq * 5 + (I)] = __builtin_amdgcn_s_memtime(); } while (0)
+#ifdef UG_DIAG_PHASES
+    // one steady K-tile (kt == 10) of the workgroup's SECOND tile, lane 0 of waves 0 and 4 (one of each group): 4 stamps per phase - L segment start,
+    // L done (reads / DMAs issued and the counted wait passed), first barrier passed, MFMAs issued - and one behind the last barrier
+#define UG_PSTAMP(KT, I) do { if ((threadIdx.x & 255) == 0 && tile_seq == 1 && (KT) == 10) stamp_lds[256 + (threadIdx.x >> 8) * 32 + (I)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define UG_PSTAMP(KT, I) do { } while (0)
+#endif
 #else
 #define UG_STAMP(I) do { } while (0)
+#define UG_PSTAMP(KT, I) do { } while (0)
 #endif
 
     int tile = blockIdx.x;
@@ -480,31 +493,44 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
             if (LORA && kt + 1 == nkA) lora_src(cur, 1);
             if (CONV && n1 && ((kt + 1) & (cv.ktp - 1)) == 0) conv_src(cur, 1, (kt + 1) / cv.ktp);
             // phase 0: quadrant (0,0)
+            UG_PSTAMP(kt, 0);
             read_A(cb + SLOT_A0); read_B(breg0, cb + SLOT_B0);
             if (MODE >= 2) UG_WAIT_VM(8, false);                                     // B1(kt) landed; B1(kt+1) was staged in the phase 3 before
             else if (pre0) UG_WAIT_VM(10, x01);
             else if (n1) { if (!skip_b1) stB(nb + SLOT_B1, cur, 1, k1); UG_WAIT_VM(8, x01); }   // B1(kt) landed
             else UG_WAIT_VM(2, x01);
+            UG_PSTAMP(kt, 1);
             UG_BARRIER();
+            UG_PSTAMP(kt, 2);
             UG_MMA_QUADRANT(0, 0, breg0);
+            UG_PSTAMP(kt, 3);
             UG_BARRIER();
+            UG_PSTAMP(kt, 4);
             // phase 1: quadrant (0,1)
             // (Measured and dropped the same day: the steady copy issuing this phase's two DMA pieces BEFORE its four reads: +-0.5 % per shape)
             read_B(breg, cb + SLOT_B1);
             if (pre0) UG_WAIT_VM(8, x01);
             else if (n1) { stA(nb + SLOT_A1, cur, 1, k1); UG_WAIT_VM(8, x01); }   // A1(kt) landed
             else UG_WAIT_VM(0, x01);
+            UG_PSTAMP(kt, 5);
             UG_BARRIER();
+            UG_PSTAMP(kt, 6);
             UG_MMA_QUADRANT(0, 1, breg);
+            UG_PSTAMP(kt, 7);
             UG_BARRIER();
+            UG_PSTAMP(kt, 8);
             // phase 2: quadrant (1,1)
             read_A(cb + SLOT_A1);
             if (LORA && kt + 2 == nkA) lora_src(cur, 0);
             if (CONV && n2 && ((kt + 2) & (cv.ktp - 1)) == 0) conv_src(cur, 0, (kt + 2) / cv.ktp);
             if (n2) stA(cb + SLOT_A0, cur, 0, k2);
+            UG_PSTAMP(kt, 9);
             UG_BARRIER();
+            UG_PSTAMP(kt, 10);
             UG_MMA_QUADRANT(1, 1, breg);
+            UG_PSTAMP(kt, 11);
             UG_BARRIER();
+            UG_PSTAMP(kt, 12);
             // phase 3: quadrant (1,0), B0 from registers
             // (Measured and dropped the same day: A0(kt+2) in this phase too - six pieces, issue order unchanged - is 2-7 % SLOWER: profiles/r05_gemm_loop_ab.log)
             // (... and: A1 + B1(kt+1) in phase 1, A0 + B0(kt+2) here, phases 0 / 2 reads only - four pieces among four reads, four alone: 0.9-2.1 % SLOWER)
@@ -512,9 +538,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
             else if (n2 && early_b1) { stB(cb + SLOT_B0, cur, 0, k2); stB(cb + SLOT_B1, cur, 1, k2); UG_WAIT_VM(10, x3); }
             else if (n2) { stB(cb + SLOT_B0, cur, 0, k2); UG_WAIT_VM(8, x3); }    // A0, B0(kt+1) landed
             else if (n1) UG_WAIT_VM(4, x3);
+            UG_PSTAMP(kt, 13);
             UG_BARRIER();
+            UG_PSTAMP(kt, 14);
             UG_MMA_QUADRANT(1, 0, breg0);
+            UG_PSTAMP(kt, 15);
             UG_BARRIER();
+            UG_PSTAMP(kt, 16);
         };
         {
             constexpr auto GENERIC = std::integral_constant<int, 0>{};
@@ -911,8 +941,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
         for (int i = 0; i < 248; ++i) out[i] = i < tile_seq * 5 ? stamp_lds[i] : 0ull;
         out[248] = stamp_lds[250]; out[249] = __builtin_amdgcn_s_memrealtime();    // entry / exit on the chip-wide real-time counter (per-XCD finish times)
     }
+#ifdef UG_DIAG_PHASES
+    if (threadIdx.x == 0 && slabs != nullptr) {      // phase stamps of waves 0 and 4 behind the tile stamps of all 256 workgroups
+        unsigned long long* out = (unsigned long long*)slabs + (size_t)256 * 250 + (size_t)blockIdx.x * 64;
+        for (int i = 0; i < 64; ++i) out[i] = stamp_lds[256 + i];
+    }
+#endif
 #endif
 #undef UG_STAMP
+#undef UG_PSTAMP
 #undef UG_MMA_QUADRANT
 #undef UG_BARRIER
 }
@@ -995,7 +1032,7 @@ int launch(const ug_gemm_desc& d, hipStream_t s) {
             hipLaunchKernelGGL((gemm256_kernel<EPI, EPI != UG_EPI_F32>), grid, dim3(512), LDS256_BYTES + 16 + UG_STAMP_LDS, s, d, (int)(t256 / groups), total, wide16 | gm, full, nsl, slabs, tickets, UgConvGeom{});
         } else {
 #ifdef UG_DIAG_STAMPS
-            if (nsl == 1 && d.workspace && (size_t)d.workspace_bytes >= 4096 + (size_t)256 * 250 * 8) slabs = (float*)((char*)d.workspace + 4096);
+            if (nsl == 1 && d.workspace && (size_t)d.workspace_bytes >= 4096 + (size_t)256 * 250 * 8 + (size_t)256 * 64 * 8) slabs = (float*)((char*)d.workspace + 4096);
 #endif
             hipLaunchKernelGGL((gemm256_kernel<EPI, false>), grid, dim3(512), LDS256_BYTES + 16 + UG_STAMP_LDS, s, d, (int)(t256 / groups), total, wide16 | gm, full, nsl, slabs, tickets, UgConvGeom{});
         }
