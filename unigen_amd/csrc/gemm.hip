@@ -307,7 +307,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
     };
     // (Round 3's cross-tile stream - the last two K-tiles of a tile staging the next tile's first two, UG_GEMM_XTILE - measured neutral
     // (profiles/r03o_*: -0.7...+0.9 % per shape) and lived on in the probe build until round 5, when the buffer-form DMAs replaced the per-lane pointers it
-    // swapped; removed from the source.)
+    // swapped; removed from the source. Rebuilt on the round-5 loop in buffer form the same round - the next tile's A0 / B0 pieces of K-tiles 0 and 1
+    // issued by the last two K-tiles of this one, sources selected by value, no spills, 242-250 VGPRs, bit-identical: -0.6...+0.2 % per shape and
+    // -0.3 % images/s interleaved on one box; with the epilogue's bias / gate loads hoisted ahead of those DMAs as well, 16-40 B/lane of scratch and
+    // -2 %: profiles/r05_gemm_loop_ab.log steps 8 and 9. Issuing the first K-tiles' DMAs earlier does not buy back the 3-5 us a tile waits for them
+    // (profiles/r05x_gemm_tile_stamps.log); what they queue behind there was not identified.)
     auto stage = [&](unsigned char* slot, const bf16_t* const (&src)[2], int64_t ko) {
         glds16(src[0] + ko, slot + st_off);
         glds16(src[1] + ko, slot + st_off + 8 * 128);
