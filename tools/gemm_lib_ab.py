@@ -37,6 +37,15 @@ SHAPES = [
     ("attn out res_gate", B * NI, D, D, L.EPI_RES_GATE),
     ("zero-res res_scale", B * (NI + T), D, D, L.EPI_RES_SCALE),
 ]
+if os.environ.get("UG_AB_SHAPES") == "sd3":      # cfg5's projections (UniGenSD3, D = 1536, B = 8, 1024^2): K = 1536 is 24 K-tiles per tile - the per-tile cost weighs twice what it does at K = 3072
+    B, D = 8, 1536
+    SHAPES = [
+        ("sd3 qkv image bias", B * NI, 3 * D, D, L.EPI_BIAS),
+        ("sd3 attn out res_gate", B * NI, D, D, L.EPI_RES_GATE),
+        ("sd3 ff up gelu", B * NI, 4 * D, D, L.EPI_BIAS_GELU),
+        ("sd3 ff down K=6144 res_gate", B * NI, D, 4 * D, L.EPI_RES_GATE),
+        ("sd3 joint rows 8 x 4429 out res_gate", B * (NI + 333), D, D, L.EPI_RES_SCALE),
+    ]
 if len(sys.argv) > 1:
     SHAPES = [s for s in SHAPES if any(a in s[0] for a in sys.argv[1:])]
 for label, M, N, K, epi in SHAPES:
