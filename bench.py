@@ -419,7 +419,72 @@ class _PowerSampler:
                     source="amdgpu hwmon power1_input / freq1_input of this rank's device, every 0.2 s inside the timed region")
 
 
-def _roofline_blocks(s, elapsed, pk16, pk32, attn_kernel, traffic_file=None):
+# 3 + 2 of the 4 TCC counter slots: FETCH_SIZE and WRITE_SIZE cannot share a pass (MI355X_MICROARCH.md, counter table); the matrix-pipe pass is the third
+PMC_PASSES = (("FETCH_SIZE",), ("WRITE_SIZE",), ("SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"))
+
+
+def _under_profiler():
+    return any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+
+
+def same_run_traffic(limit_s=150.0):
+    """`roofline.traffic` measured by THIS run on THIS box: one child per counter pass - `rocprofv3 --kernel-trace --pmc <counter> -- python3 bench.py
+    --pmc-child` (the cfg2 B = 4 workload, one 4-forward step, no timers / probes / CPU legs; the program goes straight after `--`) - after every timed
+    region of the parent is over. Bytes beyond the XCD L2 per GEMM launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 / launches over all gemm256 / gemm128
+    launches (KiB units; gfx950's FETCH_SIZE counts wide coalesced reads at half their bytes; Infinity-Cache hits are included: an upper bound on HBM
+    bytes). A pass that fails or overruns `limit_s` raises; the caller then falls back to the recorded profile and says so."""
+    import csv, shutil, signal, subprocess, tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        raise RuntimeError("rocprofv3 not found")
+    td = tempfile.mkdtemp(prefix="ug_bench_pmc_", dir="/tmp")
+    sums, launches, secs, ns256 = {}, {}, {}, {}
+    try:
+        for counters in PMC_PASSES:
+            t0 = time.perf_counter()
+            out = os.path.join(td, counters[0])
+            cmd = [exe, "--kernel-trace", "--pmc", *counters, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.join(ROOT, "bench.py"), "--pmc-child"]
+            p = subprocess.Popen(cmd, cwd=td, env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, start_new_session=True)
+            try:
+                log, _ = p.communicate(timeout=limit_s)
+            except subprocess.TimeoutExpired:
+                os.killpg(p.pid, signal.SIGKILL)            # exactly the process group started above
+                p.communicate()
+                raise RuntimeError(f"PMC pass {counters} overran {limit_s:.0f} s")
+            if p.returncode != 0:
+                raise RuntimeError(f"PMC pass {counters} exited {p.returncode}: {log[-300:]}")
+            files = [os.path.join(r, f) for r, _, fs in os.walk(out) for f in fs if f.endswith("counter_collection.csv")]
+            if not files:
+                raise RuntimeError(f"PMC pass {counters}: no counter_collection.csv")
+            for path in files:
+                with open(path, newline="") as f:
+                    for r in csv.DictReader(f):
+                        k256 = "gemm256_kernel" in r["Kernel_Name"]
+                        c = r["Counter_Name"]
+                        if c in ("FETCH_SIZE", "WRITE_SIZE") and (k256 or "gemm128_kernel" in r["Kernel_Name"]):
+                            sums[c] = sums.get(c, 0.0) + float(r["Counter_Value"])
+                            launches[c] = launches.get(c, 0) + 1
+                        elif c in ("SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE") and k256:        # the dominant kernel alone
+                            sums[c] = sums.get(c, 0.0) + float(r["Counter_Value"])
+                            launches[c] = launches.get(c, 0) + 1
+                            ns256[c] = ns256.get(c, 0.0) + float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+            secs[counters[0]] = round(time.perf_counter() - t0, 1)
+    finally:
+        shutil.rmtree(td, ignore_errors=True)
+    if not launches.get("FETCH_SIZE") or launches.get("FETCH_SIZE") != launches.get("WRITE_SIZE"):
+        raise RuntimeError(f"PMC passes saw different GEMM launch counts: {launches}")
+    n = launches["FETCH_SIZE"]
+    fetch, write = 2.0 * sums["FETCH_SIZE"] * 1024.0 / n, sums["WRITE_SIZE"] * 1024.0 / n
+    res = dict(traffic=fetch + write, fetch_bytes_per_launch_corrected=fetch, write_bytes_per_launch=write, launches=n, pass_seconds=secs)
+    if sums.get("GRBM_GUI_ACTIVE"):
+        # busy cycles are summed over the 1024 SIMDs, GRBM_GUI_ACTIVE over the 8 XCDs (tools/pmc_summary.py: the same arithmetic)
+        cyc = sums["GRBM_GUI_ACTIVE"] / 8.0
+        res["gemm256"] = dict(mfma_busy=sums["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * 1024.0), effective_clock_ghz=cyc / ns256["GRBM_GUI_ACTIVE"],
+                              launches=launches["GRBM_GUI_ACTIVE"], avg_launch_us_profiled=ns256["GRBM_GUI_ACTIVE"] / launches["GRBM_GUI_ACTIVE"] / 1e3)
+    return res
+
+
+def _roofline_blocks(s, elapsed, pk16, pk32, attn_kernel, traffic_file=None, live=None):
     """`roofline` (the bf16 MFMA GEMM, the dominant kernel) and `roofline_attention` from a KernelTimer summary: algorithmic FLOPs of the launches
     inside the timed region / their HIP-event durations, against the 2.5 PFLOP/s datasheet peak and the bare-MFMA rate measured in this run."""
     out = {}
@@ -439,6 +504,19 @@ def _roofline_blocks(s, elapsed, pk16, pk32, attn_kernel, traffic_file=None):
         if "mfma_busy_frac" in g256:
             pmc = dict(measured_in_this_run=False, file=f"profiles/{base}", mfma_busy=g256["mfma_busy_frac"], effective_clock_ghz=g256["effective_clock_ghz"],
                        hbm_side_gbps=g256["hbm_bytes_per_launch"] / (g256["avg_launch_us_profiled"] * 1e-6) / 1e9)
+    if live is not None and "traffic" in live:
+        traffic = live["traffic"]
+        traffic_src = dict(measured_in_this_run=True, launches=live["launches"], fetch_bytes_per_launch_corrected=live["fetch_bytes_per_launch_corrected"],
+                           write_bytes_per_launch=live["write_bytes_per_launch"], pass_seconds=live["pass_seconds"],
+                           collected="two child processes of this run, after its timed regions: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (one pass each) -- python3 bench.py --pmc-child")
+        traffic_note = ("measured in this run on this box: (2*FETCH_SIZE + WRITE_SIZE)*1024 per GEMM launch over one 4-forward step of the same workload under rocprofv3 "
+                        "(gfx950 FETCH_SIZE correction; KiB units); the L2-fabric counters include Infinity-Cache hits, so this is traffic beyond the XCD L2, an upper bound on HBM bytes")
+        if "gemm256" in live:
+            g = live["gemm256"]
+            pmc = dict(measured_in_this_run=True, mfma_busy=g["mfma_busy"], effective_clock_ghz=g["effective_clock_ghz"], launches=g["launches"],
+                       avg_launch_us_profiled=g["avg_launch_us_profiled"], collected="third child pass of this run: --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE")
+    elif live is not None and traffic_src is not None:
+        traffic_src["same_run_attempt"] = live.get("error")
     # second denominator: the measured MFMA-only rate of this chip, at the clock it holds under matrix load (pk16 / pk32)
     meas = (lambda a, pk: a / pk) if pk16 else (lambda a, pk: None)
     out["roofline"] = dict(bound="mfma", kernel="gemm256_kernel / gemm128_kernel (ug_gemm_bf16)", achieved=ach, peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s",
@@ -528,10 +606,15 @@ def main():
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--no-scaling-base", action="store_true", help="N = 1, cfg2 only: skip the extra B = 8 measurement (cfg4's per-GPU shape, the like-for-like base of the 1 -> 8 curve)")
     ap.add_argument("--no-other-configs", action="store_true", help="N = 1, cfg2 only: skip the cfg3 / cfg5 blocks (other_configs: 1 warm-up + 1 step each at B = 8)")
+    ap.add_argument("--no-pmc", action="store_true", help="N = 1, cfg2 only: skip the two rocprofv3 --pmc child passes that measure roofline.traffic in this run (then read from profiles/)")
+    ap.add_argument("--pmc-child", action="store_true", help="internal: the workload of one counter pass (cfg2, B = 4, one step, nothing else)")
     ap.add_argument("--small", action="store_true", help="debug: reduced depth (NOT the headline configuration)")
     ap.add_argument("--graph", action="store_true", help="capture one step (the whole denoise loop) in a HIP graph and replay it (SURVEY 8(f) rank 1)")
     ap.add_argument("--dry-run", action="store_true", help="no GPU work: rehearse the multi-process harness (spawn, rendezvous, barriers, JSON) on the CPU with gloo")
     args = ap.parse_args()
+    if args.pmc_child:                 # one counter pass of same_run_traffic(): the cfg2 workload's launches and nothing else
+        args.gpus, args.config, args.batch, args.steps, args.warmup = 1, "cfg2", 4, 1, 0
+        args.no_kernel_timer = args.no_cpu_baseline = args.no_scaling_base = args.no_other_configs = args.no_pmc = True
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         _self_launch(args, sys.argv[1:])                                  # does not return
@@ -639,8 +722,8 @@ def main():
             line["scaling_base"] = scaling_base
         if power is not None:
             line["power"] = power             # rank 0's GPU inside the timed region: the forward sits at the package power cap
+        traffic_file = None
         if s:
-            traffic_file = None
             cands = sorted(p for p in os.listdir(os.path.join(ROOT, "profiles")) if p.endswith("_pmc.json"))      # newest round's PMC summary
             tf = os.path.join(ROOT, "profiles", cands[-1] if cands else "r01_hbm_traffic.json")
             if os.path.exists(tf) and not args.small and config == "cfg2" and B == 4:      # PMC passes of this same command (see the file's `source`, tools/pmc_summary.py)
@@ -671,6 +754,15 @@ def main():
                 except Exception as e:                      # the headline line must survive: the failure is recorded, never hidden
                     others[oc] = dict(error=f"{type(e).__name__}: {e}")
             line["other_configs"] = others
+        if world == 1 and config == "cfg2" and B == 4 and s and not (args.small or args.graph or args.no_pmc or _under_profiler()):
+            # roofline.traffic from THIS run's own counter passes (two rocprofv3 children, after every timed region); on any failure the recorded profile stays
+            import gc
+            gc.collect(); torch.cuda.empty_cache()
+            try:
+                live = same_run_traffic()
+            except Exception as e:
+                live = dict(error=f"{type(e).__name__}: {e}")
+            line.update(_roofline_blocks(s, elapsed, pk16, pk32, info["attn_kernel"], traffic_file, live))
         print(json.dumps(line), flush=True)
     if world > 1:
         import torch.distributed as dist

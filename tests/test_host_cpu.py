@@ -746,3 +746,48 @@ def test_alternating_pack_groupings_keep_the_weight_bytes_constant():
         assert held_bytes() == want, (held_bytes(), want)
     assert all(torch.equal(before[n], q) for n, q in model.named_parameters() if n.startswith(p))
     assert len([k for k in model._packed if k.startswith(p)]) <= 4
+
+
+_FAKE_ROCPROFV3 = r"""#!/usr/bin/env python3
+# stands for rocprofv3 in the same-run traffic test: checks the command shape bench.py builds and writes the counter CSV a real pass would
+import os, sys
+a = sys.argv[1:]
+assert "--kernel-trace" in a and "--output-format" in a and a[a.index("--output-format") + 1] == "csv", a
+sep = a.index("--")
+prog = a[sep + 1:]
+assert os.path.basename(prog[0]).startswith("python") and prog[1].endswith("bench.py") and prog[2:] == ["--pmc-child"], prog      # the program itself after `--`
+counters = a[a.index("--pmc") + 1:a.index("--output-format")]
+if os.environ.get("FAKE_PMC_FAIL") == counters[0]:
+    sys.exit(3)
+out = os.path.join(a[a.index("-d") + 1], "host"); os.makedirs(out)
+rows = ["Kernel_Name,Counter_Name,Counter_Value,Start_Timestamp,End_Timestamp"]
+val = dict(FETCH_SIZE=1000.0, WRITE_SIZE=300.0, SQ_VALU_MFMA_BUSY_CYCLES=700.0 * 1024, GRBM_GUI_ACTIVE=8 * 1000.0)
+for i in range(6):
+    name = ["void (anonymous namespace)::gemm256_kernel<2, false, 128, false>(ug_gemm_desc)", "void (anonymous namespace)::gemm128_kernel<2>(ug_gemm_desc)",
+            "void (anonymous namespace)::flash_attn_kernel<128>(x)"][i % 3]
+    for c in counters:
+        rows.append(f'"{name}",{c},{val[c]},{1000 * i},{1000 * i + 500}')
+open(os.path.join(out, "1_counter_collection.csv"), "w").write("\n".join(rows) + "\n")
+"""
+
+
+def test_same_run_traffic_reads_its_own_counter_passes(tmp_path, monkeypatch):
+    """bench.same_run_traffic(): one rocprofv3 child per counter pass with the program straight after `--`, bytes per GEMM launch =
+    (2 x FETCH_SIZE + WRITE_SIZE) x 1024 over gemm256 + gemm128 launches only, matrix-pipe busy of gemm256 alone; a failing pass raises (bench.py then
+    keeps the recorded profile and says so)."""
+    import bench
+    fake = tmp_path / "rocprofv3"
+    fake.write_text(_FAKE_ROCPROFV3)
+    fake.chmod(0o755)
+    monkeypatch.setenv("PATH", f"{tmp_path}:{os.environ['PATH']}")
+    r = bench.same_run_traffic(limit_s=30)
+    assert r["launches"] == 4                                             # 2 x gemm256 + 2 x gemm128 of the 6 kernels in the fake trace
+    assert r["fetch_bytes_per_launch_corrected"] == 2 * 1000.0 * 1024 and r["write_bytes_per_launch"] == 300.0 * 1024
+    assert r["traffic"] == (2 * 1000.0 + 300.0) * 1024
+    assert abs(r["gemm256"]["mfma_busy"] - 0.7) < 1e-12 and r["gemm256"]["launches"] == 2 and abs(r["gemm256"]["effective_clock_ghz"] - 2.0) < 1e-12
+    blocks = bench._roofline_blocks(dict(gemm=dict(flops=1e15, ms=1000.0, launches=4)), 1.0, 2000.0, 1900.0, "attn", None, r)
+    assert blocks["roofline"]["traffic"] == r["traffic"] and blocks["roofline"]["traffic_source"]["measured_in_this_run"] is True
+    assert blocks["roofline"]["pmc_gemm256"]["measured_in_this_run"] is True
+    monkeypatch.setenv("FAKE_PMC_FAIL", "WRITE_SIZE")
+    with pytest.raises(RuntimeError, match="WRITE_SIZE"):
+        bench.same_run_traffic(limit_s=30)
