@@ -508,7 +508,7 @@ def _roofline_blocks(s, elapsed, pk16, pk32, attn_kernel, traffic_file=None, liv
         traffic = live["traffic"]
         traffic_src = dict(measured_in_this_run=True, launches=live["launches"], fetch_bytes_per_launch_corrected=live["fetch_bytes_per_launch_corrected"],
                            write_bytes_per_launch=live["write_bytes_per_launch"], pass_seconds=live["pass_seconds"],
-                           collected="two child processes of this run, after its timed regions: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (one pass each) -- python3 bench.py --pmc-child")
+                           collected="child processes of this run, after its timed regions: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (one pass each) -- python3 bench.py --pmc-child")
         traffic_note = ("measured in this run on this box: (2*FETCH_SIZE + WRITE_SIZE)*1024 per GEMM launch over one 4-forward step of the same workload under rocprofv3 "
                         "(gfx950 FETCH_SIZE correction; KiB units); the L2-fabric counters include Infinity-Cache hits, so this is traffic beyond the XCD L2, an upper bound on HBM bytes")
         if "gemm256" in live:
