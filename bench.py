@@ -438,7 +438,7 @@ def same_run_traffic(limit_s=150.0):
     if not os.path.exists(exe):
         raise RuntimeError("rocprofv3 not found")
     td = tempfile.mkdtemp(prefix="ug_bench_pmc_", dir="/tmp")
-    sums, launches, secs, ns256 = {}, {}, {}, {}
+    acc, secs = {}, {}          # (kernel class, counter) -> [sum, launches, ns]
     try:
         for counters in PMC_PASSES:
             t0 = time.perf_counter()
@@ -459,28 +459,35 @@ def same_run_traffic(limit_s=150.0):
             for path in files:
                 with open(path, newline="") as f:
                     for r in csv.DictReader(f):
-                        k256 = "gemm256_kernel" in r["Kernel_Name"]
-                        c = r["Counter_Name"]
-                        if c in ("FETCH_SIZE", "WRITE_SIZE") and (k256 or "gemm128_kernel" in r["Kernel_Name"]):
-                            sums[c] = sums.get(c, 0.0) + float(r["Counter_Value"])
-                            launches[c] = launches.get(c, 0) + 1
-                        elif c in ("SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE") and k256:        # the dominant kernel alone
-                            sums[c] = sums.get(c, 0.0) + float(r["Counter_Value"])
-                            launches[c] = launches.get(c, 0) + 1
-                            ns256[c] = ns256.get(c, 0.0) + float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+                        name = r["Kernel_Name"]
+                        classes = (("gemm_all", "gemm256") if "gemm256_kernel" in name else ("gemm_all",) if "gemm128_kernel" in name
+                                   else ("attn",) if "flash_attn" in name else ())
+                        for cls in classes:
+                            a = acc.setdefault((cls, r["Counter_Name"]), [0.0, 0, 0.0])
+                            a[0] += float(r["Counter_Value"]); a[1] += 1; a[2] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
             secs[counters[0]] = round(time.perf_counter() - t0, 1)
     finally:
         shutil.rmtree(td, ignore_errors=True)
-    if not launches.get("FETCH_SIZE") or launches.get("FETCH_SIZE") != launches.get("WRITE_SIZE"):
-        raise RuntimeError(f"PMC passes saw different GEMM launch counts: {launches}")
-    n = launches["FETCH_SIZE"]
-    fetch, write = 2.0 * sums["FETCH_SIZE"] * 1024.0 / n, sums["WRITE_SIZE"] * 1024.0 / n
-    res = dict(traffic=fetch + write, fetch_bytes_per_launch_corrected=fetch, write_bytes_per_launch=write, launches=n, pass_seconds=secs)
-    if sums.get("GRBM_GUI_ACTIVE"):
+    def traffic_of(cls):
+        f, w = acc.get((cls, "FETCH_SIZE")), acc.get((cls, "WRITE_SIZE"))
+        if not f or not w or f[1] != w[1]:
+            raise RuntimeError(f"PMC passes saw different {cls} launch counts: {f and f[1]} / {w and w[1]}")
+        fetch, write = 2.0 * f[0] * 1024.0 / f[1], w[0] * 1024.0 / w[1]
+        return dict(traffic=fetch + write, fetch_bytes_per_launch_corrected=fetch, write_bytes_per_launch=write, launches=f[1])
+
+    def busy_of(cls):
         # busy cycles are summed over the 1024 SIMDs, GRBM_GUI_ACTIVE over the 8 XCDs (tools/pmc_summary.py: the same arithmetic)
-        cyc = sums["GRBM_GUI_ACTIVE"] / 8.0
-        res["gemm256"] = dict(mfma_busy=sums["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * 1024.0), effective_clock_ghz=cyc / ns256["GRBM_GUI_ACTIVE"],
-                              launches=launches["GRBM_GUI_ACTIVE"], avg_launch_us_profiled=ns256["GRBM_GUI_ACTIVE"] / launches["GRBM_GUI_ACTIVE"] / 1e3)
+        b, g = acc.get((cls, "SQ_VALU_MFMA_BUSY_CYCLES")), acc.get((cls, "GRBM_GUI_ACTIVE"))
+        if not b or not g or not g[0]:
+            return None
+        cyc = g[0] / 8.0
+        return dict(mfma_busy=b[0] / (cyc * 1024.0), effective_clock_ghz=cyc / g[2], launches=g[1], avg_launch_us_profiled=g[2] / g[1] / 1e3)
+
+    res = dict(traffic_of("gemm_all"), pass_seconds=secs)
+    if busy_of("gemm256"):
+        res["gemm256"] = busy_of("gemm256")
+    if ("attn", "FETCH_SIZE") in acc:
+        res["attn"] = dict(traffic_of("attn"), **(busy_of("attn") or {}))
     return res
 
 
@@ -532,6 +539,9 @@ def _roofline_blocks(s, elapsed, pk16, pk32, attn_kernel, traffic_file=None, liv
                                          unit="TFLOP/s", frac=a2 / MFMA_BF16_PEAK_TFLOPS, peak_measured=pk32 or None, frac_of_measured=meas(a2, pk32),
                                          launches=at["launches"],
                                          avg_launch_us=1000.0 * at["ms"] / at["launches"], share_of_step_time=at["ms"] * 1e-3 / elapsed)
+        if live is not None and "attn" in live:           # the same three counter passes of this run, attention launches
+            la = live["attn"]
+            out["roofline_attention"].update(traffic=la["traffic"], pmc_attn=dict(measured_in_this_run=True, **{k: v for k, v in la.items() if k != "traffic"}))
     return out
 
 

@@ -788,6 +788,9 @@ def test_same_run_traffic_reads_its_own_counter_passes(tmp_path, monkeypatch):
     blocks = bench._roofline_blocks(dict(gemm=dict(flops=1e15, ms=1000.0, launches=4)), 1.0, 2000.0, 1900.0, "attn", None, r)
     assert blocks["roofline"]["traffic"] == r["traffic"] and blocks["roofline"]["traffic_source"]["measured_in_this_run"] is True
     assert blocks["roofline"]["pmc_gemm256"]["measured_in_this_run"] is True
+    assert r["attn"]["launches"] == 2 and r["attn"]["traffic"] == (2 * 1000.0 + 300.0) * 1024 and abs(r["attn"]["mfma_busy"] - 0.7) < 1e-12
+    both = bench._roofline_blocks(dict(gemm=dict(flops=1e15, ms=1000.0, launches=4), attn=dict(flops=1e14, ms=200.0, launches=2)), 1.0, 2000.0, 1900.0, "attn", None, r)
+    assert both["roofline_attention"]["traffic"] == r["attn"]["traffic"] and both["roofline_attention"]["pmc_attn"]["measured_in_this_run"] is True
     monkeypatch.setenv("FAKE_PMC_FAIL", "WRITE_SIZE")
     with pytest.raises(RuntimeError, match="WRITE_SIZE"):
         bench.same_run_traffic(limit_s=30)
