@@ -31,6 +31,7 @@ ALLOWED = {"torch": torch, "nn": nn, "F": F, "List": List}
 SHA256 = {
     "src/UniGenUtils.py": "b459854c104b4c01543accb6add1d4f8e398b060bd0d58e812728682ab67b224",
     "src/UniGenTransformer.py": "7c626da9c4201e36c06f020eb6d9a16cf89b0eff6fea154140306c277fc1bd4c",
+    "src/UniGenPipeline.py": "ce2a1bbe35d5e927af22f8a361d9dbd2de94fbf178f08d75ccd0cfb27a1a02ab",
 }
 BUILTINS = {n: getattr(builtins, n) for n in (
     "len", "range", "enumerate", "zip", "dict", "list", "tuple", "int", "float", "bool", "sum", "min", "max", "abs", "isinstance", "hasattr",

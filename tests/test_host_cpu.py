@@ -259,6 +259,51 @@ def test_pipeline_call_delegates_to_attached_encoders_and_vae(monkeypatch):
     assert out.images.shape == (1, 16, 64)
 
 
+def test_pipeline_call_prepares_the_control_image_as_the_reference_does(monkeypatch):
+    """src/UniGenPipeline.py:622-657 / :293-316: ONE control image serves every prompt of the batch (repeat to batch_size x num_images_per_prompt), the
+    latents take the PREPARED image's height / width (not the arguments'), and the SD3 pipeline doubles the image batch under classifier-free
+    guidance and widens a one-channel depth map to three channels before the VAE."""
+    from types import SimpleNamespace
+    from unigen_amd import pipeline as P
+    seen = {}
+
+    class VAE:
+        dtype = torch.bfloat16
+        config = SimpleNamespace(scaling_factor=0.5, shift_factor=0.25)
+
+        def encode(self, x):
+            seen["vae_in"] = tuple(x.shape)
+            z = x[:, :1].float().mean(dim=(2, 3), keepdim=True).expand(x.shape[0], 16, x.shape[2] // 8, x.shape[3] // 8)
+            return SimpleNamespace(latent_dist=SimpleNamespace(sample=lambda generator=None: z.to(torch.bfloat16)))
+
+    def fake_loop(tr, **kw):
+        seen["latents"], seen["control"] = tuple(kw["latents"].shape), kw.get("control_tokens", kw.get("control_latents"))
+        return kw["latents"]
+
+    monkeypatch.setattr(P, "denoise_loop", fake_loop)
+    monkeypatch.setattr(P, "sd3_denoise_loop", fake_loop)
+    mod = importlib.import_module("src.UniGenPipeline")
+    pipe = mod.UniGenFLUXPipeline.from_pretrained(None, transformer=_model())
+    pipe.vae = VAE()
+    img = torch.full((1, 3, 32, 48), 0.75)
+    emb = dict(prompt_embeds=torch.zeros(3, 8, 64), pooled_prompt_embeds=torch.zeros(3, 64), condition_pooled_prompt_embeds=torch.zeros(3, 64))
+    pipe(control_image=img, height=64, width=64, num_inference_steps=2, **emb)           # height / width arguments disagree with the tensor: the tensor wins
+    assert seen["vae_in"] == (3, 3, 32, 48) and seen["latents"] == (3, 2 * 3, 64) and tuple(seen["control"].shape) == (3, 6, 64)
+    assert torch.equal(seen["control"], torch.full((3, 6, 64), 0.25, dtype=torch.bfloat16))          # (0.75 - 0.25) * 0.5 for every repeated sample
+    # SD3: CFG doubles the prepared batch, the latents stay at one copy per sample; a one-channel map reaches the VAE with three channels
+    sd3 = mod.UniGenSD3Pipeline.from_pretrained(None, transformer=SimpleNamespace(device=torch.device("cpu"), dtype=torch.bfloat16, config=SimpleNamespace(in_channels=16)))
+    sd3.vae = VAE()
+    depth = torch.full((1, 1, 32, 32), 0.75)
+    e3 = dict(prompt_embeds=torch.zeros(2, 8, 64), pooled_prompt_embeds=torch.zeros(2, 64), negative_prompt_embeds=torch.zeros(2, 8, 64),
+              negative_pooled_prompt_embeds=torch.zeros(2, 64), condition_pooled_prompt_embeds=torch.zeros(2, 64))
+    sd3(control_image=depth, guidance_scale=7.0, num_inference_steps=2, **e3)
+    assert seen["vae_in"] == (4, 3, 32, 32) and seen["latents"] == (2, 16, 4, 4) and tuple(seen["control"].shape) == (4, 16, 4, 4)
+    sd3(control_image=depth, guidance_scale=1.0, num_inference_steps=2, **{k: v for k, v in e3.items() if not k.startswith("negative")})
+    assert seen["vae_in"] == (2, 3, 32, 32) and seen["latents"] == (2, 16, 4, 4)
+    sd3(control_image=torch.zeros(2, 16, 4, 4), guidance_scale=7.0, num_inference_steps=2, **e3)        # VAE latents pass through, one copy per sample
+    assert seen["latents"] == (2, 16, 4, 4) and tuple(seen["control"].shape) == (2, 16, 4, 4)
+
+
 def test_rope_cache_is_keyed_on_content_identity():
     """RoPE tables were cached by (data_ptr, shape, dtype) of the ids tensors; a freed 4 x 2 grid's ids and a fresh 2 x 4
     grid's (same N, same shape) can share an address. The cache entry now keeps the ids alive and tracks `_version`."""

@@ -215,3 +215,29 @@ def test_sd3_single_block_matches_the_reference_forward(bx, tag):
         ts = torch.where((sos[e] >= 0)[:, None], rows[sos[e].clamp_min(0)], torch.zeros((), dtype=dt))
         st = _block_state(bx, f"single.expert{e}", dt)
         assert _close(R.sd3_single_block(st, "b", 2, xs[e][None], ts[None]), bx[f"out.single.expert{e}.token.{tag}.x"], tag)
+
+
+# ---- the pipelines' control-image preparation (src/UniGenPipeline.py:107, :457) ---------------------------------------------------------------------
+def _pipeline_fixture():
+    from safetensors import safe_open
+    with safe_open(os.path.join(os.path.dirname(__file__), "golden", "ref_pipeline.safetensors"), "pt") as f:
+        return {k: f.get_tensor(k) for k in f.keys()}
+
+
+def test_prepare_image_of_both_pipelines_equals_the_reference_methods():
+    """`prepare_image` of the two pipeline twins against outputs of the reference's own methods (tests/golden/make_ref_pipeline_golden.py): one image
+    for the whole batch, one per prompt x num_images_per_prompt, packed latents, the CFG doubling, guess mode, the one-channel depth map."""
+    import importlib
+    mod = importlib.import_module("src.UniGenPipeline")
+    fx = _pipeline_fixture()
+    seen = 0
+    for kind, cls in (("flux", mod.UniGenFLUXPipeline), ("sd3", mod.UniGenSD3Pipeline)):
+        pipe = cls.from_pretrained(None, transformer=None)
+        for name in sorted({k.split(".")[1] for k in fx if k.startswith(kind + ".")}):
+            img, (bs, nipp, cfg, guess), want = fx[f"{kind}.{name}.image"], fx[f"{kind}.{name}.args"].tolist(), fx[f"{kind}.{name}.out"]
+            kw = dict(do_classifier_free_guidance=bool(cfg), guess_mode=bool(guess)) if kind == "sd3" else {}
+            got = pipe.prepare_image(image=img, width=img.shape[-1], height=img.shape[-2], batch_size=bs, num_images_per_prompt=nipp, device="cpu",
+                                     dtype=torch.bfloat16, **kw)
+            assert got.dtype == want.dtype and got.shape == want.shape and torch.equal(got, want), (kind, name)
+            seen += 1
+    assert seen == 9

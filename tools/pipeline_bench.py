@@ -32,8 +32,8 @@ def timed(f):
 
 
 t_all, img = timed(lambda: pipe(control_image=image, output_type="pt", **call).images)
-packed = pipe._encode_control(image, 1024, 1024, BF, None)
-t_enc, _ = timed(lambda: pipe._encode_control(image, 1024, 1024, BF, None))
+packed = pipe._encode_control(image, BF, None)
+t_enc, _ = timed(lambda: pipe._encode_control(image, BF, None))
 t_loop, lat = timed(lambda: pipe(control_image=packed, output_type="latent", **call).images)
 t_dec, _ = timed(lambda: pipe._decode(lat, 1024, 1024, "pt"))
 assert img.shape == (B, 3, 1024, 1024) and bool(torch.isfinite(img.float()).all())

@@ -196,18 +196,26 @@ class UniGenFLUXPipeline:
                                  num_images_per_prompt=num_images_per_prompt, max_sequence_length=max_sequence_length, lora_scale=None)
         return out[0], out[1]
 
-    def _encode_control(self, image: torch.Tensor, height, width, dtype, generator):
-        """prepare_image -> vae.encode -> (x - shift) * scale -> _pack_latents (:622-647). Packed latents [B, N, 4C] pass through."""
+    def prepare_image(self, image, width, height, batch_size, num_images_per_prompt, device, dtype, guess_mode=False):
+        """The reference's method of the same name (src/UniGenPipeline.py:457-483): a tensor passes through untouched, anything else goes through
+        `image_processor.preprocess`; ONE control image serves the whole batch (repeated `batch_size` times), otherwise every image is repeated
+        `num_images_per_prompt` times next to its prompt (repeat_interleave), then device / dtype."""
+        if not isinstance(image, torch.Tensor):
+            if self.image_processor is None:
+                raise NotImplementedError("control_image is not a tensor and no image processor is attached: set `pipe.image_processor` (.preprocess(image, height=, width=))")
+            image = self.image_processor.preprocess(image, height=height, width=width)
+        repeat_by = batch_size if image.shape[0] == 1 else num_images_per_prompt
+        return image.repeat_interleave(repeat_by, dim=0).to(device=device, dtype=dtype)
+
+    def _encode_control(self, image: torch.Tensor, dtype, generator):
+        """vae.encode -> (x - shift) * scale -> _pack_latents of a prepared control image (:634-647). Packed latents [B, N, 4C] pass through."""
         if image.ndim == 3:
             return image
         if image.ndim != 4:
             raise ValueError("control_image must be an image batch [B, 3, H, W] or packed condition latents [B, N, 4*C]")
         if self.vae is None:
             raise NotImplementedError("control_image given as pixels but no VAE is attached: set `pipe.vae` (AutoencoderKL surface) or pass packed latents")
-        if self.image_processor is not None:
-            image = self.image_processor.preprocess(image, height=height, width=width)
-        vdt = getattr(self.vae, "dtype", dtype)
-        image = image.to(device=self.transformer.device, dtype=vdt)
+        image = image.to(device=self.transformer.device, dtype=getattr(self.vae, "dtype", dtype))
         if hasattr(self.vae, "encode_scaled"):           # native VAE (unigen_amd/vae.py): sampling and the affine run in ug_vae_sample
             z = self.vae.encode_scaled(image, generator=generator)
         else:
@@ -269,9 +277,17 @@ class UniGenFLUXPipeline:
         height = height or self.default_sample_size * self.vae_scale_factor
         width = width or self.default_sample_size * self.vae_scale_factor
         hl, wl = height // (self.vae_scale_factor * 2), width // (self.vae_scale_factor * 2)
-        B = prompt_embeds.shape[0]
-        control = [self._encode_control(c, height, width, dtype, generator) for c in control_image] if multi else \
-            self._encode_control(control_image, height, width, dtype, generator)
+        B = prompt_embeds.shape[0]                       # batch_size * num_images_per_prompt: the encoders repeat per image
+        vdt = getattr(self.vae, "dtype", dtype) if self.vae is not None else dtype
+        control = []
+        for c in (control_image if multi else [control_image]):
+            c = self.prepare_image(image=c, width=width, height=height, batch_size=B, num_images_per_prompt=num_images_per_prompt, device=dev, dtype=vdt)
+            if c.ndim == 4:                              # the latents take the prepared control image's size (:631, :957), not the arguments'
+                height, width = c.shape[-2:]
+                hl, wl = height // (self.vae_scale_factor * 2), width // (self.vae_scale_factor * 2)
+            control.append(self._encode_control(c, dtype, generator))
+        if not multi:
+            control = control[0]
         if latents is None:
             latents = torch.randn(B, hl * wl, tr.config.in_channels, generator=generator, device=dev if generator is None or generator.device.type != "cpu" else "cpu",
                                   dtype=torch.float32).to(dev)
@@ -354,11 +370,27 @@ class UniGenSD3Pipeline:
             self.transformer.to(device=device, dtype=dtype)
         return self
 
+    def prepare_image(self, image, width, height, batch_size, num_images_per_prompt, device, dtype, do_classifier_free_guidance=False, guess_mode=False):
+        """The reference's method of the same name (src/UniGenPipeline.py:107-141): as UniGenFLUXPipeline.prepare_image, then the batch doubled for
+        classifier-free guidance (unless guess_mode) and a one-channel map (depth) repeated to three channels."""
+        if not isinstance(image, torch.Tensor):
+            if self.image_processor is None:
+                raise NotImplementedError("control_image is not a tensor and no image processor is attached: set `pipe.image_processor` (.preprocess(image, height=, width=))")
+            image = self.image_processor.preprocess(image, height=height, width=width)
+        repeat_by = batch_size if image.shape[0] == 1 else num_images_per_prompt
+        image = image.repeat_interleave(repeat_by, dim=0).to(device=device, dtype=dtype)
+        if do_classifier_free_guidance and not guess_mode:
+            image = torch.cat([image] * 2)
+        if image.shape[1] == 1:
+            image = image.repeat(1, 3, 1, 1)
+        return image
+
     @torch.no_grad()
     def __call__(self, prompt=None, condition_prompt=None, control_image=None, conditioning_scale: float = 1.0, height=None, width=None,
                  num_inference_steps: int = 28, guidance_scale: float = 7.0, generator=None, latents=None, prompt_embeds=None,
                  negative_prompt_embeds=None, pooled_prompt_embeds=None, negative_pooled_prompt_embeds=None,
-                 condition_pooled_prompt_embeds=None, output_type: str = "latent", return_dict: bool = True, gate_uniforms=None, **kwargs):
+                 condition_pooled_prompt_embeds=None, output_type: str = "latent", return_dict: bool = True, gate_uniforms=None,
+                 num_images_per_prompt: int = 1, control_use_vae_shift_factor: bool = True, **kwargs):
         tr = self.transformer
         dev = tr.device
         cast = lambda t: t.to(device=dev, dtype=tr.dtype)
@@ -369,15 +401,22 @@ class UniGenSD3Pipeline:
                                           "signature; CLIP/T5 are outside this package), or pass the embeds")
             if prompt is not None:
                 prompt_embeds, negative_prompt_embeds, pooled_prompt_embeds, negative_pooled_prompt_embeds = self.encode_prompt(
-                    prompt=prompt, prompt_2=None, prompt_3=None, do_classifier_free_guidance=cfg_on, device=dev)[:4]
+                    prompt=prompt, prompt_2=None, prompt_3=None, do_classifier_free_guidance=cfg_on, device=dev, num_images_per_prompt=num_images_per_prompt)[:4]
             if condition_prompt is not None:
                 condition_pooled_prompt_embeds = self.encode_prompt(prompt=condition_prompt, prompt_2=None, prompt_3=None, do_classifier_free_guidance=False,
-                                                                    device=dev)[2]
-        if control_image is not None and control_image.ndim == 4 and control_image.shape[1] != tr.config.in_channels:
+                                                                    device=dev, num_images_per_prompt=num_images_per_prompt)[2]
+        if control_image is None:
+            raise ValueError("control_image is required (pixels [B, 3 or 1, H, W] with a VAE attached, or VAE latents [B, C, H/8, W/8])")
+        is_latent = isinstance(control_image, torch.Tensor) and control_image.ndim == 4 and control_image.shape[1] == tr.config.in_channels
+        if not is_latent:
+            # :293-308: prepare_image (one image serves the batch; every image repeated per num_images_per_prompt; doubled under CFG), then the VAE
             if self.vae is None:
                 raise NotImplementedError("control_image given as pixels but no VAE is attached: set `pipe.vae` or pass VAE latents [B, C, H/8, W/8]")
-            z = self.vae.encode(control_image.to(device=dev, dtype=getattr(self.vae, "dtype", tr.dtype))).latent_dist.sample(generator=generator)
-            control_image = (z - self.vae.config.shift_factor) * self.vae.config.scaling_factor
+            nb = (prompt_embeds.shape[0] if prompt_embeds is not None else 1)            # batch_size * num_images_per_prompt (the encoder repeats per image)
+            control_image = self.prepare_image(image=control_image, width=width, height=height, batch_size=nb, num_images_per_prompt=num_images_per_prompt,
+                                               device=dev, dtype=getattr(self.vae, "dtype", tr.dtype), do_classifier_free_guidance=cfg_on, guess_mode=False)
+            z = self.vae.encode(control_image).latent_dist.sample(generator=generator)
+            control_image = (z - (self.vae.config.shift_factor if control_use_vae_shift_factor else 0.0)) * self.vae.config.scaling_factor
         if output_type != "latent" and self.vae is None:
             raise NotImplementedError("output_type other than 'latent' needs a VAE: set `pipe.vae` (AutoencoderKL surface)")
         if cfg_on:
@@ -386,11 +425,12 @@ class UniGenSD3Pipeline:
             prompt_embeds = torch.cat([cast(negative_prompt_embeds), cast(prompt_embeds)], 0)
             pooled_prompt_embeds = torch.cat([cast(negative_pooled_prompt_embeds), cast(pooled_prompt_embeds)], 0)
             condition_pooled_prompt_embeds = torch.cat([cast(condition_pooled_prompt_embeds)] * 2, 0)
-        B = control_image.shape[0]
         if control_image.ndim != 4 or control_image.shape[1] != tr.config.in_channels:
             raise ValueError("control_image must be VAE latents [B, C, H/8, W/8] (vae.encode happens upstream)")
+        # a prepared pixel batch arrives doubled under CFG (prepare_image); latents the caller passes directly hold one copy per sample
+        B = control_image.shape[0] // (2 if (cfg_on and not is_latent) else 1)
         if latents is None:
-            latents = torch.randn(control_image.shape, generator=generator, device=dev, dtype=torch.float32)
+            latents = torch.randn((B,) + tuple(control_image.shape[1:]), generator=generator, device=dev, dtype=torch.float32)
         out = sd3_denoise_loop(tr, latents=cast(latents).clone(), control_latents=cast(control_image), prompt_embeds=cast(prompt_embeds),
                                pooled_prompt_embeds=cast(pooled_prompt_embeds), condition_pooled_prompt_embeds=cast(condition_pooled_prompt_embeds),
                                num_inference_steps=num_inference_steps, guidance_scale=guidance_scale, conditioning_scale=conditioning_scale,
