@@ -143,7 +143,9 @@ int ug_flash_attn_fwd(const void* q, int64_t q_row_stride, int64_t q_batch_strid
  * (diffusers embeddings.get_timestep_embedding; called inside time_text_embed, UniGenTransformer.py:1222). */
 int ug_timestep_embed(const float* t, void* out, int64_t ldo, int64_t B, int32_t dim, ug_stream_t stream);
 
-/* x = bf16( float(x) + dt * float(v) )  FlowMatchEulerDiscreteScheduler.step (src/UniGenPipeline.py:768). */
+/* x = bf16( float(x) + bf16( bf16(dt) * v ) )  FlowMatchEulerDiscreteScheduler.step (called at src/UniGenPipeline.py:768 / :411) as torch evaluates
+ * `sample.float() + (sigma_next - sigma) * model_output`: the step is a 0-dim fp32 tensor, so the product is a bf16 op (both operands cast, result rounded)
+ * before the fp32 add. dt = the fp32 difference of the scheduler's fp32 sigmas. (dt = -0.25, FLUX-schnell's four steps: exact.) _f32 twin: no rounding. */
 int ug_euler_step(void* x, const void* v, float dt, int64_t n, ug_stream_t stream);
 
 /* out = uncond + gs * (text - uncond), each step rounded to bf16 as the reference's tensor ops do: classifier-free guidance of

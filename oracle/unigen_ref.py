@@ -759,7 +759,12 @@ def schnell_sigmas(num_steps: int, shift: float = 1.0) -> torch.Tensor:
 
 
 def euler_step(latents: torch.Tensor, model_output: torch.Tensor, sigma: float, sigma_next: float) -> torch.Tensor:
-    prev = latents.to(torch.float32) + (sigma_next - sigma) * model_output.to(torch.float32)
+    """FlowMatchEulerDiscreteScheduler.step (diffusers 0.32.2; called at src/UniGenPipeline.py:768 / :411), executed as torch executes it:
+    the scheduler's sigmas are an fp32 tensor on the model's device, `sigma_next - sigma` a 0-dim fp32 tensor, and `step * model_output` therefore
+    takes model_output's dtype (type promotion ignores 0-dim operands of the same category) with BOTH operands cast to it: in bf16 the step and the
+    product are rounded before the product meets the upcast sample. Written as the scheduler writes it; torch does the rest."""
+    sig = torch.tensor([sigma, sigma_next], dtype=torch.float32)
+    prev = latents.to(torch.float32) + (sig[1] - sig[0]) * model_output
     return prev.to(model_output.dtype)
 
 

@@ -281,6 +281,19 @@ def test_timestep_euler_add(gpu):
     ref = R.euler_step(x, v, 1.0, 0.75)
     m = report("euler_step", xd, ref)
     assert m["mismatch_frac"] == 0.0, m
+    # a step that is no power of two (SD3's shifted 28-step schedule): the scheduler's `step * model_output` is a bf16 op (0-dim fp32 times bf16: both operands
+    # cast to bf16, result rounded) before the fp32 add - a good part of the elements differ by one bf16 ulp from the unrounded form; bit-equal to the oracle
+    from unigen_amd.pipeline import _step32
+    s0, s1 = 0.9873806, 0.9741077
+    xd = x.to(gpu).clone()
+    ops.euler_step(xd, v.to(gpu), _step32(s0, s1))
+    ref = R.euler_step(x, v, s0, s1)
+    assert report("euler_step_rounded_product", xd, ref)["mismatch_frac"] == 0.0
+    unrounded = (x.float() + (s1 - s0) * v.float()).to(BF)
+    assert 0.0 < float((ref != unrounded).float().mean()) < 0.5
+    x32, v32 = x.float().to(gpu), v.float().to(gpu)                       # the fp32 twin: nothing to round
+    ops.euler_step(x32, v32, _step32(s0, s1))
+    assert torch.equal(x32.cpu(), R.euler_step(x.float(), v.float(), s0, s1))
     o = torch.empty(4, 64, 64, device=gpu, dtype=BF)
     ops.add(x.to(gpu), v.to(gpu), o)
     assert torch.equal(o.cpu(), x + v)

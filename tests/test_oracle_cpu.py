@@ -189,6 +189,11 @@ def test_schedule_and_euler():
     x, v = torch.randn(2, 4, 8).bfloat16(), torch.randn(2, 4, 8).bfloat16()
     y = R.euler_step(x, v, 1.0, 0.75)
     assert y.dtype == torch.bfloat16 and torch.equal(y, (x.float() - 0.25 * v.float()).bfloat16())
+    # diffusers' statement under torch's type promotion: the step is a 0-dim fp32 tensor, so `step * model_output` is a bf16 op (both operands cast, result rounded) before the fp32 add
+    sg = torch.tensor([0.9873806, 0.9741077], dtype=torch.float32)
+    y2 = R.euler_step(x, v, 0.9873806, 0.9741077)
+    assert torch.equal(y2, (x.float() + ((sg[1] - sg[0]).bfloat16().float() * v.float()).bfloat16().float()).bfloat16())          # step AND product rounded
+    assert torch.equal(R.euler_step(x.float(), v.float(), 0.9873806, 0.9741077), x.float() + (sg[1] - sg[0]) * v.float())
     # bf16 timestep quirk of the reference: 0.75 -> 752 (not 750) after `.to(bf16) * 1000`
     assert float((torch.tensor(0.75).bfloat16() * 1000)) == 752.0
 

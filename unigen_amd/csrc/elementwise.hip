@@ -355,14 +355,19 @@ __global__ void timestep_embed_kernel(const float* __restrict__ t, T* __restrict
     ElemT<T>::st(out + (int64_t)b * ldo + half + k, sinf(a));
 }
 
+// FlowMatchEulerDiscreteScheduler.step as torch evaluates it (diffusers 0.32.2): `sample.float() + (sigma_next - sigma) * model_output`, where the
+// step is a 0-dim fp32 tensor (an element difference of the scheduler's fp32 sigmas, on the model's device) and model_output a bf16 tensor - torch's type
+// promotion gives the PRODUCT the dimensioned operand's dtype and casts BOTH operands to it: the step is rounded to bf16, the product is rounded to bf16, then
+// the fp32 add, then the cast back. (With FLUX-schnell's four steps dt = -0.25 and everything is exact; SD3's 28 shifted steps round.)
 template <typename T>
 __global__ void euler_step_kernel(T* __restrict__ x, const T* __restrict__ v, float dt, int64_t nchunk) {
     for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < nchunk; c += (int64_t)gridDim.x * blockDim.x) {
         float a[8], b[8];
+        const float dtr = ElemT<T>::rnd(dt);
         ElemT<T>::load8(x + c * 8, a);
         ElemT<T>::load8(v + c * 8, b);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) a[e] = a[e] + dt * b[e];
+        for (int e = 0; e < 8; ++e) a[e] = a[e] + ElemT<T>::rnd(dtr * b[e]);
         ElemT<T>::store8(x + c * 8, a);
     }
 }

@@ -58,6 +58,12 @@ def sd3_default_sigmas(num_inference_steps: int, shift: float = 3.0, num_train_t
     return [s_max + i * (s_min - s_max) / max(n - 1, 1) for i in range(n)]
 
 
+def _step32(sigma: float, sigma_next: float) -> float:
+    """`sigma_next - sigma` as the scheduler computes it: both are elements of an fp32 tensor, the difference an fp32 subtraction."""
+    s = torch.tensor([sigma, sigma_next], dtype=torch.float32)
+    return float(s[1] - s[0])
+
+
 def prepare_latent_image_ids(height: int, width: int, device, dtype) -> torch.Tensor:
     """FluxPipeline._prepare_latent_image_ids: [h*w, 3], [:,1] = row, [:,2] = col."""
     ids = torch.zeros(height, width, 3)
@@ -125,7 +131,7 @@ def denoise_loop(transformer, *, latents: torch.Tensor, control_tokens, prompt_e
                               timestep=timestep / 1000, txt_ids=negative_text_ids, img_ids=latent_image_ids, guidance=guidance,
                               condition_ids=condition_ids, gate_uniform=nuni)[0]
             noise_pred = ops.cfg_combine(neg.contiguous(), noise_pred.contiguous(), float(true_cfg_scale), torch.empty_like(neg, memory_format=torch.contiguous_format))
-        ops.euler_step(latents, noise_pred, sig[i + 1] - sig[i])
+        ops.euler_step(latents, noise_pred, _step32(sig[i], sig[i + 1]))
         if callback_on_step_end is not None:
             t = torch.tensor(sig[i] * 1000.0, dtype=torch.float32, device=latents.device)
             have = dict(latents=latents, prompt_embeds=prompt_embeds, noise_pred=noise_pred, timestep=timestep)
@@ -342,7 +348,7 @@ def sd3_denoise_loop(transformer, *, latents: torch.Tensor, control_latents: tor
             ops.cfg_combine(out[:B].contiguous(), out[B:].contiguous(), guidance_scale, pred)
         else:
             pred = out
-        ops.euler_step(latents, pred, sig[i + 1] - sig[i])
+        ops.euler_step(latents, pred, _step32(sig[i], sig[i + 1]))
     return latents
 
 
