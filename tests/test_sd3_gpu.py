@@ -73,6 +73,54 @@ def test_sd3_pipeline_cfg_loop(gpu):
     assert m["rel_l2"] <= 3e-2, m
 
 
+def test_sd3_pipeline_guidance_window_sigmas_and_callback(gpu):
+    """src/UniGenPipeline.py:364-427: `conditioning_scale * controlnet_keep[i]` per step (control_guidance_start / _end), caller-given sigmas, and
+    `callback_on_step_end` replacing the latents - the same loop on the oracle, step by step."""
+    from unigen_amd.pipeline import control_keep, flow_match_sigmas
+    cls = importlib.import_module("src.UniGenTransformer").UniGenSD3
+    model = cls.from_config(dict(TINY), device=gpu, dtype=BF)
+    model.init_condition_block(condition_nums=1, condition_types=["depth"], control_params=dict(use_shared_expert=True, use_modulate=True))
+    model.init_synthetic_(seed=8, std=0.05, bias_std=0.02)
+    with torch.no_grad():                                                      # zero-initialised in the reference: give the control path a voice
+        for n_, p_ in model.named_parameters():
+            if "controlnet_add" in n_:
+                p_.normal_(0.0, 0.05, generator=torch.Generator(device=gpu).manual_seed(3))
+    state = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    rcfg = R.SD3Config(use_modulate=True, **TINY)
+    inp = R.make_sd3_inputs(rcfg, B=1, hw=16, T=24)
+    uni = torch.rand(64, rcfg.expert_nums, generator=torch.Generator().manual_seed(2))
+    pipe = importlib.import_module("src.UniGenPipeline").UniGenSD3Pipeline.from_pretrained(None, transformer=model)
+    my_sigmas, scale = [1.0, 0.7, 0.35], [0.8]
+    assert control_keep(3, 0.0, 0.5) == [1.0, 0.0, 0.0] and control_keep(4, [0.25], [1.0]) == [0.0, 1.0, 1.0, 1.0]
+    seen = []
+
+    def cb(p_, i, t, kw):
+        seen.append((i, float(t), sorted(kw)))
+        return {"latents": kw["latents"] * 0.5} if i == 0 else {}
+
+    res = pipe(control_image=inp["condition_hidden_states"], latents=inp["hidden_states"], prompt_embeds=inp["encoder_hidden_states"],
+               pooled_prompt_embeds=inp["pooled_projections"], condition_pooled_prompt_embeds=inp["condition_pooled_projections"],
+               num_inference_steps=3, sigmas=my_sigmas, guidance_scale=1.0, conditioning_scale=scale, control_guidance_start=0.0, control_guidance_end=0.5,
+               gate_uniforms=[uni.to(gpu)] * 3, callback_on_step_end=cb, callback_on_step_end_tensor_inputs=["latents", "noise_pred"]).images
+    sig = flow_match_sigmas(3, sigmas=my_sigmas, shift=3.0)
+    keep = control_keep(3, 0.0, 0.5)
+    lat, lat_nowindow = inp["hidden_states"].clone(), None
+    for i in range(3):
+        fw = lambda cs: R.unigen_sd3_forward(state, rcfg, hidden_states=lat, condition_hidden_states=inp["condition_hidden_states"],
+                                             encoder_hidden_states=inp["encoder_hidden_states"], pooled_projections=inp["pooled_projections"],
+                                             condition_pooled_projections=inp["condition_pooled_projections"], timestep=torch.full((1,), sig[i] * 1000.0),
+                                             gate_uniform=uni, conditioning_scale=cs, dtype=BF)[0]
+        pred = fw(scale[0] * keep[i])
+        if i == 1:
+            assert rel_l2(fw(scale[0]), pred) > 1e-3          # the window matters in this setup: step 1 with the control path on differs
+        lat = R.euler_step(lat, pred, sig[i], sig[i + 1])
+        if i == 0:
+            lat = lat * 0.5
+    assert [c[0] for c in seen] == [0, 1, 2] and abs(seen[1][1] - sig[1] * 1000.0) < 1e-3 and seen[0][2] == ["latents", "noise_pred"]
+    m = report("sd3_pipeline_window_callback_3steps", res, lat)
+    assert m["rel_l2"] <= 3e-2, m
+
+
 def test_sd3_full_depth_fp32(gpu):
     """SD3.5-medium DEPTH (24 joint blocks, dual attention in 0-12, the last block context_pre_only; 24 control blocks) at toy width through
     the fp32 verification twins against the fp32 oracle."""

@@ -322,17 +322,39 @@ class UniGenFLUXPipeline:
 
 
 @torch.no_grad()
+def sd3_default_sigmas_unshifted(num_inference_steps: int, num_train_timesteps: int = 1000) -> List[float]:
+    """The same default when the scheduler uses dynamic shifting: its __init__ then leaves the training sigmas unshifted (sigma_min = 1 / T)."""
+    n = num_inference_steps
+    return [1.0 + i * (1.0 / num_train_timesteps - 1.0) / max(n - 1, 1) for i in range(n)]
+
+
+def control_keep(num_steps: int, start=0.0, end=1.0) -> List[float]:
+    """`controlnet_keep` of the reference's SD3 pipeline (src/UniGenPipeline.py:364-370): step i keeps the control branch (1.0) unless
+    i / n < control_guidance_start or (i + 1) / n > control_guidance_end (0.0); lists are taken at their first entry, as the reference does."""
+    s = start[0] if isinstance(start, (list, tuple)) else start
+    e = end[0] if isinstance(end, (list, tuple)) else end
+    return [1.0 - float(i / num_steps < s or (i + 1) / num_steps > e) for i in range(num_steps)]
+
+
 def sd3_denoise_loop(transformer, *, latents: torch.Tensor, control_latents: torch.Tensor, prompt_embeds: torch.Tensor,
                      pooled_prompt_embeds: torch.Tensor, condition_pooled_prompt_embeds: torch.Tensor, num_inference_steps: int = 28,
-                     guidance_scale: float = 7.0, conditioning_scale: float = 1.0, shift: float = 3.0, sigmas: Optional[Sequence[float]] = None,
-                     gate_uniforms=None) -> torch.Tensor:
-    """UniGenSD3Pipeline.__call__ loop (src/UniGenPipeline.py:375-433). With guidance_scale > 1 the caller passes prompt / pooled / condition
+                     guidance_scale: float = 7.0, conditioning_scale=1.0, shift: float = 3.0, sigmas: Optional[Sequence[float]] = None,
+                     gate_uniforms=None, use_dynamic_shifting: bool = False, mu: Optional[float] = None, control_guidance_start=0.0,
+                     control_guidance_end=1.0, callback_on_step_end=None, callback_on_step_end_tensor_inputs: Sequence[str] = ("latents",),
+                     pipeline=None, condition_types=None) -> torch.Tensor:
+    """UniGenSD3Pipeline.__call__ loop (src/UniGenPipeline.py:372-433). With guidance_scale > 1 the caller passes prompt / pooled / condition
     embeds already doubled as [negative | positive] (reference :286-290); latents [B, C, H, W] are duplicated per step, the two halves of
-    the prediction are combined with classifier-free guidance, then the flow-match Euler step. The timestep is passed unscaled."""
+    the prediction are combined with classifier-free guidance, then the flow-match Euler step. The timestep is passed unscaled. Per step
+    `conditioning_scale * controlnet_keep[i]` (:383-389; a list-valued scale is taken at its first entry); `callback_on_step_end(pipeline, i, t,
+    {name: tensor})` may replace `latents` and `prompt_embeds` (:416-427; the negative embeds it may also return are not read again by the loop)."""
     cfg_on = guidance_scale > 1.0
     if sigmas is None:
-        sigmas = sd3_default_sigmas(num_inference_steps, shift)
-    sig = flow_match_sigmas(num_inference_steps, sigmas=sigmas, shift=shift)
+        sigmas = sd3_default_sigmas_unshifted(num_inference_steps) if use_dynamic_shifting else sd3_default_sigmas(num_inference_steps, shift)
+    else:
+        num_inference_steps = len(sigmas)
+    sig = flow_match_sigmas(num_inference_steps, sigmas=sigmas, shift=shift, use_dynamic_shifting=use_dynamic_shifting, mu=mu)
+    keep = control_keep(num_inference_steps, control_guidance_start, control_guidance_end)
+    scale = conditioning_scale[0] if isinstance(conditioning_scale, (list, tuple)) else conditioning_scale
     B = latents.shape[0]
     latents = latents.contiguous()
     ctrl = torch.cat([control_latents] * 2) if cfg_on and control_latents.shape[0] == B else control_latents
@@ -341,14 +363,21 @@ def sd3_denoise_loop(transformer, *, latents: torch.Tensor, control_latents: tor
         x_in = torch.cat([latents] * 2) if cfg_on else latents
         t = torch.full((x_in.shape[0],), sig[i] * 1000.0, device=latents.device, dtype=torch.float32)
         uni = None if gate_uniforms is None else gate_uniforms[i]
-        out = transformer(hidden_states=x_in, condition_hidden_states=ctrl, conditioning_scale=conditioning_scale, timestep=t,
+        out = transformer(hidden_states=x_in, condition_hidden_states=ctrl, conditioning_scale=scale * keep[i], timestep=t,
                           encoder_hidden_states=prompt_embeds, pooled_projections=pooled_prompt_embeds,
-                          condition_pooled_projections=condition_pooled_prompt_embeds, gate_uniform=uni)[0]
+                          condition_pooled_projections=condition_pooled_prompt_embeds, gate_uniform=uni, condition_types=condition_types)[0]
         if cfg_on:
             ops.cfg_combine(out[:B].contiguous(), out[B:].contiguous(), guidance_scale, pred)
         else:
             pred = out
         ops.euler_step(latents, pred, _step32(sig[i], sig[i + 1]))
+        if callback_on_step_end is not None:
+            have = dict(latents=latents, prompt_embeds=prompt_embeds, noise_pred=pred, timestep=t)
+            outs = callback_on_step_end(pipeline, i, t[0], {k: have[k] for k in callback_on_step_end_tensor_inputs})
+            new_latents = outs.pop("latents", latents)
+            if new_latents is not latents:
+                latents = new_latents.to(latents.dtype).contiguous()
+            prompt_embeds = outs.pop("prompt_embeds", prompt_embeds)
     return latents
 
 
@@ -360,7 +389,7 @@ class UniGenSD3Pipeline:
         self.transformer = transformer
         self.vae_scale_factor = vae_scale_factor
         self.default_sample_size = 128
-        sc = dict(shift=3.0)
+        sc = dict(shift=3.0, use_dynamic_shifting=False, base_image_seq_len=256, max_image_seq_len=4096, base_shift=0.5, max_shift=1.15)
         sc.update(scheduler_config or {})
         self.scheduler = SimpleNamespace(config=sc)
         # delegated stages, as in UniGenFLUXPipeline: encode_prompt(prompt=, ..., do_classifier_free_guidance=) -> (embeds, negative embeds,
@@ -396,7 +425,9 @@ class UniGenSD3Pipeline:
                  num_inference_steps: int = 28, guidance_scale: float = 7.0, generator=None, latents=None, prompt_embeds=None,
                  negative_prompt_embeds=None, pooled_prompt_embeds=None, negative_pooled_prompt_embeds=None,
                  condition_pooled_prompt_embeds=None, output_type: str = "latent", return_dict: bool = True, gate_uniforms=None,
-                 num_images_per_prompt: int = 1, control_use_vae_shift_factor: bool = True, **kwargs):
+                 num_images_per_prompt: int = 1, control_use_vae_shift_factor: bool = True, sigmas=None, mu: Optional[float] = None,
+                 control_guidance_start=0.0, control_guidance_end=1.0, callback_on_step_end=None,
+                 callback_on_step_end_tensor_inputs: Sequence[str] = ("latents",), **kwargs):
         tr = self.transformer
         dev = tr.device
         cast = lambda t: t.to(device=dev, dtype=tr.dtype)
@@ -437,10 +468,19 @@ class UniGenSD3Pipeline:
         B = control_image.shape[0] // (2 if (cfg_on and not is_latent) else 1)
         if latents is None:
             latents = torch.randn((B,) + tuple(control_image.shape[1:]), generator=generator, device=dev, dtype=torch.float32)
+        # :323-339: with a dynamically shifting scheduler, mu from the latent grid's token count and the scheduler's own shift parameters
+        sc = self.scheduler.config
+        dyn = bool(sc.get("use_dynamic_shifting"))
+        if dyn and mu is None:
+            ps = tr.config.patch_size
+            mu = calculate_shift((latents.shape[2] // ps) * (latents.shape[3] // ps), sc["base_image_seq_len"], sc["max_image_seq_len"], sc["base_shift"], sc["max_shift"])
         out = sd3_denoise_loop(tr, latents=cast(latents).clone(), control_latents=cast(control_image), prompt_embeds=cast(prompt_embeds),
                                pooled_prompt_embeds=cast(pooled_prompt_embeds), condition_pooled_prompt_embeds=cast(condition_pooled_prompt_embeds),
                                num_inference_steps=num_inference_steps, guidance_scale=guidance_scale, conditioning_scale=conditioning_scale,
-                               shift=self.scheduler.config["shift"], gate_uniforms=gate_uniforms)
+                               shift=self.scheduler.config["shift"], gate_uniforms=gate_uniforms, sigmas=sigmas,
+                               use_dynamic_shifting=dyn, mu=mu, control_guidance_start=control_guidance_start, control_guidance_end=control_guidance_end,
+                               callback_on_step_end=callback_on_step_end, callback_on_step_end_tensor_inputs=callback_on_step_end_tensor_inputs,
+                               pipeline=self, condition_types=condition_prompt)
         if output_type != "latent":
             z = (out / self.vae.config.scaling_factor) + self.vae.config.shift_factor
             out = self.vae.decode(z.to(getattr(self.vae, "dtype", z.dtype)), return_dict=False)[0]
