@@ -184,6 +184,11 @@ def test_pipeline_schedule_and_pack_roundtrip():
     assert abs(mu - 1.15) < 1e-9
     s = P.flow_match_sigmas(4, use_dynamic_shifting=True, mu=mu)
     assert s[0] == 1.0 and 0.25 < s[3] < 1.0
+    # the pipeline hands the scheduler's own base / max lengths and shifts to the loop (src/UniGenPipeline.py:663-670); a config that names none gets diffusers' defaults
+    pp = importlib.import_module("src.UniGenPipeline").UniGenFLUXPipeline(scheduler_config=dict(use_dynamic_shifting=True, base_shift=0.4, max_shift=1.0))
+    sc = pp.scheduler.config
+    assert (sc["base_image_seq_len"], sc["max_image_seq_len"], sc["base_shift"], sc["max_shift"]) == (256, 4096, 0.4, 1.0)
+    assert abs(P.calculate_shift(4096, sc["base_image_seq_len"], sc["max_image_seq_len"], sc["base_shift"], sc["max_shift"]) - 1.0) < 1e-9
     x = torch.randn(2, 16, 8, 12)
     p = P.pack_latents(x)
     assert p.shape == (2, 24, 64) and torch.equal(P.unpack_latents(p, 64, 96, 8), x)

@@ -99,14 +99,17 @@ def denoise_loop(transformer, *, latents: torch.Tensor, control_tokens, prompt_e
                  true_cfg_scale: float = 1.0, negative_prompt_embeds: Optional[torch.Tensor] = None,
                  negative_pooled_prompt_embeds: Optional[torch.Tensor] = None, negative_text_ids: Optional[torch.Tensor] = None,
                  negative_gate_uniforms=None, callback_on_step_end=None, callback_on_step_end_tensor_inputs: Sequence[str] = ("latents",),
-                 pipeline=None) -> torch.Tensor:
+                 pipeline=None, shift_params: Optional[dict] = None) -> torch.Tensor:
     """The hot loop (src/UniGenPipeline.py:721-789): per step `timestep = t.expand(B).to(latents.dtype)`, transformer(timestep / 1000)[0],
     latents = latents + (sigma_next - sigma) * noise_pred evaluated in fp32 and cast back. Updates and returns `latents` in place.
     True classifier-free guidance (`:748-763`: `true_cfg_scale > 1` with negative embeds): a second forward on the negative prompt - called, as
     the reference does, WITHOUT `conditioning_scale` (the forward's default) - and `neg + true_cfg_scale * (pred - neg)` in the latents' dtype
     (ug_cfg_combine: the three bf16 tensor ops' roundings). `callback_on_step_end(pipeline, i, t, {name: tensor})` (`:774-781`) may return
     replacements for `latents` and `prompt_embeds`."""
-    mu = calculate_shift(latents.shape[1]) if use_dynamic_shifting else None
+    # :663-670: mu from the token count and the SCHEDULER's base / max sequence lengths and shifts (the diffusers defaults when it names none)
+    sp = shift_params or {}
+    mu = calculate_shift(latents.shape[1], sp.get("base_image_seq_len", 256), sp.get("max_image_seq_len", 4096), sp.get("base_shift", 0.5),
+                         sp.get("max_shift", 1.15)) if use_dynamic_shifting else None
     sig = flow_match_sigmas(num_inference_steps, sigmas=sigmas, shift=shift, use_dynamic_shifting=use_dynamic_shifting, mu=mu)
     B = latents.shape[0]
     guidance = None
@@ -152,7 +155,7 @@ class UniGenFLUXPipeline:
         self.transformer = transformer
         self.vae_scale_factor = vae_scale_factor
         self.default_sample_size = 128
-        sc = dict(shift=1.0, use_dynamic_shifting=False)
+        sc = dict(shift=1.0, use_dynamic_shifting=False, base_image_seq_len=256, max_image_seq_len=4096, base_shift=0.5, max_shift=1.15)
         sc.update(scheduler_config or {})
         self.scheduler = SimpleNamespace(config=sc)
         self._device, self._dtype = None, BF
@@ -172,7 +175,7 @@ class UniGenFLUXPipeline:
             if os.path.exists(p):
                 with open(p) as f:
                     raw = json.load(f)
-                sc = {k: raw[k] for k in ("shift", "use_dynamic_shifting") if k in raw}
+                sc = {k: raw[k] for k in ("shift", "use_dynamic_shifting", "base_image_seq_len", "max_image_seq_len", "base_shift", "max_shift") if k in raw}
             if vae is None and os.path.exists(os.path.join(root, "vae", "config.json")):
                 from .vae import AutoencoderKL
                 vae = AutoencoderKL.from_pretrained(os.path.join(root, "vae"))
@@ -313,7 +316,7 @@ class UniGenFLUXPipeline:
                            negative_prompt_embeds=cast(negative_prompt_embeds) if do_true_cfg else None,
                            negative_pooled_prompt_embeds=cast(negative_pooled_prompt_embeds) if do_true_cfg else None,
                            negative_gate_uniforms=negative_gate_uniforms, callback_on_step_end=callback_on_step_end,
-                           callback_on_step_end_tensor_inputs=callback_on_step_end_tensor_inputs, pipeline=self)
+                           callback_on_step_end_tensor_inputs=callback_on_step_end_tensor_inputs, pipeline=self, shift_params=self.scheduler.config)
         if output_type != "latent":
             out = self._decode(out, height, width, output_type)
         if not return_dict:
