@@ -155,6 +155,14 @@ class HipModule(nn.Module):
         """train.py:317: transformer blocks are recomputed in the backward (torch.utils.checkpoint around each block of unigen_amd/training.py)."""
         self._grad_checkpoint = True
 
+    def disable_gradient_checkpointing(self):
+        self._grad_checkpoint = False
+
+    def enable_xformers_memory_efficient_attention(self, *args, **kwargs):
+        """train.py:337 (behind `--enable_xformers_memory_efficient_attention`): nothing to switch - attention here is always the fused flash kernel
+        (ug_flash_attn_fwd / _bwd); kept so that the flag does not turn into an AttributeError."""
+        return None
+
     def init_synthetic_(self, seed: int = 0, std: float = 0.02, bias_std: float = 0.0) -> "HipModule":
         """Seeded N(0, std^2) weights, zero (or N(0, bias_std^2)) biases, unit RMSNorm weights; the zero-res projections are
         randomised too so the control path contributes. Generated on the parameters' device."""
