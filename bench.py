@@ -427,12 +427,13 @@ def _under_profiler():
     return any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
 
 
-def same_run_traffic(limit_s=150.0):
+def same_run_traffic(limit_s=60.0):
     """`roofline.traffic` measured by THIS run on THIS box: one child per counter pass - `rocprofv3 --kernel-trace --pmc <counter> -- python3 bench.py
     --pmc-child` (the cfg2 B = 4 workload, one 4-forward step, no timers / probes / CPU legs; the program goes straight after `--`) - after every timed
     region of the parent is over. Bytes beyond the XCD L2 per GEMM launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 / launches over all gemm256 / gemm128
     launches (KiB units; gfx950's FETCH_SIZE counts wide coalesced reads at half their bytes; Infinity-Cache hits are included: an upper bound on HBM
-    bytes). A pass that fails or overruns `limit_s` raises; the caller then falls back to the recorded profile and says so."""
+    bytes). A pass takes 5-7 s; one that fails or overruns `limit_s` raises (the remaining passes are not started) and the caller falls back to the
+    recorded profile and says so - the worst case adds `limit_s` to the run, never more."""
     import csv, shutil, signal, subprocess, tempfile
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
