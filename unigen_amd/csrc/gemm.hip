@@ -445,6 +445,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
         // loop's time): the fragment reads cost their ~14 % wherever they are issued - operand delivery, not segment placement.)
         // (Measured and dropped: signalling the hand-off barrier 2-4 MFMAs before the end of a segment, so that the other group is
         // released while this one still has MFMAs queued: -9 % - the two groups' MFMAs then share the pipe, matrix beside matrix.)
+        // (Measured and dropped, round 5, timing-only build: HALF the barriers - waves 0-3 keep the one between a phase's load and matrix segments, waves 4-7
+        // the one behind the matrix segment, so that a group runs matrix -> load without a hand-off and the groups' matrix segments may overlap; alone,
+        // with the matrix segment at s_setprio 1, and entering at 1 / raising to 3 behind the first MFMA: 0.1-1.6 %, 1.1-4.1 %, 1.1-2.6 % SLOWER than the
+        // eight strict hand-offs (profiles/r05_gemm_loop_ab.log step 10). The alternation itself is worth more than the ~90 cycles a hand-off costs.)
         // (Measured and dropped: 2 segments of 32 MFMAs per K-tile and wave group with all DMA issued by waves 4-7 - 4 barriers per
         // K-tile instead of 8 - ran 5-8 % slower on the full chip and equal on 16 CUs: the hand-offs are not where the loop loses time,
         // and the coarser slot lifetimes cut the DMA lead from ~1.3 to 1.0 K-tiles.)
