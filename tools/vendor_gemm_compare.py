@@ -15,6 +15,10 @@ rn = lambda *s, sc=1.0: (torch.randn(*s, generator=g, device=dev) * sc).to(BF)
 B, NI, T, D = 4, 4096, 512, 3072
 SHAPES = [("attn out", B * NI, D, D), ("qkv image", B * NI, 3 * D, D), ("ff up", B * NI, 4 * D, D), ("ff down K=12288", B * NI, D, 4 * D),
           ("single out K=15360", B * (NI + T), D, 5 * D), ("single qkv+mlp", B * (NI + T), 7 * D, D), ("8192^3", 8192, 8192, 8192)]
+if os.environ.get("UG_AB_SHAPES") == "sd3":       # cfg5 (UniGenSD3, D = 1536, 16 samples under CFG): K = 1536 is 24 K-tiles per tile
+    M5, D5 = 16 * 4096, 1536
+    SHAPES = [("sd3 attn out", M5, D5, D5), ("sd3 qkv", M5, 3 * D5, D5), ("sd3 ff up", M5, 4 * D5, D5), ("sd3 ff down K=6144", M5, D5, 4 * D5),
+              ("sd3 context rows out", 16 * 333, D5, D5), ("sd3 context qkv", 16 * 333, 3 * D5, D5)]
 for label, M, N, K in SHAPES:
     a, w, b = rn(M, K), rn(N, K, sc=0.03), rn(N, sc=0.1)
     out = torch.empty(M, N, device=dev, dtype=BF)
