@@ -64,6 +64,11 @@ def _step32(sigma: float, sigma_next: float) -> float:
     return float(s[1] - s[0])
 
 
+def _t32(sigma: float) -> float:
+    """A timestep as the scheduler holds it: `sigmas * num_train_timesteps` on the fp32 sigma tensor (one fp32 product)."""
+    return float(torch.tensor(sigma, dtype=torch.float32) * 1000.0)
+
+
 def prepare_latent_image_ids(height: int, width: int, device, dtype) -> torch.Tensor:
     """FluxPipeline._prepare_latent_image_ids: [h*w, 3], [:,1] = row, [:,2] = col."""
     ids = torch.zeros(height, width, 3)
@@ -121,7 +126,7 @@ def denoise_loop(transformer, *, latents: torch.Tensor, control_tokens, prompt_e
         negative_text_ids = torch.zeros(negative_prompt_embeds.shape[1], 3, device=latents.device, dtype=text_ids.dtype)
     for i in range(num_inference_steps):
         # `t.expand(B).to(latents.dtype)`: built on the device (a fill kernel, no host copy -> the loop is HIP-graph capturable)
-        timestep = torch.full((B,), sig[i] * 1000.0, dtype=torch.float32, device=latents.device).to(latents.dtype)
+        timestep = torch.full((B,), _t32(sig[i]), dtype=torch.float32, device=latents.device).to(latents.dtype)
         uni = None if gate_uniforms is None else gate_uniforms[i]
         noise_pred = transformer(hidden_states=latents, condition_hidden_states=control_tokens, conditioning_scale=conditioning_scale,
                                  encoder_hidden_states=prompt_embeds, pooled_projections=pooled_prompt_embeds,
@@ -136,7 +141,7 @@ def denoise_loop(transformer, *, latents: torch.Tensor, control_tokens, prompt_e
             noise_pred = ops.cfg_combine(neg.contiguous(), noise_pred.contiguous(), float(true_cfg_scale), torch.empty_like(neg, memory_format=torch.contiguous_format))
         ops.euler_step(latents, noise_pred, _step32(sig[i], sig[i + 1]))
         if callback_on_step_end is not None:
-            t = torch.tensor(sig[i] * 1000.0, dtype=torch.float32, device=latents.device)
+            t = torch.tensor(_t32(sig[i]), dtype=torch.float32, device=latents.device)
             have = dict(latents=latents, prompt_embeds=prompt_embeds, noise_pred=noise_pred, timestep=timestep)
             outs = callback_on_step_end(pipeline, i, t, {k: have[k] for k in callback_on_step_end_tensor_inputs})
             new_latents = outs.pop("latents", latents)
@@ -364,7 +369,7 @@ def sd3_denoise_loop(transformer, *, latents: torch.Tensor, control_latents: tor
     pred = torch.empty_like(latents)
     for i in range(num_inference_steps):
         x_in = torch.cat([latents] * 2) if cfg_on else latents
-        t = torch.full((x_in.shape[0],), sig[i] * 1000.0, device=latents.device, dtype=torch.float32)
+        t = torch.full((x_in.shape[0],), _t32(sig[i]), device=latents.device, dtype=torch.float32)
         uni = None if gate_uniforms is None else gate_uniforms[i]
         out = transformer(hidden_states=x_in, condition_hidden_states=ctrl, conditioning_scale=scale * keep[i], timestep=t,
                           encoder_hidden_states=prompt_embeds, pooled_projections=pooled_prompt_embeds,
