@@ -82,6 +82,7 @@ def _host_info(max_threads: int):
     except AttributeError:
         avail = os.cpu_count() or 1
     cores = max(1, min(avail, max_threads))
+    _host_info.available = dict(affinity=avail, cpu_count=os.cpu_count() or avail)      # what the host offers, beside what was used (`cores`)
     cpu_model, mem_gb = "", 0.0
     try:
         with open("/proc/cpuinfo") as f:
@@ -97,6 +98,16 @@ def _host_info(max_threads: int):
     except OSError:
         pass
     return cores, cpu_model, mem_gb
+
+
+def _cores_note(d: dict) -> dict:
+    """`cores` = the torch threads the oracle was given (min(affinity, 16): a GPU box grants one GPU's share of the host); `cores_available` = the
+    affinity mask of this process and `os.cpu_count()` of the host, so the choice is visible beside the number."""
+    av = getattr(_host_info, "available", None)
+    if av:
+        d["cores_available"] = av["affinity"]
+        d["host_cpu_count"] = av["cpu_count"]
+    return d
 
 
 def cpu_baseline_other(model, config: str, max_threads: int = 16):
@@ -124,10 +135,10 @@ def cpu_baseline_other(model, config: str, max_threads: int = 16):
         out = run()
     dt = time.perf_counter() - t0
     assert torch.isfinite(out.float()).all()
-    return dict(value=1.0 / (per_image * dt), unit="images/s", cores=cores, kind="port", cpu=cpu_model, mode="full",
+    return _cores_note(dict(value=1.0 / (per_image * dt), unit="images/s", cores=cores, kind="port", cpu=cpu_model, mode="full",
                 sample=f"oracle (bf16 torch CPU restatement of the reference) timed on ONE full-depth forward of {what}, the GPU run's own random-init "
                        f"weights: {dt:.1f} s on {cores} threads; an image = {per_image} such forwards -> images/s = 1 / ({per_image} x {dt:.1f} s)",
-                sample_seconds=dt)
+                sample_seconds=dt))
 
 
 def cpu_baseline(model, mode: str = "auto", max_threads: int = 16):
@@ -170,10 +181,10 @@ def cpu_baseline(model, mode: str = "auto", max_threads: int = 16):
             t1 = time.perf_counter(); out = gpu_run(); torch.cuda.synchronize(); dg = time.perf_counter() - t1
         rel = float((out.float().cpu() - ref.float()).norm() / ref.float().norm())
         fl = 4 * canonical_flops_per_forward(3072, 1024, 512, 19, 38, 9, 19, 1)
-        return dict(value=1.0 / dt, unit="images/s", cores=cores, kind="port", cpu=cpu_model, mode="cfg1",
+        return _cores_note(dict(value=1.0 / dt, unit="images/s", cores=cores, kind="port", cpu=cpu_model, mode="cfg1",
                     sample=f"cfg1 END TO END (512^2, B=1, 4 steps, full depth): oracle {dt:.1f} s per image on {cores} threads ({fl / dt / 1e12:.2f} TFLOP/s); "
                            f"the HIP path runs the same job in {dg * 1e3:.0f} ms; relL2(final latents, oracle bf16) = {rel:.3e}",
-                    sample_seconds=dt, sample_tflops=fl / 1e12, cpu_tflops_per_s=fl / dt / 1e12, gpu_cfg1_images_per_s=1.0 / dg, cfg1_rel_l2_vs_oracle=rel)
+                    sample_seconds=dt, sample_tflops=fl / 1e12, cpu_tflops_per_s=fl / dt / 1e12, gpu_cfg1_images_per_s=1.0 / dg, cfg1_rel_l2_vs_oracle=rel))
     B, grid, T = 1, 64, 512
     full_flops_per_image = 4 * canonical_flops_per_forward(3072, 4096, 512, 19, 38, 9, 19, 1)
     if mode == "full":
@@ -206,8 +217,8 @@ def cpu_baseline(model, mode: str = "auto", max_threads: int = 16):
         sample = (f"ESTIMATE (host has {mem_gb:.0f} GB free, the full model needs ~90): oracle on ONE forward, B=1, 1024^2, FLUX width, depth cut to {n_d} double + "
                   f"{n_s} single base blocks, tiled weights: {sample_flops / 1e12:.2f} TFLOP in {dt:.1f} s on {cores} threads, scaled by algorithmic FLOPs to "
                   f"the full 4-step image ({full_flops_per_image / 1e12:.1f} TFLOP)")
-    return dict(value=img_per_s, unit="images/s", cores=cores, kind="port", cpu=cpu_model, mode=mode, sample=sample, sample_seconds=dt,
-                sample_tflops=sample_flops / 1e12, cpu_tflops_per_s=sample_flops / dt / 1e12)
+    return _cores_note(dict(value=img_per_s, unit="images/s", cores=cores, kind="port", cpu=cpu_model, mode=mode, sample=sample, sample_seconds=dt,
+                sample_tflops=sample_flops / 1e12, cpu_tflops_per_s=sample_flops / dt / 1e12))
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -555,16 +566,25 @@ METRIC_NAMES = dict(cfg2="images/sec at 1024^2, FLUX-schnell+canny, 4-step", cfg
                     cfg3="images/sec at 1024^2, FLUX-schnell + depth+canny+openpose, 4-step", cfg5="images/sec at 1024^2, SD3.5-medium + depth, 28-step CFG")
 
 
-def measure_other_config(config, rank, dev, ops, pk16, pk32, steps=1, warmup=1):
+def _pass_stats(B, per_pass):
+    """min / median / max of the passes of a side block, as images/s and ms (no single samples)."""
+    ps = sorted(per_pass)
+    med = ps[len(ps) // 2] if len(ps) % 2 else 0.5 * (ps[len(ps) // 2 - 1] + ps[len(ps) // 2])
+    return dict(ms_per_pass=[1000.0 * t for t in per_pass], images_per_s_best=B / ps[0], images_per_s_median=B / med, images_per_s_worst=B / ps[-1])
+
+
+def measure_other_config(config, rank, dev, ops, pk16, pk32, steps=3, warmup=1):
     """BASELINE.json configs[2] (cfg3) / configs[4] (cfg5) at their stated batch (B = 8) inside the default N = 1 run, so the driver's own record carries
-    them: the same fields as the headline block (value, ms_per_step, roofline, roofline_attention), `warmup` + `steps` passes of the hot path."""
+    them: the same fields as the headline block (value, ms_per_step, roofline, roofline_attention), `warmup` + `steps` passes of the hot path;
+    `value` is over all timed passes, `passes` holds every pass's own time with min / median / max."""
     B = 8
     if config == "cfg5":
         model, one_step, info = _sd3_workload(B, rank, dev, False)
     else:
         model, one_step, info = _flux_workload(config, B, rank, dev, False)
     timer = ops.KernelTimer()
-    elapsed, _, _ = _timed(one_step, steps, warmup, dev, 1, timer, ops)
+    per_pass = []
+    elapsed, _, _ = _timed(one_step, steps, warmup, dev, 1, timer, ops, per_pass=per_pass)
     s = timer.summary()
     value = B * steps / elapsed
     fl_img = info["flops_per_image"]
@@ -575,12 +595,40 @@ def measure_other_config(config, rank, dev, ops, pk16, pk32, steps=1, warmup=1):
              flops_per_image=fl_img, flops_per_image_kind=info["flops_kind"], e2e_mfma_frac=value * fl_img / (MFMA_BF16_PEAK_TFLOPS * 1e12))
     if pk16:
         d["e2e_frac_of_measured"] = value * fl_img / (pk16 * 1e12)
+    d["passes"] = _pass_stats(B, per_pass)
     d.update(_roofline_blocks(s, elapsed, pk16, pk32, info["attn_kernel"]))
     del model, one_step
     return d
 
 
-def _timed(one_step, steps, warmup, dev, world, timer, ops, power=None):
+def measure_small_m(model, name, rank, dev, ops, pk16, pk32, steps=2, warmup=1):
+    """The small-M regime the reference's own launch script runs (script/infer.sh:62-63: --batch_size 1; BASELINE configs[0] is 512^2, B = 1), on
+    the headline run's own UniGenFlux (same weights), inside the default line: `b1_1024` = one 1024^2 image (N = 4096,
+    M = 4608 joint rows), `cfg1_gpu` = configs[0]'s geometry on the GPU (512^2: N = 1024, M = 1536). 1 warm-up + 2 passes of the 4-step loop."""
+    grid = dict(b1_1024=64, cfg1_gpu=32)[name]
+    _, one_step, _ = _flux_workload_inputs_only(model, 1, rank, dev, grid=grid)
+    timer = ops.KernelTimer()
+    per_pass = []
+    elapsed, _, _ = _timed(one_step, steps, warmup, dev, 1, timer, ops, per_pass=per_pass)
+    s = timer.summary()
+    value = steps / elapsed
+    n_d, n_s = model.config.num_layers, model.config.num_single_layers
+    fl_img = 4 * canonical_flops_per_forward(model.inner_dim, grid * grid, 512, n_d, n_s, model._ctl.cn_joint_layers, model._ctl.cn_single_layers, 1)
+    what = {"b1_1024": "UniGenFlux canny, 1024x1024, batch=1 (the reference's script/infer.sh launch shape), N=4096 + T=512, 4 steps",
+            "cfg1_gpu": "cfg1 geometry on the GPU: UniGenFlux canny, 512x512, batch=1, N=1024 + T=512, 4 steps (BASELINE configs[0] names the CPU path; this is the same job on the MI355X)"}[name]
+    d = dict(metric="images/sec, FLUX-schnell+canny, 4-step, batch 1", value=value, unit="images/s", n_gpus=1, steps=steps, warmup=warmup,
+             ms_per_step=1000.0 * elapsed / steps, dtype="bf16", data="synthetic", config=dict(workload=what, per_gpu_batch=1, step="one 4-step denoise loop of one image"),
+             flops_per_image=fl_img, flops_per_image_kind="canonical (SURVEY 8(d))", e2e_mfma_frac=value * fl_img / (MFMA_BF16_PEAK_TFLOPS * 1e12),
+             passes=_pass_stats(1, per_pass))
+    if pk16:
+        d["e2e_frac_of_measured"] = value * fl_img / (pk16 * 1e12)
+    d.update(_roofline_blocks(s, elapsed, pk16, pk32, "flash_attn_kernel<128> (ug_flash_attn_fwd)"))
+    return d
+
+
+def _timed(one_step, steps, warmup, dev, world, timer, ops, power=None, per_pass=None):
+    """`per_pass`: a list that receives every pass's own wall time (a device synchronisation after each pass: only for the side blocks, whose
+    passes last seconds or are reported per pass - the headline region is timed as ONE bracket, as the contract says)."""
     from unigen_amd import dist_utils as DU
     for _ in range(warmup):
         out = one_step()
@@ -590,7 +638,11 @@ def _timed(one_step, steps, warmup, dev, world, timer, ops, power=None):
         power.start()
     t0 = time.perf_counter()
     for _ in range(steps):
+        tp = time.perf_counter()
         out = one_step()
+        if per_pass is not None:
+            torch.cuda.synchronize(dev)
+            per_pass.append(time.perf_counter() - tp)
     if dev.type == "cuda":
         torch.cuda.synchronize(dev)
     own = time.perf_counter() - t0                 # this rank's own K steps; the job's time is the MAX over ranks of the barrier-bracketed region
@@ -616,7 +668,7 @@ def main():
                     help="full = one full-depth 1024^2 oracle forward x 4 (needs ~90 GB host RAM); cfg1 = BASELINE configs[0] end to end (512^2, B = 1, 4 steps) on CPU and GPU")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--no-scaling-base", action="store_true", help="N = 1, cfg2 only: skip the extra B = 8 measurement (cfg4's per-GPU shape, the like-for-like base of the 1 -> 8 curve)")
-    ap.add_argument("--no-other-configs", action="store_true", help="N = 1, cfg2 only: skip the cfg3 / cfg5 blocks (other_configs: 1 warm-up + 1 step each at B = 8)")
+    ap.add_argument("--no-other-configs", action="store_true", help="N = 1, cfg2 only: skip the cfg3 / cfg5 blocks (other_configs: 1 warm-up + 3 passes each at B = 8) and the batch-1 blocks (small_m)")
     ap.add_argument("--no-pmc", action="store_true", help="N = 1, cfg2 only: skip the two rocprofv3 --pmc child passes that measure roofline.traffic in this run (then read from profiles/)")
     ap.add_argument("--pmc-child", action="store_true", help="internal: the workload of one counter pass (cfg2, B = 4, one step, nothing else)")
     ap.add_argument("--small", action="store_true", help="debug: reduced depth (NOT the headline configuration)")
@@ -751,6 +803,15 @@ def main():
             if config != "cfg5":
                 line["parity"] = fixture_parity(dev)
         if world == 1 and config == "cfg2" and B == 4 and not (args.small or args.graph or args.no_other_configs or args.no_kernel_timer):
+            # the batch-1 regime on the same model (same weights, nothing rebuilt): a few seconds
+            small = {}
+            for nm in ("b1_1024", "cfg1_gpu"):
+                try:
+                    small[nm] = measure_small_m(model, nm, rank, dev, ops, pk16, pk32)
+                except Exception as e:
+                    small[nm] = dict(error=f"{type(e).__name__}: {e}")
+            line["small_m"] = small
+        if world == 1 and config == "cfg2" and B == 4 and not (args.small or args.graph or args.no_other_configs or args.no_kernel_timer):
             # BASELINE configs[2] and [4] inside the driver's own record: one warm-up + one pass each at their stated B = 8,
             # after everything of the headline block is final - the cfg2 numbers above are untouched by this
             import gc
@@ -781,11 +842,11 @@ def main():
         dist.destroy_process_group()
 
 
-def _flux_workload_inputs_only(model, B, rank, dev):
-    """A second batch size on an existing UniGenFlux (the B = 8 scaling base): same input recipe as _flux_workload."""
+def _flux_workload_inputs_only(model, B, rank, dev, grid=64):
+    """A second batch size / image size on an existing UniGenFlux (the B = 8 scaling base, the B = 1 blocks): same input recipe as _flux_workload."""
     from unigen_amd.pipeline import denoise_loop, prepare_latent_image_ids
     from unigen_amd import dist_utils as DU
-    grid, T = 64, 512
+    T = 512
     N, E = grid * grid, model._ctl.expert_nums
     g = torch.Generator(device=dev).manual_seed(DU.rank_seed(12443, rank) + 1000)
     rn = lambda *s: torch.randn(*s, generator=g, device=dev, dtype=torch.float32)

@@ -151,7 +151,7 @@ def main() -> None:
         for lin in lins.values():
             lin.float()
 
-    out = os.path.join(HERE, "ref_leaf.safetensors")
+    out = os.path.join(os.environ.get("UG_GOLDEN_OUT", HERE), "ref_leaf.safetensors")
     # ONE metadata key: safetensors writes the metadata map in an unspecified order, a second key makes the file's bytes vary run to run
     save_file(fx, out, metadata={"origin": "reference functions executed by tests/golden/make_ref_leaf_golden.py, seed 12443"})
     print(f"wrote {out}: {len(fx)} tensors, {os.path.getsize(out) / 1024:.0f} KiB")

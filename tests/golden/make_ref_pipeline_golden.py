@@ -44,7 +44,7 @@ def main() -> None:
         img = torch.randn(*shape, generator=g)
         out = sd3(me, img, shape[-1], shape[-2], bs, nipp, "cpu", torch.bfloat16, do_classifier_free_guidance=bool(cfg), guess_mode=bool(guess))
         fx[f"sd3.{name}.image"], fx[f"sd3.{name}.args"], fx[f"sd3.{name}.out"] = img, torch.tensor([bs, nipp, cfg, guess]), out.contiguous()
-    path = os.path.join(HERE, "ref_pipeline.safetensors")
+    path = os.path.join(os.environ.get("UG_GOLDEN_OUT", HERE), "ref_pipeline.safetensors")
     save_file(fx, path, metadata={"origin": "outputs of the reference's own prepare_image methods (src/UniGenPipeline.py:107, :457), executed from /root/reference by tests/golden/make_ref_pipeline_golden.py"})
     print("wrote", path, len(fx), "tensors", os.path.getsize(path), "bytes")
 

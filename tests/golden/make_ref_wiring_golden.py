@@ -361,7 +361,7 @@ def main() -> None:
     # ONE metadata key: safetensors writes the header's metadata map in an unspecified order, a second key would make the file's bytes vary run to run
     meta = {"origin": "reference methods executed by tests/golden/make_ref_wiring_golden.py; first lines: " + ", ".join(f"{k}:{v}" for k, v in lines.items())}
     for name, fx in (("ref_blocks", make_blocks(ref)), ("ref_wiring", make_wiring(ref))):
-        out = os.path.join(HERE, name + ".safetensors")
+        out = os.path.join(os.environ.get("UG_GOLDEN_OUT", HERE), name + ".safetensors")
         save_file(fx, out, metadata=meta)
         print(f"wrote {out}: {len(fx)} tensors, {os.path.getsize(out) / 1024:.0f} KiB")
 

@@ -345,6 +345,37 @@ def test_sd3_default_sigmas_match_diffusers_0_32_2():
     assert max(abs(a - b) for a, b in zip(sig, lit)) < 1e-6
 
 
+def test_both_denoise_loops_run_the_transformer_without_autograd(monkeypatch):
+    """`@torch.no_grad()` of the reference's pipeline `__call__`s (src/UniGenPipeline.py:143, 486) sits on BOTH loops here: a model whose
+    control modules require grad (after `init_trainable_param()`) must still take the inference forward inside the sampling loop, with no
+    graph kept across the steps (the decorator had slipped onto a helper above `sd3_denoise_loop`)."""
+    from types import SimpleNamespace
+    from unigen_amd import ops, pipeline as P
+    seen = []
+
+    class Fake:
+        config = SimpleNamespace(guidance_embeds=False)
+
+        def __call__(self, hidden_states=None, **kw):
+            seen.append(torch.is_grad_enabled())
+            return (torch.zeros_like(hidden_states),)
+
+    monkeypatch.setattr(ops, "euler_step", lambda lat, pred, dt: lat)
+    monkeypatch.setattr(ops, "cfg_combine", lambda a, b, s, out: out)
+    w = torch.nn.Parameter(torch.ones(1))              # something that requires grad is alive while the loops run
+    with torch.enable_grad():
+        P.denoise_loop(Fake(), latents=torch.zeros(1, 4, 8) * w.detach(), control_tokens=torch.zeros(1, 4, 8), prompt_embeds=torch.zeros(1, 2, 8),
+                       pooled_prompt_embeds=torch.zeros(1, 8), condition_pooled_prompt_embeds=torch.zeros(1, 8), text_ids=torch.zeros(2, 3),
+                       latent_image_ids=torch.zeros(4, 3), condition_ids=torch.zeros(4, 3), num_inference_steps=2)
+        n_flux = len(seen)
+        P.sd3_denoise_loop(Fake(), latents=torch.zeros(1, 4, 4, 4), control_latents=torch.zeros(1, 4, 4, 4), prompt_embeds=torch.zeros(2, 2, 8),
+                           pooled_prompt_embeds=torch.zeros(2, 8), condition_pooled_prompt_embeds=torch.zeros(2, 8), num_inference_steps=3)
+        assert torch.is_grad_enabled()
+    assert n_flux == 2 and len(seen) == 5 and not any(seen)
+    # the helpers that sit next to the loops are plain functions
+    assert P.sd3_default_sigmas_unshifted(4)[0] == 1.0 and P.control_keep(4, 0.0, 0.5) == [1.0, 1.0, 0.0, 0.0]
+
+
 def test_vae_dropin_names_and_loading(tmp_path):
     """unigen_amd.vae.AutoencoderKL keeps diffusers' parameter names / shapes (FLUX VAE: 83.8 M parameters) and loads the diffusers directory layout."""
     from types import SimpleNamespace

@@ -142,3 +142,27 @@ def test_joint_attention_matches_the_reference_processor(fx, tag):
     # a context-first concatenation (the base FLUX blocks' order) is a different function: the fixture tells the two apart
     q = torch.cat([enc, x], 1)
     assert rel(R.sd3_attention(st, "a", 2, q[:, :x.shape[1]], q[:, x.shape[1]:])[0], fx[f"attn.joint.cpo0.{tag}.out"]) > 1e-2
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/src"), reason="the reference tree exists in the build container only")
+def test_committed_reference_fixtures_regenerate_bit_identically(tmp_path):
+    """The pin verifies itself: every generator that executes the reference's own code (make_ref_leaf / _wiring / _pipeline)
+    is run into a scratch directory and each tensor it writes must equal, bit for bit, the tensor of the same name in the committed fixture -
+    and no committed tensor may be missing from the regenerated file. A fixture that drifted from the reference (or a generator edited
+    without regenerating) fails here instead of silently re-defining what "the reference says"."""
+    import subprocess
+    import sys
+    golden = os.path.join(os.path.dirname(__file__), "golden")
+    env = dict(os.environ, UG_GOLDEN_OUT=str(tmp_path))
+    for gen in ("make_ref_leaf_golden.py", "make_ref_wiring_golden.py", "make_ref_pipeline_golden.py"):
+        r = subprocess.run([sys.executable, os.path.join(golden, gen)], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, f"{gen}: {r.stderr[-800:]}"
+    produced = sorted(p for p in os.listdir(tmp_path) if p.endswith(".safetensors"))
+    assert produced == ["ref_blocks.safetensors", "ref_leaf.safetensors", "ref_pipeline.safetensors", "ref_wiring.safetensors"]
+    for name in produced:
+        with safe_open(os.path.join(tmp_path, name), "pt") as new, safe_open(os.path.join(golden, name), "pt") as old:
+            assert sorted(new.keys()) == sorted(old.keys()), name
+            for k in old.keys():
+                a, b = new.get_tensor(k), old.get_tensor(k)
+                assert a.dtype == b.dtype and a.shape == b.shape and torch.equal(a.view(torch.uint8) if a.is_floating_point() else a,
+                                                                                b.view(torch.uint8) if b.is_floating_point() else b), f"{name}:{k}"

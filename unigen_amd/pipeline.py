@@ -329,7 +329,6 @@ class UniGenFLUXPipeline:
         return SimpleNamespace(images=out)
 
 
-@torch.no_grad()
 def sd3_default_sigmas_unshifted(num_inference_steps: int, num_train_timesteps: int = 1000) -> List[float]:
     """The same default when the scheduler uses dynamic shifting: its __init__ then leaves the training sigmas unshifted (sigma_min = 1 / T)."""
     n = num_inference_steps
@@ -344,6 +343,7 @@ def control_keep(num_steps: int, start=0.0, end=1.0) -> List[float]:
     return [1.0 - float(i / num_steps < s or (i + 1) / num_steps > e) for i in range(num_steps)]
 
 
+@torch.no_grad()
 def sd3_denoise_loop(transformer, *, latents: torch.Tensor, control_latents: torch.Tensor, prompt_embeds: torch.Tensor,
                      pooled_prompt_embeds: torch.Tensor, condition_pooled_prompt_embeds: torch.Tensor, num_inference_steps: int = 28,
                      guidance_scale: float = 7.0, conditioning_scale=1.0, shift: float = 3.0, sigmas: Optional[Sequence[float]] = None,
