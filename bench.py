@@ -440,22 +440,28 @@ def _under_profiler():
 
 def same_run_traffic(limit_s=60.0):
     """`roofline.traffic` measured by THIS run on THIS box: one child per counter pass - `rocprofv3 --kernel-trace --pmc <counter> -- python3 bench.py
-    --pmc-child` (the cfg2 B = 4 workload, one 4-forward step, no timers / probes / CPU legs; the program goes straight after `--`) - after every timed
+    --pmc-child` (the cfg2 B = 4 workload, a warm-up step + one 4-forward step of which only the second is counted, no timers / probes / CPU legs; the interpreter's ELF image goes straight after `--`) - after every timed
     region of the parent is over. Bytes beyond the XCD L2 per GEMM launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 / launches over all gemm256 / gemm128
     launches (KiB units; gfx950's FETCH_SIZE counts wide coalesced reads at half their bytes; Infinity-Cache hits are included: an upper bound on HBM
-    bytes). A pass takes 5-7 s; one that fails or overruns `limit_s` raises (the remaining passes are not started) and the caller falls back to the
+    bytes). A pass takes 8-10 s; one that fails or overruns `limit_s` raises (the remaining passes are not started) and the caller falls back to the
     recorded profile and says so - the worst case adds `limit_s` to the run, never more."""
     import csv, shutil, signal, subprocess, tempfile
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         raise RuntimeError("rocprofv3 not found")
+    # the program after `--` must be the interpreter itself (an ELF image), never a shim script or launcher: under --pmc the profiler's preloaded
+    # library has initialised the GPU before the program starts, and any further exec from there takes the machine down
+    py = os.path.realpath(sys.executable)
+    with open(py, "rb") as f:
+        if f.read(4) != b"\x7fELF":
+            raise RuntimeError(f"{py} is not an ELF interpreter: counter passes not started")
     td = tempfile.mkdtemp(prefix="ug_bench_pmc_", dir="/tmp")
-    acc, secs = {}, {}          # (kernel class, counter) -> [sum, launches, ns]
+    rows, secs = {}, {}         # (kernel class, counter) -> [(start ns, value, duration ns)] in dispatch order
     try:
         for counters in PMC_PASSES:
             t0 = time.perf_counter()
             out = os.path.join(td, counters[0])
-            cmd = [exe, "--kernel-trace", "--pmc", *counters, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.join(ROOT, "bench.py"), "--pmc-child"]
+            cmd = [exe, "--kernel-trace", "--pmc", *counters, "--output-format", "csv", "-d", out, "--", py, os.path.join(ROOT, "bench.py"), "--pmc-child"]
             p = subprocess.Popen(cmd, cwd=td, env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, start_new_session=True)
             try:
                 log, _ = p.communicate(timeout=limit_s)
@@ -475,11 +481,20 @@ def same_run_traffic(limit_s=60.0):
                         classes = (("gemm_all", "gemm256") if "gemm256_kernel" in name else ("gemm_all",) if "gemm128_kernel" in name
                                    else ("attn",) if "flash_attn" in name else ())
                         for cls in classes:
-                            a = acc.setdefault((cls, r["Counter_Name"]), [0.0, 0, 0.0])
-                            a[0] += float(r["Counter_Value"]); a[1] += 1; a[2] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+                            rows.setdefault((cls, r["Counter_Name"]), []).append((float(r["Start_Timestamp"]), float(r["Counter_Value"]),
+                                                                                  float(r["End_Timestamp"]) - float(r["Start_Timestamp"])))
             secs[counters[0]] = round(time.perf_counter() - t0, 1)
     finally:
         shutil.rmtree(td, ignore_errors=True)
+    # the child runs the step twice; only the SECOND step's launches count (the first packs weights, allocates workspaces and fills the caches:
+    # ADVICE r5) - both steps launch the same kernels in the same order, so the later half by start time is the warm step
+    acc = {}                    # (kernel class, counter) -> [sum, launches, ns]
+    for key, lst in rows.items():
+        lst.sort()
+        if len(lst) % 2:
+            raise RuntimeError(f"PMC pass saw an odd number of {key[0]} launches over two identical steps: {len(lst)}")
+        warm = lst[len(lst) // 2:]
+        acc[key] = [sum(v for _, v, _ in warm), len(warm), sum(d for _, _, d in warm)]
     def traffic_of(cls):
         f, w = acc.get((cls, "FETCH_SIZE")), acc.get((cls, "WRITE_SIZE"))
         if not f or not w or f[1] != w[1]:
@@ -528,7 +543,7 @@ def _roofline_blocks(s, elapsed, pk16, pk32, attn_kernel, traffic_file=None, liv
         traffic_src = dict(measured_in_this_run=True, launches=live["launches"], fetch_bytes_per_launch_corrected=live["fetch_bytes_per_launch_corrected"],
                            write_bytes_per_launch=live["write_bytes_per_launch"], pass_seconds=live["pass_seconds"],
                            collected="child processes of this run, after its timed regions: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (one pass each) -- python3 bench.py --pmc-child")
-        traffic_note = ("measured in this run on this box: (2*FETCH_SIZE + WRITE_SIZE)*1024 per GEMM launch over one 4-forward step of the same workload under rocprofv3 "
+        traffic_note = ("measured in this run on this box: (2*FETCH_SIZE + WRITE_SIZE)*1024 per GEMM launch over one WARM 4-forward step of the same workload under rocprofv3 (the child's first step - weight packing, workspace allocation, cold caches - is excluded) "
                         "(gfx950 FETCH_SIZE correction; KiB units); the L2-fabric counters include Infinity-Cache hits, so this is traffic beyond the XCD L2, an upper bound on HBM bytes")
         if "gemm256" in live:
             g = live["gemm256"]
@@ -676,7 +691,7 @@ def main():
     ap.add_argument("--dry-run", action="store_true", help="no GPU work: rehearse the multi-process harness (spawn, rendezvous, barriers, JSON) on the CPU with gloo")
     args = ap.parse_args()
     if args.pmc_child:                 # one counter pass of same_run_traffic(): the cfg2 workload's launches and nothing else
-        args.gpus, args.config, args.batch, args.steps, args.warmup = 1, "cfg2", 4, 1, 0
+        args.gpus, args.config, args.batch, args.steps, args.warmup = 1, "cfg2", 4, 1, 1      # warm-up + one step: the parser keeps the second step's launches
         args.no_kernel_timer = args.no_cpu_baseline = args.no_scaling_base = args.no_other_configs = args.no_pmc = True
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -829,6 +844,7 @@ def main():
         if world == 1 and config == "cfg2" and B == 4 and s and not (args.small or args.graph or args.no_pmc or _under_profiler()):
             # roofline.traffic from THIS run's own counter passes (two rocprofv3 children, after every timed region); on any failure the recorded profile stays
             import gc
+            model = one_step = step8 = out = None       # the parent's 37 GB of weights go before the children build their own copy
             gc.collect(); torch.cuda.empty_cache()
             try:
                 live = same_run_traffic()

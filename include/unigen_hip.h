@@ -57,7 +57,10 @@ enum {
 };
 
 typedef struct ug_gemm_desc {
-    /* C[m][n] = epilogue( sum_k A[m][k] * W[n][k] + bias[n] ), all bf16, W in nn.Linear layout [N][K] */
+    /* C[m][n] = epilogue( sum_k A[m][k] * W[n][k] + bias[n] ), all bf16, W in nn.Linear layout [N][K].
+     * Row maps (x_rpb, x_bstride): logical row m sits at physical row (m / rpb) * bstride + m % rpb (rpb 0: m itself). The A map may be
+     * anything (bstride < rpb broadcasts a batch); a NON-MONOTONIC A map (bstride < rpb) is served by the 128^2 kernel only - the 256^2
+     * kernel's DMA offsets are unsigned distances from a tile's first row - and is refused (UG_ERR_BAD_SHAPE) with UG_EPI_QKV_ROPE. */
     const void* A; int64_t lda; int64_t a_rpb; int64_t a_bstride;
     const void* W; int64_t ldw;
     const void* bias;                 /* [N] bf16 or NULL */

@@ -98,10 +98,19 @@ class FluxConfig:
 # primitives (diffusers 0.32.2 semantics)
 # ---------------------------------------------------------------------------------------------------------------------
 
+LORA_KEY = "__lora__"   # optional entry of a state: {projection prefix: [(A [r, K], B [N, r], scaling), ...]} - the ACTIVE PEFT adapters of that Linear
+
+
 def linear(state: State, prefix: str, x: torch.Tensor) -> torch.Tensor:
+    """nn.Linear at `prefix`; when the state carries LoRA adapters for it (LORA_KEY) the projection is peft 0.15's LoRA Linear (lora_linear
+    below): what `enable_lora` (src/lora_switching_module.py:11-38) switches per condition by setting the scalings of the others to 0."""
     w = state[prefix + ".weight"].to(x.dtype)
     b = state.get(prefix + ".bias")
-    return F.linear(x, w, None if b is None else b.to(x.dtype))
+    b = None if b is None else b.to(x.dtype)
+    ad = state.get(LORA_KEY)
+    if ad and prefix in ad:
+        return lora_linear(x, w, b, [(A.to(x.dtype), Bm.to(x.dtype), sc) for A, Bm, sc in ad[prefix]])
+    return F.linear(x, w, b)
 
 
 def timestep_sinusoid(t: torch.Tensor, dim: int = 256) -> torch.Tensor:

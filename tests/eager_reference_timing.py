@@ -32,8 +32,12 @@ if a.batch > 1 and a.only != "hip":
     # Round 4, gpurun_out/r04w_eager_b2.log and r04w_eager_b2_math.log: `--only eager --batch 2` ended in "Memory access fault by GPU ... Write access to a
     # read-only page" (core dump) - in the first forward with the default SDPA backends, in the second with the math backend. The faulting op was never
     # identified: the cause is UNIDENTIFIED. What the records do establish: no ug_* entry point ran in those processes (--only eager never calls the
-    # engine); the process ran this repository's oracle on the GPU under the engine's state-dict tensors. The oracle's own index arithmetic at that
-    # token count is exercised with bounds checks on the CPU build (tests/test_oracle_cpu.py::test_routing_indices_stay_in_range_at_two_full_samples).
+    # engine); the process ran this repository's oracle on the GPU under the engine's state-dict tensors. Round 6 checked what this repository
+    # contributes to that process on the bounds-checked CPU build: the same forward at the same token counts over the engine's packed state-dict views under
+    # a dispatch mode that inspects EVERY aten call (tests/test_oracle_cpu.py::test_eager_forward_at_the_faulting_token_count_writes_only_its_own_tensors) -
+    # every in-place destination is a tensor the oracle allocated itself (never a parameter, an input or an expanded view) and every index handed to
+    # index / index_put / gather / scatter lies inside its dimension. Nothing to fix was found here, so nothing changed that would justify a second launch;
+    # what differs from B = 1 on the torch side is, e.g., topk / one_hot at capacity 1366 > 1024 and hipBLASLt / SDPA shapes - not examinable offline.
     # A GPU fault can reset the host's GPUs for everyone: the case is not launched again.
     sys.exit("tests/eager_reference_timing.py: the eager path is only run at --batch 1 (B >= 2 faulted the GPU in round 4 - cause unidentified - see "
              "gpurun_out/r04w_eager_b2.log, gpurun_out/r04w_eager_b2_math.log and profiles/r04w_eager_reference.log); `--only hip` takes any batch")

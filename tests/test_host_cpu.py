@@ -459,6 +459,69 @@ def test_enable_lora_context_manager_semantics():
     assert mod.module_active_adapters(object()) == []
 
 
+def test_add_lora_makes_the_projections_peft_shaped_layers_enable_lora_switches():
+    """A12 on the hot path: `HipModule.add_lora` turns the holders of the named projections into PEFT-shaped layers that
+    `enable_lora(list(model.modules()), [...])` - the reference's call shape, src/lora_switching_module.py:11-38 - finds and switches; the base
+    parameters stay the same objects under the same state-dict keys; targets the engine cannot extend are refused, not ignored."""
+    from unigen_amd import lib as L
+    from unigen_amd.lora import LoRALayer, fuse_adapters
+    mod = importlib.import_module("src.lora_switching_module")
+    m = _model(3, cls="MultiCondtionUniGenFlux")
+    keys0 = set(m.state_dict())
+    wq = m.get_parameter("control_joint_trans_blocks.0.attn.to_q.weight")
+    assert mod.enable_lora(list(m.modules()), ["canny"]).lora_modules == []          # nothing attached yet (as on the reference without PEFT layers)
+    specs = [("canny", 8, 16.0), ("depth", 4, 4.0), ("openpose", 16, 8.0)]
+    for i, (name, r, alpha) in enumerate(specs):
+        hits = m.add_lora(["attn.to_q", "attn.to_k", "attn.to_v", "attn.to_out.0"], name, r, alpha, prefix="control_", init_lora_weights=False, seed=i)
+    n_joint, n_single = m._ctl.cn_joint_layers, m._ctl.cn_single_layers
+    assert len(hits) == 4 * n_joint + 3 * n_single and all(h.startswith("control_") for h in hits)
+    assert m.get_parameter("control_joint_trans_blocks.0.attn.to_q.weight") is wq      # same Parameter object, same key
+    new_keys = set(m.state_dict()) - keys0
+    assert keys0 <= set(m.state_dict()) and len(new_keys) == 2 * 3 * len(hits)
+    assert "control_joint_trans_blocks.0.attn.to_q.lora_A.canny.weight" in new_keys and "control_single_trans_blocks.1.attn.to_v.lora_B.openpose.weight" in new_keys
+    layers = [x for x in m.modules() if isinstance(x, LoRALayer)]
+    assert len(layers) == len(hits) and all(mod.module_active_adapters(x) == ["canny", "depth", "openpose"] for x in layers)
+    lay = m.get_submodule("control_joint_trans_blocks.0.attn.to_q")
+    assert lay.scaling == {"canny": 2.0, "depth": 1.0, "openpose": 0.5}
+    ctx = mod.enable_lora(list(m.modules()), ["canny"])
+    assert len(ctx.lora_modules) == len(hits)
+    with ctx:
+        assert lay.scaling == {"canny": 2.0, "depth": 0.0, "openpose": 0.0} and lay.live_adapters() == ["canny"]
+        assert m._lora_live(["control_joint_trans_blocks.0.attn.to_q"]) and not m._lora_live(["transformer_blocks.0.attn.to_q"])
+        A, Bm = fuse_adapters([lay, m.get_submodule("control_joint_trans_blocks.0.attn.to_k"), None], [256, 256, 256], torch.bfloat16, "cpu")
+        assert A.shape == (64, 256) and Bm.shape == (768, 64)                       # 8 + 8 ranks, padded to the K-tile
+        assert torch.equal(A[:8], lay.lora_A["canny"].weight) and not Bm[:256, 8:].any() and not Bm[256:512, :8].any() and not Bm[512:].any()
+        assert torch.equal(Bm[:256, :8], (lay.lora_B["canny"].weight.float() * 2.0).to(torch.bfloat16))
+        # the fused operands say what peft's LoRA Linear says, projection by projection (fp32): [x W^T | ...] + (x A_cat^T) B_bd^T
+        from oracle import unigen_ref as R
+        lk = m.get_submodule("control_joint_trans_blocks.0.attn.to_k")
+        x = torch.randn(5, 256)
+        A32, B32 = fuse_adapters([lay, lk, None], [256, 256, 256], torch.float32, "cpu")
+        fusedy = (x @ A32.t()) @ B32.t()
+        for j, ly in enumerate((lay, lk)):
+            want = R.lora_linear(x, torch.zeros(256, 256), None, [(ly.lora_A["canny"].weight.float(), ly.lora_B["canny"].weight.float(), 2.0)])
+            assert torch.allclose(fusedy[:, j * 256:(j + 1) * 256], want, atol=1e-5)
+        assert not fusedy[:, 512:].any()
+    # Q10: the reference "restores" through set_scale(saved scaling) = saved * alpha / r (idempotent only when alpha == r)
+    assert lay.scaling == {"canny": 4.0, "depth": 1.0, "openpose": 0.25}
+    # diffusers scale_lora_layers / unscale_lora_layers around a forward (joint_attention_kwargs["scale"])
+    with m._lora_scaled({"scale": 0.5}):
+        assert lay.scaling == {"canny": 2.0, "depth": 0.5, "openpose": 0.125}
+    assert lay.scaling == {"canny": 4.0, "depth": 1.0, "openpose": 0.25}
+    with pytest.raises(L.UniGenHipError, match="not a projection the HIP engine can extend"):
+        m.add_lora(["norm1.linear"], "x", 4, 4.0)
+    with pytest.raises(L.UniGenHipError, match="not a projection"):
+        m.add_lora(["proj_out"], "x", 4, 4.0)                                        # the model's final proj_out (the single blocks' proj_out is fine under a prefix)
+    assert m.add_lora(["proj_out", "proj_mlp"], "x", 4, 4.0, prefix="single_transformer_blocks.0.") == ["single_transformer_blocks.0.proj_mlp", "single_transformer_blocks.0.proj_out"]
+    with pytest.raises(ValueError, match="no module"):
+        m.add_lora(["attn.to_q"], "x", 4, 4.0, prefix="nowhere.")
+    # the training forward does not carry adapters: refused loudly while any is live
+    with pytest.raises(NotImplementedError, match="LoRA"):
+        m._refuse_lora_in_training()
+    with mod.enable_lora(list(m.modules()), []):
+        m._refuse_lora_in_training()
+
+
 def test_control_checkpoint_wire_formats(tmp_path):
     """the reference's `--transformer` formats (infer.py:124-140, src/hook.py:10-27) all reach load_state_dict."""
     from safetensors.torch import save_file
@@ -843,11 +906,12 @@ if os.environ.get("FAKE_PMC_FAIL") == counters[0]:
 out = os.path.join(a[a.index("-d") + 1], "host"); os.makedirs(out)
 rows = ["Kernel_Name,Counter_Name,Counter_Value,Start_Timestamp,End_Timestamp"]
 val = dict(FETCH_SIZE=1000.0, WRITE_SIZE=300.0, SQ_VALU_MFMA_BUSY_CYCLES=700.0 * 1024, GRBM_GUI_ACTIVE=8 * 1000.0)
-for i in range(6):
+for i in range(12):        # two identical steps of 6 launches; the FIRST (cold: packing, allocation, cold caches) reads 3 x the bytes and must not be counted
     name = ["void (anonymous namespace)::gemm256_kernel<2, false, 128, false>(ug_gemm_desc)", "void (anonymous namespace)::gemm128_kernel<2>(ug_gemm_desc)",
             "void (anonymous namespace)::flash_attn_kernel<128>(x)"][i % 3]
     for c in counters:
-        rows.append(f'"{name}",{c},{val[c]},{1000 * i},{1000 * i + 500}')
+        rows.append(f'"{name}",{c},{val[c] * (3 if i < 6 and c.endswith("SIZE") else 1)},{1000 * i},{1000 * i + 500}')
+rows[1:] = rows[1:][::-1]      # file order is not dispatch order
 open(os.path.join(out, "1_counter_collection.csv"), "w").write("\n".join(rows) + "\n")
 """
 
@@ -855,14 +919,14 @@ open(os.path.join(out, "1_counter_collection.csv"), "w").write("\n".join(rows) +
 def test_same_run_traffic_reads_its_own_counter_passes(tmp_path, monkeypatch):
     """bench.same_run_traffic(): one rocprofv3 child per counter pass with the program straight after `--`, bytes per GEMM launch =
     (2 x FETCH_SIZE + WRITE_SIZE) x 1024 over gemm256 + gemm128 launches only, matrix-pipe busy of gemm256 alone; a failing pass raises (bench.py then
-    keeps the recorded profile and says so)."""
+    keeps the recorded profile and says so). The child runs the step twice and only the second, warm step's launches are counted."""
     import bench
     fake = tmp_path / "rocprofv3"
     fake.write_text(_FAKE_ROCPROFV3)
     fake.chmod(0o755)
     monkeypatch.setenv("PATH", f"{tmp_path}:{os.environ['PATH']}")
     r = bench.same_run_traffic(limit_s=30)
-    assert r["launches"] == 4                                             # 2 x gemm256 + 2 x gemm128 of the 6 kernels in the fake trace
+    assert r["launches"] == 4                                             # 2 x gemm256 + 2 x gemm128 of the 6 kernels of the fake trace's SECOND (warm) step
     assert r["fetch_bytes_per_launch_corrected"] == 2 * 1000.0 * 1024 and r["write_bytes_per_launch"] == 300.0 * 1024
     assert r["traffic"] == (2 * 1000.0 + 300.0) * 1024
     assert abs(r["gemm256"]["mfma_busy"] - 0.7) < 1e-12 and r["gemm256"]["launches"] == 2 and abs(r["gemm256"]["effective_clock_ghz"] - 2.0) < 1e-12

@@ -126,6 +126,40 @@ def test_gemm_rowmaps_inplace_grouped_lora(gpu):
     assert m["rel_l2"] <= 3e-3, m   # T = x A^T is rounded to bf16 between the two products (peft does the same in bf16)
 
 
+def test_gemm_a_row_maps_short_batches_and_broadcast(gpu):
+    """the 256^2 kernel's buffer-form DMA offsets are unsigned distances from a tile's first row. (a) rows-per-batch below the tile
+    height (a 256-row tile spans several batch jumps) on a shape the dispatcher gives to the 256^2 kernel (160 tiles) must read the right rows;
+    (b) a NON-monotonic map (batch stride 0 = one batch broadcast to all) on the same shape class must leave that kernel instead of wrapping its
+    offsets; (c) the fused q/k epilogue, which only exists in that kernel, refuses such a map."""
+    from unigen_amd import lib as L, ops
+    g = torch.Generator().manual_seed(9)
+    K, N = 256, 2048
+    w, b = _rand(g, N, K, scale=K ** -0.5), _rand(g, N, scale=0.1)
+    wd, bd = w.to(gpu), b.to(gpu)
+    # (a) 128 batches of 40 rows inside a [128, 72, K] buffer: M = 5120 = 20 row tiles, 6-7 batch jumps of 32 rows inside every tile
+    Bn, rpb, Lt = 128, 40, 72
+    abuf = _rand(g, Bn, Lt, K)
+    ref = ((abuf[:, 32:].float().reshape(Bn * rpb, K) @ w.float().t()) + b.float()).to(BF)
+    out = torch.empty(Bn * rpb, N, device=gpu, dtype=BF)
+    ops.gemm(abuf.to(gpu)[0, 32:], wd, bd, out, M=Bn * rpb, lda=K, a_map=ops.RowMap(rpb, Lt))
+    m = report("gemm_rowmap_short_batches", out, ref)
+    assert m["rel_l2"] <= TOL, m
+    # (b) one 320-row batch read by 16 logical batches (batch stride 0): M = 5120 again
+    rows = 320
+    a1 = _rand(g, rows, K)
+    ref = ((a1.float() @ w.float().t()) + b.float()).to(BF).repeat(16, 1)
+    out = torch.empty(16 * rows, N, device=gpu, dtype=BF)
+    ops.gemm(a1.to(gpu), wd, bd, out, M=16 * rows, lda=K, a_map=ops.RowMap(rows, 0))
+    m = report("gemm_rowmap_broadcast", out, ref)
+    assert m["rel_l2"] <= TOL, m
+    # (c)
+    wq = torch.ones(128, device=gpu, dtype=BF)
+    cs = torch.zeros(512, 64, 2, device=gpu); cs[..., 0] = 1.0
+    with pytest.raises(L.UniGenHipError, match="monotonic"):
+        ops.gemm(a1.to(gpu), wd, bd, torch.empty(512, N, device=gpu, dtype=BF), M=512, lda=K, a_map=ops.RowMap(256, 0),
+                 qk_rope=ops.QkRope(wq, wq, cs, 0, 0, 256, dh=128))
+
+
 def test_gemm_rejects_bad_args(gpu):
     from unigen_amd import lib as L, ops
     a = torch.zeros(8, 72, device=gpu, dtype=BF)

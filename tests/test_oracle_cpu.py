@@ -337,3 +337,88 @@ def test_topkgating_dense_form_equals_index_form(S, E, k):
     v = tos >= 0
     out[v] = x[tos[v]]
     assert torch.equal(torch.einsum("sec,sm->ecm", dm.float(), x), out)
+
+
+def test_eager_forward_at_the_faulting_token_count_writes_only_its_own_tensors():
+    """ADVICE r5 (the round-4 GPU fault of tests/eager_reference_timing.py --only eager --batch 2, "Write access to a read-only page"): the process ran
+    this oracle over the engine's PACKED state-dict views at B = 2, N = 4096, T = 512. On ROCm builds torch's device-side index asserts are compiled
+    out, so an out-of-range index or an in-place write into a packed / expanded parameter view would surface exactly like that. Here the same
+    forward - same input recipe, same token counts, the engine's own packed views as the state, reduced width and depth (no index or destination of
+    the oracle depends on them) - runs on the bounds-checked CPU build under a dispatch mode that checks EVERY aten call:
+      * a mutated argument (any `op_`, `out=`) never shares storage with a parameter or an input, and is not an expanded (stride-0) view;
+      * every integer index tensor handed to index / index_put / gather / scatter / index_select / index_add lies inside the indexed dimension.
+    It passes: the oracle writes only tensors it allocated itself and every index is in range, so the fault is not explained by this repository's
+    code; it stays attributed to a torch / ROCm kernel at those shapes (cause unidentified) and the script keeps refusing --batch > 1."""
+    import importlib
+    from torch.utils._python_dispatch import TorchDispatchMode
+    from unigen_amd.pipeline import prepare_latent_image_ids
+    cfg_d = dict(num_layers=2, num_single_layers=4, attention_head_dim=128, num_attention_heads=2, joint_attention_dim=64, pooled_projection_dim=64)
+    cls = importlib.import_module("src.UniGenTransformer").UniGenFlux
+    model = cls.from_config(cfg_d, device="cpu", dtype=torch.bfloat16)
+    model.init_condition_block(condition_nums=1, condition_types=["canny"], control_params=dict(
+        use_rope=True, use_shared_expert=True, use_consis_module=False, use_single_trans_blocks=True, single_control_dev=2,
+        single_block_control_method="overall_add", top_num=1, expert_num_each_condition=3))
+    model.init_synthetic_(seed=0, std=0.02)
+    # the groupings the inference engine makes on its first forward: the state dict then consists of views of packed buffers, as in the GPU process
+    for i in range(2):
+        for p in (f"transformer_blocks.{i}", ):
+            model._attn_qkv(p + ".attn"); model._attn_add_qkv(p + ".attn")
+    for j in range(4):
+        assert model._single_qkv_mlp(f"single_transformer_blocks.{j}") is not None
+    model._attn_qkv("control_joint_trans_blocks.0.attn"); model._attn_add_qkv("control_joint_trans_blocks.0.attn")
+    pe = "moe.moe_layer.experts.deepspeed_experts."
+    model._pack_stack("moe.wc", [f"{pe}{e}.0.0.weight" for e in range(6)])
+    state = dict(model.state_dict())
+    cfg = R.FluxConfig(**cfg_d)
+    B, grid, T = 2, 64, 512
+    N = grid * grid
+    g = torch.Generator().manual_seed(5)
+    rn = lambda *s: torch.randn(*s, generator=g)
+    BF = torch.bfloat16
+    inp = dict(hidden_states=rn(B, N, 64).to(BF), condition_hidden_states=rn(B, N, 64).to(BF), encoder_hidden_states=(0.1 * rn(B, T, 64)).to(BF),
+               pooled_projections=rn(B, 64).to(BF), condition_pooled_projections=rn(B, 64).to(BF))
+    ids = prepare_latent_image_ids(grid, grid, "cpu", BF)
+    txt = torch.zeros(T, 3, dtype=BF)
+    t = torch.full((B,), 0.75, dtype=BF)
+    uni = torch.rand(B * N, cfg.expert_nums, generator=g)
+    protected = {v.untyped_storage().data_ptr() for v in list(state.values()) + list(inp.values()) + [ids, txt, t, uni]}
+    seen = dict(mutating=0, indexed=0)
+    INDEXED = {"index.Tensor": None, "index_put_.default": None, "index_put.default": None, "_index_put_impl_.default": None, "gather.default": 1, "scatter_.value": 1,
+               "scatter_.src": 1, "scatter.value": 1, "scatter.src": 1, "index_select.default": 1, "index_add_.default": 1, "index_add.default": 1}
+
+    class Check(TorchDispatchMode):
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            kwargs = kwargs or {}
+            sch = func._schema
+            for i, a_ in enumerate(sch.arguments):
+                if a_.alias_info is not None and a_.alias_info.is_write:
+                    v = args[i] if i < len(args) else kwargs.get(a_.name)
+                    for tt in (v if isinstance(v, (list, tuple)) else [v]):
+                        if isinstance(tt, torch.Tensor):
+                            seen["mutating"] += 1
+                            assert tt.untyped_storage().data_ptr() not in protected, f"{func}: writes into a parameter / input storage"
+                            assert all(st != 0 or sz == 1 for st, sz in zip(tt.stride(), tt.shape)), f"{func}: writes into an expanded view"
+            name = str(func).replace("aten.", "")
+            if name in INDEXED:
+                seen["indexed"] += 1
+                src = args[0]
+                if INDEXED[name] is None:                    # index / index_put: a list of optional index tensors, one per leading dimension
+                    d = 0
+                    for ix in args[1]:
+                        if ix is None:
+                            d += 1
+                        elif ix.dtype == torch.bool:
+                            assert tuple(ix.shape) == tuple(src.shape[d:d + ix.dim()]), f"{func}: mask shape"
+                            d += ix.dim()
+                        else:
+                            assert ix.numel() == 0 or (int(ix.min()) >= -src.shape[d] and int(ix.max()) < src.shape[d]), f"{func}: index out of range on dim {d}"
+                            d += 1
+                else:
+                    dim, ix = args[1], args[2]
+                    assert ix.numel() == 0 or (int(ix.min()) >= -src.shape[dim] and int(ix.max()) < src.shape[dim]), f"{func}: index out of range"
+            return func(*args, **kwargs)
+
+    with torch.no_grad(), Check():
+        out = R.unigen_flux_forward(state, cfg, timestep=t, img_ids=ids, txt_ids=txt, condition_ids=ids, gate_uniform=uni, dtype=BF, **inp)[0]
+    assert out.shape == (B, N, 64) and torch.isfinite(out.float()).all()
+    assert seen["mutating"] > 10 and seen["indexed"] > 10, seen

@@ -267,7 +267,8 @@ def linear_n(x: torch.Tensor, ws, bs):
 class MoeGate(torch.autograd.Function):
     """gates = softmax(F.linear((x + c).float(), wg.float())) [S, E] fp32 and the arg-max expert per token: ug_moe_gate_top1 forward,
     ug_moe_gate_bwd backward (deepspeed TopKGate, src/UniGenUtils.py:99). top_k = 2 (top2gating): ug_moe_gate_top2, idx [2, S] with the second
-    choice drawn through `noise` (the Gumbel sample added to the logits). idx is not differentiable, and neither is the noised arg-max."""
+    choice drawn through `noise` (the Gumbel sample added to the logits). idx is not differentiable, and neither is the noised arg-max.
+    Third output: the fp32 logits [S, E] for top_k > 2 (topkgating's capacity rule ranks them; not differentiable), an empty tensor otherwise."""
 
     @staticmethod
     def forward(ctx, x, c, wg, top_k=1, noise=None):
@@ -285,13 +286,14 @@ class MoeGate(torch.autograd.Function):
             idx = torch.empty(top_k, S, device=x.device, dtype=torch.int32)
             logits = torch.empty(S, E, device=x.device, dtype=torch.float32)
             ops.moe_gate_topk(x, c, wgc, top_k, gates, logits, idx)
-            MoeGate.last_logits = logits           # read by training._route right after apply() (the capacity rule ranks logits; not differentiable)
+        if top_k <= 2:
+            logits = torch.empty(0, device=x.device, dtype=torch.float32)
         ctx.save_for_backward(gates, x, c, wgc)
-        ctx.mark_non_differentiable(idx)
-        return gates, idx
+        ctx.mark_non_differentiable(idx, logits)
+        return gates, idx, logits
 
     @staticmethod
-    def backward(ctx, dgates, _didx):
+    def backward(ctx, dgates, _didx, _dlogits):
         gates, x, c, wg = ctx.saved_tensors
         dxc, dwg = ops.moe_gate_bwd(gates, dgates.float().contiguous(), x, c, wg)
         return (dxc if ctx.needs_input_grad[0] else None), (dxc if ctx.needs_input_grad[1] else None), (dwg if ctx.needs_input_grad[2] else None), None, None

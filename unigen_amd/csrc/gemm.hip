@@ -980,8 +980,12 @@ int launch(const ug_gemm_desc& d, hipStream_t s) {
     const int f = forced_tile();
     if (f == 128) big = false;
     if (f == 256 && (!lora || (d.K >= 2 * BK && EPI != UG_EPI_F32))) big = true;
-    // the 256^2 kernel's buffer-form DMAs carry 32-bit byte offsets relative to the tile's first row: 255 rows plus at most one batch jump of the A row map
-    const int64_t a_jump = d.a_rpb > 0 && d.a_bstride > d.a_rpb ? d.a_bstride - d.a_rpb : 0;
+    // the 256^2 kernel's buffer-form DMAs carry UNSIGNED 32-bit byte offsets relative to the tile's first row: the A row map must be monotonic
+    // (batch stride >= rows per batch; a broadcasting map such as RowMap(N, 0) goes to the 128^2 kernel, which keeps per-lane pointers), and the
+    // offset spans 255 rows plus one batch jump per batch boundary inside the tile: ceil(255 / rows_per_batch) of them
+    if (!lora && d.a_rpb > 0 && d.a_bstride < d.a_rpb) big = false;
+    const int64_t a_jumps = d.a_rpb > 0 ? (255 + d.a_rpb - 1) / d.a_rpb : 0;
+    const int64_t a_jump = d.a_rpb > 0 && d.a_bstride > d.a_rpb ? (d.a_bstride - d.a_rpb) * a_jumps : 0;
     if (!lora && ((255 + a_jump) * d.lda + d.K) * 2 + 256 >= (int64_t)1 << 31) big = false;
     if (!lora && (255 * d.ldw + d.K) * 2 + 256 >= (int64_t)1 << 31) big = false;
     static bool attr_set = false;
@@ -1080,6 +1084,14 @@ int launch_qkrope(const ug_gemm_desc& d, hipStream_t s) {
         if (ncu <= 0) ncu = 256;
     }
     const int total = (int)((d.M / 256) * (d.N / 256));
+    {   // this epilogue only exists in the 256^2 kernel: its buffer-form A offsets need a monotonic row map and < 2^31 bytes per tile (see launch())
+        const int64_t a_jumps = d.a_rpb > 0 ? (255 + d.a_rpb - 1) / d.a_rpb : 0;
+        const int64_t a_jump = d.a_rpb > 0 && d.a_bstride > d.a_rpb ? (d.a_bstride - d.a_rpb) * a_jumps : 0;
+        UG_REQUIRE((d.a_rpb == 0 || d.a_bstride >= d.a_rpb) && ((255 + a_jump) * d.lda + d.K) * 2 + 256 < ((int64_t)1 << 31) &&
+                   (255 * d.ldw + d.K) * 2 + 256 < ((int64_t)1 << 31), UG_ERR_BAD_SHAPE,
+                   "ug_gemm_bf16: UG_EPI_QKV_ROPE needs a monotonic A row map (batch stride %lld >= rows per batch %lld) and tiles below 2^31 bytes",
+                   (long long)d.a_bstride, (long long)d.a_rpb);
+    }
     UG_REQUIRE(d.c_rpb % 256 == 0, UG_ERR_UNSUPPORTED, "ug_gemm_bf16: UG_EPI_QKV_ROPE needs the C row map's rows per batch (%lld) to be a multiple of 256",
                (long long)d.c_rpb);
 #ifdef UG_PROBE_BUILD

@@ -11,6 +11,7 @@ from torch import nn
 
 from . import lib as L
 from . import ops
+from .lora import LoRALayer, fuse_adapters
 from .ops import RowMap
 
 BF = torch.bfloat16
@@ -21,6 +22,19 @@ class _Holder(nn.Module):
 
     def forward(self, *a, **k):  # pragma: no cover
         raise L.UniGenHipError("parameter holder: unigen_amd modules are executed by the HIP engine, not called directly")
+
+
+class _LoRAHolder(_Holder, LoRALayer):
+    """The holder of a projection that carries LoRA adapters (HipModule.add_lora): the same `weight` / `bias` parameters plus
+    `lora_A.<adapter>.weight`, `lora_B.<adapter>.weight` and the PEFT layer attributes `enable_lora` reads."""
+
+    def __init__(self, plain: _Holder):
+        super().__init__()
+        for n, p_ in plain._parameters.items():         # the SAME Parameter objects: packed views, state-dict keys and optimiser references survive
+            self.register_parameter(n, p_)
+        for n, m in plain._modules.items():
+            self.add_module(n, m)
+        self._init_lora()
 
 
 def _register(root: nn.Module, name: str, shape: Tuple[int, ...], device, dtype) -> nn.Parameter:
@@ -124,6 +138,8 @@ class HipModule(nn.Module):
         self._packed: Dict[str, torch.Tensor] = {}
         self._emb_tab: Dict[str, torch.Tensor] = {}       # AdaLN linear outputs of the current step, by module prefix (_adaln_group)
         self.trainable_control_modules: Dict[str, nn.Module] = {}
+        self._lora_sites: Dict[str, _LoRAHolder] = {}     # projection prefix -> its adapter-carrying holder (add_lora)
+        self._lora_fused: Dict[Tuple, Tuple] = {}         # fused adapter operands per launch (prefixes + adapter state), see _lora_operands
 
     def _check_dtype(self, *inputs: torch.Tensor):
         """bf16 = the product path; fp32 = the verification path (every C-ABI call goes to its `_f32` twin, unigen_amd/ops.py).
@@ -181,6 +197,111 @@ class HipModule(nn.Module):
                     p.copy_(torch.randn(p.shape, generator=g, device=p.device, dtype=torch.float32) * std)
         return self
 
+    # ------------------------------------------------------------------ LoRA (A12) -------------------------------------
+    # The projections whose GEMM launches take the adapter K-segment (every attention / feed-forward projection of a joint or single block, in
+    # the base, control, shared-expert and consistency blocks alike). PEFT matches `target_modules` by module-name suffix; a suffix that hits a
+    # parameter the engine runs another way (AdaLN linears, embedders, experts, zero-res projections) is refused rather than silently ignored.
+    LORA_CAPABLE = ("attn.to_q", "attn.to_k", "attn.to_v", "attn.add_q_proj", "attn.add_k_proj", "attn.add_v_proj", "attn.to_out.0", "attn.to_add_out",
+                    "attn2.to_q", "attn2.to_k", "attn2.to_v", "attn2.to_out.0", "ff.net.0.proj", "ff.net.2", "ff_context.net.0.proj", "ff_context.net.2",
+                    "proj_mlp", "proj_out")
+
+    def add_lora(self, target_suffixes: Sequence[str], adapter_name: str, r: int, lora_alpha: float, A=None, B=None, prefix: str = "",
+                 init_lora_weights: bool = True, seed: int = 0) -> Sequence[str]:
+        """Attach the LoRA adapter `adapter_name` (rank r, scaling lora_alpha / r) to every projection whose module name ends with one of
+        `target_suffixes` (PEFT's `target_modules` rule: name == key or name.endswith("." + key)) and starts with `prefix` (e.g.
+        "control_joint_trans_blocks." for the per-condition adapters of the control branch). The projection's holder becomes a PEFT-shaped layer
+        (`lora_A`, `lora_B`, `scaling`, `active_adapters`, `set_scale`) that `enable_lora(list(model.modules()), [...])`
+        (src/lora_switching_module.py:11-38) switches; the engines' GEMM launches for that weight take the live adapters as a K-segment of the base
+        product (`ug_gemm_desc.lora_T / lora_B`). A / B: None (PEFT's initial values: A uniform, B zero - or B random too with
+        init_lora_weights=False, PEFT's testing mode), or {module name: tensor}. Returns the module names that received the adapter.
+        No adapter attached -> nothing changes anywhere (bit-identical outputs, same launches)."""
+        hits = []
+        for name, mod in list(self.named_modules()):
+            if not name.startswith(prefix) or not any(name == t or name.endswith("." + t) for t in target_suffixes):
+                continue
+            w = mod._parameters.get("weight")
+            if w is None or w.dim() != 2:
+                continue
+            if not any(name == c or name.endswith("." + c) for c in self.LORA_CAPABLE) or name == "proj_out" or ".experts." in name:
+                raise L.UniGenHipError(f"add_lora: {name} is not a projection the HIP engine can extend with an adapter K-segment "
+                                       f"(supported suffixes: {', '.join(self.LORA_CAPABLE)} inside transformer blocks)")
+            hits.append(name)
+        if not hits:
+            raise ValueError(f"add_lora: no module under prefix {prefix!r} matches {list(target_suffixes)}")
+        g = torch.Generator().manual_seed(seed)
+        for name in hits:
+            parent_name, _, leaf = name.rpartition(".")
+            parent = self.get_submodule(parent_name) if parent_name else self
+            mod = parent._modules[leaf]
+            if not isinstance(mod, _LoRAHolder):
+                mod = _LoRAHolder(mod)
+                parent._modules[leaf] = mod
+                self._lora_sites[name] = mod
+            a = A.get(name) if isinstance(A, dict) else A
+            b = B.get(name) if isinstance(B, dict) else B
+            if b is None and not init_lora_weights:
+                b = torch.randn(mod.weight.shape[0], r, generator=g) * 0.02
+            mod.add_adapter(adapter_name, r, lora_alpha, A=a, B=b, generator=g)
+        self._pname_cache = None
+        self._lora_fused.clear()
+        return hits
+
+    def _lora_scaled(self, joint_attention_kwargs):
+        """`scale_lora_layers(self, lora_scale)` ... `unscale_lora_layers(self, lora_scale)` around a forward (src/UniGenTransformer.py:1200-1208,
+        1266-1269; diffusers 0.32.2 utils/peft_utils.py): `joint_attention_kwargs["scale"]` multiplies every adapter's scaling for the duration of
+        the forward; 1.0 (or no adapter-carrying projection) is a no-op, 0 is undone by `set_scale(adapter, 1.0)`."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            w = (joint_attention_kwargs or {}).get("scale", 1.0)
+            on = bool(self._lora_sites) and w is not None and w != 1.0
+            if on:
+                for m in self._lora_sites.values():
+                    m.scale_layer(w)
+            try:
+                yield
+            finally:
+                if on:
+                    for m in self._lora_sites.values():
+                        if w != 0:
+                            m.unscale_layer(w)
+                        else:
+                            for a in m.active_adapters:
+                                m.set_scale(a, 1.0)
+        return cm()
+
+    def _refuse_lora_in_training(self):
+        if self._lora_sites and any(m.live_adapters() for m in self._lora_sites.values()):
+            raise NotImplementedError("the differentiable forward (unigen_amd/training.py) does not carry LoRA adapters: run under torch.no_grad(), "
+                                      "or disable them (enable_lora(modules, []))")
+
+    def _lora_live(self, prefixes: Sequence[str]) -> bool:
+        """Does any projection of this launch carry an adapter that contributes right now?"""
+        if not self._lora_sites:
+            return False
+        return any(p in self._lora_sites and self._lora_sites[p].live_adapters() for p in prefixes)
+
+    def _lora_operands(self, prefixes: Sequence[str], a: torch.Tensor, M: int, tag: str, lda: Optional[int] = None, a_map: RowMap = ops.IDENT):
+        """(T, B) for ONE launch over the row-concatenated weights of `prefixes` (the fused q|k|v[|proj_mlp] launch, or a single projection):
+        T = a A_cat^T [M, R] - ONE GEMM for all live adapters of all projections of the launch - and the block-diagonal, scaling-folded B [N, R]
+        (lora.fuse_adapters). (None, None) when no adapter is live: the caller's launch is then exactly the adapter-free one."""
+        if not self._lora_live(prefixes):
+            return None, None
+        sites = [self._lora_sites.get(p) for p in prefixes]
+        state = tuple((p, tuple((n, s.scaling[n], s.lora_A[n].weight._version, s.lora_B[n].weight._version, s.lora_A[n].weight.data_ptr())
+                                for n in s.live_adapters())) for p, s in zip(prefixes, sites) if s is not None)
+        key = (tuple(prefixes), self.dtype)
+        hit = self._lora_fused.get(key)
+        if hit is None or hit[0] != state:
+            widths = [self.get_parameter(p + ".weight").shape[0] for p in prefixes]
+            hit = (state,) + fuse_adapters(sites, widths, self.dtype, self.device)
+            self._lora_fused[key] = hit
+        A_cat, B_bd = hit[1], hit[2]
+        t = self._w("lora_t_" + tag, (M, A_cat.shape[0]))
+        ops.gemm(a, A_cat, None, t, M=M, lda=lda, a_map=a_map)
+        return t, B_bd
+
     # ------------------------------------------------------------------ weight packing --------------------------------
     @staticmethod
     def _storage_moved():
@@ -191,6 +312,7 @@ class HipModule(nn.Module):
     def _apply(self, fn, *a, **k):
         r = super()._apply(fn, *a, **k)          # .to() / .cuda() / .float(): every parameter gets new storage
         self._storage_moved()
+        self._lora_fused.clear()
         return r
 
     def _P(self, name: str) -> torch.Tensor:
@@ -405,9 +527,12 @@ class HipModule(nn.Module):
         w_qkv, b_qkv = self._attn_qkv(a)
         # sample rows: q / k RMSNorm + RoPE in the projection's epilogue when the shapes allow it (whole 256^2 tiles, heads of 128)
         cs = getattr(rope, "cs", None)
-        fused = (wq is not None and (cs is not None or (cos is None and dh == 64)) and ops.qk_rope_fusable(B * Ls, 3 * D, 2 * D, dh, ns.dtype))
+        # live LoRA adapters of to_q / to_k / to_v: T = ns A_cat^T in one GEMM, then the K-segment of this launch (the q/k RMSNorm + RoPE then
+        # runs as its own kernel: UG_EPI_QKV_ROPE is not LoRA-extended)
+        lt, lb = self._lora_operands([a + ".to_q", a + ".to_k", a + ".to_v"], ns, B * Ls, "s")
+        fused = (lt is None and wq is not None and (cs is not None or (cos is None and dh == 64)) and ops.qk_rope_fusable(B * Ls, 3 * D, 2 * D, dh, ns.dtype))
         ops.gemm(ns, w_qkv, b_qkv, qkv2[Lc:], M=B * Ls, ldc=3 * D, c_map=RowMap(Ls, Lj),
-                 qk_rope=ops.QkRope(wq, wk, cs, Ls, Lc, 2 * D, dh=dh) if fused else None)
+                 qk_rope=ops.QkRope(wq, wk, cs, Ls, Lc, 2 * D, dh=dh) if fused else None, lora_t=lt, lora_b=lb)
         # context stream
         emb_c = None
         if c_out is not None or not ctx_cached:
@@ -419,9 +544,11 @@ class HipModule(nn.Module):
                 nc = self._modulate(c_in, emb_c, 0, 1, B, "c")
             w_a, b_a = self._attn_add_qkv(a)
             if c_out is not None:
-                ops.gemm(nc, w_a, b_a, qkv2, M=B * Lc, ldc=3 * D, c_map=RowMap(Lc, Lj))
+                lt, lb = self._lora_operands([a + ".add_q_proj", a + ".add_k_proj", a + ".add_v_proj"], nc, B * Lc, "c")
+                ops.gemm(nc, w_a, b_a, qkv2, M=B * Lc, ldc=3 * D, c_map=RowMap(Lc, Lj), lora_t=lt, lora_b=lb)
             else:
-                ops.gemm(nc, w_a[D:], b_a[D:], qkv2[0, D:], M=B * Lc, ldc=3 * D, c_map=RowMap(Lc, Lj))
+                lt, lb = self._lora_operands([a + ".add_k_proj", a + ".add_v_proj"], nc, B * Lc, "c")
+                ops.gemm(nc, w_a[D:], b_a[D:], qkv2[0, D:], M=B * Lc, ldc=3 * D, c_map=RowMap(Lc, Lj), lora_t=lt, lora_b=lb)
         if touch:
             if c_out is not None and not fused:
                 ops.qk_rmsnorm_rope(qkv2, batches=B, rows_per_batch=Lj, ld=3 * D, q_off=0, k_off=D, heads=H, dh=dh, wq_a=waq, wk_a=wak,
@@ -449,32 +576,36 @@ class HipModule(nn.Module):
                            v_strides=st, o_strides=(D, Ls * D))
             att_s, att_map = att, RowMap()
         # sample: x = x + gate_msa * to_out(attn)
+        lt, lb = self._lora_operands([a + ".to_out.0"], att_s, B * Ls, "o", lda=D, a_map=att_map)
         ops.gemm(att_s, self._P(a + ".to_out.0.weight"), self._P(a + ".to_out.0.bias"), s_out.base, M=B * Ls, epilogue=L.EPI_RES_GATE, lda=D,
                  a_map=att_map, ldc=s_out.ld, c_map=s_out.map, residual=s_in.base, ldr=s_in.ld, r_map=s_in.map, gate=emb_s[:, 2 * D:],
-                 gate_ld=emb_s.stride(0), rows_per_sample=Ls)
+                 gate_ld=emb_s.stride(0), rows_per_sample=Ls, lora_t=lt, lora_b=lb)
         if dual:
             # x = x + gate_msa2 * attn2(LN(x_in) * (1 + scale_msa2) + shift_msa2): self-attention over the sample tokens only
             a2 = p + ".attn2"
             q2 = self._w("qkv2_" + tag, (B * Ls, 3 * D))
             w2, b2 = self._attn_qkv(a2)
             w2q, w2k = opt(a2 + ".norm_q.weight"), opt(a2 + ".norm_k.weight")
-            fused2 = w2q is not None and dh == 64 and ops.qk_rope_fusable(B * Ls, 3 * D, 2 * D, dh, n2.dtype)     # attn2 has no RoPE
-            ops.gemm(n2, w2, b2, q2, M=B * Ls, qk_rope=ops.QkRope(w2q, w2k, None, Ls, 0, 2 * D, dh=dh) if fused2 else None)
+            lt, lb = self._lora_operands([a2 + ".to_q", a2 + ".to_k", a2 + ".to_v"], n2, B * Ls, "s")
+            fused2 = lt is None and w2q is not None and dh == 64 and ops.qk_rope_fusable(B * Ls, 3 * D, 2 * D, dh, n2.dtype)     # attn2 has no RoPE
+            ops.gemm(n2, w2, b2, q2, M=B * Ls, qk_rope=ops.QkRope(w2q, w2k, None, Ls, 0, 2 * D, dh=dh) if fused2 else None, lora_t=lt, lora_b=lb)
             if w2q is not None and not fused2:
                 ops.qk_rmsnorm_rope(q2, batches=B, rows_per_batch=Ls, ld=3 * D, q_off=0, k_off=D, heads=H, dh=dh, wq_b=w2q, wk_b=w2k, split=0)
             att2 = self._w("att2_" + tag, (B * Ls, D))
             st2 = (3 * D, Ls * 3 * D)
             ops.flash_attn(q2, q2[0, D:], q2[0, 2 * D:], att2, batches=B, heads=H, dh=dh, Lq=Ls, Lkv=Ls, q_strides=st2, k_strides=st2,
                            v_strides=st2, o_strides=(D, Ls * D))
+            lt, lb = self._lora_operands([a2 + ".to_out.0"], att2, B * Ls, "o")
             ops.gemm(att2, self._P(a2 + ".to_out.0.weight"), self._P(a2 + ".to_out.0.bias"), s_out.base, M=B * Ls, epilogue=L.EPI_RES_GATE,
                      ldc=s_out.ld, c_map=s_out.map, residual=s_out.base, ldr=s_out.ld, r_map=s_out.map, gate=emb_s[:, 8 * D:],
-                     gate_ld=emb_s.stride(0), rows_per_sample=Ls)
+                     gate_ld=emb_s.stride(0), rows_per_sample=Ls, lora_t=lt, lora_b=lb)
         # x = x + gate_mlp * ff(norm2(x) * (1 + scale_mlp) + shift_mlp)
         self._ff(p + ".ff", B, s_out, emb_s, "s")
         if c_out is not None:
+            lt, lb = self._lora_operands([a + ".to_add_out"], att, B * Lc, "o", lda=D, a_map=RowMap(Lc, Lj))
             ops.gemm(att, self._P(a + ".to_add_out.weight"), self._P(a + ".to_add_out.bias"), c_out.base, M=B * Lc, epilogue=L.EPI_RES_GATE, lda=D,
                      a_map=RowMap(Lc, Lj), ldc=c_out.ld, c_map=c_out.map, residual=c_in.base, ldr=c_in.ld, r_map=c_in.map, gate=emb_c[:, 2 * D:],
-                     gate_ld=emb_c.stride(0), rows_per_sample=Lc)
+                     gate_ld=emb_c.stride(0), rows_per_sample=Lc, lora_t=lt, lora_b=lb)
             self._ff(p + ".ff_context", B, c_out, emb_c, "c")
 
     def _pnames(self):
@@ -488,7 +619,9 @@ class HipModule(nn.Module):
         D = self.inner_dim
         n2 = self._modulate(s, emb, 3, 4, B, tag)
         hid = self._w("ffh_" + tag, (B * s.Ls, 4 * D))
-        ops.gemm(n2, self._P(p + ".net.0.proj.weight"), self._P(p + ".net.0.proj.bias"), hid, M=B * s.Ls, epilogue=L.EPI_BIAS_GELU)
+        lt, lb = self._lora_operands([p + ".net.0.proj"], n2, B * s.Ls, "f0")
+        ops.gemm(n2, self._P(p + ".net.0.proj.weight"), self._P(p + ".net.0.proj.bias"), hid, M=B * s.Ls, epilogue=L.EPI_BIAS_GELU, lora_t=lt, lora_b=lb)
+        lt, lb = self._lora_operands([p + ".net.2"], hid, B * s.Ls, "f2")
         ops.gemm(hid, self._P(p + ".net.2.weight"), self._P(p + ".net.2.bias"), s.base, M=B * s.Ls, epilogue=L.EPI_RES_GATE, ldc=s.ld, c_map=s.map,
-                 residual=s.base, ldr=s.ld, r_map=s.map, gate=emb[:, 5 * D:], gate_ld=emb.stride(0), rows_per_sample=s.Ls)
+                 residual=s.base, ldr=s.ld, r_map=s.map, gate=emb[:, 5 * D:], gate_ld=emb.stride(0), rows_per_sample=s.Ls, lora_t=lt, lora_b=lb)
 

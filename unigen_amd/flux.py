@@ -301,22 +301,28 @@ class UniGenFlux(HipModule):
         if packed is not None:
             w7, b7 = packed
             # q / k RMSNorm + RoPE ride in the same launch's epilogue when the shapes allow (whole 256^2 tiles)
-            fused = cs is not None and ops.qk_rope_fusable(B * Lj, 7 * D, 2 * D, dh, n.dtype)
+            # live LoRA adapters of the four projections: ONE T = n A_cat^T for all of them, then the K-segment of this launch (engine._lora_operands)
+            lt, lb = self._lora_operands([a + ".to_q", a + ".to_k", a + ".to_v", p + ".proj_mlp"], n, B * Lj, "j")
+            fused = lt is None and cs is not None and ops.qk_rope_fusable(B * Lj, 7 * D, 2 * D, dh, n.dtype)
             ops.gemm(n, w7, b7, sb, M=B * Lj, ldc=8 * D, epilogue=L.EPI_BIAS_GELU, gelu_from_n=3 * D, c_shift_from_n=3 * D, c_shift=D,
-                     qk_rope=ops.QkRope(wq, wk, cs, Lj, 0, 2 * D, dh=dh) if fused else None)
+                     qk_rope=ops.QkRope(wq, wk, cs, Lj, 0, 2 * D, dh=dh) if fused else None, lora_t=lt, lora_b=lb)
         else:
             w_qkv, b_qkv = self._attn_qkv(a)
-            ops.gemm(n, w_qkv, b_qkv, sb, M=B * Lj, ldc=8 * D)
-            ops.gemm(n, self._P(p + ".proj_mlp.weight"), self._P(p + ".proj_mlp.bias"), sb[0, 4 * D:], M=B * Lj, epilogue=L.EPI_BIAS_GELU, ldc=8 * D)
+            lt, lb = self._lora_operands([a + ".to_q", a + ".to_k", a + ".to_v"], n, B * Lj, "j")
+            ops.gemm(n, w_qkv, b_qkv, sb, M=B * Lj, ldc=8 * D, lora_t=lt, lora_b=lb)
+            lt, lb = self._lora_operands([p + ".proj_mlp"], n, B * Lj, "jm")
+            ops.gemm(n, self._P(p + ".proj_mlp.weight"), self._P(p + ".proj_mlp.bias"), sb[0, 4 * D:], M=B * Lj, epilogue=L.EPI_BIAS_GELU, ldc=8 * D,
+                     lora_t=lt, lora_b=lb)
         if not fused:
             ops.qk_rmsnorm_rope(sb, batches=B, rows_per_batch=Lj, ld=8 * D, q_off=0, k_off=D, heads=H, dh=dh, wq_b=wq, wk_b=wk, split=0,
                                 cos=cos, sin=sin)
         st = (8 * D, Lj * 8 * D)
         ops.flash_attn(sb, sb[0, D:], sb[0, 2 * D:], sb[0, 3 * D:], batches=B, heads=H, dh=dh, Lq=Lj, Lkv=Lj, q_strides=st, k_strides=st,
                        v_strides=st, o_strides=st)
+        lt, lb = self._lora_operands([p + ".proj_out"], sb[0, 3 * D:], B * Lj, "jo", lda=8 * D)
         ops.gemm(sb[0, 3 * D:], self._P(p + ".proj_out.weight"), self._P(p + ".proj_out.bias"), h_out.base, M=B * Lj, epilogue=L.EPI_RES_GATE,
                  lda=8 * D, ldc=h_out.ld, c_map=h_out.map, residual=h_in.base, ldr=h_in.ld, r_map=h_in.map, gate=emb[:, 2 * D:],
-                 gate_ld=emb.stride(0), rows_per_sample=Lj)
+                 gate_ld=emb.stride(0), rows_per_sample=Lj, lora_t=lt, lora_b=lb)
 
     # ------------------------------------------------------------------ CoMoE -----------------------------------------
     def _comoe(self, B: int, N: int, T: int, x: torch.Tensor, cond_tokens: torch.Tensor, ctrl_enc: torch.Tensor, control_temb: torch.Tensor,
@@ -419,8 +425,9 @@ class UniGenFlux(HipModule):
         train.py:622-662 after `init_trainable_param()` - the differentiable forward of unigen_amd/training.py. Same arguments, same 3-tuple."""
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             from . import training
+            self._refuse_lora_in_training()
             return training.flux_forward(self, *args, **kwargs)
-        with torch.no_grad():
+        with torch.no_grad(), self._lora_scaled(kwargs.get("joint_attention_kwargs")):
             return self._forward_inference(*args, **kwargs)
 
     def _forward_inference(self, hidden_states: torch.Tensor, condition_hidden_states=None, conditioning_scale: float = 1.0,

@@ -351,8 +351,9 @@ class UniGenSD3(HipModule):
         `init_trainable_param()` - the differentiable forward of unigen_amd/training.py. Same arguments, same 3-tuple."""
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             from . import training
+            self._refuse_lora_in_training()
             return training.sd3_forward(self, *args, **kwargs)
-        with torch.no_grad():
+        with torch.no_grad(), self._lora_scaled(kwargs.get("joint_attention_kwargs")):
             return self._forward_inference(*args, **kwargs)
 
     def _forward_inference(self, hidden_states: torch.Tensor, condition_hidden_states: torch.Tensor = None, conditioning_scale: float = 1.0,

@@ -176,7 +176,7 @@ def _route(model, x, c, uniform):
     if K == 1:
         C = max(int(math.ceil(S / E)), 4)
         # gate logits / softmax / arg-max and their backward: HIP kernels (round 2 ran F.linear + F.softmax here: vendor BLAS on a product path)
-        gates, idx = A.MoeGate.apply(x2, c2, wg)
+        gates, idx, _ = A.MoeGate.apply(x2, c2, wg)
         if uniform is None:
             uniform = torch.rand(S, E, device=dev, dtype=torch.float32)
         slot, tos = torch.empty(S, device=dev, dtype=torch.int32), torch.empty(E, C, device=dev, dtype=torch.int32)
@@ -187,8 +187,7 @@ def _route(model, x, c, uniform):
         w = (gates.gather(1, idx.long().unsqueeze(1)).squeeze(1) * kept[0].float()).to(x.dtype).unsqueeze(0)      # combine weight, rounded as `cw.to(dt)`
     elif K > 2:                                          # deepspeed topkgating: no random draw; the capacity rule ranks the chosen LOGITS against zeros
         C = max(int(math.ceil((S / E) * float(K))), 4)
-        gates, idx = A.MoeGate.apply(x2, c2, wg, K, None)
-        logits = A.MoeGate.last_logits
+        gates, idx, logits = A.MoeGate.apply(x2, c2, wg, K, None)
         slot, tos = torch.empty(K, S, device=dev, dtype=torch.int32), torch.empty(E, C, device=dev, dtype=torch.int32)
         w_dev = torch.empty(K, S, device=dev, dtype=torch.float32)
         ops.moe_capacity_topk(gates.detach().contiguous(), logits, idx, C, slot, tos, w_dev, exp_counts, l_aux_k)
@@ -202,7 +201,7 @@ def _route(model, x, c, uniform):
         C = max(int(math.ceil((S / E) * 2.0)), 4)
         if uniform is None:                            # gumbel_rsample
             uniform = torch.distributions.gumbel.Gumbel(torch.tensor(0.0, device=dev), torch.tensor(1.0, device=dev)).rsample((S, E))
-        gates, idx = A.MoeGate.apply(x2, c2, wg, 2, uniform.to(torch.float32).contiguous())
+        gates, idx, _ = A.MoeGate.apply(x2, c2, wg, 2, uniform.to(torch.float32).contiguous())
         slot, tos = torch.empty(2, S, device=dev, dtype=torch.int32), torch.empty(E, C, device=dev, dtype=torch.int32)
         w_dev = torch.empty(2, S, device=dev, dtype=torch.float32)      # the kernel's weights: not on the tape, recomputed below from `gates`
         ops.moe_capacity_top2(gates.detach().contiguous(), idx, C, slot, tos, w_dev, exp_counts, l_aux_k)
