@@ -622,11 +622,12 @@ def measure_small_m(model, name, rank, dev, ops, pk16, pk32, steps=2, warmup=1):
     M = 4608 joint rows), `cfg1_gpu` = configs[0]'s geometry on the GPU (512^2: N = 1024, M = 1536). 1 warm-up + 2 passes of the 4-step loop."""
     grid = dict(b1_1024=64, cfg1_gpu=32)[name]
     _, one_step, _ = _flux_workload_inputs_only(model, 1, rank, dev, grid=grid)
-    timer = ops.KernelTimer()
     per_pass = []
-    elapsed, _, _ = _timed(one_step, steps, warmup, dev, 1, timer, ops, per_pass=per_pass)
-    s = timer.summary()
+    elapsed, _, _ = _timed(one_step, steps, warmup, dev, 1, None, ops, per_pass=per_pass)      # no kernel timer here: its two events per launch are host work too
     value = steps / elapsed
+    timer = ops.KernelTimer()
+    t_elapsed, _, _ = _timed(one_step, 1, 0, dev, 1, timer, ops)                                 # one more pass under the timer for the kernels' own rates
+    s = timer.summary()
     n_d, n_s = model.config.num_layers, model.config.num_single_layers
     fl_img = 4 * canonical_flops_per_forward(model.inner_dim, grid * grid, 512, n_d, n_s, model._ctl.cn_joint_layers, model._ctl.cn_single_layers, 1)
     what = {"b1_1024": "UniGenFlux canny, 1024x1024, batch=1 (the reference's script/infer.sh launch shape), N=4096 + T=512, 4 steps",
@@ -637,7 +638,24 @@ def measure_small_m(model, name, rank, dev, ops, pk16, pk32, steps=2, warmup=1):
              passes=_pass_stats(1, per_pass))
     if pk16:
         d["e2e_frac_of_measured"] = value * fl_img / (pk16 * 1e12)
-    d.update(_roofline_blocks(s, elapsed, pk16, pk32, "flash_attn_kernel<128> (ug_flash_attn_fwd)"))
+    d.update(_roofline_blocks(s, t_elapsed, pk16, pk32, "flash_attn_kernel<128> (ug_flash_attn_fwd)"))
+    d["gemm_and_attention_launches_per_image"] = int(sum(v["launches"] for v in s.values()))
+    d["gemm_and_attention_kernel_ms_per_image"] = sum(v["ms"] for v in s.values())
+    # The same loop captured once in a HIP graph and replayed (`--graph`): at batch 1 a forward is ~1.5 k launches of tens of
+    # microseconds each, so the host's launch rate (Python + ctypes per call), not the kernels, can pace the plain loop; the replay has no host in it.
+    try:
+        torch.cuda.synchronize(dev)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            g_out = one_step()
+        gp = []
+        _timed(lambda: (graph.replay(), g_out)[1], steps, 1, dev, 1, None, ops, per_pass=gp)
+        best = min(gp)
+        d["hip_graph"] = dict(value=1.0 / best, unit="images/s", ms_per_step=1000.0 * best, e2e_mfma_frac=fl_img / best / (MFMA_BF16_PEAK_TFLOPS * 1e12),
+                              passes=_pass_stats(1, gp), note="one 4-step loop captured in a HIP graph, replayed; best of the passes")
+        del graph, g_out
+    except Exception as e:                                   # the plain numbers above stand on their own
+        d["hip_graph"] = dict(error=f"{type(e).__name__}: {e}")
     return d
 
 

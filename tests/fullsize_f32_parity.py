@@ -76,6 +76,7 @@ with torch.no_grad():
     out32 = m32(timestep=t.to(dev), **{k: (mv(v) if k == "gate_uniform" else mv(v, torch.float32)) for k, v in inp.items()})[0].cpu()
     torch.cuda.synchronize(); res["hip_f32_s"] = round(time.perf_counter() - t0, 1)
     del m32
+    torch.cuda.empty_cache()          # the fp32 oracle below runs for minutes on the host: the GPU memory goes back first (the suite runs beside this child)
     st32 = {k: (v.float() if v.is_floating_point() else v) for k, v in st16.items()}
     del st16
     print("hip f32 done", res, flush=True)

@@ -418,7 +418,7 @@ def test_fused_qk_rope_forward_vs_fp32_verification(gpu, monkeypatch):
 
 
 @pytest.mark.parametrize("which", ["flux64", "multi", "sd3"])
-def test_full_model_forward_parity(gpu, which):
+def test_full_model_forward_parity(gpu, which, fullsize_child):
     """ONE forward of the FULL model against the CPU oracle on the same 18.8 B synthetic parameters (tests/fullsize_f32_parity.py, run in a child
     process so that its ~120 GB of host copies are returned at once): the fp32 verification path must meet the north star's 1e-3 against the fp32
     oracle, and the bf16 product path must be as close to that truth as the oracle's own bf16 evaluation.
@@ -426,12 +426,11 @@ def test_full_model_forward_parity(gpu, which):
               T = 512, B = 1; round 2 measured 9.95e-5 and 2.12e-2 vs 2.11e-2; the N = 1024 case it replaces measured 9.2e-5);
     "multi":  MultiCondtionUniGenFlux, depth + canny + openpose (cfg3's model: E = 12, per-condition CoMoE summed), N = 1024 (1.0e-4, 1.936e-2 vs 1.944e-2);
     "sd3":    UniGenSD3 at SD3.5-medium size (24 joint blocks with dual attention in 0-12, D = 1536, 24 heads of 64; N = 1024, T = 333)."""
-    import json, os, subprocess, sys
+    import json, os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    argv = {"flux64": ["flux", "64", "--no-ref16"], "multi": ["multi", "--no-ref16"], "sd3": ["sd3"]}[which]
-    p = subprocess.run([sys.executable, os.path.join(root, "tests", "fullsize_f32_parity.py"), *argv], capture_output=True, text=True, timeout=1100, cwd=root)
-    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
-    line = [l for l in p.stdout.splitlines() if l.startswith("FULLSIZE_PARITY")][-1]
+    p = fullsize_child()            # tests/fullsize_f32_parity.py {flux 64 --no-ref16 | multi --no-ref16 | sd3}: started beside the suite (tests/conftest.py)
+    assert p["returncode"] == 0, p["stdout"][-2000:] + p["stderr"][-2000:]
+    line = [l for l in p["stdout"].splitlines() if l.startswith("FULLSIZE_PARITY")][-1]
     r = json.loads(line[len("FULLSIZE_PARITY "):])
     print(line)
     assert r["rel_l2_hip_f32_vs_oracle_f32"] <= 1e-3, r
@@ -445,16 +444,15 @@ def test_full_model_forward_parity(gpu, which):
         assert r["rel_l2_hip_bf16_vs_oracle_f32"] <= 1.25 * rec["rel_l2_oracle_bf16_vs_oracle_f32"] + 1e-3, (r, rec)
 
 
-def test_full_depth_gradient_parity(gpu):
+def test_full_depth_gradient_parity(gpu, fullsize_child):
     """ONE training step at the FULL depth and width (19 + 38 base blocks, 9 + 19 control blocks, D = 3072; 512^2, N = 1024, T = 512, B = 1; reference
     train.py:622-662) against torch autograd of the CPU oracle in fp32, same weights / inputs / RTS draw / target (tests/fullsize_train_parity.py in a
     child process): gradients of all 743 trainable parameters (6.89 B elements) through the fp32 verification twins within 1e-3 (round 2 measured
     3.5e-5), the bf16 product path within 3e-2 (8.5e-3), the losses equal to 1e-5, parameters behind discarded outputs exactly zero."""
-    import json, os, subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    p = subprocess.run([sys.executable, os.path.join(root, "tests", "fullsize_train_parity.py")], capture_output=True, text=True, timeout=1100, cwd=root)
-    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
-    line = [l for l in p.stdout.splitlines() if l.startswith("FULLSIZE_TRAIN_PARITY")][-1]
+    import json
+    p = fullsize_child()            # tests/fullsize_train_parity.py, started beside the suite (tests/conftest.py)
+    assert p["returncode"] == 0, p["stdout"][-2000:] + p["stderr"][-2000:]
+    line = [l for l in p["stdout"].splitlines() if l.startswith("FULLSIZE_TRAIN_PARITY")][-1]
     r = json.loads(line[len("FULLSIZE_TRAIN_PARITY "):])
     print(line)
     assert r["parameters_trainable"] > 700 and r["elements"] > 6_000_000_000

@@ -1,13 +1,28 @@
 """Where an attention-forward workgroup's time goes: s_memtime stamps of a -DUG_ATTN_STAMPS build of attention.hip (kernel entry, end of the
 prologue, end of the tile loop, end of the epilogue, per wave group; the CU it ran on), written into the buffer passed as the log-sum-exp output.
-Build:  hipcc -DUG_ATTN_STAMPS ... attention.hip  linked with the other objects into tools/probe/bin/libunigen_attn_stamps.so
-run:    UG_LIB_PATH=tools/probe/bin/libunigen_attn_stamps.so python tools/attn_stamps.py
+Build:  python tools/attn_stamps.py --build     (hipcc -DUG_ATTN_STAMPS attention.hip, linked with the product's other objects into tools/probe/bin/libunigen_attn_stamps.so)
+run:    UG_LIB_PATH=tools/probe/bin/libunigen_attn_stamps.so python tools/attn_stamps.py [64|128]
+Round 6: per wave group the stagger loop's time split into its four segments, summed over the tiles in the kernel (UG_SEG accumulators): Y = the
+softmax segment (group B: incl. the issue of its LDS-DMAs), barrier behind Y, X = the matrix segment P.V + K.Q^T (group B: incl. its DMA wait),
+barrier behind X. A wave that waits long at a barrier is waiting for the OTHER group's segment.
 Per shape, medians over workgroups (group A = waves 0-3, group B = waves 4-7, one segment behind):
   prologue = entry -> first S^T segment may start      loop = the tile loop      epilogue = loop end -> O stores issued (A: incl. its trailing barrier)
   gap      = on one CU: a workgroup's entry minus the previous workgroup's last epilogue end (dispatch of the next workgroup)
   span     = first entry -> last end on a CU, against the sum of its workgroups' in-kernel times"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+if "--build" in sys.argv:
+    import subprocess
+    from unigen_amd import build as Bd
+    Bd.build()                                                      # the product objects the stamp library links against
+    out = os.path.join(ROOT, "tools", "probe", "bin"); os.makedirs(out, exist_ok=True)
+    obj = os.path.join(out, "attention_stamps.o")
+    subprocess.run([Bd.HIPCC, "-DUG_ATTN_STAMPS", *Bd.FLAGS, *Bd.EXTRA["attention.hip"], "-c", os.path.join(Bd.CSRC, "attention.hip"), "-o", obj], check=True)
+    objs = [obj if s_ == "attention.hip" else os.path.join(Bd.CSRC, s_.replace(".hip", ".o")) for s_ in Bd.SOURCES]
+    lib = os.path.join(out, "libunigen_attn_stamps.so")
+    subprocess.run([Bd.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs], check=True)
+    print(lib); sys.exit(0)
 import numpy as np
 import torch
 from unigen_amd import ops, lib as L
@@ -15,13 +30,15 @@ from unigen_amd import ops, lib as L
 assert "stamps" in L.LIB_PATH, "set UG_LIB_PATH to the -DUG_ATTN_STAMPS build"
 dev, BF = torch.device("cuda:0"), torch.bfloat16
 g = torch.Generator(device=dev).manual_seed(0)
-B, H, dh = 4, 24, 128
+dh = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 128
+# dh 128: the cfg2 forward's shapes (B = 4); dh 64: cfg5's (UniGenSD3, B = 8 with CFG = 16 samples: joint 4096 + 333, attn2 over the 4096 image tokens)
+B, H = (4, 24) if dh == 128 else (16, 24)
 D = H * dh
-for Lq, Lkv in [(4608, 4608), (4096, 4608), (8192, 8704)]:
+for Lq, Lkv in ([(4608, 4608), (4096, 4608), (8192, 8704)] if dh == 128 else [(4429, 4429), (4096, 4429), (4096, 4096)]):
     qkv = (torch.randn(B, Lkv, 3 * D, generator=g, device=dev)).to(BF)
     out = torch.empty(B, Lq, D, device=dev, dtype=BF)
     nwg = B * H * ((Lq + 255) // 256)
-    lse = torch.zeros(B, H, max(Lq, (nwg * 2 * 16 + B * H - 1) // (B * H)), device=dev, dtype=torch.float32)
+    lse = torch.zeros(B, H, max(Lq, (nwg * 2 * 24 + B * H - 1) // (B * H)), device=dev, dtype=torch.float32)
     st = (3 * D, Lkv * 3 * D)
     run = lambda: ops.flash_attn(qkv[0, Lkv - Lq:], qkv[0, 0, D:], qkv[0, 0, 2 * D:], out, batches=B, heads=H, dh=dh, Lq=Lq, Lkv=Lkv, q_strides=st, k_strides=st,
                                  v_strides=st, o_strides=(D, Lq * D), lse=lse)
@@ -31,7 +48,8 @@ for Lq, Lkv in [(4608, 4608), (4096, 4608), (8192, 8704)]:
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); run(); e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1)
-    raw = lse.view(-1).cpu().numpy().view(np.uint64)[: nwg * 2 * 8].reshape(nwg, 2, 8).astype(np.int64)
+    raw = lse.view(-1).cpu().numpy().view(np.uint64)[: nwg * 2 * 12].reshape(nwg, 2, 12).astype(np.int64)
+    seg = raw[:, :, 8:12]                                   # [wg][group][Y, barrier, X, barrier] cycles summed over the tiles
     st_ = raw[:, :, 0:4]                                    # [wg][group][stamp]
     clk = (raw[:, :, 3] - raw[:, :, 0]) / np.maximum(raw[:, :, 5] - raw[:, :, 4], 1) * 100e6       # Hz, per workgroup
     ghz = float(np.median(clk)) / 1e9
@@ -60,6 +78,13 @@ for Lq, Lkv in [(4608, 4608), (4096, 4608), (8192, 8704)]:
     for gi, gn in enumerate("AB"):
         print(f"   group {gn}: prologue {us(med(pro[:, gi])):6.2f}  loop {us(med(loop[:, gi])):7.2f} ({us(med(loop[:, gi])) / ntile * 1e3:6.1f} ns per key tile)  "
               f"epilogue {us(med(epi[:, gi])):6.2f} us")
+    for gi, gn in enumerate("AB"):
+        tot_seg = seg[:, gi, :].sum(1)
+        sh = np.median(seg[:, gi, :] / np.maximum(tot_seg[:, None], 1), axis=0)
+        pt = [us(med(seg[:, gi, k])) / ntile * 1e3 for k in range(4)]
+        print(f"   group {gn} per key tile: Y {pt[0]:6.1f}  wait {pt[1]:6.1f}  X {pt[2]:6.1f}  wait {pt[3]:6.1f} ns   "
+              f"(shares {sh[0] * 100:4.1f} / {sh[1] * 100:4.1f} / {sh[2] * 100:4.1f} / {sh[3] * 100:4.1f} %; in cycles at {ghz:.2f} GHz: "
+              f"{med(seg[:, gi, 0]) / ntile:5.0f} / {med(seg[:, gi, 1]) / ntile:5.0f} / {med(seg[:, gi, 2]) / ntile:5.0f} / {med(seg[:, gi, 3]) / ntile:5.0f})")
     print(f"   workgroup entry -> last end {us(med(tot)):7.2f} us; gap to the next workgroup on the CU: median {us(med(gaps)):5.2f}  p10 {us(np.percentile(gaps, 10)):5.2f}  "
           f"p90 {us(np.percentile(gaps, 90)):5.2f} us; CU span {us(med(spans)):8.1f} us of which in workgroups {us(med(busy)):8.1f} us "
           f"({med(busy) / med(spans) * 100:.1f} %); launch / CU span = {ms * 1e3 / us(med(spans)):.3f}")

@@ -121,13 +121,20 @@ __global__ __launch_bounds__(64 * NW, OCC) void flash_attn_kernel(
     const int r = lane & 31, h = lane >> 5;
     /* -DUG_ATTN_STAMPS (tools/attn_stamps.py, a separate library build; never the product): wave 0 / wave 4 of every workgroup record s_memtime at
      * the kernel's entry, the end of the prologue, the end of the tile loop and the end of the epilogue, s_memrealtime at both ends and the CU they
-     * ran on, into the buffer the caller passes as `lse_out` (16 dwords per workgroup and wave group; the log-sum-exp is then not written). */
+     * ran on, into the buffer the caller passes as `lse_out` (24 dwords per workgroup and wave group, incl. the four per-segment accumulators of the stagger loop; the log-sum-exp is then not written). */
 #ifdef UG_ATTN_STAMPS
     unsigned long long ug_st[4], ug_rt0 = __builtin_amdgcn_s_memrealtime();
 #define UG_ASTAMP(I) do { ug_st[I] = __builtin_amdgcn_s_memtime(); } while (0)
     UG_ASTAMP(0);
+    // per-segment accumulators of the stagger loop (round 6): cycles a wave spends in Y (softmax, incl. group B's DMA issue), at the barrier behind
+    // it, in X (P.V + K.Q^T, incl. group B's DMA wait) and at the barrier behind that, summed over the tiles
+    unsigned long long ug_seg[4] = {0, 0, 0, 0}, ug_t = 0;
+#define UG_SEG0() do { ug_t = __builtin_amdgcn_s_memtime(); } while (0)
+#define UG_SEG(I) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); ug_seg[I] += n_ - ug_t; ug_t = n_; } while (0)
 #else
 #define UG_ASTAMP(I) do { } while (0)
+#define UG_SEG0() do { } while (0)
+#define UG_SEG(I) do { } while (0)
 #endif
 
     // XCD-aware block order: all query tiles of one (batch, head) run on one XCD so its K/V stay in that L2.
@@ -595,13 +602,18 @@ __global__ __launch_bounds__(64 * NW, OCC) void flash_attn_kernel(
             // group A publishes K(t+1), V(t) and at once re-fills the staging registers with K(t+2), V(t+1): its VALU segment has slack
             // (the partner's matrix segment is longer), whereas a fetch at the head of its own X(t) delayed the first MFMA
             if constexpr (!DMA) { if (groupA) { publish(t + 1, t); fetch(t + 2, t + 1); } }
+            UG_SEG(0);
             seg_barrier();
+            UG_SEG(1);
             // X(t) = P.V(t) then K.Q^T(t+1): A in even segment 2t+2 | B in odd segment 2t+3 (publish). (Measured and dropped: group B
             // reading its first V^T fragments ahead of the barrier, inside its softmax segment: -4 %, -10 % with two k-steps.)
             do_X(t, cur_c, t + 1 < ntiles);
             if (!groupA) { if constexpr (DMA) dma_wait(); else publish(t + 2, t + 1); }
+            UG_SEG(2);
             seg_barrier();
+            UG_SEG(3);
         };
+        UG_SEG0();
         for (int t = 0; t < ntiles; t += 2) {
             tile(t, std::integral_constant<int, 0>{});
             if (t + 1 < ntiles) tile(t + 1, std::integral_constant<int, 1>{});
@@ -649,13 +661,16 @@ __global__ __launch_bounds__(64 * NW, OCC) void flash_attn_kernel(
 #ifdef UG_ATTN_STAMPS
     UG_ASTAMP(3);
     if (lse_out != nullptr && lane == 0 && (wave & 3) == 0) {
-        unsigned long long* d = (unsigned long long*)lse_out + ((int64_t)blockIdx.x * 2 + (wave >> 2)) * 8;
+        unsigned long long* d = (unsigned long long*)lse_out + ((int64_t)blockIdx.x * 2 + (wave >> 2)) * 12;
+        d[8] = ug_seg[0]; d[9] = ug_seg[1]; d[10] = ug_seg[2]; d[11] = ug_seg[3];
         d[0] = ug_st[0]; d[1] = ug_st[1]; d[2] = ug_st[2]; d[3] = ug_st[3]; d[4] = ug_rt0; d[5] = __builtin_amdgcn_s_memrealtime();
         d[6] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);   // XCC_ID | HW_ID
         d[7] = (unsigned long long)logical;
     }
 #endif
 #undef UG_ASTAMP
+#undef UG_SEG0
+#undef UG_SEG
 }
 
 
