@@ -87,7 +87,8 @@ def test_multicondition_forward_under_enable_lora_matches_oracle(setup, gpu, ena
     ref16, _, cnt16 = R.unigen_flux_forward(st, rcfg, timestep=t, dtype=BF, **inp)
     plain = R.unigen_flux_forward(state, rcfg, timestep=t, dtype=torch.float32, **inp)[0]
     moved = rel_l2(truth, plain)
-    assert moved > 2e-2, f"the adapters barely change the oracle's output ({moved:.2e}): the test would not see a dropped K-segment"
+    # a dropped K-segment would put the fp32 twins `moved` away from the truth: it must sit well above their 1e-3 tolerance to be seen
+    assert moved > 3e-3, f"the adapters barely change the oracle's output ({moved:.2e}): the test would not see a dropped K-segment"
     e32 = rel_l2(out32, truth)
     err_hip, err_ref = rel_l2(out, truth), rel_l2(ref16, truth)
     m = report(f"lora_forward_{'+'.join(enabled)}", out, ref16, err_f32_twins=e32, err_hip_vs_fp32=err_hip, err_oraclebf16_vs_fp32=err_ref, adapters_move_output=moved)

@@ -11,6 +11,10 @@ instruction classes between its head and its backward branch:
   dma       LDS-DMA loads: global_load_lds_* (64-bit per-lane address, "global form") or buffer_load_* ... lds ("buffer form": SGPR resource + lane offset + SGPR offset)
   ds_read   LDS fragment reads, branch = scalar branches, wait = s_waitcnt, barrier = s_barrier
 and scales them to "per 128 MFMAs" (one K-tile of the 256 x 256 x 64 kernel per wave).
+Round 6: `--match "flash_attn_kernel<"` gives the attention forward's tile loop (two key tiles per trip: 64 MFMAs at head width 128, 32 at 64). The
+count is STATIC: it includes the blocks a trip only enters on the ragged last tile (v_cmp / v_cndmask masking), when a row's reference point moves
+(the v_pk_mul_f32 rescale of the O accumulators) and for one wave group only (the LDS-DMA address arithmetic); `op_histogram` lists every opcode.
+The per-score softmax work - what every trip executes - is v_fma_f32 + v_exp_f32 + v_add_f32 per score, v_max3_f32 and v_cvt_pk_bf16_f32 per two.
 """
 from __future__ import annotations
 
@@ -137,8 +141,12 @@ def census(lib: str, match: str):
                      buffer_form=sum(1 for _, x in loop if x.startswith("buffer_load") and re.search(r"\blds\b", x)))
         n = c.get("mfma", 0)
         per128 = {k: round(v * 128.0 / n, 1) for k, v in c.items()} if n else {}
+        hist = {}
+        for _, ins in loop:
+            hist[ins.split()[0]] = hist.get(ins.split()[0], 0) + 1
         res[name] = dict(loop_instructions=len(loop), counts=c, dma_forms=forms, per_128_mfma=per128,
-                         valu_ops=_top(loop, "valu"), salu_ops=_top(loop, "salu"))
+                         valu_ops=_top(loop, "valu"), salu_ops=_top(loop, "salu"),
+                         op_histogram=dict(sorted(hist.items(), key=lambda kv: -kv[1])))
     return res
 
 

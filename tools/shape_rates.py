@@ -1,5 +1,6 @@
 """Per-shape GEMM / attention rates INSIDE the cfg2 forward (KernelTimer events around every launch, grouped by the launch's FLOP count):
-which shapes run below the stand-alone micro-benchmark numbers, and by how much. usage: python tools/shape_rates.py [--batch 4]"""
+which shapes run below the stand-alone micro-benchmark numbers, and by how much. usage: python tools/shape_rates.py [--batch 4] [--grid 64]
+(--batch 1 --grid 32 = cfg1's geometry, 512^2; --batch 1 = the reference script's launch shape at 1024^2). Shapes: GEMM (M, N, K, groups, epilogue), attention (B, H, Lq, Lkv, dh)."""
 import argparse, collections, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -7,14 +8,14 @@ from unigen_amd import ops
 from unigen_amd.flux import UniGenFlux
 from unigen_amd.pipeline import prepare_latent_image_ids
 
-ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=4); a = ap.parse_args()
+ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=4); ap.add_argument("--grid", type=int, default=64); a = ap.parse_args()
 dev, BF = torch.device("cuda:0"), torch.bfloat16
 model = UniGenFlux.from_config({}, device=dev, dtype=BF)
 model.init_condition_block(condition_nums=1, condition_types=["canny"], control_params=dict(
     use_rope=True, use_shared_expert=True, use_consis_module=False, use_single_trans_blocks=True, single_control_dev=2,
     single_block_control_method="overall_add", top_num=1, expert_num_each_condition=3))
 model.init_synthetic_(seed=0, std=0.02)
-B, grid, T = a.batch, 64, 512
+B, grid, T = a.batch, a.grid, 512
 N = grid * grid
 g = torch.Generator(device=dev).manual_seed(5)
 rn = lambda *s: torch.randn(*s, generator=g, device=dev)
@@ -30,11 +31,15 @@ for _ in range(3):
     run()
 torch.cuda.synchronize(); ops.set_timer(None)
 groups = collections.defaultdict(list)
-for kind, flops, e0, e1 in timer.records:
-    groups[(kind, round(flops / 1e9))].append(e0.elapsed_time(e1))
+for (kind, flops, e0, e1), tag in zip(timer.records, timer.tags):
+    groups[(kind, tag, flops / 1e9)].append(e0.elapsed_time(e1))
 tot = sum(sum(v) for v in groups.values())
-print(f"sum of the timed launches: {tot / 3:.1f} ms per forward")
-print(f"{'kind':5s} {'GFLOP/launch':>13s} {'launches':>8s} {'avg us':>9s} {'TFLOP/s':>9s} {'share':>7s}")
-for (kind, gf), v in sorted(groups.items(), key=lambda kv: -sum(kv[1])):
+print(f"B = {B}, {16 * grid}^2: sum of the timed launches: {tot / 3:.1f} ms per forward")
+print(f"{'kind':5s} {'shape':>34s} {'GFLOP':>8s} {'launches':>8s} {'avg us':>9s} {'TFLOP/s':>9s} {'share':>7s}  tiles 256^2 / 128^2")
+for (kind, tag, gf), v in sorted(groups.items(), key=lambda kv: -sum(kv[1])):
     avg = sum(v) / len(v)
-    print(f"{kind:5s} {gf:13d} {len(v) // 3:8d} {avg * 1e3:9.1f} {gf / avg:9.1f} {sum(v) / tot:7.1%}")
+    tiles = ""
+    if kind == "gemm":
+        M, N, K, G, epi = tag
+        tiles = f"{-(-M // 256) * -(-N // 256) * G} / {-(-M // 128) * -(-N // 128) * G}"
+    print(f"{kind:5s} {str(tag):>34s} {gf:8.1f} {len(v) // 3:8d} {avg * 1e3:9.1f} {gf / avg:9.1f} {sum(v) / tot:7.1%}  {tiles}")

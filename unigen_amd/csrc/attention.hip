@@ -88,7 +88,23 @@ __device__ __forceinline__ float ug_max_halves(float x) {
 // the VALU, together (the lock-step loop, STAGGER = false, kept for A/B: both phases then serialise and a tile costs the sum).
 // Two barriers per tile; every thread fetches its share of K(t+2), V(t+1) at the start of an even segment and publishes it to LDS at
 // the end of the following odd one, into buffers nobody reads in those two segments.
-template <int DH, int NW, bool STAGGER, int PRIO = 1, bool WIDE = false, bool DMA = false, int KV = 64, int OCC = 2>   // head dim 128 | 64; waves per workgroup: 8 (256 query rows, 1 / CU) or 4 (128 rows, 2 / CU)
+template <int DH, int NW, bool STAGGER, int PRIO = 1, bool WIDE = false, bool DMA = false, int KV = 64, int OCC = 2, bool LSUM = false, int AIS = 0>   // head dim 128 | 64; waves per workgroup: 8 (256 query rows, 1 / CU) or 4 (128 rows, 2 / CU)
+// AIS (round 6, DMA stagger only): WHO issues the LDS-DMAs of K(t+2) / V(t+1), and where. The per-segment stamps (tools/attn_stamps.py, profiles/r06b_*)
+// show the loop's period is the SUM of the two groups' softmax segments - the matrix segment X is the shorter one of every pair (dh 64: Y 1497 /
+// X 1063 cycles for group A, Y 2264 / X 1115 for group B) - and that group B's Y is 770 cycles longer than A's only because it opens with the
+// tile's 4 DMA issues per wave (~140 cycles each + their address arithmetic), while group A then sits 1300 cycles at the barrier behind its X.
+//   0: group B at the start of its softmax segment Y(t) (rounds 2-5);
+//   1: group A at the END of its matrix segment X(t) - the same global segment 2t+2, so every buffer-reuse and landing deadline is unchanged
+//      (K(t)'s and V(t-1)'s last readers finished in segment 2t+1; the data is waited for at the end of A's next softmax segment, 2t+3, and first
+//      read in 2t+4) - i.e. inside the time A would spend waiting for B's softmax anyway;
+//   2: split: group A issues K(t+2) at the end of X(t), group B V(t+1) at the start of Y(t) (each waits for its own).
+// LSUM (round 6, stagger only): the softmax row sums leave the VALU. With the scores' scale / exp2 / max / pack the running sum `l += p` is one of ~5
+// VALU instructions per score and the softmax segment Y is what the barriers wait for (tools/attn_stamps.py); here each lane's probabilities are
+// summed on the matrix pipe instead, inside X, from the SAME packed bf16 fragments P.V consumes: v_mfma_f32_4x4x4_16b_bf16 (16 blocks of 4x4x4) with
+// A = ones makes D[b][i][j] = sum_k B[b][k][j], i.e. every lane gets the sum of the four bf16 values IT passes as B (lane = block b, column j),
+// accumulated over the tile's 8 half-fragments: 8 two-pass MFMAs per tile and wave (+12.5 % matrix-pipe cycles) for 32 v_add_f32 (-20 % of the
+// softmax segment's issue cycles). The denominator is then the sum of the ROUNDED probabilities - the ones the numerator multiplies - not of their
+// fp32 originals (relative difference <= 2^-9 / sqrt(keys), below the output's own bf16 rounding).
 // KV: keys per tile. 64 everywhere in rounds 1-2; round 3 adds KV = 128 for head dim 64 (UniGenSD3): a 128-key tile of 128-byte rows is the
 // same 16 KiB image, the same register budget (S^T 64 + P 32 + O 32 + Q 16 against 32 + 16 + 64 + 32 at dh 128 / 64 keys) and the same 32
 // MFMAs per matrix segment as the dh 128 kernel, so the per-segment costs (two barriers, the max exchange, the lazy-rescale test, fences,
@@ -230,6 +246,10 @@ __global__ __launch_bounds__(64 * NW, OCC) void flash_attn_kernel(
 #pragma unroll
         for (int i = 0; i < 16; ++i) oacc[db][i] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
+    static_assert(!LSUM || STAGGER, "the matrix-pipe row sum lives in the stagger loop's X segment");
+    f32x4 lacc = {0.f, 0.f, 0.f, 0.f};                // LSUM: register 0 = this lane's running row sum (rows 1-3 of its 4x4 block: unused copies)
+    bf16x4 ones4 = {(short)0x3f80, (short)0x3f80, (short)0x3f80, (short)0x3f80};
+    if constexpr (LSUM) asm volatile("" : "+v"(ones4));        // one VGPR pair for the loop, not re-materialised per use
 
     const int ntiles = (Lkv + KVB - 1) / KVB;
     bf16x8 pf[NKB][2];                                 // P^T fragments of the tile between its S and P stages
@@ -313,7 +333,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void flash_attn_kernel(
         const float m_new = up ? tmax : m_run;
         if (!__all(!up)) {
             const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-            l_run *= alpha;
+            if constexpr (LSUM) lacc[0] *= alpha; else l_run *= alpha;
 #pragma unroll
             for (int db = 0; db < NDB; ++db)
 #pragma unroll
@@ -336,7 +356,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void flash_attn_kernel(
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 p[i] = __builtin_amdgcn_exp2f(fmaf(sacc[kb][i], c, -mc));
-                l_run += p[i];
+                if constexpr (!LSUM) l_run += p[i];
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
@@ -403,6 +423,11 @@ __global__ __launch_bounds__(64 * NW, OCC) void flash_attn_kernel(
 #pragma unroll
             for (int db = 0; db < NDB; ++db)
                 oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[ks][db], pf[ks >> 1][ks & 1], oacc[db], 0, 0, 0);
+            if constexpr (LSUM) {        // this lane's 8 probabilities of the k-step, summed on the matrix pipe (see the template's header)
+                const bf16x8 pw = pf[ks >> 1][ks & 1];
+                lacc = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(ones4, __builtin_shufflevector(pw, pw, 0, 1, 2, 3), lacc, 0, 0, 0);
+                lacc = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(ones4, __builtin_shufflevector(pw, pw, 4, 5, 6, 7), lacc, 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
             if (ks + 2 < NKS) rdv(ks + 2);
             else if (have_qk) {                                                    // the first 2 QPRE k-steps of the second half
@@ -570,9 +595,14 @@ __global__ __launch_bounds__(64 * NW, OCC) void flash_attn_kernel(
             if (kt < ntiles) dma_tile(Kb, k_rs, dko, kt, l0 + (kt & 1) * 2 * TILE);
             if (vt < ntiles) dma_tile(Vb, v_rs, dvo, vt, l0 + (vt & 1) * 2 * TILE + TILE);
         };
+        static_assert(AIS == 0 || DMA, "AIS re-assigns the LDS-DMA issue");
         auto dma_wait = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
         if constexpr (PRIO == 2) { if (!groupA) __builtin_amdgcn_s_setprio(1); }
-        if constexpr (DMA) {
+        if constexpr (DMA && AIS == 1) {                       // group A is the issuer throughout
+            if (groupA) { dma_fetch(0, ntiles); dma_wait(); }      // K(0) only
+            seg_barrier();
+            if (groupA) dma_fetch(1, 0);                           // waited for at the end of A's Y(0)
+        } else if constexpr (DMA) {
             if (!groupA) { dma_fetch(0, ntiles); dma_wait(); }     // K(0) only
             seg_barrier();
             if (!groupA) dma_fetch(1, 0);
@@ -585,30 +615,33 @@ __global__ __launch_bounds__(64 * NW, OCC) void flash_attn_kernel(
         if (!groupA) seg_barrier();                    // B idles through segment 0
         UG_ASTAMP(1);
         do_QK(0, std::integral_constant<int, 0>{});    // A: segment 0 | B: segment 1
-        if (!groupA) { if constexpr (DMA) dma_wait(); else publish(1, 0); }    // end of segment 1 (B)
+        if (!groupA) { if constexpr (DMA && AIS != 1) dma_wait(); else if constexpr (!DMA) publish(1, 0); }    // end of segment 1 (B)
         seg_barrier();
         // one tile = Y(t) | X(t); buffer parity is a compile-time constant (two tiles per trip)
         auto tile = [&](int t, auto cur_c) __attribute__((always_inline)) {
             // Y(t): A in odd segment 2t+1 (publishes K(t+1), V(t) at its end) | B in even segment 2t+2 (fetches K(t+2), V(t+1) at its start)
-            if (!groupA) { if constexpr (DMA) dma_fetch(t + 2, t + 1); else fetch(t + 2, t + 1); }
+            if (!groupA) { if constexpr (DMA && AIS == 0) dma_fetch(t + 2, t + 1); else if constexpr (DMA && AIS == 2) dma_fetch(ntiles, t + 1); else if constexpr (!DMA) fetch(t + 2, t + 1); }
             if constexpr (PRIO == 3) __builtin_amdgcn_s_setprio(1);                  // the softmax segment outranks the partner's matrix stream at issue
             do_SM();
             // P^T is "used" here: hipcc otherwise sinks the (pure) scale / exp2 / pack chain across the barrier to its first use, the
             // P.V MFMAs - i.e. out of this VALU-only segment into the matrix-only one, which then ran at ~60 cycles per MFMA
 #pragma unroll
             for (int kb = 0; kb < NKB; ++kb) { asm volatile("" : "+v"(pf[kb][0])); asm volatile("" : "+v"(pf[kb][1])); }
-            asm volatile("" : "+v"(l_run), "+v"(m_run));
+            if constexpr (LSUM) asm volatile("" : "+v"(m_run)); else asm volatile("" : "+v"(l_run), "+v"(m_run));
             if constexpr (PRIO == 3) __builtin_amdgcn_s_setprio(0);
             // group A publishes K(t+1), V(t) and at once re-fills the staging registers with K(t+2), V(t+1): its VALU segment has slack
             // (the partner's matrix segment is longer), whereas a fetch at the head of its own X(t) delayed the first MFMA
             if constexpr (!DMA) { if (groupA) { publish(t + 1, t); fetch(t + 2, t + 1); } }
+            if constexpr (DMA && AIS != 0) { if (groupA) dma_wait(); }             // A's DMAs of the end of X(t-1): K(t+1) (and V(t), AIS 1), first read in X(t)
             UG_SEG(0);
             seg_barrier();
             UG_SEG(1);
             // X(t) = P.V(t) then K.Q^T(t+1): A in even segment 2t+2 | B in odd segment 2t+3 (publish). (Measured and dropped: group B
             // reading its first V^T fragments ahead of the barrier, inside its softmax segment: -4 %, -10 % with two k-steps.)
             do_X(t, cur_c, t + 1 < ntiles);
-            if (!groupA) { if constexpr (DMA) dma_wait(); else publish(t + 2, t + 1); }
+            if (!groupA) { if constexpr (DMA && AIS != 1) dma_wait(); else if constexpr (!DMA) publish(t + 2, t + 1); }
+            if constexpr (DMA && AIS == 1) { if (groupA) dma_fetch(t + 2, t + 1); }
+            if constexpr (DMA && AIS == 2) { if (groupA) dma_fetch(t + 2, ntiles); }
             UG_SEG(2);
             seg_barrier();
             UG_SEG(3);
@@ -623,6 +656,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void flash_attn_kernel(
     }
 
     // ---- epilogue: O[q][d] = O^T / l ----
+    if constexpr (LSUM) l_run = lacc[0];
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     // training: log2 sum_k 2^(c s) of the row for the backward kernels (m_run is the row's reference point, shared by both lane halves)
 #ifndef UG_ATTN_STAMPS
@@ -2110,8 +2144,26 @@ static int flash_attn_fwd_impl(const void* q, int64_t q_row_stride, int64_t q_ba
     // library, profiles/r04h_attn_m16_in_app.log): its advantage is the higher clock the chip reaches for that shape after ~10 ms of back-to-back
     // launches; a 0.9 ms launch between GEMMs never gets there, and at equal clock its 64 MFMA issues per tile cost the partner wave's softmax more
     // issue slots than 32 do. Not shipped.)
-    if (dh == 128) UG_ATTN_LAUNCH_KV(64, 2, 128, 8, true, 3, true, true);
-    else UG_ATTN_LAUNCH_KV(64, 4, 64, 8, true, 0, true, true);
+    // UG_ATTN_LSUM_128 / UG_ATTN_LSUM_64 (build-time, 0 | 1): the row sums on the matrix pipe (template parameter LSUM), per head width
+#ifndef UG_ATTN_LSUM_128
+#define UG_ATTN_LSUM_128 0
+#endif
+#ifndef UG_ATTN_LSUM_64
+#define UG_ATTN_LSUM_64 0
+#endif
+#ifndef UG_ATTN_AIS_128
+#define UG_ATTN_AIS_128 0
+#endif
+#ifndef UG_ATTN_AIS_64
+#define UG_ATTN_AIS_64 0
+#endif
+#define UG_ATTN_LAUNCH_LS(KVV, OCCV, LS, AISV, DHV, NWV, STG, ...)                                                                                  \
+    hipLaunchKernelGGL((flash_attn_kernel<DHV, NWV, STG, __VA_ARGS__, KVV, OCCV, LS, AISV>), dim3((unsigned)nwg), dim3(64 * NWV), 2 * 2 * KVV * 2 * DHV + (STG ? 32 * NWV * 2 * DHV : 0), (hipStream_t)stream, \
+                       (const bf16_t*)q, q_row_stride, q_batch_stride, (const bf16_t*)k, k_row_stride, k_batch_stride, (const bf16_t*)v, \
+                       v_row_stride, v_batch_stride, (bf16_t*)o, o_row_stride, o_batch_stride, (int)heads, (int)Lq, (int)Lkv, nQ, c, lse_out, lse_ld)
+    if (dh == 128) UG_ATTN_LAUNCH_LS(64, 2, (UG_ATTN_LSUM_128 != 0), UG_ATTN_AIS_128, 128, 8, true, 3, true, true);
+    else UG_ATTN_LAUNCH_LS(64, 4, (UG_ATTN_LSUM_64 != 0), UG_ATTN_AIS_64, 64, 8, true, 0, true, true);
+#undef UG_ATTN_LAUNCH_LS
 #undef UG_ATTN_LAUNCH_KV
 #else
     static int nw = -1;

@@ -27,6 +27,7 @@ class KernelTimer:
     def __init__(self, kinds=("gemm", "attn")):
         self.kinds = set(kinds)
         self.records = []   # (kind, flops, start_event, end_event)
+        self.tags = []      # per record: the launch's shape, e.g. (M, N, K, groups) of a GEMM (tools/shape_rates.py)
 
     def begin(self, kind):
         if kind not in self.kinds:
@@ -35,12 +36,13 @@ class KernelTimer:
         ev.record(torch.cuda.current_stream())
         return ev
 
-    def end(self, kind, flops, ev0):
+    def end(self, kind, flops, ev0, tag=None):
         if ev0 is None:
             return
         ev1 = torch.cuda.Event(enable_timing=True)
         ev1.record(torch.cuda.current_stream())
         self.records.append((kind, flops, ev0, ev1))
+        self.tags.append(tag)
 
     def summary(self):
         """-> {kind: dict(launches, flops, ms)} (call after a device synchronize)."""
@@ -203,7 +205,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: to
     ev = _timer.begin("gemm") if _timer is not None else None
     L.check(_fn("ug_gemm_bf16", dt)(C.byref(d), stream), "ug_gemm_bf16")
     if ev is not None:
-        _timer.end("gemm", 2.0 * M * N * (K + (d.lora_r or 0)) * max(groups, 1), ev)
+        _timer.end("gemm", 2.0 * M * N * (K + (d.lora_r or 0)) * max(groups, 1), ev, tag=(M, N, K, max(groups, 1), epilogue))
     return out
 
 
@@ -279,7 +281,7 @@ def flash_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Ten
                                            v.data_ptr(), v_strides[0], v_strides[1], out.data_ptr(), o_strides[0], o_strides[1],
                                            batches, heads, Lq, Lkv, dh, scale, _stream()), "ug_flash_attn_fwd")
     if ev is not None:
-        _timer.end("attn", 4.0 * batches * heads * Lq * Lkv * dh, ev)
+        _timer.end("attn", 4.0 * batches * heads * Lq * Lkv * dh, ev, tag=(batches, heads, Lq, Lkv, dh))
     return out
 
 
