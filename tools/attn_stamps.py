@@ -18,9 +18,11 @@ if "--build" in sys.argv:
     Bd.build()                                                      # the product objects the stamp library links against
     out = os.path.join(ROOT, "tools", "probe", "bin"); os.makedirs(out, exist_ok=True)
     obj = os.path.join(out, "attention_stamps.o")
-    subprocess.run([Bd.HIPCC, "-DUG_ATTN_STAMPS", *Bd.FLAGS, *Bd.EXTRA["attention.hip"], "-c", os.path.join(Bd.CSRC, "attention.hip"), "-o", obj], check=True)
+    extra = [a_ for a_ in sys.argv if a_.startswith("-D")]          # e.g. -DUG_ATTN_AIS_64=1: the stamps of a variant
+    tag = os.environ.get("UG_STAMPS_TAG", "")
+    subprocess.run([Bd.HIPCC, "-DUG_ATTN_STAMPS", *extra, *Bd.FLAGS, *Bd.EXTRA["attention.hip"], "-c", os.path.join(Bd.CSRC, "attention.hip"), "-o", obj], check=True)
     objs = [obj if s_ == "attention.hip" else os.path.join(Bd.CSRC, s_.replace(".hip", ".o")) for s_ in Bd.SOURCES]
-    lib = os.path.join(out, "libunigen_attn_stamps.so")
+    lib = os.path.join(out, f"libunigen_attn_stamps{tag}.so")
     subprocess.run([Bd.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs], check=True)
     print(lib); sys.exit(0)
 import numpy as np
@@ -37,7 +39,8 @@ D = H * dh
 for Lq, Lkv in ([(4608, 4608), (4096, 4608), (8192, 8704)] if dh == 128 else [(4429, 4429), (4096, 4429), (4096, 4096)]):
     qkv = (torch.randn(B, Lkv, 3 * D, generator=g, device=dev)).to(BF)
     out = torch.empty(B, Lq, D, device=dev, dtype=BF)
-    nwg = B * H * ((Lq + 255) // 256)
+    QR = int(os.environ.get("UG_STAMPS_QROWS", "256"))          # query rows per workgroup of the build under test (512: the 16-wave form)
+    nwg = B * H * ((Lq + QR - 1) // QR)
     lse = torch.zeros(B, H, max(Lq, (nwg * 2 * 24 + B * H - 1) // (B * H)), device=dev, dtype=torch.float32)
     st = (3 * D, Lkv * 3 * D)
     run = lambda: ops.flash_attn(qkv[0, Lkv - Lq:], qkv[0, 0, D:], qkv[0, 0, 2 * D:], out, batches=B, heads=H, dh=dh, Lq=Lq, Lkv=Lkv, q_strides=st, k_strides=st,

@@ -37,6 +37,10 @@ __device__ __forceinline__ const void* uniform_ptr(const void* p) {      // pin 
 __device__ __forceinline__ void glds16_off(const void* base /* uniform_ptr() */, unsigned off_bytes, unsigned lds) {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off_bytes), "s"(base), "s"(lds) : "memory");
 }
+// buffer form of the same DMA: SGPR resource (base of the (batch, head)'s K or V) + per-lane byte offset + SGPR byte offset (the tile / run part)
+__device__ __forceinline__ void bufds16(u32x4 rsrc, unsigned voff, unsigned soff, unsigned lds) {
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff), "s"(rsrc), "s"(soff), "s"(lds) : "memory");
+}
 __device__ __forceinline__ void glds16_ptr(const void* g, unsigned lds) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds) : "memory");
 }
@@ -88,7 +92,13 @@ __device__ __forceinline__ float ug_max_halves(float x) {
 // the VALU, together (the lock-step loop, STAGGER = false, kept for A/B: both phases then serialise and a tile costs the sum).
 // Two barriers per tile; every thread fetches its share of K(t+2), V(t+1) at the start of an even segment and publishes it to LDS at
 // the end of the following odd one, into buffers nobody reads in those two segments.
-template <int DH, int NW, bool STAGGER, int PRIO = 1, bool WIDE = false, bool DMA = false, int KV = 64, int OCC = 2, bool LSUM = false, int AIS = 0>   // head dim 128 | 64; waves per workgroup: 8 (256 query rows, 1 / CU) or 4 (128 rows, 2 / CU)
+template <int DH, int NW, bool STAGGER, int PRIO = 1, bool WIDE = false, bool DMA = false, int KV = 64, int OCC = 2, int LSUM = 0, int AIS = 0, bool BUFD = false>   // head dim 128 | 64; waves per workgroup: 8 (256 query rows, 1 / CU) or 4 (128 rows, 2 / CU)
+// BUFD (round 6; head width 64 / OCC 4 only): the whole-tile LDS-DMAs in BUFFER form. The stamps put group B's softmax segment 770 cycles above group A's
+// (2263 vs 1497), all of it the 4 DMA issues per wave and tile; AIS = 1 showed the cost follows the issuer (A's X 1063 -> 1937), i.e. it is the issue
+// sequence itself: per tile ~20 VALU instructions of lane-offset re-derivation (kept out of registers in round 3), a 64-bit VALU pointer bump,
+// two v_readfirstlane + s_nop 4 per operand, on a SIMD whose VALU the four waves' softmax already saturates. Here the per-lane byte offset is ONE
+// VGPR held through the loop (run 1's is that ^ 16: needs K and V to share a row stride that is a multiple of 16 elements - the dispatcher checks),
+// the (batch, head) base is an SGPR resource, the tile / run offset an SGPR: per tile 4 x (s_mov m0 + buffer_load ... lds), one v_xor, scalar adds.
 // AIS (round 6, DMA stagger only): WHO issues the LDS-DMAs of K(t+2) / V(t+1), and where. The per-segment stamps (tools/attn_stamps.py, profiles/r06b_*)
 // show the loop's period is the SUM of the two groups' softmax segments - the matrix segment X is the shorter one of every pair (dh 64: Y 1497 /
 // X 1063 cycles for group A, Y 2264 / X 1115 for group B) - and that group B's Y is 770 cycles longer than A's only because it opens with the
@@ -130,8 +140,8 @@ __global__ __launch_bounds__(64 * NW, OCC) void flash_attn_kernel(
     constexpr int TILE = KVB * RB;                   // bytes of one K (or V) tile image
     constexpr int QS = DH / 16;                      // k-steps of S^T = K Q^T
     constexpr int NDB = DH / 32;                     // 32-wide d blocks of O^T
-    constexpr int QROWS = 32 * NW, NT = 64 * NW, NST = (KVB * NCH) / NT;   // staging chunks of K (and of V) per thread and tile
-    static_assert(NST >= 1, "tile smaller than the workgroup");
+    constexpr int QROWS = 32 * NW, NT = 64 * NW, NST = (KVB * NCH) / NT > 0 ? (KVB * NCH) / NT : 1;   // staging chunks of K (and of V) per thread and tile
+    static_assert((KVB * NCH) / NT >= 1 || DMA, "tile smaller than the workgroup: register staging cannot cover it (the LDS-DMA form can)");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [2][K tile | V tile]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -247,7 +257,8 @@ __global__ __launch_bounds__(64 * NW, OCC) void flash_attn_kernel(
         for (int i = 0; i < 16; ++i) oacc[db][i] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
     static_assert(!LSUM || STAGGER, "the matrix-pipe row sum lives in the stagger loop's X segment");
-    f32x4 lacc = {0.f, 0.f, 0.f, 0.f};                // LSUM: register 0 = this lane's running row sum (rows 1-3 of its 4x4 block: unused copies)
+    f32x4 lacc = {0.f, 0.f, 0.f, 0.f}, lacc2 = {0.f, 0.f, 0.f, 0.f};   // LSUM: register 0 of each = half of this lane's running row sum (rows 1-3 of its 4x4 block: unused
+                                                                       // copies); LSUM = 2: two chains, so that no MFMA of a k-step waits for the one issued just before it (4 more registers)
     bf16x4 ones4 = {(short)0x3f80, (short)0x3f80, (short)0x3f80, (short)0x3f80};
     if constexpr (LSUM) asm volatile("" : "+v"(ones4));        // one VGPR pair for the loop, not re-materialised per use
 
@@ -333,7 +344,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void flash_attn_kernel(
         const float m_new = up ? tmax : m_run;
         if (!__all(!up)) {
             const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-            if constexpr (LSUM) lacc[0] *= alpha; else l_run *= alpha;
+            if constexpr (LSUM) { lacc[0] *= alpha; lacc2[0] *= alpha; } else l_run *= alpha;
 #pragma unroll
             for (int db = 0; db < NDB; ++db)
 #pragma unroll
@@ -400,7 +411,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void flash_attn_kernel(
     // matrix pipe in this segment (its SIMD partner is in the VALU-only Y), so an exposed ds_read latency is an idle pipe. hipcc's
     // own order (sched_group_barrier hints included) ran the segment at 70-90 cycles per MFMA.
     auto qx_frag = [&](int s) __attribute__((always_inline)) -> bf16x8 { if constexpr (QLDS) return *(const bf16x8*)(smem + q_lds + 16 * ((2 * s) ^ qx)); else return qf[s]; };
-    auto do_X = [&](int t, auto cur_c, bool have_qk) __attribute__((always_inline)) {
+    auto do_X = [&](int t, auto cur_c, bool have_qk, auto&& hook) __attribute__((always_inline)) {
         constexpr int CUR = decltype(cur_c)::value;
         const unsigned char* Vbuf = smem + CUR * 2 * TILE + TILE;
         const unsigned char* Kbuf = smem + (CUR ^ 1) * 2 * TILE;
@@ -426,8 +437,10 @@ __global__ __launch_bounds__(64 * NW, OCC) void flash_attn_kernel(
             if constexpr (LSUM) {        // this lane's 8 probabilities of the k-step, summed on the matrix pipe (see the template's header)
                 const bf16x8 pw = pf[ks >> 1][ks & 1];
                 lacc = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(ones4, __builtin_shufflevector(pw, pw, 0, 1, 2, 3), lacc, 0, 0, 0);
-                lacc = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(ones4, __builtin_shufflevector(pw, pw, 4, 5, 6, 7), lacc, 0, 0, 0);
+                if constexpr (LSUM == 2) lacc2 = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(ones4, __builtin_shufflevector(pw, pw, 4, 5, 6, 7), lacc2, 0, 0, 0);
+                else lacc = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(ones4, __builtin_shufflevector(pw, pw, 4, 5, 6, 7), lacc, 0, 0, 0);
             }
+            hook(ks);                                                              // AIS 3: one LDS-DMA piece behind this k-step's MFMAs (no-op otherwise)
             __builtin_amdgcn_sched_barrier(0);
             if (ks + 2 < NKS) rdv(ks + 2);
             else if (have_qk) {                                                    // the first 2 QPRE k-steps of the second half
@@ -478,7 +491,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void flash_attn_kernel(
             if (t + 1 < ntiles) tile(t + 1, std::integral_constant<int, 1>{});
         }
     } else {
-        static_assert(!STAGGER || NW == 8, "the stagger pairs waves w and w+4 of one SIMD");
+        static_assert(!STAGGER || NW == 8 || (NW == 16 && DMA), "the stagger pairs the waves of one SIMD: w, w + 4 (and w + 8, w + 12 in the 16-wave form)");
         // X / Y stagger. A wave alternates a MATRIX-only segment X(t) = P.V of tile t followed by S^T = K.Q^T of tile t+1, and a
         // VALU-only segment Y(t+1) = online softmax of tile t+1. Waves 0-3 (group A) and 4-7 (group B) - the two waves of every
         // SIMD - run one segment apart, so in every segment a SIMD has one wave feeding the matrix pipe and one feeding the VALU
@@ -533,14 +546,15 @@ __global__ __launch_bounds__(64 * NW, OCC) void flash_attn_kernel(
                 *(u32x4*)(smem + (vt & 1) * 2 * TILE + TILE + st_off[u]) = vreg[u];
             }
         };
-        const bool groupA = __builtin_amdgcn_readfirstlane(wave) < 4;
+        const bool groupA = __builtin_amdgcn_readfirstlane(wave) < NW / 2;
         // LDS-DMA staging: a tile image is NI runs of 1 KiB (RPI rows each); wave wb of group B owns runs wb * NIW .. + NIW - 1
         // (measured and dropped: every wave issuing NI / 8 runs, group A's half at the start of its own softmax segment 2t+1 and waited for
         // at its end - same bits, -0.5 % at dh 128, -12 % at dh 64: group B's issue cost is not what bounds the segment pairs; and group A
         // issuing all of them one at a time behind the MFMAs of the first 2 NIW steps of its matrix segment: -11 % / -4 %, ~46 cycles of
         // matrix-segment time per DMA)
-        constexpr int RPI = 1024 / RB, NI = TILE / 1024, NIW = NI / 4;
-        const int wb = __builtin_amdgcn_readfirstlane(wave) & 3;
+        constexpr int RPI = 1024 / RB, NI = TILE / 1024, NIW = NI / (NW / 2);
+        static_assert(NIW >= 1, "fewer 1 KiB runs in a tile than issuing waves");
+        const int wb = __builtin_amdgcn_readfirstlane(wave) & (NW / 2 - 1);
         unsigned dko[NIW], dvo[NIW];
 #pragma unroll
         for (int u = 0; u < NIW; ++u) {
@@ -549,9 +563,30 @@ __global__ __launch_bounds__(64 * NW, OCC) void flash_attn_kernel(
             dko[u] = (unsigned)(row * (int)k_rs + ch * 8) * 2u;        // bytes
             dvo[u] = (unsigned)(row * (int)v_rs + ch * 8) * 2u;
         }
-        auto dma_tile = [&](const bf16_t* base, int64_t rs, const unsigned (&off)[NIW], int tile, unsigned dst) {
+        static_assert(!BUFD || (OCC == 4 && DH == 64 && (NIW == 2 || NIW == 1) && DMA), "BUFD is the head-width-64 four-waves-per-SIMD form");
+        unsigned bvo = 0;                              // BUFD: lane offset of run 0 inside a wave's pair of 1 KiB runs (rows lane / 8, swizzled chunk)
+        u32x4 rsK = {0u, 0u, 0u, 0u}, rsV = {0u, 0u, 0u, 0u};
+        if constexpr (BUFD) {
+            const int sw = (((lane >> 4) & 1) << 2) | ((lane >> 4) & 2);
+            bvo = (unsigned)((lane >> 3) * (int)k_rs) * 2u + (unsigned)(((lane & 7) ^ sw) << 4);
+            if constexpr (NIW == 1) bvo ^= (unsigned)(wb & 1) << 4;           // one run per wave: the run's parity (row bit 3) is the swizzle's chunk bit 0
+            asm volatile("" : "+v"(bvo));
+            const unsigned long long ka = (unsigned long long)uniform_ptr(Kb), va = (unsigned long long)uniform_ptr(Vb);
+            rsK = (u32x4){(unsigned)ka, (unsigned)(ka >> 32), 0xffffffffu, 0x00020000u};
+            rsV = (u32x4){(unsigned)va, (unsigned)(va >> 32), 0xffffffffu, 0x00020000u};
+        }
+        auto dma_tile = [&](const bf16_t* base, int64_t rs, const unsigned (&off)[NIW], int tile, unsigned dst, auto is_k) {
             if (tile * KVB + KVB <= Lkv) {             // whole tile: wave-uniform base (SGPR pair) + per-lane 32-bit byte offset
-                if constexpr (OCC == 4 && DH == 64 && NIW == 2) {
+                if constexpr (BUFD) {
+                    const unsigned so = (unsigned)((tile * KVB + wb * NIW * RPI) * (int)rs) * 2u;          // scalar: tile and run-pair part of the byte offset
+                    if constexpr (decltype(is_k)::value) {
+                        bufds16(rsK, bvo, so, dst);
+                        if constexpr (NIW == 2) bufds16(rsK, bvo ^ 16u, so + (unsigned)(RPI * (int)rs) * 2u, dst + 1024);
+                    } else {
+                        bufds16(rsV, bvo, so, dst);
+                        if constexpr (NIW == 2) bufds16(rsV, bvo ^ 16u, so + (unsigned)(RPI * (int)rs) * 2u, dst + 1024);
+                    }
+                } else if constexpr (OCC == 4 && DH == 64 && NIW == 2) {
                     // Lane offsets re-derived at the issue (not kept live through the loop: registers are what this form is short of), cheaply:
                     // run u of wave wb covers rows (2 wb + u) * 8 + lane / 8, so the wave / run part of the row goes into the scalar base and
                     // row_swz<64> reduces to a lane term with bit 0 = u: the second run's chunk is the first one's ^ 1. ~10 VALU per tile
@@ -592,13 +627,30 @@ __global__ __launch_bounds__(64 * NW, OCC) void flash_attn_kernel(
         };
         auto dma_fetch = [&](int kt, int vt) __attribute__((always_inline)) {         // tiles past the end are simply not fetched
             const unsigned l0 = __builtin_amdgcn_readfirstlane(lds_addr(smem)) + wb * NIW * 1024;
-            if (kt < ntiles) dma_tile(Kb, k_rs, dko, kt, l0 + (kt & 1) * 2 * TILE);
-            if (vt < ntiles) dma_tile(Vb, v_rs, dvo, vt, l0 + (vt & 1) * 2 * TILE + TILE);
+            if (kt < ntiles) dma_tile(Kb, k_rs, dko, kt, l0 + (kt & 1) * 2 * TILE, std::true_type{});
+            if (vt < ntiles) dma_tile(Vb, v_rs, dvo, vt, l0 + (vt & 1) * 2 * TILE + TILE, std::false_type{});
         };
         static_assert(AIS == 0 || DMA, "AIS re-assigns the LDS-DMA issue");
+        static_assert(AIS != 3 || (BUFD && NKS == 4 && NIW == 2), "AIS 3 spreads the four buffer-form pieces over the four P.V k-steps");
+        auto dma_piece = [&](int kt, int vt, int j) __attribute__((always_inline)) {
+            if constexpr (BUFD) {
+                const unsigned l0 = __builtin_amdgcn_readfirstlane(lds_addr(smem)) + wb * NIW * 1024;
+                const int tile = j < 2 ? kt : vt;
+                if (tile >= ntiles) return;
+                const unsigned dst = l0 + (tile & 1) * 2 * TILE + (j < 2 ? 0 : TILE);
+                if (tile * KVB + KVB <= Lkv) {
+                    const unsigned so = (unsigned)((tile * KVB + wb * NIW * RPI) * (int)k_rs) * 2u;
+                    if (j == 0) bufds16(rsK, bvo, so, dst);
+                    else if (j == 1) bufds16(rsK, bvo ^ 16u, so + (unsigned)(RPI * (int)k_rs) * 2u, dst + 1024);
+                    else if (j == 2) bufds16(rsV, bvo, so, dst);
+                    else bufds16(rsV, bvo ^ 16u, so + (unsigned)(RPI * (int)k_rs) * 2u, dst + 1024);
+                } else if (j == 0) dma_tile(Kb, k_rs, dko, tile, dst, std::true_type{});
+                else if (j == 2) dma_tile(Vb, v_rs, dvo, tile, dst, std::false_type{});
+            }
+        };
         auto dma_wait = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
         if constexpr (PRIO == 2) { if (!groupA) __builtin_amdgcn_s_setprio(1); }
-        if constexpr (DMA && AIS == 1) {                       // group A is the issuer throughout
+        if constexpr (DMA && (AIS == 1 || AIS == 3)) {         // group A is the issuer throughout
             if (groupA) { dma_fetch(0, ntiles); dma_wait(); }      // K(0) only
             seg_barrier();
             if (groupA) dma_fetch(1, 0);                           // waited for at the end of A's Y(0)
@@ -615,7 +667,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void flash_attn_kernel(
         if (!groupA) seg_barrier();                    // B idles through segment 0
         UG_ASTAMP(1);
         do_QK(0, std::integral_constant<int, 0>{});    // A: segment 0 | B: segment 1
-        if (!groupA) { if constexpr (DMA && AIS != 1) dma_wait(); else if constexpr (!DMA) publish(1, 0); }    // end of segment 1 (B)
+        if (!groupA) { if constexpr (DMA && AIS != 1 && AIS != 3) dma_wait(); else if constexpr (!DMA) publish(1, 0); }    // end of segment 1 (B)
         seg_barrier();
         // one tile = Y(t) | X(t); buffer parity is a compile-time constant (two tiles per trip)
         auto tile = [&](int t, auto cur_c) __attribute__((always_inline)) {
@@ -638,8 +690,14 @@ __global__ __launch_bounds__(64 * NW, OCC) void flash_attn_kernel(
             UG_SEG(1);
             // X(t) = P.V(t) then K.Q^T(t+1): A in even segment 2t+2 | B in odd segment 2t+3 (publish). (Measured and dropped: group B
             // reading its first V^T fragments ahead of the barrier, inside its softmax segment: -4 %, -10 % with two k-steps.)
-            do_X(t, cur_c, t + 1 < ntiles);
-            if (!groupA) { if constexpr (DMA && AIS != 1) dma_wait(); else if constexpr (!DMA) publish(t + 2, t + 1); }
+            if constexpr (DMA && AIS == 3) {
+                // group A: the four pieces of K(t+2) / V(t+1), one behind the MFMAs of each P.V k-step of ITS matrix segment (buffer form: two scalar
+                // instructions + the DMA each); a ragged or missing tile takes the whole-tile path behind step 0 (K) / step 2 (V)
+                do_X(t, cur_c, t + 1 < ntiles, [&](int ks) __attribute__((always_inline)) { if (groupA) dma_piece(t + 2, t + 1, ks); });
+            } else {
+                do_X(t, cur_c, t + 1 < ntiles, [](int) {});
+            }
+            if (!groupA) { if constexpr (DMA && AIS != 1 && AIS != 3) dma_wait(); else if constexpr (!DMA) publish(t + 2, t + 1); }
             if constexpr (DMA && AIS == 1) { if (groupA) dma_fetch(t + 2, t + 1); }
             if constexpr (DMA && AIS == 2) { if (groupA) dma_fetch(t + 2, ntiles); }
             UG_SEG(2);
@@ -656,7 +714,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void flash_attn_kernel(
     }
 
     // ---- epilogue: O[q][d] = O^T / l ----
-    if constexpr (LSUM) l_run = lacc[0];
+    if constexpr (LSUM) l_run = lacc[0] + lacc2[0];
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     // training: log2 sum_k 2^(c s) of the row for the backward kernels (m_run is the row's reference point, shared by both lane halves)
 #ifndef UG_ATTN_STAMPS
@@ -694,8 +752,8 @@ __global__ __launch_bounds__(64 * NW, OCC) void flash_attn_kernel(
     }
 #ifdef UG_ATTN_STAMPS
     UG_ASTAMP(3);
-    if (lse_out != nullptr && lane == 0 && (wave & 3) == 0) {
-        unsigned long long* d = (unsigned long long*)lse_out + ((int64_t)blockIdx.x * 2 + (wave >> 2)) * 12;
+    if (lse_out != nullptr && lane == 0 && (wave & (NW / 2 - 1)) == 0) {
+        unsigned long long* d = (unsigned long long*)lse_out + ((int64_t)blockIdx.x * 2 + wave / (NW / 2)) * 12;
         d[8] = ug_seg[0]; d[9] = ug_seg[1]; d[10] = ug_seg[2]; d[11] = ug_seg[3];
         d[0] = ug_st[0]; d[1] = ug_st[1]; d[2] = ug_st[2]; d[3] = ug_st[3]; d[4] = ug_rt0; d[5] = __builtin_amdgcn_s_memrealtime();
         d[6] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);   // XCC_ID | HW_ID
@@ -2144,12 +2202,12 @@ static int flash_attn_fwd_impl(const void* q, int64_t q_row_stride, int64_t q_ba
     // library, profiles/r04h_attn_m16_in_app.log): its advantage is the higher clock the chip reaches for that shape after ~10 ms of back-to-back
     // launches; a 0.9 ms launch between GEMMs never gets there, and at equal clock its 64 MFMA issues per tile cost the partner wave's softmax more
     // issue slots than 32 do. Not shipped.)
-    // UG_ATTN_LSUM_128 / UG_ATTN_LSUM_64 (build-time, 0 | 1): the row sums on the matrix pipe (template parameter LSUM), per head width
+    // UG_ATTN_LSUM_128 / UG_ATTN_LSUM_64 (build-time, 0 | 1 | 2): the row sums on the matrix pipe (template parameter LSUM: 1 = one accumulation chain, 2 = two), per head width
 #ifndef UG_ATTN_LSUM_128
 #define UG_ATTN_LSUM_128 0
 #endif
 #ifndef UG_ATTN_LSUM_64
-#define UG_ATTN_LSUM_64 0
+#define UG_ATTN_LSUM_64 1      // round 6: +1.5...+2.6 % on the cfg5 shapes by itself, +3.9...+6.3 % together with BUFD (profiles/r06_attn_variants.log); head width 128: -4 % (X is its longer segment)
 #endif
 #ifndef UG_ATTN_AIS_128
 #define UG_ATTN_AIS_128 0
@@ -2157,12 +2215,34 @@ static int flash_attn_fwd_impl(const void* q, int64_t q_row_stride, int64_t q_ba
 #ifndef UG_ATTN_AIS_64
 #define UG_ATTN_AIS_64 0
 #endif
-#define UG_ATTN_LAUNCH_LS(KVV, OCCV, LS, AISV, DHV, NWV, STG, ...)                                                                                  \
-    hipLaunchKernelGGL((flash_attn_kernel<DHV, NWV, STG, __VA_ARGS__, KVV, OCCV, LS, AISV>), dim3((unsigned)nwg), dim3(64 * NWV), 2 * 2 * KVV * 2 * DHV + (STG ? 32 * NWV * 2 * DHV : 0), (hipStream_t)stream, \
+#ifndef UG_ATTN_BUFD_64
+#define UG_ATTN_BUFD_64 1      // round 6: +2.3...+4.6 %, bit-identical (profiles/r06_attn_variants.log)
+#endif
+#define UG_ATTN_LAUNCH_LS(KVV, OCCV, LS, AISV, BUFV, DHV, NWV, STG, ...)                                                                                  \
+    hipLaunchKernelGGL((flash_attn_kernel<DHV, NWV, STG, __VA_ARGS__, KVV, OCCV, LS, AISV, BUFV>), dim3((unsigned)nwg), dim3(64 * NWV), 2 * 2 * KVV * 2 * DHV + (STG ? 32 * NWV * 2 * DHV : 0), (hipStream_t)stream, \
                        (const bf16_t*)q, q_row_stride, q_batch_stride, (const bf16_t*)k, k_row_stride, k_batch_stride, (const bf16_t*)v, \
                        v_row_stride, v_batch_stride, (bf16_t*)o, o_row_stride, o_batch_stride, (int)heads, (int)Lq, (int)Lkv, nQ, c, lse_out, lse_ld)
-    if (dh == 128) UG_ATTN_LAUNCH_LS(64, 2, (UG_ATTN_LSUM_128 != 0), UG_ATTN_AIS_128, 128, 8, true, 3, true, true);
-    else UG_ATTN_LAUNCH_LS(64, 4, (UG_ATTN_LSUM_64 != 0), UG_ATTN_AIS_64, 64, 8, true, 0, true, true);
+#ifndef UG_ATTN_NW16_64
+#define UG_ATTN_NW16_64 0
+#endif
+    // the buffer-form DMAs (BUFD) need one row stride for K and V, a multiple of 16 elements, and byte offsets of a (batch, head)'s keys below 2^31
+    const bool bufd_ok = UG_ATTN_BUFD_64 != 0 && k_row_stride == v_row_stride && k_row_stride % 16 == 0 && Lkv * k_row_stride * 2 < (1ll << 31);
+    if (dh == 128) UG_ATTN_LAUNCH_LS(64, 2, UG_ATTN_LSUM_128, UG_ATTN_AIS_128, false, 128, 8, true, 3, true, true);
+#if UG_ATTN_NW16_64       // measured and not shipped (round 6): -0.8...+1.8 % - shorter segments, but every barrier now waits for the slowest of 16 waves
+    else if (bufd_ok) {
+        // ONE 16-wave workgroup per CU (512 query rows) instead of two 8-wave ones: the same four waves per SIMD, but one K / V stream for all of them
+        // (half the L2 -> LDS traffic and half the DMA instructions per query); 96 KiB of LDS (K | V double buffer 32 + the Q image 64)
+        const int nQ16 = (int)((Lq + 511) / 512);
+        const int64_t nwg16 = (int64_t)nQ16 * heads * batches;
+        static bool attr16 = false;
+        if (!attr16) { (void)hipFuncSetAttribute((const void*)flash_attn_kernel<64, 16, true, 0, true, true, 64, 4, UG_ATTN_LSUM_64, (UG_ATTN_AIS_64 == 3 ? 0 : UG_ATTN_AIS_64), true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * 64 * 2 * 64 + 32 * 16 * 2 * 64); attr16 = true; }
+        hipLaunchKernelGGL((flash_attn_kernel<64, 16, true, 0, true, true, 64, 4, UG_ATTN_LSUM_64, (UG_ATTN_AIS_64 == 3 ? 0 : UG_ATTN_AIS_64), true>), dim3((unsigned)nwg16), dim3(1024), 2 * 2 * 64 * 2 * 64 + 32 * 16 * 2 * 64, (hipStream_t)stream,
+                           (const bf16_t*)q, q_row_stride, q_batch_stride, (const bf16_t*)k, k_row_stride, k_batch_stride, (const bf16_t*)v,
+                           v_row_stride, v_batch_stride, (bf16_t*)o, o_row_stride, o_batch_stride, (int)heads, (int)Lq, (int)Lkv, nQ16, c, lse_out, lse_ld);
+    }
+#endif
+    else if (bufd_ok) UG_ATTN_LAUNCH_LS(64, 4, UG_ATTN_LSUM_64, UG_ATTN_AIS_64, true, 64, 8, true, 0, true, true);
+    else UG_ATTN_LAUNCH_LS(64, 4, UG_ATTN_LSUM_64, (UG_ATTN_AIS_64 == 3 ? 1 : UG_ATTN_AIS_64), false, 64, 8, true, 0, true, true);
 #undef UG_ATTN_LAUNCH_LS
 #undef UG_ATTN_LAUNCH_KV
 #else
