@@ -508,10 +508,12 @@ def test_lora_linear_switch(gpu):
                 assert m["rel_l2"] <= 4e-3 and m["err_hip_vs_fp32"] <= 1.05 * m["err_ref16_vs_fp32"], m
 
 
-@pytest.mark.parametrize("M,N,K,epi", [(2304, 3072, 6144, "res_gate"), (4608, 4096, 8192, "gelu"), (2000, 2900 // 4 * 4, 6208, "bias")])
+@pytest.mark.parametrize("M,N,K,epi", [(2304, 3072, 6144, "res_gate"), (4608, 4096, 8192, "gelu"), (2000, 2900 // 4 * 4, 6208, "bias"),
+                                       (512, 3072, 12288, "res_gate"), (1024, 3072, 12288, "res_gate"), (1536, 3072, 15360, "res_gate"), (1000, 3072, 12288, "bias")])
 def test_gemm_splitk_tail(gpu, M, N, K, epi):
     """Shapes whose 256x256 tiles leave a partially filled last round: the remainder tiles are split along K, partial sums go through
-    the fp32 workspace and the last arriver reduces them in fixed slice order -> correct AND bitwise repeatable."""
+    the fp32 workspace and the last arriver reduces them in fixed slice order -> correct AND bitwise repeatable. The last four are the batch-1 / 512^2
+    forms of ff.net.2 and of the single blocks' proj_out (24-72 tiles, K = 12288 / 15360; round 6): fewer tiles than CUs, every tile cut into K-slices."""
     from unigen_amd import lib as L, ops
     g = torch.Generator().manual_seed(M + N + K)
     a, w, b = _rand(g, M, K), _rand(g, N, K, scale=K ** -0.5), _rand(g, N, scale=0.1)

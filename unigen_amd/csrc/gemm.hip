@@ -977,6 +977,25 @@ int launch(const ug_gemm_desc& d, hipStream_t s) {
     const double e128 = 0.01 * UG_TUNE("UG_GEMM_E128_PCT", 60) * (double)t128 / (double)(((t128 + 511) / 512) * 512);
     const bool lora = d.lora_r > 0;
     bool big = (!lora || (d.K >= 2 * BK && EPI != UG_EPI_F32)) && d.M >= 192 && d.N >= 192 && e256 >= e128;
+    // Round 6 (small-M regime: the reference's own launch shape is batch 1, script/infer.sh:62-63): a FEW tiles with a LONG K loop - the text-stream and
+    // 512^2 forms of ff.net.2 (K = 12288) and of the single blocks' proj_out (K = 15360): 24-72 tiles of 256^2 - lost the fill comparison above to the
+    // 128^2 kernel, which then ran one round of whole K loops (512 x 3072 x 12288: 187 us = 207 TFLOP/s, profiles/r06i_shape_rates_cfg1.log) although
+    // the 256^2 kernel would cut exactly these launches into K-slices that fill the chip (its split-K tail). Priced in microseconds with the measured
+    // unit costs - a 256^2 K-tile 1.53 us, a 128^2 K-tile 0.97 us with one workgroup on the CU / 1.27 us with two, the slab round trip 20 + 4 us per slice:
+    if (!big && !lora && EPI != UG_EPI_F32 && d.M >= 192 && d.N >= 192 && d.workspace && ug_aligned(d.workspace, 16) && UG_TUNE("UG_GEMM_SPLITK_TAIL", 1) &&
+        UG_TUNE("UG_GEMM_SPLITK_SMALLM", 1)) {
+        const int G = 256, nkt = (int)(d.K / BK);
+        const int rem = (int)(t256 % G);
+        if (t256 < G && rem * 2 <= G && nkt >= UG_TUNE("UG_GEMM_SPLITK_MIN_KT", 96)) {
+            const int rem8 = (rem + 7) / 8 * 8;
+            int cand = G / rem8; if (cand > 8) cand = 8; if (cand > nkt / 4) cand = nkt / 4;
+            if (cand >= 2 && (size_t)d.workspace_bytes >= 4096 + (size_t)rem8 * cand * 65536 * sizeof(float)) {
+                const double t_split = 1.53 * nkt / cand + 20.0 + 4.0 * cand;
+                const double t_128 = (double)((t128 + 511) / 512) * nkt * (t128 <= G ? 0.97 : 1.27);
+                if (t_split < 0.9 * t_128) big = true;
+            }
+        }
+    }
     const int f = forced_tile();
     if (f == 128) big = false;
     if (f == 256 && (!lora || (d.K >= 2 * BK && EPI != UG_EPI_F32))) big = true;
