@@ -39,6 +39,10 @@ FULLSIZE_JOBS = {          # test id fragment -> child command (relative to the 
     "test_full_model_forward_parity[multi]": ["tests/fullsize_f32_parity.py", "multi", "--no-ref16"],
     "test_full_model_forward_parity[sd3]": ["tests/fullsize_f32_parity.py", "sd3"],
 }
+# A GPU box grants one GPU's share of the host: 16 cores. Two 16-thread pools on them (the child's oracle and the suite's own small oracle evaluations)
+# oversubscribe - measured: the chain took 640 s beside the suite against 370 s alone - so the cores are SPLIT while the chain runs: 11 threads for
+# the child's fp32 oracle (its matmuls scale), 5 for the suite's process (its oracle work is small cases).
+CHILD_THREADS, SUITE_THREADS = 11, 5
 _jobs = {}                 # key -> dict(event, result)
 _state = dict(proc=None, stop=False, thread=None)
 
@@ -66,7 +70,7 @@ def _chain(keys):
         t0 = time.perf_counter()
         try:
             p = subprocess.Popen([sys.executable, *[os.path.join(ROOT, FULLSIZE_JOBS[k][0]), *FULLSIZE_JOBS[k][1:]]], cwd=ROOT, stdout=subprocess.PIPE,
-                                 stderr=subprocess.PIPE, text=True)
+                                 stderr=subprocess.PIPE, text=True, env=dict(os.environ, UG_ORACLE_THREADS=str(CHILD_THREADS), OMP_NUM_THREADS=str(CHILD_THREADS)))
             _state["proc"] = p
             out, err = p.communicate(timeout=1100)
             _jobs[k]["result"] = dict(returncode=p.returncode, stdout=out, stderr=err, seconds=time.perf_counter() - t0)
@@ -95,6 +99,8 @@ def pytest_collection_finish(session):
         _jobs[k] = dict(event=threading.Event(), result=None)
     _state["thread"] = threading.Thread(target=_chain, args=(keys,), daemon=True)
     _state["thread"].start()
+    _state["threads_before"] = torch.get_num_threads()
+    torch.set_num_threads(SUITE_THREADS)
 
 
 def pytest_sessionfinish(session, exitstatus):
@@ -114,6 +120,9 @@ def fullsize_child(request):
         if key in _jobs:
             _jobs[key]["event"].wait()
             r = _jobs[key]["result"]
+            if all(j["event"].is_set() for j in _jobs.values()) and _state.get("threads_before"):
+                import torch
+                torch.set_num_threads(_state["threads_before"])          # the chain is done: the suite has the cores to itself again
             print(f"[fullsize child {key}: {r['seconds']:.0f} s beside the suite]")
             return r
         import time
