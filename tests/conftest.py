@@ -40,9 +40,9 @@ FULLSIZE_JOBS = {          # test id fragment -> child command (relative to the 
     "test_full_model_forward_parity[sd3]": ["tests/fullsize_f32_parity.py", "sd3"],
 }
 # A GPU box grants one GPU's share of the host: 16 cores. Two 16-thread pools on them (the child's oracle and the suite's own small oracle evaluations)
-# oversubscribe - measured: the chain took 640 s beside the suite against 370 s alone - so the cores are SPLIT while the chain runs: 11 threads for
-# the child's fp32 oracle (its matmuls scale), 5 for the suite's process (its oracle work is small cases).
-CHILD_THREADS, SUITE_THREADS = 11, 5
+# oversubscribe - measured: the chain took 640 s beside the suite against 370 s alone, the suite 642 s; with the split 477 s (profiles/r06k_gputest_durations.log) - so the cores are SPLIT while the chain runs: 13 threads for
+# the child's fp32 oracle (its matmuls scale), 3 for the suite's process (its oracle work is small cases).
+CHILD_THREADS, SUITE_THREADS = 13, 3
 _jobs = {}                 # key -> dict(event, result)
 _state = dict(proc=None, stop=False, thread=None)
 

@@ -18,7 +18,7 @@ from oracle import unigen_ref as R
 from unigen_amd.flux import UniGenFlux
 from unigen_amd.sd3 import UniGenSD3
 
-torch.set_num_threads(int(os.environ.get("UG_ORACLE_THREADS", min(16, os.cpu_count() or 16))))     # tests/conftest.py gives the children 11 of the box's 16 cores while the suite runs beside them
+torch.set_num_threads(int(os.environ.get("UG_ORACLE_THREADS", min(16, os.cpu_count() or 16))))     # tests/conftest.py gives the children 13 of the box's 16 cores while the suite runs beside them
 dev, BF = torch.device("cuda:0"), torch.bfloat16
 def _opt(name, default):
     return int(sys.argv[sys.argv.index(name) + 1]) if name in sys.argv else default

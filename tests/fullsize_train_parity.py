@@ -14,7 +14,7 @@ from unigen_amd.flux import UniGenFlux
 from unigen_amd.sd3 import UniGenSD3
 
 ap = argparse.ArgumentParser(); ap.add_argument("--layers", type=int, nargs=2, default=None); ap.add_argument("--sd3", action="store_true"); a = ap.parse_args()
-torch.set_num_threads(int(os.environ.get("UG_ORACLE_THREADS", min(16, os.cpu_count() or 16))))     # tests/conftest.py gives the children 11 of the box's 16 cores while the suite runs beside them
+torch.set_num_threads(int(os.environ.get("UG_ORACLE_THREADS", min(16, os.cpu_count() or 16))))     # tests/conftest.py gives the children 13 of the box's 16 cores while the suite runs beside them
 dev, BF = torch.device("cuda:0"), torch.bfloat16
 if a.sd3:
     Model, oracle_forward, over = UniGenSD3, R.unigen_sd3_forward, {}
