@@ -21,7 +21,13 @@ else:
     lib_b = C.CDLL(path_b)
     for name, (res, args) in L.SIGNATURES.items():
         fn = getattr(lib_b, name); fn.restype = res; fn.argtypes = args
-    LIBS = [("base", lib_b), ("new", lib_a)]
+    LIBS = [(os.environ.get("UG_LIB_B_LABEL", "base"), lib_b), ("new", lib_a)]
+    for kv in [x for x in os.environ.get("UG_LIBS", "").split(";") if x]:        # more builds: UG_LIBS="label=path;label=path" (tools/build_variant.py)
+        lbl, pth = kv.split("=", 1)
+        lx = C.CDLL(os.path.abspath(pth))
+        for name, (res, args) in L.SIGNATURES.items():
+            fn = getattr(lx, name); fn.restype = res; fn.argtypes = args
+        LIBS.append((lbl, lx))
 from unigen_amd import ops
 from unigen_amd.ops import QkRope, RowMap
 dev, BF = torch.device("cuda:0"), torch.bfloat16
@@ -45,6 +51,27 @@ if os.environ.get("UG_AB_SHAPES") == "sd3":      # cfg5's projections (UniGenSD3
         ("sd3 ff up gelu", B * NI, 4 * D, D, L.EPI_BIAS_GELU),
         ("sd3 ff down K=6144 res_gate", B * NI, D, 4 * D, L.EPI_RES_GATE),
         ("sd3 joint rows 8 x 4429 out res_gate", B * (NI + 333), D, D, L.EPI_RES_SCALE),
+    ]
+if os.environ.get("UG_AB_SHAPES") == "smallm":   # round 6: the launches whose tiles are cut into K-slices - batch-1 / 512^2 forms (fewer tiles than CUs) and cfg2's proj_out (remainder round)
+    B = 1
+    SHAPES = [
+        ("text ff down 512 x 3072 x 12288 res_gate", 512, D, 4 * D, L.EPI_RES_GATE),
+        ("512^2 ff down 1024 x 3072 x 12288 res_gate", 1024, D, 4 * D, L.EPI_RES_GATE),
+        ("512^2 single out 1536 x 3072 x 15360 res_gate", 1536, D, 5 * D, L.EPI_RES_GATE),
+        ("cfg2 single out 18432 x 3072 x 15360 res_gate", 18432, D, 5 * D, L.EPI_RES_GATE),
+        ("cfg2 text ff down 2048 x 3072 x 12288 res_gate", 2048, D, 4 * D, L.EPI_RES_GATE),
+    ]
+if os.environ.get("UG_AB_SHAPES") == "k3072":    # round 6: K = 3072 launches with a partially filled last round (or fewer tiles than CUs): does the cheaper slab round trip make their split pay?
+    B = 1
+    SHAPES = [
+        ("cfg2 zero-res 18432 x 3072 x 3072 res_scale", 18432, D, D, L.EPI_RES_SCALE),
+        ("b1 qkv image 4096 x 9216 x 3072 bias", 4096, 3 * D, D, L.EPI_BIAS),
+        ("b1 ff up 4096 x 12288 x 3072 gelu", 4096, 4 * D, D, L.EPI_BIAS_GELU),
+        ("b1 attn out 4096 x 3072 x 3072 res_gate", 4096, D, D, L.EPI_RES_GATE),
+        ("text qkv 512 x 9216 x 3072 bias", 512, 3 * D, D, L.EPI_BIAS),
+        ("text ff up 512 x 12288 x 3072 gelu", 512, 4 * D, D, L.EPI_BIAS_GELU),
+        ("512^2 attn out 1024 x 3072 x 3072 res_gate", 1024, D, D, L.EPI_RES_GATE),
+        ("cfg2 text ff up 2048 x 12288 x 3072 gelu", 2048, 4 * D, D, L.EPI_BIAS_GELU),
     ]
 if len(sys.argv) > 1:
     SHAPES = [s for s in SHAPES if any(a in s[0] for a in sys.argv[1:])]

@@ -17,6 +17,12 @@
 #include <stdlib.h>
 #include <type_traits>
 
+#ifndef UG_GEMM_SLAB_SC
+#define UG_GEMM_SLAB_SC 1
+#endif
+#ifndef UG_GEMM_SPLITK_MIN_KT_DEFAULT
+#define UG_GEMM_SPLITK_MIN_KT_DEFAULT 96
+#endif
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 64;
@@ -634,6 +640,21 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
         if (rem >= 0) {
             // ---- split-K tail: slab out, ticket, last arriver reduces (cdna guide section 5, "in-launch split-K reduction") ----
             float* my = slabs + ((size_t)rem * nslices + slice) * 65536;
+            // UG_GEMM_SLAB_SC (round 6): the slabs travel at SYSTEM scope - `sc0 sc1` stores write through this XCD's L2, `sc0 sc1` loads never hit a
+            // stale line of the reader's - instead of plain accesses bracketed by agent-scope fences. On this chip an agent release is `buffer_wbl2 sc1`
+            // (write back EVERY dirty line of the XCD's L2: by every slice workgroup) and an acquire `buffer_inv sc1` (drop the L2's contents: under the
+            // other workgroups' operand panels); with them the slab round trip measured ~46 us + 6 us per slice (profiles/r06j_shape_rates_cfg1_after_dispatch.log).
+#if UG_GEMM_SLAB_SC
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+#pragma unroll
+                        for (int b = 0; b < 2; ++b)
+                            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(my + ((((i * 2 + j) * 4 + a) * 2 + b) * 512 + tid_e) * 4), "v"(acc[i][j][a][b]) : "memory");
+#else
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -643,12 +664,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
 #pragma unroll
                         for (int b = 0; b < 2; ++b)
                             *(f32x4*)(my + ((((i * 2 + j) * 4 + a) * 2 + b) * 512 + tid_e) * 4) = acc[i][j][a][b];
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // every storing wave
+#endif
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // every storing wave: its slab part has reached memory
             __syncthreads();
             unsigned* flag = (unsigned*)(smem + LDS256_BYTES);
             if (tid_e == 0) {
+#if !UG_GEMM_SLAB_SC
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // keep: hipcc may drop the fence's own wait
+#endif
                 *flag = __hip_atomic_fetch_add(tickets + rem, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             __syncthreads();
@@ -656,8 +680,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
             __syncthreads();                                              // flag is re-used by a later item
             if (!last) continue;
             if (tid_e == 0) {
+#if !UG_GEMM_SLAB_SC
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
                 __hip_atomic_store(tickets + rem, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // all arrivals are in: ready for the next launch
             }
             __syncthreads();
@@ -671,6 +697,25 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
                         for (int b = 0; b < 2; ++b) acc[i][j][a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
             for (int sl = 0; sl < nslices; ++sl) {
                 const float* sp = slabs + ((size_t)rem * nslices + sl) * 65536;
+#if UG_GEMM_SLAB_SC
+                // system-scope loads, 8 in flight per lane (the accumulators leave no room for a whole slab's 32), same slice and element order as before
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        f32x4 t[4][2];
+#pragma unroll
+                        for (int a = 0; a < 4; ++a)
+#pragma unroll
+                            for (int b = 0; b < 2; ++b)
+                                asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(t[a][b]) : "v"(sp + ((((i * 2 + j) * 4 + a) * 2 + b) * 512 + tid_e) * 4) : "memory");
+                        asm volatile("s_waitcnt vmcnt(0)" : "+v"(t[0][0]), "+v"(t[0][1]), "+v"(t[1][0]), "+v"(t[1][1]), "+v"(t[2][0]), "+v"(t[2][1]), "+v"(t[3][0]), "+v"(t[3][1])::"memory");
+#pragma unroll
+                        for (int a = 0; a < 4; ++a)
+#pragma unroll
+                            for (int b = 0; b < 2; ++b) acc[i][j][a][b] += t[a][b];
+                    }
+#else
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -680,6 +725,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const ug_gemm_desc p, c
 #pragma unroll
                             for (int b = 0; b < 2; ++b)
                                 acc[i][j][a][b] += *(const f32x4*)(sp + ((((i * 2 + j) * 4 + a) * 2 + b) * 512 + tid_e) * 4);
+#endif
             }
         }
         if constexpr (EPI == UG_EPI_QKV_ROPE) {
@@ -981,16 +1027,16 @@ int launch(const ug_gemm_desc& d, hipStream_t s) {
     // 512^2 forms of ff.net.2 (K = 12288) and of the single blocks' proj_out (K = 15360): 24-72 tiles of 256^2 - lost the fill comparison above to the
     // 128^2 kernel, which then ran one round of whole K loops (512 x 3072 x 12288: 187 us = 207 TFLOP/s, profiles/r06i_shape_rates_cfg1.log) although
     // the 256^2 kernel would cut exactly these launches into K-slices that fill the chip (its split-K tail). Priced in microseconds with the measured
-    // unit costs - a 256^2 K-tile 1.53 us, a 128^2 K-tile 0.97 us with one workgroup on the CU / 1.27 us with two, the slab round trip 20 + 4 us per slice:
+    // unit costs - a 256^2 K-tile 1.53 us, a 128^2 K-tile 0.97 us with one workgroup on the CU / 1.27 us with two, the slab round trip 22 + 2.5 us per slice (46 + 6 before the slabs went to system scope, below):
     if (!big && !lora && EPI != UG_EPI_F32 && d.M >= 192 && d.N >= 192 && d.workspace && ug_aligned(d.workspace, 16) && UG_TUNE("UG_GEMM_SPLITK_TAIL", 1) &&
         UG_TUNE("UG_GEMM_SPLITK_SMALLM", 1)) {
         const int G = 256, nkt = (int)(d.K / BK);
         const int rem = (int)(t256 % G);
-        if (t256 < G && rem * 2 <= G && nkt >= UG_TUNE("UG_GEMM_SPLITK_MIN_KT", 96)) {
+        if (t256 < G && rem * 2 <= G && nkt >= UG_TUNE("UG_GEMM_SPLITK_MIN_KT", UG_GEMM_SPLITK_MIN_KT_DEFAULT)) {
             const int rem8 = (rem + 7) / 8 * 8;
             int cand = G / rem8; if (cand > 8) cand = 8; if (cand > nkt / 4) cand = nkt / 4;
             if (cand >= 2 && (size_t)d.workspace_bytes >= 4096 + (size_t)rem8 * cand * 65536 * sizeof(float)) {
-                const double t_split = 1.53 * nkt / cand + 20.0 + 4.0 * cand;
+                const double t_split = 1.53 * nkt / cand + (UG_GEMM_SLAB_SC ? 22.0 + 2.5 * cand : 46.0 + 6.0 * cand);     // slab round trip as measured with / without the system-scope slabs
                 const double t_128 = (double)((t128 + 511) / 512) * nkt * (t128 <= G ? 0.97 : 1.27);
                 if (t_split < 0.9 * t_128) big = true;
             }
@@ -1048,7 +1094,7 @@ int launch(const ug_gemm_desc& d, hipStream_t s) {
         const int split_on = UG_TUNE("UG_GEMM_SPLITK_TAIL", 1);
         // Measured (MI355X): the slab round trip + fences cost ~35 us, so the split only pays when a tile's K loop is long
         // (K = 15360 single-block proj_out: +3.5 %; K = 3072 shapes: -2...-3 %) -> require >= 96 K-tiles.
-        if (split_on && !lora && rem > 0 && rem * 2 <= G && d.workspace && nkt >= UG_TUNE("UG_GEMM_SPLITK_MIN_KT", 96)) {
+        if (split_on && !lora && rem > 0 && rem * 2 <= G && d.workspace && nkt >= UG_TUNE("UG_GEMM_SPLITK_MIN_KT", UG_GEMM_SPLITK_MIN_KT_DEFAULT)) {
             const int rem8 = (rem + 7) / 8 * 8;
             int cand = G / rem8; if (cand > 8) cand = 8; if (cand > nkt / 4) cand = nkt / 4;
             const size_t need = 4096 + (size_t)rem8 * cand * 65536 * sizeof(float);
