@@ -631,7 +631,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void flash_attn_kernel(
             if (vt < ntiles) dma_tile(Vb, v_rs, dvo, vt, l0 + (vt & 1) * 2 * TILE + TILE, std::false_type{});
         };
         static_assert(AIS == 0 || DMA, "AIS re-assigns the LDS-DMA issue");
-        static_assert(AIS != 3 || (BUFD && NKS == 4 && NIW == 2), "AIS 3 spreads the four buffer-form pieces over the four P.V k-steps");
+        static_assert((AIS != 3 && AIS != 4) || (BUFD && NKS == 4 && NIW == 2), "AIS 3 / 4 spread the buffer-form pieces over the P.V k-steps");
         auto dma_piece = [&](int kt, int vt, int j) __attribute__((always_inline)) {
             if constexpr (BUFD) {
                 const unsigned l0 = __builtin_amdgcn_readfirstlane(lds_addr(smem)) + wb * NIW * 1024;
@@ -672,7 +672,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void flash_attn_kernel(
         // one tile = Y(t) | X(t); buffer parity is a compile-time constant (two tiles per trip)
         auto tile = [&](int t, auto cur_c) __attribute__((always_inline)) {
             // Y(t): A in odd segment 2t+1 (publishes K(t+1), V(t) at its end) | B in even segment 2t+2 (fetches K(t+2), V(t+1) at its start)
-            if (!groupA) { if constexpr (DMA && AIS == 0) dma_fetch(t + 2, t + 1); else if constexpr (DMA && AIS == 2) dma_fetch(ntiles, t + 1); else if constexpr (!DMA) fetch(t + 2, t + 1); }
+            if (!groupA) { if constexpr (DMA && AIS == 0) dma_fetch(t + 2, t + 1); else if constexpr (DMA && (AIS == 2 || AIS == 4)) dma_fetch(ntiles, t + 1); else if constexpr (!DMA) fetch(t + 2, t + 1); }
             if constexpr (PRIO == 3) __builtin_amdgcn_s_setprio(1);                  // the softmax segment outranks the partner's matrix stream at issue
             do_SM();
             // P^T is "used" here: hipcc otherwise sinks the (pure) scale / exp2 / pack chain across the barrier to its first use, the
@@ -690,7 +690,10 @@ __global__ __launch_bounds__(64 * NW, OCC) void flash_attn_kernel(
             UG_SEG(1);
             // X(t) = P.V(t) then K.Q^T(t+1): A in even segment 2t+2 | B in odd segment 2t+3 (publish). (Measured and dropped: group B
             // reading its first V^T fragments ahead of the barrier, inside its softmax segment: -4 %, -10 % with two k-steps.)
-            if constexpr (DMA && AIS == 3) {
+            if constexpr (DMA && AIS == 4) {
+                // split: group A issues the two K(t+2) pieces behind the first two P.V k-steps of its matrix segment, group B the V(t+1) tile at the start of its softmax segment
+                do_X(t, cur_c, t + 1 < ntiles, [&](int ks) __attribute__((always_inline)) { if (groupA && ks < 2) dma_piece(t + 2, ntiles, ks); });
+            } else if constexpr (DMA && AIS == 3) {
                 // group A: the four pieces of K(t+2) / V(t+1), one behind the MFMAs of each P.V k-step of ITS matrix segment (buffer form: two scalar
                 // instructions + the DMA each); a ragged or missing tile takes the whole-tile path behind step 0 (K) / step 2 (V)
                 do_X(t, cur_c, t + 1 < ntiles, [&](int ks) __attribute__((always_inline)) { if (groupA) dma_piece(t + 2, t + 1, ks); });
@@ -2242,7 +2245,7 @@ static int flash_attn_fwd_impl(const void* q, int64_t q_row_stride, int64_t q_ba
     }
 #endif
     else if (bufd_ok) UG_ATTN_LAUNCH_LS(64, 4, UG_ATTN_LSUM_64, UG_ATTN_AIS_64, true, 64, 8, true, 0, true, true);
-    else UG_ATTN_LAUNCH_LS(64, 4, UG_ATTN_LSUM_64, (UG_ATTN_AIS_64 == 3 ? 1 : UG_ATTN_AIS_64), false, 64, 8, true, 0, true, true);
+    else UG_ATTN_LAUNCH_LS(64, 4, UG_ATTN_LSUM_64, (UG_ATTN_AIS_64 == 3 ? 1 : UG_ATTN_AIS_64 == 4 ? 2 : UG_ATTN_AIS_64), false, 64, 8, true, 0, true, true);
 #undef UG_ATTN_LAUNCH_LS
 #undef UG_ATTN_LAUNCH_KV
 #else
