@@ -22,6 +22,29 @@ for (M, N, K, epi) in [(16384, 9216, 3072, L.EPI_BIAS), (18432, 3072, 15360, L.E
         if ref is None: ref = out
         elif not torch.equal(ref, out): bad += 1; print("GEMM mismatch", M, N, K, epi, it, (ref.float() - out.float()).abs().max().item())
     print("gemm", M, N, K, epi, "ok" if bad == 0 else "MISMATCH", flush=True)
+# Round 6: the split-K slabs travel at system scope without fences (UG_GEMM_SLAB_SC). A slice's partial sums read too early - or a stale line of the slab area from
+# an earlier launch - would show as a run-to-run difference: 200 repeats of the sliced small-M launches, with ANOTHER sliced launch on other data in between (it
+# rewrites the same slab area and tickets), every output compared bit for bit with the first one.
+shapes = [(512, 3072, 12288), (1024, 3072, 12288), (1536, 3072, 15360)]
+data = []
+for (M, N, K) in shapes:
+    a = (torch.rand(M, K, generator=g, device=dev) * 2 - 1).to(torch.bfloat16)
+    w = ((torch.rand(N, K, generator=g, device=dev) * 2 - 1) * K ** -0.5).to(torch.bfloat16)
+    b = (torch.rand(N, generator=g, device=dev) * 0.1).to(torch.bfloat16)
+    data.append((M, N, K, a, w, b))
+refs = [None] * len(data)
+for it in range(200):
+    for i, (M, N, K, a, w, b) in enumerate(data):
+        out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+        ops.gemm(a, w, b, out, M=M)
+        if refs[i] is None:
+            refs[i] = out
+            exact = (a.float() @ w.float().t() + b.float())
+            e = float((out.float() - exact).norm() / exact.norm())
+            assert e < 4e-3, (M, N, K, e)
+        elif not torch.equal(refs[i], out):
+            bad += 1; print("split-K mismatch", M, N, K, it, (refs[i].float() - out.float()).abs().max().item())
+print("gemm split-K small-M x 200 interleaved", "ok" if bad == 0 else "MISMATCH", flush=True)
 H, dh = 24, 128; D = H * dh
 for (B, Lq, Lkv) in [(4, 4608, 4608), (4, 4096, 4608)]:
     qkv = torch.randn(B, Lkv, 3 * D, generator=g, device=dev).to(torch.bfloat16)
