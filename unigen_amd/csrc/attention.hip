@@ -563,21 +563,32 @@ __global__ __launch_bounds__(64 * NW, OCC) void flash_attn_kernel(
             dko[u] = (unsigned)(row * (int)k_rs + ch * 8) * 2u;        // bytes
             dvo[u] = (unsigned)(row * (int)v_rs + ch * 8) * 2u;
         }
-        static_assert(!BUFD || (OCC == 4 && DH == 64 && (NIW == 2 || NIW == 1) && DMA), "BUFD is the head-width-64 four-waves-per-SIMD form");
+        constexpr bool BUFD64 = BUFD && OCC == 4 && DH == 64;      // the one-live-VGPR form; any other BUFD kernel keeps its per-run lane offsets (dko / dvo) and only moves
+                                                                 // the tile part of the address from a 64-bit VALU pointer + v_readfirstlane pair into the scalar offset
+        static_assert(!BUFD || DMA, "BUFD is a form of the LDS-DMA staging");
+        static_assert(!BUFD64 || NIW == 2 || NIW == 1, "the head-width-64 form derives run 1 from run 0");
         unsigned bvo = 0;                              // BUFD: lane offset of run 0 inside a wave's pair of 1 KiB runs (rows lane / 8, swizzled chunk)
         u32x4 rsK = {0u, 0u, 0u, 0u}, rsV = {0u, 0u, 0u, 0u};
         if constexpr (BUFD) {
-            const int sw = (((lane >> 4) & 1) << 2) | ((lane >> 4) & 2);
-            bvo = (unsigned)((lane >> 3) * (int)k_rs) * 2u + (unsigned)(((lane & 7) ^ sw) << 4);
-            if constexpr (NIW == 1) bvo ^= (unsigned)(wb & 1) << 4;           // one run per wave: the run's parity (row bit 3) is the swizzle's chunk bit 0
-            asm volatile("" : "+v"(bvo));
+            if constexpr (BUFD64) {
+                const int sw = (((lane >> 4) & 1) << 2) | ((lane >> 4) & 2);
+                bvo = (unsigned)((lane >> 3) * (int)k_rs) * 2u + (unsigned)(((lane & 7) ^ sw) << 4);
+                if constexpr (NIW == 1) bvo ^= (unsigned)(wb & 1) << 4;           // one run per wave: the run's parity (row bit 3) is the swizzle's chunk bit 0
+                asm volatile("" : "+v"(bvo));
+            }
             const unsigned long long ka = (unsigned long long)uniform_ptr(Kb), va = (unsigned long long)uniform_ptr(Vb);
             rsK = (u32x4){(unsigned)ka, (unsigned)(ka >> 32), 0xffffffffu, 0x00020000u};
             rsV = (u32x4){(unsigned)va, (unsigned)(va >> 32), 0xffffffffu, 0x00020000u};
         }
         auto dma_tile = [&](const bf16_t* base, int64_t rs, const unsigned (&off)[NIW], int tile, unsigned dst, auto is_k) {
             if (tile * KVB + KVB <= Lkv) {             // whole tile: wave-uniform base (SGPR pair) + per-lane 32-bit byte offset
-                if constexpr (BUFD) {
+                if constexpr (BUFD && !BUFD64) {
+                    const unsigned so = (unsigned)(tile * KVB * (int)rs) * 2u;                             // scalar: the tile part; the run rows are in the lane offsets
+#pragma unroll
+                    for (int u = 0; u < NIW; ++u) {
+                        if constexpr (decltype(is_k)::value) bufds16(rsK, off[u], so, dst + u * 1024); else bufds16(rsV, off[u], so, dst + u * 1024);
+                    }
+                } else if constexpr (BUFD) {
                     const unsigned so = (unsigned)((tile * KVB + wb * NIW * RPI) * (int)rs) * 2u;          // scalar: tile and run-pair part of the byte offset
                     if constexpr (decltype(is_k)::value) {
                         bufds16(rsK, bvo, so, dst);
@@ -631,9 +642,9 @@ __global__ __launch_bounds__(64 * NW, OCC) void flash_attn_kernel(
             if (vt < ntiles) dma_tile(Vb, v_rs, dvo, vt, l0 + (vt & 1) * 2 * TILE + TILE, std::false_type{});
         };
         static_assert(AIS == 0 || DMA, "AIS re-assigns the LDS-DMA issue");
-        static_assert((AIS != 3 && AIS != 4) || (BUFD && NKS == 4 && NIW == 2), "AIS 3 / 4 spread the buffer-form pieces over the P.V k-steps");
+        static_assert((AIS != 3 && AIS != 4) || (BUFD64 && NKS == 4 && NIW == 2), "AIS 3 / 4 spread the buffer-form pieces over the P.V k-steps");
         auto dma_piece = [&](int kt, int vt, int j) __attribute__((always_inline)) {
-            if constexpr (BUFD) {
+            if constexpr (BUFD64) {
                 const unsigned l0 = __builtin_amdgcn_readfirstlane(lds_addr(smem)) + wb * NIW * 1024;
                 const int tile = j < 2 ? kt : vt;
                 if (tile >= ntiles) return;
@@ -2230,7 +2241,12 @@ static int flash_attn_fwd_impl(const void* q, int64_t q_row_stride, int64_t q_ba
 #endif
     // the buffer-form DMAs (BUFD) need one row stride for K and V, a multiple of 16 elements, and byte offsets of a (batch, head)'s keys below 2^31
     const bool bufd_ok = UG_ATTN_BUFD_64 != 0 && k_row_stride == v_row_stride && k_row_stride % 16 == 0 && Lkv * k_row_stride * 2 < (1ll << 31);
-    if (dh == 128) UG_ATTN_LAUNCH_LS(64, 2, UG_ATTN_LSUM_128, UG_ATTN_AIS_128, false, 128, 8, true, 3, true, true);
+#ifndef UG_ATTN_BUFD_128
+#define UG_ATTN_BUFD_128 0
+#endif
+    const bool bufd128_ok = UG_ATTN_BUFD_128 != 0 && Lkv * k_row_stride * 2 < (1ll << 31) && Lkv * v_row_stride * 2 < (1ll << 31);
+    if (dh == 128 && bufd128_ok) UG_ATTN_LAUNCH_LS(64, 2, UG_ATTN_LSUM_128, UG_ATTN_AIS_128, true, 128, 8, true, 3, true, true);
+    else if (dh == 128) UG_ATTN_LAUNCH_LS(64, 2, UG_ATTN_LSUM_128, UG_ATTN_AIS_128, false, 128, 8, true, 3, true, true);
 #if UG_ATTN_NW16_64       // measured and not shipped (round 6): -0.8...+1.8 % - shorter segments, but every barrier now waits for the slowest of 16 waves
     else if (bufd_ok) {
         // ONE 16-wave workgroup per CU (512 query rows) instead of two 8-wave ones: the same four waves per SIMD, but one K / V stream for all of them
