@@ -2229,6 +2229,9 @@ static int flash_attn_fwd_impl(const void* q, int64_t q_row_stride, int64_t q_ba
 #ifndef UG_ATTN_AIS_64
 #define UG_ATTN_AIS_64 0
 #endif
+#ifndef UG_ATTN_PRIO_64
+#define UG_ATTN_PRIO_64 0      // 1: s_setprio around the matrix stream, 3: around the softmax segment (the head-width-128 default)
+#endif
 #ifndef UG_ATTN_BUFD_64
 #define UG_ATTN_BUFD_64 1      // round 6: +2.3...+4.6 %, bit-identical (profiles/r06_attn_variants.log)
 #endif
@@ -2260,7 +2263,7 @@ static int flash_attn_fwd_impl(const void* q, int64_t q_row_stride, int64_t q_ba
                            v_row_stride, v_batch_stride, (bf16_t*)o, o_row_stride, o_batch_stride, (int)heads, (int)Lq, (int)Lkv, nQ16, c, lse_out, lse_ld);
     }
 #endif
-    else if (bufd_ok) UG_ATTN_LAUNCH_LS(64, 4, UG_ATTN_LSUM_64, UG_ATTN_AIS_64, true, 64, 8, true, 0, true, true);
+    else if (bufd_ok) UG_ATTN_LAUNCH_LS(64, 4, UG_ATTN_LSUM_64, UG_ATTN_AIS_64, true, 64, 8, true, UG_ATTN_PRIO_64, true, true);
     else UG_ATTN_LAUNCH_LS(64, 4, UG_ATTN_LSUM_64, (UG_ATTN_AIS_64 == 3 ? 1 : UG_ATTN_AIS_64 == 4 ? 2 : UG_ATTN_AIS_64), false, 64, 8, true, 0, true, true);
 #undef UG_ATTN_LAUNCH_LS
 #undef UG_ATTN_LAUNCH_KV
