@@ -160,3 +160,55 @@ def test_lora_segment_at_full_width(gpu):
     m = report("lora_block_full_width", xs.view(B, N, D), x_16, err_hip_vs_fp32=ex, err_oraclebf16_vs_fp32=rx, err_ctx_hip=ee, err_ctx_oraclebf16=re, adapters_move_output=moved)
     assert moved > 5 * ex, m
     assert ex <= 1.25 * rx + 1e-3 and ee <= 1.25 * re + 1e-3, m
+
+
+def test_sd3_forward_with_adapters_matches_oracle(gpu):
+    """UniGenSD3 (the shared `_double_block`: dual attention `attn2`, the `context_pre_only` last block, the control blocks) with adapters on its joint
+    blocks' attention / feed-forward projections, switched by `enable_lora`, against the oracle's SD3 forward with R.lora_linear at those projections.
+    The transformer-block experts' own projections are grouped launches over experts and are refused by add_lora."""
+    from unigen_amd import lib as L
+    from tests.test_sd3_gpu import TINY as SD3_TINY
+    mod = importlib.import_module("src.lora_switching_module")
+    cls = importlib.import_module("src.UniGenTransformer").UniGenSD3
+
+    def build(dtype):
+        m = cls.from_config(dict(SD3_TINY), device=gpu, dtype=dtype)
+        m.init_condition_block(condition_nums=1, condition_types=["depth"], control_params=dict(use_shared_expert=True, use_modulate=False))      # the shipped yaml's transformer-block experts
+        return m
+
+    def attach(m):
+        targets = ["attn.to_q", "attn.to_k", "attn.to_v", "attn.to_out.0", "attn.add_q_proj", "attn.add_k_proj", "attn.add_v_proj", "attn.to_add_out",
+                   "attn2.to_q", "attn2.to_k", "attn2.to_v", "attn2.to_out.0", "ff.net.0.proj", "ff.net.2"]
+        m.add_lora(targets, "depth", 8, 16.0, prefix="transformer_blocks.", init_lora_weights=False, seed=31)
+        hits = m.add_lora(ATTN, "canny", 4, 8.0, prefix="control_", init_lora_weights=False, seed=32)
+        assert hits and all(h.startswith("control_") for h in hits)
+
+    model = build(BF)
+    model.init_synthetic_(seed=5, std=0.05, bias_std=0.02)
+    attach(model)
+    with pytest.raises(L.UniGenHipError, match="not a projection"):
+        model.add_lora(["attn.to_q"], "x", 4, 4.0, prefix="moe.")
+    state = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    m32 = build(torch.float32)
+    attach(m32)
+    res = m32.load_state_dict({k: v.float() for k, v in model.state_dict().items()}, strict=False)
+    assert not res.missing_keys and not res.unexpected_keys, res
+    rcfg = R.SD3Config(use_modulate=False, **SD3_TINY)
+    inp = R.make_sd3_inputs(rcfg, B=2, hw=16, T=24)
+    t = torch.full((2,), 600.0)
+    dinp = {k: v.to(gpu) for k, v in inp.items()}
+    with mod.enable_lora(list(model.modules()), ["depth"]), mod.enable_lora(list(m32.modules()), ["depth"]):
+        ad = _oracle_adapters(model, state)
+        assert ad and all(k.startswith("transformer_blocks.") for k in ad)          # the control blocks' "canny" adapters are switched off
+        out = model(timestep=t.to(gpu), **dinp)[0]
+        out32 = m32(timestep=t.to(gpu), **dinp)[0]
+        torch.cuda.synchronize()
+    st = dict(state); st[R.LORA_KEY] = ad
+    truth = R.unigen_sd3_forward(st, rcfg, timestep=t, dtype=torch.float32, **inp)[0]
+    ref16 = R.unigen_sd3_forward(st, rcfg, timestep=t, dtype=BF, **inp)[0]
+    plain = R.unigen_sd3_forward(state, rcfg, timestep=t, dtype=torch.float32, **inp)[0]
+    moved, e32 = rel_l2(truth, plain), rel_l2(out32, truth)
+    err_hip, err_ref = rel_l2(out, truth), rel_l2(ref16, truth)
+    m = report("lora_sd3_forward", out, ref16, err_f32_twins=e32, err_hip_vs_fp32=err_hip, err_oraclebf16_vs_fp32=err_ref, adapters_move_output=moved)
+    assert moved > 3e-3 and e32 <= 1e-3, m
+    assert err_hip <= 1.25 * err_ref + 1e-3, m
