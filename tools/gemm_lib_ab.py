@@ -61,6 +61,19 @@ if os.environ.get("UG_AB_SHAPES") == "smallm":   # round 6: the launches whose t
         ("cfg2 single out 18432 x 3072 x 15360 res_gate", 18432, D, 5 * D, L.EPI_RES_GATE),
         ("cfg2 text ff down 2048 x 3072 x 12288 res_gate", 2048, D, 4 * D, L.EPI_RES_GATE),
     ]
+if os.environ.get("UG_AB_SHAPES") == "w128":     # round 6: launches the dispatcher gives to the 128^2 kernel (4-wave against 8-wave workgroups, -DUG_GEMM128_W8=1|2)
+    B = 1
+    SHAPES = [
+        ("512^2 attn out 1024 x 3072 x 3072 res_gate", 1024, D, D, L.EPI_RES_GATE),
+        ("text attn out 512 x 3072 x 3072 res_gate", 512, D, D, L.EPI_RES_GATE),
+        ("text k|v 512 x 6144 x 3072 bias", 512, 2 * D, D, L.EPI_BIAS),
+        ("text qkv 512 x 9216 x 3072 bias", 512, 3 * D, D, L.EPI_BIAS),
+        ("text ff up 512 x 12288 x 3072 gelu", 512, 4 * D, D, L.EPI_BIAS_GELU),
+        ("512^2 zero-res 1536 x 3072 x 3072 res_scale", 1536, D, D, L.EPI_RES_SCALE),
+        ("cfg2 text attn out 2048 x 3072 x 3072 res_gate", 2048, D, D, L.EPI_RES_GATE),
+        ("cfg2 text qkv 2048 x 9216 x 3072 bias", 2048, 3 * D, D, L.EPI_BIAS),
+        ("lora T 16384 x 64 x 3072 bias", 16384, 64, D, L.EPI_BIAS),
+    ]
 if os.environ.get("UG_AB_SHAPES") == "k3072":    # round 6: K = 3072 launches with a partially filled last round (or fewer tiles than CUs): does the cheaper slab round trip make their split pay?
     B = 1
     SHAPES = [

@@ -20,6 +20,9 @@
 #ifndef UG_GEMM_SLAB_SC
 #define UG_GEMM_SLAB_SC 1
 #endif
+#ifndef UG_GEMM128_W8
+#define UG_GEMM128_W8 2      // round 6: 8-wave workgroups everywhere the 128^2 kernel runs: +3...+7 % on its launches, bit-identical (profiles/r06aa_gemm128_w8_ab.log)
+#endif
 #ifndef UG_GEMM_SPLITK_MIN_KT_DEFAULT
 #define UG_GEMM_SPLITK_MIN_KT_DEFAULT 96
 #endif
@@ -30,8 +33,14 @@ constexpr int TILE_BYTES = BM * BK * 2;        // 16 KiB per operand tile
 constexpr int BUF_BYTES = 2 * TILE_BYTES;      // A + W
 constexpr int LDS_BYTES = 2 * BUF_BYTES;       // double buffered: 64 KiB -> 2 workgroups / CU
 
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm128_kernel(const ug_gemm_desc p) {
+// NWV (round 6): waves per workgroup. 4 = rounds 1-5: a wave owns 64 x 64 of the tile and issues 8 LDS-DMAs per 32 MFMAs - alone on a CU (launches of at most
+// one tile per CU: the batch-1 text / 512^2 projections) that issue sequence, not its latency, paces the K loop (0.94 us per K-tile = 28 % of the CU's MFMA
+// rate; a four-stage prefetch changed nothing, profiles/r06q_gemm128_four_stage_ab.log). 8 = a wave owns 32 x 64 (16 MFMAs, 4 DMAs, 12 fragment reads per
+// K-tile): two waves per SIMD from ONE workgroup cover each other's issue stalls. Same MFMA shape, same K order per output element: bit-identical.
+template <int EPI, int NWV = 4>
+__global__ __launch_bounds__(64 * NWV, 2) void gemm128_kernel(const ug_gemm_desc p) {
+    constexpr int MI = 16 / NWV;                       // 16-row m-subtiles per wave: 4 (64 rows) or 2 (32 rows)
+    constexpr int SR = 16 / NWV;                       // 8-row staging groups per wave and operand: 4 (32 rows) or 2 (16 rows)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -44,9 +53,9 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(const ug_gemm_desc p) {
     const int64_t m0 = (int64_t)tc.tm * BM, n0 = (int64_t)tc.tn * BN;
     const int g = blockIdx.z;
 
-    f32x4 acc[4][4];
+    f32x4 acc[MI][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -65,10 +74,10 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(const ug_gemm_desc p) {
             Wb = (const bf16_t*)p.lora_B; ldw = p.ldb; Kseg = p.lora_r;
         }
         // per-lane staging sources: 4 glds for A rows, 4 for W rows per K-tile
-        const bf16_t* asrc[4]; const bf16_t* wsrc[4];
+        const bf16_t* asrc[SR]; const bf16_t* wsrc[SR];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = wave * 32 + i * 8 + (lane >> 3);
+        for (int i = 0; i < SR; ++i) {
+            const int row = wave * (8 * SR) + i * 8 + (lane >> 3);
             const int c = (lane & 7) ^ (row & 7);              // source chunk that lands at linear position lane&7
             int64_t am = m0 + row; if (am > M - 1) am = M - 1;
             int64_t wn = n0 + row; if (wn > N - 1) wn = N - 1;
@@ -82,8 +91,8 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(const ug_gemm_desc p) {
             unsigned char* Wbuf = Abuf + TILE_BYTES;
             const int64_t ko = (int64_t)kt * BK;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int off = (wave * 32 + i * 8) * 128;       // wave-uniform LDS row base; hardware adds lane*16
+            for (int i = 0; i < SR; ++i) {
+                const int off = (wave * (8 * SR) + i * 8) * 128;       // wave-uniform LDS row base; hardware adds lane*16
                 glds16(asrc[i] + ko, Abuf + off);
                 glds16(wsrc[i] + ko, Wbuf + off);
             }
@@ -99,16 +108,16 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(const ug_gemm_desc p) {
             const unsigned char* Wbuf = Abuf + TILE_BYTES;
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                bf16x8 af[4], wf[4];
+                bf16x8 af[MI], wf[4];
                 const int choff = (((s * 4 + fch) ^ fsw) << 4);
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    af[i] = *(const bf16x8*)(Abuf + (wr * 64 + i * 16 + frow) * 128 + choff);
+                for (int i = 0; i < MI; ++i)
+                    af[i] = *(const bf16x8*)(Abuf + (wr * (16 * MI) + i * 16 + frow) * 128 + choff);
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     wf[j] = *(const bf16x8*)(Wbuf + (wc * 64 + j * 16 + frow) * 128 + choff);
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < MI; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
@@ -128,8 +137,8 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(const ug_gemm_desc p) {
     }
     const TileSplit ts = tile_split<EPI>(p, n0);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int64_t m = m0 + wr * 64 + i * 16 + (lane & 15);
+    for (int i = 0; i < MI; ++i) {
+        const int64_t m = m0 + wr * (16 * MI) + i * 16 + (lane & 15);
         if (m >= M) continue;
         RowCtx rc = row_ctx<EPI>(p, g, (unsigned)m);
         rc.coff += ts.cshift;
@@ -1056,6 +1065,7 @@ int launch(const ug_gemm_desc& d, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)gemm128_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm128_kernel<EPI, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         (void)hipFuncSetAttribute((const void*)gemm256_kernel<EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256_BYTES + 16 + UG_STAMP_LDS);
         if (EPI != UG_EPI_F32)
             (void)hipFuncSetAttribute((const void*)gemm256_kernel<EPI, EPI != UG_EPI_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256_BYTES + 16 + UG_STAMP_LDS);
@@ -1116,7 +1126,11 @@ int launch(const ug_gemm_desc& d, hipStream_t s) {
     } else {
         const int nM = (int)((d.M + BM - 1) / BM), nN = (int)((d.N + BN - 1) / BN);
         dim3 grid((unsigned)(nM * nN), 1, (unsigned)groups);
-        hipLaunchKernelGGL(gemm128_kernel<EPI>, grid, dim3(256), LDS_BYTES, s, d);
+        // UG_GEMM128_W8 (build-time): 0 = the 4-wave workgroup everywhere, 1 = the 8-wave form for launches of at most one tile per CU, 2 = everywhere
+        if (UG_GEMM128_W8 == 2 || (UG_GEMM128_W8 == 1 && (int64_t)nM * nN * groups <= 256))
+            hipLaunchKernelGGL((gemm128_kernel<EPI, 8>), grid, dim3(512), LDS_BYTES, s, d);
+        else
+            hipLaunchKernelGGL(gemm128_kernel<EPI>, grid, dim3(256), LDS_BYTES, s, d);
     }
     UG_CHECK_LAUNCH("ug_gemm_bf16");
     return UG_OK;
