@@ -411,10 +411,11 @@ __global__ __launch_bounds__(64 * NW, OCC) void flash_attn_kernel(
     // matrix pipe in this segment (its SIMD partner is in the VALU-only Y), so an exposed ds_read latency is an idle pipe. hipcc's
     // own order (sched_group_barrier hints included) ran the segment at 70-90 cycles per MFMA.
     auto qx_frag = [&](int s) __attribute__((always_inline)) -> bf16x8 { if constexpr (QLDS) return *(const bf16x8*)(smem + q_lds + 16 * ((2 * s) ^ qx)); else return qf[s]; };
-    auto do_X = [&](int t, auto cur_c, bool have_qk, auto&& hook) __attribute__((always_inline)) {
+    auto do_X = [&](int t, auto cur_c, bool have_qk, auto&& hook, auto kofs_c) __attribute__((always_inline)) {
         constexpr int CUR = decltype(cur_c)::value;
+        constexpr int KOFS = decltype(kofs_c)::value;       // >= 0 (AIS 5): byte offset of the ring slot that holds K(t+1), a compile-time constant like CUR
         const unsigned char* Vbuf = smem + CUR * 2 * TILE + TILE;
-        const unsigned char* Kbuf = smem + (CUR ^ 1) * 2 * TILE;
+        const unsigned char* Kbuf = KOFS >= 0 ? smem + KOFS : smem + (CUR ^ 1) * 2 * TILE;
         bf16x8 vf[NKS][NDB];
         auto rdv = [&](int ks) __attribute__((always_inline)) {
 #pragma unroll
@@ -636,9 +637,12 @@ __global__ __launch_bounds__(64 * NW, OCC) void flash_attn_kernel(
                 }
             }
         };
+        // AIS 5: K tiles live in a ring of THREE slots - the two K halves of the double buffer and the (unused: Q stays in registers) Q image area behind it
+        auto kslot = [&](int s3) __attribute__((always_inline)) -> int { return s3 < 2 ? s3 * 2 * TILE : 4 * TILE; };
+        static_assert(AIS != 5 || (DMA && !QLDS && !BUFD64), "AIS 5 keeps its third K slot where the Q image would be");
         auto dma_fetch = [&](int kt, int vt) __attribute__((always_inline)) {         // tiles past the end are simply not fetched
             const unsigned l0 = __builtin_amdgcn_readfirstlane(lds_addr(smem)) + wb * NIW * 1024;
-            if (kt < ntiles) dma_tile(Kb, k_rs, dko, kt, l0 + (kt & 1) * 2 * TILE, std::true_type{});
+            if (kt < ntiles) dma_tile(Kb, k_rs, dko, kt, l0 + (AIS == 5 ? kslot(kt % 3) : (kt & 1) * 2 * TILE), std::true_type{});
             if (vt < ntiles) dma_tile(Vb, v_rs, dvo, vt, l0 + (vt & 1) * 2 * TILE + TILE, std::false_type{});
         };
         static_assert(AIS == 0 || DMA, "AIS re-assigns the LDS-DMA issue");
@@ -681,9 +685,13 @@ __global__ __launch_bounds__(64 * NW, OCC) void flash_attn_kernel(
         if (!groupA) { if constexpr (DMA && AIS != 1 && AIS != 3) dma_wait(); else if constexpr (!DMA) publish(1, 0); }    // end of segment 1 (B)
         seg_barrier();
         // one tile = Y(t) | X(t); buffer parity is a compile-time constant (two tiles per trip)
-        auto tile = [&](int t, auto cur_c) __attribute__((always_inline)) {
+        auto tile = [&](int t, auto cur_c, auto k3_c) __attribute__((always_inline)) {
+            constexpr int K3 = decltype(k3_c)::value;            // t % 3 (AIS 5: the K ring slot of tile t; the loop is unrolled over 6 tiles so that it is a constant)
             // Y(t): A in odd segment 2t+1 (publishes K(t+1), V(t) at its end) | B in even segment 2t+2 (fetches K(t+2), V(t+1) at its start)
-            if (!groupA) { if constexpr (DMA && AIS == 0) dma_fetch(t + 2, t + 1); else if constexpr (DMA && (AIS == 2 || AIS == 4)) dma_fetch(ntiles, t + 1); else if constexpr (!DMA) fetch(t + 2, t + 1); }
+            if (!groupA) { if constexpr (DMA && AIS == 0) dma_fetch(t + 2, t + 1); else if constexpr (DMA && (AIS == 2 || AIS == 4 || AIS == 5)) dma_fetch(ntiles, t + 1); else if constexpr (!DMA) fetch(t + 2, t + 1); }
+            // AIS 5: group A issues K(t+2) at the START of its softmax segment (2t+1) into ring slot (t+2) % 3, whose last readers (QK(t-1): segments 2t-2, 2t-1) are
+            // done - with two slots it would be the buffer group B's X(t-1) reads K(t) from right now; group B keeps V(t+1) (start of ITS softmax segment, 2t+2)
+            if constexpr (DMA && AIS == 5) { if (groupA) dma_fetch(t + 2, ntiles); }
             if constexpr (PRIO == 3) __builtin_amdgcn_s_setprio(1);                  // the softmax segment outranks the partner's matrix stream at issue
             do_SM();
             // P^T is "used" here: hipcc otherwise sinks the (pure) scale / exp2 / pack chain across the barrier to its first use, the
@@ -695,21 +703,27 @@ __global__ __launch_bounds__(64 * NW, OCC) void flash_attn_kernel(
             // group A publishes K(t+1), V(t) and at once re-fills the staging registers with K(t+2), V(t+1): its VALU segment has slack
             // (the partner's matrix segment is longer), whereas a fetch at the head of its own X(t) delayed the first MFMA
             if constexpr (!DMA) { if (groupA) { publish(t + 1, t); fetch(t + 2, t + 1); } }
-            if constexpr (DMA && AIS != 0) { if (groupA) dma_wait(); }             // A's DMAs of the end of X(t-1): K(t+1) (and V(t), AIS 1), first read in X(t)
+            if constexpr (DMA && AIS == 5) {
+                // K(t+1) (issued one tile ago) must have landed before X(t); K(t+2), issued at the top of this segment, may stay in flight: NIW pieces
+                if (groupA) { if (t + 2 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIW) : "memory"); else dma_wait(); }
+            } else if constexpr (DMA && AIS != 0) { if (groupA) dma_wait(); }      // A's DMAs of the end of X(t-1): K(t+1) (and V(t), AIS 1), first read in X(t)
             UG_SEG(0);
             seg_barrier();
             UG_SEG(1);
             // X(t) = P.V(t) then K.Q^T(t+1): A in even segment 2t+2 | B in odd segment 2t+3 (publish). (Measured and dropped: group B
             // reading its first V^T fragments ahead of the barrier, inside its softmax segment: -4 %, -10 % with two k-steps.)
-            if constexpr (DMA && AIS == 4) {
+            if constexpr (DMA && AIS == 5) {
+                constexpr int KN = (K3 + 1) % 3;
+                do_X(t, cur_c, t + 1 < ntiles, [](int) {}, std::integral_constant<int, (KN < 2 ? KN * 2 * TILE : 4 * TILE)>{});
+            } else if constexpr (DMA && AIS == 4) {
                 // split: group A issues the two K(t+2) pieces behind the first two P.V k-steps of its matrix segment, group B the V(t+1) tile at the start of its softmax segment
-                do_X(t, cur_c, t + 1 < ntiles, [&](int ks) __attribute__((always_inline)) { if (groupA && ks < 2) dma_piece(t + 2, ntiles, ks); });
+                do_X(t, cur_c, t + 1 < ntiles, [&](int ks) __attribute__((always_inline)) { if (groupA && ks < 2) dma_piece(t + 2, ntiles, ks); }, std::integral_constant<int, -1>{});
             } else if constexpr (DMA && AIS == 3) {
                 // group A: the four pieces of K(t+2) / V(t+1), one behind the MFMAs of each P.V k-step of ITS matrix segment (buffer form: two scalar
                 // instructions + the DMA each); a ragged or missing tile takes the whole-tile path behind step 0 (K) / step 2 (V)
-                do_X(t, cur_c, t + 1 < ntiles, [&](int ks) __attribute__((always_inline)) { if (groupA) dma_piece(t + 2, t + 1, ks); });
+                do_X(t, cur_c, t + 1 < ntiles, [&](int ks) __attribute__((always_inline)) { if (groupA) dma_piece(t + 2, t + 1, ks); }, std::integral_constant<int, -1>{});
             } else {
-                do_X(t, cur_c, t + 1 < ntiles, [](int) {});
+                do_X(t, cur_c, t + 1 < ntiles, [](int) {}, std::integral_constant<int, -1>{});
             }
             if (!groupA) { if constexpr (DMA && AIS != 1 && AIS != 3) dma_wait(); else if constexpr (!DMA) publish(t + 2, t + 1); }
             if constexpr (DMA && AIS == 1) { if (groupA) dma_fetch(t + 2, t + 1); }
@@ -719,9 +733,20 @@ __global__ __launch_bounds__(64 * NW, OCC) void flash_attn_kernel(
             UG_SEG(3);
         };
         UG_SEG0();
-        for (int t = 0; t < ntiles; t += 2) {
-            tile(t, std::integral_constant<int, 0>{});
-            if (t + 1 < ntiles) tile(t + 1, std::integral_constant<int, 1>{});
+        if constexpr (AIS == 5) {
+            for (int t = 0; t < ntiles; t += 6) {                  // buffer parity AND K ring slot as compile-time constants: period 6
+                tile(t, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+                if (t + 1 < ntiles) tile(t + 1, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+                if (t + 2 < ntiles) tile(t + 2, std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
+                if (t + 3 < ntiles) tile(t + 3, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+                if (t + 4 < ntiles) tile(t + 4, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+                if (t + 5 < ntiles) tile(t + 5, std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{});
+            }
+        } else {
+            for (int t = 0; t < ntiles; t += 2) {
+                tile(t, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+                if (t + 1 < ntiles) tile(t + 1, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+            }
         }
         UG_ASTAMP(2);
         if (groupA) seg_barrier();                     // A's trailing (empty) segment pairs with B's last one
@@ -2248,6 +2273,7 @@ static int flash_attn_fwd_impl(const void* q, int64_t q_row_stride, int64_t q_ba
 #define UG_ATTN_BUFD_128 0
 #endif
     const bool bufd128_ok = UG_ATTN_BUFD_128 != 0 && Lkv * k_row_stride * 2 < (1ll << 31) && Lkv * v_row_stride * 2 < (1ll << 31);
+    // (AIS 5 at head width 128 needs the launch's Q-image area as its third K slot: it is part of the stagger kernels' LDS request either way)
     if (dh == 128 && bufd128_ok) UG_ATTN_LAUNCH_LS(64, 2, UG_ATTN_LSUM_128, UG_ATTN_AIS_128, true, 128, 8, true, 3, true, true);
     else if (dh == 128) UG_ATTN_LAUNCH_LS(64, 2, UG_ATTN_LSUM_128, UG_ATTN_AIS_128, false, 128, 8, true, 3, true, true);
 #if UG_ATTN_NW16_64       // measured and not shipped (round 6): -0.8...+1.8 % - shorter segments, but every barrier now waits for the slowest of 16 waves
