@@ -939,3 +939,19 @@ def test_same_run_traffic_reads_its_own_counter_passes(tmp_path, monkeypatch):
     monkeypatch.setenv("FAKE_PMC_FAIL", "WRITE_SIZE")
     with pytest.raises(RuntimeError, match="WRITE_SIZE"):
         bench.same_run_traffic(limit_s=30)
+
+
+def test_fullsize_children_are_scheduled_beside_the_suite():
+    """tests/conftest.py: the four full-size oracle comparisons are started as background children when collection ends and their tests run last
+    (VERDICT r5 item 4). Without a GPU nothing is started; the mapping from test ids to child commands and the reordering are checked here."""
+    import conftest as CT
+    assert CT.CHILD_THREADS + CT.SUITE_THREADS == 16
+    for key, cmd in CT.FULLSIZE_JOBS.items():
+        assert os.path.exists(os.path.join(ROOT, cmd[0])), cmd
+        assert CT._job_key("tests/test_fullsize_gpu.py::" + key) == key
+    assert CT._job_key("tests/test_fullsize_gpu.py::test_cfg3_three_conditions_b8_whole_forward_properties") is None
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests"), "-q", "-m", "gpu", "--collect-only"], capture_output=True, text=True, timeout=300, cwd=ROOT)
+    ids = [l for l in r.stdout.splitlines() if "::" in l]
+    tail = ids[-4:]
+    assert [CT._job_key(i) for i in tail] == list(CT.FULLSIZE_JOBS), tail
+    assert not any(CT._job_key(i) for i in ids[:-4])
