@@ -592,7 +592,7 @@ extern "C" int ug_conv2d_nhwc(const ug_conv_desc* dp, ug_stream_t stream) {
         }
     }
     // 256 x 128 tiles, three stages (Cout = 128 layers; convolutions with too few 256^2 tiles): whole tiles in M, at least one tile per CU pair
-    constexpr int LDS_BIG = 3 * (256 + CBN) * CBK * 2, LDS_SMALL = 2 * (128 + CBN) * CBK * 2;
+    [[maybe_unused]] constexpr int LDS_BIG = 3 * (256 + CBN) * CBK * 2, LDS_SMALL = 2 * (128 + CBN) * CBK * 2;
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)conv2d_nhwc_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_SMALL);
