@@ -5,7 +5,7 @@ N = 1024, T = 512, B = 1), one forward:
   hip_bf16 = the HIP product path;  ref_bf16 = the CPU oracle in bf16
 Too slow for the test suite (the fp32 oracle forward takes minutes on 16 cores); run it as a tool and keep the line under profiles/.
 
-  python tests/fullsize_f32_parity.py [flux|multi|sd3] [GRID] [--batch B] [--hw H] [--no-ref16] [--no-truth32] [--write-bounds --commit SHA]
+  python tests/fullsize_f32_parity.py [flux|multi|sd3] [GRID] [--batch B] [--hw H] [--no-ref16] [--no-truth32] [--lora] [--write-bounds --commit SHA]
 --batch B      the BASELINE configs' own batch (cfg2: flux 64 --batch 4; cfg3: multi 64 --batch 8; cfg5: sd3 --hw 128 --batch 8). The MoE's capacity and
                its random token selection run over all B x N tokens at once, so this is not B independent B = 1 cases.
 --no-truth32   leave the fp32 oracle out (at B = 8 it does not fit a 20-minute GPU-box call); the record then holds the three distances among
@@ -54,12 +54,21 @@ m16 = Model.from_config({}, device=dev, dtype=BF)
 NC, CT = (3, ["depth", "canny", "openpose"]) if MULTI else (1, ["canny"])
 m16.init_condition_block(condition_nums=NC, condition_types=list(CT), control_params=dict(CTL))
 m16.init_synthetic_(seed=0, std=0.02)
+LORA = "--lora" in sys.argv          # round 6: per-condition rank-16 LoRA adapters on the control branch's attention projections, all live (A12 on the hot path at full size)
+def attach_lora(m):
+    for i, name in enumerate(CT):
+        m.add_lora(["attn.to_q", "attn.to_k", "attn.to_v", "attn.to_out.0"], name, 16, 32.0, prefix="control_", init_lora_weights=False, seed=40 + i)
+if LORA:
+    attach_lora(m16)
 rel = lambda a, b: float((a.double().cpu() - b.double().cpu()).norm() / b.double().cpu().norm())
 res = {}
 with torch.no_grad():
     mv = lambda v, f=None: [mv(x, f) for x in v] if isinstance(v, (list, tuple)) else (v.to(dev) if f is None or not v.is_floating_point() else v.to(dev).to(f))
     out16 = m16(timestep=t.to(dev), **{k: mv(v) for k, v in inp.items()})[0].float().cpu()
     st16 = {k: v.detach().cpu() for k, v in m16.state_dict().items()}
+    lora_sites = {n: [(a, lay.scaling[a]) for a in lay.live_adapters()] for n, lay in m16._lora_sites.items()} if LORA else {}
+    if LORA:       # the oracle's linear() takes the same adapters (R.LORA_KEY -> R.lora_linear) from the model's own tensors
+        st16[R.LORA_KEY] = {n: [(st16[f"{n}.lora_A.{a}.weight"], st16[f"{n}.lora_B.{a}.weight"], sc) for a, sc in v] for n, v in lora_sites.items()}
     sd16 = dict(m16.state_dict())
     NO_REF16 = "--no-ref16" in sys.argv          # the test suite's 1024^2 case: skip the oracle's own bf16 evaluation (65 s of host time; its ratio to the HIP bf16 error is pinned at N = 1024)
     if NO_REF16:
@@ -69,6 +78,8 @@ with torch.no_grad():
     print("bf16 done", res, flush=True)
     m32 = UniGenFlux.from_config({}, device=dev, dtype=torch.float32)
     m32.init_condition_block(condition_nums=NC, condition_types=list(CT), control_params=dict(CTL))
+    if LORA:
+        attach_lora(m32)
     m32.load_state_dict({k: (v.float() if v.is_floating_point() else v) for k, v in sd16.items()})
     del m16, sd16
     torch.cuda.empty_cache()
@@ -77,7 +88,9 @@ with torch.no_grad():
     torch.cuda.synchronize(); res["hip_f32_s"] = round(time.perf_counter() - t0, 1)
     del m32
     torch.cuda.empty_cache()          # the fp32 oracle below runs for minutes on the host: the GPU memory goes back first (the suite runs beside this child)
-    st32 = {k: (v.float() if v.is_floating_point() else v) for k, v in st16.items()}
+    st32 = {k: (v.float() if v.is_floating_point() else v) for k, v in st16.items() if k != R.LORA_KEY}
+    if LORA:
+        st32[R.LORA_KEY] = {n: [(st32[f"{n}.lora_A.{a}.weight"], st32[f"{n}.lora_B.{a}.weight"], sc) for a, sc in v] for n, v in lora_sites.items()}
     del st16
     print("hip f32 done", res, flush=True)
     truth = None
@@ -87,6 +100,8 @@ if SD3:
     wl = f"UniGenSD3, SD3.5-medium depth and width, N={(HW // cfg.patch_size) ** 2}, T=333, B={BATCH}"
 else:
     wl = ("MultiCondtionUniGenFlux (3 conditions, E = 12), " if MULTI else "") + f"one forward at full depth and width, {16 * GRID}^2 (N={GRID * GRID}, T=512), B={BATCH}"
+if LORA:
+    wl += f"; rank-16 LoRA adapters ({', '.join(CT)}) live on {len(lora_sites)} control-branch attention projections"
 opt = lambda a, b: rel(a, b) if a is not None and b is not None else None
 res.update(workload=wl, rel_l2_hip_f32_vs_oracle_f32=opt(out32, truth), rel_l2_hip_bf16_vs_oracle_f32=opt(out16, truth),
            rel_l2_oracle_bf16_vs_oracle_f32=opt(ref16, truth), rel_l2_hip_bf16_vs_oracle_bf16=opt(out16, ref16),
